@@ -1,0 +1,153 @@
+/*
+ * npp_hip.h -- C ABI of libnpp_hip.so: the MI355X (gfx950) implementation of the
+ * per-image NPP-Net optimisation path.
+ *
+ * The reference (ArmastusChen/Learning-Continuous-Implicit-Representation-for-Near-
+ * Periodic-Patterns) has no FFI or operator registry for this path: it is plain
+ * Python calling PyTorch.  Each entry point below therefore replaces a Python call
+ * site of the reference (cited as file:line relative to the reference root) and is
+ * what a ctypes binding on the reference side would bind.
+ *
+ * Conventions
+ *   - every function returns 0 (NPP_OK) or a negative npp_status; nothing throws;
+ *     npp_last_error_string() describes the last failure on the calling thread;
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller; the library
+ *     allocates no caller-visible memory and keeps no state between calls;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and
+ *     re-entrant across streams; nothing here synchronises the device;
+ *   - coordinates are (row=y, col=x) int32 pairs;
+ *   - parameters live in ONE fp32 blob in the reference's own tensor layout
+ *     (torch nn.Linear: weight [out][in] row-major, then bias), tensors in the order
+ *     npp_param_layout() reports, so it maps 1:1 onto the reference's state_dict.
+ */
+#ifndef NPP_HIP_H
+#define NPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPP_MAX_K 5         /* proposals (options/arg_config.py:73 p_topk, BASELINE c5) */
+#define NPP_N_OFF 5         /* options/arg_config.py:20 freq_offsets */
+#define NPP_N_FREQ 10       /* options/arg_config.py:27 multires */
+#define NPP_E 462           /* embedding width per proposal: 22 * (1 + 2*10) */
+#define NPP_WIDTH 256       /* MLP width this build is specialised for (BASELINE c2) */
+#define NPP_MAX_TENSORS 32
+#define NPP_ROW_TILE 64     /* rows per workgroup of the fused MLP kernels */
+
+typedef enum {
+  NPP_OK = 0,
+  NPP_ERR_ARG = -1,         /* bad argument (null pointer, size, unsupported K/width) */
+  NPP_ERR_LAUNCH = -2,      /* hipLaunchKernel / runtime error, see error string */
+  NPP_ERR_UNSUPPORTED = -3,
+  NPP_ERR_SELFTEST = -4
+} npp_status;
+
+/* models/embedder.py:60-90 get_embedder(...) arguments + :26 the Fourier freqs
+ * (random in the reference; an explicit input here). */
+typedef struct {
+  int32_t K;                          /* number of periodicity proposals */
+  int32_t H, W;                       /* res = (H, W), embedder.py:112-113 */
+  float angles_deg[NPP_MAX_K][2];     /* selected_angles[k] (degrees) */
+  float periods[NPP_MAX_K][2];        /* selected_periods[k] */
+  float offsets[NPP_N_OFF];           /* freq_offsets, default 0,-1,1,.5,-.5 */
+  float freqs[NPP_N_FREQ];            /* Embedder freq_bands (embedder.py:26) */
+} npp_embed_cfg;
+
+/* ---- meta ---------------------------------------------------------------- */
+int npp_version(void);
+const char* npp_last_error_string(void);
+int npp_device_count(void);
+
+/* ---- parameters ---------------------------------------------------------- */
+/* Tensor table of the fp32 parameter blob for NPP_Net (K>1, models/networks.py:40-49)
+ * or NPP_Net_top1 (K==1, :128-140).  names[i] points at static strings with the
+ * reference's state_dict names; offsets/rows/cols are in floats.  Returns the number
+ * of tensors (>0) or a negative status.  *total = floats in the blob. */
+int npp_param_layout(int K, int width, const char** names, int64_t* offsets,
+                     int32_t* rows, int32_t* cols, int64_t* total);
+
+/* Bytes of the bf16 MFMA-fragment-ordered weight packs the fused kernels read.
+ * which = 0: forward pack, 1: backward (dgrad, transposed) pack. */
+int64_t npp_pack_bytes(int K, int width, int which);
+
+/* Re-pack the fp32 blob into both bf16 packs (run after every optimiser step). */
+int npp_pack_weights(const float* d_params, void* d_wf, void* d_wb, int K, int width,
+                     void* stream);
+/* Same mapping evaluated on the HOST (no GPU needed): used by the CPU tests to check
+ * the fragment maps against a NumPy model of the MFMA.  Buffers are host memory. */
+int npp_pack_weights_host(const float* params, void* wf, void* wb, int K, int width);
+
+/* ---- a1+a2+a4: embedder -------------------------------------------------- */
+/* Replaces Embedder_periodic.embed + Embedder.embed + cat (models/embedder.py:140-148,
+ * :51-56; NPP_completion/train.py:93-105): coords (N,2) -> (N, K*462), row-major,
+ * reference column order.  out_dtype 0 = fp32, 1 = bf16.  precise != 0 uses full-
+ * range sinf/cosf (fp32 parity path), 0 uses the hardware v_sin/v_cos. */
+int npp_embed_fwd(const int32_t* d_coords_yx, int64_t N, const npp_embed_cfg* cfg,
+                  void* d_out, int out_dtype, int precise, void* stream);
+/* The 22-vector stage alone (embedder.py:140-148): (N,2) -> (N, K*22) fp32. */
+int npp_warp_fwd(const int32_t* d_coords_yx, int64_t N, const npp_embed_cfg* cfg,
+                 float* d_out, void* stream);
+
+/* ---- a5+a6+a7: fused coordinate MLP -------------------------------------- */
+/* Workspace sizes (bytes) for a padded batch of Bp rows (multiple of NPP_ROW_TILE):
+ *  sizes[0] s-stash (snake derivative, fragment order, bf16)
+ *  sizes[1] actT   (layer inputs, feature-major bf16, incl. the embedding)
+ *  sizes[2] dzT    (pre-activation gradients, feature-major bf16)
+ *  sizes[3] grad slabs (ksplit * param floats * 4) */
+int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]);
+
+/* Replaces render() -> run_network -> NPP_Net.forward -> sigmoid
+ * (models/helpers.py:41-62, models/networks.py:56-95 / :145-173) INCLUDING the
+ * embedding lookup it is fed with (train.py:166-181): coords (Bp,2) -> pred (Bp,3).
+ * d_wf: forward pack; d_params: fp32 blob (biases + rgb_linear are read from it).
+ * d_sstash / d_actT may be NULL (inference / full-image render, train.py:277-309);
+ * when given, the kernel also writes what npp_mlp_bwd / npp_mlp_wgrad need.
+ * Bp must be a multiple of NPP_ROW_TILE (pad with any valid coordinate). */
+int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg,
+                int width, const void* d_wf, const float* d_params, float* d_pred,
+                void* d_sstash, void* d_actT, void* stream);
+
+/* Backward of the same (what loss.backward() does through networks.py:56-95):
+ * d_dpred (Bp,3) = dL/dpred (rows >= the real batch must be 0).  Writes dzT. */
+int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width,
+                const void* d_wb, const float* d_params, const void* d_sstash,
+                void* d_dzT, void* stream);
+
+/* Weight/bias gradients: ksplit partial slabs in the parameter-blob layout
+ * (slab s at d_gslabs + s * total floats); npp_adam_step sums them. */
+int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width,
+                  int ksplit, float* d_gslabs, void* stream);
+
+/* ---- a8: adaptive robust pixel loss -------------------------------------- */
+/* Replaces img2mse(pred, gt, 'robust_loss_adaptive', adaptive_pix, mask)
+ * (models/mse_calculator.py:13-27 -> robust_loss_pytorch/adaptive.py:183-204) and its
+ * backward.  pred/gt (N,3), mask (N,1) or NULL.  latents: [alpha(3) | scale(3)].
+ * spline: values[n_knots] then tangents[n_knots] fp32 (distribution.py:129-141).
+ * Outputs: d_loss[0] += mean nll (caller zeroes), d_dpred (N,3) = weight * dL/dpred,
+ * d_dlatent[6] += weight * dL/dlatents (caller zeroes). */
+int npp_pixel_loss(const float* d_pred, const float* d_gt, const float* d_mask, int64_t N,
+                   const float* d_latents, const float* d_spline, int n_knots,
+                   float x_scale, float weight, float* d_loss, float* d_dpred,
+                   float* d_dlatent, void* stream);
+
+/* ---- a14: Adam ------------------------------------------------------------ */
+/* torch.optim.Adam step (models/helpers.py:164; NPP_completion/train.py:253-254) over
+ * n floats: g = sum of n_slabs slabs (slab stride = slab_stride floats).  `step` is
+ * the 1-based step count used for bias correction. */
+int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,
+                  int n_slabs, int64_t slab_stride, float lr, float beta1, float beta2,
+                  float eps, int step, void* stream);
+
+/* ---- diagnostics ---------------------------------------------------------- */
+/* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the
+ * accumulator-as-next-operand chain) with exact integer data.  d_scratch >= 1 MiB. */
+int npp_selftest_mfma(void* d_scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPP_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libnpp_hip.so (include/npp_hip.h).  Fails loudly; never falls back."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnpp_hip.so")
+
+NPP_MAX_K, NPP_N_OFF, NPP_N_FREQ, NPP_E, NPP_WIDTH, NPP_ROW_TILE = 5, 5, 10, 462, 256, 64
+
+
+class NppError(RuntimeError):
+    pass
+
+
+class EmbedCfg(C.Structure):
+    """npp_embed_cfg (include/npp_hip.h) == get_embedder(...) arguments, models/embedder.py:60-90."""
+    _fields_ = [("K", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("angles_deg", (C.c_float * 2) * NPP_MAX_K),
+                ("periods", (C.c_float * 2) * NPP_MAX_K),
+                ("offsets", C.c_float * NPP_N_OFF),
+                ("freqs", C.c_float * NPP_N_FREQ)]
+
+    @classmethod
+    def make(cls, angles_deg, periods, freqs, res, offsets=(0.0, -1.0, 1.0, 0.5, -0.5)):
+        import numpy as np
+        a = np.asarray(angles_deg, dtype=np.float32).reshape(-1, 2)
+        p = np.asarray(periods, dtype=np.float32).reshape(-1, 2)
+        f = np.asarray(freqs, dtype=np.float32).reshape(-1)
+        if a.shape != p.shape or not (1 <= a.shape[0] <= NPP_MAX_K):
+            raise ValueError(f"need 1..{NPP_MAX_K} proposals with 2 angles and 2 periods each")
+        if f.shape[0] != NPP_N_FREQ or len(offsets) != NPP_N_OFF:
+            raise ValueError("this build is specialised for multires=10 and 5 freq_offsets")
+        c = cls()
+        c.K, c.H, c.W = a.shape[0], int(res[0]), int(res[1])
+        for k in range(a.shape[0]):
+            for o in range(2):
+                c.angles_deg[k][o] = float(a[k, o])
+                c.periods[k][o] = float(p[k, o])
+        for j in range(NPP_N_OFF):
+            c.offsets[j] = float(offsets[j])
+        for j in range(NPP_N_FREQ):
+            c.freqs[j] = float(f[j])
+        return c
+
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_cfgp = C.POINTER(EmbedCfg)
+
+# every symbol include/npp_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "npp_version": (_i32, []),
+    "npp_last_error_string": (C.c_char_p, []),
+    "npp_device_count": (_i32, []),
+    "npp_param_layout": (_i32, [_i32, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32), C.POINTER(_i64)]),
+    "npp_pack_bytes": (_i64, [_i32, _i32, _i32]),
+    "npp_pack_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "npp_pack_weights_host": (_i32, [_vp, _vp, _vp, _i32, _i32]),
+    "npp_embed_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _i32, _i32, _vp]),
+    "npp_warp_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _vp]),
+    "npp_train_workspace": (_i32, [_i32, _i32, _i64, _i32, C.POINTER(_i64)]),
+    "npp_mlp_fwd": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "npp_mlp_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_selftest_mfma": (_i32, [_vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libnpp_hip.so once and type every entry point.  Raises if the library or any
+    declared symbol is missing -- the product has no other implementation to fall back to."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NppError(f"{LIB_PATH} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+                       "there is no CPU fallback")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NppError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise NppError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc is not None and rc < 0:
+        msg = lib().npp_last_error_string()
+        raise NppError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def param_layout(K, width=NPP_WIDTH):
+    """[(name, offset, rows, cols)], total floats -- the reference's state_dict order."""
+    L = lib()
+    names = (C.c_char_p * 32)()
+    offs = (_i64 * 32)()
+    rows = (C.c_int32 * 32)()
+    cols = (C.c_int32 * 32)()
+    total = _i64(0)
+    n = check(L.npp_param_layout(K, width, names, offs, rows, cols, C.byref(total)), "npp_param_layout")
+    out = []
+    for i in range(n):
+        out.append((names[i].decode(), int(offs[i]), int(rows[i]), int(cols[i])))
+    return out, int(total.value)

@@ -1,0 +1,292 @@
+// npp_api.hip -- host-side glue of libnpp_hip.so: error plumbing, the parameter table,
+// weight packing (device kernel + host twin), and the MFMA lane-map self test.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "npp_common.h"
+
+namespace npp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return NPP_ERR_LAUNCH;
+  }
+  return NPP_OK;
+}
+
+static const char* kNames[kNumLayers] = {
+    "periodic_linears.0", "periodic_linears.1", "periodic_linears.2", "periodic_linears.3",
+    "periodic_linears.4", "periodic_linears.5", "periodic_linears.6", "periodic_linears.7",
+    "feature_linear1",    "scale_linears.0",    "feature_linear2",    "pos_linears.0",
+    "rgb_linear"};
+static char g_name_buf[kNumLayers * 2][40];
+
+// ---- weight packing --------------------------------------------------------------
+// forward pack element (l, ks, nt, lane, j) = W_l[nt*32 + (lane&31)][fwd_col(...)]
+// backward pack element (v, ns, kt, lane, j) = W_layer[16 ns + perm16(h, j)][col0 + kt*32 + (lane&31)]
+NPP_HD float fwd_pack_value(const float* P, const NetDesc& d, int l, int ks, int nt, int lane, int j) {
+  const int col = fwd_col(d.K, l, ks, lane >> 5, j);
+  if (col < 0) return 0.0f;
+  const int row = nt * 32 + (lane & 31);
+  return P[d.w_off[l] + (int64_t)row * d.n_in[l] + col];
+}
+NPP_HD float bwd_pack_value(const float* P, const NetDesc& d, const BwdDesc& b, int v, int ns, int kt,
+                            int lane, int j) {
+  const int l = b.layer[v];
+  const int n = 16 * ns + perm16(lane >> 5, j);
+  const int col = b.col0[v] + kt * 32 + (lane & 31);
+  return P[d.w_off[l] + (int64_t)n * d.n_in[l] + col];
+}
+
+// Decode a forward-pack 16-byte unit index into (l, ks, nt, lane).
+NPP_HD bool fwd_unit(const NetDesc& d, int64_t u, int& l, int& ks, int& nt, int& lane) {
+  for (l = 0; l < kNumLayers; ++l) {
+    if (!d.present[l] || d.nt_f[l] == 0) continue;
+    const int64_t n = (int64_t)d.ks_f[l] * d.nt_f[l] * 64;
+    if (u >= d.wf_off[l] && u < d.wf_off[l] + n) {
+      int64_t r = u - d.wf_off[l];
+      lane = (int)(r & 63);
+      r >>= 6;
+      nt = (int)(r % d.nt_f[l]);
+      ks = (int)(r / d.nt_f[l]);
+      return true;
+    }
+  }
+  return false;
+}
+NPP_HD bool bwd_unit(const BwdDesc& b, int64_t u, int& v, int& ns, int& kt, int& lane) {
+  for (v = 0; v < kNumBwd; ++v) {
+    if (!b.present[v]) continue;
+    const int64_t n = (int64_t)b.ns[v] * kNT * 64;
+    if (u >= b.off16[v] && u < b.off16[v] + n) {
+      int64_t r = u - b.off16[v];
+      lane = (int)(r & 63);
+      r >>= 6;
+      kt = (int)(r % kNT);
+      ns = (int)(r / kNT);
+      return true;
+    }
+  }
+  return false;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ P, bf16x8* __restrict__ wf,
+                                    bf16x8* __restrict__ wb, NetDesc d, BwdDesc b, int64_t nf,
+                                    int64_t nb) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < nf) {
+    int l, ks, nt, lane;
+    if (fwd_unit(d, u, l, ks, nt, lane)) {
+      bf16x8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (__bf16)fwd_pack_value(P, d, l, ks, nt, lane, j);
+      wf[u] = r;
+    }
+  } else if (u < nf + nb) {
+    const int64_t ub = u - nf;
+    int v, ns, kt, lane;
+    if (bwd_unit(b, ub, v, ns, kt, lane)) {
+      bf16x8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (__bf16)bwd_pack_value(P, d, b, v, ns, kt, lane, j);
+      wb[ub] = r;
+    }
+  }
+}
+
+static uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+
+// ---- MFMA lane-map self test -------------------------------------------------------
+// out[0..1023]   : D = A(32x16) * B(16x32) stored row-major via the documented C/D map
+// out[1024..2047]: Y = A2(32x32) * X, X = D converted to bf16 and fed back as the B
+//                  operand of two k-steps (accumulator-as-operand chain), A2 packed with
+//                  perm16 k order.
+__global__ void selftest_kernel(float* out) {
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 31, h = lane >> 5;
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * h + j;                       // documented A/B operand map
+    a[j] = (__bf16)(float)(((m * 3 + k * 5) % 5) - 2);   // A[m][k]
+    b[j] = (__bf16)(float)(((k * 7 + m * 2) % 4) - 1);   // B[k][n=m]
+  }
+  f32x16 acc = {};
+  acc = mfma_bf16(a, b, acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[acc_row(r, h) * 32 + m] = acc[r];
+  f32x16 y = {};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 x = pack_acc(acc, s), a2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + perm16(h, j);         // row of X this element multiplies
+      a2[j] = (__bf16)(float)(((m * 5 + k * 3) % 7) - 3);  // A2[m][k]
+    }
+    y = mfma_bf16(a2, x, y);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[1024 + acc_row(r, h) * 32 + m] = y[r];
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+extern "C" {
+
+int npp_version(void) { return 100; }
+const char* npp_last_error_string(void) { return g_err; }
+
+int npp_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+static int check_kw(int K, int width) {
+  if (K < 1 || K > NPP_MAX_K) { set_error("K=%d outside [1,%d]", K, NPP_MAX_K); return NPP_ERR_ARG; }
+  if (width != NPP_WIDTH) {
+    set_error("width=%d: this build is specialised for width %d", width, NPP_WIDTH);
+    return NPP_ERR_UNSUPPORTED;
+  }
+  return NPP_OK;
+}
+
+int npp_param_layout(int K, int width, const char** names, int64_t* offsets, int32_t* rows,
+                     int32_t* cols, int64_t* total) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  const NetDesc d = make_desc(K);
+  int n = 0;
+  for (int l = 0; l < kNumLayers; ++l) {
+    if (!d.present[l]) continue;
+    for (int wb = 0; wb < 2; ++wb) {
+      snprintf(g_name_buf[n], sizeof(g_name_buf[n]), "%s.%s", kNames[l], wb ? "bias" : "weight");
+      if (names) names[n] = g_name_buf[n];
+      if (offsets) offsets[n] = wb ? d.b_off[l] : d.w_off[l];
+      if (rows) rows[n] = d.n_out[l];
+      if (cols) cols[n] = wb ? 1 : d.n_in[l];
+      ++n;
+    }
+  }
+  if (total) *total = d.total_params;
+  return n;
+}
+
+int64_t npp_pack_bytes(int K, int width, int which) {
+  if (check_kw(K, width)) return -1;
+  return 16 * (which == 0 ? make_desc(K).wf_total16 : bwd_total16(K));
+}
+
+int npp_pack_weights(const float* d_params, void* d_wf, void* d_wb, int K, int width, void* stream) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  if (!d_params || !d_wf || !d_wb) { set_error("npp_pack_weights: null pointer"); return NPP_ERR_ARG; }
+  const NetDesc d = make_desc(K);
+  const BwdDesc b = make_bwd_desc(K);
+  const int64_t nf = d.wf_total16, nb = bwd_total16(K);
+  const int threads = 256;
+  const int64_t blocks = (nf + nb + threads - 1) / threads;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream,
+                     d_params, (bf16x8*)d_wf, (bf16x8*)d_wb, d, b, nf, nb);
+  return check_launch("npp_pack_weights");
+}
+
+int npp_pack_weights_host(const float* params, void* wf, void* wb, int K, int width) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  const NetDesc d = make_desc(K);
+  const BwdDesc b = make_bwd_desc(K);
+  uint16_t* f = (uint16_t*)wf;
+  uint16_t* g = (uint16_t*)wb;
+  for (int64_t u = 0; u < d.wf_total16; ++u) {
+    int l, ks, nt, lane;
+    if (!fwd_unit(d, u, l, ks, nt, lane)) { set_error("fwd unit %lld unmapped", (long long)u); return NPP_ERR_ARG; }
+    for (int j = 0; j < 8; ++j) f[u * 8 + j] = f32_to_bf16_host(fwd_pack_value(params, d, l, ks, nt, lane, j));
+  }
+  const int64_t nb = bwd_total16(K);
+  for (int64_t u = 0; u < nb; ++u) {
+    int v, ns, kt, lane;
+    if (!bwd_unit(b, u, v, ns, kt, lane)) { set_error("bwd unit %lld unmapped", (long long)u); return NPP_ERR_ARG; }
+    for (int j = 0; j < 8; ++j) g[u * 8 + j] = f32_to_bf16_host(bwd_pack_value(params, d, b, v, ns, kt, lane, j));
+  }
+  return NPP_OK;
+}
+
+int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || !sizes) { set_error("npp_train_workspace: bad Bp/ksplit"); return NPP_ERR_ARG; }
+  sizes[0] = sstash_bytes(Bp);
+  sizes[1] = (int64_t)act_rows(K) * Bp * 2;
+  sizes[2] = (int64_t)kDzRows * Bp * 2;
+  sizes[3] = (int64_t)ksplit * make_desc(K).total_params * 4;
+  return NPP_OK;
+}
+
+int npp_selftest_mfma(void* d_scratch, void* stream) {
+  if (!d_scratch) { set_error("npp_selftest_mfma: null scratch"); return NPP_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, s, (float*)d_scratch);
+  int rc = check_launch("npp_selftest_mfma");
+  if (rc) return rc;
+  std::vector<float> out(2048);
+  hipError_t e = hipMemcpyAsync(out.data(), d_scratch, 2048 * sizeof(float), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { set_error("selftest copy: %s", hipGetErrorString(e)); return NPP_ERR_LAUNCH; }
+  // host model with exact integers
+  int A[32][16], B[16][32], D[32][32], A2[32][32];
+  for (int m = 0; m < 32; ++m)
+    for (int k = 0; k < 16; ++k) { A[m][k] = ((m * 3 + k * 5) % 5) - 2; B[k][m] = ((k * 7 + m * 2) % 4) - 1; }
+  for (int m = 0; m < 32; ++m)
+    for (int k = 0; k < 32; ++k) A2[m][k] = ((m * 5 + k * 3) % 7) - 3;
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      int acc = 0;
+      for (int k = 0; k < 16; ++k) acc += A[i][k] * B[k][j];
+      D[i][j] = acc;
+    }
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      if (out[i * 32 + j] != (float)D[i][j]) {
+        set_error("selftest: plain MFMA lane map mismatch at (%d,%d): got %g want %d", i, j, out[i * 32 + j], D[i][j]);
+        return NPP_ERR_SELFTEST;
+      }
+      int acc = 0;
+      for (int k = 0; k < 32; ++k) acc += A2[i][k] * D[k][j];
+      if (out[1024 + i * 32 + j] != (float)acc) {
+        set_error("selftest: accumulator-as-operand chain mismatch at (%d,%d): got %g want %d", i, j,
+                  out[1024 + i * 32 + j], acc);
+        return NPP_ERR_SELFTEST;
+      }
+    }
+  return NPP_OK;
+}
+
+}  // extern "C"

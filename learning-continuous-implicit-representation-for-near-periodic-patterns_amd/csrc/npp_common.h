@@ -1,0 +1,90 @@
+// npp_common.h -- device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "npp_layout.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+namespace npp {
+
+// host-side error plumbing (npp_api.cpp)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+constexpr float kInv2Pi = 0.15915494309189535f;
+
+// Embedder constants precomputed on the host from npp_embed_cfg (kernel argument).
+// models/embedder.py:117-127: freq = period + offset, theta = deg2rad(angle).
+struct EmbedDev {
+  int32_t K, H, W, pad;
+  float inv_w, inv_h;
+  float cs[NPP_MAX_K][2], sn[NPP_MAX_K][2];            // cos/sin(theta_i)
+  float per[NPP_MAX_K][2][NPP_N_OFF];                  // period_i + offset_o
+  float freq[NPP_N_FREQ];                              // Fourier freq (rad per unit)
+  float freq_rev[NPP_N_FREQ];                          // freq / 2pi (revolutions)
+};
+
+// ---- a1: one warped coordinate (models/embedder.py:110-133) -------------------
+// i in [0,22): 0 -> x/W*2-1 ; 1..10 -> sin/cos pairs of orientation 0 over the 5
+// offsets ; 11 -> y/H*2-1 ; 12..21 -> orientation 1.
+template <bool PRECISE>
+__device__ __forceinline__ float warp_value(const EmbedDev& e, int p, int i, float y, float x) {
+  const int ori = i >= 11;
+  const int ii = ori ? i - 11 : i;
+  if (ii == 0) {
+    // (x / res[1] - 0.5) * 2   (embedder.py:112-113)
+    return ori ? (y / (float)e.H - 0.5f) * 2.0f : (x / (float)e.W - 0.5f) * 2.0f;
+  }
+  const int o = (ii - 1) >> 1;
+  const bool is_cos = (ii - 1) & 1;
+  const float per = e.per[p][ori][o];
+  // y*cos + x*sin, rounded like the reference's two torch ops (no fma contraction)
+  const float t = __fadd_rn(__fmul_rn(y, e.cs[p][ori]), __fmul_rn(x, e.sn[p][ori]));
+  if (PRECISE) {
+    float r = fmodf(t, per);                       // torch.remainder: sign of divisor
+    if (r != 0.0f && ((per < 0.0f) != (r < 0.0f))) r += per;
+    const float phi = ((r / per) * 2.0f) * 3.14159265358979323846f;
+    return is_cos ? cosf(phi) : sinf(phi);
+  } else {
+    const float q = floorf(t / per);
+    float r = fmaf(-q, per, t);                    // exact remainder for |q| < 2^24
+    r = r < 0.0f ? r + per : r;
+    r = r >= per ? r - per : r;
+    const float rev = r / per;                     // phase in revolutions, [0,1)
+    return is_cos ? __builtin_amdgcn_cosf(rev) : __builtin_amdgcn_sinf(rev);
+  }
+}
+
+// ---- a6: snake and its derivative (models/activations.py:29-35, a = 1) -----------
+__device__ __forceinline__ float snake_fast(float z) {
+  const float s = __builtin_amdgcn_sinf(z * kInv2Pi);
+  return fmaf(s, s, z);
+}
+__device__ __forceinline__ void snake_fast2(float z, float& a, float& da) {
+  const float rev = z * kInv2Pi;
+  const float s = __builtin_amdgcn_sinf(rev);
+  const float c = __builtin_amdgcn_cosf(rev);
+  a = fmaf(s, s, z);
+  da = fmaf(2.0f * s, c, 1.0f);                    // 1 + sin(2z)
+}
+
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& acc, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)acc[8 * s + j];
+  return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+
+}  // namespace npp

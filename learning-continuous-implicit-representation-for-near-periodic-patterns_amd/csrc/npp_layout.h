@@ -1,0 +1,169 @@
+// npp_layout.h -- index maps shared by host code and device kernels: the parameter
+// blob (reference layout), the bf16 MFMA-fragment weight packs, and the training
+// stash arrays.  Single source of truth; the CPU tests exercise it through
+// npp_pack_weights_host() against a NumPy model of the MFMA lane maps.
+//
+// Network restated (models/networks.py:56-95, K>1; :145-173, K==1), W=256, D=8:
+//   L0: emb0(462)->256   L1..L4: 256->256   L5: [emb0(462), h(256)]->256 (cat :71)
+//   L6,L7: 256->256      F1 = feature_linear1 (no activation)
+//   S  = scale_linears[0]: [f1(256), aux((K-1)*462)]->256 (cat :76)   (K>1)
+//   F2 = feature_linear2 (no activation)                               (K>1)
+//   P  = pos_linears[0]: [f1, f2](512)->128 (cat :85)  /  f1(256)->128 (K==1)
+//   RGB = rgb_linear 128->3, then sigmoid (models/helpers.py:55-56)
+// snake after L0..L7, S, P (models/activations.py:29-35).
+#pragma once
+#include <stdint.h>
+#include "npp_hip.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NPP_HD __host__ __device__ inline
+#else
+#define NPP_HD inline
+#endif
+
+namespace npp {
+
+constexpr int kW = NPP_WIDTH;       // 256
+constexpr int kE = NPP_E;           // 462
+constexpr int kNT = kW / 32;        // 8 neuron tiles of 32
+constexpr int kKSAct = kW / 16;     // 16 k-steps per 256 activation features
+constexpr int kKSEmb = 30;          // k-steps per proposal embedding (480 slots >= 462)
+constexpr int kEmbSlots = kKSEmb * 16;
+constexpr int kRowTile = NPP_ROW_TILE;  // 64 rows per workgroup = NB * 32
+constexpr int kNB = kRowTile / 32;      // batch tiles per workgroup
+
+enum Layer : int { L0 = 0, L1, L2, L3, L4, L5, L6, L7, LF1, LS, LF2, LP, LRGB, kNumLayers };
+
+// ---- MFMA 32x32x16 bf16 lane maps (cdna_hip_programming.md section 3) ----------
+// accumulator: lane l holds column (l & 31); register r holds row acc_row(r, l >> 5)
+NPP_HD int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// An accumulator tile converted to bf16 (registers 8s..8s+7) is the B operand of
+// k-step s; element j of lane-half h is then row 16s + perm16(h, j).  All activation
+// operands in this library use that order, so A-operand (weight) fragments are packed
+// with the same k order.
+NPP_HD int perm16(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// ---- embedding slot order ------------------------------------------------------
+// One proposal = 30 k-steps of 16 slots.  k-steps 0..27: t = 8*ks + j enumerates
+// (freq fj = t / 22, warp index i = t % 22); lane-half 0 holds sin(f v_i), half 1
+// holds cos(f v_i) (same argument, one range reduction).  k-step 28: v_0..v_15,
+// k-step 29: v_16..v_21.  Returns the reference column in [0,462)
+// (models/embedder.py:41-44,56: block 0 identity, 1+2f sin, 2+2f cos) or -1 (padding).
+NPP_HD int emb_col(int ks, int h, int j) {
+  if (ks < 28) {
+    int t = 8 * ks + j;
+    if (t >= 220) return -1;
+    int fj = t / 22, i = t % 22;
+    return (1 + 2 * fj + h) * 22 + i;
+  }
+  if (ks == 28) return 8 * h + j;
+  return (h == 0 && j < 6) ? 16 + j : -1;
+}
+
+struct NetDesc {
+  int32_t K;
+  int32_t present[kNumLayers];
+  int32_t n_out[kNumLayers], n_in[kNumLayers];       // reference shapes
+  int64_t w_off[kNumLayers], b_off[kNumLayers];      // floats into the blob
+  int64_t total_params;
+  // forward pack: [ks][nt][64 lanes][8] bf16 per layer, offsets in 16-byte units
+  int32_t ks_f[kNumLayers], nt_f[kNumLayers];
+  int64_t wf_off[kNumLayers];
+  int64_t wf_total16;
+  // backward (dgrad) pack: virtual layers, each 8 output tiles x ns k-steps
+  int64_t wb_total16;
+};
+
+// virtual dgrad layers, in the order the backward kernel runs them
+enum BwdLayer : int { BP1 = 0, BP2, BF2, BS, BF1, B7, B6, B5, B4, B3, B2, B1, kNumBwd };
+struct BwdDesc {
+  int32_t present[kNumBwd];
+  int32_t layer[kNumBwd];     // forward layer whose weight it transposes
+  int32_t col0[kNumBwd];      // first reference input column of the 256 outputs
+  int32_t ns[kNumBwd];        // k-steps over the layer's output neurons
+  int64_t off16[kNumBwd];     // offset in 16-byte units
+};
+
+NPP_HD NetDesc make_desc(int K) {
+  NetDesc d{};
+  d.K = K;
+  const int multi = K > 1;
+  int64_t off = 0, off16 = 0;
+  for (int l = 0; l < kNumLayers; ++l) {
+    int nout = kW, nin = kW, ks = kKSAct, nt = kNT, present = 1;
+    switch (l) {
+      case L0: nin = kE; ks = kKSEmb; break;
+      case L5: nin = kE + kW; ks = kKSEmb + kKSAct; break;
+      case LS: nin = kW + (K - 1) * kE; ks = kKSAct + (K - 1) * kKSEmb; present = multi; break;
+      case LF2: present = multi; break;
+      case LP: nout = kW / 2; nin = multi ? 2 * kW : kW; ks = multi ? 2 * kKSAct : kKSAct; nt = kNT / 2; break;
+      case LRGB: nout = 3; nin = kW / 2; ks = 0; nt = 0; break;
+      default: break;
+    }
+    d.present[l] = present;
+    d.n_out[l] = nout; d.n_in[l] = nin; d.ks_f[l] = ks; d.nt_f[l] = nt;
+    if (!present) { d.w_off[l] = d.b_off[l] = -1; d.wf_off[l] = -1; continue; }
+    d.w_off[l] = off; off += (int64_t)nout * nin;
+    d.b_off[l] = off; off += nout;
+    d.wf_off[l] = off16; off16 += (int64_t)ks * nt * 64;
+  }
+  d.total_params = off;
+  d.wf_total16 = off16;
+  d.wb_total16 = 0;
+  return d;
+}
+
+NPP_HD BwdDesc make_bwd_desc(int K) {
+  BwdDesc b{};
+  const int multi = K > 1;
+  const int lay[kNumBwd] = {LP, LP, LF2, LS, LF1, L7, L6, L5, L4, L3, L2, L1};
+  int64_t off = 0;
+  for (int v = 0; v < kNumBwd; ++v) {
+    b.layer[v] = lay[v];
+    b.col0[v] = (v == BP2) ? kW : (v == B5 ? kE : 0);
+    b.ns[v] = (v == BP1 || v == BP2) ? (kW / 2) / 16 : kKSAct;
+    b.present[v] = (v == BP2 || v == BF2 || v == BS) ? multi : 1;
+    b.off16[v] = off;
+    if (b.present[v]) off += (int64_t)b.ns[v] * kNT * 64;
+  }
+  return b;
+}
+NPP_HD int64_t bwd_total16(int K) {
+  BwdDesc b = make_bwd_desc(K);
+  int64_t t = 0;
+  for (int v = 0; v < kNumBwd; ++v) if (b.present[v]) t += (int64_t)b.ns[v] * kNT * 64;
+  return t;
+}
+
+// Reference input column of forward-pack element (layer l, k-step ks, lane half h,
+// element j), or -1 for zero padding.
+NPP_HD int fwd_col(int K, int l, int ks, int h, int j) {
+  switch (l) {
+    case L0: return emb_col(ks, h, j);
+    case L5: return ks < kKSEmb ? emb_col(ks, h, j) : kE + 16 * (ks - kKSEmb) + perm16(h, j);
+    case LS: {
+      if (ks < kKSAct) return 16 * ks + perm16(h, j);
+      int q = ks - kKSAct, p = q / kKSEmb, c = emb_col(q % kKSEmb, h, j);
+      return c < 0 ? -1 : kW + p * kE + c;
+    }
+    default: return 16 * ks + perm16(h, j);
+  }
+}
+
+// ---- training stash rows (feature-major bf16 arrays [rows][Bp]) -------------------
+// actT: a0..a7, f1, a_s, f2 (256 rows each), a_p (128 rows), then K*480 embedding slots
+constexpr int kActF1 = 8, kActAS = 9, kActF2 = 10, kActAP = 11;
+constexpr int kActEmbRow0 = 11 * kW + kW / 2;          // 2944
+NPP_HD int act_rows(int K) { return kActEmbRow0 + K * kEmbSlots; }
+// dzT: dz0..dz7, dz_f1, dz_s, dz_f2 (256 rows each), dz_p (128), dz_rgb (4 rows, 3 used)
+constexpr int kDzF1 = 8, kDzS = 9, kDzF2 = 10, kDzP = 11;
+constexpr int kDzRgbRow0 = 11 * kW + kW / 2;            // 2944
+constexpr int kDzRows = kDzRgbRow0 + 4;
+// s-stash (snake derivative, bf16, fragment order): slots 0..7 = L0..L7, 8 = S (256
+// wide), 9 = P (128 wide).  Per layer [wg][nt][bt][s][64][8].
+NPP_HD int64_t sstash_off_bytes(int slot, int64_t Bp) {
+  return (int64_t)slot * Bp * kW * 2;  // slot 9 (P) is last and only half as wide
+}
+NPP_HD int64_t sstash_bytes(int64_t Bp) { return 9 * Bp * kW * 2 + Bp * (kW / 2) * 2; }
+
+}  // namespace npp

@@ -1,0 +1,161 @@
+// npp_loss_adam.hip -- K4 adaptive robust pixel loss (forward + closed-form backward)
+// and K8 fused Adam.  Both are tiny, HBM/latency-bound elementwise kernels.
+//
+// K4 restates models/mse_calculator.py:13-27 -> robust_loss_pytorch/adaptive.py:183-204
+// -> distribution.py:171-210 (nll = rho + log c + logZ(alpha)) -> general.py:85-118
+// ('otherwise' branch; alpha is confined to (0.001,1.999) by adaptive.py:146-164) ->
+// distribution.py:90-114,143-169 + cubic_spline.py:65-97 (log-partition spline).
+// Backward (derivation in oracle/npp_oracle.py: robust_nll_grads):
+//   beta = 2-alpha, u = (x/c)^2/beta + 1, e = alpha/2
+//   d rho/dx = x/c^2 u^(e-1) ; d rho/dc = -x^2/c^3 u^(e-1) ;
+//   d rho/da = -(2/a^2)(u^e - 1) + (beta/a) u^e (ln(u)/2 + e (x/c)^2/(beta^2 u))
+#include "npp_common.h"
+
+namespace npp {
+
+struct ChanParams {   // per-channel quantities derived from the latents
+  float alpha, c, beta, logc_plus_logz, dlogz, dalpha_dl, dc_dl;
+};
+
+__device__ inline ChanParams chan_params(float latent_alpha, float latent_scale, const float* spline,
+                                         int n_knots, float x_scale) {
+  ChanParams p;
+  // adaptive.py:146-164 + util.py:64-72: alpha = sigmoid(l)*(hi-lo)+lo, lo=.001, hi=1.999
+  const float sg = 1.0f / (1.0f + expf(-latent_alpha));
+  p.alpha = sg * (1.999f - 0.001f) + 0.001f;
+  p.dalpha_dl = sg * (1.0f - sg) * (1.999f - 0.001f);
+  // adaptive.py:166-181 + util.py:86-95: c = (1-1e-5)*softplus(l + log(e-1)) + 1e-5
+  const float xs = latent_scale + 0.54132485f;   // log(expm1(1))
+  const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
+  p.c = (1.0f - 1e-5f) * sp + 1e-5f;
+  p.dc_dl = (1.0f - 1e-5f) / (1.0f + expf(-xs));
+  p.beta = fmaxf(1.1920929e-07f, fabsf(p.alpha - 2.0f));
+  // distribution.py:90-114 partition_spline_curve (alpha < 4 branch)
+  const float den = fabsf(p.alpha - 2.0f) + 0.25f;
+  const float xc = (2.25f * p.alpha - 4.5f) / den + p.alpha + 2.0f;
+  const float dxc = 0.5625f / (den * den) + 1.0f;
+  // cubic_spline.py:65-97
+  const float xq = xc * x_scale;
+  const float* vals = spline;
+  const float* tans = spline + n_knots;
+  const int lo = (int)floorf(fminf(fmaxf(xq, 0.0f), (float)(n_knots - 2)));
+  const float t = xq - (float)lo, t2 = t * t, t3 = t * t2;
+  const float h01 = -2.0f * t3 + 3.0f * t2, h00 = 1.0f - h01, h11 = t3 - t2, h10 = h11 - t2 + t;
+  const float v0 = vals[lo], v1 = vals[lo + 1], m0 = tans[lo], m1 = tans[lo + 1];
+  float val = v0 * h00 + v1 * h01 + m0 * h10 + m1 * h11;
+  const float dh01 = -6.0f * t2 + 6.0f * t, dh11 = 3.0f * t2 - 2.0f * t, dh10 = dh11 - 2.0f * t + 1.0f;
+  float dval = (v1 - v0) * dh01 + m0 * dh10 + m1 * dh11;
+  if (t < 0.0f) { val = tans[0] * t + vals[0]; dval = tans[0]; }
+  else if (t > 1.0f) { val = tans[n_knots - 1] * (t - 1.0f) + vals[n_knots - 1]; dval = tans[n_knots - 1]; }
+  p.logc_plus_logz = logf(p.c) + val;
+  p.dlogz = dval * x_scale * dxc;
+  return p;
+}
+
+// One thread per row (3 channels), grid-stride; block reduction via wave shuffles, then
+// one atomicAdd per block per output (7 floats).
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ gt,
+                                                         const float* __restrict__ mask, int64_t N,
+                                                         const float* __restrict__ latents,
+                                                         const float* __restrict__ spline, int n_knots,
+                                                         float x_scale, float weight,
+                                                         float* __restrict__ loss_out,
+                                                         float* __restrict__ dpred,
+                                                         float* __restrict__ dlatent) {
+  __shared__ ChanParams cp[3];
+  __shared__ float red[4][7];
+  if (threadIdx.x < 3) cp[threadIdx.x] = chan_params(latents[threadIdx.x], latents[3 + threadIdx.x], spline, n_knots, x_scale);
+  __syncthreads();
+  const float inv = 1.0f / (3.0f * (float)N);
+  float acc[7] = {0, 0, 0, 0, 0, 0, 0};   // loss, dalpha[3], dc[3]
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    const float m = mask ? mask[r] : 1.0f;
+    const float w = m + (1.0f - m) * 0.3f;          // mse_calculator.py:17
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const ChanParams p = cp[ch];
+      const float d0 = pred[r * 3 + ch] - gt[r * 3 + ch];
+      const float x = mask ? d0 * m + (1.0f - m) * d0 * 0.3f : d0;
+      const float xs = x / p.c, ssx = xs * xs;
+      const float u = ssx / p.beta + 1.0f;
+      const float e = 0.5f * p.alpha;
+      const float lnu = logf(u);
+      const float ue = expf(e * lnu);               // pow(u, e), u >= 1
+      const float ue1 = ue / u;
+      const float rho = (p.beta / p.alpha) * (ue - 1.0f);
+      acc[0] += rho + p.logc_plus_logz;
+      dpred[r * 3 + ch] = weight * inv * w * (x / (p.c * p.c)) * ue1;
+      acc[1 + ch] += -(2.0f / (p.alpha * p.alpha)) * (ue - 1.0f) +
+                     (p.beta / p.alpha) * ue * (0.5f * lnu + e * ssx / (p.beta * p.beta * u)) + p.dlogz;
+      acc[4 + ch] += -(x * x) / (p.c * p.c * p.c) * ue1 + 1.0f / p.c;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    if (k == 0) atomicAdd(loss_out, v * inv);
+    else if (k < 4) atomicAdd(dlatent + (k - 1), weight * inv * v * cp[k - 1].dalpha_dl);
+    else atomicAdd(dlatent + 3 + (k - 4), weight * inv * v * cp[k - 4].dc_dl);
+  }
+}
+
+// torch.optim.Adam single-tensor maths (helpers.py:164): the gradient is the sum of the
+// split-K slabs written by npp_mlp_wgrad, so this kernel is also the wgrad reduction.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ g,
+                                                   int64_t n, int n_slabs, int64_t slab_stride,
+                                                   float step_size, float b1, float b2, float inv_sqrt_bc2,
+                                                   float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = 0.0f;
+  for (int s = 0; s < n_slabs; ++s) gi += g[(int64_t)s * slab_stride + i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+extern "C" int npp_pixel_loss(const float* d_pred, const float* d_gt, const float* d_mask, int64_t N,
+                              const float* d_latents, const float* d_spline, int n_knots, float x_scale,
+                              float weight, float* d_loss, float* d_dpred, float* d_dlatent, void* stream) {
+  if (N <= 0 || !d_pred || !d_gt || !d_latents || !d_spline || !d_loss || !d_dpred || !d_dlatent || n_knots < 2) {
+    set_error("npp_pixel_loss: bad arguments (N=%lld, n_knots=%d)", (long long)N, n_knots);
+    return NPP_ERR_ARG;
+  }
+  int64_t blocks = (N + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pixel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pred, d_gt,
+                     d_mask, N, d_latents, d_spline, n_knots, x_scale, weight, d_loss, d_dpred, d_dlatent);
+  return check_launch("npp_pixel_loss");
+}
+
+extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
+                             int64_t slab_stride, float lr, float beta1, float beta2, float eps, int step,
+                             void* stream) {
+  if (n <= 0 || !d_p || !d_m || !d_v || !d_gslabs || n_slabs < 1 || step < 1) {
+    set_error("npp_adam_step: bad arguments");
+    return NPP_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
+                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps);
+  return check_launch("npp_adam_step");
+}

@@ -1,0 +1,226 @@
+// npp_mlp_bwd.hip -- K3a: fused backward (dgrad) chain of the coordinate MLP, bf16 MFMA.
+//
+// What autograd does through models/networks.py:56-95 / :145-173 and the sigmoid of
+// models/helpers.py:56, restricted to the activations: given dL/dpred it produces the
+// pre-activation gradients dz_l of every layer, feature-major in bf16 (the operand
+// layout npp_mlp_wgrad contracts over the batch).  No gradient flows to the embedding
+// inputs, so L0 and the embedding columns of L5 / S have no dgrad.
+//
+// Same transposed formulation as the forward kernel: dA^T[k][b] = W^T[k][n] dZ^T[n][b]
+// with W^T pre-packed as MFMA A-operand fragments (npp_pack_weights, backward pack) and
+// the accumulator tile of one layer reused, after x snake'(z) and conversion to bf16, as
+// the B operand of the next.  snake'(z) = 1 + sin(2z) was stashed by the forward kernel
+// in fragment order, so it is read back with one 16-byte load per lane per fragment.
+#include "npp_common.h"
+
+namespace npp {
+
+constexpr int kThreadsB = 256;
+constexpr int kRegionBytesB = kKSAct * kNB * 1024;
+constexpr int kSmemBwd = 2 * kRegionBytesB + kRowTile * 3 * 4;
+
+struct BwdArgs {
+  const float* dpred;
+  const float* pred;
+  int64_t Bp;
+  const bf16x8* wb;
+  const float* params;
+  const bf16x8* sstash;
+  __bf16* dzT;
+};
+
+struct LaneB {
+  int tid, wave, lane, b, h;
+};
+
+__device__ __forceinline__ bf16x8 ldsB(const char* region, int ks, int bt, int lane) {
+  return *(const bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16);
+}
+__device__ __forceinline__ void stsB(char* region, int ks, int bt, int lane, const bf16x8& v) {
+  *(bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16) = v;
+}
+
+template <int NS>
+__device__ __forceinline__ void mma_bwd(f32x16 (&acc)[2][kNB], const char* region, const bf16x8* __restrict__ wp,
+                                        int kt0, const LaneB& L) {
+#pragma unroll 2
+  for (int ns = 0; ns < NS; ++ns) {
+    bf16x8 w[2], x[kNB];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w[t] = wp[(ns * kNT + kt0 + t) * 64 + L.lane];
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) x[bt] = ldsB(region, ns, bt, L.lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int bt = 0; bt < kNB; ++bt) acc[t][bt] = mfma_bf16(w[t], x[bt], acc[t][bt]);
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
+}
+
+// dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
+template <bool HAS_S>
+__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const bf16x8* sst, __bf16* dz_rows,
+                                             int64_t Bp, int64_t row0, int wg, int kt0, const LaneB& L) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ntg = kt0 + t;
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      f32x16 g = acc[t][bt];
+      if (HAS_S) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 sf = sst[((((int64_t)wg * kNT + ntg) * kNB + bt) * 2 + s) * 64 + L.lane];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[8 * s + j] *= (float)sf[j];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (out) stsB(out, 2 * ntg + s, bt, L.lane, pack_acc(g, s));
+      __bf16* dst = dz_rows + (int64_t)(ntg * 32) * Bp + row0 + bt * 32 + L.b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)acc_row(r, L.h) * Bp] = (__bf16)g[r];
+    }
+  }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDesc d, BwdDesc bd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R0 = smem;
+  char* R1 = smem + kRegionBytesB;
+  float* sDraw = (float*)(smem + 2 * kRegionBytesB);   // [64 rows][3]
+
+  LaneB L;
+  L.tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  L.lane = threadIdx.x & 63;
+  L.b = L.lane & 31;
+  L.h = L.lane >> 5;
+  const int wg = blockIdx.x;
+  const int64_t row0 = (int64_t)wg * kRowTile, Bp = A.Bp;
+  const float* P = A.params;
+  const int kt0 = 2 * L.wave;
+  auto ss = [&](int slot) { return (const bf16x8*)((const char*)A.sstash + sstash_off_bytes(slot, Bp)); };
+  auto dzr = [&](int idx) { return A.dzT + (int64_t)idx * kW * Bp; };
+
+  // ---- sigmoid backward (helpers.py:56): draw = dpred * pred * (1 - pred); also dz_rgb^T
+  if (L.tid < kRowTile * 3) {
+    const int row = L.tid / 3, c = L.tid - row * 3;
+    const float pr = A.pred[(row0 + row) * 3 + c];
+    const float g = A.dpred[(row0 + row) * 3 + c] * pr * (1.0f - pr);
+    sDraw[L.tid] = g;
+    A.dzT[(int64_t)(kDzRgbRow0 + c) * Bp + row0 + row] = (__bf16)g;
+  }
+  __syncthreads();
+
+  // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
+  //      wave w owns P's neuron tile w.  dz_p fragments -> R0 (8 k-steps), rows -> dzT.
+  {
+    const float* Wr = P + d.w_off[LRGB];
+    float wr[3][16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wr[c][r] = Wr[c * (kW / 2) + L.wave * 32 + acc_row(r, L.h)];
+    const bf16x8* sp = ss(9);
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      const int row = bt * 32 + L.b;
+      const float g0 = sDraw[row * 3 + 0], g1 = sDraw[row * 3 + 1], g2 = sDraw[row * 3 + 2];
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 sf = sp[((((int64_t)wg * (kNT / 2) + L.wave) * kNB + bt) * 2 + s) * 64 + L.lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[8 * s + j] *= (float)sf[j];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) stsB(R0, 2 * L.wave + s, bt, L.lane, pack_acc(g, s));
+      __bf16* dst = A.dzT + (int64_t)(kDzP * kW + L.wave * 32) * Bp + row0 + bt * 32 + L.b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)acc_row(r, L.h) * Bp] = (__bf16)g[r];
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][kNB], acc1[2][kNB];
+  const bf16x8* wb = A.wb;
+
+  // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
+  zero_acc(acc1);
+  mma_bwd<8>(acc1, R0, wb + bd.off16[BP1], kt0, L);            // df1, part 1 (kept in registers)
+  if (MULTI) {
+    zero_acc(acc);
+    mma_bwd<8>(acc, R0, wb + bd.off16[BP2], kt0, L);           // df2 = dz_f2 (F2 is linear)
+    bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), Bp, row0, wg, kt0, L);
+    __syncthreads();
+    // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
+    zero_acc(acc);
+    mma_bwd<kKSAct>(acc, R1, wb + bd.off16[BF2], kt0, L);
+    bwd_epilogue<true>(acc, R0, ss(8), dzr(kDzS), Bp, row0, wg, kt0, L);
+    __syncthreads();
+    // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
+    //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
+    mma_bwd<kKSAct>(acc1, R0, wb + bd.off16[BS], kt0, L);
+  }
+  bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), Bp, row0, wg, kt0, L);
+  __syncthreads();
+
+  // ---- F1, L7 .. L1 dgrads, ping-pong R1 -> R0 -> R1 ...; each output is multiplied by
+  //      the snake derivative of the layer that produced that activation.
+  //      virtual layer v: BF1 -> dz_7, B7 -> dz_6, ..., B1 -> dz_0
+#pragma unroll
+  for (int v = BF1; v <= B1; ++v) {
+    const int out_layer = 7 - (v - BF1);            // L7 .. L0
+    char* in = ((v - BF1) & 1) ? R0 : R1;
+    char* out = ((v - BF1) & 1) ? R1 : R0;
+    zero_acc(acc);
+    mma_bwd<kKSAct>(acc, in, wb + bd.off16[v], kt0, L);
+    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, ss(out_layer), dzr(out_layer), Bp, row0, wg, kt0, L);
+    if (v != B1) __syncthreads();
+  }
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                           const float* d_params, const void* d_sstash, void* d_dzT, void* stream) {
+  if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_bwd: K=%d", K); return NPP_ERR_ARG; }
+  if (width != NPP_WIDTH) { set_error("npp_mlp_bwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
+  if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_bwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
+  if (!d_dpred || !d_pred || !d_wb || !d_params || !d_sstash || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
+  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const bf16x8*)d_sstash, (__bf16*)d_dzT};
+  const NetDesc d = make_desc(K);
+  const BwdDesc bd = make_bwd_desc(K);
+  const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);
+  hipStream_t s = (hipStream_t)stream;
+#define NPP_LAUNCH_B(M)                                                                            \
+  do {                                                                                             \
+    static bool attr_set = false;                                                                  \
+    if (!attr_set) {                                                                               \
+      hipError_t ea = hipFuncSetAttribute((const void*)mlp_bwd_kernel<M>,                          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBwd);   \
+      if (ea != hipSuccess) { set_error("npp_mlp_bwd: smem attr: %s", hipGetErrorString(ea)); return NPP_ERR_LAUNCH; } \
+      attr_set = true;                                                                             \
+    }                                                                                              \
+    hipLaunchKernelGGL((mlp_bwd_kernel<M>), grid, block, kSmemBwd, s, A, d, bd);                   \
+  } while (0)
+  if (K > 1) NPP_LAUNCH_B(true); else NPP_LAUNCH_B(false);
+#undef NPP_LAUNCH_B
+  return check_launch("npp_mlp_bwd");
+}

@@ -1,0 +1,204 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the header
+declares, reports the reference's parameter table, and its weight-fragment packing
+(evaluated by the HOST twin of the device packer) reproduces W @ x under a NumPy model
+of the documented v_mfma_f32_32x32x16_bf16 lane maps.  No GPU calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import npp_amd
+from npp_amd._lib import SYMBOLS, param_layout, check
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "npp_hip.h")).read()
+    declared = set(re.findall(r"\b(npp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(SYMBOLS), declared ^ set(SYMBOLS)
+    L = npp_amd.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.npp_version() >= 100
+
+
+@pytest.mark.parametrize("K", [1, 3, 5])
+def test_param_layout_matches_reference_state_dict(K):
+    lay, total = param_layout(K)
+    shapes = oracle.param_shapes(K)
+    assert [n for n, *_ in lay] == list(shapes)          # same tensors, same order
+    off = 0
+    for name, o, rows, cols in lay:
+        assert o == off
+        shp = shapes[name]
+        assert rows == shp[0] and cols == (shp[1] if len(shp) == 2 else 1)
+        off += int(np.prod(shp))
+    assert off == total
+    if K == 3:
+        assert total == 1197572 - 257                     # SURVEY.md 8a5 minus the unused alpha_linear
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    L = npp_amd.lib()
+    assert L.npp_pack_bytes(9, 256, 0) < 0
+    assert L.npp_pack_bytes(3, 512, 0) < 0
+    assert b"width" in L.npp_last_error_string()
+    sizes = (C.c_int64 * 4)()
+    assert L.npp_train_workspace(3, 256, 100, 4, sizes) < 0   # Bp not a multiple of 64
+    assert L.npp_train_workspace(3, 256, 128, 4, sizes) == 0
+    assert sizes[3] == 4 * 1197315 * 4
+
+
+# ---- NumPy model of the MFMA fragment maps (cdna_hip_programming.md section 3) ----
+def perm16(h, j):
+    return 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def emb_col(ks, h, j):
+    if ks < 28:
+        t = 8 * ks + j
+        if t >= 220:
+            return -1
+        return (1 + 2 * (t // 22) + h) * 22 + t % 22
+    if ks == 28:
+        return 8 * h + j
+    return 16 + j if (h == 0 and j < 6) else -1
+
+
+def bf16_bits_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def mfma_tile(a_frag, b_frag):
+    """a_frag, b_frag: (64, 8) per-lane operand fragments -> D[32][32] with
+    D[m][n] = sum over (h, j) of A[lane m + 32h][j] * B[lane n + 32h][j]."""
+    A = a_frag.reshape(2, 32, 8)
+    B = b_frag.reshape(2, 32, 8)
+    return np.einsum("hmj,hnj->mn", A.astype(np.float64), B.astype(np.float64))
+
+
+def pack_host(P_flat, K):
+    L = npp_amd.lib()
+    nf, nb = L.npp_pack_bytes(K, 256, 0), L.npp_pack_bytes(K, 256, 1)
+    wf = np.zeros(nf // 2, np.uint16)
+    wb = np.zeros(nb // 2, np.uint16)
+    check(L.npp_pack_weights_host(P_flat.ctypes.data, wf.ctypes.data, wb.ctypes.data, K, 256), "pack_host")
+    return bf16_bits_to_f32(wf).reshape(-1, 64, 8), bf16_bits_to_f32(wb).reshape(-1, 64, 8)
+
+
+def flat_params(P, K):
+    lay, total = param_layout(K)
+    flat = np.zeros(total, np.float32)
+    for name, o, rows, cols in lay:
+        flat[o:o + rows * cols] = P[name].reshape(-1)
+    return flat, {n: o for n, o, *_ in lay}
+
+
+def act_frags(X):
+    """X: (feat, 32) activation tile set -> fragments [ks][64][8] in accumulator-chain order."""
+    ks_n = X.shape[0] // 16
+    out = np.zeros((ks_n, 64, 8), np.float32)
+    for ks in range(ks_n):
+        for h in range(2):
+            for j in range(8):
+                out[ks, 32 * h:32 * h + 32, j] = X[16 * ks + perm16(h, j), :]
+    return out
+
+
+def emb_frags(E):
+    """E: (462, 32) one proposal's embedding (reference column order) -> [30][64][8]."""
+    out = np.zeros((30, 64, 8), np.float32)
+    for ks in range(30):
+        for h in range(2):
+            for j in range(8):
+                c = emb_col(ks, h, j)
+                if c >= 0:
+                    out[ks, 32 * h:32 * h + 32, j] = E[c, :]
+    return out
+
+
+def test_emb_slot_order_is_a_bijection_onto_the_462_columns():
+    cols = [emb_col(ks, h, j) for ks in range(30) for h in range(2) for j in range(8)]
+    real = [c for c in cols if c >= 0]
+    assert sorted(real) == list(range(462)) and len(cols) == 480
+
+
+@pytest.mark.parametrize("K", [3, 1])
+def test_forward_pack_reproduces_linear_layers(K):
+    rng = np.random.RandomState(0)
+    P = oracle.init_params(K, seed=3)
+    P = {k: oracle.bf16_round(v) for k, v in P.items()}       # exact in bf16: pack is lossless
+    flat, _ = flat_params(P, K)
+    wf, _ = pack_host(flat, K)
+    W = 256
+    unit = 0
+    # layer order and k-step structure of the forward pack (npp_layout.h make_desc)
+    layers = [("periodic_linears.0", ["emb0"])] + [(f"periodic_linears.{i}", ["act"]) for i in range(1, 5)]
+    layers += [("periodic_linears.5", ["emb0", "act"]), ("periodic_linears.6", ["act"]),
+               ("periodic_linears.7", ["act"]), ("feature_linear1", ["act"])]
+    if K > 1:
+        layers += [("scale_linears.0", ["act"] + [f"emb{p}" for p in range(1, K)]), ("feature_linear2", ["act"]),
+                   ("pos_linears.0", ["act", "act"])]
+    else:
+        layers += [("pos_linears.0", ["act"])]
+    for name, parts in layers:
+        Wm = P[name + ".weight"]
+        nt_n = Wm.shape[0] // 32
+        # a random input in the REFERENCE column order, plus its fragments in kernel order
+        x_ref, frags = [], []
+        for part in parts:
+            if part.startswith("emb"):
+                E = rng.randn(462, 32).astype(np.float32)
+                frags.append(emb_frags(E))
+                x_ref.append(E)
+            else:
+                X = rng.randn(W, 32).astype(np.float32)
+                frags.append(act_frags(X))
+                x_ref.append(X)
+        # reference concat orders: L5 [emb, h] (networks.py:71), S [f1, aux] (:76), P [f1, f2] (:85)
+        x_ref = np.concatenate(x_ref, 0)
+        frags = np.concatenate(frags, 0)
+        assert x_ref.shape[0] == Wm.shape[1], name
+        ks_n = frags.shape[0]
+        out = np.zeros((Wm.shape[0], 32))
+        for ks in range(ks_n):
+            for nt in range(nt_n):
+                out[nt * 32:(nt + 1) * 32] += mfma_tile(wf[unit + ks * nt_n + nt], frags[ks])
+        unit += ks_n * nt_n
+        np.testing.assert_allclose(out, Wm.astype(np.float64) @ x_ref.astype(np.float64), rtol=1e-9, atol=1e-9,
+                                   err_msg=name)
+    assert unit == wf.shape[0]
+
+
+@pytest.mark.parametrize("K", [3, 1])
+def test_backward_pack_reproduces_transposed_products(K):
+    rng = np.random.RandomState(1)
+    P = {k: oracle.bf16_round(v) for k, v in oracle.init_params(K, seed=4).items()}
+    flat, _ = flat_params(P, K)
+    _, wb = pack_host(flat, K)
+    E = 462
+    # virtual dgrad layers in kernel order (npp_layout.h BwdLayer): (weight, first input column)
+    v = [("pos_linears.0", 0)]
+    if K > 1:
+        v += [("pos_linears.0", 256), ("feature_linear2", 0), ("scale_linears.0", 0)]
+    v += [("feature_linear1", 0), ("periodic_linears.7", 0), ("periodic_linears.6", 0), ("periodic_linears.5", E),
+          ("periodic_linears.4", 0), ("periodic_linears.3", 0), ("periodic_linears.2", 0), ("periodic_linears.1", 0)]
+    unit = 0
+    for name, col0 in v:
+        Wm = P[name + ".weight"]
+        n_out = Wm.shape[0]
+        dz = rng.randn(n_out, 32).astype(np.float32)
+        frags = act_frags(dz)                       # contraction index = the layer's output neurons
+        ns_n = n_out // 16
+        out = np.zeros((256, 32))
+        for ns in range(ns_n):
+            for kt in range(8):
+                out[kt * 32:(kt + 1) * 32] += mfma_tile(wb[unit + ns * 8 + kt], frags[ns])
+        unit += ns_n * 8
+        ref = Wm[:, col0:col0 + 256].astype(np.float64).T @ dz.astype(np.float64)
+        np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9, err_msg=f"{name}@{col0}")
+    assert unit == wb.shape[0]
