@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference's model plumbing for the hot path:
+create_npp_net (models/helpers.py:75-175), render (:41-62), the Adam + LR rule of
+NPP_completion/train.py:253-263, with the state kept in device buffers that the HIP
+kernels read directly.  Nothing here computes; it owns memory and calls the C ABI."""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import EmbedCfg, param_layout, NPP_E, NPP_WIDTH
+
+LATENT_ALPHA_INIT = 2.3841858e-07   # logit(0.5) in fp32 (robust_loss_pytorch/util.py:75-83)
+
+
+class NPPNet:
+    """NPP_Net (K>1) / NPP_Net_top1 (K==1) with its embedders, optimiser state and the
+    adaptive pixel-loss latents (the reference's module-level `adaptive_pix`,
+    models/helpers.py:8-9), all resident on one GPU.
+
+    state_dict()/load_state_dict() use the reference's tensor names and layouts
+    (models/networks.py:40-49): the blob is the reference's tensors back to back.
+    """
+
+    def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=4,
+                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5)):
+        self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
+        self.K = int(self.cfg.K)
+        self.device = torch.device(device)
+        self.layout, self.n_params = param_layout(self.K)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        # adaptive_pix latents: [latent_alpha(3) | latent_scale(3)]  (adaptive.py:146-181)
+        self.latents = torch.tensor([LATENT_ALPHA_INIT] * 3 + [0.0] * 3, dtype=torch.float32, device=self.device)
+        self.lat_m = torch.zeros_like(self.latents)
+        self.lat_v = torch.zeros_like(self.latents)
+        self.dlatent = torch.zeros(6, dtype=torch.float32, device=self.device)
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
+        self.ksplit = int(ksplit)
+        self.lrate, self.lrate_decay = float(lrate), int(lrate_decay)
+        self.lr = float(lrate)
+        self.global_step = 0        # train.py:337
+        self.opt_step = 0           # Adam's per-parameter step count
+        self.wf = torch.empty(ops.pack_bytes(self.K, 0), dtype=torch.uint8, device=self.device)
+        self.wb = torch.empty(ops.pack_bytes(self.K, 1), dtype=torch.uint8, device=self.device)
+        self._ws = {}
+        if params is not None:
+            self.load_state_dict(params)
+
+    # ---- parameters -----------------------------------------------------------------
+    def load_state_dict(self, sd):
+        flat = np.zeros(self.n_params, np.float32)
+        for name, off, rows, cols in self.layout:
+            a = sd[name]
+            a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            if a.size != rows * cols:
+                raise ValueError(f"{name}: expected {rows}x{cols}, got {a.shape}")
+            flat[off:off + rows * cols] = a.astype(np.float32).reshape(-1)
+        self.params.copy_(torch.from_numpy(flat))
+        self.repack()
+
+    def state_dict(self):
+        flat = self.params.detach().cpu().numpy()
+        out = {}
+        for name, off, rows, cols in self.layout:
+            a = flat[off:off + rows * cols]
+            out[name] = a.reshape(rows, cols).copy() if name.endswith("weight") else a.copy()
+        return out
+
+    def grads(self):
+        """Sum of the split-K slabs, as a reference-named dict (for tests)."""
+        g = self._ws_last["gslabs"].view(self.ksplit, self.n_params).sum(0).cpu().numpy()
+        out = {}
+        for name, off, rows, cols in self.layout:
+            a = g[off:off + rows * cols]
+            out[name] = a.reshape(rows, cols).copy() if name.endswith("weight") else a.copy()
+        return out
+
+    def repack(self):
+        ops.pack_weights(self.params, self.K, self.wf, self.wb)
+
+    # ---- workspaces -----------------------------------------------------------------
+    def workspace(self, Bp):
+        ws = self._ws.get(Bp)
+        if ws is None:
+            s = ops.train_workspace(self.K, Bp, self.ksplit)
+            dev = self.device
+            ws = {
+                "sstash": torch.empty(s[0], dtype=torch.uint8, device=dev),
+                "actT": torch.empty(s[1], dtype=torch.uint8, device=dev),
+                "dzT": torch.empty(s[2], dtype=torch.uint8, device=dev),
+                "gslabs": torch.empty(s[3] // 4, dtype=torch.float32, device=dev),
+                "pred": torch.empty((Bp, 3), dtype=torch.float32, device=dev),
+                "dpred": torch.zeros((Bp, 3), dtype=torch.float32, device=dev),
+            }
+            self._ws[Bp] = ws
+        self._ws_last = ws
+        return ws
+
+    # ---- the path ---------------------------------------------------------------------
+    def render(self, coords):
+        """render(None, emb[coords], args, **render_kwargs) of the reference (helpers.py:41-62)
+        for arbitrary pixel coordinates; no gradient state is kept (train.py:277-309)."""
+        n = coords.shape[0]
+        bp = ops.pad_rows(n)
+        if bp != n:
+            pad = torch.zeros((bp - n, 2), dtype=torch.int32, device=coords.device)
+            coords = torch.cat([coords, pad], 0)
+        pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params)
+        return pred[:n]
+
+    def forward_train(self, coords_padded):
+        """Forward with stashes; coords must already be padded to a multiple of 64 rows."""
+        ws = self.workspace(coords_padded.shape[0])
+        ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["sstash"], ws["actT"])
+        return ws["pred"]
+
+    def backward(self, Bp):
+        """loss.backward() through the MLP: consumes ws['dpred'] (rows beyond the batch 0)."""
+        ws = self._ws[Bp]
+        ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["sstash"], ws["dzT"])
+        ops.mlp_wgrad(ws["dzT"], ws["actT"], Bp, self.K, self.ksplit, ws["gslabs"])
+
+    def pixel_loss(self, Bp, n_rows, gt, mask=None, weight=1.0):
+        """img2mse on the first n_rows rows of the current prediction (train.py:195);
+        writes dL/dpred for those rows and accumulates the latent gradients."""
+        ws = self._ws[Bp]
+        ops.pixel_loss(ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale,
+                       weight, self.loss_buf, ws["dpred"][:n_rows], self.dlatent)
+
+    def optimizer_step(self, Bp):
+        """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""
+        ws = self._ws[Bp]
+        self.opt_step += 1
+        ops.adam_step(self.params, self.m, self.v, ws["gslabs"], self.ksplit, self.n_params, self.lr, self.opt_step)
+        ops.adam_step(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, self.lr, self.opt_step)
+        self.repack()
+        self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
+        self.global_step += 1
+
+    def zero_grad(self):
+        self.dlatent.zero_()
+        self.loss_buf.zero_()

@@ -1,0 +1,132 @@
+"""Thin torch-tensor wrappers over the C ABI (include/npp_hip.h).  torch is used for device
+memory and streams only; every call goes to libnpp_hip.so on the current HIP stream."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, EmbedCfg, param_layout, NPP_ROW_TILE, NPP_E, NPP_WIDTH  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _req(t, dtype, name, shape=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError(f"{name}: expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def pad_rows(n):
+    return (n + NPP_ROW_TILE - 1) // NPP_ROW_TILE * NPP_ROW_TILE
+
+
+def selftest(device="cuda"):
+    scratch = torch.empty(1 << 18, dtype=torch.float32, device=device)
+    check(lib().npp_selftest_mfma(_p(scratch), _stream()), "npp_selftest_mfma")
+
+
+def embed_fwd(coords, cfg, out_dtype=torch.float32, precise=True):
+    """coords (N,2) int32 (row, col) -> (N, K*462); replaces Embedder_periodic.embed +
+    Embedder.embed + cat (models/embedder.py:140-148, :51-56; train.py:93-105)."""
+    _req(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    out = torch.empty((n, cfg.K * NPP_E), dtype=out_dtype, device=coords.device)
+    code = {torch.float32: 0, torch.bfloat16: 1}[out_dtype]
+    check(lib().npp_embed_fwd(_p(coords), n, C.byref(cfg), _p(out), code, int(bool(precise)), _stream()),
+          "npp_embed_fwd")
+    return out
+
+
+def warp_fwd(coords, cfg):
+    """(N,2) -> (N, K*22) fp32: the Embedder_periodic stage alone (embedder.py:140-148)."""
+    _req(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    out = torch.empty((n, cfg.K * 22), dtype=torch.float32, device=coords.device)
+    check(lib().npp_warp_fwd(_p(coords), n, C.byref(cfg), _p(out), _stream()), "npp_warp_fwd")
+    return out
+
+
+def pack_bytes(K, which, width=NPP_WIDTH):
+    n = lib().npp_pack_bytes(K, width, which)
+    check(n, "npp_pack_bytes")
+    return int(n)
+
+
+def pack_weights(params, K, wf=None, wb=None, width=NPP_WIDTH):
+    _req(params, torch.float32, "params")
+    if wf is None:
+        wf = torch.empty(pack_bytes(K, 0, width), dtype=torch.uint8, device=params.device)
+    if wb is None:
+        wb = torch.empty(pack_bytes(K, 1, width), dtype=torch.uint8, device=params.device)
+    check(lib().npp_pack_weights(_p(params), _p(wf), _p(wb), K, width, _stream()), "npp_pack_weights")
+    return wf, wb
+
+
+def train_workspace(K, Bp, ksplit, width=NPP_WIDTH):
+    sizes = (C.c_int64 * 4)()
+    check(lib().npp_train_workspace(K, width, Bp, ksplit, sizes), "npp_train_workspace")
+    return [int(s) for s in sizes]
+
+
+def mlp_fwd(coords, cfg, wf, params, pred=None, sstash=None, actT=None, width=NPP_WIDTH):
+    """Fused embedder + MLP + sigmoid: coords (Bp,2) -> pred (Bp,3).  Replaces the table
+    gather + render() (train.py:166-189; helpers.py:41-62; networks.py:56-95)."""
+    _req(coords, torch.int32, "coords")
+    bp = coords.shape[0]
+    if pred is None:
+        pred = torch.empty((bp, 3), dtype=torch.float32, device=coords.device)
+    check(lib().npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(sstash),
+                            _p(actT), _stream()), "npp_mlp_fwd")
+    return pred
+
+
+def mlp_bwd(dpred, pred, K, wb, params, sstash, dzT, width=NPP_WIDTH):
+    _req(dpred, torch.float32, "dpred")
+    _req(pred, torch.float32, "pred", dpred.shape)
+    check(lib().npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(sstash),
+                            _p(dzT), _stream()), "npp_mlp_bwd")
+
+
+def mlp_wgrad(dzT, actT, Bp, K, ksplit, gslabs, width=NPP_WIDTH):
+    _req(gslabs, torch.float32, "gslabs")
+    check(lib().npp_mlp_wgrad(_p(dzT), _p(actT), Bp, K, width, ksplit, _p(gslabs), _stream()), "npp_mlp_wgrad")
+
+
+def load_spline(device):
+    """values|tangents fp32 on the device + (n_knots, x_scale); table: resources/partition_spline.npz
+    (this repo's own derivation, tools/gen_partition_spline.py; distribution.py:129-141)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "partition_spline.npz")
+    with np.load(path) as f:
+        vals, tans, xs = f["values"].astype(np.float32), f["tangents"].astype(np.float32), float(f["x_scale"])
+    t = torch.from_numpy(np.concatenate([vals, tans])).to(device)
+    return t, int(vals.shape[0]), xs
+
+
+def pixel_loss(pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss, dpred, dlatent):
+    """img2mse(pred, gt, 'robust_loss_adaptive', adaptive_pix, mask) + backward
+    (models/mse_calculator.py:13-27).  loss / dlatent are accumulated into (caller zeroes)."""
+    _req(pred, torch.float32, "pred")
+    _req(gt, torch.float32, "gt", pred.shape)
+    n = pred.shape[0]
+    check(lib().npp_pixel_loss(_p(pred), _p(gt), _p(mask), n, _p(latents), _p(spline), n_knots, x_scale, weight,
+                               _p(loss), _p(dpred), _p(dlatent), _stream()), "npp_pixel_loss")
+
+
+def adam_step(p, m, v, gslabs, n_slabs, slab_stride, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam step (helpers.py:164) over the flat blob; g = sum of the slabs."""
+    _req(p, torch.float32, "p")
+    check(lib().npp_adam_step(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, lr, b1, b2, eps,
+                              step, _stream()), "npp_adam_step")
