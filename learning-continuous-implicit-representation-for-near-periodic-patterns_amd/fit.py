@@ -1,0 +1,93 @@
+"""The per-image optimisation loop of NPP_completion/train.py:133-337, host side.
+
+One CompletionFit owns one image on one GPU: the masked input, the train/val pixel
+split (loaders/loaders.py:107-108), the NPPNet state and the NumPy RNG whose call order
+follows the reference (np.random.choice over i_train per iteration, train.py:172).  All
+arithmetic of an iteration runs in libnpp_hip.so; this file samples indices, gathers the
+ground-truth colours (torch indexing: glue) and sequences the kernels.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import NPPNet
+
+
+class CompletionFit:
+    def __init__(self, img, mask, angles_deg, periods, freqs, params, device="cuda", N_rand=8192,
+                 ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None):
+        """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
+        masked_img = img * mask is what the loop trains on (train.py:173)."""
+        img = np.asarray(img, np.float32)
+        mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
+        self.H, self.W = img.shape[:2]
+        self.device = torch.device(device)
+        valid = np.ones_like(mask) if valid_mask is None else np.asarray(valid_mask, np.float32).reshape(mask.shape)
+        mask = mask * valid
+        # loaders.py:107-108: np.nonzero order (row-major) for both splits
+        self.i_train = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
+        self.i_val = np.stack(np.nonzero((1 - mask[..., 0]) * valid[..., 0]), 1).astype(np.int32)
+        self.img = torch.from_numpy(img).to(self.device)
+        self.mask = torch.from_numpy(mask).to(self.device)
+        self.masked_img = (self.img * self.mask).contiguous()
+        self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
+                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
+        self.N_rand = int(min(N_rand, self.i_train.shape[0]))
+        self.rng = np.random.RandomState(seed)
+        self.i_train_dev = torch.from_numpy(self.i_train).to(self.device)
+        yy, xx = np.meshgrid(np.arange(self.H, dtype=np.int32), np.arange(self.W, dtype=np.int32), indexing="ij")
+        self.i_all_dev = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(self.device)
+        self.iteration = 0
+
+    # ---- sampling (train.py:172-181) -------------------------------------------------
+    def sample_pixels(self):
+        """np.random.choice(n_train, N_rand, replace=False) -> coords (N_rand,2) on device."""
+        sel = self.rng.choice(self.i_train.shape[0], size=[self.N_rand], replace=False)
+        return self.i_train_dev[torch.from_numpy(sel).to(self.device)]
+
+    def gather_gt(self, coords):
+        return self.masked_img[coords[:, 0].long(), coords[:, 1].long()].contiguous()
+
+    # ---- one optimisation iteration (pixel loss; patch losses are added by the caller) ----
+    def step(self, coords=None, extra_coords=None, patch_loss=None):
+        """coords: pixel-loss rows (sampled when None).  extra_coords: rows of the predicted
+        patches appended after them (train.py:181); patch_loss(pred_patch_rows, dpred_patch_rows)
+        must fill dL/dpred for those rows and return nothing (its kernels accumulate)."""
+        net = self.net
+        if coords is None:
+            coords = self.sample_pixels()
+        n_pix = coords.shape[0]
+        allc = coords if extra_coords is None else torch.cat([coords, extra_coords], 0)
+        n = allc.shape[0]
+        bp = ops.pad_rows(n)
+        if bp != n:
+            allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
+        ws = net.workspace(bp)
+        net.zero_grad()                                  # optimizer.zero_grad() (train.py:192)
+        pred = net.forward_train(allc.contiguous())
+        if n_pix < bp:
+            ws["dpred"][n_pix:].zero_()
+        gt = self.gather_gt(coords)
+        net.pixel_loss(bp, n_pix, gt)                    # img2mse(pred[:N_rand], gt, ...) (train.py:195)
+        if patch_loss is not None:
+            patch_loss(pred[n_pix:n], ws["dpred"][n_pix:n])
+        net.backward(bp)                                 # loss.backward()
+        net.optimizer_step(bp)                           # optimizer.step() + LR rule + global_step
+        self.iteration += 1
+        return net.loss_buf
+
+    # ---- evaluation (train.py:270-331) -----------------------------------------------
+    @torch.no_grad()
+    def render_image(self):
+        """Full H x W grid through the fused forward: the 'fitted pixels/s' pass."""
+        return self.net.render(self.i_all_dev).reshape(self.H, self.W, 3)
+
+    def psnr(self, region="known"):
+        """-10 log10 MSE over known / unknown pixels against the clean image."""
+        pred = self.render_image()
+        m = self.mask if region == "known" else (1.0 - self.mask)
+        d2 = ((pred - self.img) ** 2) * m
+        mse = d2.sum() / (m.sum() * 3).clamp_min(1.0)
+        return float(-10.0 * math.log10(max(float(mse), 1e-20)))
