@@ -147,6 +147,29 @@ __global__ void selftest_kernel(float* out) {
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[1024 + acc_row(r, h) * 32 + m] = y[r];
+
+  // part 3: a 16-KiB W-format operand tile (128 features x 64 rows) holding
+  // v(feature, row) = (7 feature + 3 row) % 251 - 125, written with the producer-side
+  // addressing (wfmt_unit + perm16) and read back with the consumer-side transposed reads;
+  // out[2048 + ((tt*4 + t)*64 + lane)*8 + j] must equal v(32 tt + (lane&31), 16 t + 8 (lane>>5) + j)
+  __shared__ __attribute__((aligned(16))) char tile[16384];
+  for (int u = lane; u < 1024; u += 64) {            // unit = (ks 0..7, bt, b, hh)
+    const int hh = u & 1, b = (u >> 1) & 31, bt = (u >> 6) & 1, ks = u >> 7;
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int feat = 16 * ks + perm16(hh, j), row = bt * 32 + b;
+      f[j] = (__bf16)(float)(((7 * feat + 3 * row) % 251) - 125);
+    }
+    *(bf16x8*)(tile + wfmt_unit(8, 0, ks, bt, b, hh)) = f;
+  }
+  __syncthreads();
+  for (int tt = 0; tt < 4; ++tt)
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 f = wfrag_read(tile, wfrag_offset(tt, t, lane));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[2048 + ((tt * 4 + t) * 64 + lane) * 8 + j] = (float)f[j];
+    }
 }
 
 }  // namespace npp
@@ -244,8 +267,8 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
   if (rc) return rc;
   if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || !sizes) { set_error("npp_train_workspace: bad Bp/ksplit"); return NPP_ERR_ARG; }
   sizes[0] = sstash_bytes(Bp);
-  sizes[1] = (int64_t)act_rows(K) * Bp * 2;
-  sizes[2] = (int64_t)kDzRows * Bp * 2;
+  sizes[1] = (int64_t)act_total_ks(K) * (Bp / kRowTile) * 2048;
+  sizes[2] = (int64_t)kDzTotalKs * (Bp / kRowTile) * 2048;
   sizes[3] = (int64_t)ksplit * make_desc(K).total_params * 4;
   return NPP_OK;
 }
@@ -256,8 +279,8 @@ int npp_selftest_mfma(void* d_scratch, void* stream) {
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, s, (float*)d_scratch);
   int rc = check_launch("npp_selftest_mfma");
   if (rc) return rc;
-  std::vector<float> out(2048);
-  hipError_t e = hipMemcpyAsync(out.data(), d_scratch, 2048 * sizeof(float), hipMemcpyDeviceToHost, s);
+  std::vector<float> out(2048 + 8192);
+  hipError_t e = hipMemcpyAsync(out.data(), d_scratch, (2048 + 8192) * sizeof(float), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) { set_error("selftest copy: %s", hipGetErrorString(e)); return NPP_ERR_LAUNCH; }
   // host model with exact integers
@@ -286,6 +309,18 @@ int npp_selftest_mfma(void* d_scratch, void* stream) {
         return NPP_ERR_SELFTEST;
       }
     }
+  for (int tt = 0; tt < 4; ++tt)
+    for (int t = 0; t < 4; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int feat = 32 * tt + (lane & 31), row = 16 * t + 8 * (lane >> 5) + j;
+          const float want = (float)(((7 * feat + 3 * row) % 251) - 125);
+          const float got = out[2048 + ((tt * 4 + t) * 64 + lane) * 8 + j];
+          if (got != want) {
+            set_error("selftest: W-format transposed read mismatch tt=%d t=%d lane=%d j=%d: got %g want %g", tt, t, lane, j, got, want);
+            return NPP_ERR_SELFTEST;
+          }
+        }
   return NPP_OK;
 }
 

@@ -87,4 +87,38 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
 
+// Workgroup barrier for LDS hand-offs that leaves global memory traffic in flight.
+// __syncthreads() makes hipcc emit s_waitcnt vmcnt(0) first, which drains every outstanding
+// stash store and weight prefetch at each of the ~30 barriers of the fused kernels (measured:
+// 54 % of wave time in SQ_WAIT_ANY).  Only LDS operations (lgkmcnt) need to have completed
+// before the other waves may read what this wave wrote; loads into registers are still
+// waited for by the compiler at their first use.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// ---- W-format operand tiles in LDS (npp_layout.h wfmt_unit) ---------------------------
+// A 16-KiB tile = 4 k-step pairs (128 features) x 2 batch tiles x 2 KiB of one 64-row
+// workgroup tile, copied linearly from global memory.  wfrag_offset() is the byte offset of
+// the first of the two ds_read_b64_tr_b16 that build, for this lane, the MFMA operand
+// fragment "feature (lane & 31) of 32-feature tile tt, batch rows 16 t + 8 (lane >> 5) + 0..7"
+// (t = 0..3 indexes the four 16-row k-steps of the 64 rows); the second read is 256 B on.
+// Lane 4q+p of each 16-lane group addresses row q, feature quad p (cdna_hip_programming.md
+// T10); within a 32-lane half the 32 addresses tile one 256-byte line: conflict-free.
+__device__ __forceinline__ int wfrag_offset(int tt, int t, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  return ((tt * 2 + (t >> 1)) * 8 + 4 * (t & 1) + 2 * h) * 256 + (g & 1) * 128 + (p & 1) * 64 + q * 16 + (p >> 1) * 8;
+}
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x8 wfrag_read(const char* tile, int off) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off + 256));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
 }  // namespace npp

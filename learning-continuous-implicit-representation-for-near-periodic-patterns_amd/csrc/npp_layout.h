@@ -150,15 +150,33 @@ NPP_HD int fwd_col(int K, int l, int ks, int h, int j) {
   }
 }
 
-// ---- training stash rows (feature-major bf16 arrays [rows][Bp]) -------------------
-// actT: a0..a7, f1, a_s, f2 (256 rows each), a_p (128 rows), then K*480 embedding slots
-constexpr int kActF1 = 8, kActAS = 9, kActF2 = 10, kActAP = 11;
-constexpr int kActEmbRow0 = 11 * kW + kW / 2;          // 2944
-NPP_HD int act_rows(int K) { return kActEmbRow0 + K * kEmbSlots; }
-// dzT: dz0..dz7, dz_f1, dz_s, dz_f2 (256 rows each), dz_p (128), dz_rgb (4 rows, 3 used)
-constexpr int kDzF1 = 8, kDzS = 9, kDzF2 = 10, kDzP = 11;
-constexpr int kDzRgbRow0 = 11 * kW + kW / 2;            // 2944
-constexpr int kDzRows = kDzRgbRow0 + 4;
+// ---- training stash for wgrad: "W-format" fragment arrays -----------------------------
+// Every layer input (actF) and every pre-activation gradient (dzF) is stored as the very
+// 16-byte fragments the fused kernels hold in registers: unit (k-step ks of 16 features,
+// batch tile bt, row b, lane-half hh) = 8 bf16 = features 16 ks + perm16(hh, 0..7) of one
+// row.  An array with NKS k-steps occupies NKS * 2 KiB per 64-row workgroup tile:
+//   [wg][ks pair][bt][8 lines of 256 B], line = [ks & 1][hh][row & 3][16 B]
+// so that (a) the two 16-byte stores a wave issues per accumulator tile fill whole 256-B
+// lines, (b) a 128-feature operand tile of one workgroup tile is ONE contiguous 16-KiB
+// chunk (linear copy into LDS), and (c) the transposed reads (ds_read_b64_tr_b16) by which
+// npp_mlp_wgrad turns rows-of-features into the batch-contiguous MFMA operands hit 64
+// distinct banks per 32-lane half.
+NPP_HD int64_t wfmt_unit(int nks, int64_t wg, int ks, int bt, int b, int hh) {
+  return ((((wg * (nks >> 1) + (ks >> 1)) * 2 + bt) * 8 + (b >> 2)) * 256) + (ks & 1) * 128 + hh * 64 + (b & 3) * 16;
+}
+// k-step offsets of the arrays inside actF / dzF (array base = offset * n_wg * 2 KiB)
+constexpr int kActF1 = 8, kActAS = 9, kActF2 = 10;          // 256-wide arrays: index * 16
+constexpr int kActKsAP = 11 * kKSAct;                        // a_p (128 wide, 8 k-steps)
+constexpr int kActKsEmb0 = kActKsAP + kKSAct / 2;            // 184: proposal p at + 30 p
+NPP_HD int act_total_ks(int K) { return kActKsEmb0 + K * kKSEmb; }
+constexpr int kDzF1 = 8, kDzS = 9, kDzF2 = 10;
+constexpr int kDzKsP = 11 * kKSAct;                          // dz_p (8 k-steps)
+constexpr int kDzKsRgb = kDzKsP + kKSAct / 2;                // dz_rgb: 2 k-steps, 3 features used
+constexpr int kDzTotalKs = kDzKsRgb + 2;
+NPP_HD int64_t wfmt_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_off * n_wg * 2048; }
+// inverse of perm16 on the 16 columns of a k-step: column c -> (hh, j)
+NPP_HD int unperm_hh(int c) { return (c >> 2) & 1; }
+NPP_HD int unperm_j(int c) { return ((c >> 3) << 2) | (c & 3); }
 // s-stash (snake derivative, bf16, fragment order): slots 0..7 = L0..L7, 8 = S (256
 // wide), 9 = P (128 wide).  Per layer [wg][nt][bt][s][64][8].
 NPP_HD int64_t sstash_off_bytes(int slot, int64_t Bp) {

@@ -2,8 +2,8 @@
 //
 // What autograd does through models/networks.py:56-95 / :145-173 and the sigmoid of
 // models/helpers.py:56, restricted to the activations: given dL/dpred it produces the
-// pre-activation gradients dz_l of every layer, feature-major in bf16 (the operand
-// layout npp_mlp_wgrad contracts over the batch).  No gradient flows to the embedding
+// pre-activation gradients dz_l of every layer as bf16 fragments in the W-format line
+// layout of npp_layout.h (what npp_mlp_wgrad copies into LDS and reads transposed).  No gradient flows to the embedding
 // inputs, so L0 and the embedding columns of L5 / S have no dgrad.
 //
 // Same transposed formulation as the forward kernel: dA^T[k][b] = W^T[k][n] dZ^T[n][b]
@@ -26,7 +26,7 @@ struct BwdArgs {
   const bf16x8* wb;
   const float* params;
   const bf16x8* sstash;
-  __bf16* dzT;
+  char* dzF;
 };
 
 struct LaneB {
@@ -68,8 +68,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
 
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
 template <bool HAS_S>
-__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const bf16x8* sst, __bf16* dz_rows,
-                                             int64_t Bp, int64_t row0, int wg, int kt0, const LaneB& L) {
+__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const bf16x8* sst, char* dz_array,
+                                             int wg, int kt0, const LaneB& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ntg = kt0 + t;
@@ -85,11 +85,11 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
         }
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (out) stsB(out, 2 * ntg + s, bt, L.lane, pack_acc(g, s));
-      __bf16* dst = dz_rows + (int64_t)(ntg * 32) * Bp + row0 + bt * 32 + L.b;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)acc_row(r, L.h) * Bp] = (__bf16)g[r];
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 f = pack_acc(g, s);
+        if (out) stsB(out, 2 * ntg + s, bt, L.lane, f);
+        *(bf16x8*)(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h)) = f;
+      }
     }
   }
 }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   const float* P = A.params;
   const int kt0 = 2 * L.wave;
   auto ss = [&](int slot) { return (const bf16x8*)((const char*)A.sstash + sstash_off_bytes(slot, Bp)); };
-  auto dzr = [&](int idx) { return A.dzT + (int64_t)idx * kW * Bp; };
+  auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, gridDim.x); };
 
   // ---- sigmoid backward (helpers.py:56): draw = dpred * pred * (1 - pred); also dz_rgb^T
   if (L.tid < kRowTile * 3) {
@@ -120,9 +120,21 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     const float pr = A.pred[(row0 + row) * 3 + c];
     const float g = A.dpred[(row0 + row) * 3 + c] * pr * (1.0f - pr);
     sDraw[L.tid] = g;
-    A.dzT[(int64_t)(kDzRgbRow0 + c) * Bp + row0 + row] = (__bf16)g;
   }
-  __syncthreads();
+  wg_barrier();
+  // dz_rgb as a 2-k-step W-format array: features 0..2 real, the rest zero
+  {
+    const int q1 = L.tid >> 7, bt = (L.tid >> 6) & 1, row = bt * 32 + L.b;
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+    if (q1 == 0 && L.h == 0) {
+      f[0] = (__bf16)sDraw[row * 3 + 0];
+      f[1] = (__bf16)sDraw[row * 3 + 1];
+      f[2] = (__bf16)sDraw[row * 3 + 2];
+    }
+    *(bf16x8*)(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h)) = f;
+  }
 
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
   //      wave w owns P's neuron tile w.  dz_p fragments -> R0 (8 k-steps), rows -> dzT.
@@ -148,13 +160,14 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
         for (int j = 0; j < 8; ++j) g[8 * s + j] *= (float)sf[j];
       }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) stsB(R0, 2 * L.wave + s, bt, L.lane, pack_acc(g, s));
-      __bf16* dst = A.dzT + (int64_t)(kDzP * kW + L.wave * 32) * Bp + row0 + bt * 32 + L.b;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)acc_row(r, L.h) * Bp] = (__bf16)g[r];
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 f = pack_acc(g, s);
+        stsB(R0, 2 * L.wave + s, bt, L.lane, f);
+        *(bf16x8*)(A.dzF + wfmt_array_base(kDzKsP, gridDim.x) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h)) = f;
+      }
     }
   }
-  __syncthreads();
+  wg_barrier();
 
   f32x16 acc[2][kNB], acc1[2][kNB];
   const bf16x8* wb = A.wb;
@@ -165,19 +178,19 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   if (MULTI) {
     zero_acc(acc);
     mma_bwd<8>(acc, R0, wb + bd.off16[BP2], kt0, L);           // df2 = dz_f2 (F2 is linear)
-    bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), Bp, row0, wg, kt0, L);
-    __syncthreads();
+    bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
+    wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
     mma_bwd<kKSAct>(acc, R1, wb + bd.off16[BF2], kt0, L);
-    bwd_epilogue<true>(acc, R0, ss(8), dzr(kDzS), Bp, row0, wg, kt0, L);
-    __syncthreads();
+    bwd_epilogue<true>(acc, R0, ss(8), dzr(kDzS), wg, kt0, L);
+    wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
     mma_bwd<kKSAct>(acc1, R0, wb + bd.off16[BS], kt0, L);
   }
-  bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), Bp, row0, wg, kt0, L);
-  __syncthreads();
+  bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), wg, kt0, L);
+  wg_barrier();
 
   // ---- F1, L7 .. L1 dgrads, ping-pong R1 -> R0 -> R1 ...; each output is multiplied by
   //      the snake derivative of the layer that produced that activation.
@@ -189,8 +202,8 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     char* out = ((v - BF1) & 1) ? R1 : R0;
     zero_acc(acc);
     mma_bwd<kKSAct>(acc, in, wb + bd.off16[v], kt0, L);
-    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, ss(out_layer), dzr(out_layer), Bp, row0, wg, kt0, L);
-    if (v != B1) __syncthreads();
+    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, ss(out_layer), dzr(out_layer), wg, kt0, L);
+    if (v != B1) wg_barrier();
   }
 }
 
@@ -204,7 +217,7 @@ extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp
   if (width != NPP_WIDTH) { set_error("npp_mlp_bwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_bwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
   if (!d_dpred || !d_pred || !d_wb || !d_params || !d_sstash || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
-  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const bf16x8*)d_sstash, (__bf16*)d_dzT};
+  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const bf16x8*)d_sstash, (char*)d_dzT};
   const NetDesc d = make_desc(K);
   const BwdDesc bd = make_bwd_desc(K);
   const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);

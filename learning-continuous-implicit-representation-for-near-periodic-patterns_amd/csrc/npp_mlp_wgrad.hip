@@ -3,17 +3,19 @@
 //
 // dW_l[n][k] = sum_b dz_l[n][b] * a_{l-1}[k][b]   (autograd of F.linear, networks.py:56-95)
 // db_l[n]    = sum_b dz_l[n][b]
-// Both operands come feature-major ([feature][row], written by npp_mlp_fwd / npp_mlp_bwd),
-// i.e. contiguous along the contraction index b: a plain "NT" GEMM with M = layer outputs,
-// N = layer inputs (or the 480 embedding slots of a proposal), K = padded batch.
-// A job = one (dz block, input block) pair; jobs are cut into 128x128 output tiles and the
+// The contraction runs over the batch.  Both operands arrive as the bf16 fragments the
+// fused forward / backward kernels hold in registers (one 16-byte unit = 8 features of one
+// row; "W-format" arrays, npp_layout.h): a 128-feature operand tile of one 64-row workgroup
+// tile is a contiguous 16-KiB chunk that is copied linearly into LDS, and the MFMA operand
+// fragments (one feature, 8 consecutive rows per lane) are produced by the hardware
+// transposing read ds_read_b64_tr_b16 -- conflict-free by construction of the line layout.
+// A job = one (dz array, input array) pair; jobs are cut into 128x128 output tiles and the
 // batch is split over gridDim.y; every (tile, split) writes its partial sums with plain
 // stores into slab `split` of the gradient buffer, in the reference's parameter layout
-// ([out][in] row-major).  npp_adam_step adds the slabs, so there are no atomics and the
-// result is bitwise reproducible.
+// ([out][in] row-major).  npp_adam_step adds the slabs: no atomics, bit-reproducible.
 //
 // Algorithmic work: 2 * sum_l n_out*n_in FLOP per batch row (embedding pad slots and the
-// 128-row padding of the 3-row rgb job are not counted).
+// padding of the 3-row rgb job are not counted).
 #include "npp_common.h"
 
 namespace npp {
@@ -26,8 +28,8 @@ constexpr int kSmemW = 4 * kWTileBytes;              // A,B double buffered = 64
 constexpr int kMaxJobs = 24;
 
 struct WJob {
-  int32_t dz_row0, m;          // rows of dzT, number of valid rows (layer outputs)
-  int32_t src_row0, n;         // rows of actT, number of valid rows (inputs / emb slots)
+  int32_t a_ks0, a_nks, m;     // dz array: k-step offset inside dzF, k-steps, valid outputs
+  int32_t b_ks0, b_nks, n;     // input array inside actF, k-steps, valid inputs / emb slots
   int32_t colmode, col0;       // 0: col = col0 + idx ; 1: col = col0 + emb_col(slot idx), pad slots skipped
   int32_t ld, bias_on;         // reference row stride (n_in) ; 1 = this job also produces db
   int64_t w_off, b_off;        // float offsets in the parameter blob
@@ -35,16 +37,14 @@ struct WJob {
 };
 
 struct WArgs {
-  const __bf16* dzT;
-  const __bf16* actT;
-  int64_t Bp;
+  const char* dzF;
+  const char* actF;
+  int64_t n_wg;                // 64-row workgroup tiles in the batch (Bp / 64)
   float* gslabs;
   int64_t slab_stride;
-  int32_t njobs, kchunk;
+  int32_t njobs, wg_chunk;     // workgroup tiles per split
   WJob jobs[kMaxJobs];
 };
-
-__device__ __forceinline__ uint32_t swz(int row, int ch) { return (uint32_t)(row * 128 + ((ch ^ (row & 7)) << 4)); }
 
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,12 +61,16 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     if (j < A.njobs && (int)blockIdx.x >= A.jobs[j].tile0) J = A.jobs[j];
   const int t_local = blockIdx.x - J.tile0;
   const int tm = t_local / J.tiles_n, tn = t_local - tm * J.tiles_n;
-  const int m_valid = min(kWT, J.m - tm * kWT), n_valid = min(kWT, J.n - tn * kWT);
-  const int64_t Bp = A.Bp;
-  const int64_t k_begin = (int64_t)blockIdx.y * A.kchunk;
-  const int64_t k_end = min(Bp, k_begin + (int64_t)A.kchunk);
-  const __bf16* gA = A.dzT + (int64_t)(J.dz_row0 + tm * kWT) * Bp;
-  const __bf16* gB = A.actT + (int64_t)(J.src_row0 + tn * kWT) * Bp;
+  // operand tiles: 4 k-step pairs (128 features); fewer are valid at the array's end
+  const int a_pairs = min(4, (J.a_nks >> 1) - tm * 4), b_pairs = min(4, (J.b_nks >> 1) - tn * 4);
+  const int a_bytes = a_pairs * 4096, b_bytes = b_pairs * 4096;
+  const int64_t n_wg = A.n_wg;
+  const int64_t wg_begin = (int64_t)blockIdx.y * A.wg_chunk;
+  const int64_t wg_end = min(n_wg, wg_begin + (int64_t)A.wg_chunk);
+  // byte address of (workgroup tile g, pair p) inside an array: ((g * nks/2 + p) * 2) * 2048
+  const char* gA = A.dzF + wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * 4 * 4096;
+  const char* gB = A.actF + wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * 4 * 4096;
+  const int64_t a_stride = (int64_t)J.a_nks * 2048, b_stride = (int64_t)J.b_nks * 2048;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -78,15 +82,15 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   float bsum[2] = {0.0f, 0.0f};
   const bool do_bias = J.bias_on && tn == 0 && wn == 0;
 
-  // staging: 1024 16-byte chunks per operand tile, 4 per thread
+  // staging: 1024 16-byte units per operand tile, 4 per thread, linear copy
   u32x4 ra[4], rb[4];
-  auto gload = [&](int64_t k0) {
+  auto gload = [&](int64_t g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int id = tid + kWThreads * i, row = id >> 3, ch = id & 7;
+      const int off = (tid + kWThreads * i) * 16;
       const u32x4 z = {0u, 0u, 0u, 0u};
-      ra[i] = row < m_valid ? *(const u32x4*)(gA + (int64_t)row * Bp + k0 + ch * 8) : z;
-      rb[i] = row < n_valid ? *(const u32x4*)(gB + (int64_t)row * Bp + k0 + ch * 8) : z;
+      ra[i] = off < a_bytes ? *(const u32x4*)(gA + g * a_stride + off) : z;
+      rb[i] = off < b_bytes ? *(const u32x4*)(gB + g * b_stride + off) : z;
     }
   };
   auto sstore = [&](int buf) {
@@ -94,30 +98,39 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     char* sB = sA + kWTileBytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int id = tid + kWThreads * i, row = id >> 3, ch = id & 7;
-      *(u32x4*)(sA + swz(row, ch)) = ra[i];
-      *(u32x4*)(sB + swz(row, ch)) = rb[i];
+      const int off = (tid + kWThreads * i) * 16;
+      *(u32x4*)(sA + off) = ra[i];
+      *(u32x4*)(sB + off) = rb[i];
     }
   };
+  // per-lane fragment offsets: feature tile (wm|wn)*2 + i, k-step t (4 per workgroup tile)
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    offA[i] = wfrag_offset(wm * 2 + i, 0, lane);
+    offB[i] = wfrag_offset(wn * 2 + i, 0, lane);
+  }
 
   int buf = 0;
-  if (k_begin < k_end) {
-    gload(k_begin);
+  if (wg_begin < wg_end) {
+    gload(wg_begin);
     sstore(0);
   }
-  __syncthreads();
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += kWBK) {
-    const bool has_next = k0 + kWBK < k_end;
-    if (has_next) gload(k0 + kWBK);
+  wg_barrier();
+  for (int64_t g = wg_begin; g < wg_end; ++g) {
+    const bool has_next = g + 1 < wg_end;
+    if (has_next) gload(g + 1);
     const char* sA = smem + buf * 2 * kWTileBytes;
     const char* sB = sA + kWTileBytes;
 #pragma unroll
-    for (int ks = 0; ks < kWBK / 16; ++ks) {
+    for (int t = 0; t < 4; ++t) {
+      // wfrag_offset(tt, t, lane) - wfrag_offset(tt, 0, lane) = (t>>1)*2048 + (t&1)*1024
+      const int dt = (t >> 1) * 2048 + (t & 1) * 1024;
       bf16x8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[i] = *(const bf16x8*)(sA + swz(wm * 64 + i * 32 + m_l, ks * 2 + h));
-        b[i] = *(const bf16x8*)(sB + swz(wn * 64 + i * 32 + m_l, ks * 2 + h));
+        a[i] = wfrag_read(sA, offA[i] + dt);
+        b[i] = wfrag_read(sB, offB[i] + dt);
       }
       if (do_bias) {
 #pragma unroll
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
     }
     if (has_next) sstore(buf ^ 1);
-    __syncthreads();
+    wg_barrier();
     buf ^= 1;
   }
 
@@ -144,7 +157,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     if (n_idx < J.n) {
       if (J.colmode == 0) col = J.col0 + n_idx;
       else {
-        const int c = emb_col(n_idx >> 4, (n_idx >> 3) & 1, n_idx & 7);
+        // column c of k-step ks is element unperm_j(c) of lane-half unperm_hh(c) (perm16 order)
+        const int c16 = n_idx & 15;
+        const int c = emb_col(n_idx >> 4, unperm_hh(c16), unperm_j(c16));
         col = c < 0 ? -1 : J.col0 + c;
       }
     }
@@ -171,10 +186,10 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 static int build_jobs(int K, WArgs& A) {
   const NetDesc d = make_desc(K);
   int nj = 0, tile = 0;
-  auto add = [&](int layer, int dz_row0, int src_row0, int n, int colmode, int col0, int bias_on) {
+  auto add = [&](int layer, int a_ks0, int a_nks, int b_ks0, int b_nks, int n, int colmode, int col0, int bias_on) {
     WJob& j = A.jobs[nj++];
-    j.dz_row0 = dz_row0; j.m = d.n_out[layer];
-    j.src_row0 = src_row0; j.n = n;
+    j.a_ks0 = a_ks0; j.a_nks = a_nks; j.m = d.n_out[layer];
+    j.b_ks0 = b_ks0; j.b_nks = b_nks; j.n = n;
     j.colmode = colmode; j.col0 = col0;
     j.ld = d.n_in[layer]; j.bias_on = bias_on;
     j.w_off = d.w_off[layer]; j.b_off = d.b_off[layer];
@@ -182,24 +197,30 @@ static int build_jobs(int K, WArgs& A) {
     j.tiles_n = (n + kWT - 1) / kWT;
     tile += ((j.m + kWT - 1) / kWT) * j.tiles_n;
   };
-  const int emb0 = kActEmbRow0;
-  add(L0, 0 * kW, emb0, kEmbSlots, 1, 0, 1);
-  for (int l = L1; l <= L4; ++l) add(l, l * kW, (l - 1) * kW, kW, 0, 0, 1);
-  add(L5, 5 * kW, emb0, kEmbSlots, 1, 0, 1);
-  add(L5, 5 * kW, 4 * kW, kW, 0, kE, 0);
-  add(L6, 6 * kW, 5 * kW, kW, 0, 0, 1);
-  add(L7, 7 * kW, 6 * kW, kW, 0, 0, 1);
-  add(LF1, kDzF1 * kW, 7 * kW, kW, 0, 0, 1);
+  const int A16 = kKSAct;
+  auto act = [&](int layer, int dz_idx, int src_idx, int col0, int bias_on) {
+    add(layer, dz_idx * A16, A16, src_idx * A16, A16, kW, 0, col0, bias_on);
+  };
+  auto emb = [&](int layer, int dz_idx, int p, int col0, int bias_on) {
+    add(layer, dz_idx * A16, A16, kActKsEmb0 + p * kKSEmb, kKSEmb, kEmbSlots, 1, col0, bias_on);
+  };
+  emb(L0, 0, 0, 0, 1);
+  for (int l = L1; l <= L4; ++l) act(l, l, l - 1, 0, 1);
+  emb(L5, 5, 0, 0, 1);
+  act(L5, 5, 4, kE, 0);
+  act(L6, 6, 5, 0, 1);
+  act(L7, 7, 6, 0, 1);
+  act(LF1, kDzF1, 7, 0, 1);
   if (K > 1) {
-    add(LS, kDzS * kW, kActF1 * kW, kW, 0, 0, 1);
-    for (int p = 1; p < K; ++p) add(LS, kDzS * kW, emb0 + p * kEmbSlots, kEmbSlots, 1, kW + (p - 1) * kE, 0);
-    add(LF2, kDzF2 * kW, kActAS * kW, kW, 0, 0, 1);
-    add(LP, kDzP * kW, kActF1 * kW, kW, 0, 0, 1);
-    add(LP, kDzP * kW, kActF2 * kW, kW, 0, kW, 0);
+    act(LS, kDzS, kActF1, 0, 1);
+    for (int p = 1; p < K; ++p) emb(LS, kDzS, p, kW + (p - 1) * kE, 0);
+    act(LF2, kDzF2, kActAS, 0, 1);
+    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1);
+    add(LP, kDzKsP, A16 / 2, kActF2 * A16, A16, kW, 0, kW, 0);
   } else {
-    add(LP, kDzP * kW, kActF1 * kW, kW, 0, 0, 1);
+    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1);
   }
-  add(LRGB, kDzRgbRow0, kActAP * kW, kW / 2, 0, 0, 1);
+  add(LRGB, kDzKsRgb, 2, kActKsAP, A16 / 2, kW / 2, 0, 0, 1);
   A.njobs = nj;
   return tile;
 }
@@ -215,14 +236,13 @@ extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, 
   if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || ksplit > 64) { set_error("npp_mlp_wgrad: bad Bp=%lld / ksplit=%d", (long long)Bp, ksplit); return NPP_ERR_ARG; }
   if (!d_dzT || !d_actT || !d_gslabs) { set_error("npp_mlp_wgrad: null pointer"); return NPP_ERR_ARG; }
   WArgs A{};
-  A.dzT = (const __bf16*)d_dzT;
-  A.actT = (const __bf16*)d_actT;
-  A.Bp = Bp;
+  A.dzF = (const char*)d_dzT;
+  A.actF = (const char*)d_actT;
+  A.n_wg = Bp / kRowTile;
   A.gslabs = d_gslabs;
   A.slab_stride = make_desc(K).total_params;
   const int ntiles = build_jobs(K, A);
-  const int64_t steps = Bp / kWBK;
-  A.kchunk = (int)(((steps + ksplit - 1) / ksplit) * kWBK);
+  A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t ea = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemW);
