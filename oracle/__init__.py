@@ -13,3 +13,4 @@ reference loads torchvision pretrained weights that are not under
 ``/root/reference`` and no reference test pins their outputs.
 """
 from .npp_oracle import *  # noqa: F401,F403
+from .npp_patch_oracle import *  # noqa: F401,F403

@@ -1,0 +1,259 @@
+"""NumPy restatement of the patch-loss half of the path: integer glimpse crops, the
+periodicity-guided GridPatchSampler, the contextual-loss core and the LPIPS head.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned by tests/golden/g5-g7.
+
+The VGG16/VGG19 trunks are NOT restated: torchvision's pretrained weights are not part of
+/root/reference, so parity for CX / LPIPS is stated from the feature tensors onward
+("parity unpinned for the VGG trunks").
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .npp_oracle import F32, adaptive_params, robust_nll, robust_nll_grads, load_partition_spline
+
+__all__ = ["extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
+           "lpips_head", "lpips_head_grads", "scaling_layer"]
+
+
+# --------------------------------------------------------------------------
+# a9: utils/extract_glimpse.py:7-79 with mode='nearest', padding 'zeros',
+# normalized=False, centered=False, as models/sampler.py:171-178,284-291 calls it
+# --------------------------------------------------------------------------
+def extract_glimpse_int(img_chw, centres_yx, P):
+    """img (C,H,W); centres (M,2) (row, col) -> (M,C,P,P).  The reference passes offsets as
+    (x, y) and samples pixel index  c - P/2 + j  (grid_sample align_corners=False turns the
+    half-pixel offset of xs = arange(w) - (w-1)/2 into an exact integer for even P);
+    out-of-image samples are zero."""
+    img = np.asarray(img_chw, dtype=F32)
+    C, H, W = img.shape
+    cen = np.rint(np.asarray(centres_yx, dtype=np.float64)).astype(np.int64)
+    out = np.zeros((cen.shape[0], C, P, P), dtype=F32)
+    for m, (cy, cx) in enumerate(cen):
+        y0, x0 = cy - P // 2, cx - P // 2
+        ys, xs = np.arange(y0, y0 + P), np.arange(x0, x0 + P)
+        oy, ox = np.nonzero((ys >= 0) & (ys < H))[0], np.nonzero((xs >= 0) & (xs < W))[0]
+        if oy.size and ox.size:
+            out[m][:, oy[:, None], ox[None, :]] = img[:, ys[oy][:, None], xs[ox][None, :]]
+    return out
+
+
+class GridPatchSamplerOracle:
+    """models/sampler.py:8-354, periodicity-guided mode (no_reg_sampling=False), literal
+    restatement: every candidate is cropped and its unknown pixels counted, like the
+    reference does.  RNG: the NumPy RandomState passed in (the reference uses the global
+    np.random; same MT19937 stream for the same seed), same call order."""
+
+    def __init__(self, img_hw3, mask_hw1, N_samples, patch_size, pool_train, pool_val, selected_shifts, rng):
+        self.img = np.transpose(np.asarray(img_hw3, F32), (2, 0, 1))        # sampler.py:29 permute
+        self.mask = np.transpose(np.asarray(mask_hw1, F32), (2, 0, 1))
+        self.H, self.W = self.img.shape[1:]
+        s = selected_shifts[0]                                               # top-1 only (:32)
+        self.shifts = [np.array([sh[1], sh[0]], np.float64) for sh in s]     # (dy, dx) (:35)
+        self.rng = rng
+        self.reset_patchsize(patch_size, N_samples)
+        self.reset_pool(pool_train, pool_val)
+
+    def reset_patchsize(self, patch_size, N_samples):
+        self.N = int(N_samples)
+        self.P = int(patch_size)
+        self.half = self.P // 2
+        a, b = np.meshgrid(np.arange(-10, 10), np.arange(-10, 10), indexing="ij")   # :90-93
+        self.perm_a, self.perm_b = a.reshape(-1), b.reshape(-1)
+        self.perm_dist = (np.abs(a) + np.abs(b)).reshape(-1)
+
+    def reset_pool(self, pool_train, pool_val):
+        def valid(pool):                                                     # :110-121
+            pool = np.asarray(pool)
+            h = self.half
+            ok = (pool[:, 0] > h) & (pool[:, 0] < self.H - (h + 1)) & (pool[:, 1] > h) & (pool[:, 1] < self.W - (h + 1))
+            return pool[ok]
+        self.pool_train, self.pool_val = valid(pool_train), valid(pool_val)
+
+    def sample_patch_fake(self, mode):                                       # :242-293
+        pool = self.pool_train if mode == "train" else self.pool_val
+        sel = self.rng.choice(pool.shape[0], size=[self.N], replace=False)
+        cen = pool[sel].astype(np.int64)
+        h = self.half
+        grids = np.stack([np.stack(np.meshgrid(np.arange(c[0] - h, c[0] + h), np.arange(c[1] - h, c[1] + h),
+                                               indexing="ij"), -1) for c in cen])
+        return (extract_glimpse_int(self.img, cen, 2 * h), extract_glimpse_int(self.mask, cen, 2 * h), grids, cen)
+
+    def sample_patch_real(self, centres, topk, invalid_ratio):               # :127-237
+        P2 = 2 * self.half
+        imgs, masks, weights, chosen_d = [], [], [], []
+        topk_min = topk
+        for i in range(self.N):
+            cand = centres[i][None].astype(np.float64) + self.perm_a[:, None] * self.shifts[0][None] \
+                + self.perm_b[:, None] * self.shifts[1][None]
+            ok = (cand[:, 0] > 0) & (cand[:, 0] < self.H - 1) & (cand[:, 1] > 0) & (cand[:, 1] < self.W - 1)
+            cand, dist = cand[ok], self.perm_dist[ok].astype(np.float64)
+            m = extract_glimpse_int(self.mask, cand, P2)
+            good = ~((m < 0.5).sum(axis=(1, 2, 3)) > P2 * P2 * invalid_ratio)     # :181
+            cand, dist = cand[good], dist[good]
+            dist = dist.copy()
+            dist[dist == 0] = 10000                                           # exclude itself (:197)
+            if min(len(dist) - 1, topk) < topk_min:
+                topk_min = min(len(dist) - 1, topk)
+                if topk_min <= 0:
+                    return None, None, None, 0, None
+            order = np.argsort(dist, kind="stable")[:topk_min]                # torch.topk(largest=False)
+            d = dist[order]
+            inv = 1.0 / d
+            weights.append((inv / inv.sum()).astype(F32))
+            imgs.append(extract_glimpse_int(self.img, cand[order], P2))
+            masks.append(extract_glimpse_int(self.mask, cand[order], P2))
+            chosen_d.append(d)
+        if topk_min < topk:                                                   # :213-217
+            weights = [w[:topk_min] for w in weights]
+            imgs = [x[:topk_min] for x in imgs]
+            masks = [x[:topk_min] for x in masks]
+            chosen_d = [d[:topk_min] for d in chosen_d]
+        real = np.transpose(np.stack(imgs), (0, 1, 3, 4, 2))                  # (N,k,P,P,3) (:234)
+        rmask = np.transpose(np.stack(masks), (0, 1, 3, 4, 2))
+        return real, rmask, np.concatenate(weights), topk_min, np.stack(chosen_d)
+
+    def sample_patches(self, topk, invalid_ratio):                            # :297-354
+        prob = self.rng.uniform(0, 1)
+        dists = None
+        if prob < 0.5:
+            mode = "val"
+        elif 0.5 < prob < 0.8:
+            mode = "train"
+        else:
+            mode = "same"
+        fake, fmask, grids, cen = self.sample_patch_fake("val" if mode == "val" else "train")
+        if mode == "same":
+            real = np.transpose(fake, (0, 2, 3, 1))[:, None]
+            rmask = np.transpose(fmask, (0, 2, 3, 1))[:, None]
+            k, w = 1, np.ones(self.N, F32)
+        else:
+            real, rmask, w, k, dists = self.sample_patch_real(cen, topk, invalid_ratio)
+        if k == 0:
+            return dict(k=0, mode=mode)
+        fake = np.tile(fake[:, None], (1, k, 1, 1, 1))
+        fmask = np.tile(fmask[:, None], (1, k, 1, 1, 1))
+        return dict(real=real, real_mask=rmask, fake=fake, fake_mask=fmask, coords=grids, mode=mode, k=k, weight=w,
+                    centres=cen, dists=dists)
+
+
+# --------------------------------------------------------------------------
+# a12: contextual_loss/functional.py:9-63,127-163 (loss_type 'cosine')
+# --------------------------------------------------------------------------
+def _cx_common(x, y, band_width):
+    x = np.asarray(x, F32)
+    y = np.asarray(y, F32)
+    N, C = x.shape[:2]
+    mu = y.mean(axis=(0, 2, 3), keepdims=True, dtype=np.float64).astype(F32)      # :141
+    xc = (x - mu).reshape(N, C, -1)
+    yc = (y - mu).reshape(N, C, -1)
+    nx = np.maximum(np.sqrt((xc * xc).sum(1, keepdims=True)), F32(1e-12))          # F.normalize eps
+    ny = np.maximum(np.sqrt((yc * yc).sum(1, keepdims=True)), F32(1e-12))
+    xh, yh = xc / nx, yc / ny
+    raw = np.einsum("nci,ncj->nij", xh, yh).astype(F32)                            # bmm (:154)
+    S = np.clip(raw, 0, 1)
+    D = F32(1) - S
+    dmin = D.min(axis=2, keepdims=True)                                            # :134
+    jmin = D.argmin(axis=2)
+    Dt = D / (dmin + F32(1e-5))
+    w = np.exp((F32(1) - Dt) / F32(band_width))                                    # :128
+    s = w.sum(axis=2, keepdims=True)
+    cx = w / s
+    return dict(N=N, C=C, xh=xh, yh=yh, nx=nx, raw=raw, D=D, dmin=dmin, jmin=jmin, Dt=Dt, w=w, s=s, cx=cx)
+
+
+def cx_forward(x, y, band_width=0.5, weight=None):
+    t = _cx_common(x, y, band_width)
+    cxn = t["cx"].max(axis=1).mean(axis=1)                                         # max over i, mean over j (:53)
+    if weight is not None:
+        return F32(np.sum(-np.log(cxn * np.asarray(weight, F32) + F32(1e-5))))
+    return F32(np.mean(-np.log(cxn + F32(1e-5))))
+
+
+def cx_backward(x, y, band_width=0.5, weight=None):
+    """(loss, dL/dx) by the closed form derived in DESIGN.md section 7: the loss only sees
+    cx at the per-column arg-max rows, so dL/dcx is one entry per column."""
+    t = _cx_common(x, y, band_width)
+    N, C = t["N"], t["C"]
+    cx, w, s, D, dmin, jmin, Dt = t["cx"], t["w"], t["s"], t["D"], t["dmin"], t["jmin"], t["Dt"]
+    I, J = cx.shape[1:]
+    istar = cx.argmax(axis=1)                          # (N,J)
+    cmax = np.take_along_axis(cx, istar[:, None, :], 1)[:, 0, :]
+    cxn = cmax.mean(axis=1)
+    if weight is not None:
+        wt = np.asarray(weight, F32)
+        loss = F32(np.sum(-np.log(cxn * wt + F32(1e-5))))
+        dcxn = -wt / (cxn * wt + F32(1e-5))
+    else:
+        loss = F32(np.mean(-np.log(cxn + F32(1e-5))))
+        dcxn = -(F32(1) / N) / (cxn + F32(1e-5))
+    G = np.zeros_like(cx)
+    gj = (dcxn / J)[:, None] * np.ones((N, J), F32)
+    np.put_along_axis(G, istar[:, None, :], gj[:, None, :], 1)
+    A = (G * cx).sum(axis=2, keepdims=True)
+    dw = (G - A) / s
+    dDt = dw * (-w / F32(band_width))
+    dD = dDt / (dmin + F32(1e-5))
+    corr = -(dDt * D).sum(axis=2) / ((dmin[..., 0] + F32(1e-5)) ** 2)             # flows to arg-min of each row
+    np.add.at(dD, (np.arange(N)[:, None], np.arange(I)[None, :], jmin), corr)
+    raw = t["raw"]
+    draw = np.where((raw >= 0) & (raw <= 1), -dD, F32(0))                          # clamp + (1 - s)
+    dxh = np.einsum("nij,ncj->nci", draw, t["yh"]).astype(F32)
+    xh, nx = t["xh"], t["nx"]
+    dxc = (dxh - xh * (xh * dxh).sum(1, keepdims=True)) / nx
+    return loss, dxc.reshape(np.asarray(x).shape).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# a13: externel_lib/lpips/lpips.py:92-133 (+ :136-154, __init__.py:42-44)
+# --------------------------------------------------------------------------
+def scaling_layer(x):
+    """lpips.py:136-143 on an input already mapped to [-1,1] (normalize=True, :93-95)."""
+    shift = np.array([-.030, -.088, -.188], F32)[None, :, None, None]
+    scale = np.array([.458, .448, .450], F32)[None, :, None, None]
+    return ((np.asarray(x, F32) - shift) / scale).astype(F32)
+
+
+def normalize_tensor(f, eps=1e-10):
+    f = np.asarray(f, F32)
+    nrm = np.sqrt((f * f).sum(axis=1, keepdims=True))
+    return f / (nrm + F32(eps)), nrm
+
+
+def lpips_head(feats0, feats1, lins, latents_alpha, latents_scale):
+    """use_robust=True head: per layer channel-unit-normalise, per-channel robust NLL of the
+    difference, 1x1 lin conv, spatial mean; sum over layers -> (N,).  mean() of it is the loss
+    (NPP_completion/train.py:249)."""
+    val = 0
+    for f0, f1, lin, la, ls in zip(feats0, feats1, lins, latents_alpha, latents_scale):
+        h0, _ = normalize_tensor(f0)
+        h1, _ = normalize_tensor(f1)
+        N, C, H, W = h0.shape
+        d = (h0 - h1).transpose(0, 2, 3, 1).reshape(-1, C)
+        alpha, scale, _, _ = adaptive_params(la, ls)
+        nll = robust_nll(d, alpha, scale).reshape(N, H, W, C)
+        val = val + (nll * np.asarray(lin, F32)[None, None, None, :]).sum(-1).mean(axis=(1, 2))
+    return val.astype(F32)
+
+
+def lpips_head_grads(feats0, feats1, lins, latents_alpha, latents_scale):
+    """loss = mean_n val_n; returns (loss, [dL/df0_k], [dL/dlatent_alpha_k], [dL/dlatent_scale_k])."""
+    val = lpips_head(feats0, feats1, lins, latents_alpha, latents_scale)
+    loss = F32(val.mean())
+    dfs, dlas, dlss = [], [], []
+    for f0, f1, lin, la, ls in zip(feats0, feats1, lins, latents_alpha, latents_scale):
+        h0, n0 = normalize_tensor(f0)
+        h1, _ = normalize_tensor(f1)
+        N, C, H, W = h0.shape
+        d = (h0 - h1).transpose(0, 2, 3, 1).reshape(-1, C)
+        alpha, scale, dalpha, dscale = adaptive_params(la, ls)
+        dx, da, dc = robust_nll_grads(d, alpha, scale)
+        coef = np.asarray(lin, F32)[None, :] / F32(N * H * W)
+        dd = (dx * coef).reshape(N, H, W, C).transpose(0, 3, 1, 2)                # dL/dh0
+        f0 = np.asarray(f0, F32)
+        se = n0 + F32(1e-10)
+        df = dd / se - f0 * (dd * f0).sum(1, keepdims=True) / (np.maximum(n0, F32(1e-30)) * se * se)
+        dfs.append(df.astype(F32))
+        dlas.append(((da * coef).sum(0, keepdims=True, dtype=np.float64) * dalpha).astype(F32))
+        dlss.append(((dc * coef).sum(0, keepdims=True, dtype=np.float64) * dscale).astype(F32))
+    return loss, dfs, dlas, dlss
