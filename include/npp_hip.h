@@ -142,6 +142,36 @@ int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int
                   int n_slabs, int64_t slab_stride, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
 
+/* ---- a9/a10: patch crops ---------------------------------------------------- */
+/* Replaces extract_glimpse(..., mode='nearest', padding_mode='zeros', normalized=False,
+ * centered=False) as models/sampler.py:171-178,284-291 calls it (utils/extract_glimpse.py:
+ * 53-79): integer crops [c - P/2, c + P/2) of the (H,W,3) image and (H,W) mask at M centres
+ * (row, col), zeros outside.  out_rgb (M,3,P,P), out_mask (M,1,P,P) or NULL. */
+int npp_patch_gather(const float* d_img_hwc, const float* d_mask_hw, int H, int W,
+                     const int32_t* d_centres_yx, int M, int P, float* d_out_rgb,
+                     float* d_out_mask, void* stream);
+
+/* ---- a12: contextual loss core ------------------------------------------------ */
+/* Replaces contextual_loss(x, y, band_width, weight, 'cosine') and its backward w.r.t. x
+ * (externel_lib/contextual_loss/functional.py:9-63,127-163) on feature tensors (N,C,h*w) fp32
+ * NCHW (C a multiple of 32).  d_loss[0] += scale * loss ; d_dfx (N,C,hw) = scale * dL/dx or
+ * NULL for forward only.  d_weight: per-sample weights (functional.py:55-57) or NULL. */
+int64_t npp_cx_workspace_bytes(int N, int C, int hw);
+int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
+                   const float* d_weight, float scale, float* d_loss, float* d_dfx,
+                   void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- a13: LPIPS head (adaptive-robust variant), one VGG16 tap per call --------- */
+/* Replaces, for tap kk, lpips.py:99-121 + :130 (normalize_tensor, per-channel robust NLL of
+ * the difference, lin 1x1 conv, spatial mean) and its backward.  feats (N,C,hw) fp32 NCHW;
+ * d_latents [alpha(C) | scale(C)]; d_loss[0] += scale * mean_n(...); d_df0 (N,C,hw) and
+ * d_dlatent [2C] (accumulated) may both be NULL for forward only. */
+int64_t npp_lpips_workspace_bytes(int C);
+int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
+                    const float* d_lin, const float* d_latents, const float* d_spline,
+                    int n_knots, float x_scale, float scale, float* d_loss, float* d_df0,
+                    float* d_dlatent, void* d_workspace, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 /* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the
  * accumulator-as-next-operand chain) with exact integer data.  d_scratch >= 1 MiB. */

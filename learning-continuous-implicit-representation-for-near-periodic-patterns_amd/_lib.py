@@ -64,6 +64,11 @@ SYMBOLS = {
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "npp_cx_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "npp_cx_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),
+    "npp_lpips_workspace_bytes": (_i64, [_i32]),
+    "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
 }
 

@@ -13,45 +13,6 @@
 
 namespace npp {
 
-struct ChanParams {   // per-channel quantities derived from the latents
-  float alpha, c, beta, logc_plus_logz, dlogz, dalpha_dl, dc_dl;
-};
-
-__device__ inline ChanParams chan_params(float latent_alpha, float latent_scale, const float* spline,
-                                         int n_knots, float x_scale) {
-  ChanParams p;
-  // adaptive.py:146-164 + util.py:64-72: alpha = sigmoid(l)*(hi-lo)+lo, lo=.001, hi=1.999
-  const float sg = 1.0f / (1.0f + expf(-latent_alpha));
-  p.alpha = sg * (1.999f - 0.001f) + 0.001f;
-  p.dalpha_dl = sg * (1.0f - sg) * (1.999f - 0.001f);
-  // adaptive.py:166-181 + util.py:86-95: c = (1-1e-5)*softplus(l + log(e-1)) + 1e-5
-  const float xs = latent_scale + 0.54132485f;   // log(expm1(1))
-  const float sp = xs > 20.0f ? xs : log1pf(expf(xs));
-  p.c = (1.0f - 1e-5f) * sp + 1e-5f;
-  p.dc_dl = (1.0f - 1e-5f) / (1.0f + expf(-xs));
-  p.beta = fmaxf(1.1920929e-07f, fabsf(p.alpha - 2.0f));
-  // distribution.py:90-114 partition_spline_curve (alpha < 4 branch)
-  const float den = fabsf(p.alpha - 2.0f) + 0.25f;
-  const float xc = (2.25f * p.alpha - 4.5f) / den + p.alpha + 2.0f;
-  const float dxc = 0.5625f / (den * den) + 1.0f;
-  // cubic_spline.py:65-97
-  const float xq = xc * x_scale;
-  const float* vals = spline;
-  const float* tans = spline + n_knots;
-  const int lo = (int)floorf(fminf(fmaxf(xq, 0.0f), (float)(n_knots - 2)));
-  const float t = xq - (float)lo, t2 = t * t, t3 = t * t2;
-  const float h01 = -2.0f * t3 + 3.0f * t2, h00 = 1.0f - h01, h11 = t3 - t2, h10 = h11 - t2 + t;
-  const float v0 = vals[lo], v1 = vals[lo + 1], m0 = tans[lo], m1 = tans[lo + 1];
-  float val = v0 * h00 + v1 * h01 + m0 * h10 + m1 * h11;
-  const float dh01 = -6.0f * t2 + 6.0f * t, dh11 = 3.0f * t2 - 2.0f * t, dh10 = dh11 - 2.0f * t + 1.0f;
-  float dval = (v1 - v0) * dh01 + m0 * dh10 + m1 * dh11;
-  if (t < 0.0f) { val = tans[0] * t + vals[0]; dval = tans[0]; }
-  else if (t > 1.0f) { val = tans[n_knots - 1] * (t - 1.0f) + vals[n_knots - 1]; dval = tans[n_knots - 1]; }
-  p.logc_plus_logz = logf(p.c) + val;
-  p.dlogz = dval * x_scale * dxc;
-  return p;
-}
-
 // One thread per row (3 channels), grid-stride; block reduction via wave shuffles, then
 // one atomicAdd per block per output (7 floats).
 __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ pred,

@@ -1,0 +1,114 @@
+// npp_lpips.hip -- K7: LPIPS head with the reference's adaptive-robust modification, forward
+// and backward, one call per VGG16 tap.
+//
+// Replaces, from the feature tensors onward, LPIPS.forward(in0, in1, use_robust=True,
+// normalize=True) (externel_lib/lpips/lpips.py:92-133): normalize_tensor (lpips/__init__.py:
+// 42-44, eps 1e-10) -> per-channel AdaptiveLossFunction(num_dims=C).lossfun on the difference
+// (:57-61, :103-107) -> NetLinLayer 1x1 conv with the vendored non-negative weights (:146-154,
+// dropout inactive in eval) -> spatial_average (:16-17) -> sum over taps; the caller's
+// torch.mean over the batch (NPP_completion/train.py:249) is folded into `scale`.
+// Backward: d/d feats0 (through the channel normalisation) and d/d latents (per channel).
+#include "npp_common.h"
+
+namespace npp {
+
+__global__ void lpips_chan_kernel(const float* __restrict__ latents, int C, const float* __restrict__ spline,
+                                  int n_knots, float x_scale, ChanParams* __restrict__ cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) cp[c] = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
+}
+
+// one thread per (n, position); feats are NCHW so a wave reads 64 consecutive positions of one
+// channel per load.  Pass 1: channel norms.  Pass 2: robust NLL of the normalised difference,
+// its derivative (staged in df0), per-channel latent gradients by wave reduction + one atomic
+// per wave and channel.  Pass 3: normalisation backward.
+__global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                          int N, int C, int hw, const float* __restrict__ lin,
+                                                          const ChanParams* __restrict__ cp, float coef,
+                                                          float* __restrict__ loss, float* __restrict__ df0,
+                                                          float* __restrict__ dlatent) {
+  __shared__ float red[4];
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < (int64_t)N * hw;
+  const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
+  const float* a0 = f0 + (int64_t)n * C * hw + p;
+  const float* a1 = f1 + (int64_t)n * C * hw + p;
+  float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (live)
+    for (int c = 0; c < C; ++c) {
+      const float u = a0[(int64_t)c * hw], v = a1[(int64_t)c * hw];
+      s0 = fmaf(u, u, s0);
+      s1 = fmaf(v, v, s1);
+    }
+  const float n0 = sqrtf(s0), n1 = sqrtf(s1);
+  const float i0 = 1.0f / (n0 + 1e-10f), i1 = 1.0f / (n1 + 1e-10f);
+  float val = 0.0f, dot = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const ChanParams P = cp[c];
+    const float l = lin[c];
+    float da = 0.0f, dc = 0.0f;
+    if (live) {
+      const float u = a0[(int64_t)c * hw];
+      const float x = u * i0 - a1[(int64_t)c * hw] * i1;
+      const float xs = x / P.c, ssx = xs * xs;
+      const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
+      const float ue = expf(e * lnu), ue1 = ue / uu;
+      val += l * ((P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz);
+      if (g0) {
+        const float dd = l * coef * (x / (P.c * P.c)) * ue1;          // dL/d(normalised f0)_c
+        g0[(int64_t)c * hw] = dd;
+        dot = fmaf(dd, u, dot);
+        da = l * coef * (-(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) +
+                         (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz);
+        dc = l * coef * (-(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c);
+      }
+    }
+    if (g0) {                                                          // uniform branch
+      for (int off = 32; off > 0; off >>= 1) {
+        da += __shfl_xor(da, off, 64);
+        dc += __shfl_xor(dc, off, 64);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(dlatent + c, da * P.dalpha_dl);
+        atomicAdd(dlatent + C + c, dc * P.dc_dl);
+      }
+    }
+  }
+  if (g0 && live) {
+    const float se = n0 + 1e-10f;
+    const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
+    for (int c = 0; c < C; ++c) {
+      const float dd = g0[(int64_t)c * hw];
+      g0[(int64_t)c * hw] = dd * i0 - a0[(int64_t)c * hw] * k;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, coef * (red[0] + red[1] + red[2] + red[3]));
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)C * sizeof(ChanParams); }
+
+extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
+                               const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
+                               float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
+  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || !d_workspace || N < 1 || C < 1 || hw < 1 || n_knots < 2) {
+    set_error("npp_lpips_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
+    return NPP_ERR_ARG;
+  }
+  if ((d_df0 == nullptr) != (d_dlatent == nullptr)) { set_error("npp_lpips_layer: df0 and dlatent go together"); return NPP_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  ChanParams* cp = (ChanParams*)d_workspace;
+  hipLaunchKernelGGL(lpips_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, d_latents, C, d_spline, n_knots, x_scale, cp);
+  const int64_t nh = (int64_t)N * hw;
+  const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
+  hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, d_f0, d_f1, N, C, hw, d_lin,
+                     cp, coef, d_loss, d_df0, d_dlatent);
+  return check_launch("npp_lpips_layer");
+}

@@ -130,3 +130,58 @@ def adam_step(p, m, v, gslabs, n_slabs, slab_stride, lr, step, b1=0.9, b2=0.999,
     _req(p, torch.float32, "p")
     check(lib().npp_adam_step(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, lr, b1, b2, eps,
                               step, _stream()), "npp_adam_step")
+
+
+def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True):
+    """extract_glimpse(mode='nearest', zeros padding) at integer centres
+    (utils/extract_glimpse.py:53-79 via models/sampler.py:171-178,284-291)."""
+    _req(img_hwc, torch.float32, "img")
+    _req(centres_yx, torch.int32, "centres")
+    H, W = img_hwc.shape[:2]
+    M = centres_yx.shape[0]
+    rgb = torch.empty((M, 3, P, P), dtype=torch.float32, device=img_hwc.device)
+    msk = torch.empty((M, 1, P, P), dtype=torch.float32, device=img_hwc.device) if want_mask else None
+    check(lib().npp_patch_gather(_p(img_hwc), _p(mask_hw), H, W, _p(centres_yx), M, P, _p(rgb), _p(msk), _stream()),
+          "npp_patch_gather")
+    return rgb, msk
+
+
+_cx_ws = {}
+
+
+def cx_fwd_bwd(fx, fy, band_width=0.5, weight=None, scale=1.0, loss=None, want_grad=True):
+    """contextual_loss(x, y, band_width, weight, 'cosine') on features (N,C,h,w) + dL/dx
+    (externel_lib/contextual_loss/functional.py:9-63).  Returns (loss tensor[1], dfx or None)."""
+    _req(fx, torch.float32, "fx")
+    _req(fy, torch.float32, "fy", fx.shape)
+    N, C = fx.shape[:2]
+    hw = fx.shape[2] * fx.shape[3]
+    nbytes = lib().npp_cx_workspace_bytes(N, C, hw)
+    check(nbytes, "npp_cx_workspace_bytes")
+    key = (fx.device, int(nbytes))
+    ws = _cx_ws.get(key)
+    if ws is None:
+        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
+    if loss is None:
+        loss = torch.zeros(1, dtype=torch.float32, device=fx.device)
+    dfx = torch.empty_like(fx) if want_grad else None
+    check(lib().npp_cx_fwd_bwd(_p(fx), _p(fy), N, C, hw, band_width, _p(weight), scale, _p(loss), _p(dfx), _p(ws),
+                               int(nbytes), _stream()), "npp_cx_fwd_bwd")
+    return loss, dfx
+
+
+_lp_ws = {}
+
+
+def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0=None, dlatent=None):
+    """One VGG16 tap of LPIPS.forward(use_robust=True) (externel_lib/lpips/lpips.py:99-121,130)."""
+    _req(f0, torch.float32, "f0")
+    _req(f1, torch.float32, "f1", f0.shape)
+    N, C = f0.shape[:2]
+    hw = f0.shape[2] * f0.shape[3]
+    key = (f0.device, C)
+    ws = _lp_ws.get(key)
+    if ws is None:
+        ws = _lp_ws[key] = torch.empty(int(lib().npp_lpips_workspace_bytes(C)), dtype=torch.uint8, device=f0.device)
+    check(lib().npp_lpips_layer(_p(f0), _p(f1), N, C, hw, _p(lin), _p(latents), _p(spline), n_knots, x_scale, scale,
+                                _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")

@@ -243,3 +243,69 @@ def test_optimizer_step_and_lr_rule(dev):
     got = net2.state_dict()
     for k in Pn:
         np.testing.assert_allclose(got[k], Pn[k], rtol=1e-5, atol=2e-7, err_msg=k)
+
+
+# ---------------------------------------------------------------- patch-loss rows (a9-a13)
+def test_patch_gather_matches_reference_glimpse(dev, golden):
+    from npp_amd import ops
+    g = golden("g5_sampler.npz")
+    img = g["glimpse_img"][0]                                   # (3,H,W)
+    hwc = torch.from_numpy(np.ascontiguousarray(img.transpose(1, 2, 0))).to(dev)
+    msk = torch.from_numpy(np.ascontiguousarray(img[0])).to(dev)
+    cen = torch.from_numpy(g["glimpse_offs_xy"][:, ::-1].astype(np.int32).copy()).to(dev)   # reference offsets are (x,y)
+    rgb, m = ops.patch_gather(hwc, msk, cen, 16)
+    assert np.array_equal(rgb.cpu().numpy(), g["glimpse_out"])              # bit-exact: it is a copy
+    assert np.array_equal(m.cpu().numpy()[:, 0], g["glimpse_out"][:, 0])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "same", "w"])
+def test_cx_core_golden(dev, golden, tag):
+    from npp_amd import ops
+    g = golden("g6_cx.npz")
+    x = torch.from_numpy(g[f"{tag}_x"]).to(dev)
+    y = torch.from_numpy(g[f"{tag}_y"]).to(dev)
+    w = torch.from_numpy(g[f"{tag}_w"]).to(dev) if f"{tag}_w" in g.files else None
+    loss, dx = ops.cx_fwd_bwd(x, y, 0.5, w)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=5e-4, atol=5e-5)
+    ref = g[f"{tag}_dx"]
+    got = dx.cpu().numpy()
+    if np.linalg.norm(ref) < 1e-6:
+        assert np.abs(got - ref).max() < 1e-6
+    else:
+        assert rel_l2(got, ref) < 5e-3
+    # scale and forward-only
+    loss2, none = ops.cx_fwd_bwd(x, y, 0.5, w, scale=0.001, want_grad=False)
+    assert none is None and abs(loss2.item() - 0.001 * float(g[f"{tag}_loss"])) < 1e-6 + 1e-3 * abs(0.001 * float(g[f"{tag}_loss"]))
+
+
+def test_cx_core_realistic_size(dev):
+    """(6,256,24,24): the relu3_4 shape of 96x96 patches; against the oracle."""
+    from npp_amd import ops
+    rng = np.random.RandomState(0)
+    y = np.maximum(rng.randn(6, 256, 24, 24), 0).astype(np.float32)
+    x = np.maximum(0.7 * y + 0.7 * rng.randn(6, 256, 24, 24), 0).astype(np.float32)
+    loss, dx = ops.cx_fwd_bwd(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    lo, dxo = oracle.cx_backward(x, y)
+    assert abs(loss.item() - lo) < 1e-3 * abs(lo)
+    assert rel_l2(dx.cpu().numpy(), dxo) < 1e-2
+
+
+def test_lpips_head_golden(dev, golden):
+    from npp_amd import ops
+    g = golden("g7_lpips.npz")
+    spline, n_knots, xs = ops.load_spline(dev)
+    loss = torch.zeros(1, device=dev)
+    N = g["f0_0"].shape[0]
+    for k in range(5):
+        f0 = torch.from_numpy(g[f"f0_{k}"]).to(dev)
+        f1 = torch.from_numpy(g[f"f1_{k}"]).to(dev)
+        lin = torch.from_numpy(g[f"lin{k}"]).to(dev)
+        lat = torch.from_numpy(np.concatenate([g[f"la{k}"].ravel(), g[f"ls{k}"].ravel()])).to(dev)
+        df0 = torch.empty_like(f0)
+        dlat = torch.zeros_like(lat)
+        ops.lpips_layer(f0, f1, lin, lat, spline, n_knots, xs, 1.0, loss, df0, dlat)
+        C = f0.shape[1]
+        assert rel_l2(df0.cpu().numpy(), g[f"df0_{k}"]) < 2e-3, k
+        np.testing.assert_allclose(dlat[:C].cpu().numpy(), g[f"dla{k}"].ravel(), rtol=1e-2, atol=2e-6)
+        np.testing.assert_allclose(dlat[C:].cpu().numpy(), g[f"dls{k}"].ravel(), rtol=2e-3, atol=2e-7)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=5e-5)
