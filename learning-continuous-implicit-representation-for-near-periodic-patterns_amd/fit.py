@@ -13,11 +13,16 @@ import torch
 
 from . import ops
 from .model import NPPNet
+from .sampler import GridPatchSampler
+from .losses import ContextualLoss, LPIPS
 
 
 class CompletionFit:
     def __init__(self, img, mask, angles_deg, periods, freqs, params, device="cuda", N_rand=8192,
-                 ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None):
+                 ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
+                 patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
+                 contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
+                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173)."""
         img = np.asarray(img, np.float32)
@@ -40,6 +45,23 @@ class CompletionFit:
         yy, xx = np.meshgrid(np.arange(self.H, dtype=np.int32), np.arange(self.W, dtype=np.int32), indexing="ij")
         self.i_all_dev = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(self.device)
         self.iteration = 0
+        # ---- patch losses (train.py:50-51,126-130): only when the periodicity shifts are given
+        self.patch_sampler = None
+        if shifts is not None:
+            self.patch_size = int(patch_size) if patch_size else int(np.clip(max(np.asarray(periods).reshape(-1, 2)[0])
+                                                                  + (32 - max(np.asarray(periods).reshape(-1, 2)[0]) % 32), 64, 160))
+            self.patch_num = int(patch_num)
+            self.topk, self.invalid_ratio = int(num_real_patch_per_sample), float(invalid_ratio)
+            self.cx_w, self.lp_w, self.use_comp = float(contextual_weight), float(perceptual_weight), bool(use_comp)
+            self.patch_size_decay = int(patch_size_decay)
+            self.patch_sampler = GridPatchSampler(
+                img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
+                height=self.H, width=self.W, pool_train=self.i_train, pool_val=self.i_val, selected_shifts=shifts,
+                no_reg_sampling=False, rng=self.rng)
+            self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict).to(self.device)
+            self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
+                                    device=self.device)
+            self.last_source, self.skipped = None, 0
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
     def sample_pixels(self):
@@ -77,6 +99,62 @@ class CompletionFit:
         net.optimizer_step(bp)                           # optimizer.step() + LR rule + global_step
         self.iteration += 1
         return net.loss_buf
+
+    # ---- one iteration of the complete loop body, train.py:133-264 ------------------------
+    def step_full(self):
+        """Patch sampling -> pixel sampling -> fused forward -> pixel loss + contextual loss
+        (+ LPIPS when patch_source == 'same') -> backward -> Adam.  Returns False when the
+        sampler found no valid real patch: the iteration is skipped BEFORE zero_grad and
+        global_step is not advanced (train.py:160-161)."""
+        assert self.patch_sampler is not None, "construct CompletionFit with shifts=... for the patch losses"
+        i = self.iteration + 1                                   # trange(start=1, N_iters)
+        if i % self.patch_size_decay == 0 and i != 1 and self.patch_size > 31:          # train.py:137-141
+            self.patch_size //= 2
+            self.patch_num *= 2
+            self.patch_sampler.reset_patchsize(self.masked_img[None], self.mask[None], self.patch_size, self.patch_num)
+            self.patch_sampler.reset_pool(self.i_train, self.i_val)
+        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.sample_patches(
+            topk=self.topk, invalid_ratio=self.invalid_ratio)
+        self.iteration += 1
+        if k == 0:
+            self.skipped += 1
+            return False
+        self.last_source = source
+        net, P, n_p = self.net, self.patch_size, self.patch_num
+        pix = self.sample_pixels()                                # np.random.choice AFTER the sampler (train.py:172)
+        n_pix = pix.shape[0]
+        allc = torch.cat([pix, coords.reshape(-1, 2).to(torch.int32)], 0)
+        n = allc.shape[0]
+        bp = ops.pad_rows(n)
+        if bp != n:
+            allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
+        ws = net.workspace(bp)
+        net.zero_grad()
+        self.percepLoss.zero_latent_grads()
+        pred = net.forward_train(allc.contiguous())
+        if n < bp:
+            ws["dpred"][n:].zero_()
+        net.pixel_loss(bp, n_pix, self.gather_gt(pix))
+        # ---- patch plumbing (train.py:200-236) and patch losses (:238-251), autograd only through
+        #      the frozen VGG trunks; everything after the features is npp_cx_fwd_bwd / npp_lpips_layer
+        pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
+        pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
+        real_p = real.reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3).reshape(-1, 3, P, P)
+        rm = rmask.permute(0, 1, 4, 2, 3).reshape(-1, 1, P, P)
+        fk, fm = fake.reshape(-1, 3, P, P), fmask.reshape(-1, 1, P, P)
+        x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
+        loss_patch = self.contextualLoss(x_in, real_p * rm, None) * self.cx_w
+        if source == "same":
+            loss_patch = loss_patch + self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True) * self.lp_w
+        loss_patch.backward()
+        ws["dpred"][n_pix:n].copy_(pp_leaf.grad)
+        self.last_patch_loss = loss_patch.detach()
+        lr_used = net.lr
+        net.backward(bp)
+        net.optimizer_step(bp)
+        if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
+            self.percepLoss.adam_step(lr_used)
+        return True
 
     # ---- evaluation (train.py:270-331) -----------------------------------------------
     @torch.no_grad()

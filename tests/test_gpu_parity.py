@@ -309,3 +309,62 @@ def test_lpips_head_golden(dev, golden):
         np.testing.assert_allclose(dlat[:C].cpu().numpy(), g[f"dla{k}"].ravel(), rtol=1e-2, atol=2e-6)
         np.testing.assert_allclose(dlat[C:].cpu().numpy(), g[f"dls{k}"].ravel(), rtol=2e-3, atol=2e-7)
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=5e-5)
+
+
+def test_sampler_reproduces_reference_sequence(dev, golden):
+    """The product sampler (summed-area counts + HIP gather) against the reference's own
+    24-call sequence: modes, k, centres, crops, weights and RNG consumption."""
+    from npp_amd.sampler import GridPatchSampler
+    g = golden("g5_sampler.npz")
+    H = int(g["H"])
+    img, mask = oracle.synthetic_image(H)
+    i_train = np.stack(np.nonzero(mask[..., 0]), 1)
+    i_val = np.stack(np.nonzero(1 - mask[..., 0]), 1)
+    code = {"val": 0, "train": 1, "same": 2}
+    for tag, P, nsamp in (("p64", 64, 2), ("p32", 32, 4)):
+        rng = np.random.RandomState(0)
+        S = GridPatchSampler(torch.from_numpy((img * mask)[None]).to(dev), torch.from_numpy(mask[None]).to(dev), nsamp, P,
+                             H, H, i_train, i_val, [g["shifts"].tolist()], False, rng=rng)
+        assert S.pool_train.shape[0] == int(g[f"{tag}_pool_train_n"]) and S.pool_val.shape[0] == int(g[f"{tag}_pool_val_n"])
+        for it in range(24):
+            real, rmask, fake, fmask, coords, source, k, w = S.sample_patches(3, 0.3)
+            assert k == g[f"{tag}_k"][it], (tag, it)
+            if k == 0:
+                continue
+            assert code[source] == g[f"{tag}_modes"][it]
+            assert np.array_equal(coords[:, P // 2, P // 2].cpu().numpy(), g[f"{tag}_centres"][it])
+            np.testing.assert_allclose(fake.double().sum().item(), g[f"{tag}_fake_sum"][it], rtol=1e-6)
+            np.testing.assert_allclose(fmask.double().sum().item(), g[f"{tag}_fmask_sum"][it], rtol=1e-6)
+            if source != "same":
+                wv = np.sort(w.cpu().numpy().reshape(nsamp, -1), 1)
+                np.testing.assert_allclose(wv, g[f"{tag}_weights_sorted"][it][:, :k], atol=1e-6)
+            if it < 3:
+                assert np.array_equal(fake[:, 0].cpu().numpy(), g[f"{tag}_fake_{it}"])
+                assert real.shape == g[f"{tag}_real_{it}"].shape and rmask.shape == g[f"{tag}_rmask_{it}"].shape
+                if source == "same":
+                    assert np.array_equal(real.cpu().numpy(), g[f"{tag}_real_{it}"])
+        np.testing.assert_array_equal(rng.uniform(0, 1, 4), g[f"{tag}_rng_after"])
+
+
+def test_full_loop_with_patch_losses(dev):
+    """train.py:133-264 end to end on a 256^2 synthetic image: pixel + contextual (+ LPIPS on
+    'same' iterations) losses, all three patch sources exercised, fit still converges."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                        N_rand=8192, shifts=shifts, seed=0)
+    assert fit.patch_size == 64
+    seen = set()
+    lat0 = [l.clone() for l in fit.percepLoss.latents]
+    for it in range(120):
+        ok = fit.step_full()
+        if ok:
+            seen.add(fit.last_source)
+            assert torch.isfinite(fit.last_patch_loss).all()
+    assert seen == {"val", "train", "same"}
+    assert fit.psnr() > 28.5 and fit.psnr("unknown") > 27.0
+    # LPIPS robust latents were trained (only on 'same' iterations), adaptive_pix latents too
+    assert any((a - b).abs().max() > 0 for a, b in zip(lat0, fit.percepLoss.latents))
+    assert fit.net.global_step == 120 - fit.skipped
