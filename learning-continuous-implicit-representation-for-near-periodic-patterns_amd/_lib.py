@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnpp_hip.so")
+LIB_PATH = os.environ.get("NPP_LIB_PATH") or os.path.join(HERE, "libnpp_hip.so")   # override: A/B builds
 
 NPP_MAX_K, NPP_N_OFF, NPP_N_FREQ, NPP_E, NPP_WIDTH, NPP_ROW_TILE = 5, 5, 10, 462, 256, 64
 

@@ -40,7 +40,32 @@ constexpr int kChunkBytes = kChunkKS * kNB * kFragBytes;       // 16 KiB, two of
 constexpr int kNChunks = (kKSEmb + kChunkKS - 1) / kChunkKS;   // 4 (8,8,8,6)
 constexpr int kSmemV = 22 * kRowTile * 4;                      // warped coords of one proposal
 constexpr int kSmemE = (sizeof(EmbedDev) + 15) / 16 * 16;
-constexpr int kSmemFwd = 2 * kRegionBytes + kSmemV + 2 * kRowTile * 4 + 4 * kRowTile * 3 * 4 + kSmemE;
+// Branch-free embedding generation is driven by two small LDS tables built once per workgroup:
+//  SlotEnt[480]: per embedding slot (k-step, lane half, element) the byte offset of its warped
+//                coordinate in sV, the Fourier frequency in revolutions and the phase (0 = sin,
+//                1/4 = cos); identity slots have lin = 1, pad slots freq = phase = 0 (sin 0 = 0).
+//  WarpEnt[K][22]: per warped coordinate cos/sin(theta), period, 1/period, phase, or the
+//                linear form for the two normalised raw coordinates.
+struct SlotEnt { float frev; int code; };        // code = byte offset in sV | lin << 16 | cos << 17
+struct WarpEnt { float cs, sn, per, inv_per, phase, lin; };   // lin: value = t - 1 (normalised raw coordinate)
+constexpr int kSmemSlots = kEmbSlots * (int)sizeof(SlotEnt);                    // 7680
+constexpr int kSmemWarp = NPP_MAX_K * 22 * (int)sizeof(WarpEnt);                // 3520
+// the 4-wave rgb partial sums reuse region R0 after a barrier (everything else is dead by then)
+constexpr int kSmemFwd = 2 * kRegionBytes + kSmemV + 2 * kRowTile * 4 + kSmemE + kSmemSlots + kSmemWarp;
+static_assert(kSmemFwd <= 80 * 1024, "two workgroups per CU");
+
+// Diagnostic build only (-DNPP_STAMPS): per-phase s_memtime stamps of wave 0 of two workgroups,
+// read back with npp_debug_read_stamps().  Never compiled into the shipped library.
+#ifdef NPP_STAMPS
+__device__ unsigned long long g_stamps[2][64];
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && threadIdx.x == 0)                      \
+      g_stamps[blockIdx.x == 0 ? 0 : 1][i] = __builtin_amdgcn_s_memtime();                         \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 struct FwdArgs {
   const int32_t* coords;
@@ -54,6 +79,10 @@ struct FwdArgs {
 
 struct Lane {
   int tid, wave, lane, b, h;
+};
+struct EmbTabs {
+  const SlotEnt* slots;
+  const WarpEnt* warp;
 };
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* region, int ks, int bt, int lane) {
@@ -84,9 +113,13 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][kNB], const float* 
 // refilled with k-step ks+4 (16 MFMAs = 512+ cycles ahead).  The ring runs across part and
 // layer boundaries (next_wp), so loads also fly under the epilogue and the barrier; START
 // is the (compile-time) slot of this part's first k-step.
+#ifndef NPP_RING_DEPTH
+#define NPP_RING_DEPTH 4
+#endif
+constexpr int kRD = NPP_RING_DEPTH;     // k-steps of weight fragments in flight per wave
 template <int NTW>
 struct WRing {
-  bf16x8 w[4][NTW];
+  bf16x8 w[kRD][NTW];
 };
 
 template <int NTW, int NT>
@@ -99,7 +132,7 @@ __device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, const bf16x8
 template <int NTW, int NT>
 __device__ __forceinline__ void wring_fill(WRing<NTW>& r, const bf16x8* __restrict__ wp, int nt0, int lane) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) wslot_load<NTW, NT>(r, q, wp, q, nt0, lane);
+  for (int q = 0; q < kRD; ++q) wslot_load<NTW, NT>(r, q, wp, q, nt0, lane);
 }
 
 // Ring schedule positions [KS0, KS1) of a part with KSREAL real k-steps (weights at wp) padded
@@ -110,10 +143,10 @@ template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT>
 __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
                                          const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp, int nt0,
                                          const Lane& L, WRing<NTW>& ring) {
-  static_assert(KSTOT % 4 == 0 && KSREAL <= KSTOT && KS1 <= KSTOT, "ring schedule");
+  static_assert(KSTOT % kRD == 0 && KSREAL <= KSTOT && KS1 <= KSTOT, "ring schedule");
 #pragma unroll
   for (int ks = KS0; ks < KS1; ++ks) {
-    const int slot = ks & 3;
+    const int slot = ks % kRD;
     if (ks < KSREAL) {
       bf16x8 x[kNB];
 #pragma unroll
@@ -123,44 +156,63 @@ __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* re
 #pragma unroll
         for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = mfma_bf16(ring.w[slot][nt], x[bt], acc[nt][bt]);
     }
-    if (ks + 4 < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + 4, nt0, L.lane);
-    else if (ks + 4 >= KSTOT && next_wp) wslot_load<NTW, NT>(ring, slot, next_wp, ks + 4 - KSTOT, nt0, L.lane);
+    if (ks + kRD < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + kRD, nt0, L.lane);
+    else if (ks + kRD >= KSTOT && next_wp) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
     asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads
   }
 }
 
-// The 22 warped coordinates (a1) of proposal p for the 64 rows -> sV[i][row] (fp32).
-__device__ __forceinline__ void gen_warp(const EmbedDev& e, int p, float* sV, const float* sY, const float* sX,
+// The 22 warped coordinates (a1, models/embedder.py:110-133) of proposal p for the 64 rows ->
+// sV[i][row] (fp32).  Table-driven: wave w takes i = w, w+4, ...; the entry is wave-uniform.
+__device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, const float* sY, const float* sX,
                                          const Lane& L) {
   const float y = sY[L.lane], x = sX[L.lane];
-  for (int i = L.wave; i < 22; i += 4) sV[i * kRowTile + L.lane] = warp_value<false>(e, p, i, y, x);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int i = L.wave + 4 * q;
+    if (i < 22) {
+      const WarpEnt w = tw[p * 22 + i];
+      // y*cos + x*sin rounded like the reference's two torch ops; the linear entries put the
+      // normalised coordinate (x/W - .5)*2 into the same form (cs or sn = 2/res, bias = -1)
+      const float t = __fadd_rn(__fmul_rn(y, w.cs), __fmul_rn(x, w.sn));
+      const float qf = floorf(t * w.inv_per);
+      float r = fmaf(-qf, w.per, t);                  // torch.remainder: result in [0, per)
+      r = r < 0.0f ? r + w.per : r;
+      r = r >= w.per ? r - w.per : r;
+      const float sv = __builtin_amdgcn_sinf(fmaf(r, w.inv_per, w.phase));
+      sV[i * kRowTile + L.lane] = w.lin != 0.0f ? t - 1.0f : sv;
+    }
+  }
 }
 
-// One embedding fragment: k-step ks (0..29) of a proposal, batch tile bt.  Slot order:
-// npp_layout.h emb_col().  cos(x) = sin(x + 1/4 rev): one transcendental per element.
-__device__ __forceinline__ bf16x8 gen_emb_frag(const EmbedDev& e, const float* sV, int ks, int bt, const Lane& L) {
-  bf16x8 f;
-  const int row = bt * 32 + L.b;
-  if (ks < 28) {
-    const float ph = L.h ? 0.25f : 0.0f;
+// Four embedding fragments (2 k-steps x 2 batch tiles) of this wave: loads first, then the
+// arithmetic, so the two dependent LDS reads per value overlap across the 32 values.
+__device__ __forceinline__ void gen_emb_frags(const SlotEnt* ts, const float* sV, int ks0, bf16x8 (&f)[2][kNB],
+                                              const Lane& L) {
+  SlotEnt ent[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int t = 8 * ks + j;
-      float val = 0.0f;
-      if (t < 220) {
-        const int fj = t / 22, i = t - fj * 22;
-        val = __builtin_amdgcn_sinf(fmaf(sV[i * kRowTile + row], e.freq_rev[fj], ph));
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ent[q][j] = ts[(ks0 + q) * 16 + L.h * 8 + j];
+  float v[2][kNB][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[q][bt][j] = *(const float*)((const char*)sV + (ent[q][j].code & 0xffff) + (bt * 32 + L.b) * 4);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = v[q][bt][j];
+        const float ph = (ent[q][j].code & (1 << 17)) ? 0.25f : 0.0f;
+        const float sv = __builtin_amdgcn_sinf(fmaf(x, ent[q][j].frev, ph));
+        f[q][bt][j] = (__bf16)((ent[q][j].code & (1 << 16)) ? x : sv);
       }
-      f[j] = (__bf16)val;
-    }
-  } else if (ks == 28) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)sV[(8 * L.h + j) * kRowTile + row];
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)((L.h == 0 && j < 6) ? sV[(16 + j) * kRowTile + row] : 0.0f);
-  }
-  return f;
 }
 
 // Accumulate one proposal's 30 embedding k-steps.  lds_ring = 32 KiB LDS (two 16 KiB chunk
@@ -168,35 +220,42 @@ __device__ __forceinline__ bf16x8 gen_emb_frag(const EmbedDev& e, const float* s
 // wave has passed a barrier after its last lds_ring / sV read.  The weight ring holds the
 // first 4 k-steps on entry and the first 4 k-steps of next_wp on return.
 template <bool STORE_EMB, int NTW, int NT>
-__device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbedDev& e, int p, char* lds_ring,
+__device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbTabs& e, int p, char* lds_ring,
                                               float* sV, const float* sY, const float* sX,
                                               const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp,
                                               int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
-  gen_warp(e, p, sV, sY, sX, L);
+  STAMP(50);
+  gen_warp(e.warp, p, sV, sY, sX, L);
   wg_barrier();
+  STAMP(51);
   auto gen_chunk = [&](int c) {
     char* buf = lds_ring + (c & 1) * kChunkBytes;
+    const int ksl0 = 2 * L.wave;             // wave-uniform: this wave's two k-steps of the chunk
+    const int ks0 = kChunkKS * c + ksl0;
+    if (ks0 < kKSEmb) {                      // 30 is even: both k-steps are real or neither
+      bf16x8 f[2][kNB];
+      gen_emb_frags(e.slots, sV, ks0, f, L);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int ksl = 2 * L.wave + q;        // wave-uniform
-      const int ks = kChunkKS * c + ksl;
-      if (ks < kKSEmb) {
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int bt = 0; bt < kNB; ++bt) {
-          const bf16x8 f = gen_emb_frag(e, sV, ks, bt, L);
-          lds_store_frag(buf, ksl, bt, L.lane, f);
+          lds_store_frag(buf, ksl0 + q, bt, L.lane, f[q][bt]);
           if (STORE_EMB)
             *(bf16x8*)(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) +
-                       wfmt_unit(kKSEmb, wg, ks, bt, L.b, L.h)) = f;
+                       wfmt_unit(kKSEmb, wg, ks0 + q, bt, L.b, L.h)) = f[q][bt];
         }
-      }
     }
   };
   gen_chunk(0);
+  STAMP(52);
   wg_barrier();
+  STAMP(53);
   gen_chunk(1);
+  STAMP(54);
   mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring);
+  STAMP(55);
   wg_barrier();
+  STAMP(56);
   gen_chunk(2);
   mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
   wg_barrier();
@@ -252,18 +311,48 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   float* sV = (float*)(smem + 2 * kRegionBytes);
   float* sY = sV + 22 * kRowTile;
   float* sX = sY + kRowTile;
-  float* sRGB = sX + kRowTile;          // [4 waves][64 rows][3]
   // The embedder constants are indexed with run-time (proposal, orientation, offset)
   // indices: keep them in LDS, copied with compile-time indices so the by-value kernel
   // argument never needs a scratch copy.
-  EmbedDev& e = *(EmbedDev*)(sRGB + 4 * kRowTile * 3);
+  EmbedDev& ed = *(EmbedDev*)(sX + kRowTile);
+  SlotEnt* tSlots = (SlotEnt*)((char*)&ed + kSmemE);
+  WarpEnt* tWarp = (WarpEnt*)((char*)tSlots + kSmemSlots);
+  float* sRGB = (float*)R0;             // [4 waves][64 rows][3], reused after the last barrier
   if (threadIdx.x == 0) {
     const uint32_t* src = (const uint32_t*)&e_arg;
-    uint32_t* dst = (uint32_t*)&e;
+    uint32_t* dst = (uint32_t*)&ed;
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
   }
-
+  wg_barrier();
+  for (int sl = threadIdx.x; sl < kEmbSlots; sl += kThreads) {
+    const int ks = sl >> 4, hh = (sl >> 3) & 1, j = sl & 7;
+    SlotEnt en{0.0f, 0};                                   // pad slot: sin(v0 * 0 + 0) = 0
+    if (ks < 28) {
+      const int t = 8 * ks + j;
+      if (t < 220) { en.frev = ed.freq_rev[t / 22]; en.code = ((t % 22) * kRowTile * 4) | (hh << 17); }
+    } else if (ks == 28) {
+      en.code = ((8 * hh + j) * kRowTile * 4) | (1 << 16);
+    } else if (hh == 0 && j < 6) {
+      en.code = ((16 + j) * kRowTile * 4) | (1 << 16);
+    }
+    tSlots[sl] = en;
+  }
+  for (int wi = threadIdx.x; wi < ed.K * 22; wi += kThreads) {
+    const int p = wi / 22, i = wi - p * 22, ori = i >= 11, ii = ori ? i - 11 : i;
+    WarpEnt w{0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f};
+    if (ii == 0) {                                          // (x / res[1] - 0.5) * 2, (y / res[0] - 0.5) * 2
+      w.lin = 1.0f;
+      if (ori) w.cs = 2.0f * ed.inv_h; else w.sn = 2.0f * ed.inv_w;
+    } else {
+      const int o = (ii - 1) >> 1;
+      w.cs = ed.cs[p][ori]; w.sn = ed.sn[p][ori];
+      w.per = ed.per[p][ori][o]; w.inv_per = 1.0f / w.per;
+      w.phase = ((ii - 1) & 1) ? 0.25f : 0.0f;
+    }
+    tWarp[wi] = w;
+  }
+  const EmbTabs e{tSlots, tWarp};
   Lane L;
   L.tid = threadIdx.x;
   L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -297,12 +386,16 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   constexpr int A = kKSAct;                // 16 k-steps per 256 features
   auto wl = [&](int l) -> const bf16x8* { return wf + d.wf_off[l]; };
 
+  STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
   wring_fill<2, kNT>(ring, wl(L0), nt0, L.lane);
   init_bias<2>(acc, P + d.b_off[L0], nt0, L);
   mma_embedding<TRAIN, 2, kNT>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
+  STAMP(1);
   epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, ss(0), arow(0), wg, L);
+  STAMP(2);
   wg_barrier();
+  STAMP(3);
 
   // ---- L1..L4: 256 -> 256, snake, ping-pong R0 -> R1 -> R0 -> R1 -> R0
 #pragma unroll
@@ -311,17 +404,23 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     char* out = (l & 1) ? R1 : R0;
     init_bias<2>(acc, P + d.b_off[l], nt0, L);
     mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
+    STAMP(4 * l);
     epilogue<true, TRAIN, 2>(acc, out, nt0, kNT, ss(l), arow(l), wg, L);
+    STAMP(4 * l + 1);
     wg_barrier();
+    STAMP(4 * l + 2);
   }
 
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
   //      again after mma_embedding's final barrier)
   init_bias<2>(acc, P + d.b_off[L5], nt0, L);
   mma_embedding<false, 2, kNT>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
+  STAMP(20);
   mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
+  STAMP(21);
   epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, ss(5), arow(5), wg, L);
   wg_barrier();
+  STAMP(22);
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
   init_bias<2>(acc, P + d.b_off[L6], nt0, L);
@@ -381,8 +480,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, ss(9),
                            TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr, wg, L);
 
+  STAMP(40);
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,
   //      half-wave exchange by shuffle, 4-wave reduction through LDS.
+  wg_barrier();       // every wave is done with R0 / R1: R0 now carries the rgb partial sums
   {
     const float* Wr = P + d.w_off[LRGB];
     float part[kNB][3];
@@ -416,11 +517,18 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
       A_.pred[(row0 + row) * 3 + c] = 1.0f / (1.0f + __expf(-z));   // helpers.py:56 sigmoid
     }
   }
+  STAMP(41);
 }
 
 }  // namespace npp
 
 using namespace npp;
+
+#ifdef NPP_STAMPS
+extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width,
                            const void* d_wf, const float* d_params, float* d_pred, void* d_sstash, void* d_actT,

@@ -113,35 +113,48 @@ class CompletionFit:
             self.patch_num *= 2
             self.patch_sampler.reset_patchsize(self.masked_img[None], self.mask[None], self.patch_size, self.patch_num)
             self.patch_sampler.reset_pool(self.i_train, self.i_val)
-        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.sample_patches(
-            topk=self.topk, invalid_ratio=self.invalid_ratio)
+        batch = self.sample_batch()
         self.iteration += 1
-        if k == 0:
+        if batch is None:
             self.skipped += 1
             return False
-        self.last_source = source
-        net, P, n_p = self.net, self.patch_size, self.patch_num
-        pix = self.sample_pixels()                                # np.random.choice AFTER the sampler (train.py:172)
-        n_pix = pix.shape[0]
+        self.step_from(batch)
+        return True
+
+    def sample_batch(self):
+        """Host-side sampling of one iteration: sample_patches (train.py:152-157) then the pixel
+        draw (:172), in the reference's RNG order.  None when no valid real patch exists."""
+        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.sample_patches(
+            topk=self.topk, invalid_ratio=self.invalid_ratio)
+        if k == 0:
+            return None
+        pix = self.sample_pixels()
         allc = torch.cat([pix, coords.reshape(-1, 2).to(torch.int32)], 0)
         n = allc.shape[0]
         bp = ops.pad_rows(n)
         if bp != n:
             allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
+        return dict(coords=allc.contiguous(), n_pix=pix.shape[0], n=n, bp=bp, gt=self.gather_gt(pix), real=real, rmask=rmask,
+                    fake=fake, fmask=fmask, source=source, k=k, P=self.patch_size, n_p=self.patch_num)
+
+    def step_from(self, b):
+        """Device side of one iteration (everything after sampling), train.py:183-264."""
+        self.last_source = source = b["source"]
+        net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
         ws = net.workspace(bp)
         net.zero_grad()
         self.percepLoss.zero_latent_grads()
-        pred = net.forward_train(allc.contiguous())
+        pred = net.forward_train(b["coords"])
         if n < bp:
             ws["dpred"][n:].zero_()
-        net.pixel_loss(bp, n_pix, self.gather_gt(pix))
+        net.pixel_loss(bp, n_pix, b["gt"])
         # ---- patch plumbing (train.py:200-236) and patch losses (:238-251), autograd only through
         #      the frozen VGG trunks; everything after the features is npp_cx_fwd_bwd / npp_lpips_layer
         pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
         pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
-        real_p = real.reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3).reshape(-1, 3, P, P)
-        rm = rmask.permute(0, 1, 4, 2, 3).reshape(-1, 1, P, P)
-        fk, fm = fake.reshape(-1, 3, P, P), fmask.reshape(-1, 1, P, P)
+        real_p = b["real"].reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3).reshape(-1, 3, P, P)
+        rm = b["rmask"].permute(0, 1, 4, 2, 3).reshape(-1, 1, P, P)
+        fk, fm = b["fake"].reshape(-1, 3, P, P), b["fmask"].reshape(-1, 1, P, P)
         x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
         loss_patch = self.contextualLoss(x_in, real_p * rm, None) * self.cx_w
         if source == "same":
@@ -154,7 +167,6 @@ class CompletionFit:
         net.optimizer_step(bp)
         if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
             self.percepLoss.adam_step(lr_used)
-        return True
 
     # ---- evaluation (train.py:270-331) -----------------------------------------------
     @torch.no_grad()

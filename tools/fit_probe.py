@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from npp_amd.fit import CompletionFit
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 256
