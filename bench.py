@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
-    ap.add_argument("--ksplit", type=int, default=6)
+    ap.add_argument("--ksplit", type=int, default=12)
     return ap.parse_args()
 
 

@@ -87,6 +87,19 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
 
+// Streaming store of a 16-byte fragment to a stash array: written once, read once by a later
+// kernel, so it should not displace the L2-resident weight packs (NPP_STASH_NT=0 to compare).
+#ifndef NPP_STASH_NT
+#define NPP_STASH_NT 1
+#endif
+__device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
+#if NPP_STASH_NT
+  __builtin_nontemporal_store(v, (bf16x8*)p);
+#else
+  *(bf16x8*)p = v;
+#endif
+}
+
 // Workgroup barrier for LDS hand-offs that leaves global memory traffic in flight.
 // __syncthreads() makes hipcc emit s_waitcnt vmcnt(0) first, which drains every outstanding
 // stash store and weight prefetch at each of the ~30 barriers of the fused kernels (measured:

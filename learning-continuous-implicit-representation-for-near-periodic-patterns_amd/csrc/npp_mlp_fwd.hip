@@ -241,8 +241,8 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
         for (int bt = 0; bt < kNB; ++bt) {
           lds_store_frag(buf, ksl0 + q, bt, L.lane, f[q][bt]);
           if (STORE_EMB)
-            *(bf16x8*)(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) +
-                       wfmt_unit(kKSEmb, wg, ks0 + q, bt, L.b, L.h)) = f[q][bt];
+            stash_store(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) +
+                            wfmt_unit(kKSEmb, wg, ks0 + q, bt, L.b, L.h), f[q][bt]);
         }
     }
   };
@@ -296,8 +296,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
         const bf16x8 f = pack_acc(a, s);
         if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
         if (keep) keep[nt][bt][s] = f;
-        if (TRAIN && SNAKE) sstash_layer[((((int64_t)wg * ntl + ntg) * kNB + bt) * 2 + s) * 64 + L.lane] = pack_acc(ds, s);
-        if (TRAIN) *(bf16x8*)(actF_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h)) = f;
+        if (TRAIN && SNAKE)
+          stash_store(&sstash_layer[((((int64_t)wg * ntl + ntg) * kNB + bt) * 2 + s) * 64 + L.lane], pack_acc(ds, s));
+        if (TRAIN) stash_store(actF_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), f);
       }
     }
   }

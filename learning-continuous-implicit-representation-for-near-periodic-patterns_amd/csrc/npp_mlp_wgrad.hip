@@ -9,7 +9,9 @@
 // tile is a contiguous 16-KiB chunk that is copied linearly into LDS, and the MFMA operand
 // fragments (one feature, 8 consecutive rows per lane) are produced by the hardware
 // transposing read ds_read_b64_tr_b16 -- conflict-free by construction of the line layout.
-// A job = one (dz array, input array) pair; jobs are cut into 128x128 output tiles and the
+// A job = one (dz array, input array) pair; jobs are cut into 256x256 output tiles (the kernel is
+// HBM-bound on re-reading the stash arrays: with 128x128 tiles every array was read twice, 1.0 GB
+// per pass at c2; 256x256 tiles, 8 waves of 64x128, read each array once per job) and the
 // batch is split over gridDim.y; every (tile, split) writes its partial sums with plain
 // stores into slab `split` of the gradient buffer, in the reference's parameter layout
 // ([out][in] row-major).  npp_adam_step adds the slabs: no atomics, bit-reproducible.
@@ -20,11 +22,12 @@
 
 namespace npp {
 
-constexpr int kWT = 128;            // output tile (both dims)
+constexpr int kWT = 256;            // output tile (both dims)
 constexpr int kWBK = 64;            // batch rows per main-loop step
-constexpr int kWThreads = 256;
-constexpr int kWTileBytes = kWT * kWBK * 2;          // 16 KiB per operand tile
-constexpr int kSmemW = 4 * kWTileBytes;              // A,B double buffered = 64 KiB
+constexpr int kWThreads = 512;      // 8 waves: 4 (m) x 2 (n), 64 x 128 outputs each
+constexpr int kWPairs = kWT / 32;   // k-step pairs (32 features) per operand tile
+constexpr int kWTileBytes = kWT * kWBK * 2;          // 32 KiB per operand tile
+constexpr int kSmemW = 4 * kWTileBytes;              // A,B double buffered = 128 KiB
 constexpr int kMaxJobs = 24;
 
 struct WJob {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int m_l = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows [64 wm, +64), cols [128 wn, +128)
 
   // locate the job of this tile: compile-time indices into the kernel-argument table so
   // it is read with scalar loads (a run-time index would force a scratch copy of it)
@@ -61,77 +64,68 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     if (j < A.njobs && (int)blockIdx.x >= A.jobs[j].tile0) J = A.jobs[j];
   const int t_local = blockIdx.x - J.tile0;
   const int tm = t_local / J.tiles_n, tn = t_local - tm * J.tiles_n;
-  // operand tiles: 4 k-step pairs (128 features); fewer are valid at the array's end
-  const int a_pairs = min(4, (J.a_nks >> 1) - tm * 4), b_pairs = min(4, (J.b_nks >> 1) - tn * 4);
+  // operand tiles: 8 k-step pairs (256 features); fewer are valid at the array's end
+  const int a_pairs = min(kWPairs, (J.a_nks >> 1) - tm * kWPairs), b_pairs = min(kWPairs, (J.b_nks >> 1) - tn * kWPairs);
   const int a_bytes = a_pairs * 4096, b_bytes = b_pairs * 4096;
   const int64_t n_wg = A.n_wg;
   const int64_t wg_begin = (int64_t)blockIdx.y * A.wg_chunk;
   const int64_t wg_end = min(n_wg, wg_begin + (int64_t)A.wg_chunk);
   // byte address of (workgroup tile g, pair p) inside an array: ((g * nks/2 + p) * 2) * 2048
-  const char* gA = A.dzF + wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * 4 * 4096;
-  const char* gB = A.actF + wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * 4 * 4096;
+  const char* gA = A.dzF + wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * kWPairs * 4096;
+  const char* gB = A.actF + wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * kWPairs * 4096;
   const int64_t a_stride = (int64_t)J.a_nks * 2048, b_stride = (int64_t)J.b_nks * 2048;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
   const bool do_bias = J.bias_on && tn == 0 && wn == 0;
 
-  // staging: 1024 16-byte units per operand tile, 4 per thread, linear copy
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int64_t g) {
+  // staging: 2048 16-byte units per operand tile, 4 per thread, linear copy.  The stash arrays
+  // stream from HBM (~2 us latency): global loads run TWO workgroup tiles ahead of the MFMAs
+  // (two register sets, loop unrolled by two so they are named statically), the LDS image one.
+  struct Stage { u32x4 a[4], b[4]; };
+  auto gload = [&](Stage& st, int64_t g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int off = (tid + kWThreads * i) * 16;
       const u32x4 z = {0u, 0u, 0u, 0u};
-      ra[i] = off < a_bytes ? *(const u32x4*)(gA + g * a_stride + off) : z;
-      rb[i] = off < b_bytes ? *(const u32x4*)(gB + g * b_stride + off) : z;
+      st.a[i] = off < a_bytes ? *(const u32x4*)(gA + g * a_stride + off) : z;
+      st.b[i] = off < b_bytes ? *(const u32x4*)(gB + g * b_stride + off) : z;
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](const Stage& st, int buf) {
     char* sA = smem + buf * 2 * kWTileBytes;
     char* sB = sA + kWTileBytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int off = (tid + kWThreads * i) * 16;
-      *(u32x4*)(sA + off) = ra[i];
-      *(u32x4*)(sB + off) = rb[i];
+      *(u32x4*)(sA + off) = st.a[i];
+      *(u32x4*)(sB + off) = st.b[i];
     }
   };
   // per-lane fragment offsets: feature tile (wm|wn)*2 + i, k-step t (4 per workgroup tile)
-  int offA[2], offB[2];
+  int offA[2], offB[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    offA[i] = wfrag_offset(wm * 2 + i, 0, lane);
-    offB[i] = wfrag_offset(wn * 2 + i, 0, lane);
-  }
-
-  int buf = 0;
-  if (wg_begin < wg_end) {
-    gload(wg_begin);
-    sstore(0);
-  }
-  wg_barrier();
-  for (int64_t g = wg_begin; g < wg_end; ++g) {
-    const bool has_next = g + 1 < wg_end;
-    if (has_next) gload(g + 1);
+  for (int i = 0; i < 2; ++i) offA[i] = wfrag_offset(wm * 2 + i, 0, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = wfrag_offset(wn * 4 + j, 0, lane);
+  auto compute = [&](int buf) {
     const char* sA = smem + buf * 2 * kWTileBytes;
     const char* sB = sA + kWTileBytes;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       // wfrag_offset(tt, t, lane) - wfrag_offset(tt, 0, lane) = (t>>1)*2048 + (t&1)*1024
       const int dt = (t >> 1) * 2048 + (t & 1) * 1024;
-      bf16x8 a[2], b[2];
+      bf16x8 a[2], b[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = wfrag_read(sA, offA[i] + dt);
-        b[i] = wfrag_read(sB, offB[i] + dt);
-      }
+      for (int i = 0; i < 2; ++i) a[i] = wfrag_read(sA, offA[i] + dt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = wfrag_read(sB, offB[j] + dt);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -141,18 +135,36 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
     }
-    if (has_next) sstore(buf ^ 1);
+  };
+
+  // prologue: tile g0 -> LDS buffer 0, tile g0+1 -> register set s1
+  Stage s0, s1;
+  if (wg_begin < wg_end) {
+    gload(s0, wg_begin);
+    if (wg_begin + 1 < wg_end) gload(s1, wg_begin + 1);
+    sstore(s0, 0);
+  }
+  wg_barrier();
+  // steady state, two tiles per trip: on entry LDS[0] holds tile g, s1 holds tile g+1
+  for (int64_t g = wg_begin; g < wg_end; g += 2) {
+    if (g + 2 < wg_end) gload(s0, g + 2);
+    compute(0);
+    if (g + 1 < wg_end) sstore(s1, 1);
     wg_barrier();
-    buf ^= 1;
+    if (g + 1 >= wg_end) break;
+    if (g + 3 < wg_end) gload(s1, g + 3);
+    compute(1);
+    if (g + 2 < wg_end) sstore(s0, 0);
+    wg_barrier();
   }
 
   // ---- epilogue: plain stores into this split's slab, reference layout
   float* slab = A.gslabs + (int64_t)blockIdx.y * A.slab_stride;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n_idx = tn * kWT + wn * 64 + j * 32 + m_l;      // accumulator column = lane & 31
+  for (int j = 0; j < 4; ++j) {
+    const int n_idx = tn * kWT + wn * 128 + j * 32 + m_l;     // accumulator column = lane & 31
     int col = -1;
     if (n_idx < J.n) {
       if (J.colmode == 0) col = J.col0 + n_idx;
