@@ -134,6 +134,85 @@ __device__ __forceinline__ bf16x8 wfrag_read(const char* tile, int off) {
   return r;
 }
 
+// ---- shared pieces of the fused MLP kernels (npp_mlp_fwd.hip, npp_mlp_bwd.hip) ------------
+struct Lane {
+  int tid, wave, lane, b, h;
+};
+__device__ __forceinline__ bf16x8 lds_frag(const char* region, int ks, int bt, int lane) {
+  return *(const bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16);
+}
+__device__ __forceinline__ void lds_store_frag(char* region, int ks, int bt, int lane, const bf16x8& v) {
+  *(bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16) = v;
+}
+
+// ---- weight stream: a rolling register ring of 4 k-steps --------------------------------
+// With only Bp/64 workgroups in flight the kernel is latency-bound unless the L2 -> register
+// weight stream runs ahead of the MFMAs.  Each wave keeps the weight fragments of the next
+// 4 k-steps in a ring; right after the MFMAs of k-step ks have been issued, their slot is
+// refilled with k-step ks+4 (16 MFMAs = 512+ cycles ahead).  The ring runs across part and
+// layer boundaries (next_wp), so loads also fly under the epilogue and the barrier; START
+// is the (compile-time) slot of this part's first k-step.
+#ifndef NPP_RING_DEPTH
+#define NPP_RING_DEPTH 4
+#endif
+constexpr int kRD = NPP_RING_DEPTH;     // k-steps of weight fragments in flight per wave
+template <int NTW>
+struct WRing {
+  bf16x8 w[kRD][NTW];
+};
+
+template <int NTW, int NT>
+__device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, const bf16x8* __restrict__ wp, int ks, int nt0,
+                                           int lane) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) r.w[slot][nt] = wp[((int64_t)ks * NT + nt0 + nt) * 64 + lane];
+}
+// fresh fill of the ring with k-steps 0..3 of wp (START = 0 for the consumer)
+template <int NTW, int NT>
+__device__ __forceinline__ void wring_fill(WRing<NTW>& r, const bf16x8* __restrict__ wp, int nt0, int lane) {
+#pragma unroll
+  for (int q = 0; q < kRD; ++q) wslot_load<NTW, NT>(r, q, wp, q, nt0, lane);
+}
+
+// Ring schedule positions [KS0, KS1) of a part with KSREAL real k-steps (weights at wp) padded
+// to KSTOT (a multiple of 4) schedule positions, so that every part starts at ring slot 0:
+// positions >= KSREAL issue no MFMA and load nothing, they only keep the refill cadence.
+// Activation fragments of k-step ks sit at LDS k-step (ks - KS0 + ks_lds0) of `region`.
+template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT>
+__device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
+                                         const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp, int nt0,
+                                         const Lane& L, WRing<NTW>& ring) {
+  static_assert(KSTOT % kRD == 0 && KSREAL <= KSTOT && KS1 <= KSTOT, "ring schedule");
+  // activation fragments are read one k-step ahead of the MFMAs that use them (LDS latency
+  // ~130+ cycles would otherwise serialise every k-step behind its own reads)
+  constexpr int KSE = KS1 < KSREAL ? KS1 : KSREAL;       // real k-steps end
+  bf16x8 xn[kNB];
+  if (KS0 < KSE) {
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) xn[bt] = lds_frag(region, ks_lds0, bt, L.lane);
+  }
+#pragma unroll
+  for (int ks = KS0; ks < KS1; ++ks) {
+    const int slot = ks % kRD;
+    if (ks < KSREAL) {
+      bf16x8 x[kNB];
+#pragma unroll
+      for (int bt = 0; bt < kNB; ++bt) x[bt] = xn[bt];
+      if (ks + 1 < KSE) {
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) xn[bt] = lds_frag(region, ks_lds0 + ks + 1 - KS0, bt, L.lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = mfma_bf16(ring.w[slot][nt], x[bt], acc[nt][bt]);
+    }
+    if (ks + kRD < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + kRD, nt0, L.lane);
+    else if (ks + kRD >= KSTOT && next_wp) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
+    asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads
+  }
+}
+
 // ---- adaptive robust loss: per-channel quantities derived from the latents --------------
 // adaptive.py:146-181, distribution.py:90-114,143-169, cubic_spline.py:65-97 (see npp_loss_adam.hip)
 struct ChanParams {   // per-channel quantities derived from the latents

@@ -29,34 +29,6 @@ struct BwdArgs {
   char* dzF;
 };
 
-struct LaneB {
-  int tid, wave, lane, b, h;
-};
-
-__device__ __forceinline__ bf16x8 ldsB(const char* region, int ks, int bt, int lane) {
-  return *(const bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16);
-}
-__device__ __forceinline__ void stsB(char* region, int ks, int bt, int lane, const bf16x8& v) {
-  *(bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16) = v;
-}
-
-template <int NS>
-__device__ __forceinline__ void mma_bwd(f32x16 (&acc)[2][kNB], const char* region, const bf16x8* __restrict__ wp,
-                                        int kt0, const LaneB& L) {
-#pragma unroll 2
-  for (int ns = 0; ns < NS; ++ns) {
-    bf16x8 w[2], x[kNB];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) w[t] = wp[(ns * kNT + kt0 + t) * 64 + L.lane];
-#pragma unroll
-    for (int bt = 0; bt < kNB; ++bt) x[bt] = ldsB(region, ns, bt, L.lane);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int bt = 0; bt < kNB; ++bt) acc[t][bt] = mfma_bf16(w[t], x[bt], acc[t][bt]);
-  }
-}
-
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -69,7 +41,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
 template <bool HAS_S>
 __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const bf16x8* sst, char* dz_array,
-                                             int wg, int kt0, const LaneB& L) {
+                                             int wg, int kt0, const Lane& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ntg = kt0 + t;
@@ -87,7 +59,7 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
-        if (out) stsB(out, 2 * ntg + s, bt, L.lane, f);
+        if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
         stash_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
       }
     }
@@ -101,7 +73,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   char* R1 = smem + kRegionBytesB;
   float* sDraw = (float*)(smem + 2 * kRegionBytesB);   // [64 rows][3]
 
-  LaneB L;
+  Lane L;
   L.tid = threadIdx.x;
   L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   L.lane = threadIdx.x & 63;
@@ -162,7 +134,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
-        stsB(R0, 2 * L.wave + s, bt, L.lane, f);
+        lds_store_frag(R0, 2 * L.wave + s, bt, L.lane, f);
         stash_store(A.dzF + wfmt_array_base(kDzKsP, gridDim.x) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
       }
     }
@@ -171,23 +143,25 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
   f32x16 acc[2][kNB], acc1[2][kNB];
   const bf16x8* wb = A.wb;
+  WRing<2> ring;                                        // weight-stream ring, chained across layers
+  wring_fill<2, kNT>(ring, wb + bd.off16[BP1], kt0, L.lane);
 
   // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
   zero_acc(acc1);
-  mma_bwd<8>(acc1, R0, wb + bd.off16[BP1], kt0, L);            // df1, part 1 (kept in registers)
+  mma_ring<0, 8, 8, 8, 2, kNT>(acc1, R0, 0, wb + bd.off16[BP1], MULTI ? wb + bd.off16[BP2] : wb + bd.off16[BF1], kt0, L, ring);   // df1, part 1
   if (MULTI) {
     zero_acc(acc);
-    mma_bwd<8>(acc, R0, wb + bd.off16[BP2], kt0, L);           // df2 = dz_f2 (F2 is linear)
+    mma_ring<0, 8, 8, 8, 2, kNT>(acc, R0, 0, wb + bd.off16[BP2], wb + bd.off16[BF2], kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
     bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
     wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
-    mma_bwd<kKSAct>(acc, R1, wb + bd.off16[BF2], kt0, L);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wb + bd.off16[BF2], wb + bd.off16[BS], kt0, L, ring);
     bwd_epilogue<true>(acc, R0, ss(8), dzr(kDzS), wg, kt0, L);
     wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
-    mma_bwd<kKSAct>(acc1, R0, wb + bd.off16[BS], kt0, L);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc1, R0, 0, wb + bd.off16[BS], wb + bd.off16[BF1], kt0, L, ring);
   }
   bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), wg, kt0, L);
   wg_barrier();
@@ -201,7 +175,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     char* in = ((v - BF1) & 1) ? R0 : R1;
     char* out = ((v - BF1) & 1) ? R1 : R0;
     zero_acc(acc);
-    mma_bwd<kKSAct>(acc, in, wb + bd.off16[v], kt0, L);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wb + bd.off16[v], v == B1 ? nullptr : wb + bd.off16[v + 1], kt0, L, ring);
     bwd_epilogue<true>(acc, v == B1 ? nullptr : out, ss(out_layer), dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }
