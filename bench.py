@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
     ap.add_argument("--ksplit", type=int, default=12)
+    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per iteration (measured: no gain, the eager launches already run ahead of the GPU)")
     return ap.parse_args()
 
 
@@ -80,7 +82,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:      # launched by torch.distributed.run (any N >= 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -88,7 +90,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if dist is not None else 0)
 
     import oracle                      # only for the synthetic workload + cpu_baseline leg
     from npp_amd import ops
@@ -138,6 +140,14 @@ def main():
         net.backward(bp)
         net.optimizer_step(bp)
 
+    graphs = None
+    if args.graph:
+        graphs = [net.capture_step(c, n_rows, gt) for c, gt in batches]
+        eager_step = step
+
+        def step(i):                      # noqa: F811  -- graph replay of the same iteration
+            net.replay_step(graphs[i % n_batches])
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -174,7 +184,7 @@ def main():
     c0, gt0 = batches[0]
     kt = {
         "mlp_fwd_train": timed(lambda: net.forward_train(c0)),
-        "mlp_bwd_chain": timed(lambda: ops.mlp_bwd(ws["dpred"], ws["pred"], K, net.wb, net.params, ws["sstash"], ws["dzT"])),
+        "mlp_bwd_chain": timed(lambda: ops.mlp_bwd(ws["dpred"], ws["pred"], K, net.wb, net.params, ws["actT"], ws["dzT"])),
         "mlp_wgrad": timed(lambda: ops.mlp_wgrad(ws["dzT"], ws["actT"], bp, K, net.ksplit, ws["gslabs"])),
         "pixel_loss": timed(lambda: net.pixel_loss(bp, n_rows, gt0)),
         "adam+repack": timed(lambda: (ops.adam_step(net.params, net.m, net.v, ws["gslabs"], net.ksplit, net.n_params, 0.0, 1),
@@ -193,6 +203,52 @@ def main():
                 "all_kernels_tflops": {k: round(flops[k] / kt[k] / 1e12, 2) for k in flops},
                 "step_mfma_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
     render_px_s = H * H / kt["render_fwd_512sq"]
+
+    # ---- c4: stand-alone embedder on the full 1024^2 grid, fp32 (HBM-write-bound kernel K1) ----
+    c4 = None
+    if rank == 0 and not args.no_extras:
+        yy, xx = np.meshgrid(np.arange(1024, dtype=np.int32), np.arange(1024, dtype=np.int32), indexing="ij")
+        grid = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(dev)
+        a4, p4, _ = oracle.synthetic_periodicity(1024, 3)
+        from npp_amd import EmbedCfg
+        cfg4 = EmbedCfg.make(a4, p4, oracle.SEED0_FREQS, (1024, 1024))
+        out = {}
+        for name, dt, prec, bpe in (("fp32_precise", torch.float32, True, 4), ("bf16_fast", torch.bfloat16, False, 2)):
+            t_emb = timed(lambda: ops.embed_fwd(grid, cfg4, dt, precise=prec), reps=5)
+            nbytes = grid.shape[0] * (8 + bpe * 3 * 462)
+            out[name] = {"ms": t_emb * 1e3, "pixels_per_s": grid.shape[0] / t_emb, "GB_per_s": nbytes / t_emb / 1e9,
+                         "frac_of_hbm_peak": nbytes / t_emb / 1e9 / PEAK_HBM_GBS}
+        net4 = CompletionFit(*oracle.synthetic_image(64), a4, p4, oracle.SEED0_FREQS, oracle.init_params(3, seed=0), device=dev).net
+        net4.cfg = cfg4
+        t_r = timed(lambda: net4.render(grid), reps=3)
+        out["render_1024sq_bf16"] = {"ms": t_r * 1e3, "pixels_per_s": grid.shape[0] / t_r,
+                                     "TFLOP_per_s": 2 * fwd_macs * grid.shape[0] / t_r / 1e12}
+        c4 = out
+        del grid
+
+    # ---- the complete loop body of train.py:133-264 (patch sampler inputs pre-drawn, VGG trunks via
+    #      PyTorch/MIOpen glue with fixed-seed weights, CX core / LPIPS head / patch gather in HIP) ----
+    full_loop = None
+    if rank == 0 and not args.no_extras:
+        _, _, shifts = oracle.synthetic_periodicity(H, K)
+        f3 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                           N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts)
+        pre = []
+        while len(pre) < 10:
+            b = f3.sample_batch()
+            if b is not None:
+                pre.append(b)
+        for b in pre:
+            f3.step_from(b)
+        per = {}
+        for src in ("val", "train", "same"):
+            bs = [b for b in pre if b["source"] == src]
+            if bs:
+                per[src] = timed(lambda: [f3.step_from(b) for b in bs], reps=5) / len(bs) * 1e3
+        mix = 0.5 * per.get("val", 0) + 0.3 * per.get("train", per.get("val", 0)) + 0.2 * per.get("same", per.get("val", 0))
+        full_loop = {"ms_per_iter_by_patch_source": per, "ms_per_iter_mix_50_30_20": mix,
+                     "rows_per_s": (n_pix + 2 * f3.patch_size ** 2) / (mix * 1e-3),
+                     "note": "device side only (sampling pre-drawn); VGG19/VGG16 trunks run through PyTorch/MIOpen"}
 
     # ---- iterations to 28 dB on a fresh fit of the same image (not timed) -----------------
     iters_to_target, final_psnr = None, None
@@ -230,11 +286,12 @@ def main():
                                    f"step = 1 optimisation iteration over {n_pix} pixel rows + 2x{patch}^2 patch rows "
                                    f"(fused embed+MLP fwd, adaptive robust loss, bwd chain, grouped wgrad, Adam)",
                        "rows_per_step": n_rows, "image": [H, H], "K": K, "width": 256, "ksplit": args.ksplit,
-                       "images_per_gpu": 1},
+                       "images_per_gpu": 1, "hip_graph": bool(args.graph)},
             "value_per_gpu": value / world,
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
             "final_gather_ms": gather_ms,
+            "c4_embedder_1024sq": c4, "full_loop_with_patch_losses": full_loop,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -94,9 +94,10 @@ int npp_warp_fwd(const int32_t* d_coords_yx, int64_t N, const npp_embed_cfg* cfg
 
 /* ---- a5+a6+a7: fused coordinate MLP -------------------------------------- */
 /* Workspace sizes (bytes) for a padded batch of Bp rows (multiple of NPP_ROW_TILE):
- *  sizes[0] s-stash (snake derivative, fragment order, bf16)
- *  sizes[1] actT   (layer inputs, feature-major bf16, incl. the embedding)
- *  sizes[2] dzT    (pre-activation gradients, feature-major bf16)
+ *  sizes[0] 0 (reserved)
+ *  sizes[1] actF   forward stash, 16-byte fragments in W-format (csrc/npp_layout.h): fp16
+ *                  pre-activations of the snake layers, bf16 f1 / f2, bf16 embedding slots
+ *  sizes[2] dzF    pre-activation gradients, bf16 fragments in W-format
  *  sizes[3] grad slabs (ksplit * param floats * 4) */
 int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]);
 
@@ -104,22 +105,22 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
  * (models/helpers.py:41-62, models/networks.py:56-95 / :145-173) INCLUDING the
  * embedding lookup it is fed with (train.py:166-181): coords (Bp,2) -> pred (Bp,3).
  * d_wf: forward pack; d_params: fp32 blob (biases + rgb_linear are read from it).
- * d_sstash / d_actT may be NULL (inference / full-image render, train.py:277-309);
- * when given, the kernel also writes what npp_mlp_bwd / npp_mlp_wgrad need.
+ * d_actF may be NULL (inference / full-image render, train.py:277-309); when given, the
+ * kernel also writes the stash npp_mlp_bwd / npp_mlp_wgrad need.
  * Bp must be a multiple of NPP_ROW_TILE (pad with any valid coordinate). */
 int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg,
                 int width, const void* d_wf, const float* d_params, float* d_pred,
-                void* d_sstash, void* d_actT, void* stream);
+                void* d_actF, void* stream);
 
 /* Backward of the same (what loss.backward() does through networks.py:56-95):
- * d_dpred (Bp,3) = dL/dpred (rows >= the real batch must be 0).  Writes dzT. */
+ * d_dpred (Bp,3) = dL/dpred (rows >= the real batch must be 0).  Reads actF, writes dzF. */
 int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width,
-                const void* d_wb, const float* d_params, const void* d_sstash,
-                void* d_dzT, void* stream);
+                const void* d_wb, const float* d_params, const void* d_actF,
+                void* d_dzF, void* stream);
 
 /* Weight/bias gradients: ksplit partial slabs in the parameter-blob layout
  * (slab s at d_gslabs + s * total floats); npp_adam_step sums them. */
-int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width,
+int npp_mlp_wgrad(const void* d_dzF, const void* d_actF, int64_t Bp, int K, int width,
                   int ksplit, float* d_gslabs, void* stream);
 
 /* ---- a8: adaptive robust pixel loss -------------------------------------- */
@@ -141,6 +142,12 @@ int npp_pixel_loss(const float* d_pred, const float* d_gt, const float* d_mask, 
 int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,
                   int n_slabs, int64_t slab_stride, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
+
+/* Same step with step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) read from device memory
+ * (d_hp[0], d_hp[1]): lets a captured HIP graph of one optimisation iteration be replayed. */
+int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,
+                      int n_slabs, int64_t slab_stride, float beta1, float beta2, float eps,
+                      const float* d_hp, void* stream);
 
 /* ---- a9/a10: patch crops ---------------------------------------------------- */
 /* Replaces extract_glimpse(..., mode='nearest', padding_mode='zeros', normalized=False,

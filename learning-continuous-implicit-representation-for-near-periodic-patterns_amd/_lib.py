@@ -59,11 +59,12 @@ SYMBOLS = {
     "npp_embed_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _i32, _i32, _vp]),
     "npp_warp_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _vp]),
     "npp_train_workspace": (_i32, [_i32, _i32, _i64, _i32, C.POINTER(_i64)]),
-    "npp_mlp_fwd": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "npp_mlp_fwd": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_mlp_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "npp_cx_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "npp_cx_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),

@@ -266,7 +266,7 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
   int rc = check_kw(K, width);
   if (rc) return rc;
   if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || !sizes) { set_error("npp_train_workspace: bad Bp/ksplit"); return NPP_ERR_ARG; }
-  sizes[0] = sstash_bytes(Bp);
+  sizes[0] = 0;   // (the separate snake-derivative stash is gone: npp_mlp_bwd reads z from actF)
   sizes[1] = (int64_t)act_total_ks(K) * (Bp / kRowTile) * 2048;
   sizes[2] = (int64_t)kDzTotalKs * (Bp / kRowTile) * 2048;
   sizes[3] = (int64_t)ksplit * make_desc(K).total_params * 4;

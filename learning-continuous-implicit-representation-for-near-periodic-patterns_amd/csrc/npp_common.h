@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 namespace npp {
 
@@ -99,6 +100,22 @@ __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
   *(bf16x8*)p = v;
 #endif
 }
+// Pre-activations of the snake layers are stashed as fp16 (|z| is O(10); 11 significand bits):
+// the backward chain derives snake'(z) = 1 + sin 2z from them and npp_mlp_wgrad derives the layer
+// input snake(z) while staging -- ONE 16-bit array per layer instead of two.
+__device__ __forceinline__ f16x8 pack_acc_f16(const f32x16& acc, int s) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (_Float16)acc[8 * s + j];
+  return r;
+}
+__device__ __forceinline__ void stash_store(void* p, const f16x8& v) {
+#if NPP_STASH_NT
+  __builtin_nontemporal_store(v, (f16x8*)p);
+#else
+  *(f16x8*)p = v;
+#endif
+}
 
 // Workgroup barrier for LDS hand-offs that leaves global memory traffic in flight.
 // __syncthreads() makes hipcc emit s_waitcnt vmcnt(0) first, which drains every outstanding
@@ -178,10 +195,16 @@ __device__ __forceinline__ void wring_fill(WRing<NTW>& r, const bf16x8* __restri
 // to KSTOT (a multiple of 4) schedule positions, so that every part starts at ring slot 0:
 // positions >= KSREAL issue no MFMA and load nothing, they only keep the refill cadence.
 // Activation fragments of k-step ks sit at LDS k-step (ks - KS0 + ks_lds0) of `region`.
-template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT>
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `hook(ks - KS0)` is called once per schedule position, between the activation-fragment reads
+// and the MFMAs: independent VALU / LDS work placed there (the embedding generator) issues in
+// the shadow of the MFMAs of the same wave.
+template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT, typename Hook = NoHook>
 __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
                                          const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp, int nt0,
-                                         const Lane& L, WRing<NTW>& ring) {
+                                         const Lane& L, WRing<NTW>& ring, const Hook& hook = Hook()) {
   static_assert(KSTOT % kRD == 0 && KSREAL <= KSTOT && KS1 <= KSTOT, "ring schedule");
   // activation fragments are read one k-step ahead of the MFMAs that use them (LDS latency
   // ~130+ cycles would otherwise serialise every k-step behind its own reads)
@@ -207,6 +230,7 @@ __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* re
 #pragma unroll
         for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = mfma_bf16(ring.w[slot][nt], x[bt], acc[nt][bt]);
     }
+    hook(ks - KS0);
     if (ks + kRD < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + kRD, nt0, L.lane);
     else if (ks + kRD >= KSTOT && next_wp) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
     asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads

@@ -177,11 +177,4 @@ NPP_HD int64_t wfmt_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_of
 // inverse of perm16 on the 16 columns of a k-step: column c -> (hh, j)
 NPP_HD int unperm_hh(int c) { return (c >> 2) & 1; }
 NPP_HD int unperm_j(int c) { return ((c >> 3) << 2) | (c & 3); }
-// s-stash (snake derivative, bf16, fragment order): slots 0..7 = L0..L7, 8 = S (256
-// wide), 9 = P (128 wide).  Per layer [wg][nt][bt][s][64][8].
-NPP_HD int64_t sstash_off_bytes(int slot, int64_t Bp) {
-  return (int64_t)slot * Bp * kW * 2;  // slot 9 (P) is last and only half as wide
-}
-NPP_HD int64_t sstash_bytes(int64_t Bp) { return 9 * Bp * kW * 2 + Bp * (kW / 2) * 2; }
-
 }  // namespace npp

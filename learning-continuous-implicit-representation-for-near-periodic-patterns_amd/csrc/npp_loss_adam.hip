@@ -71,13 +71,16 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict
 
 // torch.optim.Adam single-tensor maths (helpers.py:164): the gradient is the sum of the
 // split-K slabs written by npp_mlp_wgrad, so this kernel is also the wgrad reduction.
+// hp != nullptr: step_size and 1/sqrt(1 - b2^t) are read from device memory ([0], [1]) so that a
+// captured HIP graph can be replayed with the values of the current step.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    int64_t n, int n_slabs, int64_t slab_stride,
                                                    float step_size, float b1, float b2, float inv_sqrt_bc2,
-                                                   float eps) {
+                                                   float eps, const float* __restrict__ hp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (hp) { step_size = hp[0]; inv_sqrt_bc2 = hp[1]; }
   float gi = 0.0f;
   for (int s = 0; s < n_slabs; ++s) gi += g[(int64_t)s * slab_stride + i];
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -117,6 +120,19 @@ extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
-                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps);
+                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps,
+                     (const float*)nullptr);
   return check_launch("npp_adam_step");
+}
+
+extern "C" int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
+                                 int64_t slab_stride, float beta1, float beta2, float eps, const float* d_hp,
+                                 void* stream) {
+  if (n <= 0 || !d_p || !d_m || !d_v || !d_gslabs || n_slabs < 1 || !d_hp) {
+    set_error("npp_adam_step_dev: bad arguments");
+    return NPP_ERR_ARG;
+  }
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
+                     d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp);
+  return check_launch("npp_adam_step_dev");
 }

@@ -9,8 +9,8 @@
 // Same transposed formulation as the forward kernel: dA^T[k][b] = W^T[k][n] dZ^T[n][b]
 // with W^T pre-packed as MFMA A-operand fragments (npp_pack_weights, backward pack) and
 // the accumulator tile of one layer reused, after x snake'(z) and conversion to bf16, as
-// the B operand of the next.  snake'(z) = 1 + sin(2z) was stashed by the forward kernel
-// in fragment order, so it is read back with one 16-byte load per lane per fragment.
+// the B operand of the next.  snake'(z) = 1 + sin 2z is derived from the fp16 pre-activation
+// fragments the forward kernel stashed (one 16-byte load per lane per fragment).
 #include "npp_common.h"
 
 namespace npp {
@@ -25,7 +25,7 @@ struct BwdArgs {
   int64_t Bp;
   const bf16x8* wb;
   const float* params;
-  const bf16x8* sstash;
+  const char* actF;        // forward stash: fp16 z fragments of the snake layers (W-format)
   char* dzF;
 };
 
@@ -40,7 +40,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
 
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
 template <bool HAS_S>
-__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const bf16x8* sst, char* dz_array,
+__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const char* z_array, char* dz_array,
                                              int wg, int kt0, const Lane& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -51,9 +51,10 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
       if (HAS_S) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const bf16x8 sf = sst[((((int64_t)wg * kNT + ntg) * kNB + bt) * 2 + s) * 64 + L.lane];
+          const f16x8 zf = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h));
 #pragma unroll
-          for (int j = 0; j < 8; ++j) g[8 * s + j] *= (float)sf[j];
+          for (int j = 0; j < 8; ++j)      // snake'(z) = 1 + sin 2z  (activations.py:29-35)
+            g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
         }
       }
 #pragma unroll
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   const int64_t row0 = (int64_t)wg * kRowTile, Bp = A.Bp;
   const float* P = A.params;
   const int kt0 = 2 * L.wave;
-  auto ss = [&](int slot) { return (const bf16x8*)((const char*)A.sstash + sstash_off_bytes(slot, Bp)); };
+  auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, gridDim.x); };   // z of layer idx
   auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, gridDim.x); };
 
   // ---- sigmoid backward (helpers.py:56): draw = dpred * pred * (1 - pred); also dz_rgb^T
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) wr[c][r] = Wr[c * (kW / 2) + L.wave * 32 + acc_row(r, L.h)];
-    const bf16x8* sp = ss(9);
+    const char* zp = A.actF + wfmt_array_base(kActKsAP, gridDim.x);
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
       const int row = bt * 32 + L.b;
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 sf = sp[((((int64_t)wg * (kNT / 2) + L.wave) * kNB + bt) * 2 + s) * 64 + L.lane];
+        const f16x8 zf = *(const f16x8*)(zp + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[8 * s + j] *= (float)sf[j];
+        for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wb + bd.off16[BF2], wb + bd.off16[BS], kt0, L, ring);
-    bwd_epilogue<true>(acc, R0, ss(8), dzr(kDzS), wg, kt0, L);
+    bwd_epilogue<true>(acc, R0, zs(kActAS), dzr(kDzS), wg, kt0, L);
     wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     char* out = ((v - BF1) & 1) ? R1 : R0;
     zero_acc(acc);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wb + bd.off16[v], v == B1 ? nullptr : wb + bd.off16[v + 1], kt0, L, ring);
-    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, ss(out_layer), dzr(out_layer), wg, kt0, L);
+    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, zs(out_layer), dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }
 }
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 using namespace npp;
 
 extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
-                           const float* d_params, const void* d_sstash, void* d_dzT, void* stream) {
+                           const float* d_params, const void* d_actT, void* d_dzT, void* stream) {
   if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_bwd: K=%d", K); return NPP_ERR_ARG; }
   if (width != NPP_WIDTH) { set_error("npp_mlp_bwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_bwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
-  if (!d_dpred || !d_pred || !d_wb || !d_params || !d_sstash || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
-  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const bf16x8*)d_sstash, (char*)d_dzT};
+  if (!d_dpred || !d_pred || !d_wb || !d_params || !d_actT || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
+  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const char*)d_actT, (char*)d_dzT};
   const NetDesc d = make_desc(K);
   const BwdDesc bd = make_bwd_desc(K);
   const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);

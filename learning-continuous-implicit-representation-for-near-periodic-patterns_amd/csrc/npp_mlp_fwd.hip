@@ -17,11 +17,11 @@
 // into a double-buffered LDS ring by all four waves, overlapped with the MFMAs of the
 // previous chunk.  rgb_linear (128->3) is a VALU dot + wave shuffle + LDS reduction.
 //
-// In training mode the kernel also writes (a) the snake derivative 1+sin(2z) in bf16
-// fragment order (read back 1:1 by npp_mlp_bwd) and (b) every layer input -- including
-// the embedding slots -- as the same 16-byte fragments it exchanges through LDS, in the
-// "W-format" line layout of npp_layout.h that npp_mlp_wgrad copies linearly into LDS and
-// reads transposed (two coalesced 16-byte stores per accumulator tile).
+// In training mode the kernel also writes, as 16-byte fragments in the "W-format" line layout of
+// npp_layout.h (two coalesced streaming stores per accumulator tile): the pre-activation z of
+// every snake layer in fp16 (npp_mlp_bwd derives 1 + sin 2z from it, npp_mlp_wgrad derives the
+// layer input snake(z) while staging), the linear outputs f1 / f2 in bf16, and the embedding
+// slots in bf16.
 //
 // Algorithmic work: 2 * ((K+1)*462*256 + 11*256^2 + 384) FLOP per row;
 // the zero padding of 462 -> 480 slots per proposal is not counted.
@@ -73,7 +73,6 @@ struct FwdArgs {
   const bf16x8* wf;
   const float* params;
   float* pred;
-  bf16x8* sstash;    // nullable
   char* actF;        // nullable: W-format fragment arrays (npp_layout.h)
 };
 
@@ -117,6 +116,24 @@ __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, co
       sV[i * kRowTile + L.lane] = w.lin != 0.0f ? t - 1.0f : sv;
     }
   }
+}
+
+// One embedding fragment (k-step ks, batch tile bt): table entries, warped coordinates, sin.
+__device__ __forceinline__ bf16x8 gen_emb_frag1(const SlotEnt* ts, const float* sV, int ks, int bt, const Lane& L) {
+  SlotEnt ent[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ent[j] = ts[ks * 16 + L.h * 8 + j];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = *(const float*)((const char*)sV + (ent[j].code & 0xffff) + (bt * 32 + L.b) * 4);
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float ph = (ent[j].code & (1 << 17)) ? 0.25f : 0.0f;
+    const float sv = __builtin_amdgcn_sinf(fmaf(v[j], ent[j].frev, ph));
+    f[j] = (__bf16)((ent[j].code & (1 << 16)) ? v[j] : sv);
+  }
+  return f;
 }
 
 // Four embedding fragments (2 k-steps x 2 batch tiles) of this wave: loads first, then the
@@ -184,17 +201,29 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   STAMP(52);
   wg_barrier();
   STAMP(53);
-  gen_chunk(1);
-  STAMP(54);
-  mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring);
+  // chunk c is multiplied while chunk c+1 is generated: this wave's four fragments of the next
+  // chunk (2 k-steps x 2 batch tiles) are produced at schedule positions 0, 2, 4, 6 of the
+  // current one, so their LDS reads / v_sin / stores issue between the MFMAs.
+  auto hook_for = [&](int c_next) {
+    return [&, c_next](int pos) {
+      if ((pos & 1) || pos >= 8) return;
+      const int fi = pos >> 1, q = fi >> 1, bt = fi & 1;
+      const int ksl = 2 * L.wave + q, ks = kChunkKS * c_next + ksl;
+      if (ks < kKSEmb) {
+        const bf16x8 f = gen_emb_frag1(e.slots, sV, ks, bt, L);
+        lds_store_frag(lds_ring + (c_next & 1) * kChunkBytes, ksl, bt, L.lane, f);
+        if (STORE_EMB)
+          stash_store(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, ks, bt, L.b, L.h), f);
+      }
+    };
+  };
+  mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
   STAMP(55);
   wg_barrier();
   STAMP(56);
-  gen_chunk(2);
-  mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
+  mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
   wg_barrier();
-  gen_chunk(3);
-  mma_ring<16, 24, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring);
+  mma_ring<16, 24, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(3));
   wg_barrier();
   mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
   wg_barrier();
@@ -203,36 +232,30 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
 // Epilogue of a 256-wide (NTW=2 per wave) or 128-wide (NTW=1) layer.
 //  SNAKE: apply x + sin^2 x; else linear.   out: LDS region that receives the bf16
 //  fragments (k-step 2*ntile+s of the next layer), may be null.
-//  TRAIN: stash the derivative (fragment order) and the activation (feature-major).
+//  TRAIN: stash z (fp16, snake layers) or the linear output (bf16) in W-format.
 template <bool SNAKE, bool TRAIN, int NTW>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int nt0, int ntl /*tiles in layer*/,
-                                         bf16x8* sstash_layer, char* actF_array, int wg, const Lane& L,
-                                         bf16x8 (*keep)[kNB][2] = nullptr) {
+                                         char* stash_array, int wg, const Lane& L, bf16x8 (*keep)[kNB][2] = nullptr) {
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int ntg = nt0 + nt;
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
-      f32x16 a, ds;
+      if (TRAIN && SNAKE) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float z = acc[nt][bt][r];
-        if (SNAKE) {
-          if (TRAIN) { float av, dv; snake_fast2(z, av, dv); a[r] = av; ds[r] = dv; }
-          else a[r] = snake_fast(z);
-        } else {
-          a[r] = z;
-        }
+        for (int s = 0; s < 2; ++s)
+          stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), pack_acc_f16(acc[nt][bt], s));
       }
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = SNAKE ? snake_fast(acc[nt][bt][r]) : acc[nt][bt][r];
       acc[nt][bt] = a;   // callers that need the fp32 activation (P -> rgb) read it back
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(a, s);
         if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
         if (keep) keep[nt][bt][s] = f;
-        if (TRAIN && SNAKE)
-          stash_store(&sstash_layer[((((int64_t)wg * ntl + ntg) * kNB + bt) * 2 + s) * 64 + L.lane], pack_acc(ds, s));
-        if (TRAIN) stash_store(actF_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), f);
+        if (TRAIN && !SNAKE) stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), f);
       }
     }
   }
@@ -308,9 +331,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   }
   wg_barrier();
 
-  auto ss = [&](int slot) -> bf16x8* {
-    return TRAIN ? (bf16x8*)((char*)A_.sstash + sstash_off_bytes(slot, Bp)) : nullptr;
-  };
   auto arow = [&](int idx) -> char* { return TRAIN ? A_.actF + wfmt_array_base(idx * kKSAct, gridDim.x) : nullptr; };
 
   f32x16 acc[2][kNB];
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   init_bias<2>(acc, P + d.b_off[L0], nt0, L);
   mma_embedding<TRAIN, 2, kNT>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
   STAMP(1);
-  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, ss(0), arow(0), wg, L);
+  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, arow(0), wg, L);
   STAMP(2);
   wg_barrier();
   STAMP(3);
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     init_bias<2>(acc, P + d.b_off[l], nt0, L);
     mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
     STAMP(4 * l);
-    epilogue<true, TRAIN, 2>(acc, out, nt0, kNT, ss(l), arow(l), wg, L);
+    epilogue<true, TRAIN, 2>(acc, out, nt0, kNT, arow(l), wg, L);
     STAMP(4 * l + 1);
     wg_barrier();
     STAMP(4 * l + 2);
@@ -353,18 +373,18 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   STAMP(20);
   mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   STAMP(21);
-  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, ss(5), arow(5), wg, L);
+  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(5), wg, L);
   wg_barrier();
   STAMP(22);
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
   init_bias<2>(acc, P + d.b_off[L6], nt0, L);
   mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
-  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, ss(6), arow(6), wg, L);
+  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, arow(6), wg, L);
   wg_barrier();
   init_bias<2>(acc, P + d.b_off[L7], nt0, L);
   mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
-  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, ss(7), arow(7), wg, L);
+  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(7), wg, L);
   wg_barrier();
 
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
@@ -373,7 +393,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   init_bias<2>(acc, P + d.b_off[LF1], nt0, L);
   mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : nullptr, nt0, L, ring);
   if (!MULTI) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
-  epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, nullptr, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
+  epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
   wg_barrier();
 
   f32x16 accp[1][kNB];
@@ -387,13 +407,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
                                    A_.actF, wg, L, ring);
     }
     wring_fill<2, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
-    epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, ss(8), arow(kActAS), wg, L);
+    epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
     init_bias<2>(acc, P + d.b_off[LF2], nt0, L);
     mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF2), nullptr, nt0, L, ring);
     wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
-    epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, nullptr, arow(kActF2), wg, L);
+    epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
     wg_barrier();
     // f1 back into LDS (R1 is idle: every wave passed the barrier after reading a_s)
 #pragma unroll
@@ -412,8 +432,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
     mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), nullptr, L.wave, L, ringp);
   }
-  epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, ss(9),
-                           TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr, wg, L);
+  epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
+                           wg, L);
 
   STAMP(40);
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,
@@ -466,20 +486,18 @@ extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width,
-                           const void* d_wf, const float* d_params, float* d_pred, void* d_sstash, void* d_actT,
-                           void* stream) {
+                           const void* d_wf, const float* d_params, float* d_pred, void* d_actT, void* stream) {
   int rc = check_embed_cfg(cfg, "npp_mlp_fwd");
   if (rc) return rc;
   if (width != NPP_WIDTH) { set_error("npp_mlp_fwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_fwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
   if (!d_coords_yx || !d_wf || !d_params || !d_pred) { set_error("npp_mlp_fwd: null pointer"); return NPP_ERR_ARG; }
-  if ((d_sstash == nullptr) != (d_actT == nullptr)) { set_error("npp_mlp_fwd: sstash and actT must both be given or both be NULL"); return NPP_ERR_ARG; }
   if (Bp / kRowTile > 0x7fffffffLL) { set_error("npp_mlp_fwd: Bp too large"); return NPP_ERR_ARG; }
   const EmbedDev e = make_embed_dev(*cfg);
   const NetDesc d = make_desc(cfg->K);
-  FwdArgs A{d_coords_yx, Bp, (const bf16x8*)d_wf, d_params, d_pred, (bf16x8*)d_sstash, (char*)d_actT};
+  FwdArgs A{d_coords_yx, Bp, (const bf16x8*)d_wf, d_params, d_pred, (char*)d_actT};
   const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreads);
-  const bool train = d_sstash != nullptr, multi = cfg->K > 1;
+  const bool train = d_actT != nullptr, multi = cfg->K > 1;
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH(T, M)                                                                          \
   do {                                                                                            \

@@ -35,6 +35,7 @@ struct WJob {
   int32_t b_ks0, b_nks, n;     // input array inside actF, k-steps, valid inputs / emb slots
   int32_t colmode, col0;       // 0: col = col0 + idx ; 1: col = col0 + emb_col(slot idx), pad slots skipped
   int32_t ld, bias_on;         // reference row stride (n_in) ; 1 = this job also produces db
+  int32_t b_is_z, pad_;        // input array holds fp16 pre-activations: layer input = snake(z)
   int64_t w_off, b_off;        // float offsets in the parameter blob
   int32_t tile0, tiles_n;      // first global tile index, tiles along n
 };
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
       st.b[i] = off < b_bytes ? *(const u32x4*)(gB + g * b_stride + off) : z;
     }
   };
+  const bool b_is_z = J.b_is_z != 0;
   auto sstore = [&](const Stage& st, int buf) {
     char* sA = smem + buf * 2 * kWTileBytes;
     char* sB = sA + kWTileBytes;
@@ -105,7 +107,15 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     for (int i = 0; i < 4; ++i) {
       const int off = (tid + kWThreads * i) * 16;
       *(u32x4*)(sA + off) = st.a[i];
-      *(u32x4*)(sB + off) = st.b[i];
+      if (b_is_z) {                  // layer input = snake(z): once per element per workgroup tile
+        const f16x8 z = __builtin_bit_cast(f16x8, st.b[i]);
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (__bf16)snake_fast((float)z[j]);
+        *(bf16x8*)(sB + off) = a;
+      } else {
+        *(u32x4*)(sB + off) = st.b[i];
+      }
     }
   };
   // per-lane fragment offsets: feature tile (wm|wn)*2 + i, k-step t (4 per workgroup tile)
@@ -198,8 +208,10 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 static int build_jobs(int K, WArgs& A) {
   const NetDesc d = make_desc(K);
   int nj = 0, tile = 0;
-  auto add = [&](int layer, int a_ks0, int a_nks, int b_ks0, int b_nks, int n, int colmode, int col0, int bias_on) {
+  auto add = [&](int layer, int a_ks0, int a_nks, int b_ks0, int b_nks, int n, int colmode, int col0, int bias_on,
+                 int b_is_z) {
     WJob& j = A.jobs[nj++];
+    j.b_is_z = b_is_z;
     j.a_ks0 = a_ks0; j.a_nks = a_nks; j.m = d.n_out[layer];
     j.b_ks0 = b_ks0; j.b_nks = b_nks; j.n = n;
     j.colmode = colmode; j.col0 = col0;
@@ -210,11 +222,12 @@ static int build_jobs(int K, WArgs& A) {
     tile += ((j.m + kWT - 1) / kWT) * j.tiles_n;
   };
   const int A16 = kKSAct;
+  // source arrays 0..7 (L0..L7 outputs) and a_s, a_p hold z (fp16); f1 / f2 are linear (bf16)
   auto act = [&](int layer, int dz_idx, int src_idx, int col0, int bias_on) {
-    add(layer, dz_idx * A16, A16, src_idx * A16, A16, kW, 0, col0, bias_on);
+    add(layer, dz_idx * A16, A16, src_idx * A16, A16, kW, 0, col0, bias_on, src_idx != kActF1 && src_idx != kActF2);
   };
   auto emb = [&](int layer, int dz_idx, int p, int col0, int bias_on) {
-    add(layer, dz_idx * A16, A16, kActKsEmb0 + p * kKSEmb, kKSEmb, kEmbSlots, 1, col0, bias_on);
+    add(layer, dz_idx * A16, A16, kActKsEmb0 + p * kKSEmb, kKSEmb, kEmbSlots, 1, col0, bias_on, 0);
   };
   emb(L0, 0, 0, 0, 1);
   for (int l = L1; l <= L4; ++l) act(l, l, l - 1, 0, 1);
@@ -227,12 +240,12 @@ static int build_jobs(int K, WArgs& A) {
     act(LS, kDzS, kActF1, 0, 1);
     for (int p = 1; p < K; ++p) emb(LS, kDzS, p, kW + (p - 1) * kE, 0);
     act(LF2, kDzF2, kActAS, 0, 1);
-    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1);
-    add(LP, kDzKsP, A16 / 2, kActF2 * A16, A16, kW, 0, kW, 0);
+    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1, 0);
+    add(LP, kDzKsP, A16 / 2, kActF2 * A16, A16, kW, 0, kW, 0, 0);
   } else {
-    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1);
+    add(LP, kDzKsP, A16 / 2, kActF1 * A16, A16, kW, 0, 0, 1, 0);
   }
-  add(LRGB, kDzKsRgb, 2, kActKsAP, A16 / 2, kW / 2, 0, 0, 1);
+  add(LRGB, kDzKsRgb, 2, kActKsAP, A16 / 2, kW / 2, 0, 0, 1, 1);
   A.njobs = nj;
   return tile;
 }

@@ -80,23 +80,23 @@ def train_workspace(K, Bp, ksplit, width=NPP_WIDTH):
     return [int(s) for s in sizes]
 
 
-def mlp_fwd(coords, cfg, wf, params, pred=None, sstash=None, actT=None, width=NPP_WIDTH):
+def mlp_fwd(coords, cfg, wf, params, pred=None, actF=None, width=NPP_WIDTH):
     """Fused embedder + MLP + sigmoid: coords (Bp,2) -> pred (Bp,3).  Replaces the table
     gather + render() (train.py:166-189; helpers.py:41-62; networks.py:56-95)."""
     _req(coords, torch.int32, "coords")
     bp = coords.shape[0]
     if pred is None:
         pred = torch.empty((bp, 3), dtype=torch.float32, device=coords.device)
-    check(lib().npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(sstash),
-                            _p(actT), _stream()), "npp_mlp_fwd")
+    check(lib().npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(actF), _stream()),
+          "npp_mlp_fwd")
     return pred
 
 
-def mlp_bwd(dpred, pred, K, wb, params, sstash, dzT, width=NPP_WIDTH):
+def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
     _req(dpred, torch.float32, "dpred")
     _req(pred, torch.float32, "pred", dpred.shape)
-    check(lib().npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(sstash),
-                            _p(dzT), _stream()), "npp_mlp_bwd")
+    check(lib().npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                            _stream()), "npp_mlp_bwd")
 
 
 def mlp_wgrad(dzT, actT, Bp, K, ksplit, gslabs, width=NPP_WIDTH):
@@ -185,3 +185,10 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
         ws = _lp_ws[key] = torch.empty(int(lib().npp_lpips_workspace_bytes(C)), dtype=torch.uint8, device=f0.device)
     check(lib().npp_lpips_layer(_p(f0), _p(f1), N, C, hw, _p(lin), _p(latents), _p(spline), n_knots, x_scale, scale,
                                 _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")
+
+
+def adam_step_dev(p, m, v, gslabs, n_slabs, slab_stride, hp, b1=0.9, b2=0.999, eps=1e-8):
+    """Adam step whose step_size / bias correction come from the device tensor hp[0:2]
+    (graph-replayable form of adam_step)."""
+    check(lib().npp_adam_step_dev(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, b1, b2, eps, _p(hp),
+                                  _stream()), "npp_adam_step_dev")
