@@ -195,12 +195,41 @@ def main():
     flops = {"mlp_fwd_train": 2 * fwd_macs * n_rows,
              "mlp_bwd_chain": 2 * (train_macs - 2 * fwd_macs) * n_rows,   # dgrad = fwd - embedding part
              "mlp_wgrad": 2 * fwd_macs * n_rows}
+    # Algorithmic HBM bytes per launch: 16-bit stash fragments, every array once.
+    E, W2 = 462, 256
+    emb_cols = K * 480
+    z_cols = 10 * W2 + W2 // 2                      # fp16 z of L0..L7, S, P
+    lin_cols = 2 * W2                               # bf16 f1, f2
+    dz_cols = 11 * W2 + W2 // 2 + 32               # dz of every layer (+ the padded rgb rows)
+    wjob_rows = (W2 + 480) * 2 + (W2 + W2) * 10 + (W2 + 480) * (K - 1) + (W2 // 2 + W2) * 2 + (32 + W2 // 2)
+    n_par = net.n_params
+    hbm_bytes = {"mlp_fwd_train": bp * (8 + 12 + 2 * (z_cols + lin_cols + emb_cols)) + 2.4e6,
+                 "mlp_bwd_chain": bp * (24 + 2 * z_cols + 2 * dz_cols) + 1.5e6,
+                 "mlp_wgrad": bp * 2 * wjob_rows + 4 * n_par * args.ksplit}
     dom = max(flops, key=lambda k: kt[k])
-    roofline = {"bound": "mfma", "kernel": dom, "achieved": flops[dom] / kt[dom] / 1e12, "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": flops[dom] / kt[dom] / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
-                "avg_launch_us": kt[dom] * 1e6,
+    tf = {k: flops[k] / kt[k] / 1e12 for k in flops}
+    gbs = {k: hbm_bytes[k] / kt[k] / 1e9 for k in flops}
+    # the roof that binds the dominant kernel is the one it sits closer to
+    hbm_bound = gbs[dom] / PEAK_HBM_GBS > tf[dom] / PEAK_BF16_TFLOPS
+    measured = None
+    try:     # PMC-measured HBM traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+             # passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")))
+        key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
+               "mlp_wgrad": "npp::wgrad_kernel"}[dom]
+        measured = (2 * pm["FETCH_SIZE"][key] + pm["WRITE_SIZE"][key]) * 1024
+    except Exception:
+        pass
+    roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+                "achieved": gbs[dom] if hbm_bound else tf[dom], "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": gbs[dom] / PEAK_HBM_GBS if hbm_bound else tf[dom] / PEAK_BF16_TFLOPS,
+                "traffic": measured, "algorithmic_bytes_per_launch": hbm_bytes[dom],
+                "algorithmic_flops_per_launch": flops[dom], "avg_launch_us": kt[dom] * 1e6,
                 "all_kernels_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
-                "all_kernels_tflops": {k: round(flops[k] / kt[k] / 1e12, 2) for k in flops},
+                "all_kernels_tflops": {k: round(v, 1) for k, v in tf.items()},
+                "all_kernels_hbm_GBs": {k: round(v, 0) for k, v in gbs.items()},
+                "all_kernels_mfma_frac": {k: round(v / PEAK_BF16_TFLOPS, 4) for k, v in tf.items()},
                 "step_mfma_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
     render_px_s = H * H / kt["render_fwd_512sq"]
 
