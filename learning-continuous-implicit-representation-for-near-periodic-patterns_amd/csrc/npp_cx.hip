@@ -43,18 +43,19 @@ __global__ void patch_gather_kernel(const float* __restrict__ img, const float* 
 // ---------------------------------------------------------------- K6 contextual loss
 struct CxWs {           // workspace carve (floats unless noted)
   float* mu;            // [C]
-  float* inx;           // [N*hw]  1 / max(|x - mu|, 1e-12)
-  float* iny;           // [N*hw]
+  float* ssx;           // [N*hw]  sum_c (x - mu)^2   (inverse norm = 1 / max(sqrt(.), 1e-12))
+  float* ssy;           // [N*hw]
   unsigned* dmin;       // [N*hw]  row min of D as float bits (D >= 0: unsigned order == float order)
   float* s;             // [N*hw]  row sum of w
   unsigned* cmax;       // [N*hw]  column max of cx as float bits
+  float* dot;           // [N*hw]  xh . dxh per position (normalisation backward)
   float* g;             // [N]     dL/dcxn / J
   float* D;             // [N*hw*hw]
   float* cx;            // [N*hw*hw]  cx, then d raw
 };
 
 __host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
-  return (int64_t)C + 5LL * N * hw + N + 2LL * N * hw * hw + 64;
+  return (int64_t)C + 6LL * N * hw + N + 2LL * N * hw * hw + 64;
 }
 
 __host__ inline CxWs carve(float* base, int N, int C, int hw) {
@@ -62,19 +63,23 @@ __host__ inline CxWs carve(float* base, int N, int C, int hw) {
   float* p = base;
   w.mu = p; p += (C + 15) / 16 * 16;
   const int64_t nh = (int64_t)N * hw;
-  w.inx = p; p += nh;
-  w.iny = p; p += nh;
+  w.ssx = p; p += nh;
+  w.ssy = p; p += nh;
   w.dmin = (unsigned*)p; p += nh;
   w.s = p; p += nh;
   w.cmax = (unsigned*)p; p += nh;
+  w.dot = p; p += nh;
   w.g = p; p += (N + 15) / 16 * 16;
   w.D = p; p += nh * hw;
   w.cx = p;
   return w;
 }
 
-// mu_c = mean over (n, pos) of y   (functional.py:141) ; one workgroup per channel
-__global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw, float* __restrict__ mu) {
+__device__ __forceinline__ float inv_norm(float ss) { return 1.0f / fmaxf(sqrtf(ss), 1e-12f); }   // F.normalize eps
+
+// mu_c = mean over (n, pos) of y (functional.py:141), one workgroup per channel; the workgroups
+// also clear the per-position accumulators of this call.
+__global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw, CxWs w) {
   __shared__ float red[4];
   const int c = blockIdx.x;
   float acc = 0.0f;
@@ -83,115 +88,170 @@ __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) mu[c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)N * hw);
+  if (threadIdx.x == 0) w.mu[c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)N * hw);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)N * hw; t += (int64_t)gridDim.x * blockDim.x) {
+    w.ssx[t] = 0.0f; w.ssy[t] = 0.0f; w.dot[t] = 0.0f;
+    w.dmin[t] = 0x7f800000u;   // +inf
+    w.cmax[t] = 0u;
+  }
 }
 
-// inverse L2 norms over channels of (x - mu), (y - mu) per position (F.normalize eps 1e-12);
-// also initialises the row-min / column-max cells.
-__global__ void cx_norm_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mu,
-                               int N, int C, int hw, CxWs w) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)N * hw) return;
-  const int n = (int)(t / hw), p = (int)(t - (int64_t)n * hw);
+// sum over channels of (x - mu)^2, (y - mu)^2 per position: block = 64 positions x 4 channel
+// lanes, grid.y = channel groups of 64; partial sums meet in two float atomics per position.
+__global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
+                                                       int C, int hw, CxWs w) {
+  __shared__ float red[2][4][64];
+  const int pl = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 64 + pl;
+  const bool live = t < (int64_t)N * hw;
+  const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
   float sx = 0.0f, sy = 0.0f;
-  for (int c = 0; c < C; ++c) {
-    const float m = mu[c];
-    const float a = x[((int64_t)n * C + c) * hw + p] - m, b = y[((int64_t)n * C + c) * hw + p] - m;
-    sx = fmaf(a, a, sx);
-    sy = fmaf(b, b, sy);
+  const int c0 = blockIdx.y * 64;
+  if (live)
+    for (int c = c0 + cl; c < min(C, c0 + 64); c += 4) {
+      const float m = w.mu[c];
+      const float a = x[((int64_t)n * C + c) * hw + p] - m, b = y[((int64_t)n * C + c) * hw + p] - m;
+      sx = fmaf(a, a, sx);
+      sy = fmaf(b, b, sy);
+    }
+  red[0][cl][pl] = sx;
+  red[1][cl][pl] = sy;
+  __syncthreads();
+  if (cl == 0 && live) {
+    atomicAdd(&w.ssx[t], red[0][0][pl] + red[0][1][pl] + red[0][2][pl] + red[0][3][pl]);
+    atomicAdd(&w.ssy[t], red[1][0][pl] + red[1][1][pl] + red[1][2][pl] + red[1][3][pl]);
   }
-  w.inx[t] = 1.0f / fmaxf(sqrtf(sx), 1e-12f);
-  w.iny[t] = 1.0f / fmaxf(sqrtf(sy), 1e-12f);
-  w.dmin[t] = 0x7f800000u;   // +inf
-  w.cmax[t] = 0u;
 }
 
 // D = 1 - clamp(inx_i iny_j sum_c (x_ci - mu_c)(y_cj - mu_c), 0, 1), row minima by atomicMin.
-// One wave per 64x64 output tile (2x2 MFMA tiles); operands read straight from the NCHW
-// tensors: for a fixed channel the 32 positions of a fragment are contiguous (128-B segments).
+// Workgroup = 64 x 64 output tile of one sample, 4 waves of 32 x 32; the channel axis is streamed
+// through LDS in chunks of 32 ([32 c][64 pos] per operand, positions contiguous as in NCHW, so the
+// fp32 MFMA operand reads are conflict-free), double buffered.
+constexpr int kCxKc = 32;
 __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
                                                      int C, int hw, CxWs w) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) float sA[2][kCxKc][64];
+  __shared__ __attribute__((aligned(16))) float sB[2][kCxKc][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tiles = (hw + 63) / 64;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  if (wid >= (int64_t)N * tiles * tiles) return;
-  const int n = (int)(wid / (tiles * tiles));
-  const int tij = (int)(wid - (int64_t)n * tiles * tiles);
+  const int n = blockIdx.x / (tiles * tiles);
+  const int tij = blockIdx.x - n * tiles * tiles;
   const int i0 = (tij / tiles) * 64, j0 = (tij % tiles) * 64;
-  const int l31 = lane & 31, kh = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1, l31 = lane & 31, kh = lane >> 5;
   const float* xn = x + (int64_t)n * C * hw;
   const float* yn = y + (int64_t)n * C * hw;
-  int ia[2], jb[2];
+  const bool vec = (hw & 3) == 0;
+  float4 ra[2], rb[2];
+  auto gload = [&](int c0) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    ia[t] = min(i0 + 32 * t + l31, hw - 1);     // clamp: out-of-range rows/cols are discarded at the store
-    jb[t] = min(j0 + 32 * t + l31, hw - 1);
-  }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-#pragma unroll 4
-  for (int c0 = 0; c0 < C; c0 += 2) {
-    const int c = c0 + kh;
-    const float m = w.mu[c];
-    float av[2], bv[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      av[t] = xn[(int64_t)c * hw + ia[t]] - m;
-      bv[t] = yn[(int64_t)c * hw + jb[t]] - m;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-  }
-  // accumulator: column (lane & 31) = j, register r = row acc_row(r, lane >> 5) = i
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int j = j0 + 32 * b + l31;
-    const float sj = j < hw ? w.iny[(int64_t)n * hw + j] : 0.0f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + 32 * a + acc_row(r, kh);
-        if (i < hw && j < hw) {
-          const float raw = acc[a][b][r] * w.inx[(int64_t)n * hw + i] * sj;
-          const float d = 1.0f - fminf(fmaxf(raw, 0.0f), 1.0f);
-          w.D[((int64_t)n * hw + i) * hw + j] = d;
-          atomicMin(&w.dmin[(int64_t)n * hw + i], __float_as_uint(d));
-        }
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
+      const int c = c0 + row;
+      const float m = c < C ? w.mu[c] : 0.0f;
+      float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+      if (c < C) {
+        if (vec && i0 + col + 3 < hw) { const float4 q = *(const float4*)(xn + (int64_t)c * hw + i0 + col); va[0] = q.x; va[1] = q.y; va[2] = q.z; va[3] = q.w; }
+        else for (int e = 0; e < 4; ++e) if (i0 + col + e < hw) va[e] = xn[(int64_t)c * hw + i0 + col + e]; else va[e] = m;
+        if (vec && j0 + col + 3 < hw) { const float4 q = *(const float4*)(yn + (int64_t)c * hw + j0 + col); vb[0] = q.x; vb[1] = q.y; vb[2] = q.z; vb[3] = q.w; }
+        else for (int e = 0; e < 4; ++e) if (j0 + col + e < hw) vb[e] = yn[(int64_t)c * hw + j0 + col + e]; else vb[e] = m;
       }
+      ra[r] = make_float4(va[0] - m, va[1] - m, va[2] - m, va[3] - m);
+      rb[r] = make_float4(vb[0] - m, vb[1] - m, vb[2] - m, vb[3] - m);
     }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
+      *(float4*)&sA[buf][row][col] = ra[r];
+      *(float4*)&sB[buf][row][col] = rb[r];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < C; c0 += kCxKc) {
+    const bool has_next = c0 + kCxKc < C;
+    if (has_next) gload(c0 + kCxKc);
+#pragma unroll
+    for (int ks = 0; ks < kCxKc / 2; ++ks) {
+      const float a = sA[buf][2 * ks + kh][wi * 32 + l31];
+      const float b = sB[buf][2 * ks + kh][wj * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (has_next) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // accumulator: column (lane & 31) = j, register r = row acc_row(r, lane >> 5) = i.  The row
+  // minimum is reduced over the 32 columns of the half-wave first: one atomic per row and wave
+  // instead of one per element (the element-wise form was atomic-bound: 2 M atomics per call).
+  const int j = j0 + wj * 32 + l31;
+  const float sj = j < hw ? inv_norm(w.ssy[(int64_t)n * hw + j]) : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi * 32 + acc_row(r, kh);
+    float d = 2.0f;                                  // neutral for the minimum (D <= 1)
+    if (i < hw && j < hw) {
+      const float raw = acc[r] * inv_norm(w.ssx[(int64_t)n * hw + i]) * sj;
+      d = 1.0f - fminf(fmaxf(raw, 0.0f), 1.0f);
+      w.D[((int64_t)n * hw + i) * hw + j] = d;
+    }
+    float m = d;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    if (l31 == 0 && i < hw) atomicMin(&w.dmin[(int64_t)n * hw + i], __float_as_uint(m));
   }
 }
 
-// one wave per row (n, i): w = exp((1 - D/(dmin + 1e-5))/h), s = sum_j w, cx = w/s, column max.
+// w = exp((1 - D/(dmin + 1e-5))/h), s = sum_j w, cx = w/s, column maxima.  One wave walks kCxRows
+// consecutive rows of one sample and keeps the running column maxima of its lanes in registers:
+// one atomicMax per column per kCxRows rows.
+constexpr int kCxRows = 8;
+constexpr int kCxMaxCols = 32;        // columns per lane held in registers: hw <= 64 * 32 = 2048
 __global__ __launch_bounds__(256) void cx_rows_fwd_kernel(int N, int hw, float inv_h, CxWs w) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  if (row >= (int64_t)N * hw) return;
-  const int n = (int)(row / hw);
-  const float dm = __uint_as_float(w.dmin[row]) + 1e-5f;
-  const float* Dr = w.D + row * hw;
-  float* cr = w.cx + row * hw;
-  float s = 0.0f;
-  for (int j = lane; j < hw; j += 64) {
-    const float wv = __expf((1.0f - Dr[j] / dm) * inv_h);
-    cr[j] = wv;
-    s += wv;
+  const int groups = (hw + kCxRows - 1) / kCxRows;
+  const int64_t gid = (int64_t)blockIdx.x * 4 + wave;
+  if (gid >= (int64_t)N * groups) return;
+  const int n = (int)(gid / groups), r0 = (int)(gid - (int64_t)n * groups) * kCxRows;
+  float cmaxv[kCxMaxCols];
+#pragma unroll
+  for (int q = 0; q < kCxMaxCols; ++q) cmaxv[q] = 0.0f;
+  for (int rr = 0; rr < kCxRows && r0 + rr < hw; ++rr) {
+    const int64_t row = (int64_t)n * hw + r0 + rr;
+    const float dm = __uint_as_float(w.dmin[row]) + 1e-5f;
+    const float* Dr = w.D + row * hw;
+    float* cr = w.cx + row * hw;
+    float wv[kCxMaxCols];
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) {
+      const int j = lane + 64 * q;
+      wv[q] = j < hw ? __expf((1.0f - Dr[j] / dm) * inv_h) : 0.0f;
+      s += wv[q];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) w.s[row] = s;
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) {
+      const int j = lane + 64 * q;
+      if (j < hw) {
+        const float c = wv[q] * inv;
+        cr[j] = c;
+        cmaxv[q] = fmaxf(cmaxv[q], c);
+      }
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) w.s[row] = s;
-  const float inv = 1.0f / s;
-  for (int j = lane; j < hw; j += 64) {
-    const float c = cr[j] * inv;
-    cr[j] = c;
-    atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(c));
+#pragma unroll
+  for (int q = 0; q < kCxMaxCols; ++q) {
+    const int j = lane + 64 * q;
+    if (j < hw) atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(cmaxv[q]));
   }
 }
 
@@ -262,75 +322,102 @@ __global__ __launch_bounds__(256) void cx_rows_bwd_kernel(int N, int hw, float i
   }
 }
 
-// dxh[c][i] = sum_j draw[i][j] * (y[c][j] - mu_c) * iny[j]  -> written as [n][c][i] scratch (= out, then
-// finished in place by cx_dx_finish).  Output tile per wave: 32 channels x 64 positions; both
-// operands are contiguous along j, so each lane reads 8 consecutive j (two 16-byte loads) for its
-// row and the 8 products go through 8 MFMAs whose two k-slots are the lane halves.
-__global__ __launch_bounds__(256) void cx_dx_kernel(const float* __restrict__ y, int N, int C, int hw, CxWs w,
-                                                    float* __restrict__ dxh) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int itiles = (hw + 63) / 64, ctiles = C / 32;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  if (wid >= (int64_t)N * ctiles * itiles) return;
-  const int n = (int)(wid / (ctiles * itiles));
-  const int rem = (int)(wid - (int64_t)n * ctiles * itiles);
-  const int c0 = (rem / itiles) * 32, i0 = (rem % itiles) * 64;
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int c = c0 + l31;
-  const float m = w.mu[c];
-  const float* yr = y + ((int64_t)n * C + c) * hw;
-  const float* iny = w.iny + (int64_t)n * hw;
-  const float* dr[2];
+// dxh[c][i] = sum_j draw[i][j] * yh[c][j], yh = (y - mu_c) * iny[j].  Workgroup = 64 channels x 64
+// positions, 4 waves of 32 x 32; both operands are contiguous along the contraction index j, so a
+// chunk of 32 columns is staged TRANSPOSED into LDS ([32 j][64 rows + 1 pad]: the fp32 MFMA reads
+// 32 consecutive rows of one j) and double buffered.  The epilogue also accumulates the per-position
+// dot product xh . dxh that the normalisation backward needs.
+__global__ __launch_bounds__(256) void cx_dx_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C,
+                                                    int hw, CxWs w, float* __restrict__ dxh) {
+  __shared__ float sA[2][kCxKc][65];
+  __shared__ float sB[2][kCxKc][65];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int itiles = (hw + 63) / 64, ctiles = (C + 63) / 64;
+  const int n = blockIdx.x / (ctiles * itiles);
+  const int rem = blockIdx.x - n * ctiles * itiles;
+  const int c0 = (rem / itiles) * 64, i0 = (rem % itiles) * 64;
+  const int wc = wave >> 1, wi = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const bool vec = (hw & 3) == 0;
+  const float* iny_ss = w.ssy + (int64_t)n * hw;
+  float4 ra[2], rb[2];
+  auto gload = [&](int j0) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) dr[t] = w.cx + ((int64_t)n * hw + min(i0 + 32 * t + l31, hw - 1)) * hw;
-  f32x16 acc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-  for (int j0 = 0; j0 < hw; j0 += 16) {
-    const int jb = j0 + 8 * kh;                      // this lane half's 8 columns
-    float a[8], b0[8], b1[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = jb + q;
-      const bool ok = j < hw;
-      a[q] = ok ? (yr[j] - m) * iny[j] : 0.0f;       // A[m = channel][k = j]
-      b0[q] = ok ? dr[0][j] : 0.0f;                  // B[k = j][n = position]
-      b1[q] = ok ? dr[1][j] : 0.0f;
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 256 * r, row = idx >> 3, col = (idx & 7) * 4;     // 64 rows x 8 float4
+      const int j = j0 + col;
+      float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+      const int c = c0 + row, i = i0 + row;
+      if (c < C) {
+        const float m = w.mu[c];
+        const float* yr = y + ((int64_t)n * C + c) * hw;
+        if (vec && j + 3 < hw) { const float4 q = *(const float4*)(yr + j); va[0] = q.x - m; va[1] = q.y - m; va[2] = q.z - m; va[3] = q.w - m; }
+        else for (int e = 0; e < 4; ++e) if (j + e < hw) va[e] = yr[j + e] - m;
+        for (int e = 0; e < 4; ++e) va[e] = (j + e < hw) ? va[e] * inv_norm(iny_ss[j + e]) : 0.0f;
+      }
+      if (i < hw) {
+        const float* dr = w.cx + ((int64_t)n * hw + i) * hw;
+        if (vec && j + 3 < hw) { const float4 q = *(const float4*)(dr + j); vb[0] = q.x; vb[1] = q.y; vb[2] = q.z; vb[3] = q.w; }
+        else for (int e = 0; e < 4; ++e) if (j + e < hw) vb[e] = dr[j + e];
+      }
+      ra[r] = make_float4(va[0], va[1], va[2], va[3]);
+      rb[r] = make_float4(vb[0], vb[1], vb[2], vb[3]);
     }
+  };
+  auto sstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b0[q], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b1[q], acc[1], 0, 0, 0);
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 256 * r, row = idx >> 3, col = (idx & 7) * 4;
+      sA[buf][col + 0][row] = ra[r].x; sA[buf][col + 1][row] = ra[r].y; sA[buf][col + 2][row] = ra[r].z; sA[buf][col + 3][row] = ra[r].w;
+      sB[buf][col + 0][row] = rb[r].x; sB[buf][col + 1][row] = rb[r].y; sB[buf][col + 2][row] = rb[r].z; sB[buf][col + 3][row] = rb[r].w;
     }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int j0 = 0; j0 < hw; j0 += kCxKc) {
+    const bool has_next = j0 + kCxKc < hw;
+    if (has_next) gload(j0 + kCxKc);
+#pragma unroll
+    for (int ks = 0; ks < kCxKc / 2; ++ks) {
+      const float a = sA[buf][2 * ks + kh][wc * 32 + l31];     // A[m = channel][k = j]
+      const float b = sB[buf][2 * ks + kh][wi * 32 + l31];     // B[k = j][n = position]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (has_next) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   // accumulator: column = position (lane & 31), rows = channels
+  const int i = i0 + wi * 32 + l31;
+  if (i < hw) {
+    const float inx = inv_norm(w.ssx[(int64_t)n * hw + i]);
+    float part = 0.0f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = i0 + 32 * t + l31;
-    if (i < hw) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dxh[((int64_t)n * C + c0 + acc_row(r, kh)) * hw + i] = acc[t][r];
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + wc * 32 + acc_row(r, kh);
+      if (c < C) {
+        const int64_t o = ((int64_t)n * C + c) * hw + i;
+        dxh[o] = acc[r];
+        part = fmaf((x[o] - w.mu[c]) * inx, acc[r], part);
+      }
     }
+    atomicAdd(&w.dot[(int64_t)n * hw + i], part);
   }
 }
 
-// dx = (dxh - xh (xh . dxh)) * inx, xh = (x - mu) inx ; thread per (n, position), in place on dxh
+// dx = (dxh - xh (xh . dxh)) * inx, xh = (x - mu) inx ; elementwise, in place on dxh
 __global__ void cx_dx_finish_kernel(const float* __restrict__ x, int N, int C, int hw, CxWs w, float* __restrict__ dx) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)N * hw) return;
-  const int n = (int)(t / hw), p = (int)(t - (int64_t)n * hw);
-  const float inx = w.inx[t];
-  float dot = 0.0f;
-  for (int c = 0; c < C; ++c) {
-    const int64_t o = ((int64_t)n * C + c) * hw + p;
-    dot = fmaf((x[o] - w.mu[c]) * inx, dx[o], dot);
-  }
-  for (int c = 0; c < C; ++c) {
-    const int64_t o = ((int64_t)n * C + c) * hw + p;
-    dx[o] = (dx[o] - (x[o] - w.mu[c]) * inx * dot) * inx;
-  }
+  if (t >= (int64_t)N * C * hw) return;
+  const int p = (int)(t % hw);
+  const int64_t nc = t / hw;
+  const int c = (int)(nc % C), n = (int)(nc / C);
+  const float inx = inv_norm(w.ssx[(int64_t)n * hw + p]);
+  dx[t] = (dx[t] - (x[t] - w.mu[c]) * inx * w.dot[(int64_t)n * hw + p]) * inx;
 }
 
 }  // namespace npp
@@ -359,8 +446,8 @@ extern "C" int64_t npp_cx_workspace_bytes(int N, int C, int hw) {
 extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
                               const float* d_weight, float scale, float* d_loss, float* d_dfx, void* d_workspace,
                               int64_t workspace_bytes, void* stream) {
-  if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f)) {
-    set_error("npp_cx_fwd_bwd: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
+  if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f) || hw > 64 * kCxMaxCols) {
+    set_error("npp_cx_fwd_bwd: bad arguments (N=%d C=%d hw=%d; hw <= 2048)", N, C, hw);
     return NPP_ERR_ARG;
   }
   if (workspace_bytes < 4 * cx_ws_floats(N, C, hw)) { set_error("npp_cx_fwd_bwd: workspace too small"); return NPP_ERR_ARG; }
@@ -368,18 +455,21 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
   const CxWs w = carve((float*)d_workspace, N, C, hw);
   const int64_t nh = (int64_t)N * hw;
   const float inv_h = 1.0f / band_width;
-  hipLaunchKernelGGL(cx_mean_kernel, dim3(C), dim3(256), 0, s, d_fy, N, C, hw, w.mu);
-  hipLaunchKernelGGL(cx_norm_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, d_fx, d_fy, w.mu, N, C, hw, w);
-  const int tiles = (hw + 63) / 64;
-  hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 3) / 4)), dim3(256), 0, s, d_fx, d_fy, N,
+  hipLaunchKernelGGL(cx_mean_kernel, dim3(C), dim3(256), 0, s, d_fy, N, C, hw, w);
+  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N,
                      C, hw, w);
-  hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+  const int tiles = (hw + 63) / 64;
+  hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)((int64_t)N * tiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
+  const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
+  hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
   hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, w);
   if (d_dfx) {
     hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
-    const int64_t waves = (int64_t)N * (C / 32) * tiles;
-    hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, d_fy, N, C, hw, w, d_dfx);
-    hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx);
+    const int ctiles = (C + 63) / 64;
+    hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,
+                       d_dfx);
+    const int64_t ne = nh * C;
+    hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx);
   }
   return check_launch("npp_cx_fwd_bwd");
 }

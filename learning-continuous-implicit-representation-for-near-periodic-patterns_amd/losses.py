@@ -45,6 +45,7 @@ class _Trunk(nn.Module):
             p.requires_grad = False     # vgg.py:26-28, pretrained_networks.py:116-118
 
     def forward(self, x):
+        x = x.contiguous()          # strided views make MIOpen fall back to its naive "nonpacked" kernels
         outs = []
         for i, m in enumerate(self.features):
             x = m(x)
