@@ -242,7 +242,7 @@ def main():
         from npp_amd import EmbedCfg
         cfg4 = EmbedCfg.make(a4, p4, oracle.SEED0_FREQS, (1024, 1024))
         out = {}
-        for name, dt, prec, bpe in (("fp32_precise", torch.float32, True, 4), ("bf16_fast", torch.bfloat16, False, 2)):
+        for name, dt, prec, bpe in (("fp32_precise", torch.float32, True, 4), ("fp32", torch.float32, False, 4), ("bf16", torch.bfloat16, False, 2)):
             t_emb = timed(lambda: ops.embed_fwd(grid, cfg4, dt, precise=prec), reps=5)
             nbytes = grid.shape[0] * (8 + bpe * 3 * 462)
             out[name] = {"ms": t_emb * 1e3, "pixels_per_s": grid.shape[0] / t_emb, "GB_per_s": nbytes / t_emb / 1e9,

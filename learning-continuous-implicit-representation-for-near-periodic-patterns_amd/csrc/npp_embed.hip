@@ -47,6 +47,11 @@ constexpr int kEmbRows = 64;     // rows per workgroup (one per lane in phase 1)
 constexpr int kEmbThreads = 256;
 constexpr int kSvStride = NPP_MAX_K * 22 + 1;   // odd stride: conflict-free row-per-lane writes
 
+// Per output column (reference order, models/embedder.py:41-44,56): index of its warped coordinate,
+// Fourier frequency and kind -- built once per workgroup so the streaming loop does no index
+// arithmetic beyond one 8-byte LDS read per value.
+struct ColEnt { float f; int code; };            // code = v index | identity << 16 | cos << 17
+
 // Phase 1: the K*22 warped values of 64 rows into LDS: lane = row, the warp index is
 // wave-uniform (wave w takes jobs w, w+4, ...) so the constant tables are read through
 // scalar loads.  Phase 2: every thread produces column PAIRS (462 is even) so stores are
@@ -56,14 +61,23 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
                                                             int64_t N, EmbedDev e,
                                                             void* __restrict__ out) {
   __shared__ float sv[kEmbRows * kSvStride];
+  __shared__ ColEnt tab[NPP_MAX_K * kE];
   __shared__ float sfreq[NPP_N_FREQ];   // lane-varying index: keep it out of the kernarg struct
   const int tid = threadIdx.x;
   if (tid == 0) {
 #pragma unroll
     for (int j = 0; j < NPP_N_FREQ; ++j) sfreq[j] = PRECISE ? e.freq[j] : e.freq_rev[j];
   }
-  const int64_t row0 = (int64_t)blockIdx.x * kEmbRows;
+  __syncthreads();
   const int K = e.K;
+  for (int c = tid; c < K * kE; c += kEmbThreads) {
+    const int p = c / kE, cc = c - p * kE, blk = cc / 22, i = cc - blk * 22;
+    ColEnt en;
+    en.code = (p * 22 + i) | (blk == 0 ? 1 << 16 : 0) | ((blk > 0 && ((blk - 1) & 1)) ? 1 << 17 : 0);
+    en.f = blk == 0 ? 0.0f : sfreq[(blk - 1) >> 1];
+    tab[c] = en;
+  }
+  const int64_t row0 = (int64_t)blockIdx.x * kEmbRows;
   {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -74,43 +88,57 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
       sv[lane * kSvStride + job] = warp_value<PRECISE>(e, job / 22, job % 22, y, x);
   }
   __syncthreads();
-  const int pairs = K * (kE / 2);
-  for (int r = 0; r < kEmbRows; ++r) {
-    const int64_t row = row0 + r;
-    if (row >= N) break;
-    for (int cp = tid; cp < pairs; cp += kEmbThreads) {
-      const int c = cp * 2;
-      const int p = c / kE, cc = c - p * kE;
-      float o2[2];
+  // Phase 2: the 64 x (K*462) outputs of this workgroup are one contiguous range of the output
+  // array: each thread produces 4 consecutive values (16-byte fp32 / 8-byte bf16 streaming stores,
+  // no ragged last pass over a row); (row, column) advance incrementally, without divisions.
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  const int rowlen = K * kE;
+  const int total = kEmbRows * rowlen;                       // multiple of 4 (64 rows)
+  int f = 4 * tid;
+  int r = f / rowlen, c = f - r * rowlen;
+  for (; f < total; f += 4 * kEmbThreads) {
+    float o4[4];
+    bool ok[4];
+    int rr = r, cc = c;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c1 = cc + u;
-        const int blk = c1 / 22, i = c1 - blk * 22;
-        const float v = sv[r * kSvStride + p * 22 + i];
-        float val = v;
-        if (blk > 0) {
-          const int fj = (blk - 1) >> 1;
-          const bool is_cos = ((blk - 1) & 1) != 0;
-          if (PRECISE) {
-            const float a = v * sfreq[fj];
-            val = is_cos ? cosf(a) : sinf(a);
-          } else {
-            const float a = v * sfreq[fj];
-            val = is_cos ? __builtin_amdgcn_cosf(a) : __builtin_amdgcn_sinf(a);
-          }
-        }
-        o2[u] = val;
-      }
-      const int64_t idx = row * (int64_t)(K * kE) + c;
-      if (BF16OUT) {
-        bf16x2 w;
-        w[0] = (__bf16)o2[0];
-        w[1] = (__bf16)o2[1];
-        *(bf16x2*)((__bf16*)out + idx) = w;
+    for (int u = 0; u < 4; ++u) {
+      const ColEnt en = tab[cc];
+      const float v = sv[rr * kSvStride + (en.code & 0xffff)];
+      float val;
+      if (PRECISE) {
+        const float a = v * en.f;
+        val = (en.code & (1 << 16)) ? v : ((en.code & (1 << 17)) ? cosf(a) : sinf(a));
       } else {
-        *(float2*)((float*)out + idx) = make_float2(o2[0], o2[1]);
+        const float sn = __builtin_amdgcn_sinf(fmaf(v, en.f, (en.code & (1 << 17)) ? 0.25f : 0.0f));
+        val = (en.code & (1 << 16)) ? v : sn;
       }
+      o4[u] = val;
+      ok[u] = row0 + rr < N;
+      if (++cc == rowlen) { cc = 0; ++rr; }
     }
+    const int64_t idx = row0 * (int64_t)rowlen + f;
+    if (ok[3]) {                                             // rows ascend: last valid => all valid
+      if (BF16OUT) {
+        bf16x4 w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = (__bf16)o4[u];
+        __builtin_nontemporal_store(w, (bf16x4*)((__bf16*)out + idx));
+      } else {
+        f32x4v w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = o4[u];
+        __builtin_nontemporal_store(w, (f32x4v*)((float*)out + idx));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) {
+          if (BF16OUT) ((__bf16*)out)[idx + u] = (__bf16)o4[u];
+          else ((float*)out)[idx + u] = o4[u];
+        }
+    }
+    c += 4 * kEmbThreads;
+    while (c >= rowlen) { c -= rowlen; ++r; }
   }
 }
 

@@ -76,6 +76,11 @@ def test_embed_golden_vectors(dev, golden):
         np.testing.assert_allclose(out, g[f"{tag}_emb"], atol=5e-4)
         fast = ops.embed_fwd(c, cfg, torch.bfloat16, precise=False).float().cpu().numpy()
         np.testing.assert_allclose(fast, g[f"{tag}_emb"], atol=1.2e-2)   # bf16 output: 2^-8 relative + fast sin
+        # fp32 output with the hardware v_sin_f32 path (the HBM-bound variant of config c4)
+        fast32 = ops.embed_fwd(c, cfg, torch.float32, precise=False).cpu().numpy()
+        err = np.abs(fast32 - g[f"{tag}_emb"]).max()
+        print(f"fp32 fast embedder max |err| vs reference ({tag}): {err:.2e}")
+        assert err < 5e-5
 
 
 def test_embed_edge_cases(dev):
@@ -172,7 +177,7 @@ def test_fused_forward_matches_oracle(dev, K, n):
     assert rel_l2(pred, oracle.sigmoid(raw_f)) < 5e-3
 
 
-@pytest.mark.parametrize("K", [3, 1])
+@pytest.mark.parametrize("K", [3, 1, 5])
 def test_fused_training_step_gradients(dev, K):
     """forward(stash) -> pixel loss -> backward chain -> grouped wgrad, against the oracle's
     hand-derived backward (itself pinned to the reference's autograd in test_oracle_golden)."""
@@ -368,3 +373,57 @@ def test_full_loop_with_patch_losses(dev):
     # LPIPS robust latents were trained (only on 'same' iterations), adaptive_pix latents too
     assert any((a - b).abs().max() > 0 for a, b in zip(lat0, fit.percepLoss.latents))
     assert fit.net.global_step == 120 - fit.skipped
+
+
+
+def test_training_step_is_bit_reproducible(dev):
+    """No atomics on the gradient path: split-K slabs + a fixed summation order make two runs of
+    the same step produce identical bits (weights after 3 optimiser steps)."""
+    K, H, n = 3, 256, 1024
+    outs = []
+    for rep in range(2):
+        net, P, angles, periods = _net(dev, K, ksplit=4)
+        c = torch.from_numpy(_coords(n, H, H, seed=3)).to(dev)
+        gt = torch.from_numpy(np.random.RandomState(1).rand(n, 3).astype(np.float32)).to(dev)
+        for it in range(3):
+            net.zero_grad(); net.forward_train(c); net.workspace(n)["dpred"].zero_()
+            net.pixel_loss(n, n, gt); net.backward(n); net.optimizer_step(n)
+        outs.append(net.params.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_minimal_and_ragged_batches(dev):
+    """One 64-row tile (the smallest launch) and a batch that is not a multiple of the tile."""
+    K, H = 3, 256
+    net, P, angles, periods = _net(dev, K)
+    for n in (1, 64, 65, 200):
+        c = _coords(n, H, H, seed=n)
+        pred = net.render(torch.from_numpy(c).to(dev)).cpu().numpy()
+        emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
+        raw, _ = oracle.mlp_forward(P, emb, K, emulate_bf16=True)
+        assert pred.shape == (n, 3) and np.abs(pred - oracle.sigmoid(raw)).max() < 4e-3
+
+
+def test_error_reporting_on_bad_arguments(dev):
+    """Bad sizes / pointers are rejected on the host with a status and a message, never launched."""
+    import ctypes as C
+    import npp_amd
+    from npp_amd import ops
+    L = npp_amd.lib()
+    cfg, *_ = _cfg(3)
+    c = torch.zeros((100, 2), dtype=torch.int32, device=dev)        # 100 rows: not a multiple of 64
+    with pytest.raises(npp_amd.NppError, match="multiple of 64"):
+        ops.mlp_fwd(c, cfg, torch.empty(16, device=dev), torch.empty(16, device=dev))
+    c64 = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+    with pytest.raises(npp_amd.NppError, match="width"):
+        ops.mlp_fwd(c64, cfg, torch.empty(16, device=dev), torch.empty(16, device=dev), width=512)
+    with pytest.raises(npp_amd.NppError, match="null"):
+        L.npp_mlp_fwd.restype = C.c_int
+        from npp_amd._lib import check
+        check(L.npp_mlp_fwd(None, 64, C.byref(cfg), 256, None, None, None, None, None), "npp_mlp_fwd")
+    bad = _cfg(3)[0]
+    bad.periods[0][0] = 0.5          # period + offset(-1) <= 0
+    with pytest.raises(npp_amd.NppError, match="period"):
+        ops.embed_fwd(c64, bad)
+    with pytest.raises(TypeError):
+        ops.embed_fwd(c64.long(), cfg)
