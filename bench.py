@@ -214,10 +214,11 @@ def main():
     measured = None
     try:     # PMC-measured HBM traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
              # passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_summary.json")))
+        import glob
+        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))[-1]))
         key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
                "mlp_wgrad": "npp::wgrad_kernel"}[dom]
-        measured = (2 * pm["FETCH_SIZE"][key] + pm["WRITE_SIZE"][key]) * 1024
+        measured = pm["kernels"][key]["hbm_bytes"]
     except Exception:
         pass
     roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,

@@ -173,20 +173,34 @@ __device__ __forceinline__ void lds_store_frag(char* region, int ks, int bt, int
 #define NPP_RING_DEPTH 4
 #endif
 constexpr int kRD = NPP_RING_DEPTH;     // k-steps of weight fragments in flight per wave
+// The packed weights are addressed through ONE buffer descriptor (SGPRs) per kernel: a part of a
+// layer is a wave-uniform offset into the pack (wptr_t, 16-byte units), the lane supplies only
+// its constant 16-byte voffset, so a refill costs no vector ALU work at all (flat loads needed a
+// 64-bit VALU add per k-step: ~1.2k of the ~9.6k VALU instructions a wave issued per tile).
+using wrsrc_t = __amdgpu_buffer_rsrc_t;
+using wptr_t = uint32_t;
+constexpr wptr_t kNoW = 0xffffffffu;      // "no next part": the ring is not refilled past this part
+__device__ __forceinline__ wrsrc_t make_wrsrc(const void* pack, int64_t units16) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pack), 0, (int)(units16 * 16), 0x00020000);
+}
 template <int NTW>
 struct WRing {
   bf16x8 w[kRD][NTW];
+  wrsrc_t rsrc;
 };
 
 template <int NTW, int NT>
-__device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, const bf16x8* __restrict__ wp, int ks, int nt0,
-                                           int lane) {
+__device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, wptr_t wp, int ks, int nt0, int lane) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) r.w[slot][nt] = wp[((int64_t)ks * NT + nt0 + nt) * 64 + lane];
+  for (int nt = 0; nt < NTW; ++nt) {
+    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane * 16, (int)((wp + (uint32_t)((ks * NT + nt0 + nt) * 64)) * 16u), 0);
+    r.w[slot][nt] = __builtin_bit_cast(bf16x8, raw);
+  }
 }
 // fresh fill of the ring with k-steps 0..3 of wp (START = 0 for the consumer)
 template <int NTW, int NT>
-__device__ __forceinline__ void wring_fill(WRing<NTW>& r, const bf16x8* __restrict__ wp, int nt0, int lane) {
+__device__ __forceinline__ void wring_fill(WRing<NTW>& r, wptr_t wp, int nt0, int lane) {
 #pragma unroll
   for (int q = 0; q < kRD; ++q) wslot_load<NTW, NT>(r, q, wp, q, nt0, lane);
 }
@@ -203,7 +217,7 @@ struct NoHook {
 // the shadow of the MFMAs of the same wave.
 template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT, typename Hook = NoHook>
 __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
-                                         const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp, int nt0,
+                                         wptr_t wp, wptr_t next_wp, int nt0,
                                          const Lane& L, WRing<NTW>& ring, const Hook& hook = Hook()) {
   static_assert(KSTOT % kRD == 0 && KSREAL <= KSTOT && KS1 <= KSTOT, "ring schedule");
   // activation fragments are read one k-step ahead of the MFMAs that use them (LDS latency
@@ -232,7 +246,7 @@ __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* re
     }
     hook(ks - KS0);
     if (ks + kRD < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + kRD, nt0, L.lane);
-    else if (ks + kRD >= KSTOT && next_wp) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
+    else if (ks + kRD >= KSTOT && next_wp != kNoW) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
     asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads
   }
 }

@@ -84,6 +84,7 @@ struct BwdDesc {
   int64_t off16[kNumBwd];     // offset in 16-byte units
 };
 
+NPP_HD int64_t bwd_total16(int K);
 NPP_HD NetDesc make_desc(int K) {
   NetDesc d{};
   d.K = K;
@@ -109,7 +110,7 @@ NPP_HD NetDesc make_desc(int K) {
   }
   d.total_params = off;
   d.wf_total16 = off16;
-  d.wb_total16 = 0;
+  d.wb_total16 = bwd_total16(K);
   return d;
 }
 

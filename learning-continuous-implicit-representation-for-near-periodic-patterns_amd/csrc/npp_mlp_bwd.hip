@@ -143,26 +143,27 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   wg_barrier();
 
   f32x16 acc[2][kNB], acc1[2][kNB];
-  const bf16x8* wb = A.wb;
   WRing<2> ring;                                        // weight-stream ring, chained across layers
-  wring_fill<2, kNT>(ring, wb + bd.off16[BP1], kt0, L.lane);
+  ring.rsrc = make_wrsrc(A.wb, d.wb_total16);
+  auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
+  wring_fill<2, kNT>(ring, wbl(BP1), kt0, L.lane);
 
   // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
   zero_acc(acc1);
-  mma_ring<0, 8, 8, 8, 2, kNT>(acc1, R0, 0, wb + bd.off16[BP1], MULTI ? wb + bd.off16[BP2] : wb + bd.off16[BF1], kt0, L, ring);   // df1, part 1
+  mma_ring<0, 8, 8, 8, 2, kNT>(acc1, R0, 0, wbl(BP1), MULTI ? wbl(BP2) : wbl(BF1), kt0, L, ring);   // df1, part 1
   if (MULTI) {
     zero_acc(acc);
-    mma_ring<0, 8, 8, 8, 2, kNT>(acc, R0, 0, wb + bd.off16[BP2], wb + bd.off16[BF2], kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
+    mma_ring<0, 8, 8, 8, 2, kNT>(acc, R0, 0, wbl(BP2), wbl(BF2), kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
     bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
     wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
-    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wb + bd.off16[BF2], wb + bd.off16[BS], kt0, L, ring);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wbl(BF2), wbl(BS), kt0, L, ring);
     bwd_epilogue<true>(acc, R0, zs(kActAS), dzr(kDzS), wg, kt0, L);
     wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
-    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc1, R0, 0, wb + bd.off16[BS], wb + bd.off16[BF1], kt0, L, ring);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc1, R0, 0, wbl(BS), wbl(BF1), kt0, L, ring);
   }
   bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), wg, kt0, L);
   wg_barrier();
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     char* in = ((v - BF1) & 1) ? R0 : R1;
     char* out = ((v - BF1) & 1) ? R1 : R0;
     zero_acc(acc);
-    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wb + bd.off16[v], v == B1 ? nullptr : wb + bd.off16[v + 1], kt0, L, ring);
+    mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wbl(v), v == B1 ? kNoW : wbl(v + 1), kt0, L, ring);
     bwd_epilogue<true>(acc, v == B1 ? nullptr : out, zs(out_layer), dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }

@@ -41,17 +41,12 @@ constexpr int kNChunks = (kKSEmb + kChunkKS - 1) / kChunkKS;   // 4 (8,8,8,6)
 constexpr int kSmemV = 22 * kRowTile * 4;                      // warped coords of one proposal
 constexpr int kSmemE = (sizeof(EmbedDev) + 15) / 16 * 16;
 // Branch-free embedding generation is driven by two small LDS tables built once per workgroup:
-//  SlotEnt[480]: per embedding slot (k-step, lane half, element) the byte offset of its warped
-//                coordinate in sV, the Fourier frequency in revolutions and the phase (0 = sin,
-//                1/4 = cos); identity slots have lin = 1, pad slots freq = phase = 0 (sin 0 = 0).
 //  WarpEnt[K][22]: per warped coordinate cos/sin(theta), period, 1/period, phase, or the
 //                linear form for the two normalised raw coordinates.
-struct SlotEnt { float frev; int code; };        // code = byte offset in sV | lin << 16 | cos << 17
 struct WarpEnt { float cs, sn, per, inv_per, phase, lin; };   // lin: value = t - 1 (normalised raw coordinate)
-constexpr int kSmemSlots = kEmbSlots * (int)sizeof(SlotEnt);                    // 7680
 constexpr int kSmemWarp = NPP_MAX_K * 22 * (int)sizeof(WarpEnt);                // 3520
 // the 4-wave rgb partial sums reuse region R0 after a barrier (everything else is dead by then)
-constexpr int kSmemFwd = 2 * kRegionBytes + kSmemV + 2 * kRowTile * 4 + kSmemE + kSmemSlots + kSmemWarp;
+constexpr int kSmemFwd = 2 * kRegionBytes + kSmemV + 2 * kRowTile * 4 + kSmemE + kSmemWarp;
 static_assert(kSmemFwd <= 80 * 1024, "two workgroups per CU");
 
 // Diagnostic build only (-DNPP_STAMPS): per-phase s_memtime stamps of wave 0 of two workgroups,
@@ -77,7 +72,7 @@ struct FwdArgs {
 };
 
 struct EmbTabs {
-  const SlotEnt* slots;
+  const float* freq_rev;   // LDS copy of EmbedDev::freq_rev[10]
   const WarpEnt* warp;
 };
 
@@ -118,52 +113,39 @@ __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, co
   }
 }
 
-// One embedding fragment (k-step ks, batch tile bt): table entries, warped coordinates, sin.
-__device__ __forceinline__ bf16x8 gen_emb_frag1(const SlotEnt* ts, const float* sV, int ks, int bt, const Lane& L) {
-  SlotEnt ent[8];
+// The two embedding fragments (batch tiles 0, 1) of k-step ks.  ks is wave-uniform, so the slot ->
+// (Fourier frequency, warped coordinate) map of npp_layout.h emb_col() is scalar arithmetic and the
+// frequency is one broadcast LDS read; per value the vector ALU does fma + v_sin + half a pack.
+// Lane-half 1 adds a quarter revolution (cos).  Padding slots (t >= 220 of k-step 27) receive
+// some finite sin value: their packed weights are zero and npp_mlp_wgrad drops their columns.
+__device__ __forceinline__ void gen_emb_pair(const float* sFr, const float* sV, int ks, bf16x8 (&f)[kNB], const Lane& L) {
+  const float* vrow = sV + L.b;
+  if (ks < 28) {
+    const float ph = L.h ? 0.25f : 0.0f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ent[j] = ts[ks * 16 + L.h * 8 + j];
-  float v[8];
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * ks + j;
+      int fj = (t * 2979) >> 16;                 // t / 22, exact for t < 240
+      const int i = t - 22 * fj;
+      fj = fj > NPP_N_FREQ - 1 ? NPP_N_FREQ - 1 : fj;
+      const float fr = sFr[fj];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = *(const float*)((const char*)sV + (ent[j].code & 0xffff) + (bt * 32 + L.b) * 4);
-  bf16x8 f;
+      for (int bt = 0; bt < kNB; ++bt)
+        f[bt][j] = (__bf16)__builtin_amdgcn_sinf(fmaf(vrow[i * kRowTile + bt * 32], fr, ph));
+    }
+  } else {                                       // identity block: v_0..v_15 | v_16..v_21, 0...
+    const int i0 = 16 * (ks - 28) + 8 * L.h;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float ph = (ent[j].code & (1 << 17)) ? 0.25f : 0.0f;
-    const float sv = __builtin_amdgcn_sinf(fmaf(v[j], ent[j].frev, ph));
-    f[j] = (__bf16)((ent[j].code & (1 << 16)) ? v[j] : sv);
-  }
-  return f;
-}
-
-// Four embedding fragments (2 k-steps x 2 batch tiles) of this wave: loads first, then the
-// arithmetic, so the two dependent LDS reads per value overlap across the 32 values.
-__device__ __forceinline__ void gen_emb_frags(const SlotEnt* ts, const float* sV, int ks0, bf16x8 (&f)[2][kNB],
-                                              const Lane& L) {
-  SlotEnt ent[2][8];
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = i0 + j < 22;
+      const int i = ok ? i0 + j : 0;
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ent[q][j] = ts[(ks0 + q) * 16 + L.h * 8 + j];
-  float v[2][kNB][8];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int bt = 0; bt < kNB; ++bt)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[q][bt][j] = *(const float*)((const char*)sV + (ent[q][j].code & 0xffff) + (bt * 32 + L.b) * 4);
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int bt = 0; bt < kNB; ++bt)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = v[q][bt][j];
-        const float ph = (ent[q][j].code & (1 << 17)) ? 0.25f : 0.0f;
-        const float sv = __builtin_amdgcn_sinf(fmaf(x, ent[q][j].frev, ph));
-        f[q][bt][j] = (__bf16)((ent[q][j].code & (1 << 16)) ? x : sv);
+      for (int bt = 0; bt < kNB; ++bt) {
+        const float v = vrow[i * kRowTile + bt * 32];
+        f[bt][j] = (__bf16)(ok ? v : 0.0f);
       }
+    }
+  }
 }
 
 // Accumulate one proposal's 30 embedding k-steps.  lds_ring = 32 KiB LDS (two 16 KiB chunk
@@ -173,48 +155,38 @@ __device__ __forceinline__ void gen_emb_frags(const SlotEnt* ts, const float* sV
 template <bool STORE_EMB, int NTW, int NT>
 __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbTabs& e, int p, char* lds_ring,
                                               float* sV, const float* sY, const float* sX,
-                                              const bf16x8* __restrict__ wp, const bf16x8* __restrict__ next_wp,
+                                              wptr_t wp, wptr_t next_wp,
                                               int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
   STAMP(50);
   gen_warp(e.warp, p, sV, sY, sX, L);
   wg_barrier();
   STAMP(51);
-  auto gen_chunk = [&](int c) {
-    char* buf = lds_ring + (c & 1) * kChunkBytes;
-    const int ksl0 = 2 * L.wave;             // wave-uniform: this wave's two k-steps of the chunk
-    const int ks0 = kChunkKS * c + ksl0;
-    if (ks0 < kKSEmb) {                      // 30 is even: both k-steps are real or neither
-      bf16x8 f[2][kNB];
-      gen_emb_frags(e.slots, sV, ks0, f, L);
+  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) : nullptr;
+  // this wave's k-step q (0, 1) of chunk c: generate, hand to the LDS ring, stash for wgrad
+  auto gen_pair = [&](int c, int q) {
+    const int ksl = 2 * L.wave + q, ks = kChunkKS * c + ksl;      // wave-uniform
+    if (ks < kKSEmb) {
+      bf16x8 f[kNB];
+      gen_emb_pair(e.freq_rev, sV, ks, f, L);
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int bt = 0; bt < kNB; ++bt) {
-          lds_store_frag(buf, ksl0 + q, bt, L.lane, f[q][bt]);
-          if (STORE_EMB)
-            stash_store(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) +
-                            wfmt_unit(kKSEmb, wg, ks0 + q, bt, L.b, L.h), f[q][bt]);
-        }
+      for (int bt = 0; bt < kNB; ++bt) {
+        lds_store_frag(lds_ring + (c & 1) * kChunkBytes, ksl, bt, L.lane, f[bt]);
+        if (STORE_EMB) stash_store(emb_base + wfmt_unit(kKSEmb, wg, ks, bt, L.b, L.h), f[bt]);
+      }
     }
   };
-  gen_chunk(0);
+  gen_pair(0, 0);
+  gen_pair(0, 1);
   STAMP(52);
   wg_barrier();
   STAMP(53);
-  // chunk c is multiplied while chunk c+1 is generated: this wave's four fragments of the next
-  // chunk (2 k-steps x 2 batch tiles) are produced at schedule positions 0, 2, 4, 6 of the
-  // current one, so their LDS reads / v_sin / stores issue between the MFMAs.
+  // chunk c is multiplied while chunk c+1 is generated: this wave's two k-steps of the next chunk
+  // are produced at schedule positions 0 and 4 of the current one, so their LDS reads / v_sin /
+  // stores issue between the MFMAs.
   auto hook_for = [&](int c_next) {
     return [&, c_next](int pos) {
-      if ((pos & 1) || pos >= 8) return;
-      const int fi = pos >> 1, q = fi >> 1, bt = fi & 1;
-      const int ksl = 2 * L.wave + q, ks = kChunkKS * c_next + ksl;
-      if (ks < kKSEmb) {
-        const bf16x8 f = gen_emb_frag1(e.slots, sV, ks, bt, L);
-        lds_store_frag(lds_ring + (c_next & 1) * kChunkBytes, ksl, bt, L.lane, f);
-        if (STORE_EMB)
-          stash_store(actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, ks, bt, L.b, L.h), f);
-      }
+      if (pos == 0) gen_pair(c_next, 0);
+      else if (pos == 4) gen_pair(c_next, 1);
     };
   };
   mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
@@ -273,8 +245,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   // indices: keep them in LDS, copied with compile-time indices so the by-value kernel
   // argument never needs a scratch copy.
   EmbedDev& ed = *(EmbedDev*)(sX + kRowTile);
-  SlotEnt* tSlots = (SlotEnt*)((char*)&ed + kSmemE);
-  WarpEnt* tWarp = (WarpEnt*)((char*)tSlots + kSmemSlots);
+  WarpEnt* tWarp = (WarpEnt*)((char*)&ed + kSmemE);
   float* sRGB = (float*)R0;             // [4 waves][64 rows][3], reused after the last barrier
   if (threadIdx.x == 0) {
     const uint32_t* src = (const uint32_t*)&e_arg;
@@ -283,19 +254,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
   }
   wg_barrier();
-  for (int sl = threadIdx.x; sl < kEmbSlots; sl += kThreads) {
-    const int ks = sl >> 4, hh = (sl >> 3) & 1, j = sl & 7;
-    SlotEnt en{0.0f, 0};                                   // pad slot: sin(v0 * 0 + 0) = 0
-    if (ks < 28) {
-      const int t = 8 * ks + j;
-      if (t < 220) { en.frev = ed.freq_rev[t / 22]; en.code = ((t % 22) * kRowTile * 4) | (hh << 17); }
-    } else if (ks == 28) {
-      en.code = ((8 * hh + j) * kRowTile * 4) | (1 << 16);
-    } else if (hh == 0 && j < 6) {
-      en.code = ((16 + j) * kRowTile * 4) | (1 << 16);
-    }
-    tSlots[sl] = en;
-  }
   for (int wi = threadIdx.x; wi < ed.K * 22; wi += kThreads) {
     const int p = wi / 22, i = wi - p * 22, ori = i >= 11, ii = ori ? i - 11 : i;
     WarpEnt w{0.0f, 0.0f, 1.0f, 1.0f, 0.0f, 0.0f};
@@ -310,7 +268,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     }
     tWarp[wi] = w;
   }
-  const EmbTabs e{tSlots, tWarp};
+  const EmbTabs e{ed.freq_rev, tWarp};
   Lane L;
   L.tid = threadIdx.x;
   L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -321,7 +279,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   const int64_t row0 = (int64_t)wg * kRowTile;
   const int64_t Bp = A_.Bp;
   const float* P = A_.params;
-  const bf16x8* wf = A_.wf;
   const int nt0 = 2 * L.wave;            // this wave's neuron tiles in 256-wide layers
 
   if (L.tid < kRowTile) {
@@ -336,10 +293,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   f32x16 acc[2][kNB];
   WRing<2> ring;                           // weight-stream register ring, live across layers
   WRing<1> ringp;                          // same for P (one neuron tile per wave)
-  constexpr int64_t U = (int64_t)kNT * 64; // 16-byte units per k-step of a 256-wide layer
-  constexpr int64_t UP = (int64_t)(kNT / 2) * 64;
+  ring.rsrc = ringp.rsrc = make_wrsrc(A_.wf, d.wf_total16);
+  constexpr wptr_t U = kNT * 64;           // 16-byte units per k-step of a 256-wide layer
+  constexpr wptr_t UP = (kNT / 2) * 64;
   constexpr int A = kKSAct;                // 16 k-steps per 256 features
-  auto wl = [&](int l) -> const bf16x8* { return wf + d.wf_off[l]; };
+  auto wl = [&](int l) -> wptr_t { return (wptr_t)d.wf_off[l]; };
 
   STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
@@ -391,7 +349,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   //      registers because P needs f1 again after S and F2 have recycled the regions.
   bf16x8 f1keep[2][kNB][2];
   init_bias<2>(acc, P + d.b_off[LF1], nt0, L);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : nullptr, nt0, L, ring);
+  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
   if (!MULTI) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
   epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
   wg_barrier();
@@ -402,8 +360,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     init_bias<2>(acc, P + d.b_off[LS], nt0, L);
     mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
     for (int p = 1; p < d.K; ++p) {
-      const bf16x8* wpp = wl(LS) + (int64_t)(A + (p - 1) * kKSEmb) * U;
-      mma_embedding<TRAIN, 2, kNT>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : nullptr, nt0,
+      const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
+      mma_embedding<TRAIN, 2, kNT>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
                                    A_.actF, wg, L, ring);
     }
     wring_fill<2, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
@@ -411,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
     init_bias<2>(acc, P + d.b_off[LF2], nt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF2), nullptr, nt0, L, ring);
+    mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
     wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
     epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
     wg_barrier();
@@ -426,11 +384,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     // ---- P = pos_linears[0]: [f1 (R1), f2 (R0)] -> 128, snake; one neuron tile per wave
     init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
     mma_ring<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
-    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, nullptr, L.wave, L, ringp);
+    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
   } else {
     // ---- NPP_Net_top1: P reads f1 (R0) directly (networks.py:162-170)
     init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
-    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), nullptr, L.wave, L, ringp);
+    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
                            wg, L);
