@@ -218,9 +218,19 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
         for (int s = 0; s < 2; ++s)
           stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), pack_acc_f16(acc[nt][bt], s));
       }
+      // snake on aligned register pairs: v_pk_mul (z / 2pi), 2 x v_sin, v_pk_fma (s*s + z), v_cvt_pk
       f32x16 a;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[r] = SNAKE ? snake_fast(acc[nt][bt][r]) : acc[nt][bt][r];
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 z = {acc[nt][bt][r], acc[nt][bt][r + 1]};
+        if (SNAKE) {
+          const f32x2 rev = z * kInv2Pi;
+          const f32x2 sn = {__builtin_amdgcn_sinf(rev[0]), __builtin_amdgcn_sinf(rev[1])};
+          z = __builtin_elementwise_fma(sn, sn, z);
+        }
+        a[r] = z[0];
+        a[r + 1] = z[1];
+      }
       acc[nt][bt] = a;   // callers that need the fp32 activation (P -> rgb) read it back
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
