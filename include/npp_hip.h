@@ -143,6 +143,15 @@ int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int
                   int n_slabs, int64_t slab_stride, float lr, float beta1, float beta2,
                   float eps, int step, void* stream);
 
+/* One launch for optimizer.step() over the network blob AND the adaptive-loss latents
+ * (create_npp_net puts both groups into one torch.optim.Adam, models/helpers.py:144-164), which
+ * also performs the next optimizer.zero_grad() (train.py:192) of the small accumulators: the
+ * latent gradient d_dlat[n_lat] is cleared after use and d_zero[n_zero] is cleared. */
+int npp_adam_step_net(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,
+                      int n_slabs, int64_t slab_stride, float* d_lat, float* d_lat_m,
+                      float* d_lat_v, float* d_dlat, int n_lat, float* d_zero, int n_zero,
+                      float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* Same step with step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) read from device memory
  * (d_hp[0], d_hp[1]): lets a captured HIP graph of one optimisation iteration be replayed. */
 int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,

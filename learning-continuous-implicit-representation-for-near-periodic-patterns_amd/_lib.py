@@ -64,6 +64,8 @@ SYMBOLS = {
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
+                                 _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "npp_cx_workspace_bytes": (_i64, [_i32, _i32, _i32]),

@@ -73,14 +73,37 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict
 // split-K slabs written by npp_mlp_wgrad, so this kernel is also the wgrad reduction.
 // hp != nullptr: step_size and 1/sqrt(1 - b2^t) are read from device memory ([0], [1]) so that a
 // captured HIP graph can be replayed with the values of the current step.
+// tail (optional, handled by one extra block): a second small parameter group -- the adaptive-loss
+// latents, whose gradient accumulator is consumed and cleared -- and an accumulator to clear for the
+// next iteration, so that one launch replaces optimizer.step() over both groups plus zero_grad().
+struct AdamTail {
+  float *p, *m, *v, *g;
+  int n;
+  float* zero;
+  int n_zero;
+};
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    int64_t n, int n_slabs, int64_t slab_stride,
                                                    float step_size, float b1, float b2, float inv_sqrt_bc2,
-                                                   float eps, const float* __restrict__ hp) {
+                                                   float eps, const float* __restrict__ hp, AdamTail tail) {
+  if (hp) { step_size = hp[0]; inv_sqrt_bc2 = hp[1]; }
+  if ((int64_t)blockIdx.x * blockDim.x >= n) {            // the extra block
+    const int t = threadIdx.x;
+    for (int i = t; i < tail.n; i += blockDim.x) {
+      const float gi = tail.g[i];
+      const float mi = b1 * tail.m[i] + (1.0f - b1) * gi;
+      const float vi = b2 * tail.v[i] + (1.0f - b2) * gi * gi;
+      tail.m[i] = mi;
+      tail.v[i] = vi;
+      tail.p[i] = tail.p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+      tail.g[i] = 0.0f;
+    }
+    for (int i = t; i < tail.n_zero; i += blockDim.x) tail.zero[i] = 0.0f;
+    return;
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (hp) { step_size = hp[0]; inv_sqrt_bc2 = hp[1]; }
   float gi = 0.0f;
   for (int s = 0; s < n_slabs; ++s) gi += g[(int64_t)s * slab_stride + i];
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -121,8 +144,27 @@ extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
                      d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps,
-                     (const float*)nullptr);
+                     (const float*)nullptr, AdamTail{});
   return check_launch("npp_adam_step");
+}
+
+extern "C" int npp_adam_step_net(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
+                                 int64_t slab_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat,
+                                 int n_lat, float* d_zero, int n_zero, float lr, float beta1, float beta2, float eps,
+                                 int step, void* stream) {
+  if (n <= 0 || !d_p || !d_m || !d_v || !d_gslabs || n_slabs < 1 || step < 1 || n_lat < 0 || n_zero < 0 ||
+      (n_lat > 0 && (!d_lat || !d_lat_m || !d_lat_v || !d_dlat)) || (n_zero > 0 && !d_zero)) {
+    set_error("npp_adam_step_net: bad arguments");
+    return NPP_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const AdamTail tail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
+                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps,
+                     (const float*)nullptr, tail);
+  return check_launch("npp_adam_step_net");
 }
 
 extern "C" int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
@@ -133,6 +175,6 @@ extern "C" int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float
     return NPP_ERR_ARG;
   }
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
-                     d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp);
+                     d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp, AdamTail{});
   return check_launch("npp_adam_step_dev");
 }

@@ -34,7 +34,11 @@ class NPPNet:
         self.lat_m = torch.zeros_like(self.latents)
         self.lat_v = torch.zeros_like(self.latents)
         self.dlatent = torch.zeros(6, dtype=torch.float32, device=self.device)
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # two loss accumulators used alternately: the fused Adam launch clears the idle one, so the
+        # value of the finished iteration stays readable and zero_grad() needs no fill kernels
+        self._loss_bufs = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._loss_idx = 0
+        self._clean = False
         self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
         self.ksplit = int(ksplit)
         self.lrate, self.lrate_decay = float(lrate), int(lrate_decay)
@@ -131,8 +135,10 @@ class NPPNet:
         """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""
         ws = self._ws[Bp]
         self.opt_step += 1
-        ops.adam_step(self.params, self.m, self.v, ws["gslabs"], self.ksplit, self.n_params, self.lr, self.opt_step)
-        ops.adam_step(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, self.lr, self.opt_step)
+        idle = self._loss_bufs[1 - self._loss_idx:2 - self._loss_idx]
+        ops.adam_step_net(self.params, self.m, self.v, ws["gslabs"], self.ksplit, self.n_params, self.latents,
+                          self.lat_m, self.lat_v, self.dlatent, idle, self.lr, self.opt_step)
+        self._clean = True
         self.repack()
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         self.global_step += 1
@@ -157,7 +163,7 @@ class NPPNet:
         hp_host, hp_dev = self._hyper()
 
         def body():
-            self.zero_grad()
+            self.zero_grad(force=True)
             self.forward_train(coords_padded)
             self.pixel_loss(bp, n_rows, gt, mask)
             self.backward(bp)
@@ -185,6 +191,17 @@ class NPPNet:
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         self.global_step += 1
 
-    def zero_grad(self):
-        self.dlatent.zero_()
-        self.loss_buf.zero_()
+    @property
+    def loss_buf(self):
+        """Accumulator of the current iteration's pixel loss (1 float on the device)."""
+        return self._loss_bufs[self._loss_idx:self._loss_idx + 1]
+
+    def zero_grad(self, force=False):
+        """optimizer.zero_grad() (train.py:192).  After optimizer_step() the latent gradient and the
+        idle loss accumulator are already zero: switch to it instead of launching fill kernels."""
+        if self._clean and not force:
+            self._loss_idx ^= 1
+        else:
+            self.dlatent.zero_()
+            self.loss_buf.zero_()
+        self._clean = False

@@ -132,6 +132,16 @@ def adam_step(p, m, v, gslabs, n_slabs, slab_stride, lr, step, b1=0.9, b2=0.999,
                               step, _stream()), "npp_adam_step")
 
 
+def adam_step_net(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat, zero, lr, step,
+                  b1=0.9, b2=0.999, eps=1e-8):
+    """optimizer.step() over the network blob and the adaptive-loss latents in one launch; clears the
+    latent gradient and `zero` (the next iteration's zero_grad of the small accumulators)."""
+    _req(p, torch.float32, "p")
+    check(lib().npp_adam_step_net(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, _p(lat), _p(lat_m),
+                                  _p(lat_v), _p(dlat), lat.numel(), _p(zero), 0 if zero is None else zero.numel(),
+                                  lr, b1, b2, eps, step, _stream()), "npp_adam_step_net")
+
+
 def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True):
     """extract_glimpse(mode='nearest', zeros padding) at integer centres
     (utils/extract_glimpse.py:53-79 via models/sampler.py:171-178,284-291)."""
