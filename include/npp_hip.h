@@ -118,10 +118,32 @@ int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, in
                 const void* d_wb, const float* d_params, const void* d_actF,
                 void* d_dzF, void* stream);
 
+/* Compatibility forms at the reference's module boundary.  NPP_Net(...).forward(None, x_periodic)
+ * (models/networks.py:56-95, NPP_Net_top1 :134-173) receives a MATERIALISED embedding:
+ * d_emb (Bp, ld >= K*462) fp32 row-major in the reference's column order (any embedder may have
+ * produced it).  out_act selects what render() applies to the network output (models/helpers.py:55-60):
+ * 0 = none (the module's own return value), 1 = sigmoid, 2 = tanh.  The backward of that forward
+ * takes the same out_act.  These read 5.5 KB per row from HBM that npp_mlp_fwd never materialises. */
+int npp_mlp_fwd_emb(const float* d_emb, int64_t ld, int64_t Bp, int K, int width, const void* d_wf,
+                    const float* d_params, float* d_out, void* d_actF, int out_act, void* stream);
+int npp_mlp_bwd_act(const float* d_dout, const float* d_out, int64_t Bp, int K, int width,
+                    const void* d_wb, const float* d_params, const void* d_actF, void* d_dzF,
+                    int out_act, void* stream);
+
 /* Weight/bias gradients: ksplit partial slabs in the parameter-blob layout
  * (slab s at d_gslabs + s * total floats); npp_adam_step sums them. */
 int npp_mlp_wgrad(const void* d_dzF, const void* d_actF, int64_t Bp, int K, int width,
                   int ksplit, float* d_gslabs, void* stream);
+
+/* d_grad[n] (+)= sum of the slabs: the parameter gradient as one blob, for optimisers other than
+ * npp_adam_step (the reference hands model.parameters() to torch.optim.Adam, helpers.py:164). */
+int npp_grad_reduce(const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t n,
+                    float* d_grad, int accumulate, void* stream);
+
+/* ---- a2 stand-alone: Embedder.embed (models/embedder.py:11-56) on any (N,d) fp32 input:
+ * out (N, d*(2*n_freq + include_input)) = [x | sin(f0 x) | cos(f0 x) | ...]; freqs is a HOST array. */
+int npp_fourier_fwd(const float* d_x, int64_t N, int d, const float* freqs, int n_freq,
+                    int include_input, float* d_out, void* stream);
 
 /* ---- a8: adaptive robust pixel loss -------------------------------------- */
 /* Replaces img2mse(pred, gt, 'robust_loss_adaptive', adaptive_pix, mask)

@@ -64,6 +64,10 @@ SYMBOLS = {
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_mlp_fwd_emb": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "npp_mlp_bwd_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "npp_grad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp]),
+    "npp_fourier_fwd": (_i32, [_vp, _i64, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
                                  _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),

@@ -114,6 +114,44 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   p[i] = p[i] - step_size * (mi / denom);
 }
 
+// Gradient of the parameter blob as one tensor (sum of the split-K slabs): what loss.backward() leaves in
+// .grad for an optimiser that is not npp_adam_step (compatibility form, torch.optim.Adam).
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const float* __restrict__ g, int n_slabs, int64_t slab_stride,
+                                                          int64_t n, float* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.0f;
+  for (int k = 0; k < n_slabs; ++k) s += g[(int64_t)k * slab_stride + i];
+  out[i] = s;
+}
+
+// a2 stand-alone: Embedder.embed (models/embedder.py:11-56) on an arbitrary (N, d) fp32 input:
+// out = [x | sin(f0 x) | cos(f0 x) | ... ] in blocks of d columns (include_input drops the first block).
+struct FourierArgs {
+  float freq[NPP_N_FREQ];
+  int32_t n_freq, d, include_input;
+};
+__global__ __launch_bounds__(256) void fourier_kernel(const float* __restrict__ x, int64_t N, FourierArgs a,
+                                                      float* __restrict__ out) {
+  const int od = a.d * (2 * a.n_freq + (a.include_input ? 1 : 0));
+  const int64_t total = N * od;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / od;
+    const int c = (int)(idx - r * od);
+    int blk = c / a.d;
+    const int i = c - blk * a.d;
+    const float v = x[r * a.d + i];
+    float o;
+    if (a.include_input) {
+      if (blk == 0) { out[idx] = v; continue; }
+      blk -= 1;
+    }
+    const float arg = v * a.freq[blk >> 1];       // p_fn(x * freq), fp32 like the reference
+    o = (blk & 1) ? cosf(arg) : sinf(arg);
+    out[idx] = o;
+  }
+}
+
 }  // namespace npp
 
 using namespace npp;
@@ -177,4 +215,32 @@ extern "C" int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
                      d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp, AdamTail{});
   return check_launch("npp_adam_step_dev");
+}
+
+extern "C" int npp_grad_reduce(const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t n, float* d_grad,
+                               int accumulate, void* stream) {
+  if (!d_gslabs || !d_grad || n <= 0 || n_slabs < 1 || slab_stride < n) {
+    set_error("npp_grad_reduce: bad arguments");
+    return NPP_ERR_ARG;
+  }
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_gslabs,
+                     n_slabs, slab_stride, n, d_grad, accumulate);
+  return check_launch("npp_grad_reduce");
+}
+
+extern "C" int npp_fourier_fwd(const float* d_x, int64_t N, int d, const float* freqs, int n_freq, int include_input,
+                               float* d_out, void* stream) {
+  if (N < 0 || d < 1 || n_freq < 0 || n_freq > NPP_N_FREQ || !freqs || (N > 0 && (!d_x || !d_out))) {
+    set_error("npp_fourier_fwd: bad arguments (N=%lld d=%d n_freq=%d)", (long long)N, d, n_freq);
+    return NPP_ERR_ARG;
+  }
+  if (N == 0) return NPP_OK;
+  FourierArgs a{};
+  for (int j = 0; j < n_freq; ++j) a.freq[j] = freqs[j];
+  a.n_freq = n_freq; a.d = d; a.include_input = include_input ? 1 : 0;
+  const int64_t total = N * d * (2 * n_freq + a.include_input);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, N, a, d_out);
+  return check_launch("npp_fourier_fwd");
 }

@@ -27,6 +27,7 @@ struct BwdArgs {
   const float* params;
   const char* actF;        // forward stash: fp16 z fragments of the snake layers (W-format)
   char* dzF;
+  int32_t out_act;         // output nonlinearity the forward applied: 0 raw, 1 sigmoid, 2 tanh
 };
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   if (L.tid < kRowTile * 3) {
     const int row = L.tid / 3, c = L.tid - row * 3;
     const float pr = A.pred[(row0 + row) * 3 + c];
-    const float g = A.dpred[(row0 + row) * 3 + c] * pr * (1.0f - pr);
+    // helpers.py:55-60: sigmoid (1), tanh (2) or the raw network output (0, npp_mlp_bwd_act only)
+    const float dact = A.out_act == 1 ? pr * (1.0f - pr) : (A.out_act == 2 ? 1.0f - pr * pr : 1.0f);
+    const float g = A.dpred[(row0 + row) * 3 + c] * dact;
     sDraw[L.tid] = g;
   }
   wg_barrier();
@@ -187,13 +190,14 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
 using namespace npp;
 
-extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
-                           const float* d_params, const void* d_actT, void* d_dzT, void* stream) {
+static int bwd_launch(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                      const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream) {
   if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_bwd: K=%d", K); return NPP_ERR_ARG; }
   if (width != NPP_WIDTH) { set_error("npp_mlp_bwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_bwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
   if (!d_dpred || !d_pred || !d_wb || !d_params || !d_actT || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
-  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const char*)d_actT, (char*)d_dzT};
+  if (out_act < 0 || out_act > 2) { set_error("npp_mlp_bwd: out_act=%d", out_act); return NPP_ERR_ARG; }
+  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const char*)d_actT, (char*)d_dzT, out_act};
   const NetDesc d = make_desc(K);
   const BwdDesc bd = make_bwd_desc(K);
   const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);
@@ -212,4 +216,14 @@ extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp
   if (K > 1) NPP_LAUNCH_B(true); else NPP_LAUNCH_B(false);
 #undef NPP_LAUNCH_B
   return check_launch("npp_mlp_bwd");
+}
+
+extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                           const float* d_params, const void* d_actT, void* d_dzT, void* stream) {
+  return bwd_launch(d_dpred, d_pred, Bp, K, width, d_wb, d_params, d_actT, d_dzT, 1, stream);
+}
+
+extern "C" int npp_mlp_bwd_act(const float* d_dout, const float* d_out, int64_t Bp, int K, int width, const void* d_wb,
+                               const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream) {
+  return bwd_launch(d_dout, d_out, Bp, K, width, d_wb, d_params, d_actT, d_dzT, out_act, stream);
 }

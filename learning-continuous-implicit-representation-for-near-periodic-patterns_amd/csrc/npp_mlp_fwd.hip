@@ -69,11 +69,18 @@ struct FwdArgs {
   const float* params;
   float* pred;
   char* actF;        // nullable: W-format fragment arrays (npp_layout.h)
+  // compatibility form (npp_mlp_fwd_emb): a materialised (Bp, K*462) fp32 embedding is the input, as
+  // NPP_Net.forward(None, x_periodic) receives it (models/networks.py:56); out_act: helpers.py:55-60
+  const float* emb;
+  int64_t emb_ld;
+  int32_t out_act;   // 0 raw, 1 sigmoid, 2 tanh
 };
 
 struct EmbTabs {
   const float* freq_rev;   // LDS copy of EmbedDev::freq_rev[10]
   const WarpEnt* warp;
+  const float* emb;        // compatibility form: materialised embedding rows instead of coordinates
+  int64_t emb_ld;
 };
 
 // acc[nt][bt] <- bias of this wave's neuron tiles (row constants as the initial accumulator)
@@ -148,17 +155,32 @@ __device__ __forceinline__ void gen_emb_pair(const float* sFr, const float* sV, 
   }
 }
 
+// Same two fragments read from a materialised reference-layout embedding row (compatibility form):
+// slot -> reference column through npp_layout.h emb_col(), padding slots are zero.
+__device__ __forceinline__ void load_emb_pair(const float* __restrict__ emb, int64_t ld, int64_t row0, int p, int ks,
+                                              bf16x8 (&f)[kNB], const Lane& L) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = emb_col(ks, L.h, j);
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      const float v = col >= 0 ? emb[(row0 + bt * 32 + L.b) * ld + p * kE + col] : 0.0f;
+      f[bt][j] = (__bf16)v;
+    }
+  }
+}
+
 // Accumulate one proposal's 30 embedding k-steps.  lds_ring = 32 KiB LDS (two 16 KiB chunk
 // buffers).  Caller guarantees sV is free to overwrite and lds_ring is free; on return every
 // wave has passed a barrier after its last lds_ring / sV read.  The weight ring holds the
 // first 4 k-steps on entry and the first 4 k-steps of next_wp on return.
-template <bool STORE_EMB, int NTW, int NT>
+template <bool STORE_EMB, int NTW, int NT, bool EMB_IN = false>
 __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbTabs& e, int p, char* lds_ring,
                                               float* sV, const float* sY, const float* sX,
                                               wptr_t wp, wptr_t next_wp,
                                               int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
   STAMP(50);
-  gen_warp(e.warp, p, sV, sY, sX, L);
+  if (!EMB_IN) gen_warp(e.warp, p, sV, sY, sX, L);
   wg_barrier();
   STAMP(51);
   char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) : nullptr;
@@ -167,7 +189,8 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
     const int ksl = 2 * L.wave + q, ks = kChunkKS * c + ksl;      // wave-uniform
     if (ks < kKSEmb) {
       bf16x8 f[kNB];
-      gen_emb_pair(e.freq_rev, sV, ks, f, L);
+      if (EMB_IN) load_emb_pair(e.emb, e.emb_ld, (int64_t)wg * kRowTile, p, ks, f, L);
+      else gen_emb_pair(e.freq_rev, sV, ks, f, L);
 #pragma unroll
       for (int bt = 0; bt < kNB; ++bt) {
         lds_store_frag(lds_ring + (c & 1) * kChunkBytes, ksl, bt, L.lane, f[bt]);
@@ -243,7 +266,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
   }
 }
 
-template <bool TRAIN, bool MULTI>
+template <bool TRAIN, bool MULTI, bool EMB_IN = false>
 __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R0 = smem;
@@ -278,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     }
     tWarp[wi] = w;
   }
-  const EmbTabs e{ed.freq_rev, tWarp};
+  const EmbTabs e{ed.freq_rev, tWarp, A_.emb, A_.emb_ld};
   Lane L;
   L.tid = threadIdx.x;
   L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   const float* P = A_.params;
   const int nt0 = 2 * L.wave;            // this wave's neuron tiles in 256-wide layers
 
-  if (L.tid < kRowTile) {
+  if (!EMB_IN && L.tid < kRowTile) {
     const int2 c = ((const int2*)A_.coords)[row0 + L.tid];
     sY[L.tid] = (float)c.x;              // (row=y, col=x)
     sX[L.tid] = (float)c.y;
@@ -313,7 +336,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
   wring_fill<2, kNT>(ring, wl(L0), nt0, L.lane);
   init_bias<2>(acc, P + d.b_off[L0], nt0, L);
-  mma_embedding<TRAIN, 2, kNT>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
+  mma_embedding<TRAIN, 2, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
   STAMP(1);
   epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, arow(0), wg, L);
   STAMP(2);
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
   //      again after mma_embedding's final barrier)
   init_bias<2>(acc, P + d.b_off[L5], nt0, L);
-  mma_embedding<false, 2, kNT>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
+  mma_embedding<false, 2, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
   STAMP(20);
   mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   STAMP(21);
@@ -371,7 +394,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
     mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
-      mma_embedding<TRAIN, 2, kNT>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
+      mma_embedding<TRAIN, 2, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
                                    A_.actF, wg, L, ring);
     }
     wring_fill<2, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
@@ -437,7 +460,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
       float z = P[d.b_off[LRGB] + c];
 #pragma unroll
       for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];
-      A_.pred[(row0 + row) * 3 + c] = 1.0f / (1.0f + __expf(-z));   // helpers.py:56 sigmoid
+      float o = 1.0f / (1.0f + __expf(-z));                         // helpers.py:56 sigmoid
+      if (EMB_IN && A_.out_act != 1) o = A_.out_act == 2 ? tanhf(z) : z;   // helpers.py:57-58 tanh / raw network output
+      A_.pred[(row0 + row) * 3 + c] = o;
     }
   }
   STAMP(41);
@@ -453,33 +478,64 @@ extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
 }
 #endif
 
+static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, bool emb_in, void* stream, const char* who) {
+  const dim3 grid((unsigned)(A.Bp / kRowTile)), block(kThreads);
+  const bool train = A.actF != nullptr, multi = d.K > 1;
+  hipStream_t s = (hipStream_t)stream;
+#define NPP_LAUNCH(T, M, E)                                                                       \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      hipError_t ea = hipFuncSetAttribute((const void*)mlp_fwd_kernel<T, M, E>,                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmemFwd);  \
+      if (ea != hipSuccess) { set_error("%s: smem attr: %s", who, hipGetErrorString(ea)); return NPP_ERR_LAUNCH; } \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((mlp_fwd_kernel<T, M, E>), grid, block, kSmemFwd, s, A, e, d);             \
+  } while (0)
+#define NPP_LAUNCH2(E)                                                                            \
+  do {                                                                                            \
+    if (train) { if (multi) NPP_LAUNCH(true, true, E); else NPP_LAUNCH(true, false, E); }         \
+    else { if (multi) NPP_LAUNCH(false, true, E); else NPP_LAUNCH(false, false, E); }             \
+  } while (0)
+  if (emb_in) NPP_LAUNCH2(true); else NPP_LAUNCH2(false);
+#undef NPP_LAUNCH2
+#undef NPP_LAUNCH
+  return check_launch(who);
+}
+
+static int fwd_check(int64_t Bp, int width, const void* in, const void* d_wf, const float* d_params, const float* d_pred,
+                     const char* who) {
+  if (width != NPP_WIDTH) { set_error("%s: width %d unsupported (build is %d)", who, width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
+  if (Bp <= 0 || Bp % kRowTile) { set_error("%s: Bp=%lld must be a positive multiple of %d", who, (long long)Bp, kRowTile); return NPP_ERR_ARG; }
+  if (!in || !d_wf || !d_params || !d_pred) { set_error("%s: null pointer", who); return NPP_ERR_ARG; }
+  if (Bp / kRowTile > 0x7fffffffLL) { set_error("%s: Bp too large", who); return NPP_ERR_ARG; }
+  return NPP_OK;
+}
+
 extern "C" int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width,
                            const void* d_wf, const float* d_params, float* d_pred, void* d_actT, void* stream) {
   int rc = check_embed_cfg(cfg, "npp_mlp_fwd");
   if (rc) return rc;
-  if (width != NPP_WIDTH) { set_error("npp_mlp_fwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
-  if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_fwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
-  if (!d_coords_yx || !d_wf || !d_params || !d_pred) { set_error("npp_mlp_fwd: null pointer"); return NPP_ERR_ARG; }
-  if (Bp / kRowTile > 0x7fffffffLL) { set_error("npp_mlp_fwd: Bp too large"); return NPP_ERR_ARG; }
-  const EmbedDev e = make_embed_dev(*cfg);
-  const NetDesc d = make_desc(cfg->K);
-  FwdArgs A{d_coords_yx, Bp, (const bf16x8*)d_wf, d_params, d_pred, (char*)d_actT};
-  const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreads);
-  const bool train = d_actT != nullptr, multi = cfg->K > 1;
-  hipStream_t s = (hipStream_t)stream;
-#define NPP_LAUNCH(T, M)                                                                          \
-  do {                                                                                            \
-    static bool attr_set = false;                                                                 \
-    if (!attr_set) {                                                                              \
-      hipError_t ea = hipFuncSetAttribute((const void*)mlp_fwd_kernel<T, M>,                      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmemFwd);  \
-      if (ea != hipSuccess) { set_error("npp_mlp_fwd: smem attr: %s", hipGetErrorString(ea)); return NPP_ERR_LAUNCH; } \
-      attr_set = true;                                                                            \
-    }                                                                                             \
-    hipLaunchKernelGGL((mlp_fwd_kernel<T, M>), grid, block, kSmemFwd, s, A, e, d);                \
-  } while (0)
-  if (train) { if (multi) NPP_LAUNCH(true, true); else NPP_LAUNCH(true, false); }
-  else { if (multi) NPP_LAUNCH(false, true); else NPP_LAUNCH(false, false); }
-#undef NPP_LAUNCH
-  return check_launch("npp_mlp_fwd");
+  if ((rc = fwd_check(Bp, width, d_coords_yx, d_wf, d_params, d_pred, "npp_mlp_fwd"))) return rc;
+  FwdArgs A{};
+  A.coords = d_coords_yx; A.Bp = Bp; A.wf = (const bf16x8*)d_wf; A.params = d_params; A.pred = d_pred;
+  A.actF = (char*)d_actT; A.out_act = 1;
+  return fwd_launch(A, make_embed_dev(*cfg), make_desc(cfg->K), false, stream, "npp_mlp_fwd");
+}
+
+extern "C" int npp_mlp_fwd_emb(const float* d_emb, int64_t ld, int64_t Bp, int K, int width, const void* d_wf,
+                               const float* d_params, float* d_out, void* d_actT, int out_act, void* stream) {
+  int rc = fwd_check(Bp, width, d_emb, d_wf, d_params, d_out, "npp_mlp_fwd_emb");
+  if (rc) return rc;
+  if (K < 1 || K > NPP_MAX_K || ld < (int64_t)K * kE || out_act < 0 || out_act > 2) {
+    set_error("npp_mlp_fwd_emb: bad K=%d / ld=%lld / out_act=%d", K, (long long)ld, out_act);
+    return NPP_ERR_ARG;
+  }
+  FwdArgs A{};
+  A.Bp = Bp; A.wf = (const bf16x8*)d_wf; A.params = d_params; A.pred = d_out; A.actF = (char*)d_actT;
+  A.emb = d_emb; A.emb_ld = ld; A.out_act = out_act;
+  EmbedDev e{};
+  e.K = K;
+  return fwd_launch(A, e, make_desc(K), true, stream, "npp_mlp_fwd_emb");
 }

@@ -92,6 +92,40 @@ def mlp_fwd(coords, cfg, wf, params, pred=None, actF=None, width=NPP_WIDTH):
     return pred
 
 
+def mlp_fwd_emb(emb, K, wf, params, out=None, actF=None, out_act=0, width=NPP_WIDTH):
+    """NPP_Net.forward(None, x_periodic) on a materialised (Bp, K*462) embedding (networks.py:56-95);
+    out_act: 0 raw network output, 1 sigmoid, 2 tanh (render, helpers.py:55-60)."""
+    _req(emb, torch.float32, "emb")
+    bp = emb.shape[0]
+    if out is None:
+        out = torch.empty((bp, 3), dtype=torch.float32, device=emb.device)
+    check(lib().npp_mlp_fwd_emb(_p(emb), emb.stride(0), bp, K, width, _p(wf), _p(params), _p(out), _p(actF), out_act,
+                                _stream()), "npp_mlp_fwd_emb")
+    return out
+
+
+def mlp_bwd_act(dout, out, K, wb, params, actF, dzF, out_act, width=NPP_WIDTH):
+    _req(dout, torch.float32, "dout")
+    _req(out, torch.float32, "out", dout.shape)
+    check(lib().npp_mlp_bwd_act(_p(dout), _p(out), dout.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                                out_act, _stream()), "npp_mlp_bwd_act")
+
+
+def grad_reduce(gslabs, n_slabs, n, grad, accumulate=False):
+    """grad (+)= sum of the split-K slabs (the blob-shaped .grad a torch optimiser consumes)."""
+    check(lib().npp_grad_reduce(_p(gslabs), n_slabs, n, n, _p(grad), int(bool(accumulate)), _stream()), "npp_grad_reduce")
+
+
+def fourier_fwd(x, freqs, include_input=True):
+    """Embedder.embed (models/embedder.py:11-56): (N,d) -> (N, d*(2*len(freqs)+include_input))."""
+    _req(x, torch.float32, "x")
+    n, d = x.shape
+    f = (C.c_float * len(freqs))(*[float(v) for v in freqs])
+    out = torch.empty((n, d * (2 * len(freqs) + int(bool(include_input)))), dtype=torch.float32, device=x.device)
+    check(lib().npp_fourier_fwd(_p(x), n, d, f, len(freqs), int(bool(include_input)), _p(out), _stream()), "npp_fourier_fwd")
+    return out
+
+
 def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
     _req(dpred, torch.float32, "dpred")
     _req(pred, torch.float32, "pred", dpred.shape)
