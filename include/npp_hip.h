@@ -210,6 +210,65 @@ int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
                     int n_knots, float x_scale, float scale, float* d_loss, float* d_df0,
                     float* d_dlatent, void* d_workspace, void* stream);
 
+/* ---- a11 / a13 trunks: frozen VGG19[0:18] / VGG16 stacks ----------------------- */
+/* Replace the torchvision/cuDNN convolution stacks the two patch losses run their inputs
+ * through (externel_lib/contextual_loss/modules/vgg.py:16-21,30-36: features[0:18] up to
+ * relu3_4; externel_lib/lpips/pretrained_networks.py:96-134: five VGG16 slices), forward and
+ * data gradient (the weights are frozen: vgg.py:26-28, pretrained_networks.py:116-118).
+ *
+ * Between layers tensors stay in a "flat padded" 16-bit layout (csrc/npp_conv.hip): for a
+ * logical (N, C, H, W) tensor, [C/8][npp_trunk_nposp(N,H,W)][8] with a zero one-pixel border
+ * around every image, so conv2d(padding=1) needs no boundary handling.  Forward activations and
+ * forward weight packs are fp16 (saturating; 11 significand bits = the TF32 class cuDNN runs the
+ * reference's trunks in), gradient tensors and gradient packs are bf16; accumulation is fp32.  Buffers must be
+ * ZERO-INITIALISED by the caller once (kernels rewrite only the position range they compute and
+ * keep borders zero).  N_total fixes a buffer's geometry; n_run <= N_total restricts a backward
+ * launch to the leading images (the ones that need a gradient). */
+int64_t npp_trunk_nposp(int N, int H, int W);                /* 16-byte units per channel chunk */
+int64_t npp_trunk_act_bytes(int N, int C, int H, int W);     /* bytes of a flat tensor (C padded to 16) */
+
+/* Pack a torch Conv2d weight (Cout, Cin, 3, 3) fp32 into bf16 MFMA A-operand fragments:
+ * which = 0 forward pack, 1 data-gradient pack (transposed, taps flipped).  in_natural != 0:
+ * the layer's input channels are in natural order (the image layer, Cin = 3 padded to 16);
+ * otherwise they are in the accumulator order the previous conv layer stored them in. */
+int64_t npp_conv_pack_bytes(int Cin, int Cout, int which);
+int npp_conv_pack(const float* d_w, int Cin, int Cout, int in_natural, void* d_pack_fwd,
+                  void* d_pack_bwd, void* stream);
+
+/* (N,3,H,W) fp32 image -> flat C=16 tensor of x*scale[c] + shift[c] (the reference's input
+ * normalisations: contextual.py:56-61 (x-mean)/std; lpips.py:96-98,136-143 scaling layer). */
+int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, const float scale[3],
+                       const float shift[3], void* d_x0, void* stream);
+
+/* One 3x3 / pad 1 convolution launch on flat tensors (Cin, Cout multiples of 16, <= 512):
+ *  mode 0  y = relu(conv(x, w) + bias)                    nn.Conv2d + nn.ReLU
+ *  mode 1  y = conv_transpose(x) * [mask > 0]             dL/d(pre-activation) of the layer below:
+ *                                                         x = dL/d(pre-act) of this layer, d_pack its
+ *                                                         gradient pack, d_mask the layer-below output
+ *  mode 2  y = conv_transpose(x)                          the same without a ReLU gate (into a pooled
+ *                                                         tensor or the image)
+ * d_tap (nullable): additionally writes the result as plain fp32 (n, Ctap, H, W) for channels
+ * < Ctap (times tap_scale[c], Ctap <= 4, when tap_scale is given): feature taps for
+ * npp_cx_fwd_bwd / npp_lpips_layer, and the image gradient.  d_y may be NULL if d_tap is set. */
+int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
+                const void* d_pack, const float* d_bias, int mode, const void* d_mask, void* d_y,
+                float* d_tap, int Ctap, const float* tap_scale, void* stream);
+
+/* nn.MaxPool2d(2,2) on flat tensors, and its backward fused with the ReLU gate of the pooled
+ * layer: dz = (route(dy) + addend) * [x > 0]; the gradient goes to the first maximum of each
+ * window in scan order (torch semantics); d_addend (nullable) is a tap gradient on x. */
+int npp_maxpool2_fwd(const void* d_x, int N, int H, int W, int C, void* d_y, void* stream);
+int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, int N_total,
+                     int n_run, int H, int W, int C, void* d_dz, void* stream);
+
+/* Tap gradient (n_run, C, H, W) fp32 -> flat (bf16, or fp16 when as_f16), gated by [y > 0]
+ * when the fp16 activation tensor d_y is given.  Also the generic fp32 -> flat importer. */
+int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C,
+                      int H, int W, void* d_dz, int as_f16, void* stream);
+/* flat (fp16 activations when is_f16, else bf16 gradients) -> (n_run, C, H, W) fp32 */
+int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W,
+                     float* d_out_nchw, int is_f16, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 /* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the
  * accumulator-as-next-operand chain) with exact integer data.  d_scratch >= 1 MiB. */

@@ -77,6 +77,17 @@ SYMBOLS = {
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
     "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
+    "npp_trunk_nposp": (_i64, [_i32, _i32, _i32]),
+    "npp_trunk_act_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "npp_conv_pack_bytes": (_i64, [_i32, _i32, _i32]),
+    "npp_conv_pack": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "npp_trunk_image_in": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
+    "npp_conv3x3": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
+                           C.POINTER(C.c_float), _vp]),
+    "npp_maxpool2_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "npp_maxpool2_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "npp_trunk_grad_in": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "npp_trunk_export": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
 }
 
 _LIB = None

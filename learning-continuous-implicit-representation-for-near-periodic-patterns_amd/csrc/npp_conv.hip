@@ -1,0 +1,537 @@
+// npp_conv.hip -- rows a11 / a13 (trunks): the frozen VGG19[0:18] (contextual loss,
+// externel_lib/contextual_loss/modules/vgg.py:7-48) and VGG16 (LPIPS,
+// externel_lib/lpips/pretrained_networks.py:96-134) convolution stacks, forward and
+// data-gradient, as 16-bit-MFMA implicit GEMMs (fp32 accumulation).  Numeric contract: FORWARD operands
+// (activations, weights) are fp16 -- 11 significand bits, the class of the TF32 convolutions cuDNN runs
+// the reference's trunks with by default -- saturated at +-65504; GRADIENT operands are bf16 (range
+// over precision: nothing here can under/overflow), ReLU gates are taken from the fp16 activations.  The reference runs them through
+// torchvision/cuDNN (F.conv2d 3x3 pad 1 + ReLU, MaxPool2d(2,2)); weights are frozen
+// (vgg.py:26-28), so only dL/dinput is ever needed.
+//
+// Layout ("flat padded"): an activation tensor (N, C, H, W) is stored as
+//   [C/8 chunks][NPOSP positions][8 channels] fp16 | bf16,  16 bytes per (chunk, position) unit,
+// where the position axis enumerates ALL images with a one-pixel zero border each,
+// pos = kConvGuard + n*(H+2)*(W+2) + y*(W+2) + x  (y, x in [0,H+2) x [0,W+2), interior 1..H, 1..W),
+// plus kConvGuard zero units on both ends.  Consequences:
+//   * a 3x3 tap is a CONSTANT position shift (ky-1)*(W+2) + (kx-1): no boundary predicates,
+//     the zero padding of conv2d(padding=1) is physically there;
+//   * the MFMA B operand (16 channels x 32 positions) of one tap is two contiguous 512-byte
+//     runs, fetched with ONE buffer_load_dwordx4 per lane straight from global memory / L2;
+//   * the GEMM is computed transposed, Z^T[co][pos] = W[co][tap,ci] X^T[tap,ci][pos], weights
+//     pre-packed as A-operand fragments (frozen: packed once), and an accumulator tile converted
+//     to bf16 is stored as two 16-byte units per lane -- which makes the channel order inside a
+//     chunk the perm16 order of npp_layout.h; the packers absorb that permutation.
+// Border / tail positions are recomputed as zeros by every kernel, so a tensor is always a
+// valid conv input.  The data-gradient of a conv is the same kernel with the flipped,
+// transposed weight pack and a ReLU-mask epilogue (dZ = dY * [Y > 0]).
+//
+// Algorithmic work: 2 * 9 * Cin * Cout FLOP per interior output position (border and padded
+// positions, and the 3 -> 16 channel padding of the first layer, are not counted).
+#include "npp_common.h"
+
+namespace npp {
+
+constexpr int kConvGuard = 256;       // zero units before / after the position axis (>= W + 3)
+constexpr int kPosRound = 512;        // position count is rounded up to a multiple of this
+
+NPP_HD int64_t conv_npos_round(int N, int H, int W) {
+  const int64_t s = (int64_t)N * (H + 2) * (W + 2);
+  return (s + kPosRound - 1) / kPosRound * kPosRound;
+}
+NPP_HD int64_t conv_nposp(int N, int H, int W) { return conv_npos_round(N, H, W) + 2 * kConvGuard; }
+
+// true channel of element j of chunk c8 in the stored (accumulator) order
+NPP_HD int conv_chan(int c8, int j) { return 32 * (c8 >> 2) + 16 * ((c8 >> 1) & 1) + perm16(c8 & 1, j); }
+
+enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2 };
+
+struct ConvArgs {
+  const void* x;         // flat input, Cin channels
+  const void* pack;      // A fragments [cot][ci_step][tap][64 lanes][8]
+  const float* bias;     // fwd only
+  const void* mask;      // dgrad-mask: flat tensor of the layer output whose ReLU gates this gradient
+  void* y;               // flat output (nullable when only the tap is wanted)
+  float* tap;            // optional fp32 (N, Ctap, H, W) copy of the result (interior only)
+  float tap_scale[4];
+  int32_t N, H, W, Wp, S, CI, cout_chunks, Ctap, has_scale, pos_tiles;
+  int64_t nposp, npos_valid;
+  uint32_t x_bytes, pack_bytes;
+};
+
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <bool F16> struct OpT { typedef bf16x8 frag; typedef __bf16 elem; };
+template <> struct OpT<true> { typedef f16x8 frag; typedef _Float16 elem; };
+
+template <int CT, int PT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  typedef typename OpT<MODE == kConvFwd>::frag frag_t;       // forward: fp16 operands; gradients: bf16
+  typedef typename OpT<MODE == kConvFwd>::elem elem_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = lane & 31, h = lane >> 5;
+  // XCD-aware: consecutive position blocks (which share halo rows) go to the same XCD / L2
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int tile0 = (bid * 4 + wave) * PT;
+  if (tile0 >= a.pos_tiles) return;                      // whole wave; the kernel has no barriers
+  const int cot0 = blockIdx.y * CT;
+  const int KS = a.CI * 9;
+
+  const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack), 0, (int)a.pack_bytes, 0x00020000);
+  const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const int voffA = lane * 16;
+  const int voffB = (int)(((int64_t)h * a.nposp + kConvGuard + (int64_t)tile0 * 32 + b - (a.Wp + 1)) * 16);
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+  frag_t A[3][CT], B[3][PT];
+  auto load = [&](int slot, int ci, int tap) {
+    const int ks = ci * 9 + tap;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (int)((uint32_t)((cot0 + ct) * KS + ks) * 1024u), 0);
+      A[slot][ct] = __builtin_bit_cast(frag_t, raw);
+    }
+    const int shift = (tap / 3) * a.Wp + (tap % 3);
+    const uint32_t soff = (uint32_t)(((int64_t)2 * ci * a.nposp + shift) * 16);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rB, voffB, (int)(soff + (uint32_t)pt * 512u), 0);
+      B[slot][pt] = __builtin_bit_cast(frag_t, raw);
+    }
+  };
+
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
+
+  load(0, 0, 0);
+  load(1, 0, 1);
+  load(2, 0, 2);
+  for (int ci = 0; ci < a.CI; ++ci) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int slot = tap % 3;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = mfma16(A[slot][ct], B[slot][pt], acc[ct][pt]);
+      if (tap + 3 < 9) load(slot, ci, tap + 3);
+      else if (ci + 1 < a.CI) load(slot, ci + 1, tap - 6);
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
+    const int n = (int)(p / a.S);
+    const int r0 = (int)(p - (int64_t)n * a.S);
+    const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
+    const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
+    const int64_t tap_base = (((int64_t)n * a.Ctap) * a.H + (yy - 1)) * a.W + (xx - 1);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int cot = cot0 + ct;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = 4 * cot + 2 * s + h;
+        if (chunk >= a.cout_chunks) continue;
+        const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
+        f16x8 m;
+        if (MODE == kConvDgradMask) m = ((const f16x8*)a.mask)[unit];
+        frag_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int co = 32 * cot + acc_row(8 * s + j, h);
+          float v = acc[ct][pt][8 * s + j];
+          if (MODE == kConvFwd) v = fminf(fmaxf(v + a.bias[co], 0.0f), 65504.0f);
+          if (MODE == kConvDgradMask) v = (float)m[j] > 0.0f ? v : 0.0f;
+          v = interior ? v : 0.0f;
+          o[j] = (elem_t)v;
+          if (a.tap && interior && co < a.Ctap)
+            a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? v * a.tap_scale[co & 3] : v;
+        }
+        if (a.y) ((frag_t*)a.y)[unit] = o;
+      }
+    }
+  }
+}
+
+// ---- weight packers (run once per trunk: the weights are frozen) -------------------------
+// w: torch Conv2d weight (Cout, Cin, 3, 3) fp32.
+// forward pack unit (cot, ci_step, tap, lane=(m,h)) element j = w[32 cot + m][chan_in(2 ci_step + h, j)][ky][kx]
+// dgrad  pack unit (cit, co_step, tap, lane=(m,h)) element j = w[conv_chan(2 co_step + h, j)][32 cit + m][2-ky][2-kx]
+__global__ void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int in_natural, int CIp /*padded Cin*/,
+                                 f16x8* __restrict__ pf, int64_t nf, bf16x8* __restrict__ pb, int64_t nbk) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < nf) {
+    const int lane = (int)(u & 63);
+    int64_t r = u >> 6;
+    const int tap = (int)(r % 9); r /= 9;
+    const int CI = CIp / 16;
+    const int ci_step = (int)(r % CI);
+    const int cot = (int)(r / CI);
+    const int m = lane & 31, h = lane >> 5, co = 32 * cot + m;
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c8 = 2 * ci_step + h;
+      const int ci = in_natural ? c8 * 8 + j : conv_chan(c8, j);
+      const float v = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.0f;
+      o[j] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+    }
+    pf[u] = o;
+  } else if (u < nf + nbk) {
+    const int64_t ub = u - nf;
+    const int lane = (int)(ub & 63);
+    int64_t r = ub >> 6;
+    const int tap = (int)(r % 9); r /= 9;
+    const int CO = Cout / 16;
+    const int co_step = (int)(r % CO);
+    const int cit = (int)(r / CO);
+    const int m = lane & 31, h = lane >> 5, ci = 32 * cit + m;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = conv_chan(2 * co_step + h, j);
+      const float v = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * 9 + (8 - tap)] : 0.0f;
+      o[j] = (__bf16)v;
+    }
+    pb[ub] = o;
+  }
+}
+
+// ---- image in: (N,3,H,W) fp32 -> flat C=16 (channels 0..2 natural order, rest 0), x*scale + shift ----
+__global__ void trunk_image_in_kernel(const float* __restrict__ img, int N, int H, int W, float s0, float s1, float s2,
+                                      float b0, float b1, float b2, f16x8* __restrict__ out, int64_t nposp,
+                                      int64_t npos_round) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npos_round) return;
+  const int Wp = W + 2, S = (H + 2) * Wp;
+  const int n = (int)(p / S), r = (int)(p - (int64_t)n * S), y = r / Wp, x = r - y * Wp;
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+  const f16x8 z = o;
+  if (n < N && y >= 1 && y <= H && x >= 1 && x <= W) {
+    const int64_t base = ((int64_t)n * 3 * H + (y - 1)) * W + (x - 1);
+    const int64_t cs = (int64_t)H * W;
+    o[0] = (_Float16)fmaf(img[base], s0, b0);
+    o[1] = (_Float16)fmaf(img[base + cs], s1, b1);
+    o[2] = (_Float16)fmaf(img[base + 2 * cs], s2, b2);
+  }
+  out[kConvGuard + p] = o;
+  out[nposp + kConvGuard + p] = z;
+}
+
+__device__ __forceinline__ void unit_decode(int64_t p, int H, int W, int& n, int& y, int& x) {
+  const int Wp = W + 2, S = (H + 2) * Wp;
+  n = (int)(p / S);
+  const int r = (int)(p - (int64_t)n * S);
+  y = r / Wp;
+  x = r - y * Wp;
+}
+
+// ---- MaxPool2d(2,2) forward on flat tensors: (N,C,H,W) -> (N,C,H/2,W/2) ------------------
+__global__ void maxpool2_fwd_kernel(const f16x8* __restrict__ in, int N, int H, int W, int64_t nposp_in,
+                                    f16x8* __restrict__ out, int64_t nposp_out, int64_t npos_round_out, int chunks) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npos_round_out * chunks) return;
+  const int c8 = (int)(t / npos_round_out);
+  const int64_t p = t - (int64_t)c8 * npos_round_out;
+  const int Ho = H / 2, Wo = W / 2;
+  int n, y, x;
+  unit_decode(p, Ho, Wo, n, y, x);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+  if (n < N && y >= 1 && y <= Ho && x >= 1 && x <= Wo) {
+    const int Wp = W + 2;
+    const int64_t q = (int64_t)c8 * nposp_in + kConvGuard + (int64_t)n * (H + 2) * Wp + (int64_t)(2 * y - 1) * Wp + (2 * x - 1);
+    const f16x8 a0 = in[q], a1 = in[q + 1], a2 = in[q + Wp], a3 = in[q + Wp + 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = (_Float16)fmaxf(fmaxf((float)a0[j], (float)a1[j]), fmaxf((float)a2[j], (float)a3[j]));
+  }
+  out[(int64_t)c8 * nposp_out + kConvGuard + p] = o;
+}
+
+// ---- MaxPool2d(2,2) backward fused with the ReLU gate of the pre-pool layer ----------------
+// dz[pre-pool] = (route(dy) + addend) * [x > 0]; the gradient goes to the FIRST maximum of the window in
+// scan order (torch's max_pool2d keeps `val > maxval`).  addend: optional tap gradient on the pre-pool tensor.
+__global__ void maxpool2_bwd_kernel(const bf16x8* __restrict__ dy, const f16x8* __restrict__ xin,
+                                    const bf16x8* __restrict__ addend, int N, int H, int W, int64_t nposp_in,
+                                    int64_t nposp_out, int64_t npos_range, bf16x8* __restrict__ dz, int chunks) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npos_range * chunks) return;
+  const int c8 = (int)(t / npos_range);
+  const int64_t p = t - (int64_t)c8 * npos_range;
+  int n, y, x;
+  unit_decode(p, H, W, n, y, x);
+  const int64_t u = (int64_t)c8 * nposp_in + kConvGuard + p;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.0f;
+  if (n < N && y >= 1 && y <= H && x >= 1 && x <= W) {
+    const int Ho = H / 2, Wo = W / 2, Wp = W + 2;
+    const int yo = (y - 1) / 2 + 1, xo = (x - 1) / 2 + 1;
+    const f16x8 me = xin[u];
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.0f;
+    if (yo <= Ho && xo <= Wo) {
+      const int wy = (y - 1) & 1, wx = (x - 1) & 1, k = wy * 2 + wx;     // my slot in the window
+      const int64_t q = u - wy * Wp - wx;
+      const f16x8 w0 = xin[q], w1 = xin[q + 1], w2 = xin[q + Wp], w3 = xin[q + Wp + 1];
+      const bf16x8 d = dy[(int64_t)c8 * nposp_out + kConvGuard + (int64_t)n * (Ho + 2) * (Wo + 2) + (int64_t)yo * (Wo + 2) + xo];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v0 = (float)w0[j], v1 = (float)w1[j], v2 = (float)w2[j], v3 = (float)w3[j];
+        int am = 0;
+        float mx = v0;
+        if (v1 > mx) { mx = v1; am = 1; }
+        if (v2 > mx) { mx = v2; am = 2; }
+        if (v3 > mx) { mx = v3; am = 3; }
+        g[j] = am == k ? (float)d[j] : 0.0f;
+      }
+    }
+    if (addend) {
+      const bf16x8 ad = addend[u];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += (float)ad[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)me[j] > 0.0f ? g[j] : 0.0f);
+  }
+  dz[u] = o;
+}
+
+// ---- tap gradient in: df (Ng,C,H,W) fp32 -> flat bf16; gated by [y > 0] when y is given ------------
+template <bool F16OUT>
+__global__ void trunk_grad_in_kernel(const float* __restrict__ df, const f16x8* __restrict__ yact, int Ng, int C, int H,
+                                     int W, int64_t nposp, int64_t npos_range, void* __restrict__ dz_) {
+  typedef typename OpT<F16OUT>::frag frag_t;
+  typedef typename OpT<F16OUT>::elem elem_t;
+  frag_t* dz = (frag_t*)dz_;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = C / 8;
+  if (t >= npos_range * chunks) return;
+  const int c8 = (int)(t / npos_range);
+  const int64_t p = t - (int64_t)c8 * npos_range;
+  int n, y, x;
+  unit_decode(p, H, W, n, y, x);
+  const int64_t u = (int64_t)c8 * nposp + kConvGuard + p;
+  frag_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (elem_t)0.0f;
+  if (n < Ng && y >= 1 && y <= H && x >= 1 && x <= W) {
+    f16x8 m;
+    if (yact) m = yact[u];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = conv_chan(c8, j);
+      const float v = df[(((int64_t)n * C + c) * H + (y - 1)) * W + (x - 1)];
+      o[j] = (elem_t)((!yact || (float)m[j] > 0.0f) ? v : 0.0f);
+    }
+  }
+  dz[u] = o;
+}
+
+// ---- flat -> (N,C,H,W) fp32 (tests / taps of tensors that were not exported by the conv epilogue) ----
+template <bool F16IN>
+__global__ void trunk_export_kernel(const void* __restrict__ act_, int N, int C, int H, int W, int64_t nposp,
+                                    float* __restrict__ out) {
+  typedef typename OpT<F16IN>::frag frag_t;
+  const frag_t* act = (const frag_t*)act_;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = C / 8;
+  const int64_t hw = (int64_t)H * W;
+  if (t >= (int64_t)N * hw * chunks) return;
+  const int c8 = (int)(t / (N * hw));
+  const int64_t r = t - (int64_t)c8 * N * hw;
+  const int n = (int)(r / hw);
+  const int q = (int)(r - (int64_t)n * hw), y = q / W, x = q - y * W;
+  const frag_t v = act[(int64_t)c8 * nposp + kConvGuard + (int64_t)n * (H + 2) * (W + 2) + (int64_t)(y + 1) * (W + 2) + (x + 1)];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[(((int64_t)n * C + conv_chan(c8, j)) * H + y) * W + x] = (float)v[j];
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+static int conv_geom_check(int N, int H, int W, const char* who) {
+  if (N < 1 || H < 1 || W < 1 || W + 3 > kConvGuard) {
+    set_error("%s: bad geometry N=%d H=%d W=%d (W <= %d)", who, N, H, W, kConvGuard - 3);
+    return NPP_ERR_ARG;
+  }
+  if (conv_nposp(N, H, W) * 16 * 64 > 0x7fffffffLL) {   // 512 channels * nposp * 16 B must fit a 32-bit buffer descriptor
+    set_error("%s: tensor too large for one launch (N*(H+2)*(W+2) = %lld positions)", who, (long long)conv_npos_round(N, H, W));
+    return NPP_ERR_ARG;
+  }
+  return NPP_OK;
+}
+
+extern "C" int64_t npp_trunk_nposp(int N, int H, int W) {
+  if (N < 1 || H < 1 || W < 1) return NPP_ERR_ARG;
+  return conv_nposp(N, H, W);
+}
+
+extern "C" int64_t npp_trunk_act_bytes(int N, int C, int H, int W) {
+  if (N < 1 || H < 1 || W < 1 || C < 1) return NPP_ERR_ARG;
+  return (int64_t)((C + 15) / 16 * 2) * conv_nposp(N, H, W) * 16;
+}
+
+extern "C" int64_t npp_conv_pack_bytes(int Cin, int Cout, int which) {
+  if (Cin < 1 || Cout < 1 || Cout % 16) return NPP_ERR_ARG;
+  const int CIp = (Cin + 15) / 16 * 16;
+  if (which == 0) return (int64_t)((Cout + 31) / 32) * (CIp / 16) * 9 * 1024;
+  if (which == 1) return (int64_t)((CIp + 31) / 32) * (Cout / 16) * 9 * 1024;
+  return NPP_ERR_ARG;
+}
+
+extern "C" int npp_conv_pack(const float* d_w, int Cin, int Cout, int in_natural, void* d_pack_fwd, void* d_pack_bwd,
+                             void* stream) {
+  if (!d_w || !d_pack_fwd || !d_pack_bwd || Cin < 1 || Cout < 16 || Cout % 16) {
+    set_error("npp_conv_pack: bad argument (Cin=%d Cout=%d)", Cin, Cout);
+    return NPP_ERR_ARG;
+  }
+  if (!in_natural && Cin % 16) { set_error("npp_conv_pack: Cin=%d must be a multiple of 16 unless in_natural", Cin); return NPP_ERR_ARG; }
+  const int CIp = (Cin + 15) / 16 * 16;
+  const int64_t nf = npp_conv_pack_bytes(Cin, Cout, 0) / 16, nb = npp_conv_pack_bytes(Cin, Cout, 1) / 16;
+  const int64_t n = nf + nb;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, Cin, Cout,
+                     in_natural, CIp, (f16x8*)d_pack_fwd, nf, (bf16x8*)d_pack_bwd, nb);
+  return check_launch("npp_conv_pack");
+}
+
+extern "C" int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, const float scale[3], const float shift[3],
+                                  void* d_x0, void* stream) {
+  int rc = conv_geom_check(N, H, W, "npp_trunk_image_in");
+  if (rc) return rc;
+  if (!d_img_nchw || !d_x0 || !scale || !shift) { set_error("npp_trunk_image_in: null pointer"); return NPP_ERR_ARG; }
+  const int64_t nr = conv_npos_round(N, H, W);
+  hipLaunchKernelGGL(trunk_image_in_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img_nchw,
+                     N, H, W, scale[0], scale[1], scale[2], shift[0], shift[1], shift[2], (f16x8*)d_x0, conv_nposp(N, H, W), nr);
+  return check_launch("npp_trunk_image_in");
+}
+
+template <int CT, int PT>
+static void conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t s) {
+  if (mode == kConvFwd) hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvFwd>), grid, dim3(256), 0, s, a);
+  else if (mode == kConvDgradMask) hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvDgradMask>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvDgradLin>), grid, dim3(256), 0, s, a);
+}
+
+// mode 0: y = relu(conv(x) + bias)            (forward layer)
+// mode 1: y = conv_T(x) * [mask > 0]          (data gradient through a conv into a ReLU layer's pre-activation)
+// mode 2: y = conv_T(x)                       (data gradient into a pooled tensor / the image)
+// N_total fixes the geometry of the buffers, n_run <= N_total the leading images actually computed.
+extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                           const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
+                           const float* tap_scale, void* stream) {
+  int rc = conv_geom_check(N_total, H, W, "npp_conv3x3");
+  if (rc) return rc;
+  if (!d_x || !d_pack || (!d_y && !d_tap) || mode < 0 || mode > 2 || n_run < 1 || n_run > N_total) {
+    set_error("npp_conv3x3: bad argument (mode=%d n_run=%d N=%d)", mode, n_run, N_total);
+    return NPP_ERR_ARG;
+  }
+  if (Cin % 16 || Cout % 16 || Cin < 16 || Cout < 16 || Cin > 512 || Cout > 512) {
+    set_error("npp_conv3x3: Cin=%d / Cout=%d must be multiples of 16 in [16, 512] (pad the image to 16 channels)", Cin, Cout);
+    return NPP_ERR_ARG;
+  }
+  if ((mode == kConvFwd && !d_bias) || (mode == kConvDgradMask && !d_mask)) { set_error("npp_conv3x3: mode %d needs bias / mask", mode); return NPP_ERR_ARG; }
+  if (d_tap && (Ctap < 1 || Ctap > Cout || (tap_scale && Ctap > 4))) { set_error("npp_conv3x3: bad Ctap=%d", Ctap); return NPP_ERR_ARG; }
+  ConvArgs a{};
+  a.x = d_x; a.pack = d_pack; a.bias = d_bias; a.mask = d_mask; a.y = d_y; a.tap = d_tap;
+  a.N = N_total; a.H = H; a.W = W; a.Wp = W + 2; a.S = (H + 2) * (W + 2); a.CI = Cin / 16; a.cout_chunks = Cout / 8;
+  a.Ctap = d_tap ? Ctap : 0; a.has_scale = tap_scale != nullptr;
+  for (int i = 0; i < 4; ++i) a.tap_scale[i] = (tap_scale && i < Ctap) ? tap_scale[i] : 1.0f;
+  a.nposp = conv_nposp(N_total, H, W);
+  a.npos_valid = (int64_t)N_total * a.S;
+  const int64_t range = n_run == N_total ? conv_npos_round(N_total, H, W)
+                                         : ((int64_t)n_run * a.S + kPosRound - 1) / kPosRound * kPosRound;
+  a.pos_tiles = (int)(range / 32);
+  a.x_bytes = (uint32_t)((int64_t)(Cin / 8) * a.nposp * 16);
+  const int cot_n = (Cout + 31) / 32;
+  a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
+  hipStream_t s = (hipStream_t)stream;
+  // Tile choice: the largest wave tile (fewest operand bytes per MFMA) that still gives every SIMD of the
+  // chip (256 CUs x 4) about two waves; the small late layers fall back to small tiles.
+  const int64_t tiles = (int64_t)a.pos_tiles * cot_n;
+  auto grid_for = [&](int ct, int pt) { return dim3((unsigned)((a.pos_tiles + 4 * pt - 1) / (4 * pt)), (unsigned)(cot_n / ct)); };
+  const int64_t want = 2048;
+  if (cot_n % 4 == 0 && tiles / 8 >= want) conv_launch_mode<4, 2>(a, mode, grid_for(4, 2), s);
+  else if (cot_n % 2 == 0 && tiles / 8 >= want) conv_launch_mode<2, 4>(a, mode, grid_for(2, 4), s);
+  else if (cot_n % 2 == 0 && tiles / 4 >= want) conv_launch_mode<2, 2>(a, mode, grid_for(2, 2), s);
+  else if (cot_n % 2 == 0 && tiles / 2 >= want / 2) conv_launch_mode<2, 1>(a, mode, grid_for(2, 1), s);
+  else conv_launch_mode<1, 1>(a, mode, grid_for(1, 1), s);
+  return check_launch("npp_conv3x3");
+}
+
+extern "C" int npp_maxpool2_fwd(const void* d_x, int N, int H, int W, int C, void* d_y, void* stream) {
+  int rc = conv_geom_check(N, H, W, "npp_maxpool2_fwd");
+  if (rc) return rc;
+  if (!d_x || !d_y || C % 16 || H < 2 || W < 2) { set_error("npp_maxpool2_fwd: bad argument"); return NPP_ERR_ARG; }
+  const int64_t nr = conv_npos_round(N, H / 2, W / 2), n = nr * (C / 8);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)d_x,
+                     N, H, W, conv_nposp(N, H, W), (f16x8*)d_y, conv_nposp(N, H / 2, W / 2), nr, C / 8);
+  return check_launch("npp_maxpool2_fwd");
+}
+
+extern "C" int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, int N_total, int n_run, int H, int W,
+                                int C, void* d_dz, void* stream) {
+  int rc = conv_geom_check(N_total, H, W, "npp_maxpool2_bwd");
+  if (rc) return rc;
+  if (!d_dy || !d_x || !d_dz || C % 16 || H < 2 || W < 2 || n_run < 1 || n_run > N_total) { set_error("npp_maxpool2_bwd: bad argument"); return NPP_ERR_ARG; }
+  const int64_t S = (int64_t)(H + 2) * (W + 2);
+  const int64_t range = n_run == N_total ? conv_npos_round(N_total, H, W) : ((int64_t)n_run * S + kPosRound - 1) / kPosRound * kPosRound;
+  const int64_t n = range * (C / 8);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)d_dy,
+                     (const f16x8*)d_x, (const bf16x8*)d_addend, n_run, H, W, conv_nposp(N_total, H, W),
+                     conv_nposp(N_total, H / 2, W / 2), range, (bf16x8*)d_dz, C / 8);
+  return check_launch("npp_maxpool2_bwd");
+}
+
+extern "C" int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W,
+                                 void* d_dz, int as_f16, void* stream) {
+  int rc = conv_geom_check(N_total, H, W, "npp_trunk_grad_in");
+  if (rc) return rc;
+  if (!d_df_nchw || !d_dz || C % 16 || n_run < 1 || n_run > N_total) { set_error("npp_trunk_grad_in: bad argument"); return NPP_ERR_ARG; }
+  const int64_t S = (int64_t)(H + 2) * (W + 2);
+  const int64_t range = n_run == N_total ? conv_npos_round(N_total, H, W) : ((int64_t)n_run * S + kPosRound - 1) / kPosRound * kPosRound;
+  const int64_t n = range * (C / 8);
+  if (as_f16)
+    hipLaunchKernelGGL(trunk_grad_in_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz);
+  else
+    hipLaunchKernelGGL(trunk_grad_in_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz);
+  return check_launch("npp_trunk_grad_in");
+}
+
+extern "C" int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W, float* d_out_nchw, int is_f16,
+                                void* stream) {
+  int rc = conv_geom_check(N_total, H, W, "npp_trunk_export");
+  if (rc) return rc;
+  if (!d_act || !d_out_nchw || C % 16 || n_run < 1 || n_run > N_total) { set_error("npp_trunk_export: bad argument"); return NPP_ERR_ARG; }
+  const int64_t n = (int64_t)n_run * H * W * (C / 8);
+  if (is_f16)
+    hipLaunchKernelGGL(trunk_export_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_act,
+                       n_run, C, H, W, conv_nposp(N_total, H, W), d_out_nchw);
+  else
+    hipLaunchKernelGGL(trunk_export_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_act,
+                       n_run, C, H, W, conv_nposp(N_total, H, W), d_out_nchw);
+  return check_launch("npp_trunk_export");
+}

@@ -22,7 +22,7 @@ class CompletionFit:
                  ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
-                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None):
+                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip"):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173)."""
         img = np.asarray(img, np.float32)
@@ -58,9 +58,9 @@ class CompletionFit:
                 img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
                 height=self.H, width=self.W, pool_train=self.i_train, pool_val=self.i_val, selected_shifts=shifts,
                 no_reg_sampling=False, rng=self.rng)
-            self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict).to(self.device)
+            self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, trunk=trunk, device=self.device).to(self.device)
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
-                                    device=self.device)
+                                    device=self.device, trunk=trunk)
             self.last_source, self.skipped = None, 0
 
     # ---- sampling (train.py:172-181) -------------------------------------------------

@@ -7,8 +7,10 @@ modules remain drop-ins for the reference's (`loss.backward()` keeps working).
 
 The VGG19[0:18] / VGG16 trunks are frozen third-party convolution stacks whose pretrained
 torchvision weights are not available offline: they are built here layer by
-layer (no torchvision import), run through PyTorch/MIOpen as glue, and take either a
-torchvision-format state_dict supplied by the user or a fixed-seed random init.
+layer (no torchvision import) and take either a torchvision-format state_dict supplied by the
+user or a fixed-seed random init.  They run in libnpp_hip.so as well (HipTrunk: npp_conv3x3 /
+npp_maxpool2_* on flat padded bf16 tensors, forward and data gradient); `_Trunk` is the same
+stack through torch.nn (fp32, MIOpen) and is kept only as the comparator of the GPU tests.
 """
 import numpy as np
 import torch
@@ -54,6 +56,136 @@ class _Trunk(nn.Module):
         return outs
 
 
+class _HipTrunkFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, trunk, n_grad, scale, shift):
+        taps = trunk._forward(x.contiguous(), scale, shift)
+        ctx.trunk, ctx.n_grad, ctx.scale, ctx.gen, ctx.shape = trunk, n_grad, scale, trunk._gen, tuple(x.shape)
+        return tuple(taps)
+
+    @staticmethod
+    def backward(ctx, *gt):
+        t = ctx.trunk
+        if t._gen != ctx.gen:
+            raise RuntimeError("HipTrunk: backward after a newer forward of the same trunk (its activation buffers are "
+                               "reused between calls; run forward -> backward pairwise)")
+        n = ctx.n_grad
+        g = [None if (v is None or n == 0) else v[:n].contiguous() for v in gt]
+        return t._backward(g, n, ctx.scale, ctx.shape), None, None, None, None
+
+
+class HipTrunk:
+    """conv3x3+ReLU / MaxPool2d(2,2) stack (torchvision `features` indexing) on the HIP kernels of
+    csrc/npp_conv.hip.  __call__(x (N,3,H,W), n_grad, scale, shift) -> list of fp32 (N,C,h,w) taps of
+    relu outputs; the first n_grad images carry a gradient back to x, the rest are constants (the
+    reference runs those under torch.no_grad(): contextual.py:63-64, frozen weights vgg.py:26-28)."""
+
+    def __init__(self, cfg, taps, state_dict=None, seed=1234, device="cuda"):
+        ref = _Trunk(cfg, taps, state_dict, seed)                  # same layer construction / init as the comparator
+        self.device = torch.device(device)
+        self.taps = tuple(taps)
+        self.layers = []                                           # ("conv", feat_idx_of_relu, cin, cout, w, b, pf, pb) | ("pool",)
+        for i, m in enumerate(ref.features):
+            if isinstance(m, nn.Conv2d):
+                w = m.weight.detach().to(self.device, torch.float32).contiguous()
+                b = m.bias.detach().to(self.device, torch.float32).contiguous()
+                pf, pb = ops.conv_pack(w, in_natural=(len(self.layers) == 0))
+                self.layers.append(dict(kind="conv", relu_idx=i + 1, cin=w.shape[1], cout=w.shape[0], w=w, b=b, pf=pf, pb=pb))
+            elif isinstance(m, nn.MaxPool2d):
+                self.layers.append(dict(kind="pool", idx=i))
+        for j, L in enumerate(self.layers):                         # gradient taps are supported on the top layer and before pools
+            if L["kind"] == "conv" and L["relu_idx"] in self.taps:
+                nxt = self.layers[j + 1]["kind"] if j + 1 < len(self.layers) else None
+                L["tap_ok"] = nxt in (None, "pool")
+        self._buf, self._gen = {}, 0
+
+    def _flat(self, tag, N, C, H, W):
+        key = (tag, N, C, H, W)
+        t = self._buf.get(key)
+        if t is None:
+            t = self._buf[key] = ops.trunk_alloc(N, C, H, W, self.device)
+        return t
+
+    def __call__(self, x, n_grad=0, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+        need = n_grad > 0 and x.requires_grad
+        return list(_HipTrunkFunction.apply(x, self, n_grad if need else 0, tuple(scale), tuple(shift)))
+
+    def _forward(self, x, scale, shift):
+        N, _, H, W = x.shape
+        self._gen += 1
+        self._geom = []
+        cur = self._flat("x0", N, 16, H, W)
+        ops.trunk_image_in(x, scale, shift, cur)
+        c, outs = 16, []
+        for j, L in enumerate(self.layers):
+            if L["kind"] == "conv":
+                y = self._flat(("a", j), N, L["cout"], H, W)
+                tap = None
+                if L["relu_idx"] in self.taps:
+                    tap = torch.empty((N, L["cout"], H, W), dtype=torch.float32, device=self.device)
+                    outs.append(tap)
+                ops.conv3x3(cur, N, N, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0)
+                c = L["cout"]
+            else:
+                y = self._flat(("a", j), N, c, H // 2, W // 2)
+                ops.maxpool2_fwd(cur, N, H, W, c, y)
+                H, W = H // 2, W // 2
+            self._geom.append((y, c, H, W))
+            cur = y
+        return outs
+
+    def _backward(self, gtaps, n, scale, xshape):
+        N = xshape[0]
+        dimg = torch.zeros(xshape, dtype=torch.float32, device=self.device)
+        if n == 0:
+            return dimg
+        tap_of = {}
+        k = 0
+        for j, L in enumerate(self.layers):
+            if L["kind"] == "conv" and L["relu_idx"] in self.taps:
+                if gtaps[k] is not None:
+                    if not L.get("tap_ok"):
+                        raise NotImplementedError("HipTrunk: gradient taps must sit on the top layer or right before a pool")
+                    tap_of[j] = gtaps[k]
+                k += 1
+        if not tap_of:
+            return dimg
+        flip = [0]
+
+        def gbuf(C, H, W):
+            flip[0] ^= 1
+            return self._flat(("g", flip[0]), N, C, H, W)
+
+        j = max(tap_of)
+        y, c, H, W = self._geom[j]
+        dz = gbuf(c, H, W)
+        ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, dz)           # dz_j = dL/dtap * [y > 0]
+        while True:
+            L = self.layers[j]                                      # dz = dL/d(pre-activation) of conv layer j
+            if j == 0:
+                ops.conv3x3(dz, N, n, H, W, L["cout"], 16, L["pb"], None, 2, None, None, dimg, 3, scale)
+                return dimg
+            prev = self.layers[j - 1]
+            if prev["kind"] == "conv":
+                if (j - 1) in tap_of:
+                    raise NotImplementedError("HipTrunk: gradient tap below a conv layer")
+                yp, cp, _, _ = self._geom[j - 1]
+                dzp = gbuf(cp, H, W)
+                ops.conv3x3(dz, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp)
+                dz, j = dzp, j - 1
+            else:                                                   # pool at j-1, conv at j-2
+                yp, cp, Hp, Wp = self._geom[j - 2]
+                g = gbuf(cp, H, W)
+                ops.conv3x3(dz, N, n, H, W, L["cout"], cp, L["pb"], None, 2, None, g)
+                add = None
+                if (j - 2) in tap_of:
+                    add = self._flat("tapadd", N, cp, Hp, Wp)
+                    ops.trunk_grad_in(tap_of[j - 2], None, N, n, cp, Hp, Wp, add)
+                dzp = gbuf(cp, Hp, Wp)
+                ops.maxpool2_bwd(g, yp, add, N, n, Hp, Wp, cp, dzp)
+                dz, j, H, W = dzp, j - 2, Hp, Wp
+
+
 class _CXFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fx, fy, band_width, weight):
@@ -75,18 +207,30 @@ def contextual_loss(x, y, band_width=0.5, weight=None, loss_type="cosine"):
 
 
 class ContextualLoss(nn.Module):
-    def __init__(self, band_width=0.5, loss_type="cosine", use_vgg=False, vgg_layer="relu3_4", vgg_state_dict=None):
+    _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)        # contextual.py:41-46
+
+    def __init__(self, band_width=0.5, loss_type="cosine", use_vgg=False, vgg_layer="relu3_4", vgg_state_dict=None,
+                 trunk="hip", device="cuda"):
         super().__init__()
         assert band_width > 0, "band_width parameter must be positive."
         assert loss_type == "cosine" and vgg_layer == "relu3_4"
         self.band_width = band_width
-        if use_vgg:
+        self.trunk_kind = trunk
+        if use_vgg and trunk == "hip":
+            self.hip_trunk = HipTrunk(_VGG19, taps=(17,), state_dict=vgg_state_dict, device=device)
+        elif use_vgg:                  # comparator: the same stack through torch.nn / MIOpen (tests only)
             self.vgg_model = _Trunk(_VGG19, taps=(17,), state_dict=vgg_state_dict)
-            self.register_buffer("vgg_mean", torch.tensor([[[0.485]], [[0.456]], [[0.406]]]))
-            self.register_buffer("vgg_std", torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
+            self.register_buffer("vgg_mean", torch.tensor(self._MEAN).reshape(3, 1, 1))
+            self.register_buffer("vgg_std", torch.tensor(self._STD).reshape(3, 1, 1))
 
     def forward(self, x, y, weight=None):
-        if hasattr(self, "vgg_model"):
+        if hasattr(self, "hip_trunk"):
+            assert x.shape[1] == 3 and y.shape[1] == 3, "VGG model takes 3 chennel images."
+            n = x.shape[0]                                   # (x - mean) / std is folded into the image-in kernel
+            f = self.hip_trunk(torch.cat([x, y.detach()], 0), n_grad=n, scale=[1.0 / s for s in self._STD],
+                               shift=[-m / s for m, s in zip(self._MEAN, self._STD)])[0]
+            x, y = f[:n], f[n:].detach()
+        elif hasattr(self, "vgg_model"):
             assert x.shape[1] == 3 and y.shape[1] == 3, "VGG model takes 3 chennel images."
             x = x.sub(self.vgg_mean).div(self.vgg_std)
             y = y.sub(self.vgg_mean).div(self.vgg_std)
@@ -122,13 +266,19 @@ class LPIPS(nn.Module):
     normalize) returns the batch MEAN as a scalar (the caller's torch.mean, train.py:249, is folded in)."""
     chns = [64, 128, 256, 512, 512]
 
-    def __init__(self, net="vgg", lin_weights=None, vgg_state_dict=None, device="cuda"):
+    _SHIFT, _SCALE = (-.030, -.088, -.188), (.458, .448, .450)          # lpips.py:136-143 ScalingLayer
+
+    def __init__(self, net="vgg", lin_weights=None, vgg_state_dict=None, device="cuda", trunk="hip"):
         super().__init__()
         assert net in ("vgg", "vgg16")
-        self.net = _Trunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321)
-        self.register_buffer("shift", torch.tensor([-.030, -.088, -.188])[None, :, None, None])
-        self.register_buffer("scale", torch.tensor([.458, .448, .450])[None, :, None, None])
         dev = torch.device(device)
+        self.trunk_kind = trunk
+        if trunk == "hip":
+            self.hip_trunk = HipTrunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321, device=dev)
+        else:                          # comparator: torch.nn / MIOpen (tests only)
+            self.net = _Trunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321)
+        self.register_buffer("shift", torch.tensor(self._SHIFT)[None, :, None, None])
+        self.register_buffer("scale", torch.tensor(self._SCALE)[None, :, None, None])
         if lin_weights is None:          # weights/v0.1/vgg.pth is not redistributed here: fixed-seed non-negative stand-ins
             rng = np.random.RandomState(7)
             lin_weights = [np.abs(rng.randn(c)).astype(np.float32) * 0.05 for c in self.chns]
@@ -145,12 +295,19 @@ class LPIPS(nn.Module):
 
     def forward(self, in0, in1, use_robust=True, retPerLayer=False, normalize=False):
         assert use_robust and not retPerLayer, "only the use_robust=True path of the loop is built"
-        if normalize:
-            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
-        in0, in1 = (in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale
-        outs0 = self.net(in0)
-        with torch.no_grad():
-            outs1 = self.net(in1)
+        if self.trunk_kind == "hip":       # 2x-1 (lpips.py:96-98) and the scaling layer are folded into the image-in kernel
+            a = 2.0 if normalize else 1.0
+            n = in0.shape[0]
+            f = self.hip_trunk(torch.cat([in0, in1.detach()], 0), n_grad=n, scale=[a / s for s in self._SCALE],
+                               shift=[((-1.0 if normalize else 0.0) - sh) / s for sh, s in zip(self._SHIFT, self._SCALE)])
+            outs0, outs1 = [t[:n] for t in f], [t[n:].detach() for t in f]
+        else:
+            if normalize:
+                in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+            in0, in1 = (in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale
+            outs0 = self.net(in0)
+            with torch.no_grad():
+                outs1 = self.net(in1)
         val = 0
         for kk in range(5):
             val = val + _LPIPSLayerFunction.apply(outs0[kk], outs1[kk], self, kk)

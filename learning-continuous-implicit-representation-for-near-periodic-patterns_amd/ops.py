@@ -236,3 +236,63 @@ def adam_step_dev(p, m, v, gslabs, n_slabs, slab_stride, hp, b1=0.9, b2=0.999, e
     (graph-replayable form of adam_step)."""
     check(lib().npp_adam_step_dev(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, b1, b2, eps, _p(hp),
                                   _stream()), "npp_adam_step_dev")
+
+
+# ---- a11 / a13 trunks: conv3x3 + ReLU / MaxPool2d stacks on flat padded bf16 tensors ----------------
+def trunk_nposp(N, H, W):
+    return int(check(lib().npp_trunk_nposp(N, H, W), "npp_trunk_nposp"))
+
+
+def trunk_alloc(N, C, H, W, device):
+    """Zero-initialised flat tensor for a logical (N,C,H,W) activation (csrc/npp_conv.hip layout)."""
+    nbytes = int(check(lib().npp_trunk_act_bytes(N, C, H, W), "npp_trunk_act_bytes"))
+    return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
+
+def conv_pack(weight, in_natural=False):
+    """torch Conv2d weight (Cout,Cin,3,3) fp32 -> (forward pack, data-gradient pack), bf16 MFMA fragments."""
+    _req(weight, torch.float32, "weight")
+    cout, cin = weight.shape[:2]
+    assert tuple(weight.shape[2:]) == (3, 3)
+    nf = int(check(lib().npp_conv_pack_bytes(cin, cout, 0), "npp_conv_pack_bytes"))
+    nb = int(check(lib().npp_conv_pack_bytes(cin, cout, 1), "npp_conv_pack_bytes"))
+    pf = torch.empty(nf, dtype=torch.uint8, device=weight.device)
+    pb = torch.empty(nb, dtype=torch.uint8, device=weight.device)
+    check(lib().npp_conv_pack(_p(weight), cin, cout, int(bool(in_natural)), _p(pf), _p(pb), _stream()), "npp_conv_pack")
+    return pf, pb
+
+
+def trunk_image_in(img, scale, shift, x0):
+    """(N,3,H,W) fp32 -> flat C=16 tensor of img*scale[c] + shift[c]."""
+    _req(img, torch.float32, "img")
+    N, c, H, W = img.shape
+    assert c == 3
+    s = (C.c_float * 3)(*[float(v) for v in scale])
+    b = (C.c_float * 3)(*[float(v) for v in shift])
+    check(lib().npp_trunk_image_in(_p(img), N, H, W, s, b, _p(x0), _stream()), "npp_trunk_image_in")
+
+
+def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=None, ctap=0, tap_scale=None):
+    ts = None if tap_scale is None else (C.c_float * len(tap_scale))(*[float(v) for v in tap_scale])
+    check(lib().npp_conv3x3(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), mode, _p(mask), _p(y), _p(tap),
+                            ctap, ts, _stream()), "npp_conv3x3")
+
+
+def maxpool2_fwd(x, N, H, W, c, y):
+    check(lib().npp_maxpool2_fwd(_p(x), N, H, W, c, _p(y), _stream()), "npp_maxpool2_fwd")
+
+
+def maxpool2_bwd(dy, x, addend, N_total, n_run, H, W, c, dz):
+    check(lib().npp_maxpool2_bwd(_p(dy), _p(x), _p(addend), N_total, n_run, H, W, c, _p(dz), _stream()), "npp_maxpool2_bwd")
+
+
+def trunk_grad_in(df, y, N_total, n_run, c, H, W, dz, as_f16=False):
+    _req(df, torch.float32, "df", (n_run, c, H, W))
+    check(lib().npp_trunk_grad_in(_p(df), _p(y), N_total, n_run, c, H, W, _p(dz), int(bool(as_f16)), _stream()),
+          "npp_trunk_grad_in")
+
+
+def trunk_export(act, N_total, n_run, c, H, W, is_f16=False):
+    out = torch.empty((n_run, c, H, W), dtype=torch.float32, device=act.device)
+    check(lib().npp_trunk_export(_p(act), N_total, n_run, c, H, W, _p(out), int(bool(is_f16)), _stream()), "npp_trunk_export")
+    return out

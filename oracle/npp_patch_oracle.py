@@ -2,9 +2,13 @@
 periodicity-guided GridPatchSampler, the contextual-loss core and the LPIPS head.
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned by tests/golden/g5-g7.
 
-The VGG16/VGG19 trunks are NOT restated: torchvision's pretrained weights are not part of
-/root/reference, so parity for CX / LPIPS is stated from the feature tensors onward
-("parity unpinned for the VGG trunks").
+VGG16/VGG19 trunks: torchvision's pretrained weights are not part of /root/reference, so parity
+for CX / LPIPS is stated from the feature tensors onward ("parity unpinned for the
+VGG trunks").  The STRUCTURE of the trunks (3x3/pad-1 convolutions + ReLU, 2x2 max-pools, which
+torchvision `features` indices are tapped) is restated at the bottom of this file from
+contextual_loss/modules/vgg.py:16-21,30-36 and lpips/pretrained_networks.py:96-134, and pinned
+against torch's own F.conv2d / F.max_pool2d (the third-party ops those modules call) in
+tests/test_oracle_trunk.py with arbitrary weights.
 """
 from __future__ import annotations
 
@@ -13,7 +17,8 @@ import numpy as np
 from .npp_oracle import F32, adaptive_params, robust_nll, robust_nll_grads, load_partition_spline
 
 __all__ = ["extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
-           "lpips_head", "lpips_head_grads", "scaling_layer"]
+           "lpips_head", "lpips_head_grads", "scaling_layer", "VGG19_CX_CFG", "VGG16_LPIPS_CFG", "VGG19_CX_TAPS",
+           "VGG16_LPIPS_TAPS", "conv3x3", "conv3x3_dgrad", "maxpool2", "maxpool2_bwd", "trunk_forward", "trunk_backward"]
 
 
 # --------------------------------------------------------------------------
@@ -257,3 +262,101 @@ def lpips_head_grads(feats0, feats1, lins, latents_alpha, latents_scale):
         dlas.append(((da * coef).sum(0, keepdims=True, dtype=np.float64) * dalpha).astype(F32))
         dlss.append(((dc * coef).sum(0, keepdims=True, dtype=np.float64) * dscale).astype(F32))
     return loss, dfs, dlas, dlss
+
+
+# --------------------------------------------------------------------------
+# a11 / a13 trunks: structure of the frozen convolution stacks
+#   contextual_loss/modules/vgg.py:16-21: vgg19.features[0:4 | 4:9 | 9:18] -> relu1_2, relu2_2, relu3_4
+#     (ContextualLoss uses vgg_layer='relu3_4' = features index 17, contextual.py:27,64)
+#   lpips/pretrained_networks.py:104-115: vgg16.features[0:4 | 4:9 | 9:16 | 16:23 | 23:30]
+#     -> relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 = features indices 3, 8, 15, 22, 29
+# torchvision's `features` = Conv2d(cin, v, 3, padding=1) + ReLU per number, MaxPool2d(2, 2) per 'M'.
+# --------------------------------------------------------------------------
+VGG19_CX_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256]
+VGG16_LPIPS_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]
+VGG19_CX_TAPS = (17,)
+VGG16_LPIPS_TAPS = (3, 8, 15, 22, 29)
+
+
+def conv3x3(x, w, b):
+    """F.conv2d(x, w, b, padding=1): x (N,Cin,H,W), w (Cout,Cin,3,3) cross-correlation."""
+    x = np.asarray(x, F32)
+    N, _, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    out = np.zeros((N, w.shape[0], H, W), np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            out += np.einsum("nchw,oc->nohw", xp[:, :, ky:ky + H, kx:kx + W].astype(np.float64), w[:, :, ky, kx].astype(np.float64))
+    return (out + np.asarray(b, np.float64)[None, :, None, None]).astype(F32)
+
+
+def conv3x3_dgrad(dz, w):
+    """dL/dx of conv3x3 given dL/dz: correlation with the flipped, transposed kernel."""
+    dz = np.asarray(dz, F32)
+    N, _, H, W = dz.shape
+    dp = np.pad(dz, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    out = np.zeros((N, w.shape[1], H, W), np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            out += np.einsum("nohw,oc->nchw", dp[:, :, ky:ky + H, kx:kx + W].astype(np.float64), w[:, :, 2 - ky, 2 - kx].astype(np.float64))
+    return out.astype(F32)
+
+
+def maxpool2(x):
+    """nn.MaxPool2d(2, 2) (floor mode) -> (pooled, argmax slot 0..3 in scan order, first maximum wins)."""
+    N, C, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    win = np.stack([x[:, :, dy:2 * Ho:2, dx:2 * Wo:2] for dy in (0, 1) for dx in (0, 1)], -1)
+    return win.max(-1), win.argmax(-1)          # np.argmax returns the first maximum
+
+
+def maxpool2_bwd(dy, arg, shape):
+    N, C, H, W = shape
+    Ho, Wo = H // 2, W // 2
+    dx = np.zeros(shape, F32)
+    for k, (oy, ox) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        dx[:, :, oy:2 * Ho:2, ox:2 * Wo:2] = np.where(arg == k, dy, 0)
+    return dx
+
+
+def trunk_forward(x, cfg, weights, taps):
+    """x (N,3,H,W) already normalised; weights: [(w, b)] per conv.  Returns (tap outputs, cache)."""
+    outs, cache, idx, wi = [], [], 0, 0
+    for v in cfg:
+        if v == "M":
+            y, arg = maxpool2(x)
+            cache.append(("pool", x.shape, arg))
+            x = y
+            idx += 1
+        else:
+            w, b = weights[wi]
+            wi += 1
+            z = conv3x3(x, w, b)
+            x = np.maximum(z, 0)
+            cache.append(("conv", w, z > 0))
+            idx += 2
+            if idx - 1 in taps:
+                outs.append(x)
+    return outs, cache
+
+
+def trunk_backward(cfg, cache, taps, tap_grads):
+    """dL/dx (the normalised input) from dL/dtap for every tap (None = no gradient)."""
+    tap_at, idx, k = {}, 0, 0
+    for li, v in enumerate(cfg):
+        idx += 1 if v == "M" else 2
+        if v != "M" and idx - 1 in taps:
+            tap_at[li] = tap_grads[k]
+            k += 1
+    g = None
+    for li in range(len(cfg) - 1, -1, -1):
+        if li in tap_at and tap_at[li] is not None:
+            g = tap_at[li] if g is None else g + tap_at[li]
+        if g is None:
+            continue
+        c = cache[li]
+        if c[0] == "pool":
+            g = maxpool2_bwd(g, c[2], c[1])
+        else:
+            g = conv3x3_dgrad(np.where(c[2], g, 0).astype(F32), c[1])
+    return g
