@@ -189,6 +189,21 @@ int npp_patch_gather(const float* d_img_hwc, const float* d_mask_hw, int H, int 
                      const int32_t* d_centres_yx, int M, int P, float* d_out_rgb,
                      float* d_out_mask, void* stream);
 
+/* ---- a10: patch plumbing (NPP_completion/train.py:200-236) and its backward ------ */
+/* d_pred_rows (n_p*P*P, 3): the predicted patch rows (row = (p*P + y)*P + x, train.py:178-181);
+ * d_fake (n_p,3,P,P) / d_fmask (n_p,1,P,P): fake patch and its known mask (untiled; the reference
+ * tiles them k times); d_real (n_p*k,3,P,P) / d_rmask (n_p*k,1,P,P).  comp != 0: 'val' compositing
+ * (train.py:230-231).  d_xy (2*n_p*k, 3, P, P) = [x | y]: x = (comp ? fake*fmask + pred*(1-fmask)
+ * : pred) * rmask, y = real * rmask -- the inputs of contextualLoss (and of percepLoss in 'same'
+ * mode).  The backward sums dL/dx (two sources: d_dx_b nullable) over the k copies into
+ * d_dpred_rows (n_p*P*P, 3) (overwritten). */
+int npp_patch_compose_fwd(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
+                          const float* d_real, const float* d_rmask, int n_p, int k, int P,
+                          int comp, float* d_xy, void* stream);
+int npp_patch_compose_bwd(const float* d_dx_a, const float* d_dx_b, const float* d_fmask,
+                          const float* d_rmask, int n_p, int k, int P, int comp,
+                          float* d_dpred_rows, void* stream);
+
 /* ---- a12: contextual loss core ------------------------------------------------ */
 /* Replaces contextual_loss(x, y, band_width, weight, 'cosine') and its backward w.r.t. x
  * (externel_lib/contextual_loss/functional.py:9-63,127-163) on feature tensors (N,C,h*w) fp32

@@ -4,9 +4,9 @@
 // data-gradient, as 16-bit-MFMA implicit GEMMs (fp32 accumulation).  Numeric contract: FORWARD operands
 // (activations, weights) are fp16 -- 11 significand bits, the class of the TF32 convolutions cuDNN runs
 // the reference's trunks with by default -- saturated at +-65504; GRADIENT operands are bf16 (range
-// over precision: nothing here can under/overflow), ReLU gates are taken from the fp16 activations.  The reference runs them through
-// torchvision/cuDNN (F.conv2d 3x3 pad 1 + ReLU, MaxPool2d(2,2)); weights are frozen
-// (vgg.py:26-28), so only dL/dinput is ever needed.
+// over precision: nothing here can under/overflow), ReLU gates are taken from the fp16 activations.
+// The reference runs them through torchvision/cuDNN (F.conv2d 3x3 pad 1 + ReLU, MaxPool2d(2,2));
+// weights are frozen (vgg.py:26-28), so only dL/dinput is ever needed.
 //
 // Layout ("flat padded"): an activation tensor (N, C, H, W) is stored as
 //   [C/8 chunks][NPOSP positions][8 channels] fp16 | bf16,  16 bytes per (chunk, position) unit,
@@ -27,6 +27,8 @@
 //
 // Algorithmic work: 2 * 9 * Cin * Cout FLOP per interior output position (border and padded
 // positions, and the 3 -> 16 channel padding of the first layer, are not counted).
+#include <stdlib.h>
+
 #include "npp_common.h"
 
 namespace npp {
@@ -468,14 +470,28 @@ extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: the largest wave tile (fewest operand bytes per MFMA) that still gives every SIMD of the
-  // chip (256 CUs x 4) about two waves; the small late layers fall back to small tiles.
+  // chip (256 CUs x 4) about one wave; the small late layers fall back to small tiles.
+  // NPP_CONV_TILE="ct,pt" forces one (diagnostics: tools/conv_probe.py).
   const int64_t tiles = (int64_t)a.pos_tiles * cot_n;
   auto grid_for = [&](int ct, int pt) { return dim3((unsigned)((a.pos_tiles + 4 * pt - 1) / (4 * pt)), (unsigned)(cot_n / ct)); };
-  const int64_t want = 2048;
-  if (cot_n % 4 == 0 && tiles / 8 >= want) conv_launch_mode<4, 2>(a, mode, grid_for(4, 2), s);
-  else if (cot_n % 2 == 0 && tiles / 8 >= want) conv_launch_mode<2, 4>(a, mode, grid_for(2, 4), s);
-  else if (cot_n % 2 == 0 && tiles / 4 >= want) conv_launch_mode<2, 2>(a, mode, grid_for(2, 2), s);
-  else if (cot_n % 2 == 0 && tiles / 2 >= want / 2) conv_launch_mode<2, 1>(a, mode, grid_for(2, 1), s);
+  int ct = 1, pt = 1;
+  static const char* force = getenv("NPP_CONV_TILE");
+  if (force && force[0] && force[1] == ',' && force[2]) {
+    ct = force[0] - '0'; pt = force[2] - '0';
+    if (cot_n % ct) ct = 1;
+  } else {
+    const int64_t want = 900;
+    if (cot_n % 4 == 0 && tiles / 8 >= want) { ct = 4; pt = 2; }
+    else if (cot_n % 2 == 0 && tiles / 8 >= want) { ct = 2; pt = 4; }
+    else if (cot_n % 2 == 0 && tiles / 4 >= want) { ct = 2; pt = 2; }
+    else if (cot_n % 2 == 0 && tiles / 2 >= want) { ct = 2; pt = 1; }
+  }
+  if (ct == 4 && pt == 2) conv_launch_mode<4, 2>(a, mode, grid_for(4, 2), s);
+  else if (ct == 2 && pt == 4) conv_launch_mode<2, 4>(a, mode, grid_for(2, 4), s);
+  else if (ct == 2 && pt == 2) conv_launch_mode<2, 2>(a, mode, grid_for(2, 2), s);
+  else if (ct == 2 && pt == 1) conv_launch_mode<2, 1>(a, mode, grid_for(2, 1), s);
+  else if (ct == 1 && pt == 2) conv_launch_mode<1, 2>(a, mode, grid_for(1, 2), s);
+  else if (ct == 1 && pt == 4) conv_launch_mode<1, 4>(a, mode, grid_for(1, 4), s);
   else conv_launch_mode<1, 1>(a, mode, grid_for(1, 1), s);
   return check_launch("npp_conv3x3");
 }

@@ -62,6 +62,8 @@ class CompletionFit:
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
                                     device=self.device, trunk=trunk)
             self.last_source, self.skipped = None, 0
+            self._xy, self._xy_key = None, None
+            self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
     def sample_pixels(self):
@@ -135,21 +137,58 @@ class CompletionFit:
         if bp != n:
             allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
         return dict(coords=allc.contiguous(), n_pix=pix.shape[0], n=n, bp=bp, gt=self.gather_gt(pix), real=real, rmask=rmask,
-                    fake=fake, fmask=fmask, source=source, k=k, P=self.patch_size, n_p=self.patch_num)
+                    fake=fake, fmask=fmask, source=source, k=k, P=self.patch_size, n_p=self.patch_num,
+                    raw=self.patch_sampler.last_raw)
 
     def step_from(self, b):
-        """Device side of one iteration (everything after sampling), train.py:183-264."""
+        """Device side of one iteration (everything after sampling), train.py:183-264, as explicit kernel
+        launches (no autograd): fused forward -> pixel loss -> patch plumbing (npp_patch_compose_fwd) -> VGG19 trunk
+        -> contextual loss core -> trunk data-gradient (-> the same through VGG16 / LPIPS head on 'same' iterations)
+        -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam."""
+        self.last_source = source = b["source"]
+        net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
+        ws = net.workspace(bp)
+        net.zero_grad()
+        if self.percepLoss.touched:
+            self.percepLoss.zero_latent_grads()
+        pred = net.forward_train(b["coords"])
+        if ws.get("n_rows") != n:                                # rows >= n never receive a gradient
+            ws["dpred"][n:].zero_()
+            ws["n_rows"] = n
+        net.pixel_loss(bp, n_pix, b["gt"])
+        raw = b["raw"]
+        comp = self.use_comp and source == "val"                 # train.py:230-231
+        nk = n_p * k
+        key = (nk, P)
+        if self._xy is None or self._xy_key != key:
+            self._xy = torch.empty((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
+            self._xy_key = key
+        xy = ops.patch_compose_fwd(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, self._xy)
+        self.patch_loss_buf.zero_()
+        dx_a = self.contextualLoss.fused(xy, nk, self.cx_w, self.patch_loss_buf)                    # train.py:238-239
+        dx_b = None
+        if source == "same":                                                                        # train.py:241-250
+            dx_b = self.percepLoss.fused(xy, nk, self.lp_w, self.patch_loss_buf, normalize=True)
+        ops.patch_compose_bwd(dx_a, dx_b, raw["fmask"], raw["rmask"], n_p, k, P, comp, ws["dpred"][n_pix:n])
+        self.last_patch_loss = self.patch_loss_buf
+        lr_used = net.lr
+        net.backward(bp)
+        net.optimizer_step(bp)
+        if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
+            self.percepLoss.adam_step(lr_used)
+
+    def step_from_autograd(self, b):
+        """The same iteration written like the reference's loop body, through the torch.autograd wrappers of the loss
+        modules (train.py:200-251 line by line).  Kept as the comparator of step_from() in the tests."""
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
         ws = net.workspace(bp)
         net.zero_grad()
         self.percepLoss.zero_latent_grads()
         pred = net.forward_train(b["coords"])
-        if n < bp:
-            ws["dpred"][n:].zero_()
+        ws["dpred"][n:].zero_()
+        ws["n_rows"] = n
         net.pixel_loss(bp, n_pix, b["gt"])
-        # ---- patch plumbing (train.py:200-236) and patch losses (:238-251), autograd only through
-        #      the frozen VGG trunks; everything after the features is npp_cx_fwd_bwd / npp_lpips_layer
         pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
         pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
         real_p = b["real"].reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3).reshape(-1, 3, P, P)
@@ -161,11 +200,11 @@ class CompletionFit:
             loss_patch = loss_patch + self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True) * self.lp_w
         loss_patch.backward()
         ws["dpred"][n_pix:n].copy_(pp_leaf.grad)
-        self.last_patch_loss = loss_patch.detach()
+        self.last_patch_loss = loss_patch.detach().reshape(1)
         lr_used = net.lr
         net.backward(bp)
         net.optimizer_step(bp)
-        if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
+        if self.percepLoss.touched:
             self.percepLoss.adam_step(lr_used)
 
     # ---- evaluation (train.py:270-331) -----------------------------------------------

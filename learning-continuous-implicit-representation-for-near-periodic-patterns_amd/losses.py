@@ -134,9 +134,11 @@ class HipTrunk:
             cur = y
         return outs
 
-    def _backward(self, gtaps, n, scale, xshape):
+    def _backward(self, gtaps, n, scale, xshape, zero_rest=True):
+        """dL/dx for the first n images from the tap gradients.  zero_rest=False leaves images >= n of the
+        returned tensor uninitialised (callers that only read [:n])."""
         N = xshape[0]
-        dimg = torch.zeros(xshape, dtype=torch.float32, device=self.device)
+        dimg = (torch.zeros if zero_rest else torch.empty)(xshape, dtype=torch.float32, device=self.device)
         if n == 0:
             return dimg
         tap_of = {}
@@ -239,6 +241,14 @@ class ContextualLoss(nn.Module):
                 y = self.vgg_model(y)[0]
         return contextual_loss(x, y, self.band_width, weight)
 
+    def fused(self, xy, n, scale, loss_buf, weight=None):
+        """Explicit forward + backward of `scale * self(xy[:n], xy[n:])` without autograd (the loop's path):
+        accumulates the loss into loss_buf[0] and returns dL/dxy (only [:n] is defined)."""
+        t = self.hip_trunk
+        f = t._forward(xy, [1.0 / s for s in self._STD], [-m / s for m, s in zip(self._MEAN, self._STD)])[0]
+        _, dfx = ops.cx_fwd_bwd(f[:n], f[n:], self.band_width, weight, scale, loss_buf, True)
+        return t._backward([dfx], n, [1.0 / s for s in self._STD], tuple(xy.shape), zero_rest=False)
+
 
 class _LPIPSLayerFunction(torch.autograd.Function):
     @staticmethod
@@ -312,6 +322,23 @@ class LPIPS(nn.Module):
         for kk in range(5):
             val = val + _LPIPSLayerFunction.apply(outs0[kk], outs1[kk], self, kk)
         return val
+
+    def fused(self, xy, n, scale, loss_buf, normalize=True):
+        """Explicit forward + backward of `scale * self(xy[:n], xy[n:], use_robust=True, normalize)` (batch mean)
+        without autograd: accumulates into loss_buf[0] and self.dlatents, returns dL/dxy ([:n] defined)."""
+        a = 2.0 if normalize else 1.0
+        sc = [a / s for s in self._SCALE]
+        sh = [((-1.0 if normalize else 0.0) - b) / s for b, s in zip(self._SHIFT, self._SCALE)]
+        t = self.hip_trunk
+        feats = t._forward(xy, sc, sh)
+        dfs = []
+        for kk, f in enumerate(feats):
+            df0 = torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device)
+            ops.lpips_layer(f[:n], f[n:], self.lins[kk], self.latents[kk], self.spline, self.n_knots, self.x_scale, scale,
+                            loss_buf, df0, self.dlatents[kk])
+            dfs.append(df0)
+        self.touched = True
+        return t._backward(dfs, n, sc, tuple(xy.shape), zero_rest=False)
 
     def zero_latent_grads(self):
         for d in self.dlatents:

@@ -296,3 +296,25 @@ def trunk_export(act, N_total, n_run, c, H, W, is_f16=False):
     out = torch.empty((n_run, c, H, W), dtype=torch.float32, device=act.device)
     check(lib().npp_trunk_export(_p(act), N_total, n_run, c, H, W, _p(out), int(bool(is_f16)), _stream()), "npp_trunk_export")
     return out
+
+
+# ---- a10: patch plumbing (train.py:200-236) -----------------------------------------------------------
+def patch_compose_fwd(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, xy=None):
+    """-> xy (2*n_p*k, 3, P, P) = [x | y] (see include/npp_hip.h)."""
+    _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
+    _req(real, torch.float32, "real", (n_p * k, 3, P, P))
+    _req(rmask, torch.float32, "rmask", (n_p * k, 1, P, P))
+    if comp:
+        _req(fake, torch.float32, "fake", (n_p, 3, P, P))
+        _req(fmask, torch.float32, "fmask", (n_p, 1, P, P))
+    if xy is None:
+        xy = torch.empty((2 * n_p * k, 3, P, P), dtype=torch.float32, device=pred_rows.device)
+    check(lib().npp_patch_compose_fwd(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)),
+                                      _p(xy), _stream()), "npp_patch_compose_fwd")
+    return xy
+
+
+def patch_compose_bwd(dx_a, dx_b, fmask, rmask, n_p, k, P, comp, dpred_rows):
+    _req(dpred_rows, torch.float32, "dpred_rows", (n_p * P * P, 3))
+    check(lib().npp_patch_compose_bwd(_p(dx_a), _p(dx_b), _p(fmask), _p(rmask), n_p, k, P, int(bool(comp)), _p(dpred_rows),
+                                      _stream()), "npp_patch_compose_bwd")

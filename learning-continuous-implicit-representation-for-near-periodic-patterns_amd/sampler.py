@@ -108,6 +108,7 @@ class GridPatchSampler:
             chosen = [c[:topk_min] for c in chosen]
         rgb, m = self._gather(np.concatenate(chosen, 0))
         n, k = self.N_samples, topk_min
+        self._raw_real = (rgb, m)                                                            # contiguous (n*k,3,P,P), (n*k,1,P,P)
         rgb = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                              # (n,k,P,P,3)
         m = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
         return rgb, m, torch.from_numpy(np.concatenate(weights)).to(self.device), topk_min
@@ -125,12 +126,16 @@ class GridPatchSampler:
         fake, fmask, coords, cen = self.sample_patch_fake("val" if source == "val" else "train")
         if source == "same":
             real, rmask = fake.permute(0, 2, 3, 1)[:, None].clone(), fmask.permute(0, 2, 3, 1)[:, None].clone()
+            self._raw_real = (fake, fmask)
             k = 1
             weight = torch.ones(self.N_samples, dtype=torch.float32, device=self.device)
         else:
             real, rmask, weight, k = self.sample_patch_real(cen, topk=topk, invalid_ratio=invalid_ratio)
         if k == 0:
             return None, None, None, None, None, None, 0, None
+        # contiguous channel-first crops for the fused plumbing kernels (npp_patch_compose_*): the untiled fake
+        # patch / mask and the k real patches per fake patch
+        self.last_raw = dict(fake=fake, fmask=fmask, real=self._raw_real[0], rmask=self._raw_real[1])
         fake = fake[:, None].tile([1, k, 1, 1, 1])
         fmask = fmask[:, None].tile([1, k, 1, 1, 1])
         self.last_centres = cen
