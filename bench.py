@@ -6,13 +6,19 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "c2"): one 512x512 completion image, top-3
 periodicity proposals, 256-wide x 8-layer NPP_Net, bf16 MFMA operands / fp32 accumulate.
-A step = ONE optimisation iteration of NPP_completion/train.py:133-264 over
+A step = ONE COMPLETE optimisation iteration of NPP_completion/train.py:133-264 over
 N_rand = 8192 pixel rows + patch_num * P^2 = 2 * 96^2 patch rows (P from loaders.py:133-134):
-fused embedder + MLP forward (with stashes) -> adaptive robust loss -> backward chain ->
-grouped wgrad -> Adam (+ weight re-pack).  Inputs (coordinates, ground truth) are resident
-in HBM before the timed region; nothing is cached between steps.
-`value` = rows fitted per second, summed over ranks (each rank fits its own image: weak
-scaling, no data-path collective; one all_gather of the fitted images after the loop).
+fused embedder + MLP forward (with stashes) -> adaptive robust pixel loss -> patch plumbing ->
+VGG19[0:18] trunk on the 2 * n_p * k patches -> contextual loss -> trunk data-gradient
+(-> VGG16 trunk + LPIPS head and back when the patch source is 'same', ~20 % of iterations)
+-> MLP backward chain -> grouped wgrad -> Adam (+ weight re-pack).  Every kernel of the step is
+libnpp_hip.so.  The sampler's output of each iteration (coordinates, ground-truth colours, patch
+crops: synthetic input) is drawn beforehand with the reference's RNG order and is resident in
+HBM when the timed region starts; the timed steps cycle through that pool, so the patch-source
+mix is the sampler's own (50 / 30 / 20 % val / train / same in expectation).  Nothing is cached
+between steps.  `value` = rows fitted per second, summed over ranks (each rank fits its own
+image: weak scaling, no data-path collective; one all_gather of the fitted images after the loop).
+`mlp_only_step` in the JSON is the same iteration without the patch losses (the round-1 line).
 """
 import argparse
 import json
@@ -41,38 +47,72 @@ def parse():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
     ap.add_argument("--ksplit", type=int, default=12)
-    ap.add_argument("--graph", action="store_true", help="replay one captured HIP graph per iteration (measured: no gain, the eager launches already run ahead of the GPU)")
+    ap.add_argument("--graph", action="store_true", help="(mlp-only extra) replay one captured HIP graph per iteration (measured: no gain, the eager launches already run ahead of the GPU)")
+    ap.add_argument("--pool", type=int, default=20, help="pre-drawn sampler outputs the timed steps cycle through")
     return ap.parse_args()
 
 
-def cpu_baseline(K, H, seconds_target=15.0):
-    """The oracle (NumPy fp32 port of the reference path) timed on this host's cores on a
-    bounded sample of the same workload: full train steps (embed + fwd + robust loss + bwd +
-    Adam) over 2048-row batches of the same image."""
+def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
+    """The oracle (NumPy fp32 port of the reference path) timed on this host's cores on a bounded sample of the
+    same workload: COMPLETE iterations -- embed + MLP forward + robust loss + backward + Adam over the
+    n_pix + n_p * patch^2 rows (in 2048-row chunks), plus per iteration the VGG19[0:18] trunk on the 2 * n_p * k
+    patches (im2col + SGEMM), the contextual loss with its closed-form backward and the trunk data-gradient for
+    the n_p * k predicted patches; every 5th iteration also the VGG16 trunk + LPIPS head on 2 * n_p patches
+    ('same' iterations: 20 %)."""
     import oracle
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
     img, mask = oracle.synthetic_image(H)
     P = oracle.init_params(K, seed=0)
     st = oracle.adam_init(P)
     rng = np.random.RandomState(0)
-    rows = 2048
+    rows, total = 2048, n_pix + n_p * patch * patch
     la = np.full((1, 3), 2.3841858e-07, np.float32)
     ls = np.zeros((1, 3), np.float32)
-    done, t0 = 0, time.time()
+
+    def weights(cfg):
+        ws_, cin = [], 3
+        for v in cfg:
+            if v != "M":
+                ws_.append(((rng.randn(v, cin, 3, 3) * np.sqrt(2.0 / (9 * cin))).astype(np.float32), np.zeros(v, np.float32)))
+                cin = v
+        return ws_
+    w19, w16 = weights(oracle.VGG19_CX_CFG), weights(oracle.VGG16_LPIPS_CFG)
+    chns = [64, 128, 256, 512, 512]
+    lins = [np.abs(rng.randn(c)).astype(np.float32) * 0.05 for c in chns]
+    lat_a = [np.full((1, c), 2.3841858e-07, np.float32) for c in chns]
+    lat_s = [np.zeros((1, c), np.float32) for c in chns]
+    iters, t0 = 0, time.time()
     while True:
-        c = np.stack([rng.randint(0, H, rows), rng.randint(0, H, rows)], 1)
-        emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
-        raw, cache = oracle.mlp_forward(P, emb, K)
-        pr = oracle.sigmoid(raw)
-        _, dpred, _, _ = oracle.img2mse_grads(pr, img[c[:, 0], c[:, 1]], la, ls)
-        G = oracle.mlp_backward(P, cache, dpred * pr * (1 - pr))
+        done = 0
+        while done < total:                                        # the MLP half, chunked
+            r = min(rows, total - done)
+            c = np.stack([rng.randint(0, H, r), rng.randint(0, H, r)], 1)
+            emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
+            raw, cache = oracle.mlp_forward(P, emb, K)
+            pr = oracle.sigmoid(raw)
+            _, dpred, _, _ = oracle.img2mse_grads(pr, img[c[:, 0], c[:, 1]], la, ls)
+            G = oracle.mlp_backward(P, cache, dpred * pr * (1 - pr))
+            done += r
         oracle.adam_step(P, G, st, 5e-4)
-        done += rows
+        nk = n_p * k                                               # the patch-loss half
+        xy = rng.rand(2 * nk, 3, patch, patch).astype(np.float32)
+        f, cache = oracle.trunk_forward(xy, oracle.VGG19_CX_CFG, w19, oracle.VGG19_CX_TAPS, gemm=True)
+        _, dfx = oracle.cx_backward(f[0][:nk], f[0][nk:])
+        cache_x = [(c_[0], (nk,) + tuple(c_[1][1:]), c_[2][:nk]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:nk]) for c_ in cache]
+        oracle.trunk_backward(oracle.VGG19_CX_CFG, cache_x, oracle.VGG19_CX_TAPS, [dfx], gemm=True)
+        if iters % 5 == 4:
+            xy2 = xy[:2 * n_p]
+            f, cache = oracle.trunk_forward(xy2, oracle.VGG16_LPIPS_CFG, w16, oracle.VGG16_LPIPS_TAPS, gemm=True)
+            _, dfs, _, _ = oracle.lpips_head_grads([t[:n_p] for t in f], [t[n_p:] for t in f], lins, lat_a, lat_s)
+            cache_x = [(c_[0], (n_p,) + tuple(c_[1][1:]), c_[2][:n_p]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:n_p]) for c_ in cache]
+            oracle.trunk_backward(oracle.VGG16_LPIPS_CFG, cache_x, oracle.VGG16_LPIPS_TAPS, dfs, gemm=True)
+        iters += 1
         if time.time() - t0 > seconds_target:
             break
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "rows/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{done} rows ({done // rows} train steps of {rows} rows, same image/net) in {dt:.1f}s, "
+    return {"value": iters * total / dt, "unit": "rows/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{iters} complete iterations of {total} rows (MLP half in {rows}-row chunks; VGG19 trunk + contextual loss "
+                      f"on {2 * n_p * k} {patch}x{patch} patches every iteration, VGG16 + LPIPS head every 5th) in {dt:.1f}s, "
                       f"NumPy fp32 oracle, BLAS threads = all host cores"}
 
 
@@ -98,55 +138,30 @@ def main():
 
     H, K = args.size, args.K
     img, mask = oracle.synthetic_image(H, seed=rank)           # each rank fits its own image
-    angles, periods, _ = oracle.synthetic_periodicity(H, K)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
     P = oracle.init_params(K, seed=rank)
     fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, P, device=dev, N_rand=8192,
-                        ksplit=args.ksplit, seed=rank)
+                        ksplit=args.ksplit, seed=rank, shifts=shifts)
     net = fit.net
-    patch = oracle.patch_size_from_period(periods[0])          # loaders.py:133-134 -> 96 at 512^2
-    n_pix, n_patch = fit.N_rand, 2 * patch * patch             # patch_num = 2 (arg_config.py:63)
+    patch = fit.patch_size                                     # loaders.py:133-134 -> 96 at 512^2
+    assert patch == oracle.patch_size_from_period(periods[0])
+    n_pix, n_patch = fit.N_rand, fit.patch_num * patch * patch # patch_num = 2 (arg_config.py:63)
     n_rows = n_pix + n_patch
     bp = ops.pad_rows(n_rows)
 
-    # ---- synthetic inputs, resident in HBM before timing: per-step coordinate batches ----
-    rng = np.random.RandomState(1000 + rank)
-    n_batches = 8
-    batches = []
-    for _ in range(n_batches):
-        sel = rng.choice(fit.i_train.shape[0], n_pix, replace=False)
-        pix = fit.i_train[sel]
-        cy = rng.randint(patch // 2 + 1, H - patch // 2 - 1, 2)
-        cx = rng.randint(patch // 2 + 1, H - patch // 2 - 1, 2)
-        pc = []
-        for y0, x0 in zip(cy, cx):                             # sampler.py:269-279 patch coordinate grids
-            yy, xx = np.meshgrid(np.arange(y0 - patch // 2, y0 + patch // 2),
-                                 np.arange(x0 - patch // 2, x0 + patch // 2), indexing="ij")
-            pc.append(np.stack([yy, xx], -1).reshape(-1, 2))
-        allc = np.concatenate([pix] + pc + [np.zeros((bp - n_rows, 2), np.int64)], 0).astype(np.int32)
-        c = torch.from_numpy(allc).to(dev)
-        gt = fit.img[c[:n_rows, 0].long(), c[:n_rows, 1].long()].contiguous()
-        batches.append((c, gt))
+    # ---- synthetic inputs, resident in HBM before timing: the sampler's output for `pool` iterations
+    #      (train.py:152-181: sample_patches -> pixel draw), in the reference's RNG order ----
+    pool = []
+    while len(pool) < args.pool:
+        b = fit.sample_batch()
+        if b is not None:                                      # k == 0 -> the reference skips the iteration (train.py:160-161)
+            assert b["n"] == n_rows and b["bp"] == bp
+            pool.append(b)
+    mix = {s_: sum(b["source"] == s_ for b in pool) for s_ in ("val", "train", "same")}
     ws = net.workspace(bp)
-    ws["dpred"].zero_()
 
     def step(i):
-        c, gt = batches[i % n_batches]
-        net.zero_grad()
-        net.forward_train(c)
-        # Round 1: the patch rows carry the adaptive robust loss against the image as well
-        # (the contextual / LPIPS kernels are not in the loop yet); every row
-        # goes through exactly the forward / backward / wgrad work of the reference step.
-        net.pixel_loss(bp, n_rows, gt)
-        net.backward(bp)
-        net.optimizer_step(bp)
-
-    graphs = None
-    if args.graph:
-        graphs = [net.capture_step(c, n_rows, gt) for c, gt in batches]
-        eager_step = step
-
-        def step(i):                      # noqa: F811  -- graph replay of the same iteration
-            net.replay_step(graphs[i % n_batches])
+        fit.step_from(pool[i % len(pool)])
 
     def barrier():
         torch.cuda.synchronize()
@@ -154,7 +169,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, len(pool))):               # every pool entry at least once (allocations, first-call setup)
         step(i)
     barrier()
     t0 = time.perf_counter()
@@ -169,6 +184,36 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n_rows * args.steps / dt
 
+    # ---- extra: the same iteration without the patch losses (round-1 definition of the step) ----
+    batches = [(b["coords"], fit.masked_img[b["coords"][:n_rows, 0].long(), b["coords"][:n_rows, 1].long()].contiguous()) for b in pool[:8]]
+    n_batches = len(batches)
+    ws["dpred"].zero_()
+
+    def mlp_step(i):
+        c, gt = batches[i % n_batches]
+        net.zero_grad()
+        net.forward_train(c)
+        net.pixel_loss(bp, n_rows, gt)                          # every row carries the pixel loss here
+        net.backward(bp)
+        net.optimizer_step(bp)
+
+    if args.graph:
+        graphs = [net.capture_step(c, n_rows, gt) for c, gt in batches]
+
+        def mlp_step(i):                      # noqa: F811  -- graph replay of the same iteration
+            net.replay_step(graphs[i % n_batches])
+
+    for i in range(10):
+        mlp_step(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(100):
+        mlp_step(i)
+    torch.cuda.synchronize()
+    mlp_ms = (time.perf_counter() - t1) / 100 * 1e3
+    ws["dpred"].zero_()
+    ws["n_rows"] = None
+
     # ---- per-kernel device time (HIP events on the launch stream), same region ----------
     def timed(fn, reps=20):
         for _ in range(3):
@@ -182,6 +227,21 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e-3
 
     c0, gt0 = batches[0]
+    nk = fit.patch_num * fit.topk
+    xy = torch.rand((2 * nk, 3, patch, patch), device=dev)
+    cxl, lpl = fit.contextualLoss, fit.percepLoss
+    sc19, sh19 = [1.0 / s_ for s_ in cxl._STD], [-m_ / s_ for m_, s_ in zip(cxl._MEAN, cxl._STD)]
+    f19 = cxl.hip_trunk._forward(xy, sc19, sh19)[0]
+    _, dfx = ops.cx_fwd_bwd(f19[:nk], f19[nk:], 0.5, None, 1e-3, None, True)
+    lbuf = torch.zeros(1, device=dev)
+    patch_kt = {
+        "vgg19_fwd_12img": timed(lambda: cxl.hip_trunk._forward(xy, sc19, sh19)),
+        "cx_core_fwd_bwd": timed(lambda: ops.cx_fwd_bwd(f19[:nk], f19[nk:], 0.5, None, 1e-3, lbuf, True)),
+        "vgg19_dgrad_6img": timed(lambda: cxl.hip_trunk._backward([dfx], nk, sc19, tuple(xy.shape), zero_rest=False)),
+        "contextual_total": timed(lambda: cxl.fused(xy, nk, 1e-3, lbuf)),
+        "lpips_total_4img": timed(lambda: lpl.fused(xy[:4 * fit.patch_num // 2].contiguous(), fit.patch_num, 1e-3, lbuf)),
+    }
+    lpl.zero_latent_grads()
     kt = {
         "mlp_fwd_train": timed(lambda: net.forward_train(c0)),
         "mlp_bwd_chain": timed(lambda: ops.mlp_bwd(ws["dpred"], ws["pred"], K, net.wb, net.params, ws["actT"], ws["dzT"])),
@@ -231,7 +291,7 @@ def main():
                 "all_kernels_tflops": {k: round(v, 1) for k, v in tf.items()},
                 "all_kernels_hbm_GBs": {k: round(v, 0) for k, v in gbs.items()},
                 "all_kernels_mfma_frac": {k: round(v / PEAK_BF16_TFLOPS, 4) for k, v in tf.items()},
-                "step_mfma_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+                "mlp_flops_over_full_step_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
     render_px_s = H * H / kt["render_fwd_512sq"]
 
     # ---- c4: stand-alone embedder on the full 1024^2 grid, fp32 (HBM-write-bound kernel K1) ----
@@ -256,37 +316,22 @@ def main():
         c4 = out
         del grid
 
-    # ---- the complete loop body of train.py:133-264 (patch sampler inputs pre-drawn, VGG trunks via
-    #      PyTorch/MIOpen glue with fixed-seed weights, CX core / LPIPS head / patch gather in HIP) ----
-    full_loop = None
+    # ---- per patch-source cost of the complete iteration (device + host enqueue, same pool) ----
+    per_source = None
     if rank == 0 and not args.no_extras:
-        _, _, shifts = oracle.synthetic_periodicity(H, K)
-        f3 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
-                           N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts)
-        pre = []
-        while len(pre) < 10:
-            b = f3.sample_batch()
-            if b is not None:
-                pre.append(b)
-        for b in pre:
-            f3.step_from(b)
-        per = {}
+        per_source = {}
         for src in ("val", "train", "same"):
-            bs = [b for b in pre if b["source"] == src]
+            bs = [b for b in pool if b["source"] == src]
             if bs:
-                per[src] = timed(lambda: [f3.step_from(b) for b in bs], reps=5) / len(bs) * 1e3
-        mix = 0.5 * per.get("val", 0) + 0.3 * per.get("train", per.get("val", 0)) + 0.2 * per.get("same", per.get("val", 0))
-        full_loop = {"ms_per_iter_by_patch_source": per, "ms_per_iter_mix_50_30_20": mix,
-                     "rows_per_s": (n_pix + 2 * f3.patch_size ** 2) / (mix * 1e-3),
-                     "note": "device side only (sampling pre-drawn); VGG19/VGG16 trunks run through PyTorch/MIOpen"}
+                per_source[src] = timed(lambda: [fit.step_from(b) for b in bs], reps=5) / len(bs) * 1e3
 
     # ---- iterations to 28 dB on a fresh fit of the same image (not timed) -----------------
     iters_to_target, final_psnr = None, None
     if not args.no_psnr and rank == 0:
         f2 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
-                           N_rand=8192, ksplit=args.ksplit, seed=0)
-        for it in range(1, 301):
-            f2.step()
+                           N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts)
+        for it in range(1, 301):                               # the complete loop incl. host-side sampling
+            f2.step_full()
             if iters_to_target is None and it % 5 == 0 and f2.psnr() >= 28.0:
                 iters_to_target = it
         final_psnr = f2.psnr()
@@ -304,7 +349,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(K, H)
+        cpu = cpu_baseline(K, H, patch, n_pix, fit.patch_num, fit.topk)
 
     if rank == 0:
         line = {
@@ -313,15 +358,21 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"c2: {H}x{H} completion image, top-{K} proposals, 256-wide x 8-layer NPP_Net; "
-                                   f"step = 1 optimisation iteration over {n_pix} pixel rows + 2x{patch}^2 patch rows "
-                                   f"(fused embed+MLP fwd, adaptive robust loss, bwd chain, grouped wgrad, Adam)",
+                                   f"step = 1 complete optimisation iteration (train.py:133-264) over {n_pix} pixel rows + "
+                                   f"2x{patch}^2 patch rows: fused embed+MLP fwd, adaptive robust pixel loss, patch plumbing, "
+                                   f"VGG19 trunk + contextual loss + trunk dgrad (+ VGG16/LPIPS on 'same'), bwd chain, wgrad, Adam",
                        "rows_per_step": n_rows, "image": [H, H], "K": K, "width": 256, "ksplit": args.ksplit,
-                       "images_per_gpu": 1, "hip_graph": bool(args.graph)},
+                       "images_per_gpu": 1, "patch_size": patch, "patch_source_mix_in_pool": mix,
+                       "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate"},
+            "mlp_only_step": {"ms_per_step": mlp_ms, "rows_per_s": n_rows / (mlp_ms * 1e-3),
+                              "mlp_mfma_frac": 2 * train_macs * n_rows / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                              "hip_graph": bool(args.graph)},
             "value_per_gpu": value / world,
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
             "final_gather_ms": gather_ms,
-            "c4_embedder_1024sq": c4, "full_loop_with_patch_losses": full_loop,
+            "c4_embedder_1024sq": c4, "ms_per_iter_by_patch_source": per_source,
+            "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

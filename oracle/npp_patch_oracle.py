@@ -18,7 +18,7 @@ from .npp_oracle import F32, adaptive_params, robust_nll, robust_nll_grads, load
 
 __all__ = ["extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
            "lpips_head", "lpips_head_grads", "scaling_layer", "VGG19_CX_CFG", "VGG16_LPIPS_CFG", "VGG19_CX_TAPS",
-           "VGG16_LPIPS_TAPS", "conv3x3", "conv3x3_dgrad", "maxpool2", "maxpool2_bwd", "trunk_forward", "trunk_backward"]
+           "VGG16_LPIPS_TAPS", "conv3x3", "conv3x3_dgrad", "maxpool2", "maxpool2_bwd", "trunk_forward", "trunk_backward", "conv3x3_gemm", "conv3x3_dgrad_gemm"]
 
 
 # --------------------------------------------------------------------------
@@ -302,6 +302,39 @@ def conv3x3_dgrad(dz, w):
     return out.astype(F32)
 
 
+def _im2col(x):
+    """(C,H,W) -> (H*W, 9*C) patches of the zero-padded image, column order (ky, kx, c)."""
+    C, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1)))
+    cols = np.empty((H, W, 9, C), F32)
+    for ky in range(3):
+        for kx in range(3):
+            cols[:, :, ky * 3 + kx, :] = xp[:, ky:ky + H, kx:kx + W].transpose(1, 2, 0)
+    return cols.reshape(H * W, 9 * C)
+
+
+def conv3x3_gemm(x, w, b):
+    """conv3x3 as im2col + fp32 SGEMM per image (same maths as conv3x3, BLAS speed): the form the CPU
+    baseline of bench.py times."""
+    x = np.asarray(x, F32)
+    N, _, H, W = x.shape
+    wm = np.ascontiguousarray(np.asarray(w, F32).transpose(2, 3, 1, 0).reshape(-1, w.shape[0]))     # (9*Cin, Cout)
+    out = np.empty((N, w.shape[0], H, W), F32)
+    for n in range(N):
+        out[n] = (_im2col(x[n]) @ wm + np.asarray(b, F32)[None, :]).T.reshape(w.shape[0], H, W)
+    return out
+
+
+def conv3x3_dgrad_gemm(dz, w):
+    dz = np.asarray(dz, F32)
+    N, _, H, W = dz.shape
+    wm = np.ascontiguousarray(np.asarray(w, F32)[:, :, ::-1, ::-1].transpose(2, 3, 0, 1).reshape(-1, w.shape[1]))   # (9*Cout, Cin)
+    out = np.empty((N, w.shape[1], H, W), F32)
+    for n in range(N):
+        out[n] = (_im2col(dz[n]) @ wm).T.reshape(w.shape[1], H, W)
+    return out
+
+
 def maxpool2(x):
     """nn.MaxPool2d(2, 2) (floor mode) -> (pooled, argmax slot 0..3 in scan order, first maximum wins)."""
     N, C, H, W = x.shape
@@ -319,8 +352,9 @@ def maxpool2_bwd(dy, arg, shape):
     return dx
 
 
-def trunk_forward(x, cfg, weights, taps):
+def trunk_forward(x, cfg, weights, taps, gemm=False):
     """x (N,3,H,W) already normalised; weights: [(w, b)] per conv.  Returns (tap outputs, cache)."""
+    conv = conv3x3_gemm if gemm else conv3x3
     outs, cache, idx, wi = [], [], 0, 0
     for v in cfg:
         if v == "M":
@@ -331,7 +365,7 @@ def trunk_forward(x, cfg, weights, taps):
         else:
             w, b = weights[wi]
             wi += 1
-            z = conv3x3(x, w, b)
+            z = conv(x, w, b)
             x = np.maximum(z, 0)
             cache.append(("conv", w, z > 0))
             idx += 2
@@ -340,8 +374,9 @@ def trunk_forward(x, cfg, weights, taps):
     return outs, cache
 
 
-def trunk_backward(cfg, cache, taps, tap_grads):
+def trunk_backward(cfg, cache, taps, tap_grads, gemm=False):
     """dL/dx (the normalised input) from dL/dtap for every tap (None = no gradient)."""
+    dgrad = conv3x3_dgrad_gemm if gemm else conv3x3_dgrad
     tap_at, idx, k = {}, 0, 0
     for li, v in enumerate(cfg):
         idx += 1 if v == "M" else 2
@@ -358,5 +393,5 @@ def trunk_backward(cfg, cache, taps, tap_grads):
         if c[0] == "pool":
             g = maxpool2_bwd(g, c[2], c[1])
         else:
-            g = conv3x3_dgrad(np.where(c[2], g, 0).astype(F32), c[1])
+            g = dgrad(np.where(c[2], g, 0).astype(F32), c[1])
     return g

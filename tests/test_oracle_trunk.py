@@ -76,3 +76,14 @@ def test_maxpool_first_max_ties():
     (yt * torch.from_numpy(dy)).sum().backward()
     np.testing.assert_array_equal(y, yt.detach().numpy())
     np.testing.assert_array_equal(dx, xt.grad.numpy())
+
+
+def test_gemm_form_matches_direct_form():
+    """conv3x3_gemm / conv3x3_dgrad_gemm (the im2col + SGEMM form bench.py's cpu_baseline times) == the direct form."""
+    rng = np.random.RandomState(0)
+    x = rng.randn(2, 5, 9, 7).astype(np.float32)
+    w = rng.randn(6, 5, 3, 3).astype(np.float32)
+    b = rng.randn(6).astype(np.float32)
+    np.testing.assert_allclose(oracle.conv3x3_gemm(x, w, b), oracle.conv3x3(x, w, b), rtol=1e-4, atol=1e-5)
+    dz = rng.randn(2, 6, 9, 7).astype(np.float32)
+    np.testing.assert_allclose(oracle.conv3x3_dgrad_gemm(dz, w), oracle.conv3x3_dgrad(dz, w), rtol=1e-4, atol=1e-5)
