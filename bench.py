@@ -100,7 +100,7 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
         _, dfx = oracle.cx_backward(f[0][:nk], f[0][nk:])
         cache_x = [(c_[0], (nk,) + tuple(c_[1][1:]), c_[2][:nk]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:nk]) for c_ in cache]
         oracle.trunk_backward(oracle.VGG19_CX_CFG, cache_x, oracle.VGG19_CX_TAPS, [dfx], gemm=True)
-        if iters % 5 == 4:
+        if iters % 5 == 2:
             xy2 = xy[:2 * n_p]
             f, cache = oracle.trunk_forward(xy2, oracle.VGG16_LPIPS_CFG, w16, oracle.VGG16_LPIPS_TAPS, gemm=True)
             _, dfs, _, _ = oracle.lpips_head_grads([t[:n_p] for t in f], [t[n_p:] for t in f], lins, lat_a, lat_s)

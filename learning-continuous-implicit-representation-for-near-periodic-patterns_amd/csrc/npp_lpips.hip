@@ -20,10 +20,13 @@ __global__ void lpips_chan_kernel(const float* __restrict__ latents, int C, cons
 
 // Block = 16 positions x 16 channel lanes (thread = position pl, channels cl, cl+16, ...): the deep
 // taps have few positions (6x6) but 512 channels, so the channel axis must be spread over threads
-// (one thread per position took 0.5 ms per call on them).  Phase 1: channel norms (LDS reduction
-// over the 16 channel lanes).  Phase 2: robust NLL of the normalised difference, its derivative
-// (staged in df0), per-channel latent gradients reduced over the 16 positions by shuffles -> one
-// atomic per channel and block.  Phase 3: normalisation backward.
+// (one thread per position took 0.5 ms per call on them).  Blocks are persistent over groups of 16
+// positions.  Phase 1: channel norms (LDS reduction over the 16 channel lanes).  Phase 2: robust NLL of
+// the normalised difference, its derivative (staged in df0), per-channel latent gradients reduced over
+// the 16 positions by shuffles into per-block LDS accumulators.  Phase 3: normalisation backward.
+// One global atomic per channel and block at the very end (the first version issued two per channel and
+// 16-position group: 1152 same-address atomics per latent on the first tap = 60 of its 70 us).
+constexpr int kLpipsMaxC = 512;
 __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                           int N, int C, int hw, const float* __restrict__ lin,
                                                           const ChanParams* __restrict__ cp, float coef,
@@ -31,74 +34,85 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
                                                           float* __restrict__ dlatent) {
   __shared__ float red[3][16][17];
   __shared__ float tot[4];
+  __shared__ float sdl[2 * kLpipsMaxC];
   const int pl = threadIdx.x & 15, cl = threadIdx.x >> 4;
-  const int64_t t = (int64_t)blockIdx.x * 16 + pl;
-  const bool live = t < (int64_t)N * hw;
-  const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
-  const float* a0 = f0 + (int64_t)n * C * hw + p;
-  const float* a1 = f1 + (int64_t)n * C * hw + p;
-  float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
-  float s0 = 0.0f, s1 = 0.0f;
-  if (live)
-    for (int c = cl; c < C; c += 16) {
-      const float u = a0[(int64_t)c * hw], v = a1[(int64_t)c * hw];
-      s0 = fmaf(u, u, s0);
-      s1 = fmaf(v, v, s1);
-    }
-  red[0][cl][pl] = s0;
-  red[1][cl][pl] = s1;
-  __syncthreads();
-  s0 = 0.0f; s1 = 0.0f;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sdl[i] = 0.0f;
+  const int64_t npos = (int64_t)N * hw;
+  const int64_t ngroups = (npos + 15) / 16;
+  float val = 0.0f;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t t = grp * 16 + pl;
+    const bool live = t < npos;
+    const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
+    const float* a0 = f0 + (int64_t)n * C * hw + p;
+    const float* a1 = f1 + (int64_t)n * C * hw + p;
+    float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (live)
+      for (int c = cl; c < C; c += 16) {
+        const float u = a0[(int64_t)c * hw], v = a1[(int64_t)c * hw];
+        s0 = fmaf(u, u, s0);
+        s1 = fmaf(v, v, s1);
+      }
+    __syncthreads();                                      // red[] of the previous group fully consumed
+    red[0][cl][pl] = s0;
+    red[1][cl][pl] = s1;
+    __syncthreads();
+    s0 = 0.0f; s1 = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { s0 += red[0][q][pl]; s1 += red[1][q][pl]; }
-  const float n0 = sqrtf(s0), n1 = sqrtf(s1);
-  const float i0 = 1.0f / (n0 + 1e-10f), i1 = 1.0f / (n1 + 1e-10f);
-  float val = 0.0f, dot = 0.0f;
-  for (int c = cl; c < C; c += 16) {                    // C is a multiple of 16: uniform trip count
-    const ChanParams P = cp[c];
-    const float l = lin[c];
-    float da = 0.0f, dc = 0.0f;
-    if (live) {
-      const float u = a0[(int64_t)c * hw];
-      const float x = u * i0 - a1[(int64_t)c * hw] * i1;
-      const float xs = x / P.c, ssx = xs * xs;
-      const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
-      const float ue = expf(e * lnu), ue1 = ue / uu;
-      val += l * ((P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz);
-      if (g0) {
-        const float dd = l * coef * (x / (P.c * P.c)) * ue1;          // dL/d(normalised f0)_c
-        g0[(int64_t)c * hw] = dd;
-        dot = fmaf(dd, u, dot);
-        da = l * coef * (-(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) +
-                         (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz);
-        dc = l * coef * (-(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c);
+    for (int q = 0; q < 16; ++q) { s0 += red[0][q][pl]; s1 += red[1][q][pl]; }
+    const float n0 = sqrtf(s0), n1 = sqrtf(s1);
+    const float i0 = 1.0f / (n0 + 1e-10f), i1 = 1.0f / (n1 + 1e-10f);
+    float dot = 0.0f;
+    for (int c = cl; c < C; c += 16) {                    // C is a multiple of 16: uniform trip count
+      const ChanParams P = cp[c];
+      const float l = lin[c];
+      float da = 0.0f, dc = 0.0f;
+      if (live) {
+        const float u = a0[(int64_t)c * hw];
+        const float x = u * i0 - a1[(int64_t)c * hw] * i1;
+        const float xs = x / P.c, ssx = xs * xs;
+        const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
+        const float ue = expf(e * lnu), ue1 = ue / uu;
+        val += l * ((P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz);
+        if (g0) {
+          const float dd = l * coef * (x / (P.c * P.c)) * ue1;          // dL/d(normalised f0)_c
+          g0[(int64_t)c * hw] = dd;
+          dot = fmaf(dd, u, dot);
+          da = l * coef * (-(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) +
+                           (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz);
+          dc = l * coef * (-(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c);
+        }
+      }
+      if (df0) {                                                         // uniform branch
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {                          // the 16 positions of this channel lane
+          da += __shfl_xor(da, off, 64);
+          dc += __shfl_xor(dc, off, 64);
+        }
+        if (pl == 0) {                                                   // channel c belongs to this thread alone in the block
+          sdl[c] += da * P.dalpha_dl;
+          sdl[C + c] += dc * P.dc_dl;
+        }
       }
     }
-    if (g0) {                                                          // uniform branch
+    red[2][cl][pl] = dot;
+    __syncthreads();
+    if (g0 && live) {
+      dot = 0.0f;
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {                          // the 16 positions of this channel lane
-        da += __shfl_xor(da, off, 64);
-        dc += __shfl_xor(dc, off, 64);
-      }
-      if (pl == 0) {
-        atomicAdd(dlatent + c, da * P.dalpha_dl);
-        atomicAdd(dlatent + C + c, dc * P.dc_dl);
+      for (int q = 0; q < 16; ++q) dot += red[2][q][pl];
+      const float se = n0 + 1e-10f;
+      const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
+      for (int c = cl; c < C; c += 16) {
+        const float dd = g0[(int64_t)c * hw];                            // written by this very thread above
+        g0[(int64_t)c * hw] = dd * i0 - a0[(int64_t)c * hw] * k;
       }
     }
   }
-  red[2][cl][pl] = dot;
   __syncthreads();
-  if (g0 && live) {
-    dot = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dot += red[2][q][pl];
-    const float se = n0 + 1e-10f;
-    const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
-    for (int c = cl; c < C; c += 16) {
-      const float dd = g0[(int64_t)c * hw];                            // written by this very thread above
-      g0[(int64_t)c * hw] = dd * i0 - a0[(int64_t)c * hw] * k;
-    }
-  }
+  if (df0)
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dlatent + i, sdl[i]);
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
@@ -114,7 +128,7 @@ extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)C * sizeof
 extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                                const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
                                float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
-  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || !d_workspace || N < 1 || C < 16 || (C % 16) || hw < 1 || n_knots < 2) {
+  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || !d_workspace || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 || n_knots < 2) {
     set_error("npp_lpips_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
     return NPP_ERR_ARG;
   }
@@ -124,7 +138,8 @@ extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int 
   hipLaunchKernelGGL(lpips_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, d_latents, C, d_spline, n_knots, x_scale, cp);
   const int64_t nh = (int64_t)N * hw;
   const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
-  hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)((nh + 15) / 16)), dim3(256), 0, s, d_f0, d_f1, N, C, hw, d_lin,
+  const int64_t groups = (nh + 15) / 16;
+  hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, s, d_f0, d_f1, N, C, hw, d_lin,
                      cp, coef, d_loss, d_df0, d_dlatent);
   return check_launch("npp_lpips_layer");
 }
