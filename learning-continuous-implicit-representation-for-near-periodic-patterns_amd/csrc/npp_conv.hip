@@ -28,6 +28,7 @@
 // Algorithmic work: 2 * 9 * Cin * Cout FLOP per interior output position (border and padded
 // positions, and the 3 -> 16 channel padding of the first layer, are not counted).
 #include <stdlib.h>
+#include <string.h>
 
 #include "npp_common.h"
 
@@ -69,10 +70,18 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8& a, const f16x8& b, const f
 template <bool F16> struct OpT { typedef bf16x8 frag; typedef __bf16 elem; };
 template <> struct OpT<true> { typedef f16x8 frag; typedef _Float16 elem; };
 
-template <int CT, int PT, int MODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+// One workgroup = S waves that share ONE output tile (CT x PT MFMA tiles = 32 CT output channels x 32 PT
+// positions) and split the contraction: wave w accumulates input-channel steps [w CI/S, (w+1) CI/S) x 9 taps,
+// the partial tiles meet in LDS and each wave finishes (epilogue) a share of the tiles.  Why: the trunk layers of
+// the loop are small (a 256 -> 256 layer on twelve 24 x 24 maps is 2032 MFMA tiles for 1024 SIMDs); with one small
+// tile per wave every wave re-streams its whole weight slice (1.5 KiB of operands per MFMA through L1: measured
+// 16 % of MFMA peak, L2 -> L1 bound), with big tiles there are too few waves.  Split-K keeps >= 256 workgroups
+// with 2 x 4 tiles (0.75 KiB per MFMA) and every fragment is fetched by exactly one wave.
+template <int CT, int PT, int S, int MODE>
+__global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   typedef typename OpT<MODE == kConvFwd>::frag frag_t;       // forward: fp16 operands; gradients: bf16
   typedef typename OpT<MODE == kConvFwd>::elem elem_t;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [S][CT*PT][16 regs][64 lanes] when S > 1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = lane & 31, h = lane >> 5;
@@ -80,10 +89,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   int bid = blockIdx.x;
   const int nb = gridDim.x;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-  const int tile0 = (bid * 4 + wave) * PT;
-  if (tile0 >= a.pos_tiles) return;                      // whole wave; the kernel has no barriers
+  const int tile0 = bid * PT;
   const int cot0 = blockIdx.y * CT;
   const int KS = a.CI * 9;
+  const int ci_per = a.CI / S, ci_beg = wave * ci_per, ci_end = ci_beg + ci_per;
 
   const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack), 0, (int)a.pack_bytes, 0x00020000);
   const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
@@ -116,10 +125,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
 
-  load(0, 0, 0);
-  load(1, 0, 1);
-  load(2, 0, 2);
-  for (int ci = 0; ci < a.CI; ++ci) {
+  load(0, ci_beg, 0);
+  load(1, ci_beg, 1);
+  load(2, ci_beg, 2);
+  for (int ci = ci_beg; ci < ci_end; ++ci) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int slot = tap % 3;
@@ -128,44 +137,65 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = mfma16(A[slot][ct], B[slot][pt], acc[ct][pt]);
       if (tap + 3 < 9) load(slot, ci, tap + 3);
-      else if (ci + 1 < a.CI) load(slot, ci + 1, tap - 6);
+      else if (ci + 1 < ci_end) load(slot, ci + 1, tap - 6);
       asm volatile("" ::: "memory");
     }
   }
 
-  // ---- epilogue ---------------------------------------------------------------------
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
+  // ---- epilogue of one 32 x 32 tile (ct, pt): bias / ReLU / gate, 16-bit store, optional fp32 tap -------
+  auto finish = [&](const f32x16& v16, int ct, int pt) {
     const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
-    const int n = (int)(p / a.S);
+    const int n = (int)((uint32_t)p / (uint32_t)a.S);
     const int r0 = (int)(p - (int64_t)n * a.S);
     const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
     const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
     const int64_t tap_base = (((int64_t)n * a.Ctap) * a.H + (yy - 1)) * a.W + (xx - 1);
+    const int cot = cot0 + ct;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int cot = cot0 + ct;
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = 4 * cot + 2 * s + h;
+      if (chunk >= a.cout_chunks) continue;
+      const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
+      f16x8 m;
+      if (MODE == kConvDgradMask) m = ((const f16x8*)a.mask)[unit];
+      frag_t o;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int chunk = 4 * cot + 2 * s + h;
-        if (chunk >= a.cout_chunks) continue;
-        const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
-        f16x8 m;
-        if (MODE == kConvDgradMask) m = ((const f16x8*)a.mask)[unit];
-        frag_t o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int co = 32 * cot + acc_row(8 * s + j, h);
-          float v = acc[ct][pt][8 * s + j];
-          if (MODE == kConvFwd) v = fminf(fmaxf(v + a.bias[co], 0.0f), 65504.0f);
-          if (MODE == kConvDgradMask) v = (float)m[j] > 0.0f ? v : 0.0f;
-          v = interior ? v : 0.0f;
-          o[j] = (elem_t)v;
-          if (a.tap && interior && co < a.Ctap)
-            a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? v * a.tap_scale[co & 3] : v;
-        }
-        if (a.y) ((frag_t*)a.y)[unit] = o;
+      for (int j = 0; j < 8; ++j) {
+        const int co = 32 * cot + acc_row(8 * s + j, h);
+        float v = v16[8 * s + j];
+        if (MODE == kConvFwd) v = fminf(fmaxf(v + a.bias[co], 0.0f), 65504.0f);
+        if (MODE == kConvDgradMask) v = (float)m[j] > 0.0f ? v : 0.0f;
+        v = interior ? v : 0.0f;
+        o[j] = (elem_t)v;
+        if (a.tap && interior && co < a.Ctap)
+          a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? v * a.tap_scale[co & 3] : v;
       }
+      if (a.y) ((frag_t*)a.y)[unit] = o;
+    }
+  };
+
+  if (S == 1) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) finish(acc[ct][pt], ct, pt);
+  } else {
+    constexpr int NT = CT * PT;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NT + ct * PT + pt) * 16 + r) * 64 + lane] = acc[ct][pt][r];
+    __syncthreads();
+    for (int t = wave; t < NT; t += S) {                  // tile t is finished by wave t % S
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = 0.0f;
+      for (int w2 = 0; w2 < S; ++w2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += red[((w2 * NT + t) * 16 + r) * 64 + lane];
+      finish(v, t / PT, t % PT);
     }
   }
 }
@@ -429,11 +459,24 @@ extern "C" int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, 
   return check_launch("npp_trunk_image_in");
 }
 
-template <int CT, int PT>
-static void conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t s) {
-  if (mode == kConvFwd) hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvFwd>), grid, dim3(256), 0, s, a);
-  else if (mode == kConvDgradMask) hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvDgradMask>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv3x3_kernel<CT, PT, kConvDgradLin>), grid, dim3(256), 0, s, a);
+template <int CT, int PT, int S>
+static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t s) {
+  const size_t smem = S > 1 ? (size_t)S * CT * PT * 16 * 64 * sizeof(float) : 0;
+#define NPP_CONV_GO(M)                                                                                        \
+  do {                                                                                                        \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set && smem > 48 * 1024) {                                                                      \
+      if (hipFuncSetAttribute((const void*)conv3x3_kernel<CT, PT, S, M>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)smem) != hipSuccess) { set_error("npp_conv3x3: smem attribute"); return NPP_ERR_LAUNCH; } \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL((conv3x3_kernel<CT, PT, S, M>), grid, dim3(64 * S), smem, s, a);                       \
+  } while (0)
+  if (mode == kConvFwd) NPP_CONV_GO(kConvFwd);
+  else if (mode == kConvDgradMask) NPP_CONV_GO(kConvDgradMask);
+  else NPP_CONV_GO(kConvDgradLin);
+#undef NPP_CONV_GO
+  return NPP_OK;
 }
 
 // mode 0: y = relu(conv(x) + bias)            (forward layer)
@@ -469,30 +512,38 @@ extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W
   const int cot_n = (Cout + 31) / 32;
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
   hipStream_t s = (hipStream_t)stream;
-  // Tile choice: the largest wave tile (fewest operand bytes per MFMA) that still gives every SIMD of the
-  // chip (256 CUs x 4) about one wave; the small late layers fall back to small tiles.
-  // NPP_CONV_TILE="ct,pt" forces one (diagnostics: tools/conv_probe.py).
-  const int64_t tiles = (int64_t)a.pos_tiles * cot_n;
-  auto grid_for = [&](int ct, int pt) { return dim3((unsigned)((a.pos_tiles + 4 * pt - 1) / (4 * pt)), (unsigned)(cot_n / ct)); };
-  int ct = 1, pt = 1;
+  // Tile choice: the largest output tile per workgroup (fewest operand bytes per MFMA) that still yields about one
+  // workgroup per CU, with the contraction split over S waves (CI % S == 0).  NPP_CONV_TILE="ct,pt,s" forces one
+  // (diagnostics: tools/conv_probe.py).
+  // Measured on MI355X (tools/conv_probe.py, 12 x 96^2 VGG shapes): 2x2 tiles with S = 4 win wherever the channel steps
+  // split four ways (c2_2 21 -> 18 us, c3_x 20 -> 14.5, c4_x 42 -> 25, c5_x 38 -> 15 with 1x1 S = 4); position-rich layers
+  // (>= 1024 workgroups without a split) are better off unsplit; 2x4 tiles never won at these sizes.
+  struct Cand { int ct, pt, s; int64_t min_wgs; };
+  static const Cand cands[] = {{2, 2, 1, 1024}, {2, 2, 4, 200}, {2, 1, 4, 200}, {1, 1, 4, 100}, {1, 1, 8, 1}, {2, 1, 1, 1}, {1, 1, 1, 1}};
+  auto feasible = [&](const Cand& c) { return cot_n % c.ct == 0 && a.CI % c.s == 0 && a.pos_tiles % c.pt == 0; };
+  auto wgs = [&](const Cand& c) { return (int64_t)(a.pos_tiles / c.pt) * (cot_n / c.ct); };
+  Cand pick = {1, 1, 1, 1};
   static const char* force = getenv("NPP_CONV_TILE");
-  if (force && force[0] && force[1] == ',' && force[2]) {
-    ct = force[0] - '0'; pt = force[2] - '0';
-    if (cot_n % ct) ct = 1;
-  } else {
-    const int64_t want = 900;
-    if (cot_n % 4 == 0 && tiles / 8 >= want) { ct = 4; pt = 2; }
-    else if (cot_n % 2 == 0 && tiles / 8 >= want) { ct = 2; pt = 4; }
-    else if (cot_n % 2 == 0 && tiles / 4 >= want) { ct = 2; pt = 2; }
-    else if (cot_n % 2 == 0 && tiles / 2 >= want) { ct = 2; pt = 1; }
+  bool found = false;
+  if (force && strlen(force) == 5 && force[1] == ',' && force[3] == ',') {
+    for (const Cand& c : cands)
+      if (c.ct == force[0] - '0' && c.pt == force[2] - '0' && c.s == force[4] - '0' && feasible(c)) { pick = c; found = true; }
   }
-  if (ct == 4 && pt == 2) conv_launch_mode<4, 2>(a, mode, grid_for(4, 2), s);
-  else if (ct == 2 && pt == 4) conv_launch_mode<2, 4>(a, mode, grid_for(2, 4), s);
-  else if (ct == 2 && pt == 2) conv_launch_mode<2, 2>(a, mode, grid_for(2, 2), s);
-  else if (ct == 2 && pt == 1) conv_launch_mode<2, 1>(a, mode, grid_for(2, 1), s);
-  else if (ct == 1 && pt == 2) conv_launch_mode<1, 2>(a, mode, grid_for(1, 2), s);
-  else if (ct == 1 && pt == 4) conv_launch_mode<1, 4>(a, mode, grid_for(1, 4), s);
-  else conv_launch_mode<1, 1>(a, mode, grid_for(1, 1), s);
+  if (!found && a.CI == 1) {                    // the image layer: 9 k-steps, nothing to split
+    const Cand c = {2, 1, 1, 1};
+    if (feasible(c)) { pick = c; found = true; }
+  }
+  for (const Cand& c : cands) {
+    if (found) break;
+    if (feasible(c) && wgs(c) >= c.min_wgs) { pick = c; found = true; }
+  }
+  const dim3 grid((unsigned)(a.pos_tiles / pick.pt), (unsigned)(cot_n / pick.ct));
+  int lrc = NPP_OK;
+#define NPP_CONV_CASE(CT_, PT_, S_) if (pick.ct == CT_ && pick.pt == PT_ && pick.s == S_) lrc = conv_launch_mode<CT_, PT_, S_>(a, mode, grid, s)
+  NPP_CONV_CASE(2, 2, 4); else NPP_CONV_CASE(2, 1, 4); else NPP_CONV_CASE(1, 1, 8); else NPP_CONV_CASE(1, 1, 4);
+  else NPP_CONV_CASE(2, 2, 1); else NPP_CONV_CASE(2, 1, 1); else NPP_CONV_CASE(1, 1, 1);
+#undef NPP_CONV_CASE
+  if (lrc) return lrc;
   return check_launch("npp_conv3x3");
 }
 

@@ -46,6 +46,6 @@ if __name__ == "__main__":
         child(int(sys.argv[1]), int(sys.argv[2]))
     else:
         N, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 96)
-        for tile in ("", "4,2", "2,4", "2,2", "2,1", "1,2", "1,4", "1,1"):
+        for tile in ("", "2,2,4", "2,1,4", "1,1,8", "1,1,4", "2,2,1", "2,1,1", "1,1,1"):
             env = dict(os.environ, CONV_PROBE_CHILD="1", NPP_CONV_TILE=tile)
             subprocess.run([sys.executable, os.path.abspath(__file__), str(N), str(P)], env=env, check=False)
