@@ -376,6 +376,25 @@ def test_full_loop_with_patch_losses(dev):
 
 
 
+def test_config_c5_shape_k5_with_patch_losses(dev):
+    """BASELINE.json configs[4] shape at reduced image size: top-5 proposals (NPP_Net with a 4-proposal scale layer,
+    in 2310) with the contextual loss every iteration and LPIPS on 'same' iterations, through the explicit loop."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 5
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                        N_rand=4096, shifts=shifts, seed=1, ksplit=4)
+    p0 = fit.psnr()
+    seen = set()
+    for it in range(60):
+        if fit.step_full():
+            seen.add(fit.last_source)
+            assert torch.isfinite(fit.last_patch_loss).all() and torch.isfinite(fit.net.loss_buf).all()
+    assert {"val", "train"} <= seen
+    assert fit.psnr() > max(p0 + 8.0, 26.0)
+
+
 def test_training_step_is_bit_reproducible(dev):
     """No atomics on the gradient path: split-K slabs + a fixed summation order make two runs of
     the same step produce identical bits (weights after 3 optimiser steps)."""
