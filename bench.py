@@ -326,7 +326,7 @@ def main():
                 per_source[src] = timed(lambda: [fit.step_from(b) for b in bs], reps=5) / len(bs) * 1e3
 
     # ---- iterations to 28 dB on a fresh fit of the same image (not timed) -----------------
-    iters_to_target, final_psnr = None, None
+    iters_to_target, final_psnr, e2e = None, None, None
     if not args.no_psnr and rank == 0:
         f2 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
                            N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts)
@@ -335,6 +335,20 @@ def main():
             if iters_to_target is None and it % 5 == 0 and f2.psnr() >= 28.0:
                 iters_to_target = it
         final_psnr = f2.psnr()
+        # wall time per iteration of the complete loop INCLUDING the host-side sampler (not part of `value`, whose inputs
+        # are resident before timing): with the reference's exact NumPy stream and with rng_mode='fast'
+        e2e = {}
+        for mode in ("reference", "fast"):
+            f4 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                               N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode)
+            for _ in range(20):
+                f4.step_full()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(200):
+                f4.step_full()
+            torch.cuda.synchronize()
+            e2e[mode] = {"ms_per_iter": (time.perf_counter() - t2) / 200 * 1e3, "psnr_known_dB": f4.psnr()}
 
     # ---- the one collective of the job: gather the fitted images -------------------------
     gather_ms = None
@@ -370,7 +384,7 @@ def main():
             "value_per_gpu": value / world,
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
-            "final_gather_ms": gather_ms,
+            "final_gather_ms": gather_ms, "end_to_end_incl_host_sampling": e2e,
             "c4_embedder_1024sq": c4, "ms_per_iter_by_patch_source": per_source,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,

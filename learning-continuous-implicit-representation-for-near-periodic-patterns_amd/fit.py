@@ -22,9 +22,16 @@ class CompletionFit:
                  ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
-                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip"):
+                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference"):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
-        masked_img = img * mask is what the loop trains on (train.py:173)."""
+        masked_img = img * mask is what the loop trains on (train.py:173).
+        rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
+        (np.random.uniform, np.random.choice(replace=False) for the patch centres and the N_rand pixel rows:
+        train.py:172, sampler.py:260,324) -- each choice permutes its whole population, 2.7 ms of host time per
+        iteration at 512^2, three times the device time of the iteration.  "fast" draws the same uniform
+        without-replacement samples with np.random.Generator.choice (O(size)): same distribution, different stream."""
+        if rng_mode not in ("reference", "fast"):
+            raise ValueError("rng_mode must be 'reference' or 'fast'")
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
@@ -41,6 +48,7 @@ class CompletionFit:
                           ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))
         self.rng = np.random.RandomState(seed)
+        self.fast_rng = np.random.default_rng(seed) if rng_mode == "fast" else None
         self.i_train_dev = torch.from_numpy(self.i_train).to(self.device)
         yy, xx = np.meshgrid(np.arange(self.H, dtype=np.int32), np.arange(self.W, dtype=np.int32), indexing="ij")
         self.i_all_dev = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(self.device)
@@ -57,7 +65,7 @@ class CompletionFit:
             self.patch_sampler = GridPatchSampler(
                 img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
                 height=self.H, width=self.W, pool_train=self.i_train, pool_val=self.i_val, selected_shifts=shifts,
-                no_reg_sampling=False, rng=self.rng)
+                no_reg_sampling=False, rng=self.rng, fast_rng=self.fast_rng)
             self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, trunk=trunk, device=self.device).to(self.device)
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
                                     device=self.device, trunk=trunk)
@@ -68,8 +76,11 @@ class CompletionFit:
     # ---- sampling (train.py:172-181) -------------------------------------------------
     def sample_pixels(self):
         """np.random.choice(n_train, N_rand, replace=False) -> coords (N_rand,2) on device."""
-        sel = self.rng.choice(self.i_train.shape[0], size=[self.N_rand], replace=False)
-        return self.i_train_dev[torch.from_numpy(sel).to(self.device)]
+        if self.fast_rng is not None:
+            sel = self.fast_rng.choice(self.i_train.shape[0], size=self.N_rand, replace=False)
+        else:
+            sel = self.rng.choice(self.i_train.shape[0], size=[self.N_rand], replace=False)
+        return self.i_train_dev[ops.h2d(sel, self.device)]
 
     def gather_gt(self, coords):
         return self.masked_img[coords[:, 0].long(), coords[:, 1].long()].contiguous()

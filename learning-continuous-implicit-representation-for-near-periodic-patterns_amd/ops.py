@@ -28,6 +28,46 @@ def _req(t, dtype, name, shape=None):
     return t
 
 
+class _PinnedRing:
+    """Persistent pinned staging buffers for small host -> device transfers (sampler indices, patch centres).
+    A pageable .to(device) is a synchronous copy queued behind everything already in the stream, i.e. a device sync
+    per call: it serialised the host-side sampler with the previous iteration's kernels (+0.5 ms per iteration);
+    tensor.pin_memory() registers fresh host memory on every call (3.4 ms each, measured).  Here: per size class a ring
+    of pinned blocks allocated once, each guarded by the event recorded after its last copy."""
+
+    def __init__(self, slots=8):
+        self.slots, self.rings = slots, {}
+
+    def __call__(self, a, device):
+        a = np.ascontiguousarray(a)
+        if device.type != "cuda":
+            return torch.from_numpy(a).to(device)
+        cap = 1 << max(12, int(a.nbytes - 1).bit_length())
+        ring = self.rings.get((device, cap))
+        if ring is None:
+            ring = self.rings[(device, cap)] = {"buf": [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(self.slots)],
+                                                "ev": [None] * self.slots, "i": 0}
+        i = ring["i"]
+        ring["i"] = (i + 1) % self.slots
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()                       # long complete unless the host ran > slots transfers ahead
+        stage = ring["buf"][i][:a.nbytes]
+        stage.numpy()[:] = a.reshape(-1).view(np.uint8)
+        out = stage.to(device, non_blocking=True).view(torch.from_numpy(a[:0]).dtype).reshape(a.shape)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["ev"][i] = ev
+        return out
+
+
+_pinned_ring = _PinnedRing()
+
+
+def h2d(a, device):
+    """NumPy array -> device tensor through a persistent pinned staging ring, non-blocking (see _PinnedRing)."""
+    return _pinned_ring(a, device)
+
+
 def pad_rows(n):
     return (n + NPP_ROW_TILE - 1) // NPP_ROW_TILE * NPP_ROW_TILE
 

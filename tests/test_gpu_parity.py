@@ -395,6 +395,29 @@ def test_config_c5_shape_k5_with_patch_losses(dev):
     assert fit.psnr() > max(p0 + 8.0, 26.0)
 
 
+def test_fast_rng_mode_fits_like_reference_mode(dev):
+    """rng_mode='fast' (Generator.choice instead of full-population permutations) draws the same kind of samples:
+    distinct in-range pixel rows / patch centres, and the fit reaches the same quality."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    res = {}
+    for mode in ("reference", "fast"):
+        fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                            N_rand=8192, shifts=shifts, seed=0, rng_mode=mode)
+        b = None
+        while b is None:
+            b = fit.sample_batch()
+        pix = b["coords"][:b["n_pix"]].cpu().numpy()
+        assert len({(int(r), int(c)) for r, c in pix}) == b["n_pix"]              # without replacement
+        assert mask[pix[:, 0], pix[:, 1], 0].min() == 1.0                          # all from the known (train) pool
+        for it in range(100):
+            fit.step_full()
+        res[mode] = fit.psnr()
+    assert res["fast"] > 28.5 and abs(res["fast"] - res["reference"]) < 0.5
+
+
 def test_training_step_is_bit_reproducible(dev):
     """No atomics on the gradient path: split-K slabs + a fixed summation order make two runs of
     the same step produce identical bits (weights after 3 optimiser steps)."""
