@@ -50,12 +50,14 @@ struct CxWs {           // workspace carve (floats unless noted)
   unsigned* cmax;       // [N*hw]  column max of cx as float bits
   float* dot;           // [N*hw]  xh . dxh per position (normalisation backward)
   float* g;             // [N]     dL/dcxn / J
+  float* inx;           // [N*hw]  1 / max(sqrt(ssx), 1e-12)  (written by cx_loss_kernel, read by the backward kernels)
+  float* iny;           // [N*hw]
   float* D;             // [N*hw*hw]
   float* cx;            // [N*hw*hw]  cx, then d raw
 };
 
 __host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
-  return (int64_t)C + 6LL * N * hw + N + 2LL * N * hw * hw + 64;
+  return (int64_t)C + 8LL * N * hw + N + 2LL * N * hw * hw + 64;
 }
 
 __host__ inline CxWs carve(float* base, int N, int C, int hw) {
@@ -70,12 +72,25 @@ __host__ inline CxWs carve(float* base, int N, int C, int hw) {
   w.cmax = (unsigned*)p; p += nh;
   w.dot = p; p += nh;
   w.g = p; p += (N + 15) / 16 * 16;
+  w.inx = p; p += nh;
+  w.iny = p; p += nh;
   w.D = p; p += nh * hw;
   w.cx = p;
   return w;
 }
 
 __device__ __forceinline__ float inv_norm(float ss) { return 1.0f / fmaxf(sqrtf(ss), 1e-12f); }   // F.normalize eps
+
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own 4 MiB L2.  With the natural block order
+// every XCD touched all samples (x + y = 7 MB at the loop's size) and its L2 thrashed: 75 % of wave time waiting on
+// memory (SQ_WAIT_ANY).  Logical block = (bid % 8) * ceil(nb / 8) + bid / 8 gives each XCD one contiguous run of
+// (sample, tile) pairs; the grid is rounded up to a multiple of 8 and surplus blocks exit.
+__device__ __forceinline__ int xcd_block(int nb) {
+  const int per = (nb + 7) >> 3;
+  const int l = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return l < nb ? l : -1;
+}
+
 
 // mu_c = mean over (n, pos) of y (functional.py:141), one workgroup per channel; the workgroups
 // also clear the per-position accumulators of this call.
@@ -134,8 +149,10 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   __shared__ __attribute__((aligned(16))) float sB[2][kCxKc][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tiles = (hw + 63) / 64;
-  const int n = blockIdx.x / (tiles * tiles);
-  const int tij = blockIdx.x - n * tiles * tiles;
+  const int lb = xcd_block(N * tiles * tiles);          // whole block exits together: no barrier is skipped
+  if (lb < 0) return;
+  const int n = lb / (tiles * tiles);
+  const int tij = lb - n * tiles * tiles;
   const int i0 = (tij / tiles) * 64, j0 = (tij % tiles) * 64;
   const int wi = wave >> 1, wj = wave & 1, l31 = lane & 31, kh = lane >> 5;
   const float* xn = x + (int64_t)n * C * hw;
@@ -261,7 +278,11 @@ __global__ void cx_loss_kernel(int N, int hw, const float* __restrict__ weight, 
   __shared__ float red[4];
   const int n = blockIdx.x;
   float acc = 0.0f;
-  for (int j = threadIdx.x; j < hw; j += blockDim.x) acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
+  for (int j = threadIdx.x; j < hw; j += blockDim.x) {
+    acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
+    w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);      // once per position instead of once per use
+    w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
+  }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -420,6 +441,136 @@ __global__ void cx_dx_finish_kernel(const float* __restrict__ x, int N, int C, i
   dx[t] = (dx[t] - (x[t] - w.mu[c]) * inx * w.dot[(int64_t)n * hw + p]) * inx;
 }
 
+// ---- second-generation backward contraction and row pass (hw % 32 == 0) ---------------------------------------
+// What was measured on the loop's size (6 x 576 x 576 x 256; rocprofv3 + SQ counters, tools/cx_probe.py):
+//  * the row pass was serial (8 rows per wave, 36 us) -> one row per wave, 16 waves per block: 10 us;
+//  * the backward contraction spent 10 k VALU instructions per wave on sqrt + div for the inverse norms of its operands
+//    (35 x its MFMA count) -> inverse norms computed once (cx_loss_kernel), operands as float4 rows straight from L2
+//    with 8 blocks in flight: 68 -> 31 us;
+//  * feeding v_mfma_f32_32x32x2_f32 (ONE float per lane and operand) straight from global memory does NOT work for the
+//    forward contraction, whose operands are contiguous along positions: it needs a dword load instruction per MFMA
+//    and is bound by the texture addresser (48 - 74 us against 28 us for the LDS-tiled cx_sim_kernel, whatever the
+//    prefetch depth), so that kernel stays LDS-tiled;
+//  * blocks are dealt round-robin to the 8 XCDs (4 MiB L2 each); with the natural order every XCD touches all samples.
+
+// dxh[c][i] = sum_j draw[i][j] yh[c][j]: both operands are contiguous along the contraction index j, so every lane
+// reads float4s of ITS row (A: channel c0 + lane, B: position i0 + lane) and the k order inside a block of 8 columns
+// is "lane-half kh owns columns 8t + 4kh + e" for both operands.
+__global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C,
+                                                      int hw, CxWs w, float* __restrict__ dxh) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+  const int t32 = hw / 32, ct = C / 32, cg = ct / 4 + (ct % 4 ? 1 : 0);    // 4 waves: 4 channel tiles of one position tile
+  const int lb = xcd_block(N * t32 * cg);
+  if (lb < 0) return;
+  const int n = lb / (t32 * cg);
+  const int rem = lb - n * t32 * cg;
+  const int ti = rem / cg, tc = (rem - ti * cg) * 4 + wave;
+  if (tc >= ct) return;
+  const int i0 = ti * 32, c0 = tc * 32;
+  const float mu = w.mu[c0 + l31];
+  const float4* yr = (const float4*)(y + ((int64_t)n * C + c0 + l31) * hw) + kh;       // float4 index 2t + kh
+  const float4* dr = (const float4*)(w.cx + ((int64_t)n * hw + i0 + l31) * hw) + kh;
+  const float4* sr = (const float4*)(w.iny + (int64_t)n * hw) + kh;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  constexpr int PF = 8;                                 // blocks of 8 columns in flight (32 MFMAs = 2048 cycles of cover)
+  float4 ya[PF], da[PF], sa[PF];
+  const int nt = hw / 8;
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+    if (q < nt) { ya[q] = yr[2 * q]; da[q] = dr[2 * q]; sa[q] = sr[2 * q]; }
+  for (int t0 = 0; t0 < nt; t0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int t = t0 + q;
+      if (t < nt) {
+        const float4 yv = ya[q], dv = da[q], sv = sa[q];
+        if (t + PF < nt) { ya[q] = yr[2 * (t + PF)]; da[q] = dr[2 * (t + PF)]; sa[q] = sr[2 * (t + PF)]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.x - mu) * sv.x, dv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.y - mu) * sv.y, dv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.z - mu) * sv.z, dv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.w - mu) * sv.w, dv.w, acc, 0, 0, 0);
+      }
+    }
+  }
+  // accumulator: column = position (lane & 31), rows = channels
+  const int i = i0 + l31;
+  const float inx = w.inx[(int64_t)n * hw + i];
+  float part = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + acc_row(r, kh);
+    const int64_t o = ((int64_t)n * C + c) * hw + i;
+    dxh[o] = acc[r];
+    part = fmaf((x[o] - w.mu[c]) * inx, acc[r], part);
+  }
+  part += __shfl_xor(part, 32, 64);
+  if (kh == 0) atomicAdd(&w.dot[(int64_t)n * hw + i], part);
+}
+
+// Row pass, block-parallel: 16 waves x 1 row = 16 consecutive rows of one sample per block (all rows of the matrix are
+// in flight at once: the pass is one row's latency); the column maxima of the 16 waves meet in LDS -> one atomicMax
+// per column and block.
+constexpr int kCxRowsPerWave = 1;
+constexpr int kCxRowWaves = 16;
+__global__ __launch_bounds__(64 * kCxRowWaves) void cx_rows_fwd32_kernel(int N, int hw, float inv_h, CxWs w) {
+  extern __shared__ float scm[];                         // [16 waves][hw]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blocks_per_n = (hw + kCxRowWaves * kCxRowsPerWave - 1) / (kCxRowWaves * kCxRowsPerWave);
+  const int n = blockIdx.x / blocks_per_n;
+  const int r0 = (blockIdx.x - n * blocks_per_n) * kCxRowWaves * kCxRowsPerWave + wave * kCxRowsPerWave;
+  float cmaxv[kCxMaxCols];
+#pragma unroll
+  for (int q = 0; q < kCxMaxCols; ++q) cmaxv[q] = 0.0f;
+  const int ncol = (hw + 63) / 64;                       // <= kCxMaxCols
+  for (int rr = 0; rr < kCxRowsPerWave; ++rr) {
+    if (r0 + rr >= hw) break;
+    const int64_t row = (int64_t)n * hw + r0 + rr;
+    const float dm = __uint_as_float(w.dmin[row]) + 1e-5f;
+    const float* Dr = w.D + row * hw;
+    float* cr = w.cx + row * hw;
+    float wv[kCxMaxCols];
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) {
+      if (q < ncol) {
+        const int j = lane + 64 * q;
+        wv[q] = j < hw ? __expf((1.0f - Dr[j] / dm) * inv_h) : 0.0f;
+        s += wv[q];
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) w.s[row] = s;
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) {
+      if (q < ncol) {
+        const int j = lane + 64 * q;
+        if (j < hw) {
+          const float c = wv[q] * inv;
+          cr[j] = c;
+          cmaxv[q] = fmaxf(cmaxv[q], c);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kCxMaxCols; ++q) {
+    if (q < ncol) {
+      const int j = lane + 64 * q;
+      if (j < hw) scm[wave * hw + j] = cmaxv[q];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < hw; j += 64 * kCxRowWaves) {
+    float m = scm[j];
+#pragma unroll
+    for (int v = 1; v < kCxRowWaves; ++v) m = fmaxf(m, scm[v * hw + j]);
+    atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(m));
+  }
+}
+
 }  // namespace npp
 
 using namespace npp;
@@ -459,15 +610,36 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
   hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N,
                      C, hw, w);
   const int tiles = (hw + 63) / 64;
-  hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)((int64_t)N * tiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
-  const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
-  hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+  const bool fast = (hw % 32) == 0;          // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
+  const int t32 = hw / 32;
+  if (fast) {
+    hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
+    static bool attr_set = false;
+    const size_t smem = (size_t)kCxRowWaves * hw * sizeof(float);
+    if (!attr_set && smem > 48 * 1024) {
+      if (hipFuncSetAttribute((const void*)cx_rows_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCxRowWaves * 64 * kCxMaxCols * 4) != hipSuccess) {
+        set_error("npp_cx_fwd_bwd: smem attribute"); return NPP_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(cx_rows_fwd32_kernel, dim3((unsigned)((int64_t)N * ((hw + kCxRowWaves - 1) / kCxRowWaves))), dim3(64 * kCxRowWaves), smem, s, N,
+                       hw, inv_h, w);
+  } else {
+    hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
+    const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
+    hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+  }
   hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, w);
   if (d_dfx) {
     hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     const int ctiles = (C + 63) / 64;
-    hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,
-                       d_dfx);
+    if (fast) {
+      const int64_t nb_dx = (int64_t)N * t32 * ((C / 32 + 3) / 4);
+      hipLaunchKernelGGL(cx_dx32_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
+    }
+    else
+      hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,
+                         d_dfx);
     const int64_t ne = nh * C;
     hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx);
   }
