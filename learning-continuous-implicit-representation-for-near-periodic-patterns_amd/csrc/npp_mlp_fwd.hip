@@ -32,7 +32,16 @@ namespace npp {
 EmbedDev make_embed_dev(const npp_embed_cfg& c);
 int check_embed_cfg(const npp_embed_cfg* c, const char* who);
 
-constexpr int kThreads = 256;
+// Waves per 64-row workgroup: 4 (each owns 2 of the 8 neuron tiles; <= 256 VGPRs, 2 waves per SIMD with two workgroups
+// per CU) or 8 (1 tile each; <= 128 VGPRs, 4 waves per SIMD: more independent instruction streams to cover the LDS
+// hand-off / barrier / weight-load latencies of the layer chain).  Same LDS image, same stash layout either way.
+#ifndef NPP_FWD_WAVES
+#define NPP_FWD_WAVES 4
+#endif
+constexpr int kWavesF = NPP_FWD_WAVES;
+constexpr int kNTW = kNT / kWavesF;                             // neuron tiles per wave in 256-wide layers
+constexpr int kThreads = 64 * kWavesF;
+static_assert(kWavesF == 4 || kWavesF == 8, "4 or 8 waves per workgroup");
 constexpr int kFragBytes = 1024;                               // 64 lanes x 16 B
 constexpr int kRegionBytes = kKSAct * kNB * kFragBytes;        // 32 KiB: 256 feats x 64 rows bf16
 constexpr int kChunkKS = 8;                                    // k-steps per embedding chunk
@@ -103,8 +112,8 @@ __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, co
                                          const Lane& L) {
   const float y = sY[L.lane], x = sX[L.lane];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const int i = L.wave + 4 * q;
+  for (int q = 0; q < (22 + kWavesF - 1) / kWavesF; ++q) {
+    const int i = L.wave + kWavesF * q;
     if (i < 22) {
       const WarpEnt w = tw[p * 22 + i];
       // y*cos + x*sin rounded like the reference's two torch ops; the linear entries put the
@@ -185,8 +194,9 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   STAMP(51);
   char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) : nullptr;
   // this wave's k-step q (0, 1) of chunk c: generate, hand to the LDS ring, stash for wgrad
+  constexpr int kPer = kChunkKS / kWavesF;                       // k-steps of a chunk generated by one wave (2 or 1)
   auto gen_pair = [&](int c, int q) {
-    const int ksl = 2 * L.wave + q, ks = kChunkKS * c + ksl;      // wave-uniform
+    const int ksl = kPer * L.wave + q, ks = kChunkKS * c + ksl;    // wave-uniform
     if (ks < kKSEmb) {
       bf16x8 f[kNB];
       if (EMB_IN) load_emb_pair(e.emb, e.emb_ld, (int64_t)wg * kRowTile, p, ks, f, L);
@@ -199,7 +209,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
     }
   };
   gen_pair(0, 0);
-  gen_pair(0, 1);
+  if (kPer == 2) gen_pair(0, 1);
   STAMP(52);
   wg_barrier();
   STAMP(53);
@@ -209,7 +219,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   auto hook_for = [&](int c_next) {
     return [&, c_next](int pos) {
       if (pos == 0) gen_pair(c_next, 0);
-      else if (pos == 4) gen_pair(c_next, 1);
+      else if (pos == 4 && kPer == 2) gen_pair(c_next, 1);
     };
   };
   mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
@@ -267,7 +277,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 }
 
 template <bool TRAIN, bool MULTI, bool EMB_IN = false>
-__global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
+__global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R0 = smem;
   char* R1 = smem + kRegionBytes;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   const int64_t row0 = (int64_t)wg * kRowTile;
   const int64_t Bp = A_.Bp;
   const float* P = A_.params;
-  const int nt0 = 2 * L.wave;            // this wave's neuron tiles in 256-wide layers
+  const int nt0 = kNTW * L.wave;         // this wave's neuron tiles in 256-wide layers
 
   if (!EMB_IN && L.tid < kRowTile) {
     const int2 c = ((const int2*)A_.coords)[row0 + L.tid];
@@ -323,8 +333,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
 
   auto arow = [&](int idx) -> char* { return TRAIN ? A_.actF + wfmt_array_base(idx * kKSAct, gridDim.x) : nullptr; };
 
-  f32x16 acc[2][kNB];
-  WRing<2> ring;                           // weight-stream register ring, live across layers
+  f32x16 acc[kNTW][kNB];
+  WRing<kNTW> ring;                           // weight-stream register ring, live across layers
   WRing<1> ringp;                          // same for P (one neuron tile per wave)
   ring.rsrc = ringp.rsrc = make_wrsrc(A_.wf, d.wf_total16);
   constexpr wptr_t U = kNT * 64;           // 16-byte units per k-step of a 256-wide layer
@@ -334,11 +344,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
 
   STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
-  wring_fill<2, kNT>(ring, wl(L0), nt0, L.lane);
-  init_bias<2>(acc, P + d.b_off[L0], nt0, L);
-  mma_embedding<TRAIN, 2, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
+  wring_fill<kNTW, kNT>(ring, wl(L0), nt0, L.lane);
+  init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
+  mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
   STAMP(1);
-  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, arow(0), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(0), wg, L);
   STAMP(2);
   wg_barrier();
   STAMP(3);
@@ -348,10 +358,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
   for (int l = L1; l <= L4; ++l) {
     char* in = (l & 1) ? R0 : R1;
     char* out = (l & 1) ? R1 : R0;
-    init_bias<2>(acc, P + d.b_off[l], nt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
+    init_bias<kNTW>(acc, P + d.b_off[l], nt0, L);
+    mma_ring<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
     STAMP(4 * l);
-    epilogue<true, TRAIN, 2>(acc, out, nt0, kNT, arow(l), wg, L);
+    epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
     STAMP(4 * l + 1);
     wg_barrier();
     STAMP(4 * l + 2);
@@ -359,78 +369,82 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
 
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
   //      again after mma_embedding's final barrier)
-  init_bias<2>(acc, P + d.b_off[L5], nt0, L);
-  mma_embedding<false, 2, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
+  init_bias<kNTW>(acc, P + d.b_off[L5], nt0, L);
+  mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
   STAMP(20);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
+  mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   STAMP(21);
-  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(5), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L);
   wg_barrier();
   STAMP(22);
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
-  init_bias<2>(acc, P + d.b_off[L6], nt0, L);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
-  epilogue<true, TRAIN, 2>(acc, R0, nt0, kNT, arow(6), wg, L);
+  init_bias<kNTW>(acc, P + d.b_off[L6], nt0, L);
+  mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
+  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(6), wg, L);
   wg_barrier();
-  init_bias<2>(acc, P + d.b_off[L7], nt0, L);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
-  epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(7), wg, L);
+  init_bias<kNTW>(acc, P + d.b_off[L7], nt0, L);
+  mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
+  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(7), wg, L);
   wg_barrier();
 
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
   //      registers because P needs f1 again after S and F2 have recycled the regions.
-  bf16x8 f1keep[2][kNB][2];
-  init_bias<2>(acc, P + d.b_off[LF1], nt0, L);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
-  if (!MULTI) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
-  epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
+  bf16x8 f1keep[kNTW][kNB][2];
+  init_bias<kNTW>(acc, P + d.b_off[LF1], nt0, L);
+  mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
+  const bool p_wave = L.wave < kNT / 2;            // P has 4 neuron tiles: with 8 waves the upper four only keep the barriers
+  if (!MULTI && p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+  epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
   wg_barrier();
 
   f32x16 accp[1][kNB];
   if (MULTI) {
     // ---- S = scale_linears[0]: [f1 (R0), emb(p1..pK-1) (LDS ring R1)] -> 256, snake, out -> R1
-    init_bias<2>(acc, P + d.b_off[LS], nt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
+    init_bias<kNTW>(acc, P + d.b_off[LS], nt0, L);
+    mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
-      mma_embedding<TRAIN, 2, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
+      mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
                                    A_.actF, wg, L, ring);
     }
-    wring_fill<2, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
-    epilogue<true, TRAIN, 2>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
+    wring_fill<kNTW, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
+    epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
-    init_bias<2>(acc, P + d.b_off[LF2], nt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
-    wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
-    epilogue<false, TRAIN, 2>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
+    init_bias<kNTW>(acc, P + d.b_off[LF2], nt0, L);
+    mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
+    if (p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+    epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
     wg_barrier();
     // f1 back into LDS (R1 is idle: every wave passed the barrier after reading a_s)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < kNTW; ++nt)
 #pragma unroll
       for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) lds_store_frag(R1, 2 * (nt0 + nt) + s, bt, L.lane, f1keep[nt][bt][s]);
     wg_barrier();
     // ---- P = pos_linears[0]: [f1 (R1), f2 (R0)] -> 128, snake; one neuron tile per wave
-    init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
-    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
-    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
-  } else {
+    if (p_wave) {
+      init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
+      mma_ring<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
+      mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
+    }
+  } else if (p_wave) {
     // ---- NPP_Net_top1: P reads f1 (R0) directly (networks.py:162-170)
     init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
     mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
-  epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
-                           wg, L);
+  if (p_wave)
+    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
+                             wg, L);
 
   STAMP(40);
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,
   //      half-wave exchange by shuffle, 4-wave reduction through LDS.
   wg_barrier();       // every wave is done with R0 / R1: R0 now carries the rgb partial sums
-  {
+  if (p_wave) {
     const float* Wr = P + d.w_off[LRGB];
     float part[kNB][3];
 #pragma unroll
@@ -454,6 +468,8 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_fwd_kernel(FwdArgs A_, EmbedD
         const float v = part[bt][c] + __shfl_xor(part[bt][c], 32, 64);
         if (L.h == 0) sRGB[(L.wave * kRowTile + bt * 32 + L.b) * 3 + c] = v;
       }
+  }
+  {
     wg_barrier();
     if (L.tid < kRowTile * 3) {
       const int row = L.tid / 3, c = L.tid - row * 3;
