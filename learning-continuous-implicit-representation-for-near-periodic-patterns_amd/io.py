@@ -1,0 +1,115 @@
+"""On-disk formats of the completion task, host side only.
+
+* `config.odgt` -- one JSON line written by NPP_proposal/search.py:228-280: `fpath_masked_img`, `fpath_valid_mask`,
+  `fpath_mask`, `fpath_gt_img`, `selected_angles`, `selected_periods`, `selected_shifts` (top-k lists), `distances`, ...
+  `load_data` re-roots every `fpath_*` entry onto the data directory by file name (loaders/loaders.py:67-80).
+* the four PNGs it names; read like cv2.imread(...)[:, :, ::-1] / 255 (RGB in [0,1]) and cv2.imread(..., 0) / 255 for the
+  masks (loaders/loaders.py:92-101).  PIL replaces cv2 (not installed here); PNG decoding is exact, so the arrays are identical.
+* the evaluation dump of NPP_completion/train.py:270-328: `testset_<iter:06d>/{pred_rgb_train_img, pred_rgb_val_img,
+  gt_rgb_img, input_rgb_img, pred_rgb_img, pred_rgb_img_comp}.png`.
+"""
+import json
+import os
+
+import numpy as np
+
+
+def _imread_rgb(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float64) / 255.0
+
+
+def _imread_gray(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("L"), dtype=np.float64)[:, :, None] / 255.0
+
+
+def imsave(path, arr):
+    """plt.imsave of an (H,W,3) float image in [0,1] (train.py:319-328): clip, 8 bit."""
+    from PIL import Image
+    a = np.clip(np.asarray(arr, np.float64), 0.0, 1.0)
+    Image.fromarray(np.uint8(np.rint(a * 255.0))).save(path)
+
+
+def load_data(datadir):
+    """loaders/loaders.py:67-80."""
+    with open(os.path.join(datadir, "config.odgt"), "r") as f:
+        info = json.loads(f.readline().rstrip())
+    out = {}
+    for key, val in info.items():
+        if "fpath" in key:
+            name = (val[0] if isinstance(val, list) else val).split("/")[-1]
+            out[key] = os.path.join(datadir, name)
+        else:
+            out[key] = val
+    return out
+
+
+def patch_size_from_period(periods_top1):
+    """loaders/loaders.py:133-134."""
+    mp = float(max(periods_top1))
+    return int(np.clip(mp + (32 - mp % 32), 64, 160))
+
+
+def load_npp_completion(datadir, p_topk=3, invalid_as_unknown=False, normalize_type=1):
+    """loaders/loaders.py:82-136 -> dict(img (H,W,3), mask (H,W,1), masked_img, valid_mask, i_train, i_val,
+    shifts, angles, periods, patch_size).  Arrays are float32, [0,1]; coordinates (row, col)."""
+    info = load_data(datadir)
+    masked_img = _imread_rgb(info["fpath_masked_img"])
+    img = _imread_rgb(info["fpath_gt_img"])
+    valid_mask = _imread_gray(info["fpath_valid_mask"])
+    mask = _imread_gray(info["fpath_mask"])
+    mask = mask * valid_mask                                        # :103 filter invalid region
+    if invalid_as_unknown:
+        valid_mask = np.ones_like(valid_mask)
+    i_train = np.stack(np.nonzero(mask * valid_mask)[:2], axis=1)    # :107-108
+    i_val = np.stack(np.nonzero((1 - mask) * valid_mask)[:2], axis=1)
+    if normalize_type == 2:
+        img = (img - 0.5) * 2
+    shifts = info["selected_shifts"][:p_topk]
+    angles = info["selected_angles"][:p_topk]
+    periods = info["selected_periods"][:p_topk]
+    return dict(img=img.astype(np.float32), mask=mask.astype(np.float32), masked_img=masked_img.astype(np.float32),
+                valid_mask=valid_mask.astype(np.float32), i_train=i_train, i_val=i_val, shifts=shifts,
+                angles=np.asarray(angles, np.float32), periods=np.asarray(periods, np.float32),
+                patch_size=patch_size_from_period(periods[0]), info=info)
+
+
+def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, distances=None):
+    """Write what NPP_proposal/search.py:228-280 leaves behind for one image (config.odgt + the four PNGs), e.g. for a
+    synthetic image whose periodicity is known.  img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) with 1 = known / valid."""
+    from PIL import Image
+    os.makedirs(outdir, exist_ok=True)
+    img = np.asarray(img, np.float64)
+    mask = np.asarray(mask, np.float64).reshape(img.shape[0], img.shape[1])
+    valid = np.asarray(valid_mask, np.float64).reshape(img.shape[0], img.shape[1])
+    names = {"fpath_masked_img": "masked_img.png", "fpath_valid_mask": "valid_mask.png", "fpath_mask": "unknown_mask.png",
+             "fpath_gt_img": "gt_img.png"}
+    gt8 = np.uint8(img * 255)                                         # search.py:249-252 truncating casts
+    Image.fromarray(gt8).save(os.path.join(outdir, names["fpath_gt_img"]))
+    Image.fromarray(np.uint8(img * mask[..., None] * 255)).save(os.path.join(outdir, names["fpath_masked_img"]))
+    Image.fromarray(np.uint8(valid * 255)).save(os.path.join(outdir, names["fpath_valid_mask"]))
+    Image.fromarray(np.uint8(mask * 255)).save(os.path.join(outdir, names["fpath_mask"]))
+    odgt = {k: os.path.join(outdir, v) for k, v in names.items()}
+    odgt.update(selected_angles=np.asarray(angles, np.float64).tolist(), selected_periods=np.asarray(periods, np.float64).tolist(),
+                selected_shifts=[[list(map(float, s)) for s in sh] for sh in shifts],
+                distances=list(distances) if distances is not None else [0.0] * len(shifts))
+    with open(os.path.join(outdir, "config.odgt"), "w") as f:
+        json.dump(odgt, f)
+        f.write("\n")
+    return outdir
+
+
+def dump_testset(savedir, pred_hw3, img, masked_img, mask, valid_mask):
+    """The six PNGs of train.py:319-328 from one full-grid render: the reference renders the train and val pixels
+    separately into two canvases; with a full-grid prediction these are pred * mask and pred * (1 - mask)."""
+    os.makedirs(savedir, exist_ok=True)
+    pred = np.asarray(pred_hw3, np.float64)
+    m, v = np.asarray(mask, np.float64), np.asarray(valid_mask, np.float64)
+    pred_train, pred_val = pred * m * v, pred * (1 - m) * v
+    imsave(os.path.join(savedir, "pred_rgb_train_img.png"), pred_train)
+    imsave(os.path.join(savedir, "pred_rgb_val_img.png"), pred_val)
+    imsave(os.path.join(savedir, "gt_rgb_img.png"), np.asarray(img, np.float64) * v)
+    imsave(os.path.join(savedir, "input_rgb_img.png"), np.asarray(masked_img, np.float64) * v)
+    imsave(os.path.join(savedir, "pred_rgb_img.png"), pred_val + pred_train)
+    imsave(os.path.join(savedir, "pred_rgb_img_comp.png"), pred_val + np.asarray(masked_img, np.float64) * v * m)

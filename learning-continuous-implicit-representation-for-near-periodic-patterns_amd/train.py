@@ -1,0 +1,107 @@
+"""Completion driver: what `python NPP_completion/train.py --datadir D --basedir B --p_topk K` does (run_completion.sh:13),
+on the HIP path.
+
+    python -m npp_amd.train --datadir data/completion/detected/<name> --basedir ./results --p_topk 3
+
+Reads config.odgt + PNGs (npp_amd.io), builds the net with torch's default nn.Linear init and Gaussian Fourier
+frequencies drawn from torch's global generator like the reference (models/embedder.py:26, models/networks.py:40-49;
+seed with --seed), runs N_iters iterations of the complete loop body (CompletionFit.step_full) and writes
+results/<expname>_top<K>/<name>/testset_<iter>/*.png every --i_testset iterations (train.py:270-328).
+Flags keep the reference's names and defaults (options/arg_config.py:10-36,55-100) except --netwidth, which this
+build fixes at 256 (BASELINE.json; the reference's default is 512).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--datadir", required=True)
+    ap.add_argument("--basedir", default="./results")
+    ap.add_argument("--expname", default="completion")
+    ap.add_argument("--p_topk", type=int, default=3)
+    ap.add_argument("--N_iters", type=int, default=2001)
+    ap.add_argument("--N_rand", type=int, default=8192)
+    ap.add_argument("--lrate", type=float, default=5e-4)
+    ap.add_argument("--lrate_decay", type=int, default=500)
+    ap.add_argument("--netwidth", type=int, default=256)
+    ap.add_argument("--patch_num", type=int, default=2)
+    ap.add_argument("--num_real_patch_per_sample", type=int, default=3)
+    ap.add_argument("--invalid_ratio", type=float, default=0.3)
+    ap.add_argument("--patch_size_decay", type=int, default=2000)
+    ap.add_argument("--i_testset", type=int, default=500)
+    ap.add_argument("--i_print", type=int, default=500)
+    ap.add_argument("--invalid_as_unknown", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rng_mode", default="reference", choices=["reference", "fast"])
+    ap.add_argument("--vgg19", default=None, help="torchvision vgg19 state_dict (.pth) for the contextual loss trunk")
+    ap.add_argument("--vgg16", default=None, help="torchvision vgg16 state_dict (.pth) for the LPIPS trunk")
+    ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth (the five 1x1 lin layers)")
+    ap.add_argument("--device", default="cuda:0")
+    return ap.parse_args(argv)
+
+
+def default_linear_init(layout, n_params, seed):
+    """torch nn.Linear default init per tensor of the blob (kaiming_uniform(a=sqrt 5) weight, uniform bias), drawn
+    tensor by tensor in state_dict order from a seeded CPU generator."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    fan_in = {}
+    for name, off, rows, cols in layout:
+        if name.endswith("weight"):
+            fan_in[name[:-7]] = cols
+            bound = 1.0 / np.sqrt(cols)                       # kaiming_uniform with a = sqrt(5): sqrt(6 / ((1 + 5) fan_in))
+            sd[name] = ((torch.rand(rows, cols, generator=g) * 2 - 1) * bound).numpy()
+        else:
+            bound = 1.0 / np.sqrt(fan_in[name[:-5]])
+            sd[name] = ((torch.rand(rows * cols, generator=g) * 2 - 1) * bound).numpy()
+    return sd
+
+
+def main(argv=None):
+    args = parse(argv)
+    if args.netwidth != 256:
+        raise SystemExit("this build is specialised for --netwidth 256 (BASELINE.json); the reference default 512 is not built")
+    from . import io as nio
+    from ._lib import param_layout
+    from .fit import CompletionFit
+    d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
+    K = len(d["angles"])
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()       # embedder.py:26
+    layout, n_params = param_layout(K)
+    params = default_linear_init(layout, n_params, args.seed)
+
+    def load(path):
+        return None if path is None else torch.load(path, map_location="cpu")
+    lin = load(args.lpips_lin)
+    if lin is not None:                                                                    # lin0.model.1.weight ... (1,C,1,1)
+        lin = [lin[f"lin{i}.model.1.weight"].reshape(-1).numpy() for i in range(5)]
+    fit = CompletionFit(d["img"], d["mask"], d["angles"], d["periods"], freqs, params, device=args.device, N_rand=args.N_rand,
+                        seed=args.seed, lrate=args.lrate, lrate_decay=args.lrate_decay, valid_mask=d["valid_mask"],
+                        shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
+                        num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
+                        patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
+                        vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, ksplit=12)
+    name = os.path.basename(os.path.normpath(args.datadir))
+    outroot = os.path.join(args.basedir, f"{args.expname}_top{args.p_topk}", name)
+    t0 = time.time()
+    for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
+        fit.step_full()
+        if i % args.i_testset == 0:
+            pred = fit.render_image().cpu().numpy()
+            nio.dump_testset(os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"], d["valid_mask"])
+            print(f"[EVAL] iter {i}: PSNR known {fit.psnr('known'):.2f} dB, unknown {fit.psnr('unknown'):.2f} dB")
+        if i % args.i_print == 0:
+            print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
+                  f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
+    return fit
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""config.odgt / PNG formats of the completion task (npp_amd.io; loaders/loaders.py:67-136, NPP_proposal/search.py:228-280)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+
+def _make(tmp_path, H=64, K=2):
+    from npp_amd import io as nio
+    img, mask = oracle.synthetic_image(H)
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    valid = np.ones_like(mask)
+    valid[:3] = 0                                            # an invalid band: excluded from both splits
+    d = nio.write_detected_dir(str(tmp_path / "detected" / "img0"), img, mask, valid, a, p, s)
+    return d, img, mask, valid, a, p, s
+
+
+def test_odgt_round_trip_and_splits(tmp_path):
+    from npp_amd import io as nio
+    d, img, mask, valid, a, p, s = _make(tmp_path)
+    info = json.loads(open(os.path.join(d, "config.odgt")).readline())
+    for key in ("fpath_masked_img", "fpath_valid_mask", "fpath_mask", "fpath_gt_img", "selected_angles", "selected_periods",
+                "selected_shifts", "distances"):
+        assert key in info                                    # the keys search.py:231-242 writes and loaders.py reads
+    r = nio.load_npp_completion(d, p_topk=1)
+    assert r["angles"].shape == (1, 2) and len(r["shifts"]) == 1            # top-k truncation (loaders.py:125-127)
+    r = nio.load_npp_completion(d, p_topk=3)
+    assert r["angles"].shape == (2, 2)
+    np.testing.assert_allclose(r["img"], np.uint8(img * 255) / 255.0, atol=1e-7)     # 8-bit PNG, like cv2.imread / 255
+    m = (mask * valid)[..., 0]
+    assert np.array_equal(r["mask"][..., 0], m)
+    assert np.array_equal(r["i_train"], np.stack(np.nonzero(m), 1))                  # np.nonzero order (loaders.py:107)
+    assert np.array_equal(r["i_val"], np.stack(np.nonzero((1 - m) * valid[..., 0]), 1))
+    assert r["patch_size"] == oracle.patch_size_from_period(p[0])
+    np.testing.assert_allclose(r["masked_img"], np.uint8(img * mask * 255) / 255.0, atol=1e-7)   # search.py:250: img * unknown mask
+    r2 = nio.load_npp_completion(d, invalid_as_unknown=True)
+    assert r2["valid_mask"].min() == 1.0 and r2["i_val"].shape[0] > r["i_val"].shape[0]
+
+
+def test_load_data_reroots_paths(tmp_path):
+    """search.py stores the paths it wrote to; loaders.py:70-77 keeps only the file name and joins it to --datadir."""
+    from npp_amd import io as nio
+    d, *_ = _make(tmp_path)
+    moved = str(tmp_path / "elsewhere")
+    os.rename(d, moved)
+    info = nio.load_data(moved)
+    assert info["fpath_gt_img"] == os.path.join(moved, "gt_img.png") and os.path.exists(info["fpath_gt_img"])
+    nio.load_npp_completion(moved)
+
+
+def test_dump_testset_files(tmp_path):
+    from npp_amd import io as nio
+    H = 32
+    img, mask = oracle.synthetic_image(H)
+    pred = np.clip(img + 0.01, 0, 1)
+    out = str(tmp_path / "testset_000500")
+    nio.dump_testset(out, pred, img, img * mask, mask, np.ones_like(mask))
+    assert sorted(os.listdir(out)) == sorted(["pred_rgb_train_img.png", "pred_rgb_val_img.png", "gt_rgb_img.png", "input_rgb_img.png",
+                                              "pred_rgb_img.png", "pred_rgb_img_comp.png"])          # train.py:319-328
+    from PIL import Image
+    comp = np.asarray(Image.open(os.path.join(out, "pred_rgb_img_comp.png")), np.float64) / 255
+    known = mask[..., 0] > 0
+    np.testing.assert_allclose(comp[known], img[known], atol=1 / 255 + 1e-6)          # known pixels come from the input
+
+
+@pytest.mark.gpu
+def test_train_driver_end_to_end(tmp_path):
+    """python -m npp_amd.train on a detected/ directory: config.odgt + PNGs in, testset_* PNG dumps out."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from npp_amd import io as nio, train
+    H, K = 256, 3
+    img, mask = oracle.synthetic_image(H)
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    d = nio.write_detected_dir(str(tmp_path / "detected" / "syn"), img, mask, np.ones_like(mask), a, p, s)
+    fit = train.main(["--datadir", d, "--basedir", str(tmp_path / "results"), "--p_topk", "3", "--N_iters", "121",
+                      "--i_testset", "60", "--i_print", "60", "--rng_mode", "fast"])
+    out = tmp_path / "results" / "completion_top3" / "syn"
+    assert sorted(os.listdir(out)) == ["testset_000060", "testset_000120"]
+    assert len(os.listdir(out / "testset_000120")) == 6
+    assert fit.psnr() > 26.0                               # torch-default init + freshly drawn Fourier frequencies
