@@ -284,6 +284,30 @@ int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int 
 int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W,
                      float* d_out_nchw, int is_f16, void* stream);
 
+/* ---- generic dense layers (exact fp32), SURVEY.md 8 f1 -------------------------- */
+/* What F.linear + SnakeActivation (models/activations.py:29-35) and their autograd do for topologies the fused chain
+ * kernels are not specialised for -- first user: NPP_Net_light of the proposal-ranking fits (models/networks.py:176-263,
+ * NPP_proposal/search.py:85-205).  Row-major tensors with explicit leading dimensions (so a layer can write into / read
+ * from a column block of a concatenated buffer, networks.py:247 torch.cat); w (out, in) like nn.Linear.
+ *  fwd:        y = act(x w^T + b), act 0 none / 1 snake; d_z (nullable) receives the pre-activation
+ *  bwd_data:   dx[:, :in_used] (+)= dz w[:, :in_used]
+ *  bwd_weight: dw (+)= dz^T x ; db (+)= column sums of dz (d_db nullable)
+ *  act_bwd:    dz = dy * act'(.), act 1 snake from z, 2 sigmoid from its output, 3 tanh from its output
+ *  act_fwd:    y = sigmoid (2) / tanh (3) of x, elementwise (render, models/helpers.py:55-58) */
+int npp_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b, int64_t B, int in,
+                   int out, int act, float* d_y, int64_t ldy, float* d_z, int64_t ldz, void* stream);
+int npp_linear_bwd_data(const float* d_dz, int64_t lddz, const float* d_w, int64_t B, int in, int out,
+                        float* d_dx, int64_t lddx, int in_used, int accumulate, void* stream);
+int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx, int64_t B, int in,
+                          int out, float* d_dw, float* d_db, int accumulate, void* stream);
+int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act,
+                float* d_dz, int64_t lddz, void* stream);
+int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);
+/* LPIPS.forward(use_robust=False), one VGG16 tap, forward only (externel_lib/lpips/lpips.py:99-101,110,117,130; the
+ * candidate score of NPP_proposal/search.py:193): d_out[0] += scale * sum_n mean_pos sum_c lin_c (f0n - f1n)^2. */
+int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
+                          float scale, float* d_out, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 /* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the
  * accumulator-as-next-operand chain) with exact integer data.  d_scratch >= 1 MiB. */

@@ -77,6 +77,12 @@ SYMBOLS = {
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
     "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
+    "npp_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "npp_linear_bwd_data": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
+    "npp_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "npp_act_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "npp_act_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "npp_lpips_plain_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),
     "npp_patch_compose_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "npp_patch_compose_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "npp_trunk_nposp": (_i64, [_i32, _i32, _i32]),

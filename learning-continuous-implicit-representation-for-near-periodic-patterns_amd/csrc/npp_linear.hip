@@ -1,0 +1,235 @@
+// npp_linear.hip -- generic dense layers in exact fp32 (v_mfma_f32_32x32x2_f32): what F.linear + SnakeActivation and
+// their autograd do for topologies the fused chain kernels are not specialised for.  First user: the proposal-ranking
+// fits of NPP_proposal/search.py:85-205 with NPP_Net_light (models/networks.py:176-263): 2048 rows x ~0.3 M parameters x
+// 300 iterations per candidate -- a launch-bound problem, so the layers stay separate launches and exact fp32.
+//
+// One GEMM kernel, C[m][n] = sum_k A(m,k) B(k,n) with arbitrary element strides, serves
+//   forward      y  = act(x W^T + b)    A = x  (k contiguous), B = W read as (k,n) (k contiguous)
+//   data grad    dx = dz W              A = dz (k contiguous), B = W read as (k=n_out, col) (col contiguous)
+//   weight grad  dW = dz^T x            A = dz read as (m=n_out, k=row) (m contiguous), B = x (col contiguous)
+// 64 x 64 output tile per workgroup (4 waves of 32 x 32), 32-wide k chunks staged through LDS as [k][m]: the fp32 MFMA
+// takes ONE float per lane and operand, so the operands cannot come straight from global memory (measured on the
+// contextual-loss kernels: texture-addresser-bound).  The staging thread map follows each operand's contiguous index.
+#include "npp_common.h"
+
+namespace npp {
+
+struct GemmArgs {
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbk, sbn;
+  float* C; int64_t ldc;
+  float* Z; int64_t ldz;          // optional copy of the pre-activation (forward)
+  const float* bias;              // optional, per column n
+  int M, N, K, act, accumulate;   // act: 0 none, 1 snake (x + sin^2 x)
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
+  __shared__ float sA[32][65];
+  __shared__ float sB[32][65];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, wm = wave >> 1, wn = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int m, k;
+      if (A_KC) { k = tid & 31; m = (tid >> 5) + 8 * r; } else { m = tid & 63; k = (tid >> 6) + 4 * r; }
+      sA[k][m] = (m0 + m < g.M && k0 + k < g.K) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.0f;
+      int n, kb;
+      if (B_KC) { kb = tid & 31; n = (tid >> 5) + 8 * r; } else { n = tid & 63; kb = (tid >> 6) + 4 * r; }
+      sB[kb][n] = (n0 + n < g.N && k0 + kb < g.K) ? g.B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[2 * ks + kh][wm * 32 + l31], sB[2 * ks + kh][wn * 32 + l31], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n >= g.N) return;
+  const float bv = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + acc_row(r, kh);
+    if (m >= g.M) continue;
+    float v = acc[r] + bv;
+    if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
+    if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
+    float* c = g.C + (int64_t)m * g.ldc + n;
+    *c = g.accumulate ? *c + v : v;
+  }
+}
+
+// db[n] (+)= sum_rows dz[row][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, int64_t ld, int64_t B, int N, float* __restrict__ db,
+                                                     int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+  float s = 0.0f;
+  if (n < N)
+    for (int64_t r = q; r < B; r += 4) s += dz[r * ld + n];
+  red[q][c] = s;
+  __syncthreads();
+  if (q == 0 && n < N) {
+    const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    db[n] = accumulate ? db[n] + t : t;
+  }
+}
+
+// dz = dy * act'(.) : act 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y));
+// 3 tanh from its output (1 - y^2)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ zy, int64_t ldzy, int64_t B, int N,
+                               int act, float* __restrict__ dz, int64_t lddz) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * N) return;
+  const int64_t r = t / N;
+  const int n = (int)(t - r * N);
+  const float v = zy[r * ldzy + n];
+  const float d = act == 1 ? 1.0f + sinf(2.0f * v) : (act == 2 ? v * (1.0f - v) : (act == 3 ? 1.0f - v * v : 1.0f));
+  dz[r * lddz + n] = dy[r * lddy + n] * d;
+}
+
+// y = sigmoid(x) / tanh(x) elementwise (render's output squash, helpers.py:55-58)
+__global__ void act_fwd_kernel(const float* __restrict__ x, int64_t n, int act, float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float v = x[t];
+  y[t] = act == 2 ? 1.0f / (1.0f + expf(-v)) : (act == 3 ? tanhf(v) : v);
+}
+
+// LPIPS.forward(use_robust=False), one tap (lpips.py:99-101,110,117,130): sum over (n, pos) of
+// sum_c lin_c (f0_c / (|f0| + eps) - f1_c / (|f1| + eps))^2, scaled by coef.  16 positions x 16 channel lanes per block.
+__global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restrict__ f0, const float* __restrict__ f1, int N, int C, int hw,
+                                                          const float* __restrict__ lin, float coef, float* __restrict__ out) {
+  __shared__ float red[2][16][17];
+  __shared__ float tot[4];
+  const int pl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int64_t npos = (int64_t)N * hw, ngroups = (npos + 15) / 16;
+  float val = 0.0f;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t t = grp * 16 + pl;
+    const bool live = t < npos;
+    const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
+    const float* a0 = f0 + (int64_t)n * C * hw + p;
+    const float* a1 = f1 + (int64_t)n * C * hw + p;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (live)
+      for (int c = cl; c < C; c += 16) {
+        const float u = a0[(int64_t)c * hw], v = a1[(int64_t)c * hw];
+        s0 = fmaf(u, u, s0);
+        s1 = fmaf(v, v, s1);
+      }
+    __syncthreads();
+    red[0][cl][pl] = s0;
+    red[1][cl][pl] = s1;
+    __syncthreads();
+    s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s0 += red[0][q][pl]; s1 += red[1][q][pl]; }
+    const float i0 = 1.0f / (sqrtf(s0) + 1e-10f), i1 = 1.0f / (sqrtf(s1) + 1e-10f);
+    if (live)
+      for (int c = cl; c < C; c += 16) {
+        const float d = a0[(int64_t)c * hw] * i0 - a1[(int64_t)c * hw] * i1;
+        val = fmaf(lin[c] * d, d, val);
+      }
+  }
+  for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+  if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
+}
+
+static int gemm_launch(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t s) {
+  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, dim3(256), 0, s, g);
+  else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, dim3(256), 0, s, g);
+  else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, dim3(256), 0, s, g);
+  return NPP_OK;
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+static bool lin_dims_ok(int64_t B, int in, int out) { return B >= 1 && B < (1LL << 31) && in >= 1 && out >= 1; }
+
+extern "C" int npp_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b, int64_t B, int in, int out, int act,
+                              float* d_y, int64_t ldy, float* d_z, int64_t ldz, void* stream) {
+  if (!d_x || !d_w || !d_y || !lin_dims_ok(B, in, out) || ldx < in || ldy < out || (d_z && ldz < out) || act < 0 || act > 1) {
+    set_error("npp_linear_fwd: bad argument (B=%lld in=%d out=%d act=%d)", (long long)B, in, out, act);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_x; g.sam = ldx; g.sak = 1;
+  g.B = d_w; g.sbk = 1; g.sbn = in;                  // B(k, n) = W[n][k]
+  g.C = d_y; g.ldc = ldy; g.Z = d_z; g.ldz = ldz; g.bias = d_b;
+  g.M = (int)B; g.N = out; g.K = in; g.act = act; g.accumulate = 0;
+  gemm_launch(g, true, true, (hipStream_t)stream);
+  return check_launch("npp_linear_fwd");
+}
+
+extern "C" int npp_linear_bwd_data(const float* d_dz, int64_t lddz, const float* d_w, int64_t B, int in, int out, float* d_dx,
+                                   int64_t lddx, int in_used, int accumulate, void* stream) {
+  if (!d_dz || !d_w || !d_dx || !lin_dims_ok(B, in, out) || lddz < out || in_used < 1 || in_used > in || lddx < in_used) {
+    set_error("npp_linear_bwd_data: bad argument (B=%lld in=%d out=%d in_used=%d)", (long long)B, in, out, in_used);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_dz; g.sam = lddz; g.sak = 1;               // A(m = row, k = n_out)
+  g.B = d_w; g.sbk = in; g.sbn = 1;                  // B(k = n_out, col) = W[n_out][col]
+  g.C = d_dx; g.ldc = lddx;
+  g.M = (int)B; g.N = in_used; g.K = out; g.act = 0; g.accumulate = accumulate;
+  gemm_launch(g, true, false, (hipStream_t)stream);
+  return check_launch("npp_linear_bwd_data");
+}
+
+extern "C" int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx, int64_t B, int in, int out,
+                                     float* d_dw, float* d_db, int accumulate, void* stream) {
+  if (!d_dz || !d_x || !d_dw || !lin_dims_ok(B, in, out) || lddz < out || ldx < in) {
+    set_error("npp_linear_bwd_weight: bad argument (B=%lld in=%d out=%d)", (long long)B, in, out);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_dz; g.sam = 1; g.sak = lddz;               // A(m = n_out, k = row) = dz[row][n_out]
+  g.B = d_x; g.sbk = ldx; g.sbn = 1;                 // B(k = row, col) = x[row][col]
+  g.C = d_dw; g.ldc = in;
+  g.M = out; g.N = in; g.K = (int)B; g.act = 0; g.accumulate = accumulate;
+  gemm_launch(g, false, false, (hipStream_t)stream);
+  if (d_db)
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((out + 63) / 64)), dim3(256), 0, (hipStream_t)stream, d_dz, lddz, B, out, d_db, accumulate);
+  return check_launch("npp_linear_bwd_weight");
+}
+
+extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,
+                           int64_t lddz, void* stream) {
+  if (!d_dy || !d_zy || !d_dz || B < 1 || n < 1 || lddy < n || ldzy < n || lddz < n || act < 0 || act > 3) {
+    set_error("npp_act_bwd: bad argument");
+    return NPP_ERR_ARG;
+  }
+  const int64_t t = B * n;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_dy, lddy, d_zy, ldzy, B, n, act,
+                     d_dz, lddz);
+  return check_launch("npp_act_bwd");
+}
+
+extern "C" int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream) {
+  if (!d_x || !d_y || n < 1 || act < 0 || act > 3) { set_error("npp_act_fwd: bad argument"); return NPP_ERR_ARG; }
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x, n, act, d_y);
+  return check_launch("npp_act_fwd");
+}
+
+extern "C" int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale,
+                                     float* d_out, void* stream) {
+  if (!d_f0 || !d_f1 || !d_lin || !d_out || N < 1 || C < 16 || (C % 16) || hw < 1) {
+    set_error("npp_lpips_plain_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
+    return NPP_ERR_ARG;
+  }
+  const int64_t groups = ((int64_t)N * hw + 15) / 16;
+  hipLaunchKernelGGL(lpips_plain_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, (hipStream_t)stream, d_f0, d_f1, N, C,
+                     hw, d_lin, scale / (float)hw, d_out);
+  return check_launch("npp_lpips_plain_layer");
+}

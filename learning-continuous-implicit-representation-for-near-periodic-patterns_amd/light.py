@@ -1,0 +1,258 @@
+"""Proposal-ranking fits: NPP_Net_light + the candidate loop and score of NPP_proposal/search.py:85-215,
+host side.  Every operator runs in libnpp_hip.so: the is_search embedders through npp_warp_fwd / npp_fourier_fwd, the MLP
+through the generic dense-layer kernels (npp_linear_*: exact fp32 MFMA), the adaptive robust pixel loss and Adam through
+the same kernels as the main loop, the score through the trunk / LPIPS / contextual-loss kernels.
+
+The problem is tiny (2048 rows x 0.3 M parameters x 300 iterations per candidate) and launch-bound; candidates are
+independent, so they shard one per GPU exactly like images do (parallel.py).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import EmbedCfg
+from .model import LATENT_ALPHA_INIT
+
+_SNAKE, _SIGMOID = 1, 2
+
+
+def light_layout(W=256, D=4, in_pos=42, in_per=20):
+    """[(name, rows, cols)] of the tensors NPP_Net_light's forward uses (models/networks.py:199-214,216-262 with
+    len(freq_scales) == 1), in the reference's state_dict order."""
+    out = [(f"periodic_linears.{i}", W, in_per if i == 0 else W) for i in range(D)]
+    out += [("pos_linears.0", W // 2, W + in_pos), ("feature_linear1", W, W), ("rgb_linear", 3, W // 2)]
+    return out
+
+
+class NPPNetLight:
+    """NPP_Net_light(D, W, activation='snake') with its two is_search embedders, Adam state and the adaptive pixel-loss
+    latents.  state_dict names / layouts are the reference's; scale_linears / feature_linear2 / alpha_linear (constructed by
+    the reference, never used when len(freq_scales) == 1) are not kept."""
+
+    def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500):
+        self.device = torch.device(device)
+        self.res = (int(res[0]), int(res[1]))
+        self.W, self.D = int(W), int(D)
+        self.freqs = [float(f) for f in np.asarray(freqs).reshape(-1)]
+        self.in_pos, self.in_per = 2 * (1 + 2 * len(self.freqs)), 20
+        self.cfg = EmbedCfg.make(np.asarray(angles_deg, np.float32).reshape(1, 2), np.asarray(periods, np.float32).reshape(1, 2),
+                                 np.zeros(10, np.float32), self.res)
+        self.layout = light_layout(self.W, self.D, self.in_pos, self.in_per)
+        n = sum(r * c + r for _, r, c in self.layout)
+        self.n_params = n
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.params)
+        self.m, self.v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.w, self.b, self.dw, self.db = {}, {}, {}, {}
+        off = 0
+        for name, r, c in self.layout:
+            self.w[name], self.dw[name] = self.params[off:off + r * c].view(r, c), self.grad[off:off + r * c].view(r, c)
+            off += r * c
+            self.b[name], self.db[name] = self.params[off:off + r], self.grad[off:off + r]
+            off += r
+        if params is not None:
+            self.load_state_dict(params)
+        self.latents = torch.tensor([LATENT_ALPHA_INIT] * 3 + [0.0] * 3, dtype=torch.float32, device=self.device)
+        self.lat_m, self.lat_v = torch.zeros_like(self.latents), torch.zeros_like(self.latents)
+        self.dlatent = torch.zeros(6, dtype=torch.float32, device=self.device)
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
+        self.lrate, self.lrate_decay, self.lr = float(lrate), int(lrate_decay), float(lrate)
+        self.global_step, self.opt_step = 0, 0
+        self._ws = {}
+
+    def load_state_dict(self, sd):
+        for name, r, c in self.layout:
+            for part, dst in (("weight", self.w[name]), ("bias", self.b[name])):
+                a = sd[f"{name}.{part}"]
+                a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).reshape(dst.shape))
+
+    def state_dict(self):
+        out = {}
+        for name, _, _ in self.layout:
+            out[f"{name}.weight"], out[f"{name}.bias"] = self.w[name].cpu().numpy().copy(), self.b[name].cpu().numpy().copy()
+        return out
+
+    def grads(self):
+        out = {}
+        for name, _, _ in self.layout:
+            out[f"{name}.weight"], out[f"{name}.bias"] = self.dw[name].cpu().numpy().copy(), self.db[name].cpu().numpy().copy()
+        return out
+
+    # ---- embedders (get_embedder(is_search=True), models/embedder.py:52-54,76-88) ----------------------
+    def embed(self, coords_yx):
+        """coords (N,2) int32 (row, col) -> (x_pos (N,42), x_per (N,20))."""
+        c = coords_yx.to(torch.float32)
+        H, W = self.res
+        norm = torch.stack([(c[:, 0] / H - 0.5) * 2, (c[:, 1] / W - 0.5) * 2], 1).contiguous()       # embedder.py:52-54
+        x_pos = ops.fourier_fwd(norm, self.freqs, include_input=True)
+        v = ops.warp_fwd(coords_yx.contiguous(), self.cfg)                                            # (N, 22)
+        x_per = torch.cat([v[:, 1:11], v[:, 12:22]], 1).contiguous()                                  # include_input = False
+        return x_pos, x_per
+
+    def _work(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)      # noqa: E731
+            W = self.W
+            ws = dict(z=[f(B, W) for _ in range(self.D)], h=[f(B, W) for _ in range(self.D)], hp=f(B, W + self.in_pos),
+                      zp=f(B, W // 2), ap=f(B, W // 2), raw=f(B, 3), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3), dap=f(B, W // 2),
+                      dzp=f(B, W // 2), df1=f(B, W), dh=f(B, W), dz=f(B, W))
+            self._ws[B] = ws
+        return ws
+
+    # ---- NPP_Net_light.forward + render's sigmoid (networks.py:216-262, helpers.py:55-56) ----------------
+    def forward(self, x_pos, x_per):
+        B = x_per.shape[0]
+        ws = self._work(B)
+        ws["x_per"] = x_per
+        h = x_per
+        for i in range(self.D):
+            name = f"periodic_linears.{i}"
+            ops.linear_fwd(h, self.w[name], self.b[name], _SNAKE, ws["h"][i], ws["z"][i])
+            h = ws["h"][i]
+        W = self.W
+        ops.linear_fwd(h, self.w["feature_linear1"], self.b["feature_linear1"], 0, ws["hp"][:, :W])      # cat[feature1, input_pos] :247
+        ws["hp"][:, W:].copy_(x_pos)
+        ops.linear_fwd(ws["hp"], self.w["pos_linears.0"], self.b["pos_linears.0"], _SNAKE, ws["ap"], ws["zp"])
+        ops.linear_fwd(ws["ap"], self.w["rgb_linear"], self.b["rgb_linear"], 0, ws["raw"])
+        ops.act_fwd(ws["raw"], _SIGMOID, ws["pred"])
+        return ws["pred"]
+
+    def backward(self, B):
+        """loss.backward(): consumes ws['dpred'] = dL/dpred, fills self.grad."""
+        ws, W = self._ws[B], self.W
+        ops.act_bwd(ws["dpred"], ws["pred"], _SIGMOID, ws["draw"])
+        ops.linear_bwd_weight(ws["draw"], ws["ap"], self.dw["rgb_linear"], self.db["rgb_linear"])
+        ops.linear_bwd_data(ws["draw"], self.w["rgb_linear"], ws["dap"])
+        ops.act_bwd(ws["dap"], ws["zp"], _SNAKE, ws["dzp"])
+        ops.linear_bwd_weight(ws["dzp"], ws["hp"], self.dw["pos_linears.0"], self.db["pos_linears.0"])
+        ops.linear_bwd_data(ws["dzp"], self.w["pos_linears.0"], ws["df1"], in_used=W)                    # no gradient to input_pos
+        ops.linear_bwd_weight(ws["df1"], ws["h"][self.D - 1], self.dw["feature_linear1"], self.db["feature_linear1"])
+        ops.linear_bwd_data(ws["df1"], self.w["feature_linear1"], ws["dh"])
+        for i in range(self.D - 1, -1, -1):
+            name = f"periodic_linears.{i}"
+            ops.act_bwd(ws["dh"], ws["z"][i], _SNAKE, ws["dz"])
+            x_in = ws["h"][i - 1] if i > 0 else ws["x_per"]
+            ops.linear_bwd_weight(ws["dz"], x_in, self.dw[name], self.db[name])
+            if i > 0:
+                ops.linear_bwd_data(ws["dz"], self.w[name], ws["dh"])
+
+    def train_step(self, x_pos, x_per, gt):
+        """One iteration of search.py:113-147: render -> zero_grad -> img2mse(robust_loss_adaptive) -> backward -> Adam ->
+        LR rule (set after the step) -> global_step += 1."""
+        B = x_per.shape[0]
+        pred = self.forward(x_pos, x_per)
+        ws = self._ws[B]
+        self.loss_buf.zero_()
+        self.dlatent.zero_()
+        ops.pixel_loss(pred, gt, None, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, self.loss_buf, ws["dpred"], self.dlatent)
+        self.backward(B)
+        self.opt_step += 1
+        ops.adam_step(self.params, self.m, self.v, self.grad, 1, self.n_params, self.lr, self.opt_step)
+        ops.adam_step(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, self.lr, self.opt_step)
+        self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
+        self.global_step += 1
+        return self.loss_buf
+
+    @torch.no_grad()
+    def render(self, coords_yx, chunk=20000):
+        out = []
+        for j in range(0, coords_yx.shape[0], chunk):
+            x_pos, x_per = self.embed(coords_yx[j:j + chunk])
+            out.append(self.forward(x_pos, x_per).clone())
+        return torch.cat(out, 0)
+
+
+def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
+    """The reference's construction order and torch default nn.Linear init (models/networks.py:199-214) after
+    torch.manual_seed(seed) -- search.py:92 reseeds with 0 before every candidate, so all candidates start from the same
+    weights.  Draws the unused modules too, to keep the generator in step."""
+    g = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    mods = {}
+    for i in range(D):
+        mods[f"periodic_linears.{i}"] = torch.nn.Linear(in_per if i == 0 else W, W)      # skips=[4] is never reached for D = 4
+    mods["scale_linears.0"] = torch.nn.Linear(0 + W, W)
+    mods["pos_linears.0"] = torch.nn.Linear(in_pos + W, W // 2)
+    mods["feature_linear1"] = torch.nn.Linear(W, W)
+    mods["feature_linear2"] = torch.nn.Linear(W, W)
+    mods["alpha_linear"] = torch.nn.Linear(W, 1)
+    mods["rgb_linear"] = torch.nn.Linear(W // 2, 3)
+    torch.random.set_rng_state(g)
+    return {f"{k}.{p}": getattr(m, p).detach().numpy().copy() for k, m in mods.items() for p in ("weight", "bias")}
+
+
+class ProposalRanker:
+    """The candidate loop of NPP_proposal/search.py:85-215 for one image: per candidate (angles, periods) a fresh
+    NPP_Net_light is fitted for N_iters pixel-loss iterations on the known pixels, rendered over the pseudo-mask region
+    and scored with perceptual_weight * LPIPS(use_robust=False) + contextual_weight * CX against the (known) content of
+    that region; the top-k smallest scores win (search.py:215)."""
+
+    def __init__(self, masked_img, i_train, i_val, device="cuda", N_iters=300, N_rand=2048, W=256, D=4, lrate=5e-4, lrate_decay=500,
+                 perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
+                 lpips_lin_weights=None, rng_mode="reference"):
+        from .losses import ContextualLoss, LPIPS
+        self.device = torch.device(device)
+        self.img = torch.as_tensor(np.asarray(masked_img, np.float32)).to(self.device)               # (H,W,3)
+        self.H, self.W_img = self.img.shape[:2]
+        self.i_train = np.asarray(i_train).astype(np.int32)
+        self.i_val = np.asarray(i_val).astype(np.int32)
+        self.i_train_dev = torch.from_numpy(self.i_train).to(self.device)
+        self.i_val_dev = torch.from_numpy(self.i_val).to(self.device)
+        self.N_iters, self.N_rand, self.Wn, self.D = int(N_iters), int(N_rand), int(W), int(D)
+        self.lrate, self.lrate_decay = lrate, lrate_decay
+        self.pw, self.cw = float(perceptual_weight), float(contextual_weight)
+        self.rng_mode = rng_mode
+        if freqs is None:                                      # embedder.py:26 after torch.manual_seed(0) (search.py:92)
+            g = torch.random.get_rng_state()
+            torch.manual_seed(0)
+            freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()
+            torch.random.set_rng_state(g)
+        self.freqs = np.asarray(freqs, np.float32)
+        self.percep = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device)
+        self.cx = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device)
+
+    def fit_candidate(self, angles_deg, periods, params=None):
+        net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
+                          params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
+                          device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
+        x_pos_all, x_per_all = net.embed(self.i_train_dev)                                           # search.py:104-108 tables
+        rng = np.random.RandomState(0)                                                               # np.random.seed(0), :93
+        fast = np.random.default_rng(0) if self.rng_mode == "fast" else None
+        n_train = self.i_train.shape[0]
+        n_rand = min(self.N_rand, n_train)
+        for _ in range(self.N_iters):
+            sel = fast.choice(n_train, n_rand, replace=False) if fast is not None else rng.choice(n_train, size=[n_rand], replace=False)
+            idx = ops.h2d(sel.astype(np.int64), self.device)
+            c = self.i_train_dev[idx]
+            gt = self.img[c[:, 0].long(), c[:, 1].long()].contiguous()
+            net.train_step(x_pos_all[idx].contiguous(), x_per_all[idx].contiguous(), gt)
+        return net
+
+    @torch.no_grad()
+    def score(self, net):
+        """search.py:152-197."""
+        pred = net.render(self.i_val_dev)
+        vy, vx = self.i_val_dev[:, 0].long(), self.i_val_dev[:, 1].long()
+        canvas_p = torch.zeros_like(self.img)
+        canvas_g = torch.zeros_like(self.img)
+        canvas_p[vy, vx] = pred
+        canvas_g[vy, vx] = self.img[vy, vx]
+        h0, h1, w0, w1 = int(vy.min()), int(vy.max()), int(vx.min()), int(vx.max())                   # [min, max) like :180-187
+        p = canvas_p[h0:h1, w0:w1].permute(2, 0, 1)[None].contiguous()
+        g = canvas_g[h0:h1, w0:w1].permute(2, 0, 1)[None].contiguous()
+        lp = self.percep.plain(p, g, normalize=False)
+        cx = self.cx(p, g)
+        return float(lp[0]) * self.pw + float(cx) * self.cw, float(lp[0]), float(cx)
+
+    def rank(self, candidates, topk=10):
+        """candidates: [(angles (2,), periods (2,), shifts)] -> (sorted distances, order, per-candidate details)."""
+        details = []
+        for angles, periods, *_ in candidates:
+            net = self.fit_candidate(angles, periods)
+            details.append(self.score(net))
+        d = np.array([x[0] for x in details])
+        order = np.argsort(d, kind="stable")[:min(topk, len(d))]
+        return d[order], order, details

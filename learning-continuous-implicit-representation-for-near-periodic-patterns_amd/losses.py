@@ -340,6 +340,21 @@ class LPIPS(nn.Module):
         self.touched = True
         return t._backward(dfs, n, sc, tuple(xy.shape), zero_rest=False)
 
+    @torch.no_grad()
+    def plain(self, in0, in1, normalize=False):
+        """LPIPS.forward(in0, in1, use_robust=False) (lpips.py:92-133), forward only: the candidate score of
+        NPP_proposal/search.py:193.  Returns a (1,) tensor: the SUM over the batch of the per-image distances
+        (search.py evaluates one image pair)."""
+        a = 2.0 if normalize else 1.0
+        sc = [a / s for s in self._SCALE]
+        sh = [((-1.0 if normalize else 0.0) - b) / s for b, s in zip(self._SHIFT, self._SCALE)]
+        n = in0.shape[0]
+        feats = self.hip_trunk._forward(torch.cat([in0, in1], 0).contiguous(), sc, sh)
+        out = torch.zeros(1, dtype=torch.float32, device=in0.device)
+        for kk, f in enumerate(feats):
+            ops.lpips_plain_layer(f[:n], f[n:], self.lins[kk], 1.0, out)
+        return out
+
     def zero_latent_grads(self):
         for d in self.dlatents:
             d.zero_()

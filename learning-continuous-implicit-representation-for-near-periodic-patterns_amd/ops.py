@@ -358,3 +358,51 @@ def patch_compose_bwd(dx_a, dx_b, fmask, rmask, n_p, k, P, comp, dpred_rows):
     _req(dpred_rows, torch.float32, "dpred_rows", (n_p * P * P, 3))
     check(lib().npp_patch_compose_bwd(_p(dx_a), _p(dx_b), _p(fmask), _p(rmask), n_p, k, P, int(bool(comp)), _p(dpred_rows),
                                       _stream()), "npp_patch_compose_bwd")
+
+
+# ---- generic dense layers (exact fp32): F.linear + snake and their autograd ----------------
+def linear_fwd(x, w, b, act, y, z=None):
+    """y = act(x w^T + b) on row-major 2-D tensors; x / y / z may be column blocks of wider buffers (stride(0) = ld)."""
+    B, cin = x.shape
+    cout = w.shape[0]
+    assert w.shape[1] == cin and y.shape == (B, cout) and x.stride(1) == 1 and y.stride(1) == 1 and w.is_contiguous()
+    check(lib().npp_linear_fwd(_p(x), x.stride(0), _p(w), _p(b), B, cin, cout, act, _p(y), y.stride(0), _p(z),
+                               0 if z is None else z.stride(0), _stream()), "npp_linear_fwd")
+    return y
+
+
+def linear_bwd_data(dz, w, dx, in_used=None, accumulate=False):
+    B, cout = dz.shape
+    cin = w.shape[1]
+    in_used = cin if in_used is None else in_used
+    assert dx.shape == (B, in_used) and dz.stride(1) == 1 and dx.stride(1) == 1
+    check(lib().npp_linear_bwd_data(_p(dz), dz.stride(0), _p(w), B, cin, cout, _p(dx), dx.stride(0), in_used, int(bool(accumulate)),
+                                    _stream()), "npp_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight(dz, x, dw, db=None, accumulate=False):
+    B, cout = dz.shape
+    cin = x.shape[1]
+    assert dw.shape == (cout, cin) and dw.is_contiguous() and x.stride(1) == 1 and dz.stride(1) == 1
+    check(lib().npp_linear_bwd_weight(_p(dz), dz.stride(0), _p(x), x.stride(0), B, cin, cout, _p(dw), _p(db), int(bool(accumulate)),
+                                      _stream()), "npp_linear_bwd_weight")
+
+
+def act_bwd(dy, zy, act, dz):
+    B, n = dy.shape
+    check(lib().npp_act_bwd(_p(dy), dy.stride(0), _p(zy), zy.stride(0), B, n, act, _p(dz), dz.stride(0), _stream()), "npp_act_bwd")
+    return dz
+
+
+def act_fwd(x, act, y):
+    check(lib().npp_act_fwd(_p(x), x.numel(), act, _p(y), _stream()), "npp_act_fwd")
+    return y
+
+
+def lpips_plain_layer(f0, f1, lin, scale, out):
+    _req(f0, torch.float32, "f0")
+    _req(f1, torch.float32, "f1", f0.shape)
+    N, C = f0.shape[:2]
+    check(lib().npp_lpips_plain_layer(_p(f0), _p(f1), N, C, f0.shape[2] * f0.shape[3], _p(lin), scale, _p(out), _stream()),
+          "npp_lpips_plain_layer")

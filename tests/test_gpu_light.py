@@ -1,0 +1,162 @@
+"""SURVEY.md 8 f1 on the GPU: the generic dense-layer kernels (npp_linear_*), NPP_Net_light on them, the is_search
+embedders, the plain LPIPS head and the candidate fit / ranking loop, through the C ABI.  References: NumPy for the dense
+layers (fp32 round-off), the reference's own modules through tests/golden/g10_light.npz for everything else."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import npp_amd
+    npp_amd.lib()
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("B,cin,cout", [(1, 1, 1), (70, 20, 64), (257, 106, 32), (2048, 256, 256), (33, 298, 128), (100, 128, 3)])
+def test_dense_layer_kernels_vs_numpy(dev, B, cin, cout):
+    """forward (bias, snake, pre-activation copy, strided output), data gradient (partial columns, accumulate), weight + bias
+    gradient, activation backward: exact-fp32 MFMA, so agreement is fp32 round-off."""
+    from npp_amd import ops
+    rng = np.random.RandomState(B + cin)
+    x, w, b = rng.randn(B, cin).astype(np.float32), (rng.randn(cout, cin) / np.sqrt(cin)).astype(np.float32), rng.randn(cout).astype(np.float32)
+    xb = torch.zeros(B, cin + 5, device=dev)
+    xb[:, 2:2 + cin] = torch.from_numpy(x).to(dev)                              # x as a column block of a wider buffer
+    xv = xb[:, 2:2 + cin]
+    wt, bt = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    yb = torch.full((B, cout + 3), 7.0, device=dev)
+    z = torch.empty(B, cout, device=dev)
+    ops.linear_fwd(xv, wt, bt, 1, yb[:, 1:1 + cout], z)
+    zr = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(yb[:, 1:1 + cout].cpu().numpy(), zr + np.sin(zr) ** 2, rtol=3e-5, atol=3e-5)
+    assert float(yb[:, 0].min()) == 7.0 and float(yb[:, 1 + cout:].min()) == 7.0       # neighbours untouched
+    ops.linear_fwd(xv, wt, None, 0, yb[:, 1:1 + cout])
+    np.testing.assert_allclose(yb[:, 1:1 + cout].cpu().numpy(), zr - b, rtol=2e-5, atol=2e-5)
+    dz = rng.randn(B, cout).astype(np.float32)
+    dzt = torch.from_numpy(dz).to(dev)
+    used = max(1, cin - 3)
+    dx = torch.ones(B, used, device=dev)
+    ops.linear_bwd_data(dzt, wt, dx, in_used=used, accumulate=True)
+    np.testing.assert_allclose(dx.cpu().numpy(), 1.0 + (dz.astype(np.float64) @ w.astype(np.float64))[:, :used], rtol=3e-5, atol=3e-5)
+    dw, db = torch.empty(cout, cin, device=dev), torch.empty(cout, device=dev)
+    ops.linear_bwd_weight(dzt, xv, dw, db)
+    scale = np.sqrt(B)
+    np.testing.assert_allclose(dw.cpu().numpy(), dz.T.astype(np.float64) @ x.astype(np.float64), rtol=1e-4, atol=3e-5 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), dz.sum(0, dtype=np.float64), rtol=1e-4, atol=3e-5 * scale)
+    g = torch.empty(B, cout, device=dev)
+    ops.act_bwd(dzt, z, 1, g)
+    np.testing.assert_allclose(g.cpu().numpy(), dz * (1 + np.sin(2 * zr)), rtol=1e-4, atol=1e-4)
+
+
+def _P(g):
+    return {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+
+
+def test_search_embedders_vs_reference(dev, golden):
+    from npp_amd.light import NPPNetLight, default_light_init
+    g = golden("g10_light.npz")
+    res = tuple(int(v) for v in g["res"])
+    net = NPPNetLight(g["angles"], g["periods"], g["freqs"], res, default_light_init(64), W=64, device=dev)
+    x_pos, x_per = net.embed(torch.from_numpy(g["coords"].astype(np.int32)).to(dev))
+    np.testing.assert_allclose(x_pos.cpu().numpy(), g["pos_emb"], atol=2e-5)         # models/embedder.py:52-56, is_search
+    np.testing.assert_allclose(x_per.cpu().numpy(), g["per_emb"], atol=2e-5)         # :84-88, include_input False
+
+
+def test_light_net_vs_reference(dev, golden):
+    """NPP_Net_light forward + every parameter gradient against the reference module's own autograd (g10_light.npz)."""
+    from npp_amd.light import NPPNetLight
+    g = golden("g10_light.npz")
+    res = tuple(int(v) for v in g["res"])
+    net = NPPNetLight(g["angles"], g["periods"], g["freqs"], res, _P(g), W=64, device=dev)
+    x_pos, x_per = torch.from_numpy(g["pos_emb"]).to(dev), torch.from_numpy(g["per_emb"]).to(dev)
+    pred = net.forward(x_pos, x_per)
+    B = x_per.shape[0]
+    np.testing.assert_allclose(net._ws[B]["raw"].cpu().numpy(), g["raw"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(pred.cpu().numpy(), g["pred"], atol=1e-5)
+    dpred = 2.0 * (g["pred"] - g["tgt"]) / g["pred"].size                             # d mean((pred - tgt)^2) / dpred
+    net._ws[B]["dpred"].copy_(torch.from_numpy(dpred.astype(np.float32)).to(dev))
+    net.backward(B)
+    G = net.grads()
+    for name, _, _ in net.layout:
+        for part in ("weight", "bias"):
+            assert rel_l2(G[f"{name}.{part}"], g[f"grad.{name}.{part}"]) < 3e-4, (name, part)
+
+
+def test_lpips_plain_vs_reference(dev, golden):
+    from npp_amd import ops
+    g = golden("g10_light.npz")
+    out = torch.zeros(1, device=dev)
+    for k in range(5):
+        ops.lpips_plain_layer(torch.from_numpy(g[f"lp_f0_{k}"]).to(dev), torch.from_numpy(g[f"lp_f1_{k}"]).to(dev),
+                              torch.from_numpy(g[f"lp_lin{k}"]).to(dev), 1.0, out)
+    np.testing.assert_allclose(float(out[0]), float(g["lp_val"].reshape(-1)[0]), rtol=3e-5)
+
+
+def test_light_fit_matches_oracle_trajectory(dev):
+    """Five optimisation steps of the candidate fit (search.py:113-147) against the NumPy oracle from the same state."""
+    from npp_amd.light import NPPNetLight, default_light_init
+    H = 64
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, _ = oracle.synthetic_periodicity(H, 1)
+    freqs = oracle.SEED0_FREQS
+    P0 = default_light_init(64)
+    net = NPPNetLight(angles[0], periods[0], freqs, (H, H), P0, W=64, device=dev)
+    P = {k: v.astype(np.float32).copy() for k, v in P0.items() if k.rsplit(".", 1)[0] in dict((n, 0) for n, _, _ in net.layout)}
+    st = oracle.adam_init(P)
+    la, ls = np.full((1, 3), 2.3841858e-07, np.float32), np.zeros((1, 3), np.float32)
+    lat = np.concatenate([la, ls], 1).reshape(-1)
+    lat_st = {"m": np.zeros(6, np.float32), "v": np.zeros(6, np.float32), "t": 0}
+    rng = np.random.RandomState(0)
+    for it in range(5):
+        c = np.stack([rng.randint(0, H, 256), rng.randint(0, H, 256)], 1).astype(np.int32)
+        gt = img[c[:, 0], c[:, 1]].astype(np.float32)
+        ct = torch.from_numpy(c).to(dev)
+        x_pos, x_per = net.embed(ct)
+        lr = net.lr
+        net.train_step(x_pos, x_per, torch.from_numpy(gt).to(dev))
+        xp_o, xq_o = oracle.search_pos_embed(c, freqs, (H, H)), oracle.search_periodic_embed(c, angles[0], periods[0], (H, H))
+        raw, cache = oracle.light_forward(P, xp_o, xq_o)
+        pr = oracle.sigmoid(raw)
+        loss, dpred, dla, dls = oracle.img2mse_grads(pr, gt, lat[None, :3], lat[None, 3:])
+        G = oracle.light_backward(P, cache, dpred * pr * (1 - pr))
+        oracle.adam_step(P, G, st, lr)
+        glat = np.concatenate([np.asarray(dla).reshape(-1), np.asarray(dls).reshape(-1)])
+        lat_st["t"] += 1
+        lat_st["m"] = 0.9 * lat_st["m"] + 0.1 * glat
+        lat_st["v"] = 0.999 * lat_st["v"] + 0.001 * glat * glat
+        lat = lat - lr / (1 - 0.9 ** lat_st["t"]) * lat_st["m"] / (np.sqrt(lat_st["v"] / (1 - 0.999 ** lat_st["t"])) + 1e-8)
+        assert abs(float(net.loss_buf[0]) - float(loss)) < 2e-4 * abs(float(loss)) + 1e-6
+    sd = net.state_dict()
+    for k in P:
+        assert rel_l2(sd[k], P[k]) < 2e-3, k                     # Adam's normalised steps amplify fp32 round-off of tiny gradients
+    np.testing.assert_allclose(net.latents.cpu().numpy(), lat, atol=2e-5)
+
+
+def test_ranking_prefers_the_true_periodicity(dev):
+    """The candidate loop + score of search.py:85-215 on a synthetic lattice: the true (angles, periods) must rank above
+    a wrong period and a wrong orientation."""
+    from npp_amd.light import ProposalRanker
+    H = 128
+    img, _ = oracle.synthetic_image(H, noise=0.01)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    pseudo = np.ones((H, H), np.float32)
+    pseudo[40:88, 36:92] = 0                                     # pseudo-mask region: content known, withheld from the fit
+    i_train = np.stack(np.nonzero(pseudo), 1)
+    i_val = np.stack(np.nonzero(1 - pseudo), 1)
+    ranker = ProposalRanker(img, i_train, i_val, device=dev, N_iters=150, N_rand=2048, rng_mode="fast")
+    cands = [(angles[0], periods[0], shifts[0]), (angles[0], periods[0] * 1.37, shifts[0]), (angles[0] + 35.0, periods[0], shifts[0])]
+    d, order, details = ranker.rank(cands, topk=3)
+    assert order[0] == 0, (d, order, details)
+    assert np.all(np.diff(d) >= 0) and all(np.isfinite(x[0]) for x in details)
