@@ -350,6 +350,28 @@ def main():
             torch.cuda.synchronize()
             e2e[mode] = {"ms_per_iter": (time.perf_counter() - t2) / 200 * 1e3, "psnr_known_dB": f4.psnr()}
 
+    # ---- one proposal-ranking candidate fit (search.py:85-205: NPP_Net_light, 300 iterations x 2048 rows,
+    #      then the LPIPS + contextual score on the pseudo-mask region), wall time incl. host sampling ----
+    ranking = None
+    if rank == 0 and not args.no_extras:
+        from npp_amd.light import ProposalRanker
+        pseudo = np.ones((H, H), np.float32)
+        pseudo[H // 4:H // 4 + 128, H // 4:H // 4 + 160] = 0
+        rk = ProposalRanker(img * mask, np.stack(np.nonzero(pseudo * mask[..., 0]), 1), np.stack(np.nonzero((1 - pseudo) * mask[..., 0]), 1),
+                            device=dev, rng_mode="fast")
+        rk.fit_candidate(angles[0], periods[0])                 # warm-up (allocations, first-call setup)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        net_l = rk.fit_candidate(angles[0], periods[0])
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t3
+        sc = rk.score(net_l)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t3
+        ranking = {"fit_ms_per_iter": t_fit / rk.N_iters * 1e3, "candidate_fit_s": t_fit, "candidate_fit_plus_score_s": t_all,
+                   "rows_per_s": rk.N_iters * rk.N_rand / t_fit, "score": sc[0],
+                   "note": "NPP_Net_light D=4 W=256 on the generic exact-fp32 dense kernels; launch-bound (~40 launches per iteration)"}
+
     # ---- the one collective of the job: gather the fitted images -------------------------
     gather_ms = None
     if dist is not None:
@@ -385,7 +407,7 @@ def main():
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
             "final_gather_ms": gather_ms, "end_to_end_incl_host_sampling": e2e,
-            "c4_embedder_1024sq": c4, "ms_per_iter_by_patch_source": per_source,
+            "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "ms_per_iter_by_patch_source": per_source,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
         }

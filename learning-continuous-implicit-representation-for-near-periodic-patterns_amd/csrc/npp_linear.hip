@@ -20,7 +20,9 @@ struct GemmArgs {
   float* C; int64_t ldc;
   float* Z; int64_t ldz;          // optional copy of the pre-activation (forward)
   const float* bias;              // optional, per column n
+  float* rowsum;                  // optional: rowsum[m] += sum_k A(m,k) (the bias gradient of the weight-gradient form)
   int M, N, K, act, accumulate;   // act: 0 none, 1 snake (x + sin^2 x)
+  int kchunk;                     // k range per blockIdx.z (split-K: partial sums meet in C by atomicAdd, C pre-zeroed)
 };
 
 template <bool A_KC, bool B_KC>
@@ -32,50 +34,62 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  for (int k0 = 0; k0 < g.K; k0 += 32) {
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const bool split = gridDim.z > 1;
+  // operand chunk k0 -> registers (the loads of chunk k0 + 32 fly under the MFMAs of chunk k0)
+  float ra[8], rb[8];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       int m, k;
       if (A_KC) { k = tid & 31; m = (tid >> 5) + 8 * r; } else { m = tid & 63; k = (tid >> 6) + 4 * r; }
-      sA[k][m] = (m0 + m < g.M && k0 + k < g.K) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.0f;
+      ra[r] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.0f;
       int n, kb;
       if (B_KC) { kb = tid & 31; n = (tid >> 5) + 8 * r; } else { n = tid & 63; kb = (tid >> 6) + 4 * r; }
-      sB[kb][n] = (n0 + n < g.N && k0 + kb < g.K) ? g.B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.0f;
+      rb[r] = (n0 + n < g.N && k0 + kb < kend) ? g.B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.0f;
     }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int m, k;
+      if (A_KC) { k = tid & 31; m = (tid >> 5) + 8 * r; } else { m = tid & 63; k = (tid >> 6) + 4 * r; }
+      sA[k][m] = ra[r];
+      int n, kb;
+      if (B_KC) { kb = tid & 31; n = (tid >> 5) + 8 * r; } else { n = tid & 63; kb = (tid >> 6) + 4 * r; }
+      sB[kb][n] = rb[r];
+    }
+  };
+  const bool do_rowsum = g.rowsum && blockIdx.x == 0 && tid < 64;
+  float rs = 0.0f;
+  if (kbeg < kend) gload(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    sstore();
     __syncthreads();
+    if (k0 + 32 < kend) gload(k0 + 32);
+    if (do_rowsum) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) rs += sA[k][tid];
+    }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[2 * ks + kh][wm * 32 + l31], sB[2 * ks + kh][wn * 32 + l31], acc, 0, 0, 0);
     __syncthreads();
   }
+  if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
   const int n = n0 + wn * 32 + l31;
   if (n >= g.N) return;
-  const float bv = g.bias ? g.bias[n] : 0.0f;
+  const float bv = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + acc_row(r, kh);
     if (m >= g.M) continue;
     float v = acc[r] + bv;
+    if (split) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
     if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
     if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
     float* c = g.C + (int64_t)m * g.ldc + n;
     *c = g.accumulate ? *c + v : v;
-  }
-}
-
-// db[n] (+)= sum_rows dz[row][n]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, int64_t ld, int64_t B, int N, float* __restrict__ db,
-                                                     int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
-  float s = 0.0f;
-  if (n < N)
-    for (int64_t r = q; r < B; r += 4) s += dz[r * ld + n];
-  red[q][c] = s;
-  __syncthreads();
-  if (q == 0 && n < N) {
-    const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-    db[n] = accumulate ? db[n] + t : t;
   }
 }
 
@@ -142,8 +156,20 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
   if (threadIdx.x == 0) atomicAdd(out, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
 
-static int gemm_launch(const GemmArgs& g, bool a_kc, bool b_kc, hipStream_t s) {
-  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s) {
+  // Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
+  // be 16 workgroups looping 64 chunks each): partial sums by atomicAdd into a zeroed C.  Only for plain linear outputs
+  // written densely (ldc == N), which is what the weight-gradient form produces.
+  const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+  int splits = 1;
+  if (g.act == 0 && !g.Z && g.ldc == g.N && tiles < 128 && g.K >= 256) {
+    splits = min(32, min((g.K + 63) / 64, (512 + tiles - 1) / tiles));
+  }
+  g.kchunk = ((g.K + splits - 1) / splits + 31) / 32 * 32;
+  splits = (g.K + g.kchunk - 1) / g.kchunk;
+  if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
+  if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
+  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)splits);
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, dim3(256), 0, s, g);
@@ -198,9 +224,8 @@ extern "C" int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const floa
   g.B = d_x; g.sbk = ldx; g.sbn = 1;                 // B(k = row, col) = x[row][col]
   g.C = d_dw; g.ldc = in;
   g.M = out; g.N = in; g.K = (int)B; g.act = 0; g.accumulate = accumulate;
+  g.rowsum = d_db;                                   // db[n_out] = sum_rows dz[row][n_out] = row sums of A
   gemm_launch(g, false, false, (hipStream_t)stream);
-  if (d_db)
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((out + 63) / 64)), dim3(256), 0, (hipStream_t)stream, d_dz, lddz, B, out, d_db, accumulate);
   return check_launch("npp_linear_bwd_weight");
 }
 

@@ -248,11 +248,22 @@ class ProposalRanker:
         return float(lp[0]) * self.pw + float(cx) * self.cw, float(lp[0]), float(cx)
 
     def rank(self, candidates, topk=10):
-        """candidates: [(angles (2,), periods (2,), shifts)] -> (sorted distances, order, per-candidate details)."""
+        """candidates: [(angles (2,), periods (2,), shifts)] -> (sorted distances, order, per-candidate details).
+        Under an initialised torch.distributed process group the candidates are sharded over the ranks
+        (parallel.shard_units: independent fits, no data-path collective) and the (score, lpips, cx) rows are
+        all-gathered once at the end; every rank returns the same ranking."""
+        import torch.distributed as dist
+        from .parallel import shard_units, gather_unit_scalars
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
         details = []
-        for angles, periods, *_ in candidates:
+        for ci in mine:
+            angles, periods = candidates[ci][0], candidates[ci][1]
             net = self.fit_candidate(angles, periods)
             details.append(self.score(net))
+        if multi:
+            t = torch.tensor(details, dtype=torch.float32, device=self.device).reshape(-1, 3)
+            details = [tuple(r) for r in gather_unit_scalars(t, len(candidates)).cpu().tolist()]
         d = np.array([x[0] for x in details])
         order = np.argsort(d, kind="stable")[:min(topk, len(d))]
         return d[order], order, details

@@ -34,3 +34,18 @@ def gather_fitted(outputs, stats, group=None):
     dist.all_gather(go, pad_o, group=group)
     dist.all_gather(gs, pad_s, group=group)
     return ([g[:int(c.item())] for g, c in zip(go, counts)], [g[:int(c.item())] for g, c in zip(gs, counts)])
+
+
+def gather_unit_scalars(stats, n_units, group=None):
+    """Per-unit scalars of a job sharded with shard_units(): every rank passes the (n_local, S) rows of ITS units (in
+    unit order) and receives the (n_units, S) table of all units in unit order.  Used for the candidate scores of the
+    proposal ranking (NPP_proposal/search.py:199-215: distances -> topk), one candidate fit per GPU."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    S = stats.shape[1]
+    n_max = (n_units + world - 1) // world
+    pad = stats.new_zeros((n_max, S))
+    pad[:stats.shape[0]] = stats
+    got = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(got, pad, group=group)
+    rows = [got[r][:len(shard_units(n_units, r, world))] for r in range(world)]
+    return torch.cat(rows, 0)
