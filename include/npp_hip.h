@@ -289,10 +289,10 @@ int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, in
  * kernels are not specialised for -- first user: NPP_Net_light of the proposal-ranking fits (models/networks.py:176-263,
  * NPP_proposal/search.py:85-205).  Row-major tensors with explicit leading dimensions (so a layer can write into / read
  * from a column block of a concatenated buffer, networks.py:247 torch.cat); w (out, in) like nn.Linear.
- *  fwd:        y = act(x w^T + b), act 0 none / 1 snake; d_z (nullable) receives the pre-activation
+ *  fwd:        y = act(x w^T + b), act 0 none / 1 snake / 2 relu; d_z (nullable) receives the pre-activation
  *  bwd_data:   dx[:, :in_used] (+)= dz w[:, :in_used]
  *  bwd_weight: dw (+)= dz^T x ; db (+)= column sums of dz (d_db nullable)
- *  act_bwd:    dz = dy * act'(.), act 1 snake from z, 2 sigmoid from its output, 3 tanh from its output
+ *  act_bwd:    dz = dy * act'(.), act 1 snake from z, 2 sigmoid from its output, 3 tanh from its output, 4 relu from z
  *  act_fwd:    y = sigmoid (2) / tanh (3) of x, elementwise (render, models/helpers.py:55-58) */
 int npp_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b, int64_t B, int in,
                    int out, int act, float* d_y, int64_t ldy, float* d_z, int64_t ldz, void* stream);

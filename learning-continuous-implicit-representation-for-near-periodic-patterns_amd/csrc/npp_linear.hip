@@ -88,13 +88,14 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
     if (split) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
     if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
     if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
+    else if (g.act == 2) v = fmaxf(v, 0.0f);                             // F.relu (networks.py:66-67, activation='relu')
     float* c = g.C + (int64_t)m * g.ldc + n;
     *c = g.accumulate ? *c + v : v;
   }
 }
 
 // dz = dy * act'(.) : act 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y));
-// 3 tanh from its output (1 - y^2)
+// 3 tanh from its output (1 - y^2); 4 relu from z ([z > 0])
 __global__ void act_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ zy, int64_t ldzy, int64_t B, int N,
                                int act, float* __restrict__ dz, int64_t lddz) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,7 +103,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const
   const int64_t r = t / N;
   const int n = (int)(t - r * N);
   const float v = zy[r * ldzy + n];
-  const float d = act == 1 ? 1.0f + sinf(2.0f * v) : (act == 2 ? v * (1.0f - v) : (act == 3 ? 1.0f - v * v : 1.0f));
+  const float d = act == 1 ? 1.0f + sinf(2.0f * v) : (act == 2 ? v * (1.0f - v) : (act == 3 ? 1.0f - v * v : (act == 4 ? (v > 0.0f ? 1.0f : 0.0f) : 1.0f)));
   dz[r * lddz + n] = dy[r * lddy + n] * d;
 }
 
@@ -185,7 +186,7 @@ static bool lin_dims_ok(int64_t B, int in, int out) { return B >= 1 && B < (1LL 
 
 extern "C" int npp_linear_fwd(const float* d_x, int64_t ldx, const float* d_w, const float* d_b, int64_t B, int in, int out, int act,
                               float* d_y, int64_t ldy, float* d_z, int64_t ldz, void* stream) {
-  if (!d_x || !d_w || !d_y || !lin_dims_ok(B, in, out) || ldx < in || ldy < out || (d_z && ldz < out) || act < 0 || act > 1) {
+  if (!d_x || !d_w || !d_y || !lin_dims_ok(B, in, out) || ldx < in || ldy < out || (d_z && ldz < out) || act < 0 || act > 2) {
     set_error("npp_linear_fwd: bad argument (B=%lld in=%d out=%d act=%d)", (long long)B, in, out, act);
     return NPP_ERR_ARG;
   }
@@ -231,7 +232,7 @@ extern "C" int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const floa
 
 extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,
                            int64_t lddz, void* stream) {
-  if (!d_dy || !d_zy || !d_dz || B < 1 || n < 1 || lddy < n || ldzy < n || lddz < n || act < 0 || act > 3) {
+  if (!d_dy || !d_zy || !d_dz || B < 1 || n < 1 || lddy < n || ldzy < n || lddz < n || act < 0 || act > 4) {
     set_error("npp_act_bwd: bad argument");
     return NPP_ERR_ARG;
   }

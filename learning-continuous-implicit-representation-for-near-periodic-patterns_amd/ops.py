@@ -372,10 +372,12 @@ def linear_fwd(x, w, b, act, y, z=None):
 
 
 def linear_bwd_data(dz, w, dx, in_used=None, accumulate=False):
+    """dx (+)= dz w.  `w` may be a column slice w_full[:, a:b] of the (out, in) matrix (gradient w.r.t. one block of a
+    concatenated input, networks.py:71,76,85)."""
     B, cout = dz.shape
-    cin = w.shape[1]
-    in_used = cin if in_used is None else in_used
-    assert dx.shape == (B, in_used) and dz.stride(1) == 1 and dx.stride(1) == 1
+    cin = w.stride(0)                                    # leading dimension of the full matrix
+    in_used = w.shape[1] if in_used is None else in_used
+    assert dx.shape == (B, in_used) and dz.stride(1) == 1 and dx.stride(1) == 1 and w.stride(1) == 1
     check(lib().npp_linear_bwd_data(_p(dz), dz.stride(0), _p(w), B, cin, cout, _p(dx), dx.stride(0), in_used, int(bool(accumulate)),
                                     _stream()), "npp_linear_bwd_data")
     return dx

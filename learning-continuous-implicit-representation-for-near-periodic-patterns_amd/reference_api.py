@@ -255,8 +255,25 @@ class _NetBase(nn.Module):
         return _NetFunction.apply(x_periodic, self._blob, self, self.out_act, train)
 
 
+def _fused_config(D, W, skips, activation, *widths):
+    """The fused chain kernels serve D = 8, W = 256, skips = [4], snake and 462-wide proposals; everything else goes to the
+    generic dense-layer path (dense.py)."""
+    return D == 8 and W == NPP_WIDTH and list(skips) == [4] and activation == "snake" and all(w % NPP_E == 0 and w > 0 for w in widths)
+
+
 class NPP_Net(_NetBase):
-    """models/networks.py:8-95 (K > 1: top-1 proposal + auxiliary proposals)."""
+    """models/networks.py:8-95 (K > 1: top-1 proposal + auxiliary proposals).  Configurations outside the fused kernels'
+    specialisation (e.g. the reference's default netwidth 512, activation='relu', other multires) are constructed as
+    dense.DenseNPPNet: same arguments, parameter names and forward, one launch per layer."""
+
+    def __new__(cls, input_ch_periodic, input_ch_periodic_aux, freq_scales, freq_offsets, angle_offsets, D=8, W=256, freq_nerf=3,
+                output_ch=3, skips=[4], activation="relu", device="cuda"):
+        E1, Ea = int(input_ch_periodic) * int(freq_nerf), int(input_ch_periodic_aux) * int(freq_nerf)
+        if cls is NPP_Net and not (_fused_config(D, W, skips, activation, Ea) and E1 == NPP_E and output_ch == 3):
+            from .dense import DenseNPPNet
+            return DenseNPPNet(input_ch_periodic, input_ch_periodic_aux, freq_scales, freq_offsets, angle_offsets, D=D, W=W,
+                               freq_nerf=freq_nerf, output_ch=output_ch, skips=skips, activation=activation, device=device)
+        return super().__new__(cls)
 
     def __init__(self, input_ch_periodic, input_ch_periodic_aux, freq_scales, freq_offsets, angle_offsets, D=8, W=256,
                  freq_nerf=3, output_ch=3, skips=[4], activation="relu", device="cuda"):
@@ -270,7 +287,16 @@ class NPP_Net(_NetBase):
 
 
 class NPP_Net_top1(_NetBase):
-    """models/networks.py:100-173 (K == 1)."""
+    """models/networks.py:100-173 (K == 1); other configurations -> dense.DenseNPPNetTop1 (see NPP_Net)."""
+
+    def __new__(cls, input_ch_periodic, freq_scales, freq_offsets, angle_offsets, D=8, W=256, freq_nerf=3, output_ch=3, skips=[4],
+                activation="relu", device="cuda"):
+        E1 = int(input_ch_periodic) * int(freq_nerf)
+        if cls is NPP_Net_top1 and not (_fused_config(D, W, skips, activation) and E1 == NPP_E and output_ch == 3):
+            from .dense import DenseNPPNetTop1
+            return DenseNPPNetTop1(input_ch_periodic, freq_scales, freq_offsets, angle_offsets, D=D, W=W, freq_nerf=freq_nerf,
+                                   output_ch=output_ch, skips=skips, activation=activation, device=device)
+        return super().__new__(cls)
 
     def __init__(self, input_ch_periodic, freq_scales, freq_offsets, angle_offsets, D=8, W=256, freq_nerf=3, output_ch=3,
                  skips=[4], activation="relu", device="cuda"):

@@ -160,3 +160,70 @@ def test_ranking_prefers_the_true_periodicity(dev):
     d, order, details = ranker.rank(cands, topk=3)
     assert order[0] == 0, (d, order, details)
     assert np.all(np.diff(d) >= 0) and all(np.isfinite(x[0]) for x in details)
+
+
+@pytest.mark.parametrize("tag,K", [("small_k3", 3), ("small_k1", 1)])
+def test_generic_width_net_vs_reference(dev, golden, tag, K):
+    """NPP_Net / NPP_Net_top1 outside the fused kernels' specialisation (here W = 32, multires 2 -> 110-wide proposals) are
+    served by dense.py on the generic dense-layer kernels: forward + every parameter gradient against the reference
+    module's own autograd (g2_mlp.npz small_* cases: the full state_dict and gradients are stored)."""
+    from npp_amd import reference_api as ra
+    g = golden("g2_mlp.npz")
+    W, fn = 32, 5
+    if K > 1:
+        net = ra.NPP_Net(22, 22 * (K - 1), [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=W, freq_nerf=fn, activation="snake", device=dev)
+    else:
+        net = ra.NPP_Net_top1(22, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=W, freq_nerf=fn, activation="snake", device=dev)
+    assert type(net).__name__.startswith("Dense")
+    names = [k[len(tag) + 3:] for k in g.files if k.startswith(f"{tag}_P_")]
+    sd = {n: torch.from_numpy(g[f"{tag}_P_{n}"]) for n in names}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.split(".")[0] in ("alpha_linear", "feature_linear2") for m in missing)
+    emb = torch.from_numpy(g[f"{tag}_emb"]).to(dev)
+    raw = net(None, emb)
+    np.testing.assert_allclose(raw.detach().cpu().numpy(), g[f"{tag}_raw"], rtol=3e-4, atol=3e-5)
+    (raw * torch.from_numpy(g[f"{tag}_draw"]).to(dev)).sum().backward()
+    got = dict(net.named_parameters())
+    for n in names:
+        assert rel_l2(got[n].grad.cpu().numpy(), g[f"{tag}_G_{n}"]) < 3e-4, n
+    assert net.alpha_linear.weight.grad is None                      # constructed, never used (SURVEY.md A.15)
+
+
+def test_default_width_512_relu_trains(dev):
+    """The reference's own defaults (netwidth 512) and its other activation: a few Adam steps through the reference-style
+    loop (create-net, forward, loss.backward(), optimizer.step()) against a plain PyTorch copy of the same module."""
+    from npp_amd import reference_api as ra
+    torch.manual_seed(0)
+    net = ra.NPP_Net(22, 44, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=512, freq_nerf=21, activation="relu", device=dev)
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in net.named_parameters()}
+    x = torch.rand(300, 3 * 462, device=dev) * 2 - 1
+    y = torch.rand(300, 3, device=dev)
+
+    def torch_forward(P, xp):                                         # networks.py:56-95 in plain torch
+        F = torch.nn.functional
+        e0, aux = xp[:, :462], xp[:, 462:]
+        h = e0
+        for i in range(8):
+            h = F.relu(F.linear(h, P[f"periodic_linears.{i}.weight"], P[f"periodic_linears.{i}.bias"]))
+            if i == 4:
+                h = torch.cat([e0, h], -1)
+        f1 = F.linear(h, P["feature_linear1.weight"], P["feature_linear1.bias"])
+        s = F.relu(F.linear(torch.cat([f1, aux], -1), P["scale_linears.0.weight"], P["scale_linears.0.bias"]))
+        f2 = F.linear(s, P["feature_linear2.weight"], P["feature_linear2.bias"])
+        p = F.relu(F.linear(torch.cat([f1, f2], -1), P["pos_linears.0.weight"], P["pos_linears.0.bias"]))
+        return F.linear(p, P["rgb_linear.weight"], P["rgb_linear.bias"])
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        la = ((torch.sigmoid(net(None, x)) - y) ** 2).mean()
+        la.backward()
+        lb = ((torch.sigmoid(torch_forward(ref, x)) - y) ** 2).mean()
+        lb.backward()
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    assert abs(float(la) - float(lb)) < 1e-5
+    for k, p in net.named_parameters():
+        if ref[k].grad is None:
+            assert p.grad is None
+        else:
+            assert rel_l2(p.grad.cpu().numpy(), ref[k].grad.cpu().numpy()) < 2e-3, k
