@@ -338,9 +338,9 @@ def main():
         # wall time per iteration of the complete loop INCLUDING the host-side sampler (not part of `value`, whose inputs
         # are resident before timing): with the reference's exact NumPy stream and with rng_mode='fast'
         e2e = {}
-        for mode in ("reference", "fast"):
+        for mode, pf in (("numpy", 0), ("reference", 4), ("fast", 0)):
             f4 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
-                               N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode)
+                               N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode, prefetch=pf)
             for _ in range(20):
                 f4.step_full()
             torch.cuda.synchronize()
@@ -348,7 +348,9 @@ def main():
             for _ in range(200):
                 f4.step_full()
             torch.cuda.synchronize()
-            e2e[mode] = {"ms_per_iter": (time.perf_counter() - t2) / 200 * 1e3, "psnr_known_dB": f4.psnr()}
+            e2e[{"numpy": "numpy_stream_serial", "reference": "same_stream_native_rng_producer_thread", "fast": "fast_mode"}[mode]] = {
+                "ms_per_iter": (time.perf_counter() - t2) / 200 * 1e3, "psnr_known_dB": f4.psnr()}
+            f4.close()
 
     # ---- one proposal-ranking candidate fit (search.py:85-205: NPP_Net_light, 300 iterations x 2048 rows,
     #      then the LPIPS + contextual score on the pseudo-mask region), wall time incl. host sampling ----

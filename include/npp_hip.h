@@ -308,6 +308,19 @@ int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);
 int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                           float scale, float* d_out, void* stream);
 
+/* ---- host side: the reference's NumPy random stream, GIL-free ----------------------- */
+/* numpy.random.RandomState(seed) restated bit for bit for the three draws of an iteration (models/sampler.py:260,324;
+ * NPP_completion/train.py:172): MT19937 with init_genrand seeding, uniform() from the 53-bit double, and
+ * choice(n, size, replace=False) == permutation(n)[:size] (full Fisher-Yates with the legacy masked-rejection
+ * random_interval).  Host memory only, no GPU; one handle per stream, not thread-safe per handle. */
+void* npp_rng_create(uint32_t seed);
+void npp_rng_destroy(void* rng);
+int npp_rng_seed(void* rng, uint32_t seed);
+int npp_rng_get_state(void* rng, uint32_t* key624, int32_t* pos);      /* == RandomState.get_state()[1:3] */
+int npp_rng_set_state(void* rng, const uint32_t* key624, int32_t pos);
+double npp_rng_uniform(void* rng, double lo, double hi);
+int npp_rng_choice_noreplace(void* rng, int64_t n, int64_t size, int64_t* scratch_n, int64_t* out_size);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 /* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the
  * accumulator-as-next-operand chain) with exact integer data.  d_scratch >= 1 MiB. */

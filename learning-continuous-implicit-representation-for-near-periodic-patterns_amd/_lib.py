@@ -77,6 +77,13 @@ SYMBOLS = {
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
     "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
+    "npp_rng_create": (_vp, [C.c_uint32]),
+    "npp_rng_destroy": (None, [_vp]),
+    "npp_rng_seed": (_i32, [_vp, C.c_uint32]),
+    "npp_rng_get_state": (_i32, [_vp, _vp, C.POINTER(C.c_int32)]),
+    "npp_rng_set_state": (_i32, [_vp, _vp, C.c_int32]),
+    "npp_rng_uniform": (C.c_double, [_vp, C.c_double, C.c_double]),
+    "npp_rng_choice_noreplace": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "npp_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "npp_linear_bwd_data": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "npp_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),

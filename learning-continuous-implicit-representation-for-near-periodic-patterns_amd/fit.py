@@ -22,16 +22,22 @@ class CompletionFit:
                  ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
-                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference"):
+                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
+                 prefetch=0):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
         (np.random.uniform, np.random.choice(replace=False) for the patch centres and the N_rand pixel rows:
         train.py:172, sampler.py:260,324) -- each choice permutes its whole population, 2.7 ms of host time per
-        iteration at 512^2, three times the device time of the iteration.  "fast" draws the same uniform
-        without-replacement samples with np.random.Generator.choice (O(size)): same distribution, different stream."""
-        if rng_mode not in ("reference", "fast"):
-            raise ValueError("rng_mode must be 'reference' or 'fast'")
+        iteration at 512^2, three times the device time of the iteration.  The stream comes from the library's own
+        MT19937 (host_rng.NativeRandomState: bit-identical to np.random.RandomState(seed), GIL-free); "numpy" uses NumPy's
+        generator itself.  "fast" draws the same uniform without-replacement samples with np.random.Generator.choice
+        (O(size)): same distribution, different stream.
+        prefetch: > 0 runs the host half of the sampler (draw_batch) that many iterations ahead on a producer thread --
+        it never reads network state, so the stream and the results are unchanged; with the native generator the draws
+        overlap the training loop instead of preceding it."""
+        if rng_mode not in ("reference", "numpy", "fast"):
+            raise ValueError("rng_mode must be 'reference', 'numpy' or 'fast'")
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
@@ -47,8 +53,14 @@ class CompletionFit:
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
                           ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))
-        self.rng = np.random.RandomState(seed)
+        if rng_mode == "reference":
+            from .host_rng import NativeRandomState
+            self.rng = NativeRandomState(seed)
+        else:
+            self.rng = np.random.RandomState(seed)
         self.fast_rng = np.random.default_rng(seed) if rng_mode == "fast" else None
+        self._prefetch, self._producer, self._queue, self._stop = int(prefetch), None, None, False
+        self._draw_iter = 0                                       # iterations drawn so far (== self.iteration without prefetch)
         self.i_train_dev = torch.from_numpy(self.i_train).to(self.device)
         yy, xx = np.meshgrid(np.arange(self.H, dtype=np.int32), np.arange(self.W, dtype=np.int32), indexing="ij")
         self.i_all_dev = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(self.device)
@@ -75,13 +87,15 @@ class CompletionFit:
             self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
-    def sample_pixels(self):
-        """np.random.choice(n_train, N_rand, replace=False) -> coords (N_rand,2) on device."""
+    def draw_pixels(self):
+        """np.random.choice(n_train, N_rand, replace=False) (train.py:172): host indices."""
         if self.fast_rng is not None:
-            sel = self.fast_rng.choice(self.i_train.shape[0], size=self.N_rand, replace=False)
-        else:
-            sel = self.rng.choice(self.i_train.shape[0], size=[self.N_rand], replace=False)
-        return self.i_train_dev[ops.h2d(sel, self.device)]
+            return self.fast_rng.choice(self.i_train.shape[0], size=self.N_rand, replace=False)
+        return self.rng.choice(self.i_train.shape[0], size=[self.N_rand], replace=False)
+
+    def sample_pixels(self):
+        """-> coords (N_rand,2) on device."""
+        return self.i_train_dev[ops.h2d(self.draw_pixels(), self.device)]
 
     def gather_gt(self, coords):
         return self.masked_img[coords[:, 0].long(), coords[:, 1].long()].contiguous()
@@ -121,13 +135,16 @@ class CompletionFit:
         sampler found no valid real patch: the iteration is skipped BEFORE zero_grad and
         global_step is not advanced (train.py:160-161)."""
         assert self.patch_sampler is not None, "construct CompletionFit with shifts=... for the patch losses"
-        i = self.iteration + 1                                   # trange(start=1, N_iters)
-        if i % self.patch_size_decay == 0 and i != 1 and self.patch_size > 31:          # train.py:137-141
-            self.patch_size //= 2
-            self.patch_num *= 2
-            self.patch_sampler.reset_patchsize(self.masked_img[None], self.mask[None], self.patch_size, self.patch_num)
-            self.patch_sampler.reset_pool(self.i_train, self.i_val)
-        batch = self.sample_batch()
+        if self._prefetch > 0:
+            if self._producer is None:
+                self._start_producer()
+            d = self._queue.get()
+            if isinstance(d, BaseException):
+                raise d
+        else:
+            d = self.draw_batch()
+        self.last_draw = d                                        # host-side record of this iteration's draws (tests, logging)
+        batch = self.materialise_batch(d)
         self.iteration += 1
         if batch is None:
             self.skipped += 1
@@ -135,22 +152,70 @@ class CompletionFit:
         self.step_from(batch)
         return True
 
-    def sample_batch(self):
-        """Host-side sampling of one iteration: sample_patches (train.py:152-157) then the pixel
-        draw (:172), in the reference's RNG order.  None when no valid real patch exists."""
-        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.sample_patches(
-            topk=self.topk, invalid_ratio=self.invalid_ratio)
+    # ---- host half of one iteration's sampling (no device work: may run ahead on the producer thread) -------------
+    def draw_batch(self):
+        """train.py:137-141 (patch-size decay, by iteration index), :152-157 (sample_patches) and :172 (pixel draw), in the
+        reference's RNG order.  One call per loop iteration, including the ones that end up skipped."""
+        self._draw_iter += 1
+        i = self._draw_iter                                       # trange(start=1, N_iters)
+        if i % self.patch_size_decay == 0 and i != 1 and self.patch_size > 31:          # train.py:137-141
+            self.patch_size //= 2
+            self.patch_num *= 2
+            self.patch_sampler.reset_patchsize(None, None, self.patch_size, self.patch_num)
+            self.patch_sampler.reset_pool(self.i_train, self.i_val)
+        d = self.patch_sampler.draw(topk=self.topk, invalid_ratio=self.invalid_ratio)
+        d["n_p"] = self.patch_num
+        if d["k"] > 0:
+            d["pix"] = self.draw_pixels()                         # the reference `continue`s before this draw when k == 0
+        return d
+
+    def materialise_batch(self, d):
+        """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists."""
+        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.materialise(d)
         if k == 0:
             return None
-        pix = self.sample_pixels()
+        pix = self.i_train_dev[ops.h2d(d["pix"], self.device)]
         allc = torch.cat([pix, coords.reshape(-1, 2).to(torch.int32)], 0)
         n = allc.shape[0]
         bp = ops.pad_rows(n)
         if bp != n:
             allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
         return dict(coords=allc.contiguous(), n_pix=pix.shape[0], n=n, bp=bp, gt=self.gather_gt(pix), real=real, rmask=rmask,
-                    fake=fake, fmask=fmask, source=source, k=k, P=self.patch_size, n_p=self.patch_num,
-                    raw=self.patch_sampler.last_raw)
+                    fake=fake, fmask=fmask, source=source, k=k, P=d["P"], n_p=d["n_p"], raw=self.patch_sampler.last_raw)
+
+    def sample_batch(self):
+        """Host-side sampling of one iteration + its device half.  None when no valid real patch exists."""
+        return self.materialise_batch(self.draw_batch())
+
+    def _start_producer(self):
+        import queue
+        import threading
+        self._queue = queue.Queue(maxsize=self._prefetch)
+
+        def run():
+            try:
+                while not self._stop:
+                    d = self.draw_batch()
+                    while not self._stop:
+                        try:
+                            self._queue.put(d, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+            except BaseException as e:                            # surface sampler errors in the training thread
+                self._queue.put(e)
+        self._producer = threading.Thread(target=run, name="npp-sampler", daemon=True)
+        self._producer.start()
+
+    def close(self):
+        """Stop the producer thread (if any)."""
+        self._stop = True
+        if self._producer is not None:
+            self._producer.join(timeout=2.0)
+            self._producer = None
+
+    def __del__(self):
+        self._stop = True
 
     def step_from(self, b):
         """Device side of one iteration (everything after sampling), train.py:183-264, as explicit kernel

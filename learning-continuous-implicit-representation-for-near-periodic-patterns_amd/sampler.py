@@ -70,13 +70,24 @@ class GridPatchSampler:
         known = self.sat[y1, x1] - self.sat[y0, x1] - self.sat[y1, x0] + self.sat[y0, x0]
         return P * P - known
 
-    def _gather(self, cen):
+    def _gather(self, cen, P=None):
         c = ops.h2d(np.rint(cen).astype(np.int32), self.device)
-        return ops.patch_gather(self.img, self.mask, c, 2 * self.patch_size_h_half)
+        return ops.patch_gather(self.img, self.mask, c, P if P is not None else 2 * self.patch_size_h_half)
 
-    # ---- reference API ---------------------------------------------------------------
-    def sample_patch_fake(self, mode):
-        pool = self.pool_train if mode == "train" else self.pool_val
+    # ---- host half: everything that consumes random numbers or walks the lattice (NumPy / native RNG only, no GPU) ----
+    def draw(self, topk, invalid_ratio):
+        """The host-side decisions of one sample_patches() call, in the reference's RNG order (sampler.py:324 uniform,
+        :260 choice): patch source, fake-patch centres, and per fake patch the k best lattice candidates with their 1/d
+        weights.  Returns a dict of NumPy arrays (k == 0: no valid real patch -> the iteration is skipped, train.py:160-161).
+        Touches no device memory, so it can run ahead of the training loop on another thread."""
+        prob = self.rng.uniform(0, 1)
+        if prob < 0.5:
+            source = "val"
+        elif 0.5 < prob < 0.8:
+            source = "train"
+        else:
+            source = "same"
+        pool = self.pool_val if source == "val" else self.pool_train
         if self.fast_rng is not None:
             sel = self.fast_rng.choice(pool.shape[0], size=self.N_samples, replace=False)
         else:
@@ -85,16 +96,16 @@ class GridPatchSampler:
         h = self.patch_size_h_half
         yy = cen[:, 0, None, None] + np.arange(-h, h)[None, :, None]
         xx = cen[:, 1, None, None] + np.arange(-h, h)[None, None, :]
-        grids = np.stack(np.broadcast_arrays(yy, xx), -1)                                   # (n,P,P,2)
-        patch, pmask = self._gather(cen)
-        return patch, pmask, ops.h2d(grids.astype(np.int64), self.device), cen
-
-    def sample_patch_real(self, centres, topk=5, invalid_ratio=0.3):
-        P = 2 * self.patch_size_h_half
+        grids = np.stack(np.broadcast_arrays(yy, xx), -1).astype(np.int64)                  # (n,P,P,2), sampler.py:269-279
+        d = dict(source=source, cen=cen, grids=grids, P=2 * h, n=self.N_samples)
+        if source == "same":
+            d.update(k=1, real_cen=None, weights=np.ones(self.N_samples, np.float32))
+            return d
+        P = 2 * h
         chosen, weights = [], []
         topk_min = topk
         for i in range(self.N_samples):
-            cand = centres[i][None].astype(np.float64) + self._a[:, None] * self.selected_shifts[0][None] \
+            cand = cen[i][None].astype(np.float64) + self._a[:, None] * self.selected_shifts[0][None] \
                 + self._b[:, None] * self.selected_shifts[1][None]
             ok = (cand[:, 0] > 0) & (cand[:, 0] < self.height - 1) & (cand[:, 1] > 0) & (cand[:, 1] < self.width - 1)
             cand, dist = cand[ok], self.permute_distance[ok]
@@ -104,7 +115,8 @@ class GridPatchSampler:
             if min(len(dist) - 1, topk) < topk_min:
                 topk_min = min(len(dist) - 1, topk)
                 if topk_min <= 0:
-                    return None, None, None, 0
+                    d.update(k=0, real_cen=None, weights=None)
+                    return d
             # torch.topk(largest=False): ties are backend-defined; here: stable order
             order = np.argsort(dist, kind="stable")[:topk_min]
             inv = 1.0 / dist[order]
@@ -113,37 +125,35 @@ class GridPatchSampler:
         if topk_min < topk:
             weights = [w[:topk_min] for w in weights]
             chosen = [c[:topk_min] for c in chosen]
-        rgb, m = self._gather(np.concatenate(chosen, 0))
-        n, k = self.N_samples, topk_min
-        self._raw_real = (rgb, m)                                                            # contiguous (n*k,3,P,P), (n*k,1,P,P)
-        rgb = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                              # (n,k,P,P,3)
-        m = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
-        return rgb, m, ops.h2d(np.concatenate(weights), self.device), topk_min
+        d.update(k=topk_min, real_cen=np.concatenate(chosen, 0), weights=np.concatenate(weights))
+        return d
 
+    # ---- device half: crops of exactly the patches that are returned (npp_patch_gather) ----------------------------
+    def materialise(self, d):
+        """-> the reference's 8-tuple (sampler.py:297-354) from a draw(); also sets self.last_raw (contiguous crops for
+        the fused plumbing kernels)."""
+        if d["k"] == 0:
+            return None, None, None, None, None, None, 0, None
+        n, k, P = d["n"], d["k"], d["P"]
+        fake, fmask = self._gather(d["cen"], P)
+        coords = ops.h2d(d["grids"], self.device)
+        if d["source"] == "same":
+            real, rmask = fake.permute(0, 2, 3, 1)[:, None].clone(), fmask.permute(0, 2, 3, 1)[:, None].clone()
+            raw_real = (fake, fmask)
+        else:
+            rgb, m = self._gather(d["real_cen"], P)
+            raw_real = (rgb, m)                                                              # contiguous (n*k,3,P,P), (n*k,1,P,P)
+            real = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                         # (n,k,P,P,3)
+            rmask = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
+        weight = ops.h2d(d["weights"], self.device)
+        self.last_raw = dict(fake=fake, fmask=fmask, real=raw_real[0], rmask=raw_real[1])
+        fake_t = fake[:, None].tile([1, k, 1, 1, 1])
+        fmask_t = fmask[:, None].tile([1, k, 1, 1, 1])
+        self.last_centres = d["cen"]
+        return real, rmask, fake_t, fmask_t, coords, d["source"], k, weight
+
+    # ---- reference API ---------------------------------------------------------------
     def sample_patches(self, topk, invalid_ratio):
         """-> (real_patch (n,k,P,P,3), real_mask (n,k,P,P,1), fake_patch (n,k,3,P,P), fake_mask (n,k,1,P,P),
         fake_coords (n,P,P,2), patch_source, k, weight)   (sampler.py:297-354)"""
-        prob = self.rng.uniform(0, 1)
-        if prob < 0.5:
-            source = "val"
-        elif 0.5 < prob < 0.8:
-            source = "train"
-        else:
-            source = "same"
-        fake, fmask, coords, cen = self.sample_patch_fake("val" if source == "val" else "train")
-        if source == "same":
-            real, rmask = fake.permute(0, 2, 3, 1)[:, None].clone(), fmask.permute(0, 2, 3, 1)[:, None].clone()
-            self._raw_real = (fake, fmask)
-            k = 1
-            weight = torch.ones(self.N_samples, dtype=torch.float32, device=self.device)
-        else:
-            real, rmask, weight, k = self.sample_patch_real(cen, topk=topk, invalid_ratio=invalid_ratio)
-        if k == 0:
-            return None, None, None, None, None, None, 0, None
-        # contiguous channel-first crops for the fused plumbing kernels (npp_patch_compose_*): the untiled fake
-        # patch / mask and the k real patches per fake patch
-        self.last_raw = dict(fake=fake, fmask=fmask, real=self._raw_real[0], rmask=self._raw_real[1])
-        fake = fake[:, None].tile([1, k, 1, 1, 1])
-        fmask = fmask[:, None].tile([1, k, 1, 1, 1])
-        self.last_centres = cen
-        return real, rmask, fake, fmask, coords, source, k, weight
+        return self.materialise(self.draw(topk, invalid_ratio))

@@ -418,6 +418,32 @@ def test_fast_rng_mode_fits_like_reference_mode(dev):
     assert res["fast"] > 28.5 and abs(res["fast"] - res["reference"]) < 0.5
 
 
+def test_native_stream_and_prefetch_reproduce_numpy_sequence(dev):
+    """rng_mode='reference' (the library's MT19937) draws exactly what rng_mode='numpy' (np.random.RandomState) draws, with
+    and without the producer thread: same patch sources, centres, pixel rows, skipped iterations -- the reference's stream
+    (models/sampler.py:260,324; train.py:172)."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    seqs = {}
+    for tag, mode, pf in (("numpy", "numpy", 0), ("native", "reference", 0), ("native+prefetch", "reference", 3)):
+        fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+                            N_rand=4096, shifts=shifts, seed=5, rng_mode=mode, prefetch=pf)
+        seq = []
+        for it in range(25):
+            ok = fit.step_full()
+            d = fit.last_draw
+            seq.append((ok, d["source"], d["k"], d["cen"].tolist(), None if d["real_cen"] is None else d["real_cen"].tolist(),
+                        d["pix"].tolist() if ok else None))
+        seqs[tag] = (seq, fit.net.params.cpu().numpy().copy())
+        fit.close()
+    for tag in ("native", "native+prefetch"):
+        assert seqs[tag][0] == seqs["numpy"][0]                                # every draw of every iteration, exactly
+        # same draws -> same fit (not bit-identical: the contextual-loss kernels reduce with float atomics)
+        assert rel_l2(seqs[tag][1], seqs["numpy"][1]) < 2e-2
+
+
 def test_training_step_is_bit_reproducible(dev):
     """No atomics on the gradient path: split-K slabs + a fixed summation order make two runs of
     the same step produce identical bits (weights after 3 optimiser steps)."""
