@@ -37,7 +37,9 @@ def parse(argv=None):
     ap.add_argument("--i_print", type=int, default=500)
     ap.add_argument("--invalid_as_unknown", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--rng_mode", default="reference", choices=["reference", "fast"])
+    ap.add_argument("--rng_mode", default="reference", choices=["reference", "numpy", "fast"],
+                    help="reference: NumPy's stream from the native generator; numpy: NumPy itself; fast: O(size) draws, other stream")
+    ap.add_argument("--prefetch", type=int, default=4, help="iterations of sampler draws prepared ahead on a producer thread")
     ap.add_argument("--vgg19", default=None, help="torchvision vgg19 state_dict (.pth) for the contextual loss trunk")
     ap.add_argument("--vgg16", default=None, help="torchvision vgg16 state_dict (.pth) for the LPIPS trunk")
     ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth (the five 1x1 lin layers)")
@@ -87,7 +89,8 @@ def main(argv=None):
                         shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
                         num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
                         patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
-                        vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, ksplit=12)
+                        vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
+                        ksplit=12)
     name = os.path.basename(os.path.normpath(args.datadir))
     outroot = os.path.join(args.basedir, f"{args.expname}_top{args.p_topk}", name)
     t0 = time.time()

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Golden G8: the REFERENCE's own optimisation trajectory -- its modules driven exactly like the loop body of
+NPP_completion/train.py:164-263 (pixel-loss part: np.random.choice of N_rand known pixels, table gather, render = sigmoid(
+NPP_Net_top1(None, emb)), zero_grad, img2mse('robust_loss_adaptive', adaptive_pix), backward, Adam over net + adaptive
+latents, LR rule set after the step, global_step += 1) on the synthetic 256^2 lattice image, PyTorch CPU fp32, anomaly
+detection off.  Stores the PSNR over known / unknown pixels at a few checkpoints plus what is needed to start from the same
+point (freqs; the weights are torch.manual_seed(0) default init in the reference's construction order = tests/refinit.py).
+Takes ~1 min on 8 cores.      python tests/golden/make_golden_fit.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_OFFSETS, _net  # noqa: E402
+import oracle  # noqa: E402  (only for the synthetic image / periodicity definition)
+
+
+def main():
+    R = import_reference()
+    emb, msec = R["emb"], R["msec"]
+    H, K, N_rand, n_iters = 256, 1, 8192, 300
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, _ = oracle.synthetic_periodicity(H, K)
+    masked = img * mask
+    i_train = np.stack(np.nonzero(mask[..., 0]), 1)
+    i_all = np.stack(np.meshgrid(np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 2)
+    torch.manual_seed(0)
+    embedder, freq_nerf = emb.get_embedder(10, 0, (H, H))                       # draws freqs from the seed-0 generator
+    freqs = np.array([float(fn.__defaults__[1]) for fn in embedder.embed_fns[1::2]], np.float32)
+    ep, _ = emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[0]), selected_periods=torch.Tensor(periods[0]),
+                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)
+    torch.manual_seed(0)                                                         # weights: seed-0 default init (tests/refinit.py)
+    net = _net(R, K, 256, int(freq_nerf))
+    adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
+    opt = torch.optim.Adam(list(net.parameters()) + list(adaptive.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    with torch.no_grad():
+        tab_train = embedder.embed(ep.embed(torch.Tensor(i_train)))              # train.py:93-105 tables
+        tab_all = embedder.embed(ep.embed(torch.Tensor(i_all)))
+    masked_t, img_t, mask_t = torch.Tensor(masked), torch.Tensor(img), torch.Tensor(mask)
+
+    def psnr():
+        with torch.no_grad():
+            pred = torch.cat([torch.sigmoid(net(None, tab_all[j:j + 20000])) for j in range(0, tab_all.shape[0], 20000)]).reshape(H, H, 3)
+        out = []
+        for m in (mask_t, 1 - mask_t):
+            mse = (((pred - img_t) ** 2) * m).sum() / (m.sum() * 3)
+            out.append(float(-10 * torch.log10(mse)))
+        return out
+    np.random.seed(0)
+    checkpoints = [1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300]
+    traj, global_step, t0 = [], 0, time.time()
+    for i in range(1, n_iters + 1):
+        sel = np.random.choice(i_train.shape[0], size=[N_rand], replace=False)   # train.py:172
+        c = i_train[sel]
+        gt = masked_t[c[:, 0], c[:, 1], :]
+        pred = torch.sigmoid(net(None, tab_train[sel]))                          # render, helpers.py:41-62
+        opt.zero_grad()
+        loss = msec.img2mse(pred, gt, "robust_loss_adaptive", adaptive, torch.ones_like(gt[:, :1]))   # train.py:176,195
+        loss.backward()
+        opt.step()
+        new_lr = 5e-4 * (0.1 ** (global_step / (500 * 100)))                     # train.py:256-262
+        for g in opt.param_groups:
+            g["lr"] = new_lr
+        global_step += 1
+        if i in checkpoints:
+            traj.append([i] + psnr() + [float(loss)])
+            print(traj[-1], f"{time.time() - t0:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g8_fit.npz"), traj=np.array(traj, np.float64), freqs=freqs, H=np.int64(H), N_rand=np.int64(N_rand),
+                        latent_alpha=adaptive.latent_alpha.detach().numpy(), latent_scale=adaptive.latent_scale.detach().numpy())
+
+
+if __name__ == "__main__":
+    main()
