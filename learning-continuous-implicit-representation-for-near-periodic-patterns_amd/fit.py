@@ -23,7 +23,7 @@ class CompletionFit:
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
-                 prefetch=0):
+                 prefetch=0, use_perceptual_loss=True):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
@@ -73,6 +73,7 @@ class CompletionFit:
             self.patch_num = int(patch_num)
             self.topk, self.invalid_ratio = int(num_real_patch_per_sample), float(invalid_ratio)
             self.cx_w, self.lp_w, self.use_comp = float(contextual_weight), float(perceptual_weight), bool(use_comp)
+            self.use_perceptual_loss = bool(use_perceptual_loss)             # options/arg_config.py use_perceptual_loss
             self.patch_size_decay = int(patch_size_decay)
             self.patch_sampler = GridPatchSampler(
                 img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
@@ -248,7 +249,7 @@ class CompletionFit:
         xy = ops.patch_compose_fwd(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, self._xy)
         self.patch_loss_buf.zero_()
         dx_b = None
-        if source == "same":                                                                        # train.py:241-250
+        if source == "same" and self.use_perceptual_loss:                                           # train.py:241-250
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
                 dx_b = self.percepLoss.fused(xy, nk, self.lp_w, self.patch_loss_buf, normalize=True)
@@ -282,7 +283,7 @@ class CompletionFit:
         fk, fm = b["fake"].reshape(-1, 3, P, P), b["fmask"].reshape(-1, 1, P, P)
         x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
         loss_patch = self.contextualLoss(x_in, real_p * rm, None) * self.cx_w
-        if source == "same":
+        if source == "same" and self.use_perceptual_loss:
             loss_patch = loss_patch + self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True) * self.lp_w
         loss_patch.backward()
         ws["dpred"][n_pix:n].copy_(pp_leaf.grad)

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Golden G8b: the reference's COMPLETE loop body -- models.sampler.GridPatchSampler, the table gathers,
+NPP_Net_top1, img2mse(robust_loss_adaptive), the patch plumbing of NPP_completion/train.py:200-236 and
+contextual_loss.functional.contextual_loss on VGG19[0:18]-shaped features, Adam + LR rule -- driven on the synthetic 256^2
+image (PyTorch CPU fp32, NumPy seed 0).  Differences to a stock run, both forced by what is absent offline: the trunk is a
+VGG19[0:18]-shaped torch stack with a fixed-seed init (the build's losses._Trunk: torchvision's pretrained weights are not
+available) and the LPIPS term of 'same' iterations is left out (its trunk needs them too).
+Stores PSNR checkpoints + the patch-source / k sequence.      python tests/golden/make_golden_fit_patch.py   (~2 min)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_OFFSETS, _net  # noqa: E402
+import oracle  # noqa: E402
+
+
+def main():
+    R = import_reference()
+    emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
+    from npp_amd.losses import _Trunk, _VGG19                                   # the VGG19[0:18]-shaped stand-in, seed 1234
+    H, N_rand, n_iters, P, n_p, topk = 256, 8192, 100, 64, 2, 3
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    masked = img * mask
+    i_train = np.stack(np.nonzero(mask[..., 0]), 1)
+    i_val = np.stack(np.nonzero(1 - mask[..., 0]), 1)
+    i_all = np.stack(np.meshgrid(np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 2)
+    torch.manual_seed(0)
+    embedder, freq_nerf = emb.get_embedder(10, 0, (H, H))
+    freqs = np.array([float(fn.__defaults__[1]) for fn in embedder.embed_fns[1::2]], np.float32)
+    ep, _ = emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[0]), selected_periods=torch.Tensor(periods[0]),
+                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)
+    torch.manual_seed(0)
+    net = _net(R, 1, 256, int(freq_nerf))
+    adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
+    opt = torch.optim.Adam(list(net.parameters()) + list(adaptive.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    vgg = _Trunk(_VGG19, taps=(17,))
+    mean = torch.tensor([0.485, 0.456, 0.406]).reshape(3, 1, 1)                  # contextual.py:41-46
+    std = torch.tensor([0.229, 0.224, 0.225]).reshape(3, 1, 1)
+    with torch.no_grad():
+        tab_train = embedder.embed(ep.embed(torch.Tensor(i_train)))
+        tab_all = embedder.embed(ep.embed(torch.Tensor(i_all))).reshape(H, H, -1)   # train.py:103-105 i_all table
+    masked_t, img_t, mask_t = torch.Tensor(masked), torch.Tensor(img), torch.Tensor(mask)
+    np.random.seed(0)
+    S = R["sampler"].GridPatchSampler(img=masked_t[None], mask=mask_t[None], N_samples=n_p, patch_size=P, height=H, width=H,
+                                      pool_train=torch.Tensor(i_train), pool_val=torch.Tensor(i_val), selected_shifts=shifts,
+                                      no_reg_sampling=False)
+
+    def psnr():
+        with torch.no_grad():
+            flat = tab_all.reshape(H * H, -1)
+            pred = torch.cat([torch.sigmoid(net(None, flat[j:j + 20000])) for j in range(0, H * H, 20000)]).reshape(H, H, 3)
+        return [float(-10 * torch.log10((((pred - img_t) ** 2) * m).sum() / (m.sum() * 3))) for m in (mask_t, 1 - mask_t)]
+    checkpoints = [10, 25, 50, 75, 100]
+    traj, seq, global_step, t0 = [], [], 0, time.time()
+    for i in range(1, n_iters + 1):
+        real, rmask, fake, fmask, coords, source, k, weight = S.sample_patches(topk=topk, invalid_ratio=0.3)   # train.py:152-157
+        seq.append(({"val": 0, "train": 1, "same": 2, None: -1}[source], k))
+        if k == 0:
+            continue                                                              # :160-161
+        coords = coords.reshape(-1, 2)
+        emb_patch = tab_all[coords[:, 0], coords[:, 1], :]                        # :166-167
+        sel = np.random.choice(i_train.shape[0], size=[N_rand], replace=False)    # :172
+        c = i_train[sel]
+        gt = masked_t[c[:, 0], c[:, 1], :]
+        pred = torch.sigmoid(net(None, torch.cat([tab_train[sel], emb_patch])))  # :181,189
+        opt.zero_grad()
+        loss = msec.img2mse(pred[:N_rand], gt, "robust_loss_adaptive", adaptive, torch.ones_like(gt[:, :1]))   # :195
+        pp = pred[N_rand:].reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1))                 # :201-203
+        real_p = real.reshape(-1, k, 3).reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3)                           # :206-208
+        rm = rmask.permute(0, 1, 4, 2, 3).reshape(-1, 1, P, P)                                                    # :213-214
+        pp, real_p = pp.reshape(-1, 3, P, P), real_p.reshape(-1, 3, P, P)
+        fk, fm = fake.reshape(-1, 3, P, P), fmask.reshape(-1, 1, P, P)
+        x_in = (fk * fm + pp * (1 - fm)) * rm if source == "val" else pp * rm                                    # :228-236 (use_comp)
+        y_in = real_p * rm
+        fx = vgg((x_in - mean) / std)[0]                                                                          # contextual.py:56-64
+        with torch.no_grad():
+            fy = vgg((y_in - mean) / std)[0]
+        loss = loss + cxf.contextual_loss(fx, fy, 0.5, None) * 0.001                                              # :238-239, weight 1e-3
+        loss.backward()
+        opt.step()
+        new_lr = 5e-4 * (0.1 ** (global_step / (500 * 100)))
+        for g in opt.param_groups:
+            g["lr"] = new_lr
+        global_step += 1
+        if i in checkpoints:
+            traj.append([i] + psnr())
+            print(traj[-1], seq[-1], f"{time.time() - t0:.0f}s", flush=True)
+    np.savez_compressed(os.path.join(OUT, "g8b_fit_patch.npz"), traj=np.array(traj, np.float64), seq=np.array(seq, np.int64), freqs=freqs,
+                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step))
+
+
+if __name__ == "__main__":
+    main()

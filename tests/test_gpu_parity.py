@@ -449,6 +449,37 @@ def test_fit_trajectory_vs_reference_g8(dev, golden):
                                atol=3e-3)                                   # the adaptive-loss latents end in the same place
 
 
+def test_full_loop_trajectory_vs_reference_g8b(dev, golden):
+    """The complete loop body against the reference's own modules (g8b_fit_patch.npz: models.sampler.GridPatchSampler +
+    table gathers + NPP_Net_top1 + img2mse + the patch plumbing of train.py:200-236 + contextual_loss on a VGG19[0:18]-shaped
+    trunk with the same fixed-seed weights, LPIPS term off on both sides): same weights, frequencies and NumPy stream.
+    The patch-source / k sequence must be identical; PSNR checkpoints within 0.1 dB (the trunk runs in fp16/bf16 here and
+    torch.topk's tie order among equidistant lattice candidates is backend-defined)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8b_fit_patch.npz")
+    H, N_rand = int(g["H"]), int(g["N_rand"])
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(1), device=dev, N_rand=N_rand, seed=0, ksplit=4,
+                        shifts=shifts, rng_mode="reference", use_perceptual_loss=False)
+    assert fit.patch_size == 64 and fit.patch_num == 2
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    code = {"val": 0, "train": 1, "same": 2}
+    for i in range(1, 101):
+        ok = fit.step_full()
+        d = fit.last_draw
+        assert (code[d["source"]], d["k"]) == tuple(int(v) for v in g["seq"][i - 1]), i      # the sampler's decisions, call by call
+        assert ok == (d["k"] > 0)
+        if i in traj:
+            pk, pu = fit.psnr("known"), fit.psnr("unknown")
+            assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i])
+    assert fit.net.global_step == int(g["global_step"])
+
+
 def test_native_stream_and_prefetch_reproduce_numpy_sequence(dev):
     """rng_mode='reference' (the library's MT19937) draws exactly what rng_mode='numpy' (np.random.RandomState) draws, with
     and without the producer thread: same patch sources, centres, pixel rows, skipped iterations -- the reference's stream
