@@ -308,6 +308,13 @@ int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);
 int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                           float scale, float* d_out, void* stream);
 
+/* ---- brute-force displacement search ------------------------------------- */
+/* compute_loss of NPP_proposal/feature_searching.py:208-264: act (C, h, w) fp32 feature map whose LAST channel is excluded
+ * from the sum (:247,250), mask (h, w) 1 = known, shifts (n, 2) int32 (dx, dy).  losses[s] = sum over positions of
+ * mask * shifted mask * sum_c f(shifted act, act), f = -a*b when edge_searching else (a-b)^2; zero outside the map. */
+int npp_shift_search(const float* d_act_chw, const float* d_mask_hw, int C, int h, int w,
+                     const int32_t* d_shifts_xy, int n, int edge_searching, float* d_losses, void* stream);
+
 /* ---- host side: the reference's NumPy random stream, GIL-free ----------------------- */
 /* numpy.random.RandomState(seed) restated bit for bit for the three draws of an iteration (models/sampler.py:260,324;
  * NPP_completion/train.py:172): MT19937 with init_genrand seeding, uniform() from the 53-bit double, and

@@ -77,6 +77,7 @@ SYMBOLS = {
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
     "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
+    "npp_shift_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "npp_rng_create": (_vp, [C.c_uint32]),
     "npp_rng_destroy": (None, [_vp]),
     "npp_rng_seed": (_i32, [_vp, C.c_uint32]),

@@ -15,3 +15,4 @@ reference loads torchvision pretrained weights that are not under
 from .npp_oracle import *  # noqa: F401,F403
 from .npp_patch_oracle import *  # noqa: F401,F403
 from .npp_light_oracle import *  # noqa: F401,F403
+from .npp_search_oracle import *  # noqa: F401,F403

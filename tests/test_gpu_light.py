@@ -227,3 +227,32 @@ def test_default_width_512_relu_trains(dev):
             assert p.grad is None
         else:
             assert rel_l2(p.grad.cpu().numpy(), ref[k].grad.cpu().numpy()) < 2e-3, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_shift_search_vs_reference(dev, golden, tag):
+    """npp_shift_search + the host half of the periodicity search (proposal.py) against the reference's own compute_loss /
+    generate_possible_shifts / generate_periodicity / feature_search (g11_search.npz)."""
+    from npp_amd import proposal
+    g = golden("g11_search.npz")
+    act = torch.from_numpy(g[f"{tag}_act"]).to(dev)
+    mask = torch.from_numpy(g[f"{tag}_mask"]).to(dev)
+    rr = [int(v) for v in g[f"{tag}_rr"]]
+    for i in range(rr[0], rr[1], rr[2]):
+        r = (i, i + rr[2])
+        sh = proposal.generate_possible_shifts(act.shape[1:], r, r)
+        assert np.array_equal(sh, g[f"{tag}_shifts_{i}"])
+        for edge in (1, 0):
+            L = proposal.compute_loss(act, mask, sh, bool(edge)).cpu().numpy()
+            np.testing.assert_allclose(L, g[f"{tag}_loss_{i}_{edge}"], rtol=3e-5, atol=3e-4)
+    cands = proposal.feature_search(act, mask, rr, True)
+    np.testing.assert_allclose(np.array([c[0] for c in cands]), g[f"{tag}_fs_angles"], atol=1e-3)
+    np.testing.assert_allclose(np.array([c[1] for c in cands]), g[f"{tag}_fs_periods"], rtol=1e-5)
+    np.testing.assert_array_equal(np.array([c[2] for c in cands]), g[f"{tag}_fs_shifts"])
+    # full-scale shape: AlexNet-conv1-like map, thousands of displacements
+    big = torch.rand(65, 64, 80, device=dev)
+    bm = (torch.rand(64, 80, device=dev) > 0.2).float()
+    sh = proposal.generate_possible_shifts((64, 80), (2, 7), (2, 7))
+    Lb = proposal.compute_loss(big, bm, sh, True).cpu().numpy()
+    want = oracle.shift_losses(big.cpu().numpy(), bm.cpu().numpy(), sh[::97], True)
+    np.testing.assert_allclose(Lb[::97], want, rtol=1e-4)
