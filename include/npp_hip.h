@@ -277,9 +277,10 @@ int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, in
                      int n_run, int H, int W, int C, void* d_dz, void* stream);
 
 /* Tap gradient (n_run, C, H, W) fp32 -> flat (bf16, or fp16 when as_f16), gated by [y > 0]
- * when the fp16 activation tensor d_y is given.  Also the generic fp32 -> flat importer. */
+ * when the fp16 activation tensor d_y is given; accumulate != 0 adds it onto the gradient already in d_dz
+ * (a tap on a tensor that also feeds the next layer).  Also the generic fp32 -> flat importer. */
 int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C,
-                      int H, int W, void* d_dz, int as_f16, void* stream);
+                      int H, int W, void* d_dz, int as_f16, int accumulate, void* stream);
 /* flat (fp16 activations when is_f16, else bf16 gradients) -> (n_run, C, H, W) fp32 */
 int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W,
                      float* d_out_nchw, int is_f16, void* stream);
@@ -307,6 +308,18 @@ int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);
  * candidate score of NPP_proposal/search.py:193): d_out[0] += scale * sum_n mean_pos sum_c lin_c (f0n - f1n)^2. */
 int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                           float scale, float* d_out, void* stream);
+
+/* ---- remapping variant: Gram-matrix style loss (models/style_loss.py:37-74) ----------------- */
+/* G[n] = F[n] F[n]^T for (N, C, hw) features and its backward dF[n] = (dG[n] + dG[n]^T) F[n]; the per-element adaptive
+ * robust NLL of a - b over (N, D) with D latent pairs (AdaptiveLossFunction(num_dims = C^2), style_loss.py:23-27,60-69):
+ * d_loss[0] += sum_n coef_n[n] sum_j nll(a - b)[n][j]; d_diff (N, D) scratch; d_ddiff / d_dlatent (nullable together):
+ * coef_n dnll/dx and the accumulated latent gradients.  coef_n is a HOST array of N <= 64 factors. */
+int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, void* stream);
+int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream);
+int64_t npp_robust_elem_workspace_bytes(int D);
+int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const float* d_latents,
+                    const float* d_spline, int n_knots, float x_scale, const float* coef_n, float* d_loss,
+                    float* d_diff, float* d_ddiff, float* d_dlatent, void* d_workspace, void* stream);
 
 /* ---- brute-force displacement search ------------------------------------- */
 /* compute_loss of NPP_proposal/feature_searching.py:208-264: act (C, h, w) fp32 feature map whose LAST channel is excluded

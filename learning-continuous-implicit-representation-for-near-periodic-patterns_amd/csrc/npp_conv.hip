@@ -352,7 +352,7 @@ __global__ void maxpool2_bwd_kernel(const bf16x8* __restrict__ dy, const f16x8* 
 // ---- tap gradient in: df (Ng,C,H,W) fp32 -> flat bf16; gated by [y > 0] when y is given ------------
 template <bool F16OUT>
 __global__ void trunk_grad_in_kernel(const float* __restrict__ df, const f16x8* __restrict__ yact, int Ng, int C, int H,
-                                     int W, int64_t nposp, int64_t npos_range, void* __restrict__ dz_) {
+                                     int W, int64_t nposp, int64_t npos_range, void* __restrict__ dz_, int accumulate) {
   typedef typename OpT<F16OUT>::frag frag_t;
   typedef typename OpT<F16OUT>::elem elem_t;
   frag_t* dz = (frag_t*)dz_;
@@ -376,6 +376,13 @@ __global__ void trunk_grad_in_kernel(const float* __restrict__ df, const f16x8* 
       const float v = df[(((int64_t)n * C + c) * H + (y - 1)) * W + (x - 1)];
       o[j] = (elem_t)((!yact || (float)m[j] > 0.0f) ? v : 0.0f);
     }
+    if (accumulate) {                                   // tap gradient added onto a gradient that is already there
+      const frag_t old = dz[u];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (elem_t)((float)o[j] + (float)old[j]);
+    }
+  } else if (accumulate) {
+    return;                                             // borders / other images: leave what is there
   }
   dz[u] = o;
 }
@@ -572,7 +579,7 @@ extern "C" int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d
 }
 
 extern "C" int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W,
-                                 void* d_dz, int as_f16, void* stream) {
+                                 void* d_dz, int as_f16, int accumulate, void* stream) {
   int rc = conv_geom_check(N_total, H, W, "npp_trunk_grad_in");
   if (rc) return rc;
   if (!d_df_nchw || !d_dz || C % 16 || n_run < 1 || n_run > N_total) { set_error("npp_trunk_grad_in: bad argument"); return NPP_ERR_ARG; }
@@ -581,10 +588,10 @@ extern "C" int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_
   const int64_t n = range * (C / 8);
   if (as_f16)
     hipLaunchKernelGGL(trunk_grad_in_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
-                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz);
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate);
   else
     hipLaunchKernelGGL(trunk_grad_in_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
-                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz);
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate);
   return check_launch("npp_trunk_grad_in");
 }
 

@@ -23,6 +23,8 @@ struct GemmArgs {
   float* rowsum;                  // optional: rowsum[m] += sum_k A(m,k) (the bias gradient of the weight-gradient form)
   int M, N, K, act, accumulate;   // act: 0 none, 1 snake (x + sin^2 x)
   int kchunk;                     // k range per blockIdx.z (split-K: partial sums meet in C by atomicAdd, C pre-zeroed)
+  int nbatch;                     // > 1: blockIdx.z is a batch index (no split-K); element strides between batches:
+  int64_t sab, sbb, scb;
 };
 
 template <bool A_KC, bool B_KC>
@@ -34,8 +36,10 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const bool split = gridDim.z > 1;
+  const bool batched = g.nbatch > 1;
+  if (batched) { g.A += (int64_t)blockIdx.z * g.sab; g.B += (int64_t)blockIdx.z * g.sbb; g.C += (int64_t)blockIdx.z * g.scb; }
+  const int kbeg = batched ? 0 : blockIdx.z * g.kchunk, kend = batched ? g.K : min(g.K, kbeg + g.kchunk);
+  const bool split = !batched && gridDim.z > 1;
   // operand chunk k0 -> registers (the loads of chunk k0 + 32 fly under the MFMAs of chunk k0)
   float ra[8], rb[8];
   auto gload = [&](int k0) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
   if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
   const int n = n0 + wn * 32 + l31;
   if (n >= g.N) return;
-  const float bv = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+  const float bv = (g.bias && (batched || blockIdx.z == 0)) ? g.bias[n] : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + acc_row(r, kh);
@@ -157,11 +161,67 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
   if (threadIdx.x == 0) atomicAdd(out, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
 
+// Per-element adaptive robust NLL (robust_loss_pytorch/adaptive.py:183-204 with num_dims = D latents): one thread per
+// element index j walks the N samples -- models/style_loss.py:60-69 applies it to the N x C^2 differences of two Gram
+// matrices.  loss += sum_n coef_n sum_j nll(d[n][j]); dd[n][j] = coef_n dnll/dx; dlatent[j] / [D + j] += the latent gradients.
+__global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restrict__ d, int N, int D, const ChanParams* __restrict__ cp,
+                                                          const float* __restrict__ coef_n, float* __restrict__ loss,
+                                                          float* __restrict__ dd, float* __restrict__ dlatent) {
+  __shared__ float tot[4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  float val = 0.0f;
+  if (j < D) {
+    const ChanParams P = cp[j];
+    float ga = 0.0f, gc = 0.0f;
+    for (int n = 0; n < N; ++n) {
+      const float x = d[(int64_t)n * D + j], cf = coef_n[n];
+      const float xs = x / P.c, ssx = xs * xs;
+      const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
+      const float ue = expf(e * lnu), ue1 = ue / uu;
+      val = fmaf(cf, (P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz, val);
+      if (dd) {
+        dd[(int64_t)n * D + j] = cf * (x / (P.c * P.c)) * ue1;
+        ga = fmaf(cf, -(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) + (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz, ga);
+        gc = fmaf(cf, -(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c, gc);
+      }
+    }
+    if (dlatent) {
+      dlatent[j] += ga * P.dalpha_dl;
+      dlatent[D + j] += gc * P.dc_dl;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+  if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, tot[0] + tot[1] + tot[2] + tot[3]);
+}
+
+__global__ void elem_chan_kernel(const float* __restrict__ latents, int D, const float* __restrict__ spline, int n_knots, float x_scale,
+                                 ChanParams* __restrict__ cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < D) cp[c] = chan_params(latents[c], latents[D + c], spline, n_knots, x_scale);
+}
+
+// c = a - b elementwise
+__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ c) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) c[t] = a[t] - b[t];
+}
+
 static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s) {
   // Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
   // be 16 workgroups looping 64 chunks each): partial sums by atomicAdd into a zeroed C.  Only for plain linear outputs
   // written densely (ldc == N), which is what the weight-gradient form produces.
   const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+  if (g.nbatch > 1) {
+    g.kchunk = g.K;
+    const dim3 gridb((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)g.nbatch);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), gridb, dim3(256), 0, s, g);
+    else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), gridb, dim3(256), 0, s, g);
+    else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), gridb, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm32_kernel<false, false>), gridb, dim3(256), 0, s, g);
+    return NPP_OK;
+  }
   int splits = 1;
   if (g.act == 0 && !g.Z && g.ldc == g.N && tiles < 128 && g.K >= 256) {
     splits = min(32, min((g.K + 63) / 64, (512 + tiles - 1) / tiles));
@@ -259,3 +319,54 @@ extern "C" int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N
                      hw, d_lin, scale / (float)hw, d_out);
   return check_launch("npp_lpips_plain_layer");
 }
+
+/* Gram matrices G[n] = F[n] F[n]^T of (N, C, hw) features (models/style_loss.py:55-58), and the backward
+ * dF[n] = (dG[n] + dG[n]^T) F[n]. */
+extern "C" int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, void* stream) {
+  if (!d_f || !d_g || N < 1 || C < 1 || hw < 1) { set_error("npp_gram_fwd: bad argument"); return NPP_ERR_ARG; }
+  GemmArgs g{};
+  g.A = d_f; g.sam = hw; g.sak = 1;                  // A(m = c, k = pos)
+  g.B = d_f; g.sbk = 1; g.sbn = hw;                  // B(k = pos, n = c') = F[c'][pos]
+  g.C = d_g; g.ldc = C;
+  g.M = C; g.N = C; g.K = hw; g.nbatch = N; g.sab = g.sbb = (int64_t)C * hw; g.scb = (int64_t)C * C;
+  gemm_launch(g, true, true, (hipStream_t)stream);
+  return check_launch("npp_gram_fwd");
+}
+
+extern "C" int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream) {
+  if (!d_dg || !d_f || !d_df || N < 1 || C < 1 || hw < 1) { set_error("npp_gram_bwd: bad argument"); return NPP_ERR_ARG; }
+  GemmArgs g{};
+  g.B = d_f; g.sbk = hw; g.sbn = 1;                  // B(k = c', n = pos)
+  g.C = d_df; g.ldc = hw;
+  g.M = C; g.N = hw; g.K = C; g.nbatch = N; g.sab = (int64_t)C * C; g.sbb = g.scb = (int64_t)C * hw;
+  g.A = d_dg; g.sam = C; g.sak = 1;                  // dG F
+  gemm_launch(g, true, false, (hipStream_t)stream);
+  g.sam = 1; g.sak = C; g.accumulate = 1;            // + dG^T F
+  if (N == 1) g.nbatch = 1;
+  gemm_launch(g, false, false, (hipStream_t)stream);
+  return check_launch("npp_gram_bwd");
+}
+
+/* diff = a - b, then the per-element adaptive robust NLL over (N, D) with D latent pairs [alpha(D) | scale(D)]:
+ * d_loss[0] += sum_n coef_n sum_j nll ; d_ddiff (N, D) = coef_n dnll/dx ; d_dlatent [2 D] += latent gradients (both nullable
+ * together).  d_coef_n: N per-sample factors (host array).  d_workspace: npp_lpips_workspace_bytes(D) bytes + N floats. */
+extern "C" int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const float* d_latents, const float* d_spline,
+                               int n_knots, float x_scale, const float* coef_n, float* d_loss, float* d_diff, float* d_ddiff,
+                               float* d_dlatent, void* d_workspace, void* stream) {
+  if (!d_a || !d_b || !d_latents || !d_spline || !coef_n || !d_loss || !d_diff || !d_workspace || N < 1 || N > 64 || D < 1 || n_knots < 2 ||
+      ((d_ddiff == nullptr) != (d_dlatent == nullptr))) {
+    set_error("npp_robust_elem: bad argument (N=%d D=%d; N <= 64)", N, D);
+    return NPP_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ChanParams* cp = (ChanParams*)d_workspace;
+  float* d_coef = (float*)((char*)d_workspace + (size_t)D * sizeof(ChanParams));
+  (void)hipMemcpyAsync(d_coef, coef_n, sizeof(float) * N, hipMemcpyHostToDevice, s);
+  const int64_t n = (int64_t)N * D;
+  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_a, d_b, n, d_diff);
+  hipLaunchKernelGGL(elem_chan_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, d_latents, D, d_spline, n_knots, x_scale, cp);
+  hipLaunchKernelGGL(robust_elem_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, d_diff, N, D, cp, d_coef, d_loss, d_ddiff, d_dlatent);
+  return check_launch("npp_robust_elem");
+}
+
+extern "C" int64_t npp_robust_elem_workspace_bytes(int D) { return D < 1 ? NPP_ERR_ARG : (int64_t)D * sizeof(ChanParams) + 64 * sizeof(float); }

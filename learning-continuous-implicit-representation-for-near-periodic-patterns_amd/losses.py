@@ -130,6 +130,8 @@ class HipTrunk:
                 y = self._flat(("a", j), N, c, H // 2, W // 2)
                 ops.maxpool2_fwd(cur, N, H, W, c, y)
                 H, W = H // 2, W // 2
+                if L["idx"] in self.taps:                             # a tap on a pooled tensor (models/style_loss.py:12-14)
+                    outs.append(ops.trunk_export(y, N, N, c, H, W, is_f16=True))
             self._geom.append((y, c, H, W))
             cur = y
         return outs
@@ -144,10 +146,11 @@ class HipTrunk:
         tap_of = {}
         k = 0
         for j, L in enumerate(self.layers):
-            if L["kind"] == "conv" and L["relu_idx"] in self.taps:
+            tapped = (L["kind"] == "conv" and L["relu_idx"] in self.taps) or (L["kind"] == "pool" and L["idx"] in self.taps)
+            if tapped:
                 if gtaps[k] is not None:
-                    if not L.get("tap_ok"):
-                        raise NotImplementedError("HipTrunk: gradient taps must sit on the top layer or right before a pool")
+                    if L["kind"] == "conv" and not L.get("tap_ok"):
+                        raise NotImplementedError("HipTrunk: gradient taps must sit on the top layer, on a pool, or right before a pool")
                     tap_of[j] = gtaps[k]
                 k += 1
         if not tap_of:
@@ -158,14 +161,31 @@ class HipTrunk:
             flip[0] ^= 1
             return self._flat(("g", flip[0]), N, C, H, W)
 
+        # Reverse walk.  State: either dz = dL/d(pre-activation) of conv layer j (ReLU gate applied), or gp = dL/d(output) of
+        # pool layer j.  Layers above the highest tapped one receive no gradient.
         j = max(tap_of)
         y, c, H, W = self._geom[j]
-        dz = gbuf(c, H, W)
-        ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, dz)           # dz_j = dL/dtap * [y > 0]
+        cur = gbuf(c, H, W)
+        if self.layers[j]["kind"] == "conv":
+            ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur)         # dz_j = dL/dtap * [y > 0]
+            state = "dz"
+        else:
+            ops.trunk_grad_in(tap_of[j], None, N, n, c, H, W, cur)
+            state = "gp"
         while True:
-            L = self.layers[j]                                      # dz = dL/d(pre-activation) of conv layer j
-            if j == 0:
-                ops.conv3x3(dz, N, n, H, W, L["cout"], 16, L["pb"], None, 2, None, None, dimg, 3, scale)
+            L = self.layers[j]
+            if state == "gp":                                        # pool j: route into the conv layer below, gate, add its tap
+                yp, cp, Hp, Wp = self._geom[j - 1]
+                add = None
+                if (j - 1) in tap_of:
+                    add = self._flat("tapadd", N, cp, Hp, Wp)
+                    ops.trunk_grad_in(tap_of[j - 1], None, N, n, cp, Hp, Wp, add)
+                dzp = gbuf(cp, Hp, Wp)
+                ops.maxpool2_bwd(cur, yp, add, N, n, Hp, Wp, cp, dzp)
+                cur, j, H, W, state = dzp, j - 1, Hp, Wp, "dz"
+                continue
+            if j == 0:                                               # dz of the image layer -> dL/dimage (fp32, times input scale)
+                ops.conv3x3(cur, N, n, H, W, L["cout"], 16, L["pb"], None, 2, None, None, dimg, 3, scale)
                 return dimg
             prev = self.layers[j - 1]
             if prev["kind"] == "conv":
@@ -173,19 +193,15 @@ class HipTrunk:
                     raise NotImplementedError("HipTrunk: gradient tap below a conv layer")
                 yp, cp, _, _ = self._geom[j - 1]
                 dzp = gbuf(cp, H, W)
-                ops.conv3x3(dz, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp)
-                dz, j = dzp, j - 1
-            else:                                                   # pool at j-1, conv at j-2
-                yp, cp, Hp, Wp = self._geom[j - 2]
+                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp)
+                cur, j = dzp, j - 1
+            else:                                                    # pool at j-1: ungated gradient w.r.t. the pooled tensor
+                _, cp, _, _ = self._geom[j - 1]
                 g = gbuf(cp, H, W)
-                ops.conv3x3(dz, N, n, H, W, L["cout"], cp, L["pb"], None, 2, None, g)
-                add = None
-                if (j - 2) in tap_of:
-                    add = self._flat("tapadd", N, cp, Hp, Wp)
-                    ops.trunk_grad_in(tap_of[j - 2], None, N, n, cp, Hp, Wp, add)
-                dzp = gbuf(cp, Hp, Wp)
-                ops.maxpool2_bwd(g, yp, add, N, n, Hp, Wp, cp, dzp)
-                dz, j, H, W = dzp, j - 2, Hp, Wp
+                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 2, None, g)
+                if (j - 1) in tap_of:
+                    ops.trunk_grad_in(tap_of[j - 1], None, N, n, cp, H, W, g, accumulate=True)
+                cur, j, state = g, j - 1, "gp"
 
 
 class _CXFunction(torch.autograd.Function):
@@ -367,3 +383,62 @@ class LPIPS(nn.Module):
         for kk in range(5):
             ops.adam_step(self.latents[kk], self.lat_m[kk], self.lat_v[kk], self.dlatents[kk], 1, self.latents[kk].numel(),
                           lr, self.lat_step)
+
+
+_VGG16_STYLE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M"]          # vgg16.features[:17]: enc_1 | enc_2 | enc_3
+
+
+class StyleLoss:
+    """models/style_loss.py VGG16FeatureExtractor.style_loss with use_adaptive=True (the remapping task's extra patch loss,
+    NPP_remapping/train.py:253-261): VGG16 features[:5], [5:10], [10:17] (the three POOLED tensors; inputs are used as
+    they are, no mean / std normalisation) -> Gram matrices -> per-element adaptive robust NLL of their difference with
+    num_dims = C^2 latents per level -> / (c w h) -> mean (or per-sample mean times `weight`, summed).
+    Trunk: HipTrunk (weights unpinned like the other trunks); everything after it: npp_gram_* / npp_robust_elem."""
+    chns = [64, 128, 256]
+
+    def __init__(self, vgg_state_dict=None, device="cuda", seed=777):
+        self.device = torch.device(device)
+        self.hip_trunk = HipTrunk(_VGG16_STYLE, taps=(4, 9, 16), state_dict=vgg_state_dict, seed=seed, device=self.device)
+        # AdaptiveLossFunction(num_dims = chn ** 2) per level (style_loss.py:23-27): [latent_alpha(D) | latent_scale(D)]
+        self.latents = [torch.cat([torch.full((c * c,), 2.3841858e-07), torch.zeros(c * c)]).to(self.device) for c in self.chns]
+        self.dlatents = [torch.zeros_like(l) for l in self.latents]
+        self.lat_m = [torch.zeros_like(l) for l in self.latents]
+        self.lat_v = [torch.zeros_like(l) for l in self.latents]
+        self.lat_step = 0
+        self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
+
+    def head(self, feats, n, scale, loss_buf, weight=None, want_grad=True):
+        """From the three pooled feature tensors (2n, C, h, w) = [A | B]: accumulates scale * style_loss into loss_buf[0] and
+        the latent gradients into self.dlatents; returns [dL/dA_i] (n, C, h, w)."""
+        dfs = []
+        for i, f in enumerate(feats):
+            C_, h, w = f.shape[1:]
+            fa, fb = f[:n].contiguous(), f[n:].contiguous()
+            ga, gb = ops.gram_fwd(fa), ops.gram_fwd(fb)
+            D = C_ * C_
+            denom = float(C_ * h * w)
+            if weight is None:
+                coef = [scale / (n * D * denom)] * n                       # torch.mean over (N, C^2) of nll / (c w h)
+            else:
+                coef = [scale * float(wv) / (D * denom) for wv in weight]  # style_loss.py:66-69
+            dd = ops.robust_elem(ga.reshape(n, D), gb.reshape(n, D), self.latents[i], self.spline, self.n_knots, self.x_scale, coef,
+                                 loss_buf, want_grad, self.dlatents[i])
+            dfs.append(ops.gram_bwd(dd.reshape(n, C_, C_), fa) if want_grad else None)
+        return dfs
+
+    def fused(self, xy, n, scale, loss_buf, weight=None):
+        """Explicit forward + backward of scale * style_loss(xy[:n], xy[n:], weight): returns dL/dxy ([:n] defined)."""
+        ones, zeros = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
+        t = self.hip_trunk
+        feats = t._forward(xy, ones, zeros)
+        dfs = self.head(feats, n, scale, loss_buf, weight)
+        return t._backward(dfs, n, ones, tuple(xy.shape), zero_rest=False)
+
+    def zero_latent_grads(self):
+        for d in self.dlatents:
+            d.zero_()
+
+    def adam_step(self, lr):
+        self.lat_step += 1
+        for i in range(3):
+            ops.adam_step(self.latents[i], self.lat_m[i], self.lat_v[i], self.dlatents[i], 1, self.latents[i].numel(), lr, self.lat_step)

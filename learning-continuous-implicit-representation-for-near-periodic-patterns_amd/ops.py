@@ -326,9 +326,9 @@ def maxpool2_bwd(dy, x, addend, N_total, n_run, H, W, c, dz):
     check(lib().npp_maxpool2_bwd(_p(dy), _p(x), _p(addend), N_total, n_run, H, W, c, _p(dz), _stream()), "npp_maxpool2_bwd")
 
 
-def trunk_grad_in(df, y, N_total, n_run, c, H, W, dz, as_f16=False):
+def trunk_grad_in(df, y, N_total, n_run, c, H, W, dz, as_f16=False, accumulate=False):
     _req(df, torch.float32, "df", (n_run, c, H, W))
-    check(lib().npp_trunk_grad_in(_p(df), _p(y), N_total, n_run, c, H, W, _p(dz), int(bool(as_f16)), _stream()),
+    check(lib().npp_trunk_grad_in(_p(df), _p(y), N_total, n_run, c, H, W, _p(dz), int(bool(as_f16)), int(bool(accumulate)), _stream()),
           "npp_trunk_grad_in")
 
 
@@ -408,3 +408,37 @@ def lpips_plain_layer(f0, f1, lin, scale, out):
     N, C = f0.shape[:2]
     check(lib().npp_lpips_plain_layer(_p(f0), _p(f1), N, C, f0.shape[2] * f0.shape[3], _p(lin), scale, _p(out), _stream()),
           "npp_lpips_plain_layer")
+
+
+# ---- remapping variant: Gram-matrix style loss pieces (models/style_loss.py:37-74) ----------------------------
+def gram_fwd(f):
+    _req(f, torch.float32, "f")
+    N, Cc = f.shape[:2]
+    g = torch.empty((N, Cc, Cc), dtype=torch.float32, device=f.device)
+    check(lib().npp_gram_fwd(_p(f), N, Cc, f.shape[2] * f.shape[3], _p(g), _stream()), "npp_gram_fwd")
+    return g
+
+
+def gram_bwd(dg, f):
+    df = torch.empty_like(f)
+    N, Cc = f.shape[:2]
+    check(lib().npp_gram_bwd(_p(dg), _p(f), N, Cc, f.shape[2] * f.shape[3], _p(df), _stream()), "npp_gram_bwd")
+    return df
+
+
+_re_ws = {}
+
+
+def robust_elem(a, b, latents, spline, n_knots, x_scale, coef_n, loss, want_grad=True, dlatent=None):
+    """per-element adaptive robust NLL of (a - b) over (N, D); returns d(loss)/d(a) (N, D) or None."""
+    N, D = a.shape
+    key = (a.device, D)
+    ws = _re_ws.get(key)
+    if ws is None:
+        ws = _re_ws[key] = torch.empty(int(lib().npp_robust_elem_workspace_bytes(D)), dtype=torch.uint8, device=a.device)
+    diff = torch.empty_like(a)
+    dd = torch.empty_like(a) if want_grad else None
+    cf = (C.c_float * N)(*[float(v) for v in coef_n])
+    check(lib().npp_robust_elem(_p(a), _p(b), N, D, _p(latents), _p(spline), n_knots, x_scale, cf, _p(loss), _p(diff), _p(dd),
+                                _p(dlatent) if want_grad else None, _p(ws), _stream()), "npp_robust_elem")
+    return dd

@@ -17,7 +17,7 @@ import numpy as np
 from .npp_oracle import F32, adaptive_params, robust_nll, robust_nll_grads, load_partition_spline
 
 __all__ = ["extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
-           "lpips_head", "lpips_head_grads", "scaling_layer", "VGG19_CX_CFG", "VGG16_LPIPS_CFG", "VGG19_CX_TAPS",
+           "lpips_head", "lpips_head_grads", "scaling_layer", "style_loss_grads", "VGG19_CX_CFG", "VGG16_LPIPS_CFG", "VGG19_CX_TAPS",
            "VGG16_LPIPS_TAPS", "conv3x3", "conv3x3_dgrad", "maxpool2", "maxpool2_bwd", "trunk_forward", "trunk_backward", "conv3x3_gemm", "conv3x3_dgrad_gemm"]
 
 
@@ -262,6 +262,39 @@ def lpips_head_grads(feats0, feats1, lins, latents_alpha, latents_scale):
         dlas.append(((da * coef).sum(0, keepdims=True, dtype=np.float64) * dalpha).astype(F32))
         dlss.append(((dc * coef).sum(0, keepdims=True, dtype=np.float64) * dscale).astype(F32))
     return loss, dfs, dlas, dlss
+
+
+# --------------------------------------------------------------------------
+# remapping variant: models/style_loss.py:37-74 (use_adaptive=True) from the feature tensors on
+# --------------------------------------------------------------------------
+def style_loss_grads(A_feats, B_feats, latents_alpha, latents_scale, weight=None):
+    """Per level: Gram matrices A A^T, B B^T (:55-58), per-element adaptive robust NLL of their difference with
+    num_dims = C^2 latents (:60-65), divided by c*w*h; mean over (N, C^2) -- or, with `weight`, mean over C^2 per sample,
+    times weight, summed (:66-69).  Returns (loss, [dL/dA_i], [dL/dlatent_alpha_i], [dL/dlatent_scale_i])."""
+    loss = F32(0)
+    dAs, dlas, dlss = [], [], []
+    for A, B, la, ls in zip(A_feats, B_feats, latents_alpha, latents_scale):
+        A = np.asarray(A, F32)
+        B = np.asarray(B, F32)
+        N, C, H, W = A.shape
+        a2, b2 = A.reshape(N, C, H * W), B.reshape(N, C, H * W)
+        d = (np.einsum("nik,njk->nij", a2, a2) - np.einsum("nik,njk->nij", b2, b2)).astype(F32).reshape(N, C * C)
+        alpha, scale, dalpha, dscale = adaptive_params(la, ls)
+        nll = robust_nll(d, alpha, scale)
+        dx, da, dc = robust_nll_grads(d, alpha, scale)
+        denom = F32(C * W * H)
+        if weight is None:
+            loss = loss + F32(np.mean(nll / denom))
+            coef = np.full((N, 1), 1.0 / (N * C * C * denom), F32)
+        else:
+            wv = np.asarray(weight, F32).reshape(N)
+            loss = loss + F32(np.sum(np.mean(nll / denom, axis=1) * wv))
+            coef = (wv / (C * C * denom)).reshape(N, 1).astype(F32)
+        G = (dx * coef).reshape(N, C, C)
+        dAs.append(np.einsum("nij,njk->nik", G + G.transpose(0, 2, 1), a2).reshape(A.shape).astype(F32))
+        dlas.append(((da * coef).sum(0, keepdims=True, dtype=np.float64) * dalpha).astype(F32))
+        dlss.append(((dc * coef).sum(0, keepdims=True, dtype=np.float64) * dscale).astype(F32))
+    return loss, dAs, dlas, dlss
 
 
 # --------------------------------------------------------------------------

@@ -251,3 +251,57 @@ def test_explicit_loop_matches_autograd_loop(dev):
         if source == "same":
             for la, lb in zip(a.percepLoss.latents, b.percepLoss.latents):
                 assert rel_l2(la.cpu().numpy(), lb.cpu().numpy()) < 1e-3
+
+
+def test_style_head_vs_reference(dev, golden):
+    """npp_gram_fwd/bwd + npp_robust_elem (StyleLoss.head) against models/style_loss.py:37-74 fed the same features
+    (g12_style.npz: loss, dL/dA per level, latent gradients; mean and weighted forms)."""
+    from npp_amd.losses import StyleLoss
+    g = golden("g12_style.npz")
+    chns = [int(c) for c in g["chns"]]
+    st = StyleLoss.__new__(StyleLoss)                       # head only: no trunk, reduced channel counts
+    st.device = dev
+    from npp_amd import ops
+    st.spline, st.n_knots, st.x_scale = ops.load_spline(dev)
+    st.latents = [torch.from_numpy(np.concatenate([g[f"la{i}"].reshape(-1), g[f"ls{i}"].reshape(-1)])).to(dev) for i in range(3)]
+    n = g["A0"].shape[0]
+    feats = [torch.from_numpy(np.concatenate([g[f"A{i}"], g[f"B{i}"]], 0)).to(dev) for i in range(3)]
+    for tag, w in (("mean", None), ("weighted", g["weighted_w"])):
+        st.dlatents = [torch.zeros_like(l) for l in st.latents]
+        loss = torch.zeros(1, device=dev)
+        dfs = st.head(feats, n, 1.0, loss, None if w is None else [float(v) for v in w])
+        np.testing.assert_allclose(float(loss[0]), float(g[f"{tag}_loss"]), rtol=3e-5)
+        for i in range(3):
+            C_ = chns[i]
+            assert rel_l2(dfs[i].cpu().numpy(), g[f"{tag}_dA{i}"]) < 3e-4, (tag, i)
+            dl = st.dlatents[i].cpu().numpy()
+            assert rel_l2(dl[:C_ * C_], g[f"{tag}_dla{i}"].reshape(-1)) < 3e-3, (tag, i)
+            assert rel_l2(dl[C_ * C_:], g[f"{tag}_dls{i}"].reshape(-1)) < 3e-3, (tag, i)
+
+
+def test_style_loss_trunk_with_pool_taps_vs_torch(dev):
+    """StyleLoss end to end (VGG16 features[:17] with taps on the three POOLED tensors, Gram heads, gradient to the image)
+    against the same computation in plain PyTorch fp32 with the oracle's robust NLL replaced by ... the HIP head on torch's
+    features: isolates the trunk-with-pool-taps forward/backward (fp16 forward / bf16 gradient budget as in the other trunks)."""
+    from npp_amd.losses import StyleLoss, _Trunk, _VGG16_STYLE
+    rng = np.random.RandomState(8)
+    sd = _state_dict(_VGG16_STYLE, rng)
+    st = StyleLoss(vgg_state_dict=sd, device=dev)
+    ref = _Trunk(_VGG16_STYLE, taps=(4, 9, 16), state_dict=sd).to(dev)
+    n, P = 2, 64
+    xy = torch.from_numpy(rng.rand(2 * n, 3, P, P).astype(np.float32)).to(dev)
+    feats = st.hip_trunk._forward(xy, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+    xr = xy.clone().requires_grad_(True)
+    want = ref(xr)
+    assert [tuple(f.shape) for f in feats] == [tuple(w.shape) for w in want] == [(4, 64, 32, 32), (4, 128, 16, 16), (4, 256, 8, 8)]
+    gs = []
+    for f, w in zip(feats, want):
+        assert rel_l2(f.cpu().numpy(), w.detach().cpu().numpy()) < 3e-3
+        gs.append(torch.from_numpy(rng.randn(n, *w.shape[1:]).astype(np.float32)).to(dev))
+    dimg = st.hip_trunk._backward(gs, n, (1.0, 1.0, 1.0), tuple(xy.shape))
+    sum((w[:n] * G).sum() for w, G in zip(want, gs)).backward()
+    assert rel_l2(dimg[:n].cpu().numpy(), xr.grad[:n].cpu().numpy()) < 8e-2
+    # and the whole fused loss produces a finite, non-trivial image gradient
+    loss = torch.zeros(1, device=dev)
+    dx = st.fused(xy, n, 1.0, loss)
+    assert torch.isfinite(loss).all() and torch.isfinite(dx[:n]).all() and float(dx[:n].abs().max()) > 0

@@ -88,3 +88,20 @@ def test_lpips_head(golden):
         np.testing.assert_allclose(dlss[k], g[f"dls{k}"], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(oracle.scaling_layer(2 * g["in0"] - 1), g["scaled0"], rtol=1e-6, atol=1e-6)
     assert all((l >= 0).all() for l in lins)          # vendored lin weights are non-negative
+
+
+def test_style_loss_oracle_vs_reference(golden):
+    """oracle.style_loss_grads against models/style_loss.py:37-74 (g12_style.npz: the reference class fed prepared features)."""
+    import oracle
+    g = golden("g12_style.npz")
+    A = [g[f"A{i}"] for i in range(3)]
+    B = [g[f"B{i}"] for i in range(3)]
+    la = [g[f"la{i}"] for i in range(3)]
+    ls = [g[f"ls{i}"] for i in range(3)]
+    for tag, w in (("mean", None), ("weighted", g["weighted_w"])):
+        loss, dA, dla, dls = oracle.style_loss_grads(A, B, la, ls, w)
+        np.testing.assert_allclose(loss, g[f"{tag}_loss"], rtol=2e-5)
+        for i in range(3):
+            assert np.linalg.norm(dA[i] - g[f"{tag}_dA{i}"]) < 2e-4 * np.linalg.norm(g[f"{tag}_dA{i}"])
+            assert np.linalg.norm(dla[i] - g[f"{tag}_dla{i}"]) < 2e-3 * np.linalg.norm(g[f"{tag}_dla{i}"]) + 1e-9
+            assert np.linalg.norm(dls[i] - g[f"{tag}_dls{i}"]) < 2e-3 * np.linalg.norm(g[f"{tag}_dls{i}"]) + 1e-9
