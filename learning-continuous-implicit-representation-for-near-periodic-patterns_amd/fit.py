@@ -23,7 +23,8 @@ class CompletionFit:
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
-                 prefetch=0, use_perceptual_loss=True):
+                 prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
+                 vgg16_style_state_dict=None):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
@@ -38,18 +39,36 @@ class CompletionFit:
         overlap the training loop instead of preceding it."""
         if rng_mode not in ("reference", "numpy", "fast"):
             raise ValueError("rng_mode must be 'reference', 'numpy' or 'fast'")
+        if task not in ("completion", "remapping"):
+            raise ValueError("task must be 'completion' or 'remapping'")
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
         self.device = torch.device(device)
         valid = np.ones_like(mask) if valid_mask is None else np.asarray(valid_mask, np.float32).reshape(mask.shape)
-        mask = mask * valid
-        # loaders.py:107-108: np.nonzero order (row-major) for both splits
-        self.i_train = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
-        self.i_val = np.stack(np.nonzero((1 - mask[..., 0]) * valid[..., 0]), 1).astype(np.int32)
+        self.task = task
+        if task == "completion":
+            mask = mask * valid
+            # loaders.py:107-108: np.nonzero order (row-major) for both splits
+            self.i_train = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
+            self.i_val = np.stack(np.nonzero((1 - mask[..., 0]) * valid[..., 0]), 1).astype(np.int32)
+            pixel_mask = None                                        # gt_mask = ones (train.py:176)
+            train_img = img * mask                                   # masked_img is what the loop trains on (train.py:173)
+        else:
+            # NPP_remapping: the whole valid image is trained on (loaders.py:279), the 'val' pool and the sampler mask are the
+            # CLEAR (non-blurry) region (:280; NPP_remapping/train.py:147-155), and the pixel loss weighs blurry pixels 0.3
+            # through gt_mask = clear_mask (train.py:203; models/mse_calculator.py:17)
+            if clear_mask is None:
+                raise ValueError("task='remapping' needs clear_mask (H,W[,1]): 1 = sharp region (NPP_remapping/blur_detection.py)")
+            mask = np.asarray(clear_mask, np.float32).reshape(mask.shape) * valid
+            self.i_train = np.stack(np.nonzero(valid[..., 0]), 1).astype(np.int32)
+            self.i_val = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
+            pixel_mask = mask
+            train_img = img
         self.img = torch.from_numpy(img).to(self.device)
         self.mask = torch.from_numpy(mask).to(self.device)
-        self.masked_img = (self.img * self.mask).contiguous()
+        self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
+        self.pixel_mask = None if pixel_mask is None else torch.from_numpy(pixel_mask[..., 0].copy()).to(self.device)
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
                           ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))
@@ -82,6 +101,11 @@ class CompletionFit:
             self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, trunk=trunk, device=self.device).to(self.device)
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
                                     device=self.device, trunk=trunk)
+            self.style, self.style_w = None, 0.0
+            if style_weight is not None or task == "remapping":
+                from .losses import StyleLoss
+                self.style = StyleLoss(vgg_state_dict=vgg16_style_state_dict, device=self.device)
+                self.style_w = 1.0 if style_weight is None else float(style_weight)        # arg_config.py: style_weight 1
             self.last_source, self.skipped = None, 0
             self._xy, self._xy_key = None, None
             self._s_lp = torch.cuda.Stream(self.device)
@@ -181,8 +205,9 @@ class CompletionFit:
         bp = ops.pad_rows(n)
         if bp != n:
             allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
+        pm = None if self.pixel_mask is None else self.pixel_mask[pix[:, 0].long(), pix[:, 1].long()].contiguous()
         return dict(coords=allc.contiguous(), n_pix=pix.shape[0], n=n, bp=bp, gt=self.gather_gt(pix), real=real, rmask=rmask,
-                    fake=fake, fmask=fmask, source=source, k=k, P=d["P"], n_p=d["n_p"], raw=self.patch_sampler.last_raw)
+                    fake=fake, fmask=fmask, source=source, k=k, P=d["P"], n_p=d["n_p"], raw=self.patch_sampler.last_raw, pmask=pm)
 
     def sample_batch(self):
         """Host-side sampling of one iteration + its device half.  None when no valid real patch exists."""
@@ -238,7 +263,7 @@ class CompletionFit:
         # launches): on 'same' iterations the LPIPS branch runs on a side stream next to the contextual branch and
         # joins before npp_patch_compose_bwd (1.30 -> 1.17 ms).  Measured negative: the 12 us pixel loss on a side stream
         # costs more in event record / wait than it hides (0.742 -> 0.762 ms per 'val' iteration).
-        net.pixel_loss(bp, n_pix, b["gt"])
+        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
         raw = b["raw"]
         comp = self.use_comp and source == "val"                 # train.py:230-231
         nk = n_p * k
@@ -256,6 +281,10 @@ class CompletionFit:
         dx_a = self.contextualLoss.fused(xy, nk, self.cx_w, self.patch_loss_buf)                    # train.py:238-239
         if dx_b is not None:
             main.wait_stream(self._s_lp)
+        if self.style is not None:                                                                  # NPP_remapping/train.py:253-261
+            self.style.zero_latent_grads()
+            dx_s = self.style.fused(xy, nk, self.style_w, self.patch_loss_buf)
+            dx_b = dx_s if dx_b is None else dx_b.add_(dx_s)
         ops.patch_compose_bwd(dx_a, dx_b, raw["fmask"], raw["rmask"], n_p, k, P, comp, ws["dpred"][n_pix:n])
         self.last_patch_loss = self.patch_loss_buf
         lr_used = net.lr
@@ -263,6 +292,8 @@ class CompletionFit:
         net.optimizer_step(bp)
         if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
             self.percepLoss.adam_step(lr_used)
+        if self.style is not None:                                # the style latents are in the same optimiser (helpers.py:153-159)
+            self.style.adam_step(lr_used)
 
     def step_from_autograd(self, b):
         """The same iteration written like the reference's loop body, through the torch.autograd wrappers of the loss

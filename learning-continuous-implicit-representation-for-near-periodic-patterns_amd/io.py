@@ -113,3 +113,52 @@ def dump_testset(savedir, pred_hw3, img, masked_img, mask, valid_mask):
     imsave(os.path.join(savedir, "input_rgb_img.png"), np.asarray(masked_img, np.float64) * v)
     imsave(os.path.join(savedir, "pred_rgb_img.png"), pred_val + pred_train)
     imsave(os.path.join(savedir, "pred_rgb_img_comp.png"), pred_val + np.asarray(masked_img, np.float64) * v * m)
+
+
+def rgb_to_gray_u8(img_u8):
+    """cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) on uint8: OpenCV's 14-bit fixed point (R 4899 + G 9617 + B 1868 + 8192) >> 14."""
+    a = np.asarray(img_u8).astype(np.int64)
+    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def get_blur_map(img_u8, win_size=10, sv_num=3, thresh=50):
+    """NPP_remapping/blur_detection.py:14-60: per pixel, the share of the top `sv_num` singular values of the surrounding
+    2 win_size x 2 win_size gray block (mirror-padded like the reference's index arithmetic); normalised to [0,1]; pixels
+    above the `thresh` percentile are 'blurry' candidates, eroded 20x, dilated 40x; the complement is the CLEAR mask.
+    Returns (blur_map float64 (H,W), clear_mask float64 (H,W) in {0, 255}).  Vectorised: one batched SVD per image row."""
+    import scipy.ndimage as ndimage
+    gray = rgb_to_gray_u8(img_u8).astype(np.float64)
+    H, W = gray.shape
+    ws = win_size
+
+    def mirror(n):                                                    # blur_detection.py:18-29
+        idx = np.arange(n + 2 * ws)
+        return np.where(idx < ws, ws - idx, np.where(idx > n + ws - 1, 2 * n - idx, idx - ws))
+    pi, qj = mirror(H), mirror(W)
+    if pi.max() >= H or qj.max() >= W:
+        raise ValueError("image smaller than the blur window")
+    new_img = gray[pi[:, None], qj[None, :]]
+    blur = np.empty((H, W))
+    win = np.lib.stride_tricks.sliding_window_view(new_img, (2 * ws, 2 * ws))       # (H+1, W+1, 2ws, 2ws)
+    for i in range(H):
+        sv = np.linalg.svd(win[i, :W], compute_uv=False)
+        blur[i] = sv[:, :sv_num].sum(1) / (sv.sum(1) + 1e-6)
+    blur = (blur - blur.min()) / (blur.max() - blur.min())
+    binary = blur > np.percentile(blur, thresh)
+    binary = ndimage.binary_erosion(binary, iterations=20)
+    binary = ndimage.binary_dilation(binary, iterations=40)
+    return blur, (~binary).astype(np.float64) * 255
+
+
+def load_npp_remapping(datadir, p_topk=3, blur_thresh=50):
+    """loaders/loaders.py:244-304 -> dict(img, clear_mask (H,W,1) in [0,1], valid_mask, shifts, angles, periods, patch_size)."""
+    from PIL import Image
+    info = load_data(datadir)
+    img_u8 = np.asarray(Image.open(info["fpath_gt_img"]).convert("RGB"))
+    valid = _imread_gray(info["fpath_valid_mask"])
+    _, clear = get_blur_map(img_u8, thresh=blur_thresh)
+    clear = clear[:, :, None] * valid / 255.0                          # :263-274 (valid already / 255 here)
+    periods = info["selected_periods"][:p_topk]
+    return dict(img=(img_u8 / 255.0).astype(np.float32), clear_mask=clear.astype(np.float32), valid_mask=valid.astype(np.float32),
+                shifts=info["selected_shifts"][:p_topk], angles=np.asarray(info["selected_angles"][:p_topk], np.float32),
+                periods=np.asarray(periods, np.float32), patch_size=patch_size_from_period(periods[0]), info=info)

@@ -20,6 +20,12 @@ import torch
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="completion", choices=["completion", "remapping"],
+                    help="completion: NPP_completion/train.py; remapping: NPP_remapping/train.py (whole image trained, blur-detected clear "
+                         "mask as sampler / pixel-weight mask, Gram style loss; its defaults: contextual_weight 0.01, style_weight 1, no LPIPS)")
+    ap.add_argument("--blur_thresh", type=float, default=50)
+    ap.add_argument("--contextual_weight", type=float, default=None)
+    ap.add_argument("--style_weight", type=float, default=1.0)
     ap.add_argument("--datadir", required=True)
     ap.add_argument("--basedir", default="./results")
     ap.add_argument("--expname", default="completion")
@@ -71,7 +77,12 @@ def main(argv=None):
     from . import io as nio
     from ._lib import param_layout
     from .fit import CompletionFit
-    d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
+    remap = args.task == "remapping"
+    if remap:
+        d = nio.load_npp_remapping(args.datadir, args.p_topk, args.blur_thresh)
+        d["mask"], d["masked_img"] = d["clear_mask"], d["img"]
+    else:
+        d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
     K = len(d["angles"])
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
@@ -90,9 +101,12 @@ def main(argv=None):
                         num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
                         patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
                         vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
-                        ksplit=12)
+                        ksplit=12, task=args.task, clear_mask=d["clear_mask"] if remap else None,
+                        contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else 1e-3),
+                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not remap)
     name = os.path.basename(os.path.normpath(args.datadir))
-    outroot = os.path.join(args.basedir, f"{args.expname}_top{args.p_topk}", name)
+    expname = args.expname if not (remap and args.expname == "completion") else "remapping"
+    outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)
     t0 = time.time()
     for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
         fit.step_full()

@@ -557,3 +557,38 @@ def test_error_reporting_on_bad_arguments(dev):
         ops.embed_fwd(c64, bad)
     with pytest.raises(TypeError):
         ops.embed_fwd(c64.long(), cfg)
+
+
+def test_remapping_variant_with_style_loss(dev):
+    """NPP_remapping's loop (train.py:158-300): trains on the whole image, the clear (sharp) region is the 'val' pool and
+    the sampler mask, blurry pixels carry the 0.3-weighted pixel loss (gt_mask = clear_mask, mse_calculator.py:17), and the
+    Gram-matrix style loss joins the contextual loss.  Synthetic check of the task itself: a band of the lattice image is
+    box-blurred; after the fit the prediction inside the band is closer to the SHARP pattern than the blurred input is."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    clean, _ = oracle.synthetic_image(H, noise=0.01)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    blurred = clean.copy()
+    band = slice(96, 160)
+    k = 9
+    pad = np.pad(clean, ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="edge")
+    box = sum(pad[dy:dy + H, dx:dx + H] for dy in range(k) for dx in range(k)) / (k * k)
+    blurred[band] = box[band]
+    clear = np.ones((H, H, 1), np.float32)
+    clear[band] = 0
+    fit = CompletionFit(blurred, np.ones((H, H, 1), np.float32), angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0),
+                        device=dev, N_rand=8192, shifts=shifts, seed=0, rng_mode="fast", task="remapping", clear_mask=clear,
+                        contextual_weight=0.01, use_perceptual_loss=False)
+    assert fit.style is not None and fit.i_train.shape[0] == H * H and fit.i_val.shape[0] == int(clear.sum())
+    lat0 = [l.clone() for l in fit.style.latents]
+    for it in range(200):
+        fit.step_full()
+        assert torch.isfinite(fit.last_patch_loss).all()
+    pred = fit.render_image().cpu().numpy()
+
+    def psnr(a, b):
+        return -10 * np.log10(np.mean((a - b) ** 2))
+    p_in, p_out = psnr(blurred[band], clean[band]), psnr(pred[band], clean[band])
+    assert p_out > p_in + 3.0, (p_in, p_out)                          # the band was re-synthesised from the sharp periodic content
+    assert psnr(pred[:90], clean[:90]) > 27.0
+    assert any((a - b).abs().max() > 0 for a, b in zip(lat0, fit.style.latents))     # style latents are trained

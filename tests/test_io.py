@@ -83,3 +83,12 @@ def test_train_driver_end_to_end(tmp_path):
     assert sorted(os.listdir(out)) == ["testset_000060", "testset_000120"]
     assert len(os.listdir(out / "testset_000120")) == 6
     assert fit.psnr() > 26.0                               # torch-default init + freshly drawn Fourier frequencies
+
+
+def test_blur_map_vs_reference(golden):
+    """io.get_blur_map (vectorised) against NPP_remapping/blur_detection.py:14-60 (g13_blur.npz)."""
+    from npp_amd import io as nio
+    g = golden("g13_blur.npz")
+    bm, clear = nio.get_blur_map(g["img"], thresh=50)
+    np.testing.assert_allclose(bm, g["blur_map"], atol=1e-9)
+    assert np.array_equal(clear, g["clear"])
