@@ -132,19 +132,19 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dist is not None else 0)
 
-    import oracle                      # only for the synthetic workload + cpu_baseline leg
-    from npp_amd import ops
+    from npp_amd import ops, synthetic as syn     # (oracle/ is imported inside cpu_baseline() only)
+    from npp_amd.io import patch_size_from_period
     from npp_amd.fit import CompletionFit
 
     H, K = args.size, args.K
-    img, mask = oracle.synthetic_image(H, seed=rank)           # each rank fits its own image
-    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
-    P = oracle.init_params(K, seed=rank)
-    fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, P, device=dev, N_rand=8192,
+    img, mask = syn.synthetic_image(H, seed=rank)           # each rank fits its own image
+    angles, periods, shifts = syn.synthetic_periodicity(H, K)
+    P = syn.init_params(K, seed=rank)
+    fit = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, P, device=dev, N_rand=8192,
                         ksplit=args.ksplit, seed=rank, shifts=shifts)
     net = fit.net
     patch = fit.patch_size                                     # loaders.py:133-134 -> 96 at 512^2
-    assert patch == oracle.patch_size_from_period(periods[0])
+    assert patch == patch_size_from_period(periods[0])
     n_pix, n_patch = fit.N_rand, fit.patch_num * patch * patch # patch_num = 2 (arg_config.py:63)
     n_rows = n_pix + n_patch
     bp = ops.pad_rows(n_rows)
@@ -251,7 +251,7 @@ def main():
                                       net.repack())),
         "render_fwd_512sq": timed(lambda: net.render(fit.i_all_dev), reps=5),
     }
-    fwd_macs, train_macs = oracle.mlp_macs_per_pixel(K)
+    fwd_macs, train_macs = syn.mlp_macs_per_pixel(K)
     flops = {"mlp_fwd_train": 2 * fwd_macs * n_rows,
              "mlp_bwd_chain": 2 * (train_macs - 2 * fwd_macs) * n_rows,   # dgrad = fwd - embedding part
              "mlp_wgrad": 2 * fwd_macs * n_rows}
@@ -299,16 +299,16 @@ def main():
     if rank == 0 and not args.no_extras:
         yy, xx = np.meshgrid(np.arange(1024, dtype=np.int32), np.arange(1024, dtype=np.int32), indexing="ij")
         grid = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(dev)
-        a4, p4, _ = oracle.synthetic_periodicity(1024, 3)
+        a4, p4, _ = syn.synthetic_periodicity(1024, 3)
         from npp_amd import EmbedCfg
-        cfg4 = EmbedCfg.make(a4, p4, oracle.SEED0_FREQS, (1024, 1024))
+        cfg4 = EmbedCfg.make(a4, p4, syn.SEED0_FREQS, (1024, 1024))
         out = {}
         for name, dt, prec, bpe in (("fp32_precise", torch.float32, True, 4), ("fp32", torch.float32, False, 4), ("bf16", torch.bfloat16, False, 2)):
             t_emb = timed(lambda: ops.embed_fwd(grid, cfg4, dt, precise=prec), reps=5)
             nbytes = grid.shape[0] * (8 + bpe * 3 * 462)
             out[name] = {"ms": t_emb * 1e3, "pixels_per_s": grid.shape[0] / t_emb, "GB_per_s": nbytes / t_emb / 1e9,
                          "frac_of_hbm_peak": nbytes / t_emb / 1e9 / PEAK_HBM_GBS}
-        net4 = CompletionFit(*oracle.synthetic_image(64), a4, p4, oracle.SEED0_FREQS, oracle.init_params(3, seed=0), device=dev).net
+        net4 = CompletionFit(*syn.synthetic_image(64), a4, p4, syn.SEED0_FREQS, syn.init_params(3, seed=0), device=dev).net
         net4.cfg = cfg4
         t_r = timed(lambda: net4.render(grid), reps=3)
         out["render_1024sq_bf16"] = {"ms": t_r * 1e3, "pixels_per_s": grid.shape[0] / t_r,
@@ -328,7 +328,7 @@ def main():
     # ---- iterations to 28 dB on a fresh fit of the same image (not timed) -----------------
     iters_to_target, final_psnr, e2e = None, None, None
     if not args.no_psnr and rank == 0:
-        f2 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+        f2 = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
                            N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts)
         for it in range(1, 301):                               # the complete loop incl. host-side sampling
             f2.step_full()
@@ -339,7 +339,7 @@ def main():
         # are resident before timing): with the reference's exact NumPy stream and with rng_mode='fast'
         e2e = {}
         for mode, pf in (("numpy", 0), ("reference", 4), ("fast", 0)):
-            f4 = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
+            f4 = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
                                N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode, prefetch=pf)
             for _ in range(20):
                 f4.step_full()
