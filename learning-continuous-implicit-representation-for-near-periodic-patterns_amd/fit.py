@@ -325,6 +325,57 @@ class CompletionFit:
         if self.percepLoss.touched:
             self.percepLoss.adam_step(lr_used)
 
+    # ---- checkpoint / resume (the reference has none: start = 0, helpers.py:166) ----------------
+    def state_dict(self):
+        """Everything that determines the continuation of the fit: parameters + Adam moments + step counters of the network and
+        of every adaptive-loss latent group, the LR clock, the patch-size schedule and the position of the random streams.
+        Host tensors / NumPy arrays; not available while a producer thread is running ahead (prefetch > 0)."""
+        if self._producer is not None:
+            raise RuntimeError("state_dict() with an active producer thread: the random stream is ahead of the fit; use prefetch=0")
+        net = self.net
+        sd = {"net": {k: getattr(net, k).detach().cpu().clone() for k in ("params", "m", "v", "latents", "lat_m", "lat_v")},
+              "net_steps": (net.global_step, net.opt_step, net.lr), "iteration": self.iteration, "draw_iter": self._draw_iter,
+              "skipped": getattr(self, "skipped", 0), "rng": self.rng.get_state(),
+              "fast_rng": None if self.fast_rng is None else self.fast_rng.bit_generator.state}
+        if self.patch_sampler is not None:
+            sd["patch"] = (self.patch_size, self.patch_num)
+            lp = self.percepLoss
+            sd["lpips"] = {"latents": [t.cpu().clone() for t in lp.latents], "m": [t.cpu().clone() for t in lp.lat_m],
+                           "v": [t.cpu().clone() for t in lp.lat_v], "step": lp.lat_step}
+            if self.style is not None:
+                st = self.style
+                sd["style"] = {"latents": [t.cpu().clone() for t in st.latents], "m": [t.cpu().clone() for t in st.lat_m],
+                               "v": [t.cpu().clone() for t in st.lat_v], "step": st.lat_step}
+        return sd
+
+    def load_state_dict(self, sd):
+        if self._producer is not None:
+            raise RuntimeError("load_state_dict() with an active producer thread")
+        net = self.net
+        for k, v in sd["net"].items():
+            getattr(net, k).copy_(v.to(self.device))
+        net.global_step, net.opt_step, net.lr = sd["net_steps"]
+        net.repack()
+        net._clean = False
+        self.iteration, self._draw_iter, self.skipped = sd["iteration"], sd["draw_iter"], sd["skipped"]
+        self.rng.set_state(sd["rng"])
+        if self.fast_rng is not None and sd["fast_rng"] is not None:
+            self.fast_rng.bit_generator.state = sd["fast_rng"]
+        if self.patch_sampler is not None and "patch" in sd:
+            if (self.patch_size, self.patch_num) != tuple(sd["patch"]):
+                self.patch_size, self.patch_num = sd["patch"]
+                self.patch_sampler.reset_patchsize(None, None, self.patch_size, self.patch_num)
+                self.patch_sampler.reset_pool(self.i_train, self.i_val)
+            for obj, key in ((self.percepLoss, "lpips"), (self.style, "style")):
+                if obj is not None and key in sd:
+                    for dst, src in zip(obj.latents, sd[key]["latents"]):
+                        dst.copy_(src.to(self.device))
+                    for dst, src in zip(obj.lat_m, sd[key]["m"]):
+                        dst.copy_(src.to(self.device))
+                    for dst, src in zip(obj.lat_v, sd[key]["v"]):
+                        dst.copy_(src.to(self.device))
+                    obj.lat_step = sd[key]["step"]
+
     # ---- evaluation (train.py:270-331) -----------------------------------------------
     @torch.no_grad()
     def render_image(self):

@@ -592,3 +592,35 @@ def test_remapping_variant_with_style_loss(dev):
     assert p_out > p_in + 3.0, (p_in, p_out)                          # the band was re-synthesised from the sharp periodic content
     assert psnr(pred[:90], clean[:90]) > 27.0
     assert any((a - b).abs().max() > 0 for a, b in zip(lat0, fit.style.latents))     # style latents are trained
+
+
+@pytest.mark.parametrize("mode", ["reference", "fast"])
+def test_checkpoint_resume_continues_the_same_fit(dev, mode):
+    """state_dict() / load_state_dict() (the reference has no checkpointing): a fit resumed in a FRESH
+    object draws the same samples and ends at the same weights as the uninterrupted one."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make():
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev, N_rand=4096,
+                             shifts=shifts, seed=11, rng_mode=mode, use_perceptual_loss=False)
+    a = make()
+    for _ in range(12):
+        a.step_full()
+    sd = a.state_dict()
+    tail_a = []
+    for _ in range(10):
+        a.step_full()
+        tail_a.append((a.last_draw["source"], a.last_draw["k"], a.last_draw["cen"].tolist(), a.last_draw["pix"][:8].tolist()))
+    b = make()
+    b.load_state_dict(sd)
+    tail_b = []
+    for _ in range(10):
+        b.step_full()
+        tail_b.append((b.last_draw["source"], b.last_draw["k"], b.last_draw["cen"].tolist(), b.last_draw["pix"][:8].tolist()))
+    assert tail_a == tail_b
+    assert (a.net.global_step, a.net.opt_step, a.iteration) == (b.net.global_step, b.net.opt_step, b.iteration)
+    assert rel_l2(b.net.params.cpu().numpy(), a.net.params.cpu().numpy()) < 5e-3     # float atomics in the CX kernels: not bitwise
+    assert abs(a.psnr() - b.psnr()) < 0.05
