@@ -35,6 +35,11 @@
 namespace npp {
 
 constexpr int kConvGuard = 256;       // zero units before / after the position axis (>= W + 3)
+#ifndef NPP_CONV_RING
+#define NPP_CONV_RING 3
+#endif
+constexpr int kConvRing = NPP_CONV_RING;   // k-steps of operand fragments in flight per wave (3 or 9: must divide the 9 taps)
+static_assert(kConvRing == 3 || kConvRing == 9, "ring depth");
 constexpr int kPosRound = 512;        // position count is rounded up to a multiple of this
 
 NPP_HD int64_t conv_npos_round(int N, int H, int W) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   const int voffB = (int)(((int64_t)h * a.nposp + kConvGuard + (int64_t)tile0 * 32 + b - (a.Wp + 1)) * 16);
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-  frag_t A[3][CT], B[3][PT];
+  frag_t A[kConvRing][CT], B[kConvRing][PT];
   auto load = [&](int slot, int ci, int tap) {
     const int ks = ci * 9 + tap;
 #pragma unroll
@@ -125,19 +130,18 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
 
-  load(0, ci_beg, 0);
-  load(1, ci_beg, 1);
-  load(2, ci_beg, 2);
+#pragma unroll
+  for (int q = 0; q < kConvRing; ++q) load(q, ci_beg, q);
   for (int ci = ci_beg; ci < ci_end; ++ci) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int slot = tap % 3;
+      const int slot = tap % kConvRing;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = mfma16(A[slot][ct], B[slot][pt], acc[ct][pt]);
-      if (tap + 3 < 9) load(slot, ci, tap + 3);
-      else if (ci + 1 < ci_end) load(slot, ci + 1, tap - 6);
+      if (tap + kConvRing < 9) load(slot, ci, tap + kConvRing);
+      else if (ci + 1 < ci_end) load(slot, ci + 1, tap + kConvRing - 9);
       asm volatile("" ::: "memory");
     }
   }
