@@ -255,6 +255,17 @@ int npp_conv_pack(const float* d_w, int Cin, int Cout, int in_natural, void* d_p
 int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, const float scale[3],
                        const float shift[3], void* d_x0, void* stream);
 
+/* npp_patch_compose_fwd + npp_trunk_image_in in ONE launch (NPP_completion/train.py:200-236 followed by
+ * contextual.py:56-61): the batch [x | y] of the patch plumbing is written straight into the flat
+ * C=16 trunk input d_x0 (2*n_p*k images of P x P, value*scale[c] + shift[c]); d_xy (nullable) also
+ * receives it as fp32 (2*n_p*k,3,P,P) for the other consumers of the iteration (LPIPS / style
+ * trunks); d_zero[0..n_zero) (n_zero <= 256, nullable) is set to 0 -- the iteration's patch-loss
+ * accumulator.  Bit-identical to the two separate calls. */
+int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
+                       const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
+                       const float scale[3], const float shift[3], void* d_x0, float* d_xy,
+                       float* d_zero, int n_zero, void* stream);
+
 /* One 3x3 / pad 1 convolution launch on flat tensors (Cin, Cout multiples of 16, <= 512):
  *  mode 0  y = relu(conv(x, w) + bias)                    nn.Conv2d + nn.ReLU
  *  mode 1  y = conv_transpose(x) * [mask > 0]             dL/d(pre-activation) of the layer below:

@@ -271,6 +271,53 @@ __global__ void trunk_image_in_kernel(const float* __restrict__ img, int N, int 
   out[nposp + kConvGuard + p] = z;
 }
 
+// ---- patch plumbing + image in, fused (row a10 feeding rows a11 / a13): the batch [x | y] of npp_patch_compose_fwd
+// written straight into the trunk's flat input (x*scale + shift, fp16), optionally also as the fp32 (2 n_p k,3,P,P)
+// tensor the other trunks of the iteration read, and the iteration's patch-loss accumulator zeroed by the way.
+__global__ void trunk_patch_in_kernel(const float* __restrict__ pred, const float* __restrict__ fake,
+                                      const float* __restrict__ fmask, const float* __restrict__ real,
+                                      const float* __restrict__ rmask, int n_p, int k, int P, int comp, float s0, float s1,
+                                      float s2, float b0, float b1, float b2, f16x8* __restrict__ out, int64_t nposp,
+                                      int64_t npos_round, float* __restrict__ xy, float* __restrict__ zero, int n_zero) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_zero) zero[p] = 0.0f;
+  if (p >= npos_round) return;
+  const int Wp = P + 2, S = (P + 2) * Wp, nk = n_p * k;
+  const int n = (int)(p / S), r = (int)(p - (int64_t)n * S), y = r / Wp, x = r - y * Wp;
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+  const f16x8 z = o;
+  if (n < 2 * nk && y >= 1 && y <= P && x >= 1 && x <= P) {
+    const int64_t pp = (int64_t)P * P, q = (int64_t)(y - 1) * P + (x - 1);
+    const int pk = n < nk ? n : n - nk;
+    const float rm = rmask[(int64_t)pk * pp + q];
+    float v[3];
+    if (n < nk) {                                                                 // prediction half
+      const int pi = pk / k;
+      const float fm = comp ? fmask[(int64_t)pi * pp + q] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float pv = pred[((int64_t)pi * pp + q) * 3 + c];
+        const float u = comp ? fake[((int64_t)pi * 3 + c) * pp + q] * fm + pv * (1.0f - fm) : pv;   // train.py:230-231
+        v[c] = u * rm;                                                                              // :232-233
+      }
+    } else {                                                                      // real half, :235-236
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = real[((int64_t)pk * 3 + c) * pp + q] * rm;
+    }
+    if (xy) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xy[((int64_t)n * 3 + c) * pp + q] = v[c];
+    }
+    o[0] = (_Float16)fmaf(v[0], s0, b0);
+    o[1] = (_Float16)fmaf(v[1], s1, b1);
+    o[2] = (_Float16)fmaf(v[2], s2, b2);
+  }
+  out[kConvGuard + p] = o;
+  out[nposp + kConvGuard + p] = z;
+}
+
 __device__ __forceinline__ void unit_decode(int64_t p, int H, int W, int& n, int& y, int& x) {
   const int Wp = W + 2, S = (H + 2) * Wp;
   n = (int)(p / S);
@@ -468,6 +515,24 @@ extern "C" int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, 
   hipLaunchKernelGGL(trunk_image_in_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_img_nchw,
                      N, H, W, scale[0], scale[1], scale[2], shift[0], shift[1], shift[2], (f16x8*)d_x0, conv_nposp(N, H, W), nr);
   return check_launch("npp_trunk_image_in");
+}
+
+extern "C" int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                                  const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3],
+                                  const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, void* stream) {
+  if (n_p < 1 || k < 1 || n_zero < 0 || n_zero > 256) { set_error("npp_trunk_patch_in: bad n_p=%d k=%d n_zero=%d", n_p, k, n_zero); return NPP_ERR_ARG; }
+  const int N = 2 * n_p * k;
+  int rc = conv_geom_check(N, P, P, "npp_trunk_patch_in");
+  if (rc) return rc;
+  if (!d_pred_rows || !d_real || !d_rmask || !d_x0 || !scale || !shift || (comp && (!d_fake || !d_fmask)) || (n_zero && !d_zero)) {
+    set_error("npp_trunk_patch_in: null pointer");
+    return NPP_ERR_ARG;
+  }
+  const int64_t nr = conv_npos_round(N, P, P);
+  hipLaunchKernelGGL(trunk_patch_in_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pred_rows,
+                     d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale[0], scale[1], scale[2], shift[0], shift[1],
+                     shift[2], (f16x8*)d_x0, conv_nposp(N, P, P), nr, d_xy, d_zero, n_zero);
+  return check_launch("npp_trunk_patch_in");
 }
 
 template <int CT, int PT, int S>

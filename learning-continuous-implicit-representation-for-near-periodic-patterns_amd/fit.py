@@ -271,14 +271,20 @@ class CompletionFit:
         if self._xy is None or self._xy_key != key:
             self._xy = torch.empty((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
             self._xy_key = key
-        xy = ops.patch_compose_fwd(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, self._xy)
-        self.patch_loss_buf.zero_()
+        with_lp = source == "same" and self.use_perceptual_loss
+        cx = self.contextualLoss
+        # one launch: patch plumbing -> the contextual trunk's flat fp16 input (normalised), the fp32 batch only when another
+        # trunk of this iteration reads it, and the patch-loss accumulator cleared
+        xy = self._xy if (with_lp or self.style is not None) else None
+        sc, sh = cx.input_norm()
+        ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
+                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf)
         dx_b = None
-        if source == "same" and self.use_perceptual_loss:                                           # train.py:241-250
+        if with_lp:                                                                                 # train.py:241-250
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
                 dx_b = self.percepLoss.fused(xy, nk, self.lp_w, self.patch_loss_buf, normalize=True)
-        dx_a = self.contextualLoss.fused(xy, nk, self.cx_w, self.patch_loss_buf)                    # train.py:238-239
+        dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, x0_ready=True)       # train.py:238-239
         if dx_b is not None:
             main.wait_stream(self._s_lp)
         if self.style is not None:                                                                  # NPP_remapping/train.py:253-261

@@ -110,12 +110,18 @@ class HipTrunk:
         need = n_grad > 0 and x.requires_grad
         return list(_HipTrunkFunction.apply(x, self, n_grad if need else 0, tuple(scale), tuple(shift)))
 
-    def _forward(self, x, scale, shift):
-        N, _, H, W = x.shape
+    def input_buffer(self, N, H, W):
+        """The flat C=16 input tensor of an (N,3,H,W) batch, for producers that write it directly (ops.trunk_patch_in)."""
+        return self._flat("x0", N, 16, H, W)
+
+    def _forward(self, x, scale, shift, x0_ready=False):
+        """x: the (N,3,H,W) batch, or just its shape when the flat input was already written (x0_ready)."""
+        N, _, H, W = x if x0_ready else x.shape
         self._gen += 1
         self._geom = []
         cur = self._flat("x0", N, 16, H, W)
-        ops.trunk_image_in(x, scale, shift, cur)
+        if not x0_ready:
+            ops.trunk_image_in(x, scale, shift, cur)
         c, outs = 16, []
         for j, L in enumerate(self.layers):
             if L["kind"] == "conv":
@@ -257,13 +263,19 @@ class ContextualLoss(nn.Module):
                 y = self.vgg_model(y)[0]
         return contextual_loss(x, y, self.band_width, weight)
 
-    def fused(self, xy, n, scale, loss_buf, weight=None):
+    def input_norm(self):
+        """(scale, shift) of the trunk's input normalisation (x - mean) / std, contextual.py:56-61."""
+        return [1.0 / s for s in self._STD], [-m / s for m, s in zip(self._MEAN, self._STD)]
+
+    def fused(self, xy, n, scale, loss_buf, weight=None, x0_ready=False):
         """Explicit forward + backward of `scale * self(xy[:n], xy[n:])` without autograd (the loop's path):
-        accumulates the loss into loss_buf[0] and returns dL/dxy (only [:n] is defined)."""
+        accumulates the loss into loss_buf[0] and returns dL/dxy (only [:n] is defined).  x0_ready: xy is only the
+        SHAPE of the batch, whose normalised flat form was already written into hip_trunk.input_buffer()."""
         t = self.hip_trunk
-        f = t._forward(xy, [1.0 / s for s in self._STD], [-m / s for m, s in zip(self._MEAN, self._STD)])[0]
+        sc, sh = self.input_norm()
+        f = t._forward(xy, sc, sh, x0_ready)[0]
         _, dfx = ops.cx_fwd_bwd(f[:n], f[n:], self.band_width, weight, scale, loss_buf, True)
-        return t._backward([dfx], n, [1.0 / s for s in self._STD], tuple(xy.shape), zero_rest=False)
+        return t._backward([dfx], n, sc, tuple(xy) if x0_ready else tuple(xy.shape), zero_rest=False)
 
 
 class _LPIPSLayerFunction(torch.autograd.Function):

@@ -319,6 +319,23 @@ def trunk_image_in(img, scale, shift, x0):
     check(lib().npp_trunk_image_in(_p(img), N, H, W, s, b, _p(x0), _stream()), "npp_trunk_image_in")
 
 
+def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, x0, xy=None, zero=None):
+    """npp_patch_compose_fwd + npp_trunk_image_in in one launch: [x | y] -> flat trunk input x0 (and fp32 xy when given);
+    zero (small fp32 tensor) is cleared on the way."""
+    _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
+    _req(real, torch.float32, "real", (n_p * k, 3, P, P))
+    _req(rmask, torch.float32, "rmask", (n_p * k, 1, P, P))
+    if comp:
+        _req(fake, torch.float32, "fake", (n_p, 3, P, P))
+        _req(fmask, torch.float32, "fmask", (n_p, 1, P, P))
+    if xy is not None:
+        _req(xy, torch.float32, "xy", (2 * n_p * k, 3, P, P))
+    s = (C.c_float * 3)(*[float(v) for v in scale])
+    b = (C.c_float * 3)(*[float(v) for v in shift])
+    check(lib().npp_trunk_patch_in(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
+                                   _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), _stream()), "npp_trunk_patch_in")
+
+
 def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=None, ctap=0, tap_scale=None):
     ts = None if tap_scale is None else (C.c_float * len(tap_scale))(*[float(v) for v in tap_scale])
     check(lib().npp_conv3x3(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), mode, _p(mask), _p(y), _p(tap),

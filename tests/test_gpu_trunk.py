@@ -305,3 +305,34 @@ def test_style_loss_trunk_with_pool_taps_vs_torch(dev):
     loss = torch.zeros(1, device=dev)
     dx = st.fused(xy, n, 1.0, loss)
     assert torch.isfinite(loss).all() and torch.isfinite(dx[:n]).all() and float(dx[:n].abs().max()) > 0
+
+
+@pytest.mark.parametrize("comp", [False, True])
+@pytest.mark.parametrize("n_p,k,P", [(2, 3, 96), (4, 1, 64), (1, 2, 34)])
+def test_fused_patch_in_equals_compose_then_image_in(dev, comp, n_p, k, P):
+    """npp_trunk_patch_in == npp_patch_compose_fwd followed by npp_trunk_image_in, bit for bit (flat trunk input, the
+    optional fp32 batch, and the cleared accumulator)."""
+    from npp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(n_p * 100 + k * 10 + P)
+    r = lambda *s: torch.rand(*s, device=dev, generator=g)
+    pred, fake, real = r(n_p * P * P, 3), r(n_p, 3, P, P), r(n_p * k, 3, P, P)
+    fmask, rmask = (r(n_p, 1, P, P) > 0.4).float(), (r(n_p * k, 1, P, P) > 0.2).float()
+    scale, shift = [1 / 0.229, 1 / 0.224, 1 / 0.225], [-0.485 / 0.229, -0.456 / 0.224, -0.406 / 0.225]
+    N = 2 * n_p * k
+    xy_ref = ops.patch_compose_fwd(pred, fake, fmask, real, rmask, n_p, k, P, comp)
+    a = ops.trunk_alloc(N, 16, P, P, dev)
+    a.view(torch.int16).fill_(0x3c00)                                  # stale contents must be overwritten (borders = 0)
+    ops.trunk_image_in(xy_ref, scale, shift, a)
+    b = ops.trunk_alloc(N, 16, P, P, dev)
+    b.view(torch.int16).fill_(0x4000)
+    xy = torch.full_like(xy_ref, -7.0)
+    acc = torch.full((1,), 5.0, device=dev)
+    ops.trunk_patch_in(pred, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, b, xy, acc)
+    assert torch.equal(xy, xy_ref) and float(acc) == 0.0
+    G = 256                                                            # guard units at both ends are never written
+    va, vb = a.view(torch.int16).reshape(2, -1, 8), b.view(torch.int16).reshape(2, -1, 8)
+    assert torch.equal(va[:, G:-G], vb[:, G:-G])
+    # without the optional outputs
+    c = ops.trunk_alloc(N, 16, P, P, dev)
+    ops.trunk_patch_in(pred, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, c)
+    assert torch.equal(c.view(torch.int16).reshape(2, -1, 8)[:, G:-G], va[:, G:-G])
