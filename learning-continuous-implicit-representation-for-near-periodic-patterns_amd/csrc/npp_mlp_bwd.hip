@@ -39,9 +39,22 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
       for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
 }
 
+// The z fragments a layer's epilogue needs (stash, cold in HBM), fetched BEFORE the layer's MFMA loop so that their
+// latency is covered by it instead of stalling every epilogue (32 VGPRs).
+struct ZPre { f16x8 z[2][kNB][2]; };
+__device__ __forceinline__ void z_prefetch(ZPre& zp, const char* z_array, int wg, int kt0, const Lane& L) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        zp.z[t][bt][s] = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * (kt0 + t) + s, bt, L.b, L.h));
+}
+
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
 template <bool HAS_S>
-__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const char* z_array, char* dz_array,
+__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const ZPre* zp, char* dz_array,
                                              int wg, int kt0, const Lane& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -52,7 +65,7 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
       if (HAS_S) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const f16x8 zf = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h));
+          const f16x8 zf = zp->z[t][bt][s];
 #pragma unroll
           for (int j = 0; j < 8; ++j)      // snake'(z) = 1 + sin 2z  (activations.py:29-35)
             g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
@@ -146,6 +159,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   wg_barrier();
 
   f32x16 acc[2][kNB], acc1[2][kNB];
+  ZPre zpre;
   WRing<2> ring;                                        // weight-stream ring, chained across layers
   ring.rsrc = make_wrsrc(A.wb, d.wb_total16);
   auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
@@ -161,8 +175,9 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
+    z_prefetch(zpre, zs(kActAS), wg, kt0, L);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wbl(BF2), wbl(BS), kt0, L, ring);
-    bwd_epilogue<true>(acc, R0, zs(kActAS), dzr(kDzS), wg, kt0, L);
+    bwd_epilogue<true>(acc, R0, &zpre, dzr(kDzS), wg, kt0, L);
     wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
@@ -180,8 +195,9 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     char* in = ((v - BF1) & 1) ? R0 : R1;
     char* out = ((v - BF1) & 1) ? R1 : R0;
     zero_acc(acc);
+    z_prefetch(zpre, zs(out_layer), wg, kt0, L);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wbl(v), v == B1 ? kNoW : wbl(v + 1), kt0, L, ring);
-    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, zs(out_layer), dzr(out_layer), wg, kt0, L);
+    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, &zpre, dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }
 }
