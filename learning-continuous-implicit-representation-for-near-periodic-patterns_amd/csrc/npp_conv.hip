@@ -130,6 +130,33 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
 
+  // Epilogue operands fetched BEFORE the contraction (their latency hides under it instead of stalling the short
+  // epilogue of a 10-us kernel): the ReLU-gate units of the tiles this wave will finish (dgrad; written by the forward
+  // pass long ago -> cold) and the bias values of its output channels (forward).
+  constexpr int NT = CT * PT;
+  constexpr int NF = S == 1 ? NT : (NT + S - 1) / S;          // tiles finished by one wave
+  f16x8 gate[MODE == kConvDgradMask ? NF : 1][2];
+  float bias_r[MODE == kConvFwd ? NF : 1][16];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) {
+    const int t = S == 1 ? q : wave + q * S;
+    if (t < NT) {
+      const int ct = t / PT, pt = t % PT;
+      if (MODE == kConvDgradMask) {
+        const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int chunk = 4 * (cot0 + ct) + 2 * s + h;
+          if (chunk < a.cout_chunks) gate[q][s] = ((const f16x8*)a.mask)[(int64_t)chunk * a.nposp + kConvGuard + p];
+        }
+      }
+      if (MODE == kConvFwd) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[q][r] = a.bias[32 * (cot0 + ct) + acc_row(r, h)];
+      }
+    }
+  }
+
 #pragma unroll
   for (int q = 0; q < kConvRing; ++q) load(q, ci_beg, q);
   for (int ci = ci_beg; ci < ci_end; ++ci) {
@@ -147,7 +174,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   }
 
   // ---- epilogue of one 32 x 32 tile (ct, pt): bias / ReLU / gate, 16-bit store, optional fp32 tap -------
-  auto finish = [&](const f32x16& v16, int ct, int pt) {
+  auto finish = [&](const f32x16& v16, int ct, int pt, int q) {
     const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
     const int n = (int)((uint32_t)p / (uint32_t)a.S);
     const int r0 = (int)(p - (int64_t)n * a.S);
@@ -161,13 +188,13 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       if (chunk >= a.cout_chunks) continue;
       const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
       f16x8 m;
-      if (MODE == kConvDgradMask) m = ((const f16x8*)a.mask)[unit];
+      if (MODE == kConvDgradMask) m = gate[q][s];
       frag_t o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int co = 32 * cot + acc_row(8 * s + j, h);
         float v = v16[8 * s + j];
-        if (MODE == kConvFwd) v = fminf(fmaxf(v + a.bias[co], 0.0f), 65504.0f);
+        if (MODE == kConvFwd) v = fminf(fmaxf(v + bias_r[q][8 * s + j], 0.0f), 65504.0f);
         if (MODE == kConvDgradMask) v = (float)m[j] > 0.0f ? v : 0.0f;
         v = interior ? v : 0.0f;
         o[j] = (elem_t)v;
@@ -182,9 +209,8 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < PT; ++pt) finish(acc[ct][pt], ct, pt);
+      for (int pt = 0; pt < PT; ++pt) finish(acc[ct][pt], ct, pt, ct * PT + pt);
   } else {
-    constexpr int NT = CT * PT;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -192,14 +218,17 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wave * NT + ct * PT + pt) * 16 + r) * 64 + lane] = acc[ct][pt][r];
     __syncthreads();
-    for (int t = wave; t < NT; t += S) {                  // tile t is finished by wave t % S
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {                        // tile t is finished by wave t % S
+      const int t = wave + q * S;
+      if (t >= NT) break;
       f32x16 v;
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = 0.0f;
       for (int w2 = 0; w2 < S; ++w2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += red[((w2 * NT + t) * 16 + r) * 64 + lane];
-      finish(v, t / PT, t % PT);
+      finish(v, t / PT, t % PT, q);
     }
   }
 }

@@ -106,6 +106,26 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][kNB], const float* 
   }
 }
 
+// The same in two halves: the NEXT layer's bias values are fetched before the current layer's epilogue (their L2 latency
+// hides under it and the barrier) and moved into the accumulators where init_bias used to load them.
+template <int NTW> struct BiasPre { float v[NTW][16]; };
+template <int NTW>
+__device__ __forceinline__ void bias_fetch(BiasPre<NTW>& bp, const float* __restrict__ bias, int nt0, const Lane& L) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bp.v[nt][r] = bias[(nt0 + nt) * 32 + acc_row(r, L.h)];
+}
+template <int NTW>
+__device__ __forceinline__ void bias_apply(f32x16 (&acc)[NTW][kNB], const BiasPre<NTW>& bp) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][bt][r] = bp.v[nt][r];
+}
+
 // The 22 warped coordinates (a1, models/embedder.py:110-133) of proposal p for the 64 rows ->
 // sV[i][row] (fp32).  Table-driven: wave w takes i = w, w+4, ...; the entry is wave-uniform.
 __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, const float* sY, const float* sX,
@@ -348,6 +368,9 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
   init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
   mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
   STAMP(1);
+  BiasPre<kNTW> bn;
+  BiasPre<1> bnp;
+  bias_fetch<kNTW>(bn, P + d.b_off[L1], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(0), wg, L);
   STAMP(2);
   wg_barrier();
@@ -358,9 +381,10 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
   for (int l = L1; l <= L4; ++l) {
     char* in = (l & 1) ? R0 : R1;
     char* out = (l & 1) ? R1 : R0;
-    init_bias<kNTW>(acc, P + d.b_off[l], nt0, L);
+    bias_apply<kNTW>(acc, bn);
     mma_ring<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
     STAMP(4 * l);
+    bias_fetch<kNTW>(bn, P + d.b_off[l + 1], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
     STAMP(4 * l + 1);
     wg_barrier();
@@ -369,39 +393,44 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
 
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
   //      again after mma_embedding's final barrier)
-  init_bias<kNTW>(acc, P + d.b_off[L5], nt0, L);
+  bias_apply<kNTW>(acc, bn);
   mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
   STAMP(20);
   mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   STAMP(21);
+  bias_fetch<kNTW>(bn, P + d.b_off[L6], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L);
   wg_barrier();
   STAMP(22);
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
-  init_bias<kNTW>(acc, P + d.b_off[L6], nt0, L);
+  bias_apply<kNTW>(acc, bn);
   mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
+  bias_fetch<kNTW>(bn, P + d.b_off[L7], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(6), wg, L);
   wg_barrier();
-  init_bias<kNTW>(acc, P + d.b_off[L7], nt0, L);
+  bias_apply<kNTW>(acc, bn);
   mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
+  bias_fetch<kNTW>(bn, P + d.b_off[LF1], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(7), wg, L);
   wg_barrier();
 
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
   //      registers because P needs f1 again after S and F2 have recycled the regions.
   bf16x8 f1keep[kNTW][kNB][2];
-  init_bias<kNTW>(acc, P + d.b_off[LF1], nt0, L);
+  bias_apply<kNTW>(acc, bn);
   mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
   const bool p_wave = L.wave < kNT / 2;            // P has 4 neuron tiles: with 8 waves the upper four only keep the barriers
   if (!MULTI && p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+  if (MULTI) bias_fetch<kNTW>(bn, P + d.b_off[LS], nt0, L);
+  else if (p_wave) bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
   epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
   wg_barrier();
 
   f32x16 accp[1][kNB];
   if (MULTI) {
     // ---- S = scale_linears[0]: [f1 (R0), emb(p1..pK-1) (LDS ring R1)] -> 256, snake, out -> R1
-    init_bias<kNTW>(acc, P + d.b_off[LS], nt0, L);
+    bias_apply<kNTW>(acc, bn);
     mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
@@ -409,12 +438,16 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
                                    A_.actF, wg, L, ring);
     }
     wring_fill<kNTW, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
+    bias_fetch<kNTW>(bn, P + d.b_off[LF2], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
-    init_bias<kNTW>(acc, P + d.b_off[LF2], nt0, L);
+    bias_apply<kNTW>(acc, bn);
     mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
-    if (p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+    if (p_wave) {
+      wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+      bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
+    }
     epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
     wg_barrier();
     // f1 back into LDS (R1 is idle: every wave passed the barrier after reading a_s)
@@ -427,13 +460,13 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
     wg_barrier();
     // ---- P = pos_linears[0]: [f1 (R1), f2 (R0)] -> 128, snake; one neuron tile per wave
     if (p_wave) {
-      init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
+      bias_apply<1>(accp, bnp);
       mma_ring<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
       mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
     }
   } else if (p_wave) {
     // ---- NPP_Net_top1: P reads f1 (R0) directly (networks.py:162-170)
-    init_bias<1>(accp, P + d.b_off[LP], L.wave, L);
+    bias_apply<1>(accp, bnp);
     mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   if (p_wave)
