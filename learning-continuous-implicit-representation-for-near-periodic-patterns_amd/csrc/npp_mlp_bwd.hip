@@ -101,6 +101,29 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, gridDim.x); };   // z of layer idx
   auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, gridDim.x); };
 
+  // Everything the prologue needs from memory is requested first (weight ring of the first dgrad, the rgb weights, the cold
+  // z fragments of P), so that ONE latency is paid instead of one per dependent section.
+  WRing<2> ring;                                        // weight-stream ring, chained across layers
+  ring.rsrc = make_wrsrc(A.wb, d.wb_total16);
+  auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
+  wring_fill<2, kNT>(ring, wbl(BP1), kt0, L.lane);
+  f16x8 zp_pre[kNB][2];
+  {
+    const char* zp = A.actF + wfmt_array_base(kActKsAP, gridDim.x);
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) zp_pre[bt][s] = *(const f16x8*)(zp + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h));
+  }
+  float wr[3][16];
+  {
+    const float* Wr = P + d.w_off[LRGB];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wr[c][r] = Wr[c * (kW / 2) + L.wave * 32 + acc_row(r, L.h)];
+  }
+
   // ---- sigmoid backward (helpers.py:56): draw = dpred * pred * (1 - pred); also dz_rgb^T
   if (L.tid < kRowTile * 3) {
     const int row = L.tid / 3, c = L.tid - row * 3;
@@ -128,13 +151,6 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
   //      wave w owns P's neuron tile w.  dz_p fragments -> R0 (8 k-steps), rows -> dzT.
   {
-    const float* Wr = P + d.w_off[LRGB];
-    float wr[3][16];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) wr[c][r] = Wr[c * (kW / 2) + L.wave * 32 + acc_row(r, L.h)];
-    const char* zp = A.actF + wfmt_array_base(kActKsAP, gridDim.x);
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
       const int row = bt * 32 + L.b;
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const f16x8 zf = *(const f16x8*)(zp + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h));
+        const f16x8 zf = zp_pre[bt][s];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
       }
@@ -160,10 +176,6 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
   f32x16 acc[2][kNB], acc1[2][kNB];
   ZPre zpre;
-  WRing<2> ring;                                        // weight-stream ring, chained across layers
-  ring.rsrc = make_wrsrc(A.wb, d.wb_total16);
-  auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
-  wring_fill<2, kNT>(ring, wbl(BP1), kt0, L.lane);
 
   // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
   zero_acc(acc1);
