@@ -126,8 +126,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # Rehearsal knobs (one-GPU box): NPP_BENCH_BACKEND=gloo NPP_BENCH_DEVICE=0 runs N ranks on one card without RCCL.
+        backend = os.environ.get("NPP_BENCH_BACKEND", "nccl")
+        if "NPP_BENCH_DEVICE" in os.environ:
+            local = int(os.environ["NPP_BENCH_DEVICE"])
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dist is not None else 0)
@@ -140,8 +147,13 @@ def main():
     img, mask = syn.synthetic_image(H, seed=rank)           # each rank fits its own image
     angles, periods, shifts = syn.synthetic_periodicity(H, K)
     P = syn.init_params(K, seed=rank)
+    # Own image and own initial weights per rank, but the SAME sampler stream (seed 0) everywhere: the patch-source mix of
+    # the pool ('same' iterations cost 1.5x a 'val' one) is then identical on every GPU, i.e. per-GPU work is fixed as N
+    # grows (weak scaling) instead of the slowest random mix setting the max-over-ranks time.
     fit = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, P, device=dev, N_rand=8192,
-                        ksplit=args.ksplit, seed=rank, shifts=shifts)
+                        ksplit=args.ksplit, seed=0, shifts=shifts)
+    if world > 1:
+        args.no_extras = True          # the extras (c4 table, end-to-end, ranking, throughput mode) are N = 1 reports
     net = fit.net
     patch = fit.patch_size                                     # loaders.py:133-134 -> 96 at 512^2
     assert patch == patch_size_from_period(periods[0])
@@ -338,7 +350,7 @@ def main():
         # wall time per iteration of the complete loop INCLUDING the host-side sampler (not part of `value`, whose inputs
         # are resident before timing): with the reference's exact NumPy stream and with rng_mode='fast'
         e2e = {}
-        for mode, pf in (("numpy", 0), ("reference", 4), ("fast", 0)):
+        for mode, pf in ((("numpy", 0), ("reference", 4), ("fast", 0)) if world == 1 else ()):
             f4 = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
                                N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode, prefetch=pf)
             for _ in range(20):
@@ -438,7 +450,7 @@ def main():
             "value_per_gpu": value / world,
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
-            "final_gather_ms": gather_ms, "end_to_end_incl_host_sampling": e2e,
+            "final_gather_ms": gather_ms, "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
