@@ -260,11 +260,14 @@ int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, const float
  * C=16 trunk input d_x0 (2*n_p*k images of P x P, value*scale[c] + shift[c]); d_xy (nullable) also
  * receives it as fp32 (2*n_p*k,3,P,P) for the other consumers of the iteration (LPIPS / style
  * trunks); d_zero[0..n_zero) (n_zero <= 256, nullable) is set to 0 -- the iteration's patch-loss
- * accumulator.  Bit-identical to the two separate calls. */
+ * accumulator.  Bit-identical to the two separate calls.  which = 0: both halves (d_x0 holds
+ * 2*n_p*k images); 1: only the prediction half x, 2: only the real half y (d_x0 holds n_p*k
+ * images; d_xy, if given, is still the full [x | y] tensor and receives that half; the inputs
+ * of the other half may be NULL) -- the two halves can then run through the trunk on two streams. */
 int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
                        const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
                        const float scale[3], const float shift[3], void* d_x0, float* d_xy,
-                       float* d_zero, int n_zero, void* stream);
+                       float* d_zero, int n_zero, int which, void* stream);
 
 /* One 3x3 / pad 1 convolution launch on flat tensors (Cin, Cout multiples of 16, <= 512):
  *  mode 0  y = relu(conv(x, w) + bias)                    nn.Conv2d + nn.ReLU

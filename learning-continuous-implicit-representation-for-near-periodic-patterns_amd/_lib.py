@@ -99,7 +99,7 @@ SYMBOLS = {
     "npp_conv_pack": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "npp_trunk_image_in": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
     "npp_trunk_patch_in": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                           _vp, _vp, _vp, _i32, _vp]),
+                           _vp, _vp, _vp, _i32, _i32, _vp]),
     "npp_conv3x3": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                            C.POINTER(C.c_float), _vp]),
     "npp_maxpool2_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

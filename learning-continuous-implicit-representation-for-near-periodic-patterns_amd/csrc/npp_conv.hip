@@ -307,17 +307,20 @@ __global__ void trunk_patch_in_kernel(const float* __restrict__ pred, const floa
                                       const float* __restrict__ fmask, const float* __restrict__ real,
                                       const float* __restrict__ rmask, int n_p, int k, int P, int comp, float s0, float s1,
                                       float s2, float b0, float b1, float b2, f16x8* __restrict__ out, int64_t nposp,
-                                      int64_t npos_round, float* __restrict__ xy, float* __restrict__ zero, int n_zero) {
+                                      int64_t npos_round, float* __restrict__ xy, float* __restrict__ zero, int n_zero,
+                                      int which) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n_zero) zero[p] = 0.0f;
   if (p >= npos_round) return;
   const int Wp = P + 2, S = (P + 2) * Wp, nk = n_p * k;
-  const int n = (int)(p / S), r = (int)(p - (int64_t)n * S), y = r / Wp, x = r - y * Wp;
+  const int nl = (int)(p / S), r = (int)(p - (int64_t)nl * S), y = r / Wp, x = r - y * Wp;
+  const int n_img = which ? nk : 2 * nk;                     // images in the flat tensor
+  const int n = which == 2 ? nl + nk : nl;                   // index in the [x | y] batch
   f16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
   const f16x8 z = o;
-  if (n < 2 * nk && y >= 1 && y <= P && x >= 1 && x <= P) {
+  if (nl < n_img && y >= 1 && y <= P && x >= 1 && x <= P) {
     const int64_t pp = (int64_t)P * P, q = (int64_t)(y - 1) * P + (x - 1);
     const int pk = n < nk ? n : n - nk;
     const float rm = rmask[(int64_t)pk * pp + q];
@@ -548,19 +551,25 @@ extern "C" int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, 
 
 extern "C" int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
                                   const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3],
-                                  const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, void* stream) {
-  if (n_p < 1 || k < 1 || n_zero < 0 || n_zero > 256) { set_error("npp_trunk_patch_in: bad n_p=%d k=%d n_zero=%d", n_p, k, n_zero); return NPP_ERR_ARG; }
-  const int N = 2 * n_p * k;
+                                  const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, int which,
+                                  void* stream) {
+  if (n_p < 1 || k < 1 || n_zero < 0 || n_zero > 256 || which < 0 || which > 2) {
+    set_error("npp_trunk_patch_in: bad n_p=%d k=%d n_zero=%d which=%d", n_p, k, n_zero, which);
+    return NPP_ERR_ARG;
+  }
+  const int N = (which ? 1 : 2) * n_p * k;
   int rc = conv_geom_check(N, P, P, "npp_trunk_patch_in");
   if (rc) return rc;
-  if (!d_pred_rows || !d_real || !d_rmask || !d_x0 || !scale || !shift || (comp && (!d_fake || !d_fmask)) || (n_zero && !d_zero)) {
+  const bool need_x = which != 2, need_y = which != 1;
+  if ((need_x && !d_pred_rows) || (need_y && !d_real) || !d_rmask || !d_x0 || !scale || !shift ||
+      (need_x && comp && (!d_fake || !d_fmask)) || (n_zero && !d_zero)) {
     set_error("npp_trunk_patch_in: null pointer");
     return NPP_ERR_ARG;
   }
   const int64_t nr = conv_npos_round(N, P, P);
   hipLaunchKernelGGL(trunk_patch_in_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pred_rows,
                      d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale[0], scale[1], scale[2], shift[0], shift[1],
-                     shift[2], (f16x8*)d_x0, conv_nposp(N, P, P), nr, d_xy, d_zero, n_zero);
+                     shift[2], (f16x8*)d_x0, conv_nposp(N, P, P), nr, d_xy, d_zero, n_zero, which);
   return check_launch("npp_trunk_patch_in");
 }
 

@@ -251,19 +251,6 @@ class CompletionFit:
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
         ws = net.workspace(bp)
-        net.zero_grad()
-        if self.percepLoss.touched:
-            self.percepLoss.zero_latent_grads()
-        pred = net.forward_train(b["coords"])
-        if ws.get("n_rows") != n:                                # rows >= n never receive a gradient
-            ws["dpred"][n:].zero_()
-            ws["n_rows"] = n
-        main = torch.cuda.current_stream(self.device)
-        # The consumers of the prediction are independent and each under-fills the chip (small grids, dependent
-        # launches): on 'same' iterations the LPIPS branch runs on a side stream next to the contextual branch and
-        # joins before npp_patch_compose_bwd (1.30 -> 1.17 ms).  Measured negative: the 12 us pixel loss on a side stream
-        # costs more in event record / wait than it hides (0.742 -> 0.762 ms per 'val' iteration).
-        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
         raw = b["raw"]
         comp = self.use_comp and source == "val"                 # train.py:230-231
         nk = n_p * k
@@ -273,10 +260,23 @@ class CompletionFit:
             self._xy_key = key
         with_lp = source == "same" and self.use_perceptual_loss
         cx = self.contextualLoss
-        # one launch: patch plumbing -> the contextual trunk's flat fp16 input (normalised), the fp32 batch only when another
-        # trunk of this iteration reads it, and the patch-loss accumulator cleared
-        xy = self._xy if (with_lp or self.style is not None) else None
+        xy = self._xy if (with_lp or self.style is not None) else None      # fp32 batch only when another trunk reads it
         sc, sh = cx.input_norm()
+        main = torch.cuda.current_stream(self.device)
+        net.zero_grad()
+        if self.percepLoss.touched:
+            self.percepLoss.zero_latent_grads()
+        pred = net.forward_train(b["coords"])
+        if ws.get("n_rows") != n:                                # rows >= n never receive a gradient
+            ws["dpred"][n:].zero_()
+            ws["n_rows"] = n
+        # The consumers of the prediction are independent and each under-fills the chip (small grids, dependent
+        # launches): on 'same' iterations the LPIPS branch runs on a side stream next to the contextual branch and
+        # joins before npp_patch_compose_bwd (1.30 -> 1.17 ms).  Measured negative (event record / wait costs more than is
+        # hidden): the 12 us pixel loss on a side stream (0.742 -> 0.762 ms per 'val' iteration); the real half of the
+        # contextual batch through its own trunk instance on a side stream beside the MLP forward (0.767 -> 0.776 ms).
+        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
+        # one launch: patch plumbing -> the contextual trunk's flat fp16 input (normalised) and the patch-loss accumulator cleared
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
                            cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf)
         dx_b = None

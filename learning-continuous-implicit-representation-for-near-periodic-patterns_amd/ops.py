@@ -319,13 +319,16 @@ def trunk_image_in(img, scale, shift, x0):
     check(lib().npp_trunk_image_in(_p(img), N, H, W, s, b, _p(x0), _stream()), "npp_trunk_image_in")
 
 
-def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, x0, xy=None, zero=None):
+def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, x0, xy=None, zero=None, which=0):
     """npp_patch_compose_fwd + npp_trunk_image_in in one launch: [x | y] -> flat trunk input x0 (and fp32 xy when given);
-    zero (small fp32 tensor) is cleared on the way."""
-    _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
-    _req(real, torch.float32, "real", (n_p * k, 3, P, P))
+    zero (small fp32 tensor) is cleared on the way.  which: 0 both halves, 1 prediction half only, 2 real half only
+    (x0 then holds n_p*k images)."""
+    if which != 2:
+        _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
+    if which != 1:
+        _req(real, torch.float32, "real", (n_p * k, 3, P, P))
     _req(rmask, torch.float32, "rmask", (n_p * k, 1, P, P))
-    if comp:
+    if comp and which != 2:
         _req(fake, torch.float32, "fake", (n_p, 3, P, P))
         _req(fmask, torch.float32, "fmask", (n_p, 1, P, P))
     if xy is not None:
@@ -333,7 +336,8 @@ def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, 
     s = (C.c_float * 3)(*[float(v) for v in scale])
     b = (C.c_float * 3)(*[float(v) for v in shift])
     check(lib().npp_trunk_patch_in(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
-                                   _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), _stream()), "npp_trunk_patch_in")
+                                   _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), int(which), _stream()),
+          "npp_trunk_patch_in")
 
 
 def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=None, ctap=0, tap_scale=None):

@@ -336,3 +336,13 @@ def test_fused_patch_in_equals_compose_then_image_in(dev, comp, n_p, k, P):
     c = ops.trunk_alloc(N, 16, P, P, dev)
     ops.trunk_patch_in(pred, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, c)
     assert torch.equal(c.view(torch.int16).reshape(2, -1, 8)[:, G:-G], va[:, G:-G])
+    # the two halves separately (which = 1 / 2) == the corresponding images of the full batch
+    nk, S = n_p * k, (P + 2) * (P + 2)
+    xh, yh = ops.trunk_alloc(nk, 16, P, P, dev), ops.trunk_alloc(nk, 16, P, P, dev)
+    xy2 = torch.full_like(xy_ref, -3.0)
+    ops.trunk_patch_in(pred, fake, fmask, None, rmask, n_p, k, P, comp, scale, shift, xh, xy2, None, which=1)
+    ops.trunk_patch_in(None, None, None, real, rmask, n_p, k, P, False, scale, shift, yh, xy2, None, which=2)
+    assert torch.equal(xy2, xy_ref)
+    vx, vy = xh.view(torch.int16).reshape(2, -1, 8), yh.view(torch.int16).reshape(2, -1, 8)
+    assert torch.equal(vx[:, G:G + nk * S], va[:, G:G + nk * S])
+    assert torch.equal(vy[:, G:G + nk * S], va[:, G + nk * S:G + 2 * nk * S])
