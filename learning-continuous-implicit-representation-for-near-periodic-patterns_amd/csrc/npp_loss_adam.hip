@@ -82,13 +82,17 @@ struct AdamTail {
   float* zero;
   int n_zero;
 };
+// VEC = 4: one float4 per thread and array (n, slab_stride multiples of 4, 16-byte aligned pointers), four slab loads in
+// flight before the (order-preserving, hence bit-identical) summation: the kernel is a pure HBM stream of
+// (n_slabs + 5) * 4 B per parameter.
+template <int VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g,
                                                    int64_t n, int n_slabs, int64_t slab_stride,
                                                    float step_size, float b1, float b2, float inv_sqrt_bc2,
                                                    float eps, const float* __restrict__ hp, AdamTail tail) {
   if (hp) { step_size = hp[0]; inv_sqrt_bc2 = hp[1]; }
-  if ((int64_t)blockIdx.x * blockDim.x >= n) {            // the extra block
+  if ((int64_t)blockIdx.x * blockDim.x * VEC >= n) {      // the extra block
     const int t = threadIdx.x;
     for (int i = t; i < tail.n; i += blockDim.x) {
       const float gi = tail.g[i];
@@ -102,16 +106,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     for (int i = t; i < tail.n_zero; i += blockDim.x) tail.zero[i] = 0.0f;
     return;
   }
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (i >= n) return;
-  float gi = 0.0f;
-  for (int s = 0; s < n_slabs; ++s) gi += g[(int64_t)s * slab_stride + i];
-  const float mi = b1 * m[i] + (1.0f - b1) * gi;
-  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-  p[i] = p[i] - step_size * (mi / denom);
+  auto ld = [&](int sl) { return *(const vec_t*)(g + (int64_t)sl * slab_stride + i); };
+  vec_t gi = (vec_t)(0.0f);
+  int sl = 0;
+  for (; sl + 4 <= n_slabs; sl += 4) {
+    const vec_t a0 = ld(sl), a1 = ld(sl + 1), a2 = ld(sl + 2), a3 = ld(sl + 3);
+    gi += a0; gi += a1; gi += a2; gi += a3;
+  }
+  for (; sl < n_slabs; ++sl) gi += ld(sl);
+  vec_t mi = *(const vec_t*)(m + i), vi = *(const vec_t*)(v + i), pi = *(const vec_t*)(p + i);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float ge = gi[e];
+    const float me = b1 * mi[e] + (1.0f - b1) * ge;
+    const float ve = b2 * vi[e] + (1.0f - b2) * ge * ge;
+    mi[e] = me;
+    vi[e] = ve;
+    const float denom = sqrtf(ve) * inv_sqrt_bc2 + eps;
+    pi[e] = pi[e] - step_size * (me / denom);
+  }
+  *(vec_t*)(m + i) = mi;
+  *(vec_t*)(v + i) = vi;
+  *(vec_t*)(p + i) = pi;
+}
+
+static void adam_launch(float* p, float* m, float* v, const float* g, int64_t n, int n_slabs, int64_t slab_stride,
+                        float step_size, float b1, float b2, float inv_sqrt_bc2, float eps, const float* hp,
+                        const AdamTail& tail, bool with_tail, hipStream_t s) {
+  const bool vec = n % 4 == 0 && slab_stride % 4 == 0 &&
+                   (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0;
+  const int64_t threads = vec ? n / 4 : n;
+  const dim3 grid((unsigned)((threads + 255) / 256 + (with_tail ? 1 : 0)));
+  if (vec)
+    hipLaunchKernelGGL(adam_kernel<4>, grid, dim3(256), 0, s, p, m, v, g, n, n_slabs, slab_stride, step_size, b1, b2,
+                       inv_sqrt_bc2, eps, hp, tail);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, grid, dim3(256), 0, s, p, m, v, g, n, n_slabs, slab_stride, step_size, b1, b2,
+                       inv_sqrt_bc2, eps, hp, tail);
 }
 
 // Gradient of the parameter blob as one tensor (sum of the split-K slabs): what loss.backward() leaves in
@@ -180,9 +214,8 @@ extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
-                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps,
-                     (const float*)nullptr, AdamTail{});
+  adam_launch(d_p, d_m, d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps, nullptr,
+              AdamTail{}, false, (hipStream_t)stream);
   return check_launch("npp_adam_step");
 }
 
@@ -199,9 +232,8 @@ extern "C" int npp_adam_step_net(float* d_p, float* d_m, float* d_v, const float
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const AdamTail tail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
-                     d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps,
-                     (const float*)nullptr, tail);
+  adam_launch(d_p, d_m, d_v, d_gslabs, n, n_slabs, slab_stride, step_size, beta1, beta2, inv_sqrt_bc2, eps, nullptr, tail,
+              true, (hipStream_t)stream);
   return check_launch("npp_adam_step_net");
 }
 
@@ -212,8 +244,8 @@ extern "C" int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float
     set_error("npp_adam_step_dev: bad arguments");
     return NPP_ERR_ARG;
   }
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_p, d_m,
-                     d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp, AdamTail{});
+  adam_launch(d_p, d_m, d_v, d_gslabs, n, n_slabs, slab_stride, 0.0f, beta1, beta2, 0.0f, eps, d_hp, AdamTail{}, false,
+              (hipStream_t)stream);
   return check_launch("npp_adam_step_dev");
 }
 
