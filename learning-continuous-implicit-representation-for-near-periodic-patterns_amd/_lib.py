@@ -124,6 +124,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NppError(f"{LIB_PATH} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
                        "there is no CPU fallback")
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library
+    # is loaded, so that the library's dependency resolves to the same runtime instance torch allocates memory and creates
+    # streams with; loaded the other way round, the system runtime comes in first and the library's launches fail with
+    # "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+    import torch  # noqa: F401
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:
