@@ -325,8 +325,29 @@ def main():
         t_r = timed(lambda: net4.render(grid), reps=3)
         out["render_1024sq_bf16"] = {"ms": t_r * 1e3, "pixels_per_s": grid.shape[0] / t_r,
                                      "TFLOP_per_s": 2 * fwd_macs * grid.shape[0] / t_r / 1e12}
+        # the same render in exact fp32 (config c4's arithmetic): materialised fp32 table -> generic dense-layer kernels
+        # (v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s), in chunks of 131072 rows to bound the 5.5 KB/row table
+        from npp_amd.dense import DenseNPPNet
+        dn = DenseNPPNet(22, 44, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=256, freq_nerf=21, activation="snake", device=dev)
+        dn.load_state_dict({k_: torch.from_numpy(v_) for k_, v_ in syn.init_params(3, seed=0).items()}, strict=False)
+
+        def render_fp32():
+            outs = []
+            with torch.no_grad():
+                for a_ in range(0, grid.shape[0], 131072):
+                    emb = ops.embed_fwd(grid[a_:a_ + 131072], cfg4, torch.float32, precise=False)
+                    outs.append(torch.sigmoid(dn(None, emb)))
+            return torch.cat(outs, 0)
+        ref32 = render_fp32()
+        t_r32 = timed(render_fp32, reps=2)
+        d32 = (net4.render(grid) - ref32).abs()
+        out["render_1024sq_fp32_dense"] = {"ms": t_r32 * 1e3, "pixels_per_s": grid.shape[0] / t_r32,
+                                           "TFLOP_per_s": 2 * fwd_macs * grid.shape[0] / t_r32 / 1e12,
+                                           "frac_of_fp32_mfma_peak": 2 * fwd_macs * grid.shape[0] / t_r32 / 1e12 / 157.3,
+                                           "max_abs_diff_vs_bf16_fused": float(d32.max()),
+                                           "psnr_vs_bf16_fused_dB": float(-10.0 * torch.log10((d32.double() ** 2).mean()))}
         c4 = out
-        del grid
+        del grid, ref32, d32
 
     # ---- per patch-source cost of the complete iteration (device + host enqueue, same pool) ----
     per_source = None
