@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
-    ap.add_argument("--ksplit", type=int, default=12)
+    ap.add_argument("--ksplit", type=int, default=0, help="split-K of the weight-gradient launch; 0 = auto (CUs / tiles)")
     ap.add_argument("--graph", action="store_true", help="(mlp-only extra) replay one captured HIP graph per iteration (measured: no gain, the eager launches already run ahead of the GPU)")
     ap.add_argument("--pool", type=int, default=20, help="pre-drawn sampler outputs the timed steps cycle through")
     return ap.parse_args()
@@ -277,7 +277,7 @@ def main():
     n_par = net.n_params
     hbm_bytes = {"mlp_fwd_train": bp * (8 + 12 + 2 * (z_cols + lin_cols + emb_cols)) + 2.4e6,
                  "mlp_bwd_chain": bp * (24 + 2 * z_cols + 2 * dz_cols) + 1.5e6,
-                 "mlp_wgrad": bp * 2 * wjob_rows + 4 * n_par * args.ksplit}
+                 "mlp_wgrad": bp * 2 * wjob_rows + 4 * n_par * net.ksplit}
     dom = max(flops, key=lambda k: kt[k])
     tf = {k: flops[k] / kt[k] / 1e12 for k in flops}
     gbs = {k: hbm_bytes[k] / kt[k] / 1e9 for k in flops}
@@ -462,7 +462,7 @@ def main():
                                    f"step = 1 complete optimisation iteration (train.py:133-264) over {n_pix} pixel rows + "
                                    f"2x{patch}^2 patch rows: fused embed+MLP fwd, adaptive robust pixel loss, patch plumbing, "
                                    f"VGG19 trunk + contextual loss + trunk dgrad (+ VGG16/LPIPS on 'same'), bwd chain, wgrad, Adam",
-                       "rows_per_step": n_rows, "image": [H, H], "K": K, "width": 256, "ksplit": args.ksplit,
+                       "rows_per_step": n_rows, "image": [H, H], "K": K, "width": 256, "ksplit": net.ksplit,
                        "images_per_gpu": 1, "patch_size": patch, "patch_source_mix_in_pool": mix,
                        "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate"},
             "mlp_only_step": {"ms_per_step": mlp_ms, "rows_per_s": n_rows / (mlp_ms * 1e-3),

@@ -135,6 +135,11 @@ int npp_mlp_bwd_act(const float* d_dout, const float* d_out, int64_t Bp, int K, 
 int npp_mlp_wgrad(const void* d_dzF, const void* d_actF, int64_t Bp, int K, int width,
                   int ksplit, float* d_gslabs, void* stream);
 
+/* Output tiles (256 x 256) of the grouped weight-gradient launch for K proposals: the launch has
+ * tiles x ksplit workgroups of one per CU, so ksplit = CUs / tiles fills the chip in one round
+ * (K = 3: 21 tiles -> 12 on 256 CUs; K = 5: 25 -> 10; K = 1: 14 -> 18). */
+int npp_mlp_wgrad_tiles(int K);
+
 /* d_grad[n] (+)= sum of the slabs: the parameter gradient as one blob, for optimisers other than
  * npp_adam_step (the reference hands model.parameters() to torch.optim.Adam, helpers.py:164). */
 int npp_grad_reduce(const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t n,

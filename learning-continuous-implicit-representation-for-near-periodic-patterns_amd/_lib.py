@@ -62,6 +62,7 @@ SYMBOLS = {
     "npp_mlp_fwd": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_mlp_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "npp_mlp_wgrad_tiles": (_i32, [_i32]),
     "npp_pixel_loss": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_mlp_fwd_emb": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -254,6 +254,12 @@ static int build_jobs(int K, WArgs& A) {
 
 using namespace npp;
 
+extern "C" int npp_mlp_wgrad_tiles(int K) {
+  if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_wgrad_tiles: K=%d", K); return NPP_ERR_ARG; }
+  WArgs A{};
+  return build_jobs(K, A);
+}
+
 extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width, int ksplit,
                              float* d_gslabs, void* stream) {
   if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_wgrad: K=%d", K); return NPP_ERR_ARG; }

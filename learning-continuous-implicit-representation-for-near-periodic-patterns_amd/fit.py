@@ -19,7 +19,7 @@ from .losses import ContextualLoss, LPIPS
 
 class CompletionFit:
     def __init__(self, img, mask, angles_deg, periods, freqs, params, device="cuda", N_rand=8192,
-                 ksplit=4, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
+                 ksplit=None, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",

@@ -20,7 +20,7 @@ class NPPNet:
     (models/networks.py:40-49): the blob is the reference's tensors back to back.
     """
 
-    def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=4,
+    def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=None,
                  lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5)):
         self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
         self.K = int(self.cfg.K)
@@ -40,7 +40,7 @@ class NPPNet:
         self._loss_idx = 0
         self._clean = False
         self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
-        self.ksplit = int(ksplit)
+        self.ksplit = int(ksplit) if ksplit else ops.auto_ksplit(self.K, self.device)   # None / 0: one round of workgroups
         self.lrate, self.lrate_decay = float(lrate), int(lrate_decay)
         self.lr = float(lrate)
         self.global_step = 0        # train.py:337

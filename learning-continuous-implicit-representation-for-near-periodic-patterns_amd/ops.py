@@ -180,6 +180,14 @@ def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
                             _stream()), "npp_mlp_bwd")
 
 
+def auto_ksplit(K, device):
+    """Split-K factor that makes the grouped weight-gradient launch (tiles x ksplit workgroups, one per CU) fill the
+    chip in exactly one round."""
+    tiles = check(lib().npp_mlp_wgrad_tiles(K), "npp_mlp_wgrad_tiles")
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    return max(1, min(64, cus // tiles))
+
+
 def mlp_wgrad(dzT, actT, Bp, K, ksplit, gslabs, width=NPP_WIDTH):
     _req(gslabs, torch.float32, "gslabs")
     check(lib().npp_mlp_wgrad(_p(dzT), _p(actT), Bp, K, width, ksplit, _p(gslabs), _stream()), "npp_mlp_wgrad")

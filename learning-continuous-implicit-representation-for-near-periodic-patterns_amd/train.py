@@ -101,7 +101,7 @@ def main(argv=None):
                         num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
                         patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
                         vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
-                        ksplit=12, task=args.task, clear_mask=d["clear_mask"] if remap else None,
+                        task=args.task, clear_mask=d["clear_mask"] if remap else None,
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else 1e-3),
                         style_weight=args.style_weight if remap else None, use_perceptual_loss=not remap)
     name = os.path.basename(os.path.normpath(args.datadir))
