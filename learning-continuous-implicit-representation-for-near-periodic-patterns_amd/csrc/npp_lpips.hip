@@ -12,31 +12,39 @@
 
 namespace npp {
 
-__global__ void lpips_chan_kernel(const float* __restrict__ latents, int C, const float* __restrict__ spline,
-                                  int n_knots, float x_scale, ChanParams* __restrict__ cp) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) cp[c] = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
-}
-
-// Block = 16 positions x 16 channel lanes (thread = position pl, channels cl, cl+16, ...): the deep
-// taps have few positions (6x6) but 512 channels, so the channel axis must be spread over threads
-// (one thread per position took 0.5 ms per call on them).  Blocks are persistent over groups of 16
-// positions.  Phase 1: channel norms (LDS reduction over the 16 channel lanes).  Phase 2: robust NLL of
-// the normalised difference, its derivative (staged in df0), per-channel latent gradients reduced over
-// the 16 positions by shuffles into per-block LDS accumulators.  Phase 3: normalisation backward.
-// One global atomic per channel and block at the very end (the first version issued two per channel and
-// 16-position group: 1152 same-address atomics per latent on the first tap = 60 of its 70 us).
+// Block = 16 positions x 16 channel lanes (thread = position pl, channels cl, cl+16, ...: Q = C/16 per thread): the deep
+// taps have few positions (6x6) but 512 channels, so the channel axis must be spread over threads (one thread per
+// position took 0.5 ms per call on them).  Blocks are persistent over groups of 16 positions.
+// Prologue: the per-channel quantities of the adaptive loss (ChanParams: sigmoid / softplus / spline of the latents) and
+// the lin weights into LDS -- no separate launch, no per-element global reads of them.
+// Per group: the thread's 2 Q feature values are loaded ONCE and stay in registers through the three phases
+// (channel norms -> robust NLL, its derivative and the latent gradients -> normalisation backward); the gradient is
+// written once.  (First version: three global passes over the features, gradient staged in memory, parameters from a
+// separate kernel: 39 us per tap on average.)
+// Latent gradients: reduced over the 16 positions by shuffles into per-block LDS accumulators, one global atomic per
+// channel and block at the very end (a first version issued two per channel and 16-position group: 1152 same-address
+// atomics per latent on the first tap = 60 of its 70 us).
 constexpr int kLpipsMaxC = 512;
+template <int Q>
 __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
-                                                          int N, int C, int hw, const float* __restrict__ lin,
-                                                          const ChanParams* __restrict__ cp, float coef,
-                                                          float* __restrict__ loss, float* __restrict__ df0,
+                                                          int N, int hw, const float* __restrict__ lin,
+                                                          const float* __restrict__ latents,
+                                                          const float* __restrict__ spline, int n_knots, float x_scale,
+                                                          float coef, float* __restrict__ loss, float* __restrict__ df0,
                                                           float* __restrict__ dlatent) {
+  constexpr int C = 16 * Q;
   __shared__ float red[3][16][17];
   __shared__ float tot[4];
-  __shared__ float sdl[2 * kLpipsMaxC];
+  __shared__ float sdl[2 * C];
+  __shared__ ChanParams scp[C];
+  __shared__ float slin[C];
   const int pl = threadIdx.x & 15, cl = threadIdx.x >> 4;
   for (int i = threadIdx.x; i < 2 * C; i += 256) sdl[i] = 0.0f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    scp[c] = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
+    slin[c] = lin[c];
+  }
+  __syncthreads();
   const int64_t npos = (int64_t)N * hw;
   const int64_t ngroups = (npos + 15) / 16;
   float val = 0.0f;
@@ -47,13 +55,19 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     const float* a0 = f0 + (int64_t)n * C * hw + p;
     const float* a1 = f1 + (int64_t)n * C * hw + p;
     float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
+    float u[Q], v[Q], dd[Q];
     float s0 = 0.0f, s1 = 0.0f;
-    if (live)
-      for (int c = cl; c < C; c += 16) {
-        const float u = a0[(int64_t)c * hw], v = a1[(int64_t)c * hw];
-        s0 = fmaf(u, u, s0);
-        s1 = fmaf(v, v, s1);
-      }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int c = cl + 16 * q;
+      u[q] = live ? a0[(int64_t)c * hw] : 0.0f;
+      v[q] = live ? a1[(int64_t)c * hw] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      s0 = fmaf(u[q], u[q], s0);
+      s1 = fmaf(v[q], v[q], s1);
+    }
     __syncthreads();                                      // red[] of the previous group fully consumed
     red[0][cl][pl] = s0;
     red[1][cl][pl] = s1;
@@ -64,21 +78,23 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     const float n0 = sqrtf(s0), n1 = sqrtf(s1);
     const float i0 = 1.0f / (n0 + 1e-10f), i1 = 1.0f / (n1 + 1e-10f);
     float dot = 0.0f;
-    for (int c = cl; c < C; c += 16) {                    // C is a multiple of 16: uniform trip count
-      const ChanParams P = cp[c];
-      const float l = lin[c];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int c = cl + 16 * q;
+      const ChanParams P = scp[c];
+      const float l = slin[c];
       float da = 0.0f, dc = 0.0f;
+      dd[q] = 0.0f;
       if (live) {
-        const float u = a0[(int64_t)c * hw];
-        const float x = u * i0 - a1[(int64_t)c * hw] * i1;
+        const float x = u[q] * i0 - v[q] * i1;
         const float xs = x / P.c, ssx = xs * xs;
         const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
         const float ue = expf(e * lnu), ue1 = ue / uu;
         val += l * ((P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz);
         if (g0) {
-          const float dd = l * coef * (x / (P.c * P.c)) * ue1;          // dL/d(normalised f0)_c
-          g0[(int64_t)c * hw] = dd;
-          dot = fmaf(dd, u, dot);
+          const float d = l * coef * (x / (P.c * P.c)) * ue1;           // dL/d(normalised f0)_c
+          dd[q] = d;
+          dot = fmaf(d, u[q], dot);
           da = l * coef * (-(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) +
                            (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz);
           dc = l * coef * (-(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c);
@@ -104,10 +120,8 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
       for (int q = 0; q < 16; ++q) dot += red[2][q][pl];
       const float se = n0 + 1e-10f;
       const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
-      for (int c = cl; c < C; c += 16) {
-        const float dd = g0[(int64_t)c * hw];                            // written by this very thread above
-        g0[(int64_t)c * hw] = dd * i0 - a0[(int64_t)c * hw] * k;
-      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) g0[(int64_t)(cl + 16 * q) * hw] = dd[q] * i0 - u[q] * k;
     }
   }
   __syncthreads();
@@ -128,18 +142,29 @@ extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)C * sizeof
 extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                                const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
                                float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
-  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || !d_workspace || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 || n_knots < 2) {
+  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 || n_knots < 2) {
     set_error("npp_lpips_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
     return NPP_ERR_ARG;
   }
   if ((d_df0 == nullptr) != (d_dlatent == nullptr)) { set_error("npp_lpips_layer: df0 and dlatent go together"); return NPP_ERR_ARG; }
+  (void)d_workspace;                          // kept in the signature; the per-channel parameters now live in LDS
   hipStream_t s = (hipStream_t)stream;
-  ChanParams* cp = (ChanParams*)d_workspace;
-  hipLaunchKernelGGL(lpips_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, d_latents, C, d_spline, n_knots, x_scale, cp);
   const int64_t nh = (int64_t)N * hw;
   const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
   const int64_t groups = (nh + 15) / 16;
-  hipLaunchKernelGGL(lpips_layer_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, s, d_f0, d_f1, N, C, hw, d_lin,
-                     cp, coef, d_loss, d_df0, d_dlatent);
+  const dim3 grid((unsigned)(groups < 256 ? groups : 256));
+#define NPP_LPIPS_LAUNCH(Q)                                                                                          \
+  case 16 * Q:                                                                                                       \
+    hipLaunchKernelGGL(lpips_layer_kernel<Q>, grid, dim3(256), 0, s, d_f0, d_f1, N, hw, d_lin, d_latents, d_spline, \
+                       n_knots, x_scale, coef, d_loss, d_df0, d_dlatent);                                            \
+    break;
+  switch (C) {
+    NPP_LPIPS_LAUNCH(1) NPP_LPIPS_LAUNCH(2) NPP_LPIPS_LAUNCH(4) NPP_LPIPS_LAUNCH(8) NPP_LPIPS_LAUNCH(12) NPP_LPIPS_LAUNCH(16)
+    NPP_LPIPS_LAUNCH(24) NPP_LPIPS_LAUNCH(32)
+    default:
+      set_error("npp_lpips_layer: C=%d not instantiated (16, 32, 64, 128, 192, 256, 384, 512)", C);
+      return NPP_ERR_UNSUPPORTED;
+  }
+#undef NPP_LPIPS_LAUNCH
   return check_launch("npp_lpips_layer");
 }
