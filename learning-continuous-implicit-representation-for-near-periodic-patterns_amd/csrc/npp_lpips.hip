@@ -24,32 +24,50 @@ namespace npp {
 // Latent gradients: reduced over the 16 positions by shuffles into per-block LDS accumulators, one global atomic per
 // channel and block at the very end (a first version issued two per channel and 16-position group: 1152 same-address
 // atomics per latent on the first tap = 60 of its 70 us).
+// PL positions x CL = 256 / PL channel lanes per block: 16 x 16 for the wide taps; 4 x 64 for the deep ones (512 channels
+// on 12 x 12 / 6 x 6 maps: with 16 positions per block only 18 / 5 blocks exist and every thread walks 32 channels of
+// ~350 VALU instructions each -- 50 us of one serial chain; 4 positions per block quarter both).
+// Per-channel divisions (1/c, 1/c^2, 1/c^3, 1/beta, beta/alpha, 2/alpha^2, alpha/2 / beta^2 ...) are hoisted into the prologue.
 constexpr int kLpipsMaxC = 512;
-template <int Q>
+struct LpChan {
+  float e, inv_c, inv_c2, x2_inv_c3, inv_beta, boa, toa2, e_inv_b2, logc_plus_logz, dlogz, dalpha_dl, dc_dl;
+};
+template <int Q, int PL>
 __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                                           int N, int hw, const float* __restrict__ lin,
                                                           const float* __restrict__ latents,
                                                           const float* __restrict__ spline, int n_knots, float x_scale,
                                                           float coef, float* __restrict__ loss, float* __restrict__ df0,
                                                           float* __restrict__ dlatent) {
-  constexpr int C = 16 * Q;
-  __shared__ float red[3][16][17];
+  constexpr int CL = 256 / PL, C = CL * Q;
+  __shared__ float red[3][CL][PL + 1];
   __shared__ float tot[4];
   __shared__ float sdl[2 * C];
-  __shared__ ChanParams scp[C];
+  __shared__ LpChan scp[C];
   __shared__ float slin[C];
-  const int pl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int pl = threadIdx.x % PL, cl = threadIdx.x / PL;
   for (int i = threadIdx.x; i < 2 * C; i += 256) sdl[i] = 0.0f;
   for (int c = threadIdx.x; c < C; c += 256) {
-    scp[c] = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
+    const ChanParams P = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
+    LpChan L;
+    L.e = 0.5f * P.alpha;
+    L.inv_c = 1.0f / P.c;
+    L.inv_c2 = 1.0f / (P.c * P.c);
+    L.x2_inv_c3 = 1.0f / (P.c * P.c * P.c);
+    L.inv_beta = 1.0f / P.beta;
+    L.boa = P.beta / P.alpha;
+    L.toa2 = 2.0f / (P.alpha * P.alpha);
+    L.e_inv_b2 = L.e / (P.beta * P.beta);
+    L.logc_plus_logz = P.logc_plus_logz; L.dlogz = P.dlogz; L.dalpha_dl = P.dalpha_dl; L.dc_dl = P.dc_dl;
+    scp[c] = L;
     slin[c] = lin[c];
   }
   __syncthreads();
   const int64_t npos = (int64_t)N * hw;
-  const int64_t ngroups = (npos + 15) / 16;
+  const int64_t ngroups = (npos + PL - 1) / PL;
   float val = 0.0f;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t t = grp * 16 + pl;
+    const int64_t t = grp * PL + pl;
     const bool live = t < npos;
     const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
     const float* a0 = f0 + (int64_t)n * C * hw + p;
@@ -59,7 +77,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int c = cl + 16 * q;
+      const int c = cl + CL * q;
       u[q] = live ? a0[(int64_t)c * hw] : 0.0f;
       v[q] = live ? a1[(int64_t)c * hw] : 0.0f;
     }
@@ -73,36 +91,35 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     red[1][cl][pl] = s1;
     __syncthreads();
     s0 = 0.0f; s1 = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { s0 += red[0][q][pl]; s1 += red[1][q][pl]; }
+#pragma unroll 16
+    for (int q = 0; q < CL; ++q) { s0 += red[0][q][pl]; s1 += red[1][q][pl]; }
     const float n0 = sqrtf(s0), n1 = sqrtf(s1);
     const float i0 = 1.0f / (n0 + 1e-10f), i1 = 1.0f / (n1 + 1e-10f);
     float dot = 0.0f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int c = cl + 16 * q;
-      const ChanParams P = scp[c];
+      const int c = cl + CL * q;
+      const LpChan P = scp[c];
       const float l = slin[c];
       float da = 0.0f, dc = 0.0f;
       dd[q] = 0.0f;
       if (live) {
         const float x = u[q] * i0 - v[q] * i1;
-        const float xs = x / P.c, ssx = xs * xs;
-        const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
-        const float ue = expf(e * lnu), ue1 = ue / uu;
-        val += l * ((P.beta / P.alpha) * (ue - 1.0f) + P.logc_plus_logz);
+        const float xs = x * P.inv_c, ssx = xs * xs;
+        const float uu = fmaf(ssx, P.inv_beta, 1.0f), lnu = __logf(uu);
+        const float ue = __expf(P.e * lnu), ue1 = ue / uu;
+        val += l * (P.boa * (ue - 1.0f) + P.logc_plus_logz);
         if (g0) {
-          const float d = l * coef * (x / (P.c * P.c)) * ue1;           // dL/d(normalised f0)_c
+          const float d = l * coef * (x * P.inv_c2) * ue1;              // dL/d(normalised f0)_c
           dd[q] = d;
           dot = fmaf(d, u[q], dot);
-          da = l * coef * (-(2.0f / (P.alpha * P.alpha)) * (ue - 1.0f) +
-                           (P.beta / P.alpha) * ue * (0.5f * lnu + e * ssx / (P.beta * P.beta * uu)) + P.dlogz);
-          dc = l * coef * (-(x * x) / (P.c * P.c * P.c) * ue1 + 1.0f / P.c);
+          da = l * coef * (-P.toa2 * (ue - 1.0f) + P.boa * ue * (0.5f * lnu + P.e_inv_b2 * ssx / uu) + P.dlogz);
+          dc = l * coef * (-(x * x) * P.x2_inv_c3 * ue1 + P.inv_c);
         }
       }
       if (df0) {                                                         // uniform branch
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {                          // the 16 positions of this channel lane
+        for (int off = PL / 2; off > 0; off >>= 1) {                     // the PL positions of this channel lane
           da += __shfl_xor(da, off, 64);
           dc += __shfl_xor(dc, off, 64);
         }
@@ -116,12 +133,12 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     __syncthreads();
     if (g0 && live) {
       dot = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dot += red[2][q][pl];
+#pragma unroll 16
+      for (int q = 0; q < CL; ++q) dot += red[2][q][pl];
       const float se = n0 + 1e-10f;
       const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
 #pragma unroll
-      for (int q = 0; q < Q; ++q) g0[(int64_t)(cl + 16 * q) * hw] = dd[q] * i0 - u[q] * k;
+      for (int q = 0; q < Q; ++q) g0[(int64_t)(cl + CL * q) * hw] = dd[q] * i0 - u[q] * k;
     }
   }
   __syncthreads();
@@ -151,19 +168,37 @@ extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int 
   hipStream_t s = (hipStream_t)stream;
   const int64_t nh = (int64_t)N * hw;
   const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
-  const int64_t groups = (nh + 15) / 16;
+  const bool few = nh <= 1024 && (C % 64) == 0;           // deep taps: 4 positions x 64 channel lanes per block
+  const int PLr = few ? 4 : 16;
+  const int64_t groups = (nh + PLr - 1) / PLr;
   const dim3 grid((unsigned)(groups < 256 ? groups : 256));
-#define NPP_LPIPS_LAUNCH(Q)                                                                                          \
-  case 16 * Q:                                                                                                       \
-    hipLaunchKernelGGL(lpips_layer_kernel<Q>, grid, dim3(256), 0, s, d_f0, d_f1, N, hw, d_lin, d_latents, d_spline, \
-                       n_knots, x_scale, coef, d_loss, d_df0, d_dlatent);                                            \
-    break;
-  switch (C) {
-    NPP_LPIPS_LAUNCH(1) NPP_LPIPS_LAUNCH(2) NPP_LPIPS_LAUNCH(4) NPP_LPIPS_LAUNCH(8) NPP_LPIPS_LAUNCH(12) NPP_LPIPS_LAUNCH(16)
-    NPP_LPIPS_LAUNCH(24) NPP_LPIPS_LAUNCH(32)
-    default:
-      set_error("npp_lpips_layer: C=%d not instantiated (16, 32, 64, 128, 192, 256, 384, 512)", C);
-      return NPP_ERR_UNSUPPORTED;
+#define NPP_LPIPS_LAUNCH(Q, PL)                                                                                      \
+  hipLaunchKernelGGL((lpips_layer_kernel<Q, PL>), grid, dim3(256), 0, s, d_f0, d_f1, N, hw, d_lin, d_latents,       \
+                     d_spline, n_knots, x_scale, coef, d_loss, d_df0, d_dlatent)
+  if (few) {
+    switch (C) {
+      case 64: NPP_LPIPS_LAUNCH(1, 4); break;
+      case 128: NPP_LPIPS_LAUNCH(2, 4); break;
+      case 192: NPP_LPIPS_LAUNCH(3, 4); break;
+      case 256: NPP_LPIPS_LAUNCH(4, 4); break;
+      case 384: NPP_LPIPS_LAUNCH(6, 4); break;
+      case 512: NPP_LPIPS_LAUNCH(8, 4); break;
+      default: set_error("npp_lpips_layer: C=%d not instantiated", C); return NPP_ERR_UNSUPPORTED;
+    }
+  } else {
+    switch (C) {
+      case 16: NPP_LPIPS_LAUNCH(1, 16); break;
+      case 32: NPP_LPIPS_LAUNCH(2, 16); break;
+      case 64: NPP_LPIPS_LAUNCH(4, 16); break;
+      case 128: NPP_LPIPS_LAUNCH(8, 16); break;
+      case 192: NPP_LPIPS_LAUNCH(12, 16); break;
+      case 256: NPP_LPIPS_LAUNCH(16, 16); break;
+      case 384: NPP_LPIPS_LAUNCH(24, 16); break;
+      case 512: NPP_LPIPS_LAUNCH(32, 16); break;
+      default:
+        set_error("npp_lpips_layer: C=%d not instantiated (16, 32, 64, 128, 192, 256, 384, 512)", C);
+        return NPP_ERR_UNSUPPORTED;
+    }
   }
 #undef NPP_LPIPS_LAUNCH
   return check_launch("npp_lpips_layer");
