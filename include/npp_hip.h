@@ -223,7 +223,9 @@ int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, f
 /* Replaces, for tap kk, lpips.py:99-121 + :130 (normalize_tensor, per-channel robust NLL of
  * the difference, lin 1x1 conv, spatial mean) and its backward.  feats (N,C,hw) fp32 NCHW;
  * d_latents [alpha(C) | scale(C)]; d_loss[0] += scale * mean_n(...); d_df0 (N,C,hw) and
- * d_dlatent [2C] (accumulated) may both be NULL for forward only. */
+ * d_dlatent [2C] (accumulated) may both be NULL for forward only.  C in {16, 32, 64, 128, 192,
+ * 256, 384, 512}.  d_workspace is no longer used (the per-channel loss parameters are derived in
+ * the kernel's prologue); it stays in the signature, NULL is accepted. */
 int64_t npp_lpips_workspace_bytes(int C);
 int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
                     const float* d_lin, const float* d_latents, const float* d_spline,
