@@ -116,12 +116,49 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
                       f"NumPy fp32 oracle, BLAS threads = all host cores"}
 
 
+def dry_run_dist(args, rank, world):
+    """NPP_BENCH_DRYRUN=1: the launch / rendezvous / gather skeleton of the N-rank run without a GPU (gloo), for the CPU
+    test of the `--gpus N` spawn path (tests/test_bench_spawn.py).  No kernel runs and nothing is measured."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == args.gpus == world
+    mine = torch.full((4, 4, 3), float(rank))
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": "gloo", "collective_ranks": dist.get_world_size(),
+                          "gathered": [float(b[0, 0, 0]) for b in bufs], "max_over_ranks": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run, rendezvous on
+        # 127.0.0.1) BEFORE anything in this process touches the GPU, and exit with their code.
+        # torch.cuda.device_count() does not initialise HIP on this image.
+        from npp_amd.parallel import launch_ranks
+        dry = os.environ.get("NPP_BENCH_DRYRUN") == "1"
+        shared_card = "NPP_BENCH_DEVICE" in os.environ           # rehearsal: all ranks on one card, gloo (see below)
+        n_dev = torch.cuda.device_count()
+        if not dry and not shared_card and n_dev < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but this node exposes {n_dev} GPU(s); refusing to report an "
+                     f"N={args.gpus} line from fewer devices")
+        sys.exit(launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or run `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
+    if os.environ.get("NPP_BENCH_DRYRUN") == "1":
+        return dry_run_dist(args, rank, world)
     dist = None
+    backend = None
     if "WORLD_SIZE" in os.environ and "RANK" in os.environ:      # launched by torch.distributed.run (any N >= 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -130,11 +167,14 @@ def main():
         backend = os.environ.get("NPP_BENCH_BACKEND", "nccl")
         if "NPP_BENCH_DEVICE" in os.environ:
             local = int(os.environ["NPP_BENCH_DEVICE"])
+        elif local >= torch.cuda.device_count():
+            sys.exit(f"bench.py: rank {rank} has LOCAL_RANK {local} but the node exposes {torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dist is not None else 0)
@@ -189,8 +229,12 @@ def main():
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [n_rows * args.steps / float(x.item()) for x in allt]       # rows/s of every rank's own loop
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -471,7 +515,10 @@ def main():
             "value_per_gpu": value / world,
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
-            "final_gather_ms": gather_ms, "end_to_end_incl_host_sampling": e2e or None,
+            "final_gather_ms": gather_ms, "per_rank_rows_per_s": per_rank,
+            "collective": None if dist is None else {"backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+                                                     "ranks": dist.get_world_size()},
+            "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,

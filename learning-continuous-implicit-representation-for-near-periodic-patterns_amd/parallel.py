@@ -49,3 +49,26 @@ def gather_unit_scalars(stats, n_units, group=None):
     dist.all_gather(got, pad, group=group)
     rows = [got[r][:len(shard_units(n_units, r, world))] for r in range(world)]
     return torch.cat(rows, 0)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script, n_ranks, argv, env=None, timeout=None):
+    """Start `script` as n_ranks processes of ONE node under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1) and return its exit code.  The CALLER must not have touched the GPU: the ranks are fresh child processes
+    (a process that has initialised HIP is never re-executed).  Replaces nn.DataParallel at models/helpers.py:135-137."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver (RCCL needs it)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode

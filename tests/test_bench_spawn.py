@@ -1,0 +1,56 @@
+"""`python bench.py --gpus N` must start N ranks itself.  CPU coverage of that spawn path: the dry-run mode
+runs bench.py's own launcher + rendezvous + gather skeleton over gloo without a GPU; the mismatch cases must exit non-zero
+instead of silently reporting one rank."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(kw)
+    return e
+
+
+def test_bench_gpus2_spawns_two_ranks_gloo_dryrun():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(NPP_BENCH_DRYRUN="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                      # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["collective_ranks"] == 2
+    assert j["gathered"] == [0.0, 1.0] and j["max_over_ranks"] == 2.0
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """No GPU in this container: `--gpus 2` without the dry-run knob must fail loudly, not print an N=1 line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("node has >= 2 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_refuses_world_size_mismatch():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_launch_ranks_helper_returns_child_code(tmp_path):
+    sys.path.insert(0, ROOT)
+    from npp_amd.parallel import launch_ranks
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os, torch.distributed as d\nd.init_process_group('gloo')\nassert d.get_world_size() == 2\n"
+                  "d.barrier()\nd.destroy_process_group()\n")
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys\nsys.exit(3)\n")
+    assert launch_ranks(str(ok), 2, [], timeout=240) == 0
+    assert launch_ranks(str(bad), 2, [], timeout=240) != 0
