@@ -15,7 +15,7 @@
 #include <stdint.h>
 #include "npp_hip.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NPP_HD __host__ __device__ inline
 #else
 #define NPP_HD inline
