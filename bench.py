@@ -47,28 +47,42 @@ def parse():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
     ap.add_argument("--ksplit", type=int, default=0, help="split-K of the weight-gradient launch; 0 = auto (CUs / tiles)")
-    ap.add_argument("--graph", action="store_true", help="(mlp-only extra) replay one captured HIP graph per iteration (measured: no gain, the eager launches already run ahead of the GPU)")
     ap.add_argument("--pool", type=int, default=20, help="pre-drawn sampler outputs the timed steps cycle through")
     return ap.parse_args()
 
 
 def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
-    """The oracle (NumPy fp32 port of the reference path) timed on this host's cores on a bounded sample of the
-    same workload: COMPLETE iterations -- embed + MLP forward + robust loss + backward + Adam over the
-    n_pix + n_p * patch^2 rows (in 2048-row chunks), plus per iteration the VGG19[0:18] trunk on the 2 * n_p * k
-    patches (im2col + SGEMM), the contextual loss with its closed-form backward and the trunk data-gradient for
-    the n_p * k predicted patches; every 5th iteration also the VGG16 trunk + LPIPS head on 2 * n_p patches
-    ('same' iterations: 20 %)."""
+    """The CPU restatement of the same workload timed on this host's cores, on a bounded sample:
+    leg A -- the MLP half (embed + NPP_Net forward + robust pixel loss + backward + Adam) of WHOLE iterations
+    (all n_pix + n_p * patch^2 rows at once) in PyTorch-CPU fp32 with autograd, torch.set_num_threads(all cores)
+    (oracle/npp_torch_oracle.py, pinned to the NumPy oracle by tests/test_oracle_torch.py);
+    leg B -- the patch-loss half per iteration in the NumPy oracle (VGG19[0:18] trunk on the 2 * n_p * k patches as
+    im2col + SGEMM, contextual loss with its closed-form backward, trunk data-gradient; every 5th iteration also the
+    VGG16 trunk + LPIPS head on 2 * n_p patches, the 20 % 'same' iterations).
+    value = rows of one iteration / (leg A time + leg B time per iteration)."""
     import oracle
+    from oracle import npp_torch_oracle as T
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
     img, mask = oracle.synthetic_image(H)
-    P = oracle.init_params(K, seed=0)
-    st = oracle.adam_init(P)
     rng = np.random.RandomState(0)
-    rows, total = 2048, n_pix + n_p * patch * patch
+    total = n_pix + n_p * patch * patch
     la = np.full((1, 3), 2.3841858e-07, np.float32)
     ls = np.zeros((1, 3), np.float32)
+    # ---- leg A: MLP half, torch, whole batch
+    Pt = T.params_t(oracle.init_params(K, seed=0))
+    opt = torch.optim.Adam(list(Pt.values()), lr=5e-4, betas=(0.9, 0.999))
+    c = np.stack([rng.randint(0, H, total), rng.randint(0, H, total)], 1)
+    ct, gt = torch.from_numpy(c), img[c[:, 0], c[:, 1]]
+    T.train_step_t(Pt, opt, ct, gt, angles, periods, oracle.SEED0_FREQS, (H, H), K, la, ls)        # warm-up
+    n_a, t0 = 0, time.time()
+    while time.time() - t0 < seconds_target * 0.5:
+        T.train_step_t(Pt, opt, ct, gt, angles, periods, oracle.SEED0_FREQS, (H, H), K, la, ls)
+        n_a += 1
+    t_a = (time.time() - t0) / n_a
 
+    # ---- leg B: patch-loss half, NumPy oracle
     def weights(cfg):
         ws_, cin = [], 3
         for v in cfg:
@@ -78,42 +92,32 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
         return ws_
     w19, w16 = weights(oracle.VGG19_CX_CFG), weights(oracle.VGG16_LPIPS_CFG)
     chns = [64, 128, 256, 512, 512]
-    lins = [np.abs(rng.randn(c)).astype(np.float32) * 0.05 for c in chns]
-    lat_a = [np.full((1, c), 2.3841858e-07, np.float32) for c in chns]
-    lat_s = [np.zeros((1, c), np.float32) for c in chns]
-    iters, t0 = 0, time.time()
+    lins = [np.abs(rng.randn(c_)).astype(np.float32) * 0.05 for c_ in chns]
+    lat_a = [np.full((1, c_), 2.3841858e-07, np.float32) for c_ in chns]
+    lat_s = [np.zeros((1, c_), np.float32) for c_ in chns]
+    n_b, t1 = 0, time.time()
     while True:
-        done = 0
-        while done < total:                                        # the MLP half, chunked
-            r = min(rows, total - done)
-            c = np.stack([rng.randint(0, H, r), rng.randint(0, H, r)], 1)
-            emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
-            raw, cache = oracle.mlp_forward(P, emb, K)
-            pr = oracle.sigmoid(raw)
-            _, dpred, _, _ = oracle.img2mse_grads(pr, img[c[:, 0], c[:, 1]], la, ls)
-            G = oracle.mlp_backward(P, cache, dpred * pr * (1 - pr))
-            done += r
-        oracle.adam_step(P, G, st, 5e-4)
-        nk = n_p * k                                               # the patch-loss half
+        nk = n_p * k
         xy = rng.rand(2 * nk, 3, patch, patch).astype(np.float32)
         f, cache = oracle.trunk_forward(xy, oracle.VGG19_CX_CFG, w19, oracle.VGG19_CX_TAPS, gemm=True)
         _, dfx = oracle.cx_backward(f[0][:nk], f[0][nk:])
         cache_x = [(c_[0], (nk,) + tuple(c_[1][1:]), c_[2][:nk]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:nk]) for c_ in cache]
         oracle.trunk_backward(oracle.VGG19_CX_CFG, cache_x, oracle.VGG19_CX_TAPS, [dfx], gemm=True)
-        if iters % 5 == 2:
+        if n_b % 5 == 2:
             xy2 = xy[:2 * n_p]
             f, cache = oracle.trunk_forward(xy2, oracle.VGG16_LPIPS_CFG, w16, oracle.VGG16_LPIPS_TAPS, gemm=True)
             _, dfs, _, _ = oracle.lpips_head_grads([t[:n_p] for t in f], [t[n_p:] for t in f], lins, lat_a, lat_s)
             cache_x = [(c_[0], (n_p,) + tuple(c_[1][1:]), c_[2][:n_p]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:n_p]) for c_ in cache]
             oracle.trunk_backward(oracle.VGG16_LPIPS_CFG, cache_x, oracle.VGG16_LPIPS_TAPS, dfs, gemm=True)
-        iters += 1
-        if time.time() - t0 > seconds_target:
+        n_b += 1
+        if time.time() - t1 > seconds_target * 0.5 and n_b >= 5:
             break
-    dt = time.time() - t0
-    return {"value": iters * total / dt, "unit": "rows/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{iters} complete iterations of {total} rows (MLP half in {rows}-row chunks; VGG19 trunk + contextual loss "
-                      f"on {2 * n_p * k} {patch}x{patch} patches every iteration, VGG16 + LPIPS head every 5th) in {dt:.1f}s, "
-                      f"NumPy fp32 oracle, BLAS threads = all host cores"}
+    t_b = (time.time() - t1) / n_b
+    return {"value": total / (t_a + t_b), "unit": "rows/s", "cores": cores, "kind": "port",
+            "mlp_half_rows_per_s": total / t_a, "mlp_half_s_per_iteration": t_a, "patch_half_s_per_iteration": t_b,
+            "sample": f"{n_a} MLP-half steps of {total} rows (PyTorch-CPU fp32 autograd, {cores} threads, whole batch) in {n_a * t_a:.1f}s + "
+                      f"{n_b} patch-loss halves (NumPy oracle: VGG19 trunk + contextual loss on {2 * n_p * k} {patch}x{patch} patches, "
+                      f"VGG16 + LPIPS head every 5th) in {n_b * t_b:.1f}s"}
 
 
 def dry_run_dist(args, rank, world):
@@ -203,11 +207,17 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before timing: the sampler's output for `pool` iterations
     #      (train.py:152-181: sample_patches -> pixel draw), in the reference's RNG order ----
+    # The pool holds the sampler's expected patch-source mix EXACTLY (50 / 30 / 20 % val / train / same, sampler.py:297-354):
+    # draws arrive in the reference's RNG order and fill per-source quotas ('same' iterations cost ~1.5x a 'val' one, so a
+    # short pool's random mix would move the headline by a few per cent either way).
+    quota = {"val": args.pool // 2, "train": (args.pool * 3) // 10, "same": 0}
+    quota["same"] = args.pool - quota["val"] - quota["train"]
     pool = []
     while len(pool) < args.pool:
         b = fit.sample_batch()
-        if b is not None:                                      # k == 0 -> the reference skips the iteration (train.py:160-161)
+        if b is not None and quota[b["source"]] > 0:           # k == 0 -> the reference skips the iteration (train.py:160-161)
             assert b["n"] == n_rows and b["bp"] == bp
+            quota[b["source"]] -= 1
             pool.append(b)
     mix = {s_: sum(b["source"] == s_ for b in pool) for s_ in ("val", "train", "same")}
     ws = net.workspace(bp)
@@ -252,12 +262,6 @@ def main():
         net.pixel_loss(bp, n_rows, gt)                          # every row carries the pixel loss here
         net.backward(bp)
         net.optimizer_step(bp)
-
-    if args.graph:
-        graphs = [net.capture_step(c, n_rows, gt) for c, gt in batches]
-
-        def mlp_step(i):                      # noqa: F811  -- graph replay of the same iteration
-            net.replay_step(graphs[i % n_batches])
 
     for i in range(10):
         mlp_step(i)
@@ -325,28 +329,39 @@ def main():
     dom = max(flops, key=lambda k: kt[k])
     tf = {k: flops[k] / kt[k] / 1e12 for k in flops}
     gbs = {k: hbm_bytes[k] / kt[k] / 1e9 for k in flops}
-    # the roof that binds the dominant kernel is the one it sits closer to
-    hbm_bound = gbs[dom] / PEAK_HBM_GBS > tf[dom] / PEAK_BF16_TFLOPS
-    measured = None
-    try:     # PMC-measured HBM traffic of the same kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-             # passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), committed under profiles/
+    # SURVEY.md 8(d) declares the MLP forward / backward / weight-gradient kernels MFMA-bound: `roofline` is the FLOP view
+    # (algorithmic FLOPs of 8(d) x rows of one launch / the launch's average duration, against the dense bf16 MFMA peak).
+    # The kernels also stream this design's 16-bit activation / gradient stash through HBM (far more than 8(d)'s
+    # algorithmic 32 B/row): that byte model and the rate it implies are reported beside it as `design_traffic`.
+    measured, mfma_pmc = None, None
+    pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
+               "mlp_wgrad": "npp::wgrad_kernel"}
+    try:     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
+             # doubled per the gfx950 note in MI355X_MICROARCH.md): the newest summary committed under profiles/
         import glob
         pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))[-1]))
-        key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
-               "mlp_wgrad": "npp::wgrad_kernel"}[dom]
-        measured = pm["kernels"][key]["hbm_bytes"]
-    except Exception:
-        pass
-    roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
-                "achieved": gbs[dom] if hbm_bound else tf[dom], "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
-                "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                "frac": gbs[dom] / PEAK_HBM_GBS if hbm_bound else tf[dom] / PEAK_BF16_TFLOPS,
-                "traffic": measured, "algorithmic_bytes_per_launch": hbm_bytes[dom],
+        measured = pm["kernels"][pmc_key[dom]]["hbm_bytes"]
+    except (OSError, IndexError, KeyError, ValueError):
+        measured = None
+    try:     # matrix-pipe busy fraction of the same kernel from SQ_VALU_MFMA_BUSY_CYCLES (tools/pmc_sq.sh), same source
+        import glob
+        pq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))[-1]))
+        mfma_pmc = {k_: pq["kernels"][v_].get("mfma_pipe_busy_frac") for k_, v_ in pmc_key.items() if v_ in pq["kernels"]}
+    except (OSError, IndexError, KeyError, ValueError):
+        mfma_pmc = None
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": tf[dom], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf[dom] / PEAK_BF16_TFLOPS, "traffic": measured,
                 "algorithmic_flops_per_launch": flops[dom], "avg_launch_us": kt[dom] * 1e6,
+                "design_traffic": {"note": "HBM view of the same launch: bytes of this design's stash arrays (every array once "
+                                           "per job), NOT SURVEY 8(d)'s algorithmic bytes (32 B/row + weights)",
+                                   "bytes_per_launch": hbm_bytes[dom], "GB_per_s": gbs[dom], "frac_of_8TBs": gbs[dom] / PEAK_HBM_GBS,
+                                   "survey_8d_algorithmic_bytes_per_step": bp * 32 + 2.4e6 + 28 * n_par},
+                "mfma_pipe_busy_frac_pmc": mfma_pmc,
                 "all_kernels_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
                 "all_kernels_tflops": {k: round(v, 1) for k, v in tf.items()},
-                "all_kernels_hbm_GBs": {k: round(v, 0) for k, v in gbs.items()},
+                "all_kernels_design_traffic_GBs": {k: round(v, 0) for k, v in gbs.items()},
                 "all_kernels_mfma_frac": {k: round(v / PEAK_BF16_TFLOPS, 4) for k, v in tf.items()},
+                "render_mfma_frac": 2 * fwd_macs * H * H / kt["render_fwd_512sq"] / 1e12 / PEAK_BF16_TFLOPS,
                 "mlp_flops_over_full_step_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
     render_px_s = H * H / kt["render_fwd_512sq"]
 
@@ -511,8 +526,10 @@ def main():
                        "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate"},
             "mlp_only_step": {"ms_per_step": mlp_ms, "rows_per_s": n_rows / (mlp_ms * 1e-3),
                               "mlp_mfma_frac": 2 * train_macs * n_rows / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                              "hip_graph": bool(args.graph)},
+                              },
             "value_per_gpu": value / world,
+            "value_incl_sampling": (n_rows / (e2e["same_stream_native_rng_producer_thread"]["ms_per_iter"] * 1e-3)
+                                    if e2e and "same_stream_native_rng_producer_thread" in e2e else None),
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
             "final_gather_ms": gather_ms, "per_rank_rows_per_s": per_rank,

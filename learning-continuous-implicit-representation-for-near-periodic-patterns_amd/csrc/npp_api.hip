@@ -27,6 +27,16 @@ int check_launch(const char* what) {
   return NPP_OK;
 }
 
+bool smem_attr(SmemOnce& once, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&once.done, __ATOMIC_RELAXED) & bit) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  __atomic_fetch_or(&once.done, bit, __ATOMIC_RELAXED);
+  return true;
+}
+
 static const char* kNames[kNumLayers] = {
     "periodic_linears.0", "periodic_linears.1", "periodic_linears.2", "periodic_linears.3",
     "periodic_linears.4", "periodic_linears.5", "periodic_linears.6", "periodic_linears.7",

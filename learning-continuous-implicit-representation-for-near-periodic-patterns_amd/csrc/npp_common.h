@@ -18,6 +18,10 @@ namespace npp {
 // host-side error plumbing (npp_api.cpp)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting of a kernel: each launch site remembers which devices
+// of this process already have it (bit d of the mask), so a second GPU driven from the same process is set up as well.
+struct SmemOnce { unsigned long long done = 0; };
+bool smem_attr(SmemOnce& once, const void* fn, int bytes);
 
 constexpr float kInv2Pi = 0.15915494309189535f;
 
@@ -95,6 +99,10 @@ __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
 #define NPP_STASH_NT 1
 #endif
 __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
+#ifdef NPP_DIAG_NOSTASH      // timing-only diagnostic: the value and its address stay live, the store is not issued
+  asm volatile("" :: "v"(v), "v"(p));
+  return;
+#endif
 #if NPP_STASH_NT
   __builtin_nontemporal_store(v, (bf16x8*)p);
 #else
@@ -111,6 +119,10 @@ __device__ __forceinline__ f16x8 pack_acc_f16(const f32x16& acc, int s) {
   return r;
 }
 __device__ __forceinline__ void stash_store(void* p, const f16x8& v) {
+#ifdef NPP_DIAG_NOSTASH
+  asm volatile("" :: "v"(v), "v"(p));
+  return;
+#endif
 #if NPP_STASH_NT
   __builtin_nontemporal_store(v, (f16x8*)p);
 #else

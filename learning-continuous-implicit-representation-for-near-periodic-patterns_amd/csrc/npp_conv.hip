@@ -582,11 +582,9 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
   const size_t smem = S > 1 ? (size_t)S * CT * PT * 16 * 64 * sizeof(float) : 0;
 #define NPP_CONV_GO(M)                                                                                        \
   do {                                                                                                        \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set && smem > 48 * 1024) {                                                                      \
-      if (hipFuncSetAttribute((const void*)conv3x3_kernel<CT, PT, S, M>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)smem) != hipSuccess) { set_error("npp_conv3x3: smem attribute"); return NPP_ERR_LAUNCH; } \
-      attr_set = true;                                                                                        \
+    static SmemOnce once;                                                                                     \
+    if (smem > 48 * 1024 && !smem_attr(once, (const void*)conv3x3_kernel<CT, PT, S, M>, (int)smem)) {          \
+      set_error("npp_conv3x3: smem attribute"); return NPP_ERR_LAUNCH;                                        \
     }                                                                                                         \
     hipLaunchKernelGGL((conv3x3_kernel<CT, PT, S, M>), grid, dim3(64 * S), smem, s, a);                       \
   } while (0)

@@ -614,13 +614,10 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
   const int t32 = hw / 32;
   if (fast) {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
-    static bool attr_set = false;
+    static SmemOnce once;
     const size_t smem = (size_t)kCxRowWaves * hw * sizeof(float);
-    if (!attr_set && smem > 48 * 1024) {
-      if (hipFuncSetAttribute((const void*)cx_rows_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kCxRowWaves * 64 * kCxMaxCols * 4) != hipSuccess) {
-        set_error("npp_cx_fwd_bwd: smem attribute"); return NPP_ERR_LAUNCH;
-      }
-      attr_set = true;
+    if (smem > 48 * 1024 && !smem_attr(once, (const void*)cx_rows_fwd32_kernel, kCxRowWaves * 64 * kCxMaxCols * 4)) {
+      set_error("npp_cx_fwd_bwd: smem attribute"); return NPP_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(cx_rows_fwd32_kernel, dim3((unsigned)((int64_t)N * ((hw + kCxRowWaves - 1) / kCxRowWaves))), dim3(64 * kCxRowWaves), smem, s, N,
                        hw, inv_h, w);

@@ -232,12 +232,9 @@ static int bwd_launch(const float* d_dpred, const float* d_pred, int64_t Bp, int
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH_B(M)                                                                            \
   do {                                                                                             \
-    static bool attr_set = false;                                                                  \
-    if (!attr_set) {                                                                               \
-      hipError_t ea = hipFuncSetAttribute((const void*)mlp_bwd_kernel<M>,                          \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBwd);   \
-      if (ea != hipSuccess) { set_error("npp_mlp_bwd: smem attr: %s", hipGetErrorString(ea)); return NPP_ERR_LAUNCH; } \
-      attr_set = true;                                                                             \
+    static SmemOnce once;                                                                          \
+    if (!smem_attr(once, (const void*)mlp_bwd_kernel<M>, kSmemBwd)) {                              \
+      set_error("npp_mlp_bwd: smem attribute"); return NPP_ERR_LAUNCH;                             \
     }                                                                                              \
     hipLaunchKernelGGL((mlp_bwd_kernel<M>), grid, block, kSmemBwd, s, A, d, bd);                   \
   } while (0)

@@ -533,12 +533,9 @@ static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, boo
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH(T, M, E)                                                                       \
   do {                                                                                            \
-    static bool attr_set = false;                                                                 \
-    if (!attr_set) {                                                                              \
-      hipError_t ea = hipFuncSetAttribute((const void*)mlp_fwd_kernel<T, M, E>,                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSmemFwd);  \
-      if (ea != hipSuccess) { set_error("%s: smem attr: %s", who, hipGetErrorString(ea)); return NPP_ERR_LAUNCH; } \
-      attr_set = true;                                                                            \
+    static SmemOnce once;                                                                         \
+    if (!smem_attr(once, (const void*)mlp_fwd_kernel<T, M, E>, kSmemFwd)) {                       \
+      set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH;                                \
     }                                                                                             \
     hipLaunchKernelGGL((mlp_fwd_kernel<T, M, E>), grid, block, kSmemFwd, s, A, e, d);             \
   } while (0)

@@ -356,12 +356,8 @@ extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, 
   A.slab_stride = make_desc(K).total_params;
   const int ntiles = build_jobs(K, A);
   A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t ea = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemW);
-    if (ea != hipSuccess) { set_error("npp_mlp_wgrad: smem attr: %s", hipGetErrorString(ea)); return NPP_ERR_LAUNCH; }
-    attr_set = true;
-  }
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)wgrad_kernel, kSmemW)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
   A.ntiles = ntiles; A.ksplit = ksplit;
   hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ntiles * ksplit)), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
   return check_launch("npp_mlp_wgrad");

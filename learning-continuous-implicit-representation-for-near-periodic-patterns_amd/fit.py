@@ -24,7 +24,7 @@ class CompletionFit:
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
-                 vgg16_style_state_dict=None):
+                 vgg16_style_state_dict=None, masked_img=None):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
@@ -44,7 +44,7 @@ class CompletionFit:
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
-        self.device = torch.device(device)
+        self.device = ops.select_device(device)
         valid = np.ones_like(mask) if valid_mask is None else np.asarray(valid_mask, np.float32).reshape(mask.shape)
         self.task = task
         if task == "completion":
@@ -53,7 +53,9 @@ class CompletionFit:
             self.i_train = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
             self.i_val = np.stack(np.nonzero((1 - mask[..., 0]) * valid[..., 0]), 1).astype(np.int32)
             pixel_mask = None                                        # gt_mask = ones (train.py:176)
-            train_img = img * mask                                   # masked_img is what the loop trains on (train.py:173)
+            # masked_img is what the loop trains and samples patches on (train.py:173; the sampler gets masked_img): the file
+            # as loaded when the caller has it (it need not equal gt * mask, e.g. inputs without a clean ground truth)
+            train_img = img * mask if masked_img is None else np.asarray(masked_img, np.float32).reshape(img.shape)
         else:
             # NPP_remapping: the whole valid image is trained on (loaders.py:279), the 'val' pool and the sampler mask are the
             # CLEAR (non-blurry) region (:280; NPP_remapping/train.py:147-155), and the pixel loss weighs blurry pixels 0.3
@@ -248,6 +250,7 @@ class CompletionFit:
         launches (no autograd): fused forward -> pixel loss -> patch plumbing (npp_patch_compose_fwd) -> VGG19 trunk
         -> contextual loss core -> trunk data-gradient (-> the same through VGG16 / LPIPS head on 'same' iterations)
         -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam."""
+        ops.check_current(self.device)
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
         ws = net.workspace(bp)

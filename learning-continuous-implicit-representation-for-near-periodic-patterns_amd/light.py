@@ -30,7 +30,7 @@ class NPPNetLight:
     the reference, never used when len(freq_scales) == 1) are not kept."""
 
     def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500):
-        self.device = torch.device(device)
+        self.device = ops.select_device(device)
         self.res = (int(res[0]), int(res[1]))
         self.W, self.D = int(W), int(D)
         self.freqs = [float(f) for f in np.asarray(freqs).reshape(-1)]
@@ -194,7 +194,7 @@ class ProposalRanker:
                  perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
                  lpips_lin_weights=None, rng_mode="reference"):
         from .losses import ContextualLoss, LPIPS
-        self.device = torch.device(device)
+        self.device = ops.select_device(device)
         self.img = torch.as_tensor(np.asarray(masked_img, np.float32)).to(self.device)               # (H,W,3)
         self.H, self.W_img = self.img.shape[:2]
         self.i_train = np.asarray(i_train).astype(np.int32)

@@ -33,6 +33,42 @@ def _make_features(cfg):
     return nn.Sequential(*layers)
 
 
+_warned_random = set()
+
+
+def _warn_random_trunk(cfg, seed):
+    """No pretrained weights were supplied: the trunk keeps its fixed-seed random init.  That is what the synthetic bench and
+    the parity tests use (the reference's torchvision weights are not available offline); for a real fit it
+    changes the contextual / LPIPS / style losses, so say so once per trunk shape."""
+    key = (tuple(cfg), seed)
+    if key not in _warned_random:
+        _warned_random.add(key)
+        import warnings
+        warnings.warn(f"npp_amd.losses: VGG trunk {len([v for v in cfg if v != 'M'])} convs built with fixed-seed RANDOM weights "
+                      f"(seed {seed}): pass the torchvision state_dict (vgg_state_dict=...) to reproduce the reference's losses",
+                      stacklevel=3)
+
+
+def _trunk_keys(state_dict, features):
+    """A torchvision VGG state_dict restricted to this trunk's layers, as keys of `features` ('<idx>.weight' / '<idx>.bias').
+    Accepts the model's form ('features.<idx>.*', classifier keys ignored) and the form saved from `vgg.features` ('<idx>.*').
+    Raises if a convolution of the trunk is missing or has another shape -- never leaves a layer at its random init."""
+    want = features.state_dict()
+    out, missing = {}, []
+    for k, ref in want.items():
+        v = state_dict.get("features." + k, state_dict.get(k))
+        if v is None:
+            missing.append(k)
+        elif tuple(v.shape) != tuple(ref.shape):
+            raise ValueError(f"VGG state_dict: '{k}' has shape {tuple(v.shape)}, this trunk needs {tuple(ref.shape)}")
+        else:
+            out[k] = v
+    if missing:
+        raise KeyError(f"VGG state_dict lacks {missing[:4]}{'...' if len(missing) > 4 else ''} (expected torchvision keys "
+                       f"'features.<idx>.weight/bias' or '<idx>.weight/bias')")
+    return out
+
+
 class _Trunk(nn.Module):
     def __init__(self, cfg, taps, state_dict=None, seed=1234):
         super().__init__()
@@ -40,8 +76,10 @@ class _Trunk(nn.Module):
         torch.manual_seed(seed)
         self.features = _make_features(cfg)
         torch.random.set_rng_state(g)
-        if state_dict is not None:      # torchvision naming: features.<idx>.weight / .bias
-            self.load_state_dict({k: v for k, v in state_dict.items() if k.startswith("features.")}, strict=False)
+        if state_dict is not None:
+            self.features.load_state_dict(_trunk_keys(state_dict, self.features), strict=True)
+        else:
+            _warn_random_trunk(cfg, seed)
         self.taps = taps
         for p in self.parameters():
             p.requires_grad = False     # vgg.py:26-28, pretrained_networks.py:116-118

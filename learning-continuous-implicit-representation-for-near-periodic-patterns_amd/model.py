@@ -24,7 +24,7 @@ class NPPNet:
                  lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5)):
         self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
         self.K = int(self.cfg.K)
-        self.device = torch.device(device)
+        self.device = ops.select_device(device)
         self.layout, self.n_params = param_layout(self.K)
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         self.m = torch.zeros_like(self.params)
@@ -140,54 +140,6 @@ class NPPNet:
                           self.lat_m, self.lat_v, self.dlatent, idle, self.lr, self.opt_step)
         self._clean = True
         self.repack()
-        self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
-        self.global_step += 1
-
-    # ---- HIP-graph form of one iteration ------------------------------------------------
-    def _hyper(self):
-        """[step_size, 1/sqrt(1-b2^t)] of the NEXT Adam step into pinned host memory; the captured
-        graph copies it to the device, so a replay always uses the current step's values."""
-        if not hasattr(self, "_hp_host"):
-            self._hp_host = torch.zeros(2, dtype=torch.float32).pin_memory()
-            self._hp_dev = torch.zeros(2, dtype=torch.float32, device=self.device)
-        t = self.opt_step + 1
-        self._hp_host[0] = self.lr / (1.0 - 0.9 ** t)
-        self._hp_host[1] = 1.0 / (1.0 - 0.999 ** t) ** 0.5
-        return self._hp_host, self._hp_dev
-
-    def capture_step(self, coords_padded, n_rows, gt, mask=None):
-        """Capture zero_grad -> forward -> pixel loss -> backward -> Adam -> repack for a fixed batch
-        into a HIP graph (launch-bound inner loop; ~40 us of launch gaps per iteration otherwise)."""
-        bp = coords_padded.shape[0]
-        ws = self.workspace(bp)
-        hp_host, hp_dev = self._hyper()
-
-        def body():
-            self.zero_grad(force=True)
-            self.forward_train(coords_padded)
-            self.pixel_loss(bp, n_rows, gt, mask)
-            self.backward(bp)
-            hp_dev.copy_(hp_host, non_blocking=True)
-            ops.adam_step_dev(self.params, self.m, self.v, ws["gslabs"], self.ksplit, self.n_params, hp_dev)
-            ops.adam_step_dev(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, hp_dev)
-            self.repack()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up outside capture (first-call attribute setup)
-            body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            body()
-        return g
-
-    def replay_step(self, graph):
-        """One optimisation iteration by graph replay + the host-side bookkeeping of
-        optimizer_step (step count, LR rule of train.py:253-263)."""
-        self._hyper()
-        graph.replay()
-        self.opt_step += 1
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         self.global_step += 1
 

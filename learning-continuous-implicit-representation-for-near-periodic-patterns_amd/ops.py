@@ -19,6 +19,25 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def select_device(device):
+    """The torch.device a fit / net / ranker lives on, made the CURRENT device of this host thread.  Every entry point of the
+    C ABI launches on a stream of the current device (one process -- or at least one host thread -- per GPU, INTEGRATION.md);
+    objects built for another GPU must therefore select it before they allocate or launch."""
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(dev)
+    return dev
+
+
+def check_current(device):
+    """Raise (instead of enqueueing GPU-x kernels on GPU-y's stream) when `device` is not the thread's current device."""
+    if device.type == "cuda" and device.index != torch.cuda.current_device():
+        raise RuntimeError(f"npp_amd: object lives on {device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"call torch.cuda.set_device({device.index}) in this thread (one process / host thread per GPU)")
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 

@@ -45,9 +45,7 @@ class Embedder:
     def __init__(self, res, **kwargs):
         self.kwargs = kwargs
         self.res = res
-        self.is_search = kwargs.get("is_search", False)
-        if self.is_search:
-            raise NotImplementedError("is_search embedders belong to the proposal-ranking path (SURVEY.md 8f1), not built yet")
+        self.is_search = kwargs.get("is_search", False)         # 2-D position embedder of the proposal-ranking fits (:52-54)
         n = kwargs["num_freqs"]
         if n > NPP_N_FREQ:
             raise NotImplementedError(f"num_freqs {n} > {NPP_N_FREQ} (this build's table size)")
@@ -66,7 +64,15 @@ class Embedder:
         self.out_dim = d * (2 * n + int(self.include_input))
 
     def embed(self, inputs):
-        x = _as_f32(inputs).contiguous()
+        if self.is_search:
+            # embedder.py:52-54 normalises the (row, col) pair to [-1, 1] IN PLACE (its callers pass a .clone(),
+            # NPP_proposal/search.py:104-105); a floating-point argument is written back the same way
+            x = torch.stack([(_as_f32(inputs[:, 0]) / self.res[0] - 0.5) * 2, (_as_f32(inputs[:, 1]) / self.res[1] - 0.5) * 2], 1)
+            if inputs.is_floating_point():
+                inputs.copy_(x)
+            x = x.contiguous()
+        else:
+            x = _as_f32(inputs).contiguous()
         return ops.fourier_fwd(x, self.freq_bands.tolist(), self.include_input)
 
 
@@ -76,8 +82,7 @@ class Embedder_periodic:
     def __init__(self, res, selected_angles, selected_periods, freq_scales, freq_offsets, angle_offsets, **kwargs):
         self.kwargs = kwargs
         self.freq_scales, self.freq_offsets, self.angle_offsets = freq_scales, freq_offsets, angle_offsets
-        if kwargs.get("is_search", False) or not kwargs.get("include_input", True):
-            raise NotImplementedError("is_search embedders belong to the proposal-ranking path (SURVEY.md 8f1), not built yet")
+        self.include_input = bool(kwargs.get("include_input", True))      # False for the is_search form (:76-86): 20 columns
         if list(freq_scales) != [1] and list(freq_scales) != [1.0]:
             raise NotImplementedError("kernels are specialised for freq_scales=[1] (the reference's completion config)")
         if len(freq_offsets) != len(_DEFAULT_OFFSETS) or list(angle_offsets) not in ([0], [0.0]):
@@ -86,7 +91,7 @@ class Embedder_periodic:
         per = [float(p) for p in selected_periods]
         # the Fourier frequencies are not used by the warp stage; any finite values do
         self.cfg = EmbedCfg.make([ang], [per], [1.0] * NPP_N_FREQ, res, tuple(float(o) for o in freq_offsets))
-        self.out_dim = 2 + 2 * 2 * len(freq_offsets)
+        self.out_dim = (2 if self.include_input else 0) + 2 * 2 * len(freq_offsets)
 
     def embed(self, inputs):
         c = inputs
@@ -94,7 +99,10 @@ class Embedder_periodic:
             if c.is_floating_point() and not bool((c == c.round()).all()):
                 raise NotImplementedError("non-integer coordinates: the kernels take pixel indices (train.py:89-105 passes them)")
             c = c.to(torch.int32)
-        return ops.warp_fwd(c.contiguous(), self.cfg)
+        v = ops.warp_fwd(c.contiguous(), self.cfg)                         # (N, 22): [x_n, 10 x orientation 0, y_n, 10 x orientation 1]
+        if self.include_input:
+            return v
+        return torch.cat([v[:, 1:11], v[:, 12:22]], 1).contiguous()
 
 
 def get_embedder(multires, i=0, res=None, selected_angles=None, selected_periods=None,
@@ -309,6 +317,15 @@ class NPP_Net_top1(_NetBase):
         self.input_ch_periodic = E1
 
 
+def NPP_Net_light(input_ch_periodic, freq_scales, freq_offsets, angle_offsets, D=8, W=256, input_ch=3, output_ch=3, skips=[4],
+                  activation="relu", device="cuda"):
+    """models/networks.py:176-263 -- the network of the proposal-ranking fits; one dense-layer launch per layer
+    (dense.DenseNPPNetLight).  The fits themselves have a dedicated host loop in light.ProposalRanker."""
+    from .dense import DenseNPPNetLight
+    return DenseNPPNetLight(input_ch_periodic, freq_scales, freq_offsets, angle_offsets, D=D, W=W, input_ch=input_ch,
+                            output_ch=output_ch, skips=skips, activation=activation, device=device)
+
+
 # ---------------------------------------------------------------------------------------------
 # render plumbing (models/helpers.py:14-62)
 def batchify(fn, chunk):
@@ -400,24 +417,33 @@ def adaptive_pix(device="cuda"):
 
 
 def create_npp_net(args, selected_angles, selected_periods, res, percep_net, is_search=False, style_net=None):
-    if is_search:
-        raise NotImplementedError("NPP_Net_light / is_search belongs to the proposal-ranking path (SURVEY.md 8f1), not built yet")
     embedder, freq_nerf = get_embedder(args.multires, args.i_embed, res, is_search=is_search)
-    embedder_periodics, input_ch_periodics = [], []
-    for i in range(args.p_topk):
-        ep, ch = get_embedder(args.multires, args.i_embed, res, selected_angles=selected_angles[i],
-                              selected_periods=selected_periods[i], freq_scales=args.freq_scales,
-                              freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets)
-        embedder_periodics.append(ep)
-        input_ch_periodics.append(ch)
-    input_ch_periodics = np.array(input_ch_periodics)
-    common = dict(freq_scales=args.freq_scales, freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets,
-                  D=args.netdepth, W=args.netwidth, freq_nerf=freq_nerf, output_ch=3, skips=[4], activation=args.activation)
-    if args.p_topk > 1:
-        model = NPP_Net(input_ch_periodic=input_ch_periodics[:1].sum(), input_ch_periodic_aux=input_ch_periodics[1:].sum(),
-                        **common)
+    if is_search:
+        # helpers.py:92-105: ONE candidate (angles, periods of its two orientations), no top-K in the model; the periodic
+        # embedder is returned as a single object, not a list
+        embedder_periodics, input_ch_periodic = get_embedder(args.multires, args.i_embed, res, selected_angles=selected_angles,
+                                                             selected_periods=selected_periods, freq_scales=args.freq_scales,
+                                                             freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets,
+                                                             is_search=True)
+        model = NPP_Net_light(D=args.netdepth, W=args.netwidth, input_ch=freq_nerf, input_ch_periodic=input_ch_periodic,
+                              freq_scales=args.freq_scales, freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets,
+                              output_ch=3, skips=[4], activation=args.activation)
     else:
-        model = NPP_Net_top1(input_ch_periodic=input_ch_periodics[:1].sum(), **common)
+        embedder_periodics, input_ch_periodics = [], []
+        for i in range(args.p_topk):
+            ep, ch = get_embedder(args.multires, args.i_embed, res, selected_angles=selected_angles[i],
+                                  selected_periods=selected_periods[i], freq_scales=args.freq_scales,
+                                  freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets)
+            embedder_periodics.append(ep)
+            input_ch_periodics.append(ch)
+        input_ch_periodics = np.array(input_ch_periodics)
+        common = dict(freq_scales=args.freq_scales, freq_offsets=args.freq_offsets, angle_offsets=args.angle_offsets,
+                      D=args.netdepth, W=args.netwidth, freq_nerf=freq_nerf, output_ch=3, skips=[4], activation=args.activation)
+        if args.p_topk > 1:
+            model = NPP_Net(input_ch_periodic=input_ch_periodics[:1].sum(), input_ch_periodic_aux=input_ch_periodics[1:].sum(),
+                            **common)
+        else:
+            model = NPP_Net_top1(input_ch_periodic=input_ch_periodics[:1].sum(), **common)
     grad_vars = list(model.parameters()) + list(adaptive_pix().parameters())
     if percep_net is not None and getattr(args, "use_adaptive_perceptual_loss", False):
         for adaptive in percep_net.adaptive_perceps:

@@ -30,7 +30,7 @@ def parse(argv=None):
     ap.add_argument("--basedir", default="./results")
     ap.add_argument("--expname", default="completion")
     ap.add_argument("--p_topk", type=int, default=3)
-    ap.add_argument("--N_iters", type=int, default=2001)
+    ap.add_argument("--N_iters", type=int, default=None, help="default 2001 (completion, arg_config.py) / 2801 (remapping, NPP_remapping)")
     ap.add_argument("--N_rand", type=int, default=8192)
     ap.add_argument("--lrate", type=float, default=5e-4)
     ap.add_argument("--lrate_decay", type=int, default=500)
@@ -39,7 +39,7 @@ def parse(argv=None):
     ap.add_argument("--num_real_patch_per_sample", type=int, default=3)
     ap.add_argument("--invalid_ratio", type=float, default=0.3)
     ap.add_argument("--patch_size_decay", type=int, default=2000)
-    ap.add_argument("--i_testset", type=int, default=500)
+    ap.add_argument("--i_testset", type=int, default=None, help="default 500 (completion) / 400 (remapping)")
     ap.add_argument("--i_print", type=int, default=500)
     ap.add_argument("--invalid_as_unknown", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -49,6 +49,9 @@ def parse(argv=None):
     ap.add_argument("--vgg19", default=None, help="torchvision vgg19 state_dict (.pth) for the contextual loss trunk")
     ap.add_argument("--vgg16", default=None, help="torchvision vgg16 state_dict (.pth) for the LPIPS trunk")
     ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth (the five 1x1 lin layers)")
+    ap.add_argument("--random-trunks", action="store_true",
+                    help="run WITHOUT pretrained VGG19 / VGG16 / LPIPS-lin weights (fixed-seed random trunks: synthetic and bench "
+                         "runs only -- the losses then differ from the reference's)")
     ap.add_argument("--device", default="cuda:0")
     return ap.parse_args(argv)
 
@@ -72,8 +75,22 @@ def default_linear_init(layout, n_params, seed):
 
 def main(argv=None):
     args = parse(argv)
+    if args.N_iters is None:
+        args.N_iters = 2801 if args.task == "remapping" else 2001
+    if args.i_testset is None:
+        args.i_testset = 400 if args.task == "remapping" else 500
     if args.netwidth != 256:
         raise SystemExit("this build is specialised for --netwidth 256 (BASELINE.json); the reference default 512 is not built")
+    remap_task = args.task == "remapping"
+    need = {"--vgg19": args.vgg19} if remap_task else {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
+    if remap_task:
+        need["--vgg16"] = args.vgg16                         # the style loss runs on VGG16 features (models/style_loss.py:11)
+    lacking = [k for k, v in need.items() if v is None]
+    if lacking and not args.random_trunks:
+        raise SystemExit(f"missing pretrained weights {lacking}: the reference's contextual / LPIPS / style losses use torchvision's "
+                         f"pretrained VGG trunks and the lpips v0.1 lin layers; supply them, or pass --random-trunks to run on "
+                         f"fixed-seed random trunks (synthetic / bench runs)")
+    torch.cuda.set_device(torch.device(args.device))
     from . import io as nio
     from ._lib import param_layout
     from .fit import CompletionFit
@@ -102,6 +119,7 @@ def main(argv=None):
                         patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
                         vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
                         task=args.task, clear_mask=d["clear_mask"] if remap else None,
+                        masked_img=None if remap else d.get("masked_img"),
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else 1e-3),
                         style_weight=args.style_weight if remap else None, use_perceptual_loss=not remap)
     name = os.path.basename(os.path.normpath(args.datadir))

@@ -94,6 +94,48 @@ def test_light_net_vs_reference(dev, golden):
             assert rel_l2(G[f"{name}.{part}"], g[f"grad.{name}.{part}"]) < 3e-4, (name, part)
 
 
+def test_create_npp_net_is_search_dropin(dev, golden):
+    """The reference's own call, create_npp_net(args, angles, periods, res, percep_net=None, is_search=True)
+    (NPP_proposal/search.py:98-99, models/helpers.py:92-105), through the boundary module: embedders, NPP_Net_light forward
+    and every parameter gradient by torch autograd over the dense-layer kernels, against the reference module's own numbers
+    (g10_light.npz, W = 64)."""
+    import types
+    from npp_amd import reference_api as api
+    g = golden("g10_light.npz")
+    res = tuple(int(v) for v in g["res"])
+    args = types.SimpleNamespace(multires=10, i_embed=0, freq_scales=[1], freq_offsets=[0, -1, 1, 0.5, -0.5], angle_offsets=[0],
+                                 netdepth=4, netwidth=64, activation="snake", netchunk=1 << 22, lrate=5e-4, p_topk=1,
+                                 normalize_type=1)
+    torch.set_default_device(dev)
+    try:
+        kw, _, start, grad_vars, opt, emb, emb_per = api.create_npp_net(args, torch.tensor(g["angles"]), torch.tensor(g["periods"]),
+                                                                          res, percep_net=None, is_search=True)
+    finally:
+        torch.set_default_device("cpu")
+    model = kw["network_fn"]
+    assert type(model).__name__ == "DenseNPPNetLight" and not isinstance(emb_per, list) and start == 0
+    assert sorted(n for n, _ in model.named_parameters()) == sorted(k[3:] for k in g.files if k.startswith("sd."))
+    emb.freq_bands = torch.from_numpy(g["freqs"].astype(np.float32))                # the golden's (seeded) Fourier frequencies
+    c = torch.from_numpy(g["coords"].astype(np.float32)).to(dev)
+    x_pos = emb.embed(c.clone())
+    x_per = emb_per.embed(c)
+    np.testing.assert_allclose(x_pos.cpu().numpy(), g["pos_emb"], atol=2e-5)
+    np.testing.assert_allclose(x_per.cpu().numpy(), g["per_emb"], atol=2e-5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in _P(g).items()})
+    with torch.no_grad():
+        np.testing.assert_allclose(model(x_pos, x_per).cpu().numpy(), g["raw"], rtol=2e-4, atol=2e-5)
+    pred = api.render(x_pos, x_per, args, **kw)                                     # helpers.py:41-62 (sigmoid)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], atol=1e-5)
+    loss = ((pred - torch.from_numpy(g["tgt"]).to(dev)) ** 2).mean()
+    loss.backward()
+    for name, p_ in model.named_parameters():
+        ref = g["grad." + name]
+        if ref.size == 0:
+            assert p_.grad is None                                                   # built but unused, as in the reference
+        else:
+            assert rel_l2(p_.grad.cpu().numpy(), ref) < 3e-4, name
+
+
 def test_lpips_plain_vs_reference(dev, golden):
     from npp_amd import ops
     g = golden("g10_light.npz")

@@ -78,11 +78,45 @@ def test_train_driver_end_to_end(tmp_path):
     a, p, s = oracle.synthetic_periodicity(H, K)
     d = nio.write_detected_dir(str(tmp_path / "detected" / "syn"), img, mask, np.ones_like(mask), a, p, s)
     fit = train.main(["--datadir", d, "--basedir", str(tmp_path / "results"), "--p_topk", "3", "--N_iters", "121",
-                      "--i_testset", "60", "--i_print", "60", "--rng_mode", "fast"])
+                      "--i_testset", "60", "--i_print", "60", "--rng_mode", "fast", "--random-trunks"])
     out = tmp_path / "results" / "completion_top3" / "syn"
     assert sorted(os.listdir(out)) == ["testset_000060", "testset_000120"]
     assert len(os.listdir(out / "testset_000120")) == 6
     assert fit.psnr() > 26.0                               # torch-default init + freshly drawn Fourier frequencies
+
+
+def test_train_driver_requires_trunk_weights(tmp_path):
+    """Without pretrained VGG / LPIPS weights the driver refuses to run unless --random-trunks is given."""
+    from npp_amd import train
+    with pytest.raises(SystemExit) as e:
+        train.main(["--datadir", str(tmp_path), "--basedir", str(tmp_path / "r")])
+    assert "--random-trunks" in str(e.value)
+
+
+def test_trunk_state_dict_key_forms_and_strictness():
+    """A torchvision state_dict is accepted in both key forms ('features.N.*' and 'N.*'); a missing or mis-shaped convolution
+    raises instead of silently keeping its random init."""
+    torch = pytest.importorskip("torch")
+    from npp_amd import losses
+    ref = losses._make_features(losses._VGG19)
+    sd = {k: torch.randn_like(v) for k, v in ref.state_dict().items()}
+    full = {"features." + k: v for k, v in sd.items()}
+    full["classifier.0.weight"] = torch.zeros(3, 3)
+    for form in (sd, full):
+        t = losses._Trunk(losses._VGG19, taps=(17,), state_dict=form)
+        for k, v in sd.items():
+            assert torch.equal(t.features.state_dict()[k], v)
+    short = dict(sd)
+    short.pop("14.weight")
+    with pytest.raises(KeyError):
+        losses._Trunk(losses._VGG19, taps=(17,), state_dict=short)
+    bad = dict(sd)
+    bad["0.weight"] = torch.zeros(64, 3, 5, 5)
+    with pytest.raises(ValueError):
+        losses._Trunk(losses._VGG19, taps=(17,), state_dict=bad)
+    with pytest.warns(UserWarning, match="RANDOM"):
+        losses._warned_random.clear()
+        losses._Trunk(losses._VGG19, taps=(17,))
 
 
 def test_blur_map_vs_reference(golden):

@@ -62,8 +62,11 @@ def test_get_embedder_dimensions_and_rng_like_the_reference(golden):
 
 def test_unsupported_configurations_fail_loudly():
     api = _api()
-    with pytest.raises(NotImplementedError):
-        api.get_embedder(10, 0, (64, 64), is_search=True)
+    emb, d = api.get_embedder(10, 0, (64, 64), is_search=True)                      # embedder.py:76-80: 2-D input, 42 columns
+    assert d == 42 and emb.is_search
+    ep, d = api.get_embedder(10, 0, (64, 64), selected_angles=[1.0, 2.0], selected_periods=[5.0, 6.0], freq_scales=[1],
+                             freq_offsets=[0, -1, 1, 0.5, -0.5], angle_offsets=[0], is_search=True)
+    assert d == 20 and not ep.include_input                                        # embedder.py:84-86: include_input False
     with pytest.raises(NotImplementedError):
         api.get_embedder(10, 0, (64, 64), selected_angles=[1.0, 2.0], selected_periods=[5.0, 6.0], freq_scales=[1, 2],
                          freq_offsets=[0, -1, 1, 0.5, -0.5], angle_offsets=[0])
