@@ -51,6 +51,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box of this pool
+    shows 256 logical CPUs but grants 16 of them per GPU; 256 threads on that share run 200x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
     """The CPU restatement of the same workload timed on this host's cores, on a bounded sample:
     leg A -- the MLP half (embed + NPP_Net forward + robust pixel loss + backward + Adam) of WHOLE iterations
@@ -62,8 +75,13 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
     value = rows of one iteration / (leg A time + leg B time per iteration)."""
     import oracle
     from oracle import npp_torch_oracle as T
-    cores = os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
+    try:                                   # the NumPy oracle's SGEMMs: same thread budget
+        from threadpoolctl import threadpool_limits
+        blas_limit = threadpool_limits(limits=cores)
+    except ImportError:
+        blas_limit = None
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
     img, mask = oracle.synthetic_image(H)
     rng = np.random.RandomState(0)
@@ -113,9 +131,11 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
         if time.time() - t1 > seconds_target * 0.5 and n_b >= 5:
             break
     t_b = (time.time() - t1) / n_b
+    if blas_limit is not None:
+        blas_limit.restore_original_limits()
     return {"value": total / (t_a + t_b), "unit": "rows/s", "cores": cores, "kind": "port",
             "mlp_half_rows_per_s": total / t_a, "mlp_half_s_per_iteration": t_a, "patch_half_s_per_iteration": t_b,
-            "sample": f"{n_a} MLP-half steps of {total} rows (PyTorch-CPU fp32 autograd, {cores} threads, whole batch) in {n_a * t_a:.1f}s + "
+            "sample": f"{n_a} MLP-half steps of {total} rows (PyTorch-CPU fp32 autograd, {cores} threads = this process's CPU share of {os.cpu_count()} logical CPUs, whole batch) in {n_a * t_a:.1f}s + "
                       f"{n_b} patch-loss halves (NumPy oracle: VGG19 trunk + contextual loss on {2 * n_p * k} {patch}x{patch} patches, "
                       f"VGG16 + LPIPS head every 5th) in {n_b * t_b:.1f}s"}
 

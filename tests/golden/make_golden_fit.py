@@ -20,10 +20,12 @@ from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_
 import oracle  # noqa: E402  (only for the synthetic image / periodicity definition)
 
 
-def main():
+def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300)):
+    """K = 1: NPP_Net_top1 (g8_fit.npz).  K = 3: NPP_Net with the coarse-level proposals of the synthetic lattice, BASELINE
+    config c2's network (g8k3_fit.npz; models/networks.py:56-95, table = cat of the K proposals' embeddings, train.py:103-105)."""
     R = import_reference()
     emb, msec = R["emb"], R["msec"]
-    H, K, N_rand, n_iters = 256, 1, 8192, 300
+    H, N_rand = 256, 8192
     img, mask = oracle.synthetic_image(H)
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
     masked = img * mask
@@ -32,15 +34,15 @@ def main():
     torch.manual_seed(0)
     embedder, freq_nerf = emb.get_embedder(10, 0, (H, H))                       # draws freqs from the seed-0 generator
     freqs = np.array([float(fn.__defaults__[1]) for fn in embedder.embed_fns[1::2]], np.float32)
-    ep, _ = emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[0]), selected_periods=torch.Tensor(periods[0]),
-                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)
+    eps = [emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[k]), selected_periods=torch.Tensor(periods[k]),
+                            freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)[0] for k in range(K)]
     torch.manual_seed(0)                                                         # weights: seed-0 default init (tests/refinit.py)
     net = _net(R, K, 256, int(freq_nerf))
     adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
     opt = torch.optim.Adam(list(net.parameters()) + list(adaptive.parameters()), lr=5e-4, betas=(0.9, 0.999))
     with torch.no_grad():
-        tab_train = embedder.embed(ep.embed(torch.Tensor(i_train)))              # train.py:93-105 tables
-        tab_all = embedder.embed(ep.embed(torch.Tensor(i_all)))
+        tab_train = torch.cat([embedder.embed(ep.embed(torch.Tensor(i_train))) for ep in eps], 1)   # train.py:93-105 tables
+        tab_all = torch.cat([embedder.embed(ep.embed(torch.Tensor(i_all))) for ep in eps], 1)
     masked_t, img_t, mask_t = torch.Tensor(masked), torch.Tensor(img), torch.Tensor(mask)
 
     def psnr():
@@ -52,7 +54,6 @@ def main():
             out.append(float(-10 * torch.log10(mse)))
         return out
     np.random.seed(0)
-    checkpoints = [1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300]
     traj, global_step, t0 = [], 0, time.time()
     for i in range(1, n_iters + 1):
         sel = np.random.choice(i_train.shape[0], size=[N_rand], replace=False)   # train.py:172
@@ -70,9 +71,12 @@ def main():
         if i in checkpoints:
             traj.append([i] + psnr() + [float(loss)])
             print(traj[-1], f"{time.time() - t0:.0f}s", flush=True)
-    np.savez_compressed(os.path.join(OUT, "g8_fit.npz"), traj=np.array(traj, np.float64), freqs=freqs, H=np.int64(H), N_rand=np.int64(N_rand),
+    np.savez_compressed(os.path.join(OUT, out_name), K=np.int64(K), traj=np.array(traj, np.float64), freqs=freqs, H=np.int64(H), N_rand=np.int64(N_rand),
                         latent_alpha=adaptive.latent_alpha.detach().numpy(), latent_scale=adaptive.latent_scale.detach().numpy())
 
 
 if __name__ == "__main__":
-    main()
+    if "--k3" in sys.argv:
+        main(K=3, n_iters=150, out_name="g8k3_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100, 150))
+    else:
+        main()

@@ -21,11 +21,40 @@ from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_
 import oracle  # noqa: E402
 
 
-def main():
+def reference_lpips(R):
+    """The reference's LPIPS(net='vgg') object (externel_lib/lpips/lpips.py:27-133) without its constructor (which needs
+    torchvision + pretrained VGG16): every attribute the forward uses is set by hand, the lin layers carry the vendored
+    weights/v0.1/vgg.pth, the per-layer AdaptiveLossFunction objects are the reference's, and the trunk is the build's
+    fixed-seed VGG16-shaped stack (losses._Trunk, seed 4321) behind the `net.forward(x) -> 5 taps` interface."""
+    import lpips.lpips as LL
+    from npp_amd.losses import _Trunk, _VGG16
+    chns = [64, 128, 256, 512, 512]
+    obj = LL.LPIPS.__new__(LL.LPIPS)
+    torch.nn.Module.__init__(obj)
+    obj.pnet_type, obj.pnet_tune, obj.pnet_rand, obj.spatial, obj.lpips, obj.version = "vgg", False, False, False, True, "0.1"
+    obj.scaling_layer = LL.ScalingLayer()
+    obj.chns, obj.L = chns, 5
+    obj.adaptive_perceps = [R["adaptive"].AdaptiveLossFunction(num_dims=c, float_dtype=np.float32, device="cpu") for c in chns]
+    obj.lins = torch.nn.ModuleList([LL.NetLinLayer(c, use_dropout=True) for c in chns])
+    for i, l in enumerate(obj.lins):
+        setattr(obj, f"lin{i}", l)
+    obj.load_state_dict(torch.load("/root/reference/externel_lib/lpips/weights/v0.1/vgg.pth", map_location="cpu"), strict=False)
+    obj.eval()
+    trunk = _Trunk(_VGG16, taps=(3, 8, 15, 22, 29), seed=4321)
+
+    class Net:
+        def forward(self, x):
+            return trunk(x)
+    obj.net = Net()
+    return obj
+
+
+def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoints=(10, 25, 50, 75, 100)):
     R = import_reference()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
     from npp_amd.losses import _Trunk, _VGG19                                   # the VGG19[0:18]-shaped stand-in, seed 1234
-    H, N_rand, n_iters, P, n_p, topk = 256, 8192, 100, 64, 2, 3
+    percep = reference_lpips(R) if with_lpips else None
+    H, N_rand, P, n_p, topk = 256, 8192, 64, 2, 3
     img, mask = oracle.synthetic_image(H)
     angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
     masked = img * mask
@@ -40,7 +69,11 @@ def main():
     torch.manual_seed(0)
     net = _net(R, 1, 256, int(freq_nerf))
     adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
-    opt = torch.optim.Adam(list(net.parameters()) + list(adaptive.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    grad_vars = list(net.parameters()) + list(adaptive.parameters())
+    if percep is not None:                                                        # helpers.py:147-151
+        for a_ in percep.adaptive_perceps:
+            grad_vars += list(a_.parameters())
+    opt = torch.optim.Adam(grad_vars, lr=5e-4, betas=(0.9, 0.999))
     vgg = _Trunk(_VGG19, taps=(17,))
     mean = torch.tensor([0.485, 0.456, 0.406]).reshape(3, 1, 1)                  # contextual.py:41-46
     std = torch.tensor([0.229, 0.224, 0.225]).reshape(3, 1, 1)
@@ -58,8 +91,7 @@ def main():
             flat = tab_all.reshape(H * H, -1)
             pred = torch.cat([torch.sigmoid(net(None, flat[j:j + 20000])) for j in range(0, H * H, 20000)]).reshape(H, H, 3)
         return [float(-10 * torch.log10((((pred - img_t) ** 2) * m).sum() / (m.sum() * 3))) for m in (mask_t, 1 - mask_t)]
-    checkpoints = [10, 25, 50, 75, 100]
-    traj, seq, global_step, t0 = [], [], 0, time.time()
+    traj, seq, lp_vals, patch_vals, global_step, t0 = [], [], [], [], 0, time.time()
     for i in range(1, n_iters + 1):
         real, rmask, fake, fmask, coords, source, k, weight = S.sample_patches(topk=topk, invalid_ratio=0.3)   # train.py:152-157
         seq.append(({"val": 0, "train": 1, "same": 2, None: -1}[source], k))
@@ -83,7 +115,14 @@ def main():
         fx = vgg((x_in - mean) / std)[0]                                                                          # contextual.py:56-64
         with torch.no_grad():
             fy = vgg((y_in - mean) / std)[0]
-        loss = loss + cxf.contextual_loss(fx, fy, 0.5, None) * 0.001                                              # :238-239, weight 1e-3
+        cx = cxf.contextual_loss(fx, fy, 0.5, None)
+        patch_loss = cx * 0.001                                                                                   # :238-239, weight 1e-3
+        if percep is not None and source == "same":                                                               # :241-251
+            perc = torch.mean(percep(pp * rm, fk * rm, use_robust=True, normalize=True))
+            lp_vals.append([i, float(perc)])
+            patch_loss = patch_loss + perc * 0.001
+        patch_vals.append([i, float(patch_loss), float(cx)])
+        loss = loss + patch_loss
         loss.backward()
         opt.step()
         new_lr = 5e-4 * (0.1 ** (global_step / (500 * 100)))
@@ -93,9 +132,19 @@ def main():
         if i in checkpoints:
             traj.append([i] + psnr())
             print(traj[-1], seq[-1], f"{time.time() - t0:.0f}s", flush=True)
-    np.savez_compressed(os.path.join(OUT, "g8b_fit_patch.npz"), traj=np.array(traj, np.float64), seq=np.array(seq, np.int64), freqs=freqs,
-                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step))
+    extra = {"patch_loss": np.array(patch_vals, np.float64)}        # (iteration, weighted patch loss of the iteration, raw CX value)
+    if percep is not None:
+        extra["lpips_values"] = np.array(lp_vals, np.float64)                     # (iteration, mean LPIPS-robust value) of 'same' iterations
+        for kk, a_ in enumerate(percep.adaptive_perceps):
+            extra[f"la{kk}"] = a_.latent_alpha.detach().numpy()
+            extra[f"ls{kk}"] = a_.latent_scale.detach().numpy()
+            extra[f"lin{kk}"] = percep.lins[kk].model[1].weight.detach().numpy().reshape(-1)
+    np.savez_compressed(os.path.join(OUT, out_name), traj=np.array(traj, np.float64), seq=np.array(seq, np.int64), freqs=freqs,
+                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step), **extra)
 
 
 if __name__ == "__main__":
-    main()
+    if "--lpips" in sys.argv:
+        main(with_lpips=True, n_iters=100, out_name="g8c_fit_lpips.npz")
+    else:
+        main()
