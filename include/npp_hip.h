@@ -194,6 +194,15 @@ int npp_patch_gather(const float* d_img_hwc, const float* d_mask_hw, int H, int 
                      const int32_t* d_centres_yx, int M, int P, float* d_out_rgb,
                      float* d_out_mask, void* stream);
 
+/* The input rows of one loop iteration (NPP_completion/train.py:166-181) assembled in one launch: rows [0, n_pix) =
+ * i_train[pix[t]] (the np.random.choice of :172-174), rows [n_pix, n_pix + n_p P^2) = the pixel coordinates of the fake
+ * patches around centres `cen` (models/sampler.py:269-279), zero rows up to Bp; gt = img[row] and (optional, remapping)
+ * pmask = pmask_img[row] of the pixel rows.  coords int32 (Bp, 2) (row, col); gt (n_pix, 3). */
+int npp_batch_assemble(const int32_t* d_i_train, int64_t n_train, const int64_t* d_pix, int64_t n_pix,
+                       const int32_t* d_cen, int n_p, int P, int64_t Bp, const float* d_img_hwc,
+                       const float* d_pmask_hw, int H, int W, int32_t* d_coords, float* d_gt, float* d_pmask,
+                       void* stream);
+
 /* ---- a10: patch plumbing (NPP_completion/train.py:200-236) and its backward ------ */
 /* d_pred_rows (n_p*P*P, 3): the predicted patch rows (row = (p*P + y)*P + x, train.py:178-181);
  * d_fake (n_p,3,P,P) / d_fmask (n_p,1,P,P): fake patch and its known mask (untiled; the reference
@@ -361,6 +370,17 @@ int npp_rng_get_state(void* rng, uint32_t* key624, int32_t* pos);      /* == Ran
 int npp_rng_set_state(void* rng, const uint32_t* key624, int32_t pos);
 double npp_rng_uniform(void* rng, double lo, double hi);
 int npp_rng_choice_noreplace(void* rng, int64_t n, int64_t size, int64_t* scratch_n, int64_t* out_size);
+
+/* ---- GridPatchSampler's host-side draw (models/sampler.py:242-354: patch source :324-331, fake centres :260, lattice
+ * candidates + unknown-pixel filter + k nearest :148-214) in one GIL-free host call, consuming `rng` like the reference
+ * consumes np.random.  sat: (H+1) x (W+1) summed-area table of the known mask; pools: (row, col) int32 pairs in the
+ * reference's np.nonzero order; shifts_dydx: the two lattice shifts as (dy, dx) (sampler.py:35). */
+void* npp_sampler_create(const int64_t* sat, int H, int W, const int32_t* pool_train, int64_t n_train,
+                         const int32_t* pool_val, int64_t n_val, const double* shifts_dydx);
+void npp_sampler_destroy(void* sampler);
+int npp_sampler_set_patch(void* sampler, int patch_size, int n_samples, int64_t* pool_train_n, int64_t* pool_val_n);
+int npp_sampler_draw(void* sampler, void* rng, int topk, double invalid_ratio, int32_t* source, int32_t* k,
+                     int32_t* cen_n2, double* real_cen_ntopk2, float* weights_ntopk);
 
 /* ---- diagnostics ---------------------------------------------------------- */
 /* Checks the MFMA operand / accumulator lane maps this library relies on (incl. the

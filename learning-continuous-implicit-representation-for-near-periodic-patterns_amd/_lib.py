@@ -73,6 +73,7 @@ SYMBOLS = {
                                  _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "npp_batch_assemble": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "npp_cx_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "npp_cx_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
@@ -86,6 +87,10 @@ SYMBOLS = {
     "npp_rng_set_state": (_i32, [_vp, _vp, C.c_int32]),
     "npp_rng_uniform": (C.c_double, [_vp, C.c_double, C.c_double]),
     "npp_rng_choice_noreplace": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "npp_sampler_create": (_vp, [_vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "npp_sampler_destroy": (None, [_vp]),
+    "npp_sampler_set_patch": (_i32, [_vp, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "npp_sampler_draw": (_i32, [_vp, _vp, _i32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, _vp, _vp]),
     "npp_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "npp_linear_bwd_data": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "npp_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),

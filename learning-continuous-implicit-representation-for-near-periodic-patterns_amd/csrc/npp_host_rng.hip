@@ -178,3 +178,177 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
   for (int64_t k = size - 1; k >= 0; --k) out[k] = (int64_t)perm[k];   // out may alias scratch: widen from the top
   return NPP_OK;
 }
+
+// ---- the sampler's per-iteration draw, host side (models/sampler.py:242-354, NPP_completion/train.py:152-172) ----------
+// What GridPatchSampler.sample_patches decides on the host -- patch source (:324), fake-patch centres (:260), and per fake
+// patch the k nearest lattice candidates c + a s1 + b s2, a, b in [-10, 10) (:148-214), kept when they lie inside the image
+// and their P x P window has at most invalid_ratio * P^2 unknown pixels -- plus the N_rand pixel rows of train.py:172, in
+// the reference's RNG order, in ONE GIL-free call.  The unknown-pixel counts come from a summed-area table of the known
+// mask (4 look-ups per candidate instead of cropping it; zero padding counts as unknown, sampler.py:181).  Mirrors
+// sampler.py's Python restatement (npp_amd/sampler.py: GridPatchSampler.draw) operation by operation in float64, so both
+// produce identical draws (tests/test_host_rng.py).
+namespace {
+
+struct Sampler {
+  int H, W, half, n_samples;
+  int64_t* sat;                       // (H + 1) x (W + 1) summed-area table of known pixels
+  int32_t* pool[2];                   // [0] train, [1] val: (row, col) pairs that satisfy the margin rule of reset_pool
+  int64_t pool_n[2], pool_cap[2];
+  int32_t* raw[2];                    // unfiltered pools
+  int64_t raw_n[2];
+  double shift[2][2];                 // (dy, dx) of the two lattice shifts (sampler.py:35 flips the (dx, dy) of config.odgt)
+  int64_t* scratch;                   // permutation scratch for choice(replace=False)
+  int64_t scratch_n;
+};
+
+inline int64_t clampi(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+int64_t unknown_count(const Sampler* S, double cy, double cx, int P) {
+  // np.rint: round half to even
+  const int64_t y = (int64_t)__builtin_rint(cy), x = (int64_t)__builtin_rint(cx);
+  const int64_t y0 = clampi(y - P / 2, 0, S->H), y1 = clampi(y + P / 2, 0, S->H);
+  const int64_t x0 = clampi(x - P / 2, 0, S->W), x1 = clampi(x + P / 2, 0, S->W);
+  const int64_t w = S->W + 1;
+  const int64_t known = S->sat[y1 * w + x1] - S->sat[y0 * w + x1] - S->sat[y1 * w + x0] + S->sat[y0 * w + x0];
+  return (int64_t)P * P - known;
+}
+
+void filter_pool(Sampler* S, int which) {        // sampler.py:102-124 reset_pool
+  const int h = S->half;
+  int64_t n = 0;
+  for (int64_t i = 0; i < S->raw_n[which]; ++i) {
+    const int32_t r = S->raw[which][2 * i], c = S->raw[which][2 * i + 1];
+    if (r > h && r < S->H - (h + 1) && c > h && c < S->W - (h + 1)) {
+      S->pool[which][2 * n] = r;
+      S->pool[which][2 * n + 1] = c;
+      ++n;
+    }
+  }
+  S->pool_n[which] = n;
+}
+
+}  // namespace
+
+extern "C" void* npp_sampler_create(const int64_t* sat, int H, int W, const int32_t* pool_train, int64_t n_train,
+                                    const int32_t* pool_val, int64_t n_val, const double* shifts_dydx) {
+  if (!sat || H < 1 || W < 1 || !pool_train || !pool_val || n_train < 0 || n_val < 0 || !shifts_dydx) return nullptr;
+  Sampler* S = (Sampler*)calloc(1, sizeof(Sampler));
+  if (!S) return nullptr;
+  S->H = H; S->W = W;
+  const size_t sat_n = (size_t)(H + 1) * (W + 1);
+  S->sat = (int64_t*)malloc(sat_n * sizeof(int64_t));
+  const int64_t ns[2] = {n_train, n_val};
+  const int32_t* src[2] = {pool_train, pool_val};
+  bool ok = S->sat != nullptr;
+  for (int w = 0; w < 2 && ok; ++w) {
+    S->raw_n[w] = ns[w];
+    S->raw[w] = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(ns[w] + 1));
+    S->pool[w] = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(ns[w] + 1));
+    ok = S->raw[w] && S->pool[w];
+    if (ok) memcpy(S->raw[w], src[w], sizeof(int32_t) * 2 * (size_t)ns[w]);
+  }
+  const int64_t nmax = n_train > n_val ? n_train : n_val;
+  S->scratch = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nmax + 1));
+  S->scratch_n = nmax;
+  if (!ok || !S->scratch) { npp_sampler_destroy(S); return nullptr; }
+  memcpy(S->sat, sat, sat_n * sizeof(int64_t));
+  for (int i = 0; i < 4; ++i) S->shift[i / 2][i % 2] = shifts_dydx[i];
+  return S;
+}
+
+extern "C" void npp_sampler_destroy(void* h) {
+  Sampler* S = (Sampler*)h;
+  if (!S) return;
+  free(S->sat); free(S->scratch);
+  for (int w = 0; w < 2; ++w) { free(S->raw[w]); free(S->pool[w]); }
+  free(S);
+}
+
+/* reset_patchsize + reset_pool (sampler.py:49-124): patch size, number of fake patches, margin-filtered pools */
+extern "C" int npp_sampler_set_patch(void* h, int patch_size, int n_samples, int64_t* pool_train_n, int64_t* pool_val_n) {
+  Sampler* S = (Sampler*)h;
+  if (!S || patch_size < 2 || n_samples < 1) return NPP_ERR_ARG;
+  S->half = patch_size / 2;
+  S->n_samples = n_samples;
+  filter_pool(S, 0);
+  filter_pool(S, 1);
+  if (pool_train_n) *pool_train_n = S->pool_n[0];
+  if (pool_val_n) *pool_val_n = S->pool_n[1];
+  return NPP_OK;
+}
+
+/* One sample_patches() worth of host decisions.  Outputs: source (0 val, 1 train, 2 same), k (0: no valid real patch ->
+ * the iteration is skipped), cen int32[n][2], real_cen double[n * topk][2] (first n * k rows valid, candidate order),
+ * weights float[n * topk] (1/d normalised per fake patch, first n * k valid).  Consumes the generator exactly like
+ * np.random.uniform(0, 1) followed by np.random.choice(pool_n, [n], replace=False). */
+extern "C" int npp_sampler_draw(void* h, void* rng, int topk, double invalid_ratio, int32_t* source, int32_t* k_out,
+                                int32_t* cen, double* real_cen, float* weights) {
+  Sampler* S = (Sampler*)h;
+  if (!S || !rng || topk < 1 || topk > 16 || !source || !k_out || !cen || !real_cen || !weights || S->half < 1) return NPP_ERR_ARG;
+  const int n = S->n_samples, P = 2 * S->half;
+  const double prob = npp_rng_uniform(rng, 0.0, 1.0);
+  const int src = prob < 0.5 ? 0 : ((0.5 < prob && prob < 0.8) ? 1 : 2);          // sampler.py:326-331
+  *source = src;
+  const int which = src == 0 ? 1 : 0;                                                // 'val' -> pool_val, else pool_train
+  if (S->pool_n[which] < n) return NPP_ERR_ARG;
+  int64_t sel[64];
+  if (n > 64) return NPP_ERR_UNSUPPORTED;
+  int rc = npp_rng_choice_noreplace(rng, S->pool_n[which], n, S->scratch, sel);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    cen[2 * i] = S->pool[which][2 * sel[i]];
+    cen[2 * i + 1] = S->pool[which][2 * sel[i] + 1];
+  }
+  if (src == 2) {                                                                    // 'same': real := fake, k = 1
+    *k_out = 1;
+    for (int i = 0; i < n; ++i) weights[i] = 1.0f;
+    return NPP_OK;
+  }
+  const double thresh = (double)(P * P) * invalid_ratio;                             // sampler.py:181
+  int topk_min = topk;
+  struct Cand { double y, x, d; };
+  Cand cand[400];
+  int kept_k[64];
+  for (int i = 0; i < n; ++i) {
+    int m = 0;
+    for (int ai = -10; ai < 10; ++ai)
+      for (int bi = -10; bi < 10; ++bi) {                                            // meshgrid(indexing='ij'): a outer, b inner
+        const double a = (double)ai, b = (double)bi;
+        double y = (double)cen[2 * i] + a * S->shift[0][0];
+        y = y + b * S->shift[1][0];
+        double x = (double)cen[2 * i + 1] + a * S->shift[0][1];
+        x = x + b * S->shift[1][1];
+        if (!(y > 0 && y < S->H - 1 && x > 0 && x < S->W - 1)) continue;
+        if ((double)unknown_count(S, y, x, P) > thresh) continue;
+        double d = (double)((ai < 0 ? -ai : ai) + (bi < 0 ? -bi : bi));
+        if (d == 0) d = 10000;                                                       // :197 exclude itself
+        cand[m++] = Cand{y, x, d};
+      }
+    const int avail = (m - 1 < topk) ? m - 1 : topk;
+    if (avail < topk_min) {
+      topk_min = avail;
+      if (topk_min <= 0) { *k_out = 0; return NPP_OK; }
+    }
+    // stable selection of the topk_min smallest distances (np.argsort(kind='stable'))
+    double wsum = 0.0, inv[16];
+    bool used[400];
+    for (int c = 0; c < m; ++c) used[c] = false;
+    for (int t = 0; t < topk_min; ++t) {
+      int best = -1;
+      for (int c = 0; c < m; ++c)
+        if (!used[c] && (best < 0 || cand[c].d < cand[best].d)) best = c;
+      used[best] = true;
+      real_cen[2 * (i * topk + t)] = cand[best].y;
+      real_cen[2 * (i * topk + t) + 1] = cand[best].x;
+      inv[t] = 1.0 / cand[best].d;
+      wsum += inv[t];
+    }
+    for (int t = 0; t < topk_min; ++t) weights[i * topk + t] = (float)(inv[t] / wsum);
+    kept_k[i] = topk_min;
+  }
+  *k_out = topk_min;
+  // fake patches that were processed while topk_min was still larger keep their first topk_min candidates (:205-209);
+  // their weights stay normalised over the number they had (as in the reference, which slices without renormalising)
+  (void)kept_k;
+  return NPP_OK;
+}

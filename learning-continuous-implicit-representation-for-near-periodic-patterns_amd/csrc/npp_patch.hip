@@ -62,9 +62,54 @@ __global__ void patch_compose_bwd_kernel(const float* __restrict__ dxa, const fl
   for (int c = 0; c < 3; ++c) dpred[t * 3 + c] = acc[c];
 }
 
+// The per-iteration input rows of the loop (train.py:166-181) in one launch: the N_rand pixel rows chosen by
+// np.random.choice (indices into the known-pixel table i_train, :172-174) followed by the n_p * P * P rows of the fake
+// patches (window [c - P/2, c + P/2) around each centre, row-major, sampler.py:269-279), zero rows up to Bp; plus the
+// ground-truth colours (and the pixel-weight mask of the remapping variant) of the pixel rows.
+__global__ void batch_assemble_kernel(const int32_t* __restrict__ i_train, const int64_t* __restrict__ pix, int64_t n_pix,
+                                      const int32_t* __restrict__ cen, int n_p, int P, int64_t bp,
+                                      const float* __restrict__ img, const float* __restrict__ pmask_img, int W,
+                                      int32_t* __restrict__ coords, float* __restrict__ gt, float* __restrict__ pmask) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bp) return;
+  int32_t r = 0, c = 0;
+  if (t < n_pix) {
+    const int64_t i = pix[t];
+    r = i_train[2 * i];
+    c = i_train[2 * i + 1];
+    const float* px = img + ((int64_t)r * W + c) * 3;
+    gt[t * 3 + 0] = px[0];
+    gt[t * 3 + 1] = px[1];
+    gt[t * 3 + 2] = px[2];
+    if (pmask) pmask[t] = pmask_img[(int64_t)r * W + c];
+  } else if (t < n_pix + (int64_t)n_p * P * P) {
+    const int64_t q = t - n_pix;
+    const int p = (int)(q / ((int64_t)P * P));
+    const int rem = (int)(q - (int64_t)p * P * P);
+    r = cen[2 * p] - P / 2 + rem / P;
+    c = cen[2 * p + 1] - P / 2 + rem % P;
+  }
+  coords[2 * t] = r;
+  coords[2 * t + 1] = c;
+}
+
 }  // namespace npp
 
 using namespace npp;
+
+extern "C" int npp_batch_assemble(const int32_t* d_i_train, int64_t n_train, const int64_t* d_pix, int64_t n_pix,
+                                  const int32_t* d_cen, int n_p, int P, int64_t Bp, const float* d_img_hwc,
+                                  const float* d_pmask_hw, int H, int W, int32_t* d_coords, float* d_gt, float* d_pmask,
+                                  void* stream) {
+  if (!d_i_train || !d_pix || !d_img_hwc || !d_coords || !d_gt || n_pix < 0 || n_train < 1 || n_p < 0 || P < 0 ||
+      (n_p > 0 && !d_cen) || Bp < n_pix + (int64_t)n_p * P * P || (d_pmask && !d_pmask_hw) || H < 1 || W < 1) {
+    set_error("npp_batch_assemble: bad argument (n_pix=%lld n_p=%d P=%d Bp=%lld)", (long long)n_pix, n_p, P, (long long)Bp);
+    return NPP_ERR_ARG;
+  }
+  hipLaunchKernelGGL(batch_assemble_kernel, dim3((unsigned)((Bp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_i_train, d_pix,
+                     n_pix, d_cen, n_p, P, Bp, d_img_hwc, d_pmask_hw, W, d_coords, d_gt, d_pmask);
+  return check_launch("npp_batch_assemble");
+}
 
 extern "C" int npp_patch_compose_fwd(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
                                      const float* d_rmask, int n_p, int k, int P, int comp, float* d_xy, void* stream) {

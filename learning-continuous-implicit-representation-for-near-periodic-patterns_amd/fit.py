@@ -198,18 +198,18 @@ class CompletionFit:
 
     def materialise_batch(self, d):
         """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists."""
-        real, rmask, fake, fmask, coords, source, k, weight = self.patch_sampler.materialise(d)
+        real, rmask, fake, fmask, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False)
         if k == 0:
             return None
-        pix = self.i_train_dev[ops.h2d(d["pix"], self.device)]
-        allc = torch.cat([pix, coords.reshape(-1, 2).to(torch.int32)], 0)
-        n = allc.shape[0]
+        # coordinates of all rows (N_rand pixel rows, then the fake patches' rows, zero padding) + the pixel rows' colours:
+        # one launch (npp_batch_assemble) instead of two index gathers, two concatenations and the colour / mask gathers
+        n_pix, P, n_p = d["pix"].shape[0], d["P"], d["cen"].shape[0]
+        n = n_pix + n_p * P * P
         bp = ops.pad_rows(n)
-        if bp != n:
-            allc = torch.cat([allc, allc.new_zeros((bp - n, 2))], 0)
-        pm = None if self.pixel_mask is None else self.pixel_mask[pix[:, 0].long(), pix[:, 1].long()].contiguous()
-        return dict(coords=allc.contiguous(), n_pix=pix.shape[0], n=n, bp=bp, gt=self.gather_gt(pix), real=real, rmask=rmask,
-                    fake=fake, fmask=fmask, source=source, k=k, P=d["P"], n_p=d["n_p"], raw=self.patch_sampler.last_raw, pmask=pm)
+        allc, gt, pm = ops.batch_assemble(self.i_train_dev, ops.h2d(d["pix"], self.device), self.patch_sampler.last_cen_dev, P, bp,
+                                          self.masked_img, self.pixel_mask)
+        return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, real=real, rmask=rmask,
+                    fake=fake, fmask=fmask, source=source, k=k, P=P, n_p=d["n_p"], raw=self.patch_sampler.last_raw, pmask=pm)
 
     def sample_batch(self):
         """Host-side sampling of one iteration + its device half.  None when no valid real patch exists."""

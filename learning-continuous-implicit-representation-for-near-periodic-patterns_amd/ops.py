@@ -264,6 +264,19 @@ def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True):
     return rgb, msk
 
 
+def batch_assemble(i_train, pix, cen, P, bp, img_hwc, pmask_hw=None):
+    """-> (coords int32 (bp,2), gt (n_pix,3), pmask (n_pix,) | None): the input rows of one loop iteration, train.py:166-181."""
+    n_pix, n_p = pix.shape[0], 0 if cen is None else cen.shape[0]
+    H, W = img_hwc.shape[:2]
+    dev = img_hwc.device
+    coords = torch.empty((bp, 2), dtype=torch.int32, device=dev)
+    gt = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
+    pm = None if pmask_hw is None else torch.empty((n_pix,), dtype=torch.float32, device=dev)
+    check(lib().npp_batch_assemble(_p(i_train), i_train.shape[0], _p(pix), n_pix, _p(cen), n_p, P, bp, _p(img_hwc), _p(pmask_hw), H, W,
+                                   _p(coords), _p(gt), _p(pm), _stream()), "npp_batch_assemble")
+    return coords, gt, pm
+
+
 _cx_ws = {}
 
 

@@ -73,3 +73,98 @@ def test_same_draw_timing_report(NRS):
             break
     print(f"numpy {t_np / reps * 1e3:.2f} ms, native {t_nat / reps * 1e3:.2f} ms per draw; 2 threads / 1 thread = {best:.2f}x")
     assert best > 0
+
+
+def _samplers(H, P, n, seed, shifts=None, mask_fn=None):
+    import torch
+    import oracle
+    from npp_amd.sampler import GridPatchSampler
+    from npp_amd.host_rng import NativeRandomState
+    img, mask = oracle.synthetic_image(H)
+    if mask_fn is not None:
+        mask = mask_fn(mask)
+    _, _, sh = oracle.synthetic_periodicity(H, 1)
+    sh = shifts if shifts is not None else sh
+    i_train = np.stack(np.nonzero(mask[..., 0]), 1)
+    i_val = np.stack(np.nonzero(1 - mask[..., 0]), 1)
+    mk = lambda rng: GridPatchSampler(torch.from_numpy(img * mask)[None], torch.from_numpy(mask)[None], n, P, H, H,   # noqa: E731
+                                      i_train, i_val, sh, rng=rng)
+    return mk(np.random.RandomState(seed)), mk(NativeRandomState(seed))
+
+
+@pytest.mark.parametrize("H,P,n,seed", [(256, 64, 2, 0), (256, 32, 4, 3), (512, 96, 2, 1)])
+def test_native_sampler_draw_equals_python_draw(H, P, n, seed):
+    """npp_sampler_draw (csrc/npp_host_rng.hip) against GridPatchSampler.draw's NumPy restatement of models/sampler.py:242-354
+    driven by numpy.random.RandomState: same patch source, centres, k, lattice candidates (as float64, bit for bit), 1/d weights
+    and the same generator state afterwards, call after call."""
+    a, b = _samplers(H, P, n, seed)
+    assert a._native is None and b._native is not None
+    seen = set()
+    for it in range(150):
+        da, db = a.draw(3, 0.3), b.draw(3, 0.3)
+        seen.add((da["source"], da["k"]))
+        assert (da["source"], da["k"]) == (db["source"], db["k"]), it
+        np.testing.assert_array_equal(da["cen"], db["cen"])
+        if da["real_cen"] is None:
+            assert db["real_cen"] is None
+        else:
+            np.testing.assert_array_equal(da["real_cen"], db["real_cen"])            # float64 candidate positions, exact
+            np.testing.assert_array_equal(da["weights"], db["weights"])
+        if it % 25 == 0:                                                             # patch-size decay path: reset + re-filter
+            for s_ in (a, b):
+                s_.reset_patchsize(None, None, P if it % 50 else P // 2, n if it % 50 else 2 * n)
+                s_.reset_pool(*_pools(H))
+    assert {"val", "train", "same"} <= {s_ for s_, _ in seen}
+    assert a.rng.get_state()[2] == b.rng.get_state()[2] and np.array_equal(a.rng.get_state()[1], b.rng.get_state()[1])
+
+
+def _pools(H):
+    import oracle
+    _, mask = oracle.synthetic_image(H)
+    return np.stack(np.nonzero(mask[..., 0]), 1), np.stack(np.nonzero(1 - mask[..., 0]), 1)
+
+
+def test_native_sampler_draw_skip_and_short_k():
+    """A lattice that leaves the image after one step: few or no valid candidates -> k < topk and the k == 0 'skip' result
+    (train.py:160-161), identical in both implementations."""
+    sh = [[(200.0, 10.0), (-15.0, 180.0)]]
+    a, b = _samplers(256, 64, 2, 5, shifts=sh)
+    ks = set()
+    for it in range(60):
+        da, db = a.draw(3, 0.3), b.draw(3, 0.3)
+        assert (da["source"], da["k"]) == (db["source"], db["k"])
+        ks.add(da["k"])
+        if da["real_cen"] is not None:
+            np.testing.assert_array_equal(da["real_cen"], db["real_cen"])
+            np.testing.assert_array_equal(da["weights"], db["weights"])
+    assert 0 in ks
+
+
+def test_random_patch_mode_matches_reference_rule():
+    """no_reg_sampling=True (models/sampler.py:66-85,219-228): real patches are N * topk windows drawn without replacement
+    from the stride-P/10 windows that contain no unknown pixel; no weights; k = topk."""
+    import torch
+    import oracle
+    from npp_amd.sampler import GridPatchSampler
+    H, P, n = 256, 64, 2
+    img, mask = oracle.synthetic_image(H)
+    _, _, sh = oracle.synthetic_periodicity(H, 1)
+    i_train, i_val = _pools(H)
+    S = GridPatchSampler(torch.from_numpy(img * mask)[None], torch.from_numpy(mask)[None], n, P, H, H, i_train, i_val, sh,
+                         no_reg_sampling=True, rng=np.random.RandomState(0))
+    st = P // 10
+    want = [(y + P // 2, x + P // 2) for y in range(0, H - P + 1, st) for x in range(0, H - P + 1, st)
+            if mask[y:y + P, x:x + P, 0].min() >= 0.5]
+    assert [tuple(c) for c in S.random_centres.tolist()] == want                    # unfold order, zero unknown pixels
+    ref = np.random.RandomState(0)
+    for it in range(20):
+        d = S.draw(3, 0.3)
+        prob = ref.uniform(0, 1)
+        src = "val" if prob < 0.5 else ("train" if 0.5 < prob < 0.8 else "same")
+        pool = S.pool_val if src == "val" else S.pool_train
+        sel = ref.choice(pool.shape[0], size=[n], replace=False)
+        assert d["source"] == src and np.array_equal(d["cen"], pool[sel])
+        if src != "same":
+            rs = ref.choice(len(want), size=[n * 3], replace=False)                  # sampler.py:220
+            assert d["k"] == 3 and d["weights"] is None
+            np.testing.assert_array_equal(d["real_cen"], np.array(want, np.float64)[rs])
