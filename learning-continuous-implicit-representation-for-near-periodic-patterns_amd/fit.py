@@ -39,15 +39,18 @@ class CompletionFit:
         overlap the training loop instead of preceding it."""
         if rng_mode not in ("reference", "numpy", "fast"):
             raise ValueError("rng_mode must be 'reference', 'numpy' or 'fast'")
-        if task not in ("completion", "remapping"):
-            raise ValueError("task must be 'completion' or 'remapping'")
+        if task not in ("completion", "remapping", "segmentation"):
+            raise ValueError("task must be 'completion', 'remapping' or 'segmentation'")
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
         self.device = ops.select_device(device)
         valid = np.ones_like(mask) if valid_mask is None else np.asarray(valid_mask, np.float32).reshape(mask.shape)
         self.task = task
-        if task == "completion":
+        if task in ("completion", "segmentation"):
+            # segmentation (NPP_segmentation/train.py:62-157): the same loop with the initial PERIODIC region as the known mask
+            # and the masked-blurred image as the image trained and sampled on -- the caller passes them as `mask` and
+            # `masked_img` (io.load_npp_segmentation)
             mask = mask * valid
             # loaders.py:107-108: np.nonzero order (row-major) for both splits
             self.i_train = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
@@ -73,6 +76,8 @@ class CompletionFit:
         self.pixel_mask = None if pixel_mask is None else torch.from_numpy(pixel_mask[..., 0].copy()).to(self.device)
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
                           ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
+        if task == "segmentation":
+            self.net.lr_clock = False                              # NPP_segmentation/train.py:408 (see NPPNet.lr_clock)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))
         if rng_mode == "reference":
             from .host_rng import NativeRandomState

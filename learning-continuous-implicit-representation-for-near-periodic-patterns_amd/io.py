@@ -162,3 +162,40 @@ def load_npp_remapping(datadir, p_topk=3, blur_thresh=50):
     return dict(img=(img_u8 / 255.0).astype(np.float32), clear_mask=clear.astype(np.float32), valid_mask=valid.astype(np.float32),
                 shifts=info["selected_shifts"][:p_topk], angles=np.asarray(info["selected_angles"][:p_topk], np.float32),
                 periods=np.asarray(periods, np.float32), patch_size=patch_size_from_period(periods[0]), info=info)
+
+
+def blur_with_mask(img, mask, sigma=3):
+    """utils/ops.py:66-76 (skimage.filters.gaussian(sigma=3, multichannel=True): scipy's gaussian_filter per channel, mode
+    'nearest', truncate 4): normalised masked blur  G(img * mask) / (G(mask) + 1e-6) * mask.  img (H,W,3), mask (H,W,1)."""
+    from scipy.ndimage import gaussian_filter
+    img, mask = np.asarray(img, np.float64), np.asarray(mask, np.float64)
+    g = lambda a: gaussian_filter(a, sigma=(sigma, sigma, 0), mode="nearest", truncate=4.0)      # noqa: E731
+    return g(img * mask) / (g(mask) + 1e-6) * mask
+
+
+def load_npp_segmentation(datadir, p_topk=3, period_mask=None, non_period_mask=None):
+    """loaders/loaders.py:141-239 -> dict(img, blur_img, period_mask (H,W,1), non_period_mask (H,W,1), valid_mask, shifts,
+    angles, periods, patch_size).  The INITIAL coarse segmentation the reference computes with its vendored imsegm package
+    (SLIC superpixels + GMM + graph cut, loaders.py:162-205) is outside this build: its result is an input
+    here -- `period_mask` / `non_period_mask` arrays, or `period_mask.png` / `non_period_mask.png` (white = member) next to
+    config.odgt.  Everything after it is reproduced: the masked Gaussian blur of the image the fit trains on (:157-159), the
+    top-k periodicity and the patch size rule (:232-236)."""
+    info = load_data(datadir)
+    img = _imread_rgb(info["fpath_gt_img"])
+    valid = _imread_gray(info["fpath_valid_mask"])
+    blur = blur_with_mask(img * 255.0, valid) / 255.0
+
+    def get(arr, name):
+        if arr is not None:
+            return (np.asarray(arr, np.float64).reshape(img.shape[0], img.shape[1], 1) > 0.5).astype(np.float64)
+        path = os.path.join(datadir, name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: the initial periodic / non-periodic segmentation (imsegm in the reference, "
+                                    f"loaders/loaders.py:162-205) is not computed by this build; pass it or put {name} there")
+        return (_imread_gray(path) > 0.5).astype(np.float64)
+    pm, npm = get(period_mask, "period_mask.png"), get(non_period_mask, "non_period_mask.png")
+    periods = info["selected_periods"][:p_topk]
+    f = lambda a: np.asarray(a, np.float32)          # noqa: E731
+    return dict(img=f(img), blur_img=f(blur), period_mask=f(pm * valid), non_period_mask=f(npm), valid_mask=f(valid),
+                shifts=info["selected_shifts"][:p_topk], angles=f(info["selected_angles"][:p_topk]), periods=f(periods),
+                patch_size=patch_size_from_period(periods[0]), info=info)

@@ -44,6 +44,8 @@ class NPPNet:
         self.lrate, self.lrate_decay = float(lrate), int(lrate_decay)
         self.lr = float(lrate)
         self.global_step = 0        # train.py:337
+        self.lr_clock = True        # False: the LR clock never advances (NPP_segmentation/train.py:408: `global_step += 1` sits
+                                    # outside the loop there, so that task trains at a constant lrate) -- reproduced, not fixed
         self.opt_step = 0           # Adam's per-parameter step count
         self.wf = torch.empty(ops.pack_bytes(self.K, 0), dtype=torch.uint8, device=self.device)
         self.wb = torch.empty(ops.pack_bytes(self.K, 1), dtype=torch.uint8, device=self.device)
@@ -141,7 +143,8 @@ class NPPNet:
         self._clean = True
         self.repack()
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
-        self.global_step += 1
+        if self.lr_clock:
+            self.global_step += 1
 
     @property
     def loss_buf(self):

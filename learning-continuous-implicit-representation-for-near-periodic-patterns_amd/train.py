@@ -20,9 +20,17 @@ import torch
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="completion", choices=["completion", "remapping"],
+    ap.add_argument("--task", default="completion", choices=["completion", "remapping", "segmentation"],
                     help="completion: NPP_completion/train.py; remapping: NPP_remapping/train.py (whole image trained, blur-detected clear "
-                         "mask as sampler / pixel-weight mask, Gram style loss; its defaults: contextual_weight 0.01, style_weight 1, no LPIPS)")
+                         "mask as sampler / pixel-weight mask, Gram style loss; its defaults: contextual_weight 0.01, style_weight 1, no LPIPS); "
+                         "segmentation: NPP_segmentation/train.py (fit on the masked-blurred image with the initial periodic region as "
+                         "the known mask, constant LR, contextual_weight 0.005, no LPIPS, 601 iterations, then the L1 + LPIPS(alex) "
+                         "criteria; needs period_mask.png / non_period_mask.png beside config.odgt)")
+    ap.add_argument("--alexnet", default=None, help="torchvision alexnet state_dict (.pth) for the segmentation criterion")
+    ap.add_argument("--lpips_alex_lin", default=None, help="lpips weights/v0.1/alex.pth (segmentation criterion)")
+    ap.add_argument("--l1_thresh", type=float, default=0.15)
+    ap.add_argument("--lpips_thresh", type=float, default=0.3)
+    ap.add_argument("--lpips_layers", type=int, default=1)
     ap.add_argument("--blur_thresh", type=float, default=50)
     ap.add_argument("--contextual_weight", type=float, default=None)
     ap.add_argument("--style_weight", type=float, default=1.0)
@@ -76,15 +84,18 @@ def default_linear_init(layout, n_params, seed):
 def main(argv=None):
     args = parse(argv)
     if args.N_iters is None:
-        args.N_iters = 2801 if args.task == "remapping" else 2001
+        args.N_iters = {"remapping": 2801, "segmentation": 601}.get(args.task, 2001)     # arg_config.py:96,202,289
     if args.i_testset is None:
-        args.i_testset = 400 if args.task == "remapping" else 500
+        args.i_testset = {"remapping": 400, "segmentation": 600}.get(args.task, 500)
     if args.netwidth != 256:
         raise SystemExit("this build is specialised for --netwidth 256 (BASELINE.json); the reference default 512 is not built")
     remap_task = args.task == "remapping"
-    need = {"--vgg19": args.vgg19} if remap_task else {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
+    seg_task = args.task == "segmentation"
+    need = {"--vgg19": args.vgg19} if (remap_task or seg_task) else {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
     if remap_task:
         need["--vgg16"] = args.vgg16                         # the style loss runs on VGG16 features (models/style_loss.py:11)
+    if seg_task:
+        need.update({"--alexnet": args.alexnet, "--lpips_alex_lin": args.lpips_alex_lin})
     lacking = [k for k, v in need.items() if v is None]
     if lacking and not args.random_trunks:
         raise SystemExit(f"missing pretrained weights {lacking}: the reference's contextual / LPIPS / style losses use torchvision's "
@@ -95,9 +106,13 @@ def main(argv=None):
     from ._lib import param_layout
     from .fit import CompletionFit
     remap = args.task == "remapping"
+    seg = args.task == "segmentation"
     if remap:
         d = nio.load_npp_remapping(args.datadir, args.p_topk, args.blur_thresh)
         d["mask"], d["masked_img"] = d["clear_mask"], d["img"]
+    elif seg:
+        d = nio.load_npp_segmentation(args.datadir, args.p_topk)
+        d["mask"], d["masked_img"] = d["period_mask"], d["blur_img"]
     else:
         d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
     K = len(d["angles"])
@@ -120,10 +135,10 @@ def main(argv=None):
                         vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
                         task=args.task, clear_mask=d["clear_mask"] if remap else None,
                         masked_img=None if remap else d.get("masked_img"),
-                        contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else 1e-3),
-                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not remap)
+                        contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
+                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not (remap or seg))
     name = os.path.basename(os.path.normpath(args.datadir))
-    expname = args.expname if not (remap and args.expname == "completion") else "remapping"
+    expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
     outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)
     t0 = time.time()
     for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
@@ -132,6 +147,21 @@ def main(argv=None):
             pred = fit.render_image().cpu().numpy()
             nio.dump_testset(os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"], d["valid_mask"])
             print(f"[EVAL] iter {i}: PSNR known {fit.psnr('known'):.2f} dB, unknown {fit.psnr('unknown'):.2f} dB")
+            if seg:                                                                         # NPP_segmentation/train.py:337-406
+                from . import segment
+                alex = segment.AlexFeatures(load(args.alexnet), device=args.device)
+                al = load(args.lpips_alex_lin)
+                lins = ([al[f"lin{j}.model.1.weight"].reshape(-1).numpy() for j in range(5)] if al is not None
+                        else [np.full(c, 1.0 / c, np.float32) for c in (64, 192, 384, 256, 256)])
+                r = segment.segmentation_eval(pred * d["valid_mask"], d["blur_img"], d["valid_mask"], d["non_period_mask"], alex, lins,
+                                              args.l1_thresh, args.lpips_thresh, args.lpips_layers)
+                tdir = os.path.join(outroot, f"testset_{i:06d}")
+                nio.imsave(os.path.join(tdir, "l1_diff_img.png"), np.repeat(r["l1_img"][..., None], 3, 2))
+                nio.imsave(os.path.join(tdir, "non_period_mask_final.png"), np.repeat(r["non_period_mask_final"].astype(np.float64), 3, 2))
+                m = r["non_period_mask_final"].astype(np.float64)
+                vis = d["img"] * 0.7 + 0.3 * (np.array([0.0, 1.0, 0.0]) * m + d["img"] * (1 - m))    # :396-404
+                nio.imsave(os.path.join(tdir, "segment.png"), vis * d["valid_mask"])
+                fit.segmentation = r
         if i % args.i_print == 0:
             print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
                   f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
