@@ -419,6 +419,14 @@ def main():
             return torch.cat(outs, 0)
         ref32 = render_fp32()
         t_r32 = timed(render_fp32, reps=2)
+        # ... and FUSED in exact fp32 (npp_mlp_fwd32: one launch, v_mfma_f32_32x32x2_f32, nothing materialised): c4's line
+        fused32 = net4.render_fp32(grid)
+        t_f32 = timed(lambda: net4.render_fp32(grid), reps=3)
+        out["render_1024sq_fp32_fused"] = {"dtype": "fp32", "ms": t_f32 * 1e3, "pixels_per_s": grid.shape[0] / t_f32,
+                                           "TFLOP_per_s": 2 * fwd_macs * grid.shape[0] / t_f32 / 1e12,
+                                           "frac_of_fp32_mfma_peak": 2 * fwd_macs * grid.shape[0] / t_f32 / 1e12 / 157.3,
+                                           "max_abs_diff_vs_fp32_dense_chain": float((fused32 - ref32).abs().max())}
+        del fused32
         d32 = (net4.render(grid) - ref32).abs()
         out["render_1024sq_fp32_dense"] = {"ms": t_r32 * 1e3, "pixels_per_s": grid.shape[0] / t_r32,
                                            "TFLOP_per_s": 2 * fwd_macs * grid.shape[0] / t_r32 / 1e12,

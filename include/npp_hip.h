@@ -81,6 +81,16 @@ int npp_pack_weights(const float* d_params, void* d_wf, void* d_wb, int K, int w
  * the fragment maps against a NumPy model of the MFMA.  Buffers are host memory. */
 int npp_pack_weights_host(const float* params, void* wf, void* wb, int K, int width);
 
+/* ---- exact-fp32 fused forward (BASELINE config c4: "fp32"): the same function as npp_mlp_fwd on v_mfma_f32_32x32x2_f32
+ * (f32 operands and accumulation, 157 TFLOP/s peak; no bf16 rounding anywhere) -- the reference's own arithmetic type
+ * (models/networks.py:56-95 via F.linear, models/embedder.py:11-56,102-148).  Inference only (train.py:270-331).
+ * npp_pack32_bytes / npp_pack_weights32: the fp32 A-operand pack of the blob ([layer][group of 4 k-steps][tile][lane][4]).
+ * out_act: 0 raw / 1 sigmoid / 2 tanh (models/helpers.py:55-58). */
+int64_t npp_pack32_bytes(int K, int width);
+int npp_pack_weights32(const float* d_params, void* d_w32, int K, int width, void* stream);
+int npp_mlp_fwd32(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width, const void* d_w32,
+                  const float* d_params, float* d_out, int out_act, void* stream);
+
 /* ---- a1+a2+a4: embedder -------------------------------------------------- */
 /* Replaces Embedder_periodic.embed + Embedder.embed + cat (models/embedder.py:140-148,
  * :51-56; NPP_completion/train.py:93-105): coords (N,2) -> (N, K*462), row-major,

@@ -56,6 +56,9 @@ SYMBOLS = {
     "npp_pack_bytes": (_i64, [_i32, _i32, _i32]),
     "npp_pack_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "npp_pack_weights_host": (_i32, [_vp, _vp, _vp, _i32, _i32]),
+    "npp_pack32_bytes": (_i64, [_i32, _i32]),
+    "npp_pack_weights32": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "npp_mlp_fwd32": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "npp_embed_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _i32, _i32, _vp]),
     "npp_warp_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _vp]),
     "npp_train_workspace": (_i32, [_i32, _i32, _i64, _i32, C.POINTER(_i64)]),

@@ -36,6 +36,24 @@ struct EmbedDev {
   float freq_rev[NPP_N_FREQ];                          // freq / 2pi (revolutions)
 };
 
+// sin / cos of an fp32 argument to ~1 ulp without libm's slow path: three-term Cody-Waite reduction by pi/2 (exact products
+// for |x| up to ~1e5 rad; the embedder's arguments are |f v| < ~50) + the cephes single-precision minimax polynomials on
+// [-pi/4, pi/4].  ~20 vector instructions, no branches: what lets the precise fp32 embedder run at the store rate instead of
+// at libm's (5.0 vs 2.4 TB/s at 1024^2).
+__device__ __forceinline__ float sincos_pi2(float x, bool want_cos) {
+  const float jf = rintf(x * 0.636619772367581343f);           // x * 2 / pi
+  float y = fmaf(-jf, 1.5703125f, x);
+  y = fmaf(-jf, 4.837512969970703125e-4f, y);
+  y = fmaf(-jf, 7.54978995489188e-8f, y);
+  const int q = ((int)jf + (want_cos ? 1 : 0)) & 3;
+  const float z = y * y;
+  const float s = fmaf(y * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), y);
+  const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                       fmaf(z, -0.5f, 1.0f));
+  const float r = (q & 1) ? c : s;
+  return (q & 2) ? -r : r;
+}
+
 // ---- a1: one warped coordinate (models/embedder.py:110-133) -------------------
 // i in [0,22): 0 -> x/W*2-1 ; 1..10 -> sin/cos pairs of orientation 0 over the 5
 // offsets ; 11 -> y/H*2-1 ; 12..21 -> orientation 1.
@@ -56,7 +74,7 @@ __device__ __forceinline__ float warp_value(const EmbedDev& e, int p, int i, flo
     float r = fmodf(t, per);                       // torch.remainder: sign of divisor
     if (r != 0.0f && ((per < 0.0f) != (r < 0.0f))) r += per;
     const float phi = ((r / per) * 2.0f) * 3.14159265358979323846f;
-    return is_cos ? cosf(phi) : sinf(phi);
+    return sincos_pi2(phi, is_cos);
   } else {
     const float q = floorf(t / per);
     float r = fmaf(-q, per, t);                    // exact remainder for |q| < 2^24

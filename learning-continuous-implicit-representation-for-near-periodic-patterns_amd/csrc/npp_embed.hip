@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
       float val;
       if (PRECISE) {
         const float a = v * en.f;
-        val = (en.code & (1 << 16)) ? v : ((en.code & (1 << 17)) ? cosf(a) : sinf(a));
+        val = (en.code & (1 << 16)) ? v : sincos_pi2(a, (en.code & (1 << 17)) != 0);
       } else {
         const float sn = __builtin_amdgcn_sinf(fmaf(v, en.f, (en.code & (1 << 17)) ? 0.25f : 0.0f));
         val = (en.code & (1 << 16)) ? v : sn;

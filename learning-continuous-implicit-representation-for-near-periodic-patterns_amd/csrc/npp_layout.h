@@ -151,6 +151,61 @@ NPP_HD int fwd_col(int K, int l, int ks, int h, int j) {
   }
 }
 
+// ---- exact-fp32 forward pack (npp_mlp_fwd32.hip, v_mfma_f32_32x32x2_f32) ---------------------------------
+// A k-step contracts TWO input features (lane half h = 0 / 1).  Activation k-step s of a 256-feature input: features
+// (8 (s / 4) + s % 4, that + 4) -- register r = s % 16 of accumulator tile s / 16 in both lane halves (acc_row).  Embedding
+// k-step q of a proposal: q < 220 -> (sin, cos) block columns of (frequency q / 22, warped coordinate q % 22); 220..230 ->
+// the raw block, two coordinates per k-step; 231 is padding (232 = 58 groups of 4).  One 16-byte pack unit carries the four
+// k-steps of a GROUP for one lane: [layer][group][neuron tile][lane][4].
+constexpr int kKSEmb32 = 232, kGE32 = kKSEmb32 / 4, kGA32 = kW / 8;
+NPP_HD int emb32_col(int q, int h) {
+  if (q < 220) return (1 + 2 * (q / 22) + h) * 22 + q % 22;
+  const int i = 2 * (q - 220) + h;
+  return (q < 231 && i < 22) ? i : -1;
+}
+NPP_HD int act32_col(int s, int h) { return 8 * (s >> 2) + (s & 3) + 4 * h; }
+struct Desc32 {
+  int32_t present[kNumLayers], nt[kNumLayers], groups[kNumLayers];
+  int64_t off16[kNumLayers];
+  int64_t total16;
+};
+NPP_HD Desc32 make_desc32(int K) {
+  Desc32 d{};
+  const int multi = K > 1;
+  int64_t off = 0;
+  for (int l = 0; l < kNumLayers; ++l) {
+    int g = kGA32, nt = kNT, present = 1;
+    switch (l) {
+      case L0: g = kGE32; break;
+      case L5: g = kGE32 + kGA32; break;
+      case LS: g = kGA32 + (K - 1) * kGE32; present = multi; break;
+      case LF2: present = multi; break;
+      case LP: g = multi ? 2 * kGA32 : kGA32; nt = kNT / 2; break;
+      case LRGB: g = 0; nt = 0; present = 0; break;
+      default: break;
+    }
+    d.present[l] = present; d.nt[l] = nt; d.groups[l] = g;
+    d.off16[l] = present ? off : -1;
+    if (present) off += (int64_t)g * nt * 64;
+  }
+  d.total16 = off;
+  return d;
+}
+// reference input column of fp32-pack element (layer l, k-step ks, lane half h), or -1 (zero weight)
+NPP_HD int col32(int K, int l, int ks, int h) {
+  switch (l) {
+    case L0: return emb32_col(ks, h);
+    case L5: return ks < kKSEmb32 ? emb32_col(ks, h) : kE + act32_col(ks - kKSEmb32, h);
+    case LS: {
+      if (ks < kW / 2) return act32_col(ks, h);
+      const int q = ks - kW / 2, p = q / kKSEmb32, c = emb32_col(q % kKSEmb32, h);
+      return c < 0 ? -1 : kW + p * kE + c;
+    }
+    case LP: return K > 1 ? (ks < kW / 2 ? kW + act32_col(ks, h) : act32_col(ks - kW / 2, h)) : act32_col(ks, h);   // [f2 | f1]
+    default: return act32_col(ks, h);
+  }
+}
+
 // ---- training stash for wgrad: "W-format" fragment arrays -----------------------------
 // Every layer input (actF) and every pre-activation gradient (dzF) is stored as the very
 // 16-byte fragments the fused kernels hold in registers: unit (k-step ks of 16 features,

@@ -114,6 +114,20 @@ class NPPNet:
         pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params)
         return pred[:n]
 
+    def render_fp32(self, coords):
+        """The same render in EXACT fp32 (BASELINE config c4): fused chain on v_mfma_f32_32x32x2_f32 (npp_mlp_fwd32), the
+        reference's own arithmetic type -- no bf16 operand rounding.  The fp32 weight pack is rebuilt when the parameters have
+        changed since the last call."""
+        n = coords.shape[0]
+        bp = ops.pad_rows(n)
+        if bp != n:
+            coords = torch.cat([coords, torch.zeros((bp - n, 2), dtype=torch.int32, device=coords.device)], 0)
+        stamp = (self.opt_step, self.params._version)
+        if getattr(self, "_w32_stamp", None) != stamp:
+            self._w32 = ops.pack_weights32(self.params, self.K, getattr(self, "_w32", None))
+            self._w32_stamp = stamp
+        return ops.mlp_fwd32(coords.contiguous(), self.cfg, self._w32, self.params)[:n]
+
     def forward_train(self, coords_padded):
         """Forward with stashes; coords must already be padded to a multiple of 64 rows."""
         ws = self.workspace(coords_padded.shape[0])

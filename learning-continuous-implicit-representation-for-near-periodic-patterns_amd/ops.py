@@ -207,6 +207,26 @@ def auto_ksplit(K, device):
     return max(1, min(64, cus // tiles))
 
 
+def pack_weights32(params, K, w32=None, width=NPP_WIDTH):
+    """fp32 blob -> the fp32 A-operand pack of npp_mlp_fwd32."""
+    n = int(lib().npp_pack32_bytes(K, width))
+    if w32 is None:
+        w32 = torch.empty(n, dtype=torch.uint8, device=params.device)
+    check(lib().npp_pack_weights32(_p(params), _p(w32), K, width, _stream()), "npp_pack_weights32")
+    return w32
+
+
+def mlp_fwd32(coords_yx, cfg, w32, params, out=None, out_act=1, width=NPP_WIDTH):
+    """Exact-fp32 fused embedder + MLP forward (render), coords (Bp,2) int32 with Bp % 64 == 0 -> (Bp,3)."""
+    _req(coords_yx, torch.int32, "coords")
+    Bp = coords_yx.shape[0]
+    if out is None:
+        out = torch.empty((Bp, 3), dtype=torch.float32, device=coords_yx.device)
+    check(lib().npp_mlp_fwd32(_p(coords_yx), Bp, C.byref(cfg), width, _p(w32), _p(params), _p(out), int(out_act), _stream()),
+          "npp_mlp_fwd32")
+    return out
+
+
 def mlp_wgrad(dzT, actT, Bp, K, ksplit, gslabs, width=NPP_WIDTH):
     _req(gslabs, torch.float32, "gslabs")
     check(lib().npp_mlp_wgrad(_p(dzT), _p(actT), Bp, K, width, ksplit, _p(gslabs), _stream()), "npp_mlp_wgrad")

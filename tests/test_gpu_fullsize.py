@@ -222,3 +222,28 @@ def test_c5_full_size_iteration_set(dev):
     for _ in range(40):
         fit.step_full()
     assert bool(torch.isfinite(fit.net.params).all()) and fit.psnr() > max(p0 + 8.0, 25.0)
+
+
+@pytest.mark.parametrize("K,H", [(1, 256), (3, 512), (5, 512)])
+def test_fused_fp32_render_matches_fp32_oracle(dev, K, H):
+    """npp_mlp_fwd32 (BASELINE config c4's arithmetic: fused chain on v_mfma_f32_32x32x2_f32, f32 operands and accumulation)
+    against the NumPy oracle in plain fp32 -- no bf16 emulation on either side -- on a row sample of the full grid, and
+    against the bf16 chain on every pixel; chunking / permutation invariance is bit-exact."""
+    net, P, angles, periods = _net(dev, K, H)
+    grid = _grid(H, H, dev)
+    n = grid.shape[0]
+    full = net.render_fp32(grid)
+    assert full.shape == (n, 3) and bool(torch.isfinite(full).all())
+    rng = np.random.RandomState(K * 7 + H)
+    idx = np.concatenate([[0, H - 1, n - H, n - 1], rng.randint(0, n, 1020)])
+    c = grid[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
+    raw, _ = oracle.mlp_forward(P, emb, K)
+    got = full[torch.from_numpy(idx).to(dev)].cpu().numpy()
+    err = np.abs(got - oracle.sigmoid(raw)).max()
+    assert err < 5e-5, err                                            # fp32 round-off + hardware sin (1e-6 per call) through 10 layers
+    assert np.abs(full.cpu().numpy() - net.render(grid).cpu().numpy()).max() < 2e-2      # the bf16 chain, every pixel
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    assert torch.equal(net.render_fp32(grid[perm].contiguous()), full[perm])
+    cuts = [0, n // 4 + 1, n // 2 + 33, n]
+    assert torch.equal(torch.cat([net.render_fp32(grid[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])], 0), full)
