@@ -47,7 +47,8 @@ constexpr int kRegionBytes = kKSAct * kNB * kFragBytes;        // 32 KiB: 256 fe
 constexpr int kChunkKS = 8;                                    // k-steps per embedding chunk
 constexpr int kChunkBytes = kChunkKS * kNB * kFragBytes;       // 16 KiB, two of them = one region
 constexpr int kNChunks = (kKSEmb + kChunkKS - 1) / kChunkKS;   // 4 (8,8,8,6)
-constexpr int kSmemV = 22 * kRowTile * 4;                      // warped coords of one proposal
+constexpr int kVRows = 22 + 8;                                 // rows 22..29 repeat rows 0..7 (see gen_emb_pair)
+constexpr int kSmemV = kVRows * kRowTile * 4;                  // warped coords of one proposal
 constexpr int kSmemE = (sizeof(EmbedDev) + 15) / 16 * 16;
 // Branch-free embedding generation is driven by two small LDS tables built once per workgroup:
 //  WarpEnt[K][22]: per warped coordinate cos/sin(theta), period, 1/period, phase, or the
@@ -144,32 +145,59 @@ __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, co
       r = r < 0.0f ? r + w.per : r;
       r = r >= w.per ? r - w.per : r;
       const float sv = __builtin_amdgcn_sinf(fmaf(r, w.inv_per, w.phase));
-      sV[i * kRowTile + L.lane] = w.lin != 0.0f ? t - 1.0f : sv;
+      const float val = w.lin != 0.0f ? t - 1.0f : sv;
+      sV[i * kRowTile + L.lane] = val;
+      if (i < kVRows - 22) sV[(22 + i) * kRowTile + L.lane] = val;      // wrap rows (wave-uniform branch)
     }
   }
 }
 
+// J < jb ? a : b on the scalar unit (hipcc turns the C++ select of two uniform floats into v_cndmask per value)
+template <int J>
+__device__ __forceinline__ float scalar_pick(int jb, int a, int b) {
+  int r;
+  asm("s_cmp_gt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(jb), "n"(J), "s"(a), "s"(b) : "scc");
+  return __builtin_bit_cast(float, r);
+}
+template <int JP>
+__device__ __forceinline__ void gen_emb_quad(const float* v, int jb, int fr0, int fr1, float ph, bf16x8 (&f)[kNB]) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const float fa = scalar_pick<2 * JP>(jb, fr0, fr1), fb = scalar_pick<2 * JP + 1>(jb, fr0, fr1);
+#pragma unroll
+  for (int bt = 0; bt < kNB; ++bt) {
+    f32x2 x;
+    x[0] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP) * kRowTile + bt * 32], fa, ph));
+    x[1] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP + 1) * kRowTile + bt * 32], fb, ph));
+    const bf16x2 pk = __builtin_convertvector(x, bf16x2);
+    f[bt][2 * JP] = pk[0];
+    f[bt][2 * JP + 1] = pk[1];
+  }
+}
 // The two embedding fragments (batch tiles 0, 1) of k-step ks.  ks is wave-uniform, so the slot ->
 // (Fourier frequency, warped coordinate) map of npp_layout.h emb_col() is scalar arithmetic and the
 // frequency is one broadcast LDS read; per value the vector ALU does fma + v_sin + half a pack.
 // Lane-half 1 adds a quarter revolution (cos).  Padding slots (t >= 220 of k-step 27) receive
 // some finite sin value: their packed weights are zero and npp_mlp_wgrad drops their columns.
 __device__ __forceinline__ void gen_emb_pair(const float* sFr, const float* sV, int ks, bf16x8 (&f)[kNB], const Lane& L) {
-  const float* vrow = sV + L.b;
   if (ks < 28) {
+    // the 8 slots t = 8 ks + j span at most two frequencies: slots j >= jb belong to fj0 + 1 and their coordinate index
+    // wraps to i0 + j - 22, which the 8 wrap rows of sV turn into the plain row i0 + j.  So per k-step: two frequency
+    // reads, one row base; per value: fma + v_sin + half a pack + half a ds_read2 (immediate offsets only).
+    const int t0 = 8 * ks;
+    const int fj0 = (t0 * 2979) >> 16;           // t0 / 22, exact for t0 < 240
+    const int i0 = t0 - 22 * fj0, jb = 22 - i0;
+    const int fj1 = fj0 + 1 > NPP_N_FREQ - 1 ? NPP_N_FREQ - 1 : fj0 + 1;
+    const int fr0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sFr[fj0]));      // scalar registers
+    const int fr1 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sFr[fj1]));
+    const float* v = sV + i0 * kRowTile + L.b;
     const float ph = L.h ? 0.25f : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int t = 8 * ks + j;
-      int fj = (t * 2979) >> 16;                 // t / 22, exact for t < 240
-      const int i = t - 22 * fj;
-      fj = fj > NPP_N_FREQ - 1 ? NPP_N_FREQ - 1 : fj;
-      const float fr = sFr[fj];
-#pragma unroll
-      for (int bt = 0; bt < kNB; ++bt)
-        f[bt][j] = (__bf16)__builtin_amdgcn_sinf(fmaf(vrow[i * kRowTile + bt * 32], fr, ph));
-    }
+    gen_emb_quad<0>(v, jb, fr0, fr1, ph, f);
+    gen_emb_quad<1>(v, jb, fr0, fr1, ph, f);
+    gen_emb_quad<2>(v, jb, fr0, fr1, ph, f);
+    gen_emb_quad<3>(v, jb, fr0, fr1, ph, f);
   } else {                                       // identity block: v_0..v_15 | v_16..v_21, 0...
+    const float* vrow = sV + L.b;
     const int i0 = 16 * (ks - 28) + 8 * L.h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -212,7 +240,9 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   if (!EMB_IN) gen_warp(e.warp, p, sV, sY, sX, L);
   wg_barrier();
   STAMP(51);
-  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) : nullptr;
+  // stash address = uniform (array, workgroup, k-step, batch tile) part + this lane's 32-bit offset (npp_layout.h wfmt_unit)
+  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  const uint32_t lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
   // this wave's k-step q (0, 1) of chunk c: generate, hand to the LDS ring, stash for wgrad
   constexpr int kPer = kChunkKS / kWavesF;                       // k-steps of a chunk generated by one wave (2 or 1)
   auto gen_pair = [&](int c, int q) {
@@ -224,7 +254,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
 #pragma unroll
       for (int bt = 0; bt < kNB; ++bt) {
         lds_store_frag(lds_ring + (c & 1) * kChunkBytes, ksl, bt, L.lane, f[bt]);
-        if (STORE_EMB) stash_store(emb_base + wfmt_unit(kKSEmb, wg, ks, bt, L.b, L.h), f[bt]);
+        if (STORE_EMB) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks, bt, 0, 0) + lane_off, f[bt]);
       }
     }
   };
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
   char* R0 = smem;
   char* R1 = smem + kRegionBytes;
   float* sV = (float*)(smem + 2 * kRegionBytes);
-  float* sY = sV + 22 * kRowTile;
+  float* sY = sV + kVRows * kRowTile;
   float* sX = sY + kRowTile;
   // The embedder constants are indexed with run-time (proposal, orientation, offset)
   // indices: keep them in LDS, copied with compile-time indices so the by-value kernel
