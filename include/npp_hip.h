@@ -34,7 +34,9 @@ extern "C" {
 #define NPP_N_OFF 5         /* options/arg_config.py:20 freq_offsets */
 #define NPP_N_FREQ 10       /* options/arg_config.py:27 multires */
 #define NPP_E 462           /* embedding width per proposal: 22 * (1 + 2*10) */
-#define NPP_WIDTH 256       /* MLP width this build is specialised for (BASELINE c2) */
+#ifndef NPP_WIDTH           /* MLP width this build of the fused chain is specialised for: 256 (BASELINE c2; libnpp_hip.so) */
+#define NPP_WIDTH 256       /* or 512 (the reference's default --netwidth, options/arg_config.py:57; libnpp_hip_w512.so)  */
+#endif
 #define NPP_MAX_TENSORS 32
 #define NPP_ROW_TILE 64     /* rows per workgroup of the fused MLP kernels */
 

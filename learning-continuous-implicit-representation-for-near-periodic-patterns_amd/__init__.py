@@ -5,6 +5,6 @@ the path runs in ``libnpp_hip.so`` (hand-written HIP for gfx950) through the C A
 in ``include/npp_hip.h``.  There is no CPU fallback: if the library is missing or a symbol
 is absent, ``lib()`` raises.
 """
-from ._lib import lib, NppError, EmbedCfg, LIB_PATH, SYMBOLS  # noqa: F401
+from ._lib import lib, NppError, EmbedCfg, LIB_PATH, LIB_PATHS, FUSED_WIDTHS, SYMBOLS  # noqa: F401
 
 __all__ = ["lib", "NppError", "EmbedCfg", "LIB_PATH", "SYMBOLS"]

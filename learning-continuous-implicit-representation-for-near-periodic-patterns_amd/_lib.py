@@ -4,6 +4,10 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NPP_LIB_PATH") or os.path.join(HERE, "libnpp_hip.so")   # override: A/B builds
+# The fused MLP chain is specialised at compile time for one network width (include/npp_hip.h NPP_WIDTH): the same sources
+# built with -DNPP_WIDTH=512 give the library for the reference's default --netwidth (options/arg_config.py:57).
+LIB_PATHS = {256: LIB_PATH, 512: os.environ.get("NPP_LIB_PATH_W512") or os.path.join(HERE, "libnpp_hip_w512.so")}
+FUSED_WIDTHS = tuple(sorted(LIB_PATHS))
 
 NPP_MAX_K, NPP_N_OFF, NPP_N_FREQ, NPP_E, NPP_WIDTH, NPP_ROW_TILE = 5, 5, 10, 462, 256, 64
 
@@ -121,17 +125,20 @@ SYMBOLS = {
     "npp_trunk_export": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
 }
 
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    """Load libnpp_hip.so once and type every entry point.  Raises if the library or any
-    declared symbol is missing -- the product has no other implementation to fall back to."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise NppError(f"{LIB_PATH} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+def lib(width=NPP_WIDTH):
+    """Load the library built for `width` (libnpp_hip.so: 256, libnpp_hip_w512.so: 512) once and type every entry point.
+    Raises if the library or any declared symbol is missing -- the product has no other implementation to fall back to."""
+    L = _LIBS.get(width)
+    if L is not None:
+        return L
+    path = LIB_PATHS.get(width)
+    if path is None:
+        raise NppError(f"no fused library for width {width} (built: {FUSED_WIDTHS}); other widths run through npp_amd.dense")
+    if not os.path.exists(path):
+        raise NppError(f"{path} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
                        "there is no CPU fallback")
     # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE this library
     # is loaded, so that the library's dependency resolves to the same runtime instance torch allocates memory and creates
@@ -139,36 +146,36 @@ def lib():
     # "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
     import torch  # noqa: F401
     try:
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
     except OSError as e:
-        raise NppError(f"cannot load {LIB_PATH}: {e}") from e
+        raise NppError(f"cannot load {path}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(L, name)
         except AttributeError as e:
-            raise NppError(f"{LIB_PATH} does not export {name}") from e
+            raise NppError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    _LIB = L
+    _LIBS[width] = L
     return L
 
 
-def check(rc, what):
+def check(rc, what, width=NPP_WIDTH):
     if rc is not None and rc < 0:
-        msg = lib().npp_last_error_string()
+        msg = lib(width).npp_last_error_string()
         raise NppError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
     return rc
 
 
 def param_layout(K, width=NPP_WIDTH):
     """[(name, offset, rows, cols)], total floats -- the reference's state_dict order."""
-    L = lib()
+    L = lib(width)
     names = (C.c_char_p * 32)()
     offs = (_i64 * 32)()
     rows = (C.c_int32 * 32)()
     cols = (C.c_int32 * 32)()
     total = _i64(0)
-    n = check(L.npp_param_layout(K, width, names, offs, rows, cols, C.byref(total)), "npp_param_layout")
+    n = check(L.npp_param_layout(K, width, names, offs, rows, cols, C.byref(total)), "npp_param_layout", width)
     out = []
     for i in range(n):
         out.append((names[i].decode(), int(offs[i]), int(rows[i]), int(cols[i])))

@@ -223,8 +223,16 @@ struct WRing {
 template <int NTW, int NT>
 __device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, wptr_t wp, int ks, int nt0, int lane) {
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#if defined(NPP_DIAG_WNONE)     // ... or only the first kRD k-steps of a part are fetched at all
+  if (ks >= kRD) return;
+#endif
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
+#if defined(NPP_DIAG_WSAME)     // timing-only diagnostics (wrong results): every wave streams wave 0's tiles (L1 hits) ...
+    nt0 = 0;
+#elif defined(NPP_DIAG_WONE)    // ... or every k-step re-reads k-step 0 (the stream stays, the footprint is one k-step)
+    ks = 0;
+#endif
     const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane * 16, (int)((wp + (uint32_t)((ks * NT + nt0 + nt) * 64)) * 16u), 0);
     r.w[slot][nt] = __builtin_bit_cast(bf16x8, raw);
   }

@@ -15,7 +15,8 @@
 
 namespace npp {
 
-constexpr int kThreadsB = 256;
+constexpr int kThreadsB = 32 * kNT;          // two neuron tiles per wave: 4 waves at W = 256, 8 at W = 512
+constexpr int kKSP = kKSAct / 2;               // k-steps of the W/2-wide P layer
 constexpr int kRegionBytesB = kKSAct * kNB * 1024;
 constexpr int kSmemBwd = 2 * kRegionBytesB + kRowTile * 3 * 4;
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   wg_barrier();
   // dz_rgb as a 2-k-step W-format array: features 0..2 real, the rest zero
   {
-    const int q1 = L.tid >> 7, bt = (L.tid >> 6) & 1, row = bt * 32 + L.b;
+    const int q1 = L.tid >> 7, bt = (L.tid >> 6) & 1, row = bt * 32 + L.b;        // waves 0..3: (k-step q1, batch tile bt)
     bf16x8 f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       f[1] = (__bf16)sDraw[row * 3 + 1];
       f[2] = (__bf16)sDraw[row * 3 + 2];
     }
-    stash_store(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
+    if (q1 < 2) stash_store(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
   }
 
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
   // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
   zero_acc(acc1);
-  mma_ring<0, 8, 8, 8, 2, kNT>(acc1, R0, 0, wbl(BP1), MULTI ? wbl(BP2) : wbl(BF1), kt0, L, ring);   // df1, part 1
+  mma_ring<0, kKSP, kKSP, kKSP, 2, kNT>(acc1, R0, 0, wbl(BP1), MULTI ? wbl(BP2) : wbl(BF1), kt0, L, ring);   // df1, part 1
   if (MULTI) {
     zero_acc(acc);
-    mma_ring<0, 8, 8, 8, 2, kNT>(acc, R0, 0, wbl(BP2), wbl(BF2), kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
+    mma_ring<0, kKSP, kKSP, kKSP, 2, kNT>(acc, R0, 0, wbl(BP2), wbl(BF2), kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
     bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
     wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0

@@ -36,12 +36,13 @@ int check_embed_cfg(const npp_embed_cfg* c, const char* who);
 // per CU) or 8 (1 tile each; <= 128 VGPRs, 4 waves per SIMD: more independent instruction streams to cover the LDS
 // hand-off / barrier / weight-load latencies of the layer chain).  Same LDS image, same stash layout either way.
 #ifndef NPP_FWD_WAVES
-#define NPP_FWD_WAVES 4
+#define NPP_FWD_WAVES (NPP_WIDTH / 64)       // two neuron tiles per wave: 4 waves at W = 256, 8 at W = 512
 #endif
 constexpr int kWavesF = NPP_FWD_WAVES;
 constexpr int kNTW = kNT / kWavesF;                             // neuron tiles per wave in 256-wide layers
 constexpr int kThreads = 64 * kWavesF;
 static_assert(kWavesF == 4 || kWavesF == 8, "4 or 8 waves per workgroup");
+static_assert(kNT % kWavesF == 0 && kNT / 2 <= kWavesF, "every wave owns kNT / kWavesF neuron tiles; P's kNT / 2 tiles go one per wave");
 constexpr int kFragBytes = 1024;                               // 64 lanes x 16 B
 constexpr int kRegionBytes = kKSAct * kNB * kFragBytes;        // 32 KiB: 256 feats x 64 rows bf16
 constexpr int kChunkKS = 8;                                    // k-steps per embedding chunk
@@ -57,7 +58,10 @@ struct WarpEnt { float cs, sn, per, inv_per, phase, lin; };   // lin: value = t 
 constexpr int kSmemWarp = NPP_MAX_K * 22 * (int)sizeof(WarpEnt);                // 3520
 // the 4-wave rgb partial sums reuse region R0 after a barrier (everything else is dead by then)
 constexpr int kSmemFwd = 2 * kRegionBytes + kSmemV + 2 * kRowTile * 4 + kSmemE + kSmemWarp;
-static_assert(kSmemFwd <= 80 * 1024, "two workgroups per CU");
+// W = 256: two workgroups per CU (<= 80 KiB each); W = 512: the two 64-KiB regions leave room for one
+constexpr int kWgPerCuF = kSmemFwd <= 80 * 1024 ? 2 : 1;
+static_assert(kSmemFwd <= 160 * 1024, "LDS");
+constexpr int kWavesPerSimdF = kWgPerCuF * kWavesF / 4;          // 2 (256 VGPRs) except the 8-wave W = 256 form (4, 128 VGPRs)
 
 // Diagnostic build only (-DNPP_STAMPS): per-phase s_memtime stamps of wave 0 of two workgroups,
 // read back with npp_debug_read_stamps().  Never compiled into the shipped library.
@@ -327,7 +331,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 }
 
 template <bool TRAIN, bool MULTI, bool EMB_IN = false>
-__global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
+__global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R0 = smem;
   char* R1 = smem + kRegionBytes;
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(kThreads, kWavesF / 2) void mlp_fwd_kernel(FwdArgs 
       const int row = L.tid / 3, c = L.tid - row * 3;
       float z = P[d.b_off[LRGB] + c];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];
+      for (int w = 0; w < kNT / 2; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];   // P's neuron tiles, in order
       float o = 1.0f / (1.0f + __expf(-z));                         // helpers.py:56 sigmoid
       if (EMB_IN && A_.out_act != 1) o = A_.out_act == 2 ? tanhf(z) : z;   // helpers.py:57-58 tanh / raw network output
       A_.pred[(row0 + row) * 3 + c] = o;

@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int kT32 = 256;                          // threads: 4 waves, 2 neuron tiles each
+constexpr int kT32 = 32 * kNT;                     // threads: 2 neuron tiles per wave (4 waves at W = 256, 8 at W = 512)
 constexpr int kRegion32 = kW * kRowTile * 4;       // 64 KiB: 256 features x 64 rows fp32
 struct WarpEnt32 { float cs, sn, per, inv_per, phase, lin; };
 constexpr int kSmem32 = kRegion32 + 22 * kRowTile * 4 + 2 * kRowTile * 4 + ((sizeof(EmbedDev) + 15) / 16) * 16 +
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   // the 22 warped coordinates of proposal p -> sV (the same arithmetic as the bf16 chain's gen_warp)
   auto gen_warp = [&](int p) {
     const float y = sY[lane], x = sX[lane];
-    for (int i = wave; i < 22; i += 4) {
+    for (int i = wave; i < 22; i += kT32 / 64) {
       const WarpEnt32 w = tWarp[p * 22 + i];
       const float t = __fadd_rn(__fmul_rn(y, w.cs), __fmul_rn(x, w.sn));
       const float qf = floorf(t * w.inv_per);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
     const int row = tid / 3, c = tid - row * 3;
     float z = P[d.b_off[LRGB] + c];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];
+    for (int w = 0; w < kNT / 2; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];
     const float o = A_.out_act == 1 ? 1.0f / (1.0f + expf(-z)) : (A_.out_act == 2 ? tanhf(z) : z);
     A_.pred[(row0 + row) * 3 + c] = o;
   }

@@ -24,8 +24,9 @@ class CompletionFit:
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
-                 vgg16_style_state_dict=None, masked_img=None):
+                 vgg16_style_state_dict=None, masked_img=None, width=256):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
+        width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
         (np.random.uniform, np.random.choice(replace=False) for the patch centres and the N_rand pixel rows:
@@ -75,7 +76,7 @@ class CompletionFit:
         self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
         self.pixel_mask = None if pixel_mask is None else torch.from_numpy(pixel_mask[..., 0].copy()).to(self.device)
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
-                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay)
+                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay, width=width)
         if task == "segmentation":
             self.net.lr_clock = False                              # NPP_segmentation/train.py:408 (see NPPNet.lr_clock)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))

@@ -21,11 +21,12 @@ class NPPNet:
     """
 
     def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=None,
-                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5)):
+                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5), width=NPP_WIDTH):
         self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
         self.K = int(self.cfg.K)
+        self.width = int(width)      # 256 (BASELINE configs) or 512 (the reference's default --netwidth): one fused library each
         self.device = ops.select_device(device)
-        self.layout, self.n_params = param_layout(self.K)
+        self.layout, self.n_params = param_layout(self.K, self.width)
         self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
@@ -40,15 +41,15 @@ class NPPNet:
         self._loss_idx = 0
         self._clean = False
         self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
-        self.ksplit = int(ksplit) if ksplit else ops.auto_ksplit(self.K, self.device)   # None / 0: one round of workgroups
+        self.ksplit = int(ksplit) if ksplit else ops.auto_ksplit(self.K, self.device, self.width)   # None / 0: one round of workgroups
         self.lrate, self.lrate_decay = float(lrate), int(lrate_decay)
         self.lr = float(lrate)
         self.global_step = 0        # train.py:337
         self.lr_clock = True        # False: the LR clock never advances (NPP_segmentation/train.py:408: `global_step += 1` sits
                                     # outside the loop there, so that task trains at a constant lrate) -- reproduced, not fixed
         self.opt_step = 0           # Adam's per-parameter step count
-        self.wf = torch.empty(ops.pack_bytes(self.K, 0), dtype=torch.uint8, device=self.device)
-        self.wb = torch.empty(ops.pack_bytes(self.K, 1), dtype=torch.uint8, device=self.device)
+        self.wf = torch.empty(ops.pack_bytes(self.K, 0, self.width), dtype=torch.uint8, device=self.device)
+        self.wb = torch.empty(ops.pack_bytes(self.K, 1, self.width), dtype=torch.uint8, device=self.device)
         self._ws = {}
         if params is not None:
             self.load_state_dict(params)
@@ -83,13 +84,13 @@ class NPPNet:
         return out
 
     def repack(self):
-        ops.pack_weights(self.params, self.K, self.wf, self.wb)
+        ops.pack_weights(self.params, self.K, self.wf, self.wb, self.width)
 
     # ---- workspaces -----------------------------------------------------------------
     def workspace(self, Bp):
         ws = self._ws.get(Bp)
         if ws is None:
-            s = ops.train_workspace(self.K, Bp, self.ksplit)
+            s = ops.train_workspace(self.K, Bp, self.ksplit, self.width)
             dev = self.device
             ws = {
                 "actT": torch.empty(s[1], dtype=torch.uint8, device=dev),
@@ -111,7 +112,7 @@ class NPPNet:
         if bp != n:
             pad = torch.zeros((bp - n, 2), dtype=torch.int32, device=coords.device)
             coords = torch.cat([coords, pad], 0)
-        pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params)
+        pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params, width=self.width)
         return pred[:n]
 
     def render_fp32(self, coords):
@@ -124,21 +125,21 @@ class NPPNet:
             coords = torch.cat([coords, torch.zeros((bp - n, 2), dtype=torch.int32, device=coords.device)], 0)
         stamp = (self.opt_step, self.params._version)
         if getattr(self, "_w32_stamp", None) != stamp:
-            self._w32 = ops.pack_weights32(self.params, self.K, getattr(self, "_w32", None))
+            self._w32 = ops.pack_weights32(self.params, self.K, getattr(self, "_w32", None), self.width)
             self._w32_stamp = stamp
-        return ops.mlp_fwd32(coords.contiguous(), self.cfg, self._w32, self.params)[:n]
+        return ops.mlp_fwd32(coords.contiguous(), self.cfg, self._w32, self.params, width=self.width)[:n]
 
     def forward_train(self, coords_padded):
         """Forward with stashes; coords must already be padded to a multiple of 64 rows."""
         ws = self.workspace(coords_padded.shape[0])
-        ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["actT"])
+        ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["actT"], self.width)
         return ws["pred"]
 
     def backward(self, Bp):
         """loss.backward() through the MLP: consumes ws['dpred'] (rows beyond the batch 0)."""
         ws = self._ws[Bp]
-        ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"])
-        ops.mlp_wgrad(ws["dzT"], ws["actT"], Bp, self.K, self.ksplit, ws["gslabs"])
+        ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], self.width)
+        ops.mlp_wgrad(ws["dzT"], ws["actT"], Bp, self.K, self.ksplit, ws["gslabs"], self.width)
 
     def pixel_loss(self, Bp, n_rows, gt, mask=None, weight=1.0):
         """img2mse on the first n_rows rows of the current prediction (train.py:195);

@@ -125,8 +125,8 @@ def warp_fwd(coords, cfg):
 
 
 def pack_bytes(K, which, width=NPP_WIDTH):
-    n = lib().npp_pack_bytes(K, width, which)
-    check(n, "npp_pack_bytes")
+    n = lib(width).npp_pack_bytes(K, width, which)
+    check(n, "npp_pack_bytes", width)
     return int(n)
 
 
@@ -136,13 +136,13 @@ def pack_weights(params, K, wf=None, wb=None, width=NPP_WIDTH):
         wf = torch.empty(pack_bytes(K, 0, width), dtype=torch.uint8, device=params.device)
     if wb is None:
         wb = torch.empty(pack_bytes(K, 1, width), dtype=torch.uint8, device=params.device)
-    check(lib().npp_pack_weights(_p(params), _p(wf), _p(wb), K, width, _stream()), "npp_pack_weights")
+    check(lib(width).npp_pack_weights(_p(params), _p(wf), _p(wb), K, width, _stream()), "npp_pack_weights", width)
     return wf, wb
 
 
 def train_workspace(K, Bp, ksplit, width=NPP_WIDTH):
     sizes = (C.c_int64 * 4)()
-    check(lib().npp_train_workspace(K, width, Bp, ksplit, sizes), "npp_train_workspace")
+    check(lib(width).npp_train_workspace(K, width, Bp, ksplit, sizes), "npp_train_workspace", width)
     return [int(s) for s in sizes]
 
 
@@ -153,8 +153,8 @@ def mlp_fwd(coords, cfg, wf, params, pred=None, actF=None, width=NPP_WIDTH):
     bp = coords.shape[0]
     if pred is None:
         pred = torch.empty((bp, 3), dtype=torch.float32, device=coords.device)
-    check(lib().npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(actF), _stream()),
-          "npp_mlp_fwd")
+    check(lib(width).npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(actF), _stream()),
+          "npp_mlp_fwd", width)
     return pred
 
 
@@ -165,16 +165,16 @@ def mlp_fwd_emb(emb, K, wf, params, out=None, actF=None, out_act=0, width=NPP_WI
     bp = emb.shape[0]
     if out is None:
         out = torch.empty((bp, 3), dtype=torch.float32, device=emb.device)
-    check(lib().npp_mlp_fwd_emb(_p(emb), emb.stride(0), bp, K, width, _p(wf), _p(params), _p(out), _p(actF), out_act,
-                                _stream()), "npp_mlp_fwd_emb")
+    check(lib(width).npp_mlp_fwd_emb(_p(emb), emb.stride(0), bp, K, width, _p(wf), _p(params), _p(out), _p(actF), out_act,
+                                _stream()), "npp_mlp_fwd_emb", width)
     return out
 
 
 def mlp_bwd_act(dout, out, K, wb, params, actF, dzF, out_act, width=NPP_WIDTH):
     _req(dout, torch.float32, "dout")
     _req(out, torch.float32, "out", dout.shape)
-    check(lib().npp_mlp_bwd_act(_p(dout), _p(out), dout.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
-                                out_act, _stream()), "npp_mlp_bwd_act")
+    check(lib(width).npp_mlp_bwd_act(_p(dout), _p(out), dout.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                                out_act, _stream()), "npp_mlp_bwd_act", width)
 
 
 def grad_reduce(gslabs, n_slabs, n, grad, accumulate=False):
@@ -195,24 +195,24 @@ def fourier_fwd(x, freqs, include_input=True):
 def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
     _req(dpred, torch.float32, "dpred")
     _req(pred, torch.float32, "pred", dpred.shape)
-    check(lib().npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
-                            _stream()), "npp_mlp_bwd")
+    check(lib(width).npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                            _stream()), "npp_mlp_bwd", width)
 
 
-def auto_ksplit(K, device):
+def auto_ksplit(K, device, width=NPP_WIDTH):
     """Split-K factor that makes the grouped weight-gradient launch (tiles x ksplit workgroups, one per CU) fill the
     chip in exactly one round."""
-    tiles = check(lib().npp_mlp_wgrad_tiles(K), "npp_mlp_wgrad_tiles")
+    tiles = check(lib(width).npp_mlp_wgrad_tiles(K), "npp_mlp_wgrad_tiles", width)
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     return max(1, min(64, cus // tiles))
 
 
 def pack_weights32(params, K, w32=None, width=NPP_WIDTH):
     """fp32 blob -> the fp32 A-operand pack of npp_mlp_fwd32."""
-    n = int(lib().npp_pack32_bytes(K, width))
+    n = int(lib(width).npp_pack32_bytes(K, width))
     if w32 is None:
         w32 = torch.empty(n, dtype=torch.uint8, device=params.device)
-    check(lib().npp_pack_weights32(_p(params), _p(w32), K, width, _stream()), "npp_pack_weights32")
+    check(lib(width).npp_pack_weights32(_p(params), _p(w32), K, width, _stream()), "npp_pack_weights32", width)
     return w32
 
 
@@ -222,14 +222,14 @@ def mlp_fwd32(coords_yx, cfg, w32, params, out=None, out_act=1, width=NPP_WIDTH)
     Bp = coords_yx.shape[0]
     if out is None:
         out = torch.empty((Bp, 3), dtype=torch.float32, device=coords_yx.device)
-    check(lib().npp_mlp_fwd32(_p(coords_yx), Bp, C.byref(cfg), width, _p(w32), _p(params), _p(out), int(out_act), _stream()),
-          "npp_mlp_fwd32")
+    check(lib(width).npp_mlp_fwd32(_p(coords_yx), Bp, C.byref(cfg), width, _p(w32), _p(params), _p(out), int(out_act), _stream()),
+          "npp_mlp_fwd32", width)
     return out
 
 
 def mlp_wgrad(dzT, actT, Bp, K, ksplit, gslabs, width=NPP_WIDTH):
     _req(gslabs, torch.float32, "gslabs")
-    check(lib().npp_mlp_wgrad(_p(dzT), _p(actT), Bp, K, width, ksplit, _p(gslabs), _stream()), "npp_mlp_wgrad")
+    check(lib(width).npp_mlp_wgrad(_p(dzT), _p(actT), Bp, K, width, ksplit, _p(gslabs), _stream()), "npp_mlp_wgrad", width)
 
 
 def load_spline(device):

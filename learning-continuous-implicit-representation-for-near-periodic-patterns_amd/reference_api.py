@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import EmbedCfg, param_layout, NPP_E, NPP_WIDTH, NPP_N_FREQ
+from ._lib import EmbedCfg, param_layout, NPP_E, NPP_WIDTH, NPP_N_FREQ, FUSED_WIDTHS  # noqa: F401
 
 _DEFAULT_OFFSETS = (0.0, -1.0, 1.0, 0.5, -0.5)
 _OUT_ACT = {None: 0, 0: 0, 1: 1, 2: 2}
@@ -143,7 +143,7 @@ class _NetFunction(torch.autograd.Function):
         # `train` is decided by the caller: inside forward() grad mode is always off, and needs_input_grad
         # ignores torch.no_grad().  The stash belongs to THIS call until its backward has run.
         ws = net._take_workspace(bp) if train else None
-        out = ops.mlp_fwd_emb(e, net.K, net._wf, blob.detach(), None, ws["actT"] if train else None, out_act)
+        out = ops.mlp_fwd_emb(e, net.K, net._wf, blob.detach(), None, ws["actT"] if train else None, out_act, net.W)
         ctx.net, ctx.n, ctx.bp, ctx.out_act, ctx.ws = net, n, bp, out_act, ws
         ctx.save_for_backward(out)
         return out[:n]
@@ -158,8 +158,8 @@ class _NetFunction(torch.autograd.Function):
         g = gout.contiguous().float()
         if bp != n:
             g = torch.cat([g, g.new_zeros((bp - n, 3))], 0)
-        ops.mlp_bwd_act(g, out, net.K, net._wb, net._blob.detach(), ws["actT"], ws["dzT"], ctx.out_act)
-        ops.mlp_wgrad(ws["dzT"], ws["actT"], bp, net.K, net._ksplit, ws["gslabs"])
+        ops.mlp_bwd_act(g, out, net.K, net._wb, net._blob.detach(), ws["actT"], ws["dzT"], ctx.out_act, net.W)
+        ops.mlp_wgrad(ws["dzT"], ws["actT"], bp, net.K, net._ksplit, ws["gslabs"], net.W)
         gb = torch.empty_like(net._blob)
         ops.grad_reduce(ws["gslabs"], net._ksplit, net._n_params, gb)
         net._give_workspace(bp, ws)
@@ -175,13 +175,13 @@ class _NetBase(nn.Module):
 
     def __init__(self, K, D, W, skips, activation, device, tail_order):
         super().__init__()
-        if D != 8 or W != NPP_WIDTH or list(skips) != [4]:
-            raise NotImplementedError(f"kernels are specialised for D=8, W={NPP_WIDTH}, skips=[4] (got D={D}, W={W}, skips={skips})")
+        if D != 8 or W not in FUSED_WIDTHS or list(skips) != [4]:
+            raise NotImplementedError(f"kernels are specialised for D=8, W in {FUSED_WIDTHS}, skips=[4] (got D={D}, W={W}, skips={skips})")
         if activation != "snake":
             raise NotImplementedError("kernels implement the 'snake' activation (the reference's setting, configs/*.txt)")
         self.K, self.D, self.W, self.skips = K, D, W, list(skips)
         dev = torch.device(device)
-        self._layout, self._n_params = param_layout(K)
+        self._layout, self._n_params = param_layout(K, W)
         index = {name: (off, r, c) for name, off, r, c in self._layout}
         blob = torch.zeros(self._n_params, dtype=torch.float32)
         self._unused = {}       # tensors the reference constructs but never uses (alpha_linear; top1: feature_linear2)
@@ -198,8 +198,8 @@ class _NetBase(nn.Module):
                 else:
                     self._unused[key] = t.detach().clone()
         self._blob = nn.Parameter(blob.to(dev))
-        self._wf = torch.empty(ops.pack_bytes(K, 0), dtype=torch.uint8, device=dev)
-        self._wb = torch.empty(ops.pack_bytes(K, 1), dtype=torch.uint8, device=dev)
+        self._wf = torch.empty(ops.pack_bytes(K, 0, W), dtype=torch.uint8, device=dev)
+        self._wb = torch.empty(ops.pack_bytes(K, 1, W), dtype=torch.uint8, device=dev)
         self._packed_version = -1
         self._ksplit = 4
         self._ws = {}
@@ -233,7 +233,7 @@ class _NetBase(nn.Module):
     def _sync_pack(self):
         v = self._blob._version
         if v != self._packed_version:
-            ops.pack_weights(self._blob.detach(), self.K, self._wf, self._wb)
+            ops.pack_weights(self._blob.detach(), self.K, self._wf, self._wb, self.W)
             self._packed_version = v
 
     def _take_workspace(self, bp):
@@ -241,7 +241,7 @@ class _NetBase(nn.Module):
         free = self._ws.get(bp)
         if free:
             return free.pop()
-        s = ops.train_workspace(self.K, bp, self._ksplit)
+        s = ops.train_workspace(self.K, bp, self._ksplit, self.W)
         dev = self._blob.device
         return {"actT": torch.empty(s[1], dtype=torch.uint8, device=dev),
                 "dzT": torch.empty(s[2], dtype=torch.uint8, device=dev),
@@ -264,14 +264,14 @@ class _NetBase(nn.Module):
 
 
 def _fused_config(D, W, skips, activation, *widths):
-    """The fused chain kernels serve D = 8, W = 256, skips = [4], snake and 462-wide proposals; everything else goes to the
-    generic dense-layer path (dense.py)."""
-    return D == 8 and W == NPP_WIDTH and list(skips) == [4] and activation == "snake" and all(w % NPP_E == 0 and w > 0 for w in widths)
+    """The fused chain kernels serve D = 8, W = 256 or 512 (one library each), skips = [4], snake and 462-wide proposals;
+    everything else goes to the generic dense-layer path (dense.py)."""
+    return D == 8 and W in FUSED_WIDTHS and list(skips) == [4] and activation == "snake" and all(w % NPP_E == 0 and w > 0 for w in widths)
 
 
 class NPP_Net(_NetBase):
     """models/networks.py:8-95 (K > 1: top-1 proposal + auxiliary proposals).  Configurations outside the fused kernels'
-    specialisation (e.g. the reference's default netwidth 512, activation='relu', other multires) are constructed as
+    specialisation (e.g. netwidth 128, activation='relu', other multires) are constructed as
     dense.DenseNPPNet: same arguments, parameter names and forward, one launch per layer."""
 
     def __new__(cls, input_ch_periodic, input_ch_periodic_aux, freq_scales, freq_offsets, angle_offsets, D=8, W=256, freq_nerf=3,

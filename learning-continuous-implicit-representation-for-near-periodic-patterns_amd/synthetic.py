@@ -50,10 +50,10 @@ def synthetic_periodicity(H, K):
     return angles, periods, shifts
 
 
-def init_params(K, seed=0):
+def init_params(K, seed=0, width=256):
     """nn.Linear default init (U(-1/sqrt(in), 1/sqrt(in)) for weight and bias) for every tensor of the parameter blob, from a
     NumPy stream: initial weights are an explicit input of the path."""
-    layout, _ = param_layout(K)
+    layout, _ = param_layout(K, width)
     rng = np.random.RandomState(seed)
     P, bound = {}, 1.0
     for name, _, rows, cols in layout:

@@ -7,8 +7,8 @@ Reads config.odgt + PNGs (npp_amd.io), builds the net with torch's default nn.Li
 frequencies drawn from torch's global generator like the reference (models/embedder.py:26, models/networks.py:40-49;
 seed with --seed), runs N_iters iterations of the complete loop body (CompletionFit.step_full) and writes
 results/<expname>_top<K>/<name>/testset_<iter>/*.png every --i_testset iterations (train.py:270-328).
-Flags keep the reference's names and defaults (options/arg_config.py:10-36,55-100) except --netwidth, which this
-build fixes at 256 (BASELINE.json; the reference's default is 512).
+Flags keep the reference's names and defaults (options/arg_config.py:10-36,55-100) except --netwidth, whose default here
+is 256 (BASELINE.json's configuration); the reference's default 512 is the second fused build (libnpp_hip_w512.so).
 """
 import argparse
 import os
@@ -87,8 +87,8 @@ def main(argv=None):
         args.N_iters = {"remapping": 2801, "segmentation": 601}.get(args.task, 2001)     # arg_config.py:96,202,289
     if args.i_testset is None:
         args.i_testset = {"remapping": 400, "segmentation": 600}.get(args.task, 500)
-    if args.netwidth != 256:
-        raise SystemExit("this build is specialised for --netwidth 256 (BASELINE.json); the reference default 512 is not built")
+    if args.netwidth not in (256, 512):
+        raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     need = {"--vgg19": args.vgg19} if (remap_task or seg_task) else {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
@@ -119,7 +119,7 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()       # embedder.py:26
-    layout, n_params = param_layout(K)
+    layout, n_params = param_layout(K, args.netwidth)
     params = default_linear_init(layout, n_params, args.seed)
 
     def load(path):
@@ -136,7 +136,7 @@ def main(argv=None):
                         task=args.task, clear_mask=d["clear_mask"] if remap else None,
                         masked_img=None if remap else d.get("masked_img"),
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
-                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not (remap or seg))
+                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not (remap or seg), width=args.netwidth)
     name = os.path.basename(os.path.normpath(args.datadir))
     expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
     outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)

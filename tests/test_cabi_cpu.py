@@ -20,16 +20,17 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "npp_hip.h")).read()
     declared = set(re.findall(r"\b(npp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(SYMBOLS), declared ^ set(SYMBOLS)
-    L = npp_amd.lib()
-    for name in declared:
-        assert hasattr(L, name)
-    assert L.npp_version() >= 100
+    for width in npp_amd.FUSED_WIDTHS:                   # libnpp_hip.so (W = 256) and libnpp_hip_w512.so: same C ABI
+        L = npp_amd.lib(width)
+        for name in declared:
+            assert hasattr(L, name)
+        assert L.npp_version() >= 100
 
 
-@pytest.mark.parametrize("K", [1, 3, 5])
-def test_param_layout_matches_reference_state_dict(K):
-    lay, total = param_layout(K)
-    shapes = oracle.param_shapes(K)
+@pytest.mark.parametrize("K,W", [(1, 256), (3, 256), (5, 256), (3, 512), (1, 512)])
+def test_param_layout_matches_reference_state_dict(K, W):
+    lay, total = param_layout(K, W)
+    shapes = oracle.param_shapes(K, W=W)
     assert [n for n, *_ in lay] == list(shapes)          # same tensors, same order
     off = 0
     for name, o, rows, cols in lay:
@@ -38,15 +39,20 @@ def test_param_layout_matches_reference_state_dict(K):
         assert rows == shp[0] and cols == (shp[1] if len(shp) == 2 else 1)
         off += int(np.prod(shp))
     assert off == total
-    if K == 3:
+    if K == 3 and W == 256:
         assert total == 1197572 - 257                     # SURVEY.md 8a5 minus the unused alpha_linear
+    if K == 3 and W == 512:
+        assert total == 3836932 - 513                     # the reference's default width
 
 
 def test_bad_arguments_are_reported_not_crashed():
     L = npp_amd.lib()
     assert L.npp_pack_bytes(9, 256, 0) < 0
-    assert L.npp_pack_bytes(3, 512, 0) < 0
+    assert L.npp_pack_bytes(3, 512, 0) < 0               # each library serves the width it was compiled for
     assert b"width" in L.npp_last_error_string()
+    L5 = npp_amd.lib(512)
+    assert L5.npp_pack_bytes(3, 256, 0) < 0 and b"width" in L5.npp_last_error_string()
+    assert L5.npp_pack_bytes(3, 512, 0) > 4 * L.npp_pack_bytes(3, 256, 0) // 2
     sizes = (C.c_int64 * 4)()
     assert L.npp_train_workspace(3, 256, 100, 4, sizes) < 0   # Bp not a multiple of 64
     assert L.npp_train_workspace(3, 256, 128, 4, sizes) == 0

@@ -26,11 +26,11 @@ def _grid(H, W, dev):
     return torch.stack([yy.reshape(-1), xx.reshape(-1)], 1).contiguous().to(dev)
 
 
-def _net(dev, K, H, seed=0):
+def _net(dev, K, H, seed=0, width=256):
     from npp_amd.model import NPPNet
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
-    P = oracle.init_params(K, seed=seed)
-    return NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=3), P, angles, periods
+    P = oracle.init_params(K, W=width, seed=seed)
+    return NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=3, width=width), P, angles, periods
 
 
 @pytest.mark.parametrize("K,H", [(3, 512), (5, 512), (3, 1024)])
@@ -59,8 +59,8 @@ def test_full_grid_render_is_row_independent_and_matches_oracle_sample(dev, K, H
     assert np.abs(got - oracle.sigmoid(raw_f)).max() < 2e-2          # plain fp32 maths
 
 
-@pytest.mark.parametrize("K", [3, 1])
-def test_c2_full_grid_fused_chain_vs_exact_fp32_dense_path(dev, K):
+@pytest.mark.parametrize("K,W", [(3, 256), (1, 256), (3, 512), (1, 512)])
+def test_c2_full_grid_fused_chain_vs_exact_fp32_dense_path(dev, K, W):
     """Two independent implementations of NPP_Net inside the library on all 262 144 pixels of the c2 grid: the fused bf16
     chain (coordinates in, embedding generated in registers) and dense.py (materialised fp32 embedding from the stand-alone
     embedder, one exact-fp32 MFMA GEMM per layer).  Budget: the 0.1 dB PSNR tolerance of BASELINE.json corresponds to
@@ -68,16 +68,16 @@ def test_c2_full_grid_fused_chain_vs_exact_fp32_dense_path(dev, K):
     from npp_amd import ops, EmbedCfg
     from npp_amd.dense import DenseNPPNet, DenseNPPNetTop1
     H = 512
-    net, P, angles, periods = _net(dev, K, H)
+    net, P, angles, periods = _net(dev, K, H, width=W)       # W = 512: the reference's default --netwidth (libnpp_hip_w512.so)
     grid = _grid(H, H, dev)
     fused = net.render(grid)
     cfg = EmbedCfg.make(angles, periods, oracle.SEED0_FREQS, (H, H))
     emb = ops.embed_fwd(grid, cfg, torch.float32, precise=True)
     assert emb.shape == (H * H, K * 462)
     if K > 1:
-        dn = DenseNPPNet(22, 22 * (K - 1), [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=256, freq_nerf=21, activation="snake", device=dev)
+        dn = DenseNPPNet(22, 22 * (K - 1), [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=W, freq_nerf=21, activation="snake", device=dev)
     else:
-        dn = DenseNPPNetTop1(22, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=256, freq_nerf=21, activation="snake", device=dev)
+        dn = DenseNPPNetTop1(22, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=W, freq_nerf=21, activation="snake", device=dev)
     missing, unexpected = dn.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=False)
     assert not unexpected and all(m.split(".")[0] in ("alpha_linear", "feature_linear2") for m in missing), (missing, unexpected)
     with torch.no_grad():
@@ -85,7 +85,7 @@ def test_c2_full_grid_fused_chain_vs_exact_fp32_dense_path(dev, K):
     d = (fused - dense).abs()
     mse = float((d.double() ** 2).mean())
     psnr = -10.0 * np.log10(mse)
-    print(f"K={K}: fused vs exact-fp32 dense path over {H * H} pixels: max |d| {float(d.max()):.2e}, PSNR {psnr:.1f} dB")
+    print(f"K={K} W={W}: fused vs exact-fp32 dense path over {H * H} pixels: max |d| {float(d.max()):.2e}, PSNR {psnr:.1f} dB")
     assert float(d.max()) < 5e-3 and psnr > 65.0                     # measured: 3.8e-4 / 84 dB (K = 3), 1.6e-4 / 90 dB (K = 1)
 
 
@@ -224,12 +224,12 @@ def test_c5_full_size_iteration_set(dev):
     assert bool(torch.isfinite(fit.net.params).all()) and fit.psnr() > max(p0 + 8.0, 25.0)
 
 
-@pytest.mark.parametrize("K,H", [(1, 256), (3, 512), (5, 512)])
-def test_fused_fp32_render_matches_fp32_oracle(dev, K, H):
+@pytest.mark.parametrize("K,H,W", [(1, 256, 256), (3, 512, 256), (5, 512, 256), (3, 256, 512)])
+def test_fused_fp32_render_matches_fp32_oracle(dev, K, H, W):
     """npp_mlp_fwd32 (BASELINE config c4's arithmetic: fused chain on v_mfma_f32_32x32x2_f32, f32 operands and accumulation)
     against the NumPy oracle in plain fp32 -- no bf16 emulation on either side -- on a row sample of the full grid, and
     against the bf16 chain on every pixel; chunking / permutation invariance is bit-exact."""
-    net, P, angles, periods = _net(dev, K, H)
+    net, P, angles, periods = _net(dev, K, H, width=W)
     grid = _grid(H, H, dev)
     n = grid.shape[0]
     full = net.render_fp32(grid)

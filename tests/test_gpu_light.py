@@ -231,6 +231,32 @@ def test_generic_width_net_vs_reference(dev, golden, tag, K):
     assert net.alpha_linear.weight.grad is None                      # constructed, never used
 
 
+def test_default_width_512_snake_is_the_fused_chain(dev):
+    """netwidth 512 with the snake activation (the reference's default width, options/arg_config.py:57, with configs/*.txt's
+    activation) is served by the fused chain built with -DNPP_WIDTH=512, not by dense.py: forward + every parameter gradient of
+    the reference-style module against the exact-fp32 dense-layer implementation of the same network."""
+    from npp_amd import reference_api as ra
+    from npp_amd.dense import DenseNPPNet
+    torch.manual_seed(0)
+    net = ra.NPP_Net(22, 44, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=512, freq_nerf=21, activation="snake", device=dev)
+    assert type(net).__name__ == "NPP_Net" and net.W == 512
+    dn = DenseNPPNet(22, 44, [1], [0, -1, 1, 0.5, -0.5], [0], D=8, W=512, freq_nerf=21, activation="snake", device=dev)
+    dn.load_state_dict(net.state_dict(), strict=False)
+    x = torch.rand(300, 3 * 462, device=dev) * 2 - 1
+    y = torch.rand(300, 3, device=dev)
+    la = ((torch.sigmoid(net(None, x)) - y) ** 2).mean()
+    la.backward()
+    lb = ((torch.sigmoid(dn(None, x)) - y) ** 2).mean()
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 2e-3 * abs(float(lb))
+    g = net.grads_by_name() if hasattr(net, "grads_by_name") else None
+    ref = {k: p.grad for k, p in dn.named_parameters() if p.grad is not None}
+    blob_g = net._blob.grad
+    for name, off, r, c in net._layout:
+        got = blob_g[off:off + r * c].cpu().numpy()
+        assert rel_l2(got, ref[name].reshape(-1).cpu().numpy()) < 3e-2, name      # bf16 operands vs exact fp32
+
+
 def test_default_width_512_relu_trains(dev):
     """The reference's own defaults (netwidth 512) and its other activation: a few Adam steps through the reference-style
     loop (create-net, forward, loss.backward(), optimizer.step()) against a plain PyTorch copy of the same module."""

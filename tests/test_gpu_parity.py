@@ -151,19 +151,21 @@ def test_pack_device_equals_host_twin(dev, K):
     assert np.array_equal(wb.cpu().numpy(), hb)
 
 
-def _net(dev, K, H=256, seed=0, ksplit=3):
+def _net(dev, K, H=256, seed=0, ksplit=3, width=256):
     from npp_amd.model import NPPNet
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
-    P = oracle.init_params(K, seed=seed)
-    net = NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=ksplit)
+    P = oracle.init_params(K, W=width, seed=seed)
+    net = NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=ksplit, width=width)
     return net, P, angles, periods
 
 
-@pytest.mark.parametrize("K", [3, 1, 5])
-@pytest.mark.parametrize("n", [64, 1000])
-def test_fused_forward_matches_oracle(dev, K, n):
+@pytest.mark.parametrize("K,n,width", [(3, 64, 256), (1, 64, 256), (5, 64, 256), (3, 1000, 256), (1, 1000, 256), (5, 1000, 256),
+                                         (3, 1000, 512), (1, 200, 512), (5, 64, 512)])
+def test_fused_forward_matches_oracle(dev, K, n, width):
+    """width 512 = the reference's default --netwidth (options/arg_config.py:57): the same sources built with -DNPP_WIDTH=512
+    (libnpp_hip_w512.so), 8 waves per workgroup."""
     H = 256
-    net, P, angles, periods = _net(dev, K)
+    net, P, angles, periods = _net(dev, K, width=width)
     c = _coords(n, H, H, seed=11 + K)
     pred = net.render(torch.from_numpy(c).to(dev)).cpu().numpy()
     emb = oracle.embed(c, angles, periods, oracle.SEED0_FREQS, (H, H))
@@ -177,12 +179,12 @@ def test_fused_forward_matches_oracle(dev, K, n):
     assert rel_l2(pred, oracle.sigmoid(raw_f)) < 5e-3
 
 
-@pytest.mark.parametrize("K", [3, 1, 5])
-def test_fused_training_step_gradients(dev, K):
+@pytest.mark.parametrize("K,width", [(3, 256), (1, 256), (5, 256), (3, 512), (1, 512)])
+def test_fused_training_step_gradients(dev, K, width):
     """forward(stash) -> pixel loss -> backward chain -> grouped wgrad, against the oracle's
     hand-derived backward (itself pinned to the reference's autograd in test_oracle_golden)."""
     H, n = 256, 640 + 37       # ragged: 677 real rows padded to 704
-    net, P, angles, periods = _net(dev, K, ksplit=3)
+    net, P, angles, periods = _net(dev, K, ksplit=3, width=width)
     c = _coords(n, H, H, seed=5)
     Bp = (n + 63) // 64 * 64
     cp = np.zeros((Bp, 2), np.int32)
@@ -618,8 +620,15 @@ def test_error_reporting_on_bad_arguments(dev):
     with pytest.raises(npp_amd.NppError, match="multiple of 64"):
         ops.mlp_fwd(c, cfg, torch.empty(16, device=dev), torch.empty(16, device=dev))
     c64 = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+    with pytest.raises(npp_amd.NppError, match="width"):                     # no fused library for this width (dense.py serves it)
+        ops.mlp_fwd(c64, cfg, torch.empty(16, device=dev), torch.empty(16, device=dev), width=384)
+    from npp_amd._lib import check as _check
+    with pytest.raises(npp_amd.NppError, match="width"):                     # each library rejects the other's width on the host
+        _check(npp_amd.lib(512).npp_mlp_fwd(c64.data_ptr(), 64, C.byref(cfg), 256, c64.data_ptr(), c64.data_ptr(), c64.data_ptr(), None,
+                                            None), "npp_mlp_fwd", 512)
     with pytest.raises(npp_amd.NppError, match="width"):
-        ops.mlp_fwd(c64, cfg, torch.empty(16, device=dev), torch.empty(16, device=dev), width=512)
+        _check(L.npp_mlp_fwd(c64.data_ptr(), 64, C.byref(cfg), 512, c64.data_ptr(), c64.data_ptr(), c64.data_ptr(), None, None),
+               "npp_mlp_fwd")
     with pytest.raises(npp_amd.NppError, match="null"):
         L.npp_mlp_fwd.restype = C.c_int
         from npp_amd._lib import check

@@ -37,12 +37,19 @@ def test_bench_touches_oracle_only_in_cpu_baseline():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import importlib
     import npp_amd._lib as L
-    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
-    monkeypatch.setattr(L, "_LIB", None)
+    monkeypatch.setattr(L, "LIB_PATHS", {256: str(tmp_path / "nope.so"), 512: str(tmp_path / "nope_w512.so")})
+    monkeypatch.setattr(L, "_LIBS", {})
     try:
-        L.lib()
-        raise AssertionError("lib() must raise when libnpp_hip.so is missing")
-    except L.NppError as e:
-        assert "no CPU fallback" in str(e)
+        for w in (256, 512):
+            try:
+                L.lib(w)
+                raise AssertionError("lib() must raise when the library is missing")
+            except L.NppError as e:
+                assert "no CPU fallback" in str(e)
+        try:
+            L.lib(384)
+            raise AssertionError("lib() must raise for a width without a fused build")
+        except L.NppError as e:
+            assert "width 384" in str(e)
     finally:
         importlib.reload(L)
