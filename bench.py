@@ -436,6 +436,33 @@ def main():
         c4 = out
         del grid, ref32, d32
 
+    # ---- the reference's DEFAULT width (options/arg_config.py:57 --netwidth 512): the same fused chain, second build ----
+    w512 = None
+    if rank == 0 and not args.no_extras:
+        from npp_amd.model import NPPNet
+        W5 = 512
+        net5 = NPPNet(angles, periods, syn.SEED0_FREQS, (H, H), params=syn.init_params(K, seed=0, width=W5), device=dev, width=W5)
+        f5, t5 = syn.mlp_macs_per_pixel(K, W5)
+        yy5, xx5 = np.meshgrid(np.arange(H, dtype=np.int32), np.arange(H, dtype=np.int32), indexing="ij")
+        g5 = torch.from_numpy(np.stack([yy5, xx5], -1).reshape(-1, 2)).to(dev)
+        c5 = g5[torch.randint(0, H * H, (n_rows,), device=dev)].contiguous()
+        gt5 = torch.rand(n_rows, 3, device=dev)
+        net5.workspace(n_rows)["dpred"].zero_()
+
+        def step5():
+            net5.zero_grad()
+            net5.forward_train(c5)
+            net5.pixel_loss(n_rows, n_rows, gt5)
+            net5.backward(n_rows)
+            net5.optimizer_step(n_rows)
+        t_r5 = timed(lambda: net5.render(g5), reps=10)
+        t_s5 = timed(step5, reps=30)
+        w512 = {"workload": f"{H}x{H} K={K} netwidth 512 (libnpp_hip_w512.so), MLP half only", "ksplit": net5.ksplit,
+                "render_ms": t_r5 * 1e3, "render_pixels_per_s": H * H / t_r5, "render_mfma_frac": 2 * f5 * H * H / t_r5 / 1e12 / PEAK_BF16_TFLOPS,
+                "mlp_only_step_ms": t_s5 * 1e3, "mlp_only_rows_per_s": n_rows / t_s5,
+                "mlp_mfma_frac": 2 * t5 * n_rows / t_s5 / 1e12 / PEAK_BF16_TFLOPS}
+        del net5, g5, c5
+
     # ---- per patch-source cost of the complete iteration (device + host enqueue, same pool) ----
     per_source = None
     if rank == 0 and not args.no_extras:
@@ -565,6 +592,7 @@ def main():
                                                      "ranks": dist.get_world_size()},
             "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
+            "netwidth_512_fused": w512,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
