@@ -1,0 +1,151 @@
+"""`python -m npp_amd.search --datadir data/completion/input/<name> --outdir data/completion/detected`: the periodicity
+proposal stage, NPP_proposal/search.py:28-280 + loaders/loaders.py:9-66 for one image directory (masked_img.png, gt_img.png,
+unknown_mask.png, valid_mask.png):
+
+  feature map (proposal.im2act: gray image, or AlexNet conv1 + gray with --alexnet) -> Canny edge masking (cvlite) ->
+  brute-force displacement search per repeat-range group (npp_shift_search) -> pseudo mask around the points furthest from
+  the unknown region (utils/miscs.py:53-96) -> one 300-iteration NPP_Net_light fit per candidate, scored by
+  30 * LPIPS + 1 * CX on the pseudo-mask region (light.ProposalRanker) -> config.odgt with the top-k candidates.
+
+Flags keep the reference's names (options/arg_config.py:105-145).  Two of them are `store_false` switches there, so the
+reference's DEFAULT run is gray_only = True, edge_searching = True -- no AlexNet involved; passing `--gray_only` turns the
+AlexNet-conv1 features ON (then --alexnet <torchvision alexnet state_dict> is needed, the checkpoint the reference downloads is
+not in its tree).  Under torch.distributed the candidate fits are sharded over the ranks (ProposalRanker.rank)."""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--datadir", required=True)
+    ap.add_argument("--outdir", default="data/completion/detected")
+    ap.add_argument("--netdepth", type=int, default=4)
+    ap.add_argument("--netwidth", type=int, default=256)
+    ap.add_argument("--N_rand", type=int, default=32 * 32 * 2)
+    ap.add_argument("--N_iters", type=int, default=300)
+    ap.add_argument("--lrate", type=float, default=5e-4)
+    ap.add_argument("--lrate_decay", type=int, default=500)
+    ap.add_argument("--gray_only", action="store_false", help="(store_false like the reference) pass it to ADD the AlexNet conv1 features")
+    ap.add_argument("--edge_searching", action="store_false", help="(store_false like the reference) pass it to search WITHOUT Canny edge masking")
+    ap.add_argument("--topk_detection", type=int, default=10)
+    ap.add_argument("--search_range", type=int, nargs=3, default=(1, 10, 1))
+    ap.add_argument("--contextual_weight", type=float, default=1.0)
+    ap.add_argument("--perceptual_weight", type=float, default=30.0)
+    ap.add_argument("--alexnet", default=None, help="torchvision alexnet state_dict (.pth): conv1 of the feature extractor")
+    ap.add_argument("--vgg19", default=None, help="torchvision vgg19 state_dict (.pth): contextual-loss trunk of the ranking")
+    ap.add_argument("--vgg16", default=None, help="torchvision vgg16 state_dict (.pth): LPIPS trunk of the ranking")
+    ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth")
+    ap.add_argument("--random-trunks", action="store_true", help="fixed-seed random VGG / AlexNet weights (synthetic runs only)")
+    ap.add_argument("--rng_mode", default="reference", choices=["reference", "fast"])
+    ap.add_argument("--device", default="cuda:0")
+    return ap.parse_args(argv)
+
+
+def find_mask_centroid(mask, topk=3, threshold_ratio=0.3):
+    """utils/miscs.py:53-96: the top-k pixels furthest (Euclidean distance transform) from the unknown region and the image
+    border... of the mask, at least threshold_ratio * min(H, W) apart.  -> ([[h, w]], [distance])."""
+    import scipy.ndimage as ndimage
+    m = np.asarray(mask)
+    dis = ndimage.distance_transform_edt(m).reshape(-1)
+    order = np.argsort(-dis)
+    W = m.shape[1]
+    thr = min(m.shape[0], m.shape[1]) * threshold_ratio
+    cents, sel = [], []
+    for idx in order:
+        h, w = int(idx // W), int(idx % W)
+        if all(np.sqrt((c[0] - h) ** 2 + (c[1] - w) ** 2) >= thr for c in cents):
+            cents.append([h, w])
+            sel.append(float(dis[idx]))
+        if len(cents) == topk:
+            break
+    return cents, sel
+
+
+def pseudo_mask_split(mask, valid_mask):
+    """loaders/loaders.py:34-54: square holes of half-width dist / sqrt(2) / 1.2 around the centroids; the known pixels inside
+    them are the evaluation ('val') region of the candidate fits, the rest of the known pixels train them."""
+    m = np.asarray(mask, np.float64).reshape(mask.shape[0], mask.shape[1], 1)
+    v = np.asarray(valid_mask, np.float64).reshape(m.shape)
+    cents, dist = find_mask_centroid((m * v)[..., 0])
+    pseudo = np.ones_like(m)
+    for (h, w), d in zip(cents, dist):
+        hw = int(d / np.sqrt(2) / 1.2)
+        pseudo[max(h - hw, 0):h + hw, max(w - hw, 0):w + hw, :] = 0          # (negative starts would wrap in the reference's slice)
+    i_train = np.stack(np.nonzero(pseudo * m * v)[:2], 1)
+    i_val = np.stack(np.nonzero((1 - pseudo) * m * v)[:2], 1)
+    return pseudo, i_train, i_val
+
+
+def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
+    """masked_img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) 1 = known / valid.  -> dict with the ranked candidates."""
+    from . import proposal
+    from .light import ProposalRanker
+    m2 = np.asarray(mask, np.float64).reshape(masked_img.shape[:2])
+    v2 = np.asarray(valid_mask, np.float64).reshape(masked_img.shape[:2])
+    angles, periods, shifts = proposal.search_periodicity_by_feat(
+        np.uint8(np.asarray(masked_img) * 255), np.uint8(v2 * m2), repeat_range=tuple(args.search_range),
+        edge_searching=args.edge_searching, gray_only=args.gray_only, conv1=conv1, device=args.device)
+    if not angles:
+        raise RuntimeError("periodicity search: no displacement pair passed the angle test in any repeat-range group")
+    _, i_train, i_val = pseudo_mask_split(m2, v2)
+    t = trunks or {}
+    ranker = ProposalRanker(masked_img, i_train, i_val, device=args.device, N_iters=args.N_iters, N_rand=args.N_rand, W=args.netwidth,
+                            D=args.netdepth, lrate=args.lrate, lrate_decay=args.lrate_decay, perceptual_weight=args.perceptual_weight,
+                            contextual_weight=args.contextual_weight, vgg19_state_dict=t.get("vgg19"), vgg16_state_dict=t.get("vgg16"),
+                            lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode)
+    cands = list(zip(angles, periods, shifts))
+    dist, order, details = ranker.rank(cands, topk=args.topk_detection)
+    return {"angles": [np.asarray(angles[i], np.float64).tolist() for i in order],
+            "periods": [np.asarray(periods[i], np.float64).tolist() for i in order],
+            "shifts": [[list(map(float, s)) for s in shifts[i]] for i in order],
+            "distances": [float(d) for d in dist], "n_candidates": len(cands), "details": details}
+
+
+def main(argv=None):
+    args = parse(argv)
+    from . import io as nio
+    need = {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
+    if not args.gray_only:
+        need["--alexnet"] = args.alexnet
+    lacking = [k for k, v in need.items() if v is None]
+    if lacking and not args.random_trunks:
+        raise SystemExit(f"missing pretrained weights {lacking} (ranking: torchvision VGG19 / VGG16 + lpips v0.1 lin layers; features: "
+                         f"torchvision AlexNet); supply them or pass --random-trunks for a synthetic run")
+    torch.cuda.set_device(torch.device(args.device))
+    name = os.path.basename(os.path.normpath(args.datadir))
+    out = os.path.join(args.outdir, name)
+    if os.path.exists(out):
+        raise SystemExit("Searching: file exists, exit!!")                           # search.py:42-44
+    rd = lambda f: nio._imread_rgb(os.path.join(args.datadir, f)).astype(np.float64) / 255.0      # noqa: E731
+    rg = lambda f: nio._imread_gray(os.path.join(args.datadir, f)).astype(np.float64) / 255.0     # noqa: E731
+    masked_img, img, mask, valid = rd("masked_img.png"), rd("gt_img.png"), rg("unknown_mask.png"), rg("valid_mask.png")
+
+    def load(path):
+        return None if path is None else torch.load(path, map_location="cpu")
+    lin = load(args.lpips_lin)
+    if lin is not None:
+        lin = [lin[f"lin{i}.model.1.weight"].reshape(-1).numpy() for i in range(5)]
+    conv1 = None
+    if not args.gray_only:
+        from .proposal import AlexConv1
+        conv1 = AlexConv1(load(args.alexnet), device=args.device, allow_random=args.random_trunks)
+    res = search_image(masked_img.astype(np.float32), mask, valid, args, conv1,
+                       {"vgg19": load(args.vgg19), "vgg16": load(args.vgg16), "lin": lin})
+    nio.write_detected_dir(out, img, mask, valid, res["angles"], res["periods"], res["shifts"], res["distances"])
+    with open(os.path.join(out, "config.odgt")) as f:
+        odgt = json.loads(f.readline())
+    odgt.update(search_range=list(args.search_range), epoch=args.N_iters)           # search.py:236-237
+    with open(os.path.join(out, "config.odgt"), "w") as f:
+        json.dump(odgt, f)
+        f.write("\n")
+    print(f"[search] {res['n_candidates']} candidates ranked; best periods {res['periods'][0]} angles {res['angles'][0]} "
+          f"distance {res['distances'][0]:.4f} -> {out}/config.odgt")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
