@@ -378,6 +378,32 @@ def test_full_loop_with_patch_losses(dev):
 
 
 
+def test_complete_loop_at_the_reference_default_width_512(dev):
+    """--netwidth 512 (options/arg_config.py:57) through the complete loop (sampler, fused chain of libnpp_hip_w512.so, pixel +
+    contextual + LPIPS losses, Adam): converges like the W = 256 fit, and the explicit loop equals its autograd comparator."""
+    from npp_amd.fit import CompletionFit
+    H, K, Wn = 256, 3, 512
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make():
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, W=Wn, seed=0), device=dev,
+                             N_rand=4096, shifts=shifts, seed=1, width=Wn)
+    a, b = make(), make()
+    batch = a.materialise_batch(a.draw_batch())
+    a.step_from(batch)
+    b.step_from_autograd(batch)
+    ga, gb = a.net.grads(), b.net.grads()
+    for name in ga:
+        assert rel_l2(ga[name], gb[name]) < 2e-3, name
+    fit = make()
+    assert fit.net.width == Wn and fit.net.n_params == 3836932 - 513
+    p0 = fit.psnr()
+    for it in range(60):
+        fit.step_full()
+    assert bool(torch.isfinite(fit.net.params).all()) and fit.psnr() > max(p0 + 8.0, 26.0)
+
+
 def test_config_c5_shape_k5_with_patch_losses(dev):
     """BASELINE.json configs[4] shape at reduced image size: top-5 proposals (NPP_Net with a 4-proposal scale layer,
     in 2310) with the contextual loss every iteration and LPIPS on 'same' iterations, through the explicit loop."""
