@@ -248,13 +248,19 @@ __device__ __forceinline__ void wring_fill(WRing<NTW>& r, wptr_t wp, int nt0, in
 // to KSTOT (a multiple of 4) schedule positions, so that every part starts at ring slot 0:
 // positions >= KSREAL issue no MFMA and load nothing, they only keep the refill cadence.
 // Activation fragments of k-step ks sit at LDS k-step (ks - KS0 + ks_lds0) of `region`.
+#ifndef NPP_SLICE_VALU_PER_GAP
+#define NPP_SLICE_VALU_PER_GAP 4
+#endif
 struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
 // `hook(ks - KS0)` is called once per schedule position, between the activation-fragment reads
 // and the MFMAs: independent VALU / LDS work placed there (the embedding generator) issues in
 // the shadow of the MFMAs of the same wave.
-template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT, typename Hook = NoHook>
+// SLICED: the hook emits a small, branch-free slice per position (a handful of VALU / LDS instructions); the scheduler is
+// then told to place it INSIDE the position's MFMA run -- one MFMA, a share of the slice, one MFMA, ... -- instead of the
+// blob-after-four-MFMAs it produces by itself (MI355X_MICROARCH.md: <= 5 single-issue instructions hide per MFMA gap).
+template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT, typename Hook = NoHook, bool SLICED = false>
 __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
                                          wptr_t wp, wptr_t next_wp, int nt0,
                                          const Lane& L, WRing<NTW>& ring, const Hook& hook = Hook()) {
@@ -286,6 +292,14 @@ __device__ __forceinline__ void mma_ring(f32x16 (&acc)[NTW][kNB], const char* re
     hook(ks - KS0);
     if (ks + kRD < KSREAL) wslot_load<NTW, NT>(ring, slot, wp, ks + kRD, nt0, L.lane);
     else if (ks + kRD >= KSTOT && next_wp != kNoW) wslot_load<NTW, NT>(ring, slot, next_wp, ks + kRD - KSTOT, nt0, L.lane);
+    if (SLICED && ks < KSREAL) {
+#pragma unroll
+      for (int g = 0; g < NTW * kNB; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NPP_SLICE_VALU_PER_GAP, 0);   // its share of the slice's VALU work
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        // and of the LDS reads (slice + next fragments)
+      }
+    }
     asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads
   }
 }

@@ -38,6 +38,22 @@ int check_embed_cfg(const npp_embed_cfg* c, const char* who);
 #ifndef NPP_FWD_WAVES
 #define NPP_FWD_WAVES (NPP_WIDTH / 64)       // two neuron tiles per wave: 4 waves at W = 256, 8 at W = 512
 #endif
+#ifndef NPP_FWD_SLICED
+#define NPP_FWD_SLICED 1
+#endif
+#ifndef NPP_FWD_SLICED_PLAIN        // scheduling groups also in the plain parts that carry a chunk-0 generation
+#define NPP_FWD_SLICED_PLAIN 1
+#endif
+// Experiment kept buildable (-DNPP_FWD_OVERLAP_PROLOGUE=1; parity tests green with it): the exposed prologue of an embedding
+// pass (warped coordinates + barrier + chunk 0 + barrier = 25 % of a pass by the in-kernel stamps) moved into the MFMA gaps of
+// a preceding plain part (L5: h part first, sV reused from L0; S: f1 part split around a barrier; proposal p + 1's coordinates
+// under the last chunk of proposal p).  Measured (same-box A/B, 1024^2 K = 3 render): 2.550 -> 2.532 ms at W = 256 -- the
+// stamps of ONE workgroup shrink, the CU's throughput does not, because the co-resident workgroup was already using the SIMDs
+// during those prologues -- and 1.97 -> 2.31 ms at W = 512 (register spills).  Default off.  DESIGN.md section 4.
+#ifndef NPP_FWD_OVERLAP_PROLOGUE
+#define NPP_FWD_OVERLAP_PROLOGUE 0
+#endif
+constexpr bool kOverlapPro = NPP_FWD_OVERLAP_PROLOGUE != 0;
 constexpr int kWavesF = NPP_FWD_WAVES;
 constexpr int kNTW = kNT / kWavesF;                             // neuron tiles per wave in 256-wide layers
 constexpr int kThreads = 64 * kWavesF;
@@ -133,13 +149,14 @@ __device__ __forceinline__ void bias_apply(f32x16 (&acc)[NTW][kNB], const BiasPr
 
 // The 22 warped coordinates (a1, models/embedder.py:110-133) of proposal p for the 64 rows ->
 // sV[i][row] (fp32).  Table-driven: wave w takes i = w, w+4, ...; the entry is wave-uniform.
+constexpr int kWarpPer = (22 + kWavesF - 1) / kWavesF;        // warped coordinates computed by one wave (6 or 3)
 __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, const float* sY, const float* sX,
-                                         const Lane& L) {
+                                         const Lane& L, int q_only = -1) {
   const float y = sY[L.lane], x = sX[L.lane];
 #pragma unroll
-  for (int q = 0; q < (22 + kWavesF - 1) / kWavesF; ++q) {
+  for (int q = 0; q < kWarpPer; ++q) {
     const int i = L.wave + kWavesF * q;
-    if (i < 22) {
+    if (i < 22 && (q_only < 0 || q == q_only)) {
       const WarpEnt w = tw[p * 22 + i];
       // y*cos + x*sin rounded like the reference's two torch ops; the linear entries put the
       // normalised coordinate (x/W - .5)*2 into the same form (cs or sn = 2/res, bias = -1)
@@ -171,8 +188,12 @@ __device__ __forceinline__ void gen_emb_quad(const float* v, int jb, int fr0, in
 #pragma unroll
   for (int bt = 0; bt < kNB; ++bt) {
     f32x2 x;
+#ifdef NPP_DIAG_NOGEN        // timing-only diagnostic (wrong results): no embedding arithmetic, no coordinate reads
+    x[0] = fa; x[1] = fb;
+#else
     x[0] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP) * kRowTile + bt * 32], fa, ph));
     x[1] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP + 1) * kRowTile + bt * 32], fb, ph));
+#endif
     const bf16x2 pk = __builtin_convertvector(x, bf16x2);
     f[bt][2 * JP] = pk[0];
     f[bt][2 * JP + 1] = pk[1];
@@ -231,18 +252,111 @@ __device__ __forceinline__ void load_emb_pair(const float* __restrict__ emb, int
   }
 }
 
+// The generator cut into slices of one QUAD (slots 2 JP, 2 JP + 1 of both batch tiles = 4 values: one ds_read2 per slot,
+// 4 fma, 4 v_sin, 2 packs) so that mma_ring<..., SLICED> can thread it through the MFMAs of one schedule position.  The LDS
+// reads of a quad are issued one position before its arithmetic.  Only for chunks whose k-steps are all regular
+// (k-step < 28, hence < kKSEmb): no branch anywhere, so a position stays one scheduling region.
+template <bool STORE_EMB, int KPER>
+struct SlicedGen {
+  const float* sFr;
+  const float* vlane;      // sV + (lane & 31)
+  char* dst;               // LDS chunk buffer the fragments go to
+  char* emb_base;          // stash (uniform part) or null
+  uint32_t lane_off;
+  int lane, ksl0, ks0;     // this wave's first k-step of the chunk: local index, global index
+  float ph;
+  mutable const float* v;
+  mutable int fr0, fr1, jb;
+  mutable float val[2][kNB];
+  mutable bf16x8 f[kNB];
+
+  __device__ __forceinline__ void setup(int q2) const {
+    const int t0 = 8 * (ks0 + q2);
+    const int fj0 = (t0 * 2979) >> 16;
+    const int i0 = t0 - 22 * fj0;
+    jb = 22 - i0;
+    const int fj1 = fj0 + 1 > NPP_N_FREQ - 1 ? NPP_N_FREQ - 1 : fj0 + 1;
+    fr0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sFr[fj0]));
+    fr1 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sFr[fj1]));
+    v = vlane + i0 * kRowTile;
+  }
+  template <int JP> __device__ __forceinline__ void issue() const {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int bt = 0; bt < kNB; ++bt) val[jj][bt] = v[(2 * JP + jj) * kRowTile + bt * 32];
+  }
+  template <int JP> __device__ __forceinline__ void compute() const {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const float fa = scalar_pick<2 * JP>(jb, fr0, fr1), fb = scalar_pick<2 * JP + 1>(jb, fr0, fr1);
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      f32x2 x;
+#ifdef NPP_DIAG_NOGEN
+      x[0] = fa; x[1] = fb;
+#else
+      x[0] = __builtin_amdgcn_sinf(fmaf(val[0][bt], fa, ph));
+      x[1] = __builtin_amdgcn_sinf(fmaf(val[1][bt], fb, ph));
+#endif
+      const bf16x2 pk = __builtin_convertvector(x, bf16x2);
+      f[bt][2 * JP] = pk[0];
+      f[bt][2 * JP + 1] = pk[1];
+    }
+  }
+  __device__ __forceinline__ void finish(int q2) const {
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      lds_store_frag(dst, ksl0 + q2, bt, lane, f[bt]);
+      if (STORE_EMB) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks0 + q2, bt, 0, 0) + lane_off, f[bt]);
+    }
+  }
+  template <int JP> __device__ __forceinline__ void quad(int q2) const {
+    compute<JP>();
+    if (JP == 3) {
+      finish(q2);
+      if (q2 + 1 < KPER) { setup(q2 + 1); issue<0>(); }
+    } else {
+      issue<(JP + 1) & 3>();
+    }
+  }
+  __device__ __forceinline__ void prologue() const { setup(0); issue<0>(); }
+  // schedule position pos (0..7) of the chunk being multiplied: KPER = 2 -> quad pos & 3 of k-step pos >> 2;
+  // KPER = 1 -> quad pos >> 1 at the even positions
+  __device__ __forceinline__ void operator()(int pos) const {
+    const int qi = KPER == 2 ? pos : (pos >> 1);
+    if ((KPER == 1 && (pos & 1)) || qi >= 4 * KPER) return;
+    const int q2 = qi >> 2;
+    switch (qi & 3) {
+      case 0: quad<0>(q2); break;
+      case 1: quad<1>(q2); break;
+      case 2: quad<2>(q2); break;
+      default: quad<3>(q2); break;
+    }
+  }
+};
+
 // Accumulate one proposal's 30 embedding k-steps.  lds_ring = 32 KiB LDS (two 16 KiB chunk
 // buffers).  Caller guarantees sV is free to overwrite and lds_ring is free; on return every
 // wave has passed a barrier after its last lds_ring / sV read.  The weight ring holds the
 // first 4 k-steps on entry and the first 4 k-steps of next_wp on return.
+//  have_warp: sV already holds proposal p's warped coordinates; have_chunk0: chunk 0 of the LDS ring was generated by the
+//  caller (sliced_chunk0 below, in the gaps of a preceding plain part) and a barrier has been passed since;
+//  next_warp_p >= 0: the warped coordinates of THAT proposal are computed in the gaps of the last chunk's MFMAs (sV is idle
+//  then), so the next pass starts with have_warp.  All three are workgroup-uniform.
 template <bool STORE_EMB, int NTW, int NT, bool EMB_IN = false>
 __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbTabs& e, int p, char* lds_ring,
                                               float* sV, const float* sY, const float* sX,
                                               wptr_t wp, wptr_t next_wp,
-                                              int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
+                                              int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring,
+                                              bool have_warp = false, bool have_chunk0 = false, int next_warp_p = -1) {
   STAMP(50);
-  if (!EMB_IN) gen_warp(e.warp, p, sV, sY, sX, L);
-  wg_barrier();
+  if (!EMB_IN && !have_warp) {
+    gen_warp(e.warp, p, sV, sY, sX, L);
+    wg_barrier();
+  } else if (EMB_IN) {
+    wg_barrier();
+  }
   STAMP(51);
   // stash address = uniform (array, workgroup, k-step, batch tile) part + this lane's 32-bit offset (npp_layout.h wfmt_unit)
   char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
@@ -262,10 +376,12 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
       }
     }
   };
-  gen_pair(0, 0);
-  if (kPer == 2) gen_pair(0, 1);
-  STAMP(52);
-  wg_barrier();
+  if (!have_chunk0) {
+    gen_pair(0, 0);
+    if (kPer == 2) gen_pair(0, 1);
+    STAMP(52);
+    wg_barrier();
+  }
   STAMP(53);
   // chunk c is multiplied while chunk c+1 is generated: this wave's two k-steps of the next chunk
   // are produced at schedule positions 0 and 4 of the current one, so their LDS reads / v_sin /
@@ -276,16 +392,63 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
       else if (pos == 4 && kPer == 2) gen_pair(c_next, 1);
     };
   };
-  mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
-  STAMP(55);
-  wg_barrier();
-  STAMP(56);
-  mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
-  wg_barrier();
+  // chunks 1 and 2 hold regular k-steps only (8 .. 23 < 28): their generation is sliced into the MFMA gaps
+  auto sliced_for = [&](int c_next) {
+    SlicedGen<STORE_EMB, kPer> g;
+    g.sFr = e.freq_rev; g.vlane = sV + L.b; g.dst = lds_ring + (c_next & 1) * kChunkBytes; g.emb_base = emb_base;
+    g.lane_off = lane_off; g.lane = L.lane; g.ksl0 = kPer * L.wave; g.ks0 = kChunkKS * c_next + kPer * L.wave;
+    g.ph = L.h ? 0.25f : 0.0f;
+    return g;
+  };
+#if NPP_FWD_SLICED
+  if (!EMB_IN) {
+    const auto g1 = sliced_for(1);
+    g1.prologue();
+    mma_ring<0, 8, kKSEmb, 32, NTW, NT, decltype(g1), true>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, g1);
+    STAMP(55);
+    wg_barrier();
+    STAMP(56);
+    const auto g2 = sliced_for(2);
+    g2.prologue();
+    mma_ring<8, 16, kKSEmb, 32, NTW, NT, decltype(g2), true>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, g2);
+    wg_barrier();
+  } else
+#endif
+  {
+    mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
+    STAMP(55);
+    wg_barrier();
+    STAMP(56);
+    mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
+    wg_barrier();
+  }
   mma_ring<16, 24, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(3));
   wg_barrier();
-  mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
+  if (!EMB_IN && next_warp_p >= 0) {
+    auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, next_warp_p, sV, sY, sX, L, pos); };
+    mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, warp_hook);
+  } else {
+    mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
+  }
   wg_barrier();
+}
+
+// Chunk 0 of proposal p's embedding generated in the MFMA gaps of a PLAIN part (KS0..KS1 of the 16 k-steps of `region`) that
+// precedes the embedding part of the same layer: replaces the exposed prologue of mma_embedding.  sV must hold p's warped
+// coordinates.  The caller passes a barrier before the embedding part reads the chunk.
+template <bool STORE_EMB, int KS0, int KS1, int NTW, int NT>
+__device__ __forceinline__ void mma_plain_gen_chunk0(f32x16 (&acc)[NTW][kNB], const char* region, const EmbTabs& e, int p,
+                                                     char* lds_ring, const float* sV, wptr_t wp, wptr_t next_wp, int nt0,
+                                                     char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
+  constexpr int kPer = kChunkKS / kWavesF;
+  SlicedGen<STORE_EMB, kPer> g;
+  g.sFr = e.freq_rev; g.vlane = sV + L.b; g.dst = lds_ring;
+  g.emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  g.lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
+  g.lane = L.lane; g.ksl0 = kPer * L.wave; g.ks0 = kPer * L.wave;
+  g.ph = L.h ? 0.25f : 0.0f;
+  g.prologue();
+  mma_ring<KS0, KS1, kKSAct, kKSAct, NTW, NT, decltype(g), NPP_FWD_SLICED_PLAIN != 0>(acc, region, KS0, wp, next_wp, nt0, L, ring, g);
 }
 
 // Epilogue of a 256-wide (NTW=2 per wave) or 128-wide (NTW=1) layer.
@@ -310,7 +473,11 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 z = {acc[nt][bt][r], acc[nt][bt][r + 1]};
+#ifdef NPP_DIAG_NOSNAKE      // timing-only diagnostic (wrong results): what the chain costs without the activation arithmetic
+        if (false) {
+#else
         if (SNAKE) {
+#endif
           const f32x2 rev = z * kInv2Pi;
           const f32x2 sn = {__builtin_amdgcn_sinf(rev[0]), __builtin_amdgcn_sinf(rev[1])};
           z = __builtin_elementwise_fma(sn, sn, z);
@@ -416,7 +583,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     char* in = (l & 1) ? R0 : R1;
     char* out = (l & 1) ? R1 : R0;
     bias_apply<kNTW>(acc, bn);
-    mma_ring<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), wl(l + 1), nt0, L, ring);
+    mma_ring<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), (l == L4 && !EMB_IN && kOverlapPro) ? wl(L5) + kKSEmb * U : wl(l + 1), nt0, L, ring);
     STAMP(4 * l);
     bias_fetch<kNTW>(bn, P + d.b_off[l + 1], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
@@ -428,9 +595,18 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
   //      again after mma_embedding's final barrier)
   bias_apply<kNTW>(acc, bn);
-  mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
-  STAMP(20);
-  mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
+  if (!EMB_IN && kOverlapPro) {
+    // h part FIRST: sV still holds proposal 0's warped coordinates (written for L0, nothing else touches it), so chunk 0 of
+    // the embedding part is generated in the gaps of these 16 k-steps instead of in an exposed prologue
+    mma_plain_gen_chunk0<false, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, A_.actF, wg, L, ring);
+    STAMP(20);
+    wg_barrier();
+    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, A_.actF, wg, L, ring, true, true);
+  } else {
+    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
+    STAMP(20);
+    mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
+  }
   STAMP(21);
   bias_fetch<kNTW>(bn, P + d.b_off[L6], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L);
@@ -451,25 +627,35 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
   //      registers because P needs f1 again after S and F2 have recycled the regions.
-  bf16x8 f1keep[kNTW][kNB][2];
   bias_apply<kNTW>(acc, bn);
   mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
   const bool p_wave = L.wave < kNT / 2;            // P has 4 neuron tiles: with 8 waves the upper four only keep the barriers
   if (!MULTI && p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
   if (MULTI) bias_fetch<kNTW>(bn, P + d.b_off[LS], nt0, L);
   else if (p_wave) bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
-  epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L, MULTI ? f1keep : nullptr);
+  epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L);
   wg_barrier();
 
   f32x16 accp[1][kNB];
   if (MULTI) {
     // ---- S = scale_linears[0]: [f1 (R0), emb(p1..pK-1) (LDS ring R1)] -> 256, snake, out -> R1
     bias_apply<kNTW>(acc, bn);
-    mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
+    if (!EMB_IN && kOverlapPro) {
+      // f1 part: proposal 1's warped coordinates are computed in the gaps of its first half (sV is idle since L5), a
+      // barrier publishes them, chunk 0 of proposal 1 is generated in the gaps of the second half
+      auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, 1, sV, sY, sX, L, pos); };
+      mma_ring<0, A / 2, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring, warp_hook);
+      wg_barrier();
+      mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, A_.actF, wg, L, ring);
+      wg_barrier();
+    } else {
+      mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
+    }
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
       mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
-                                   A_.actF, wg, L, ring);
+                                   A_.actF, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
+                                   /*next_warp_p=*/(kOverlapPro && p + 1 < d.K) ? p + 1 : -1);
     }
     wring_fill<kNTW, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
     bias_fetch<kNTW>(bn, P + d.b_off[LF2], nt0, L);
@@ -482,6 +668,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
       bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
     }
+    // P needs f1 again, and this epilogue recycles its region: the wave takes ITS f1 fragments (the only ones its own f2 stores
+    // overwrite) out of R0 first and hands them back through R1 after the barrier -- live across one epilogue, not across S and F2
+    bf16x8 f1keep[kNTW][kNB][2];
+#pragma unroll
+    for (int nt = 0; nt < kNTW; ++nt)
+#pragma unroll
+      for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) f1keep[nt][bt][s] = lds_frag(R0, 2 * (nt0 + nt) + s, bt, L.lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads have landed before the stores below are issued
     epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
     wg_barrier();
     // f1 back into LDS (R1 is idle: every wave passed the barrier after reading a_s)
