@@ -130,6 +130,21 @@ int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp, int K, in
                 const void* d_wb, const float* d_params, const void* d_actF,
                 void* d_dzF, void* stream);
 
+/* The same with the patch rows' dL/dpred formed inside the launch from the patch losses' image gradients (the sum
+ * npp_patch_compose_bwd computes: NPP_completion/train.py:200-236 backwards) -- rows [row0, row0 + n_p*P*P) of d_dpred are
+ * WRITTEN (so the buffer ends up as loss.backward() would leave it), all other rows are read as in npp_mlp_bwd. */
+typedef struct {
+  const float* dx_a;      /* (n_p*k, 3, P, P) dL/dx of the contextual branch */
+  const float* dx_b;      /* same shape, second branch (LPIPS / style) or NULL */
+  const float* fmask;     /* (n_p, P, P) */
+  const float* rmask;     /* (n_p*k, P, P) */
+  int64_t row0;           /* first patch row of the batch (= N_rand) */
+  int32_t n_p, k, P, comp;
+} npp_patch_grad;
+int npp_mlp_bwd_patch(float* d_dpred, const float* d_pred, int64_t Bp, int K, int width,
+                      const void* d_wb, const float* d_params, const void* d_actF,
+                      void* d_dzF, const npp_patch_grad* patch, void* stream);
+
 /* Compatibility forms at the reference's module boundary.  NPP_Net(...).forward(None, x_periodic)
  * (models/networks.py:56-95, NPP_Net_top1 :134-173) receives a MATERIALISED embedding:
  * d_emb (Bp, ld >= K*462) fp32 row-major in the reference's column order (any embedder may have
@@ -296,6 +311,18 @@ int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const floa
                        const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
                        const float scale[3], const float shift[3], void* d_x0, float* d_xy,
                        float* d_zero, int n_zero, int which, void* stream);
+/* The same launch also computing npp_pixel_loss (the arguments of that entry point, in a struct): the two consumers of
+ * the forward launch's prediction (train.py:195 and :200-236) are independent, so they share one launch. */
+typedef struct {
+  const float* pred; const float* gt; const float* mask; int64_t N;
+  const float* latents; const float* spline; int32_t n_knots; float x_scale, weight;
+  float* loss; float* dpred; float* dlatent;
+} npp_pixel_loss_args;
+int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
+                            const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
+                            const float scale[3], const float shift[3], void* d_x0, float* d_xy,
+                            float* d_zero, int n_zero, int which, const npp_pixel_loss_args* loss,
+                            void* stream);
 
 /* One 3x3 / pad 1 convolution launch on flat tensors (Cin, Cout multiples of 16, <= 512):
  *  mode 0  y = relu(conv(x, w) + bias)                    nn.Conv2d + nn.ReLU

@@ -16,6 +16,19 @@ class NppError(RuntimeError):
     pass
 
 
+class PixelLossArgs(C.Structure):
+    """npp_pixel_loss_args (include/npp_hip.h)."""
+    _fields_ = [("pred", C.c_void_p), ("gt", C.c_void_p), ("mask", C.c_void_p), ("N", C.c_int64), ("latents", C.c_void_p),
+                ("spline", C.c_void_p), ("n_knots", C.c_int32), ("x_scale", C.c_float), ("weight", C.c_float), ("loss", C.c_void_p),
+                ("dpred", C.c_void_p), ("dlatent", C.c_void_p)]
+
+
+class PatchGrad(C.Structure):
+    """npp_patch_grad (include/npp_hip.h)."""
+    _fields_ = [("dx_a", C.c_void_p), ("dx_b", C.c_void_p), ("fmask", C.c_void_p), ("rmask", C.c_void_p),
+                ("row0", C.c_int64), ("n_p", C.c_int32), ("k", C.c_int32), ("P", C.c_int32), ("comp", C.c_int32)]
+
+
 class EmbedCfg(C.Structure):
     """npp_embed_cfg (include/npp_hip.h) == get_embedder(...) arguments, models/embedder.py:60-90."""
     _fields_ = [("K", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
@@ -74,6 +87,7 @@ SYMBOLS = {
     "npp_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_mlp_fwd_emb": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "npp_mlp_bwd_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "npp_mlp_bwd_patch": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "npp_grad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp]),
     "npp_fourier_fwd": (_i32, [_vp, _i64, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
@@ -113,6 +127,8 @@ SYMBOLS = {
     "npp_trunk_image_in": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
     "npp_trunk_patch_in": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                            _vp, _vp, _vp, _i32, _i32, _vp]),
+    "npp_trunk_patch_in_loss": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                           _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "npp_conv3x3": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                            C.POINTER(C.c_float), _vp]),
     "npp_maxpool2_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -345,4 +345,66 @@ __device__ inline ChanParams chan_params(float latent_alpha, float latent_scale,
   return p;
 }
 
+// ---- a8: adaptive robust pixel loss, forward + gradients (mse_calculator.py:13-27, robust_loss_pytorch) -----------------
+// One thread per row (3 channels), block-stride over `nb` blocks of 256 threads; block reduction via wave shuffles, then
+// one atomicAdd per block per output (7 floats).  Shared by npp_pixel_loss and the fused patch-in launch.
+struct PixelLossArgs {
+  const float* pred; const float* gt; const float* mask; int64_t N;
+  const float* latents; const float* spline; int n_knots; float x_scale, weight;
+  float* loss_out; float* dpred; float* dlatent;
+};
+inline int pixel_loss_blocks(int64_t N) { const int64_t b = (N + 255) / 256; return (int)(b > 1024 ? 1024 : b); }
+__device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid, int nb) {
+  const float* __restrict__ pred = a.pred;
+  const float* __restrict__ gt = a.gt;
+  const float* __restrict__ mask = a.mask;
+  float* __restrict__ dpred = a.dpred;
+  const int64_t N = a.N;
+  const float weight = a.weight;
+  __shared__ ChanParams cp[3];
+  __shared__ float red[4][7];
+  if (threadIdx.x < 3) cp[threadIdx.x] = chan_params(a.latents[threadIdx.x], a.latents[3 + threadIdx.x], a.spline, a.n_knots, a.x_scale);
+  __syncthreads();
+  const float inv = 1.0f / (3.0f * (float)N);
+  float acc[7] = {0, 0, 0, 0, 0, 0, 0};   // loss, dalpha[3], dc[3]
+  for (int64_t r = (int64_t)bid * blockDim.x + threadIdx.x; r < N; r += (int64_t)nb * blockDim.x) {
+    const float m = mask ? mask[r] : 1.0f;
+    const float w = m + (1.0f - m) * 0.3f;          // mse_calculator.py:17
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const ChanParams p = cp[ch];
+      const float d0 = pred[r * 3 + ch] - gt[r * 3 + ch];
+      const float x = mask ? d0 * m + (1.0f - m) * d0 * 0.3f : d0;
+      const float xs = x / p.c, ssx = xs * xs;
+      const float u = ssx / p.beta + 1.0f;
+      const float e = 0.5f * p.alpha;
+      const float lnu = logf(u);
+      const float ue = expf(e * lnu);               // pow(u, e), u >= 1
+      const float ue1 = ue / u;
+      const float rho = (p.beta / p.alpha) * (ue - 1.0f);
+      acc[0] += rho + p.logc_plus_logz;
+      dpred[r * 3 + ch] = weight * inv * w * (x / (p.c * p.c)) * ue1;
+      acc[1 + ch] += -(2.0f / (p.alpha * p.alpha)) * (ue - 1.0f) +
+                     (p.beta / p.alpha) * ue * (0.5f * lnu + e * ssx / (p.beta * p.beta * u)) + p.dlogz;
+      acc[4 + ch] += -(x * x) / (p.c * p.c * p.c) * ue1 + 1.0f / p.c;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    if (k == 0) atomicAdd(a.loss_out, v * inv);
+    else if (k < 4) atomicAdd(a.dlatent + (k - 1), weight * inv * v * cp[k - 1].dalpha_dl);
+    else atomicAdd(a.dlatent + 3 + (k - 4), weight * inv * v * cp[k - 4].dc_dl);
+  }
+}
+
+
 }  // namespace npp

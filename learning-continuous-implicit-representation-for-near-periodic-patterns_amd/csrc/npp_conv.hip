@@ -312,8 +312,14 @@ __global__ void trunk_patch_in_kernel(const float* __restrict__ pred, const floa
                                       const float* __restrict__ rmask, int n_p, int k, int P, int comp, float s0, float s1,
                                       float s2, float b0, float b1, float b2, f16x8* __restrict__ out, int64_t nposp,
                                       int64_t npos_round, float* __restrict__ xy, float* __restrict__ zero, int n_zero,
-                                      int which) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                      int which, PixelLossArgs pl, int nb_loss) {
+  // npp_trunk_patch_in_loss: the first nb_loss blocks are the adaptive pixel loss of the iteration (the other consumer of the
+  // prediction; independent of the patch rows) -- one launch instead of two dependent ones
+  if ((int)blockIdx.x < nb_loss) {
+    pixel_loss_body(pl, (int)blockIdx.x, nb_loss);
+    return;
+  }
+  const int64_t p = (int64_t)((int)blockIdx.x - nb_loss) * blockDim.x + threadIdx.x;
   if (p < n_zero) zero[p] = 0.0f;
   if (p >= npos_round) return;
   const int Wp = P + 2, S = (P + 2) * Wp, nk = n_p * k;
@@ -553,28 +559,54 @@ extern "C" int npp_trunk_image_in(const float* d_img_nchw, int N, int H, int W, 
   return check_launch("npp_trunk_image_in");
 }
 
-extern "C" int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
-                                  const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3],
-                                  const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, int which,
-                                  void* stream) {
+static int patch_in_launch(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                           const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3], const float shift[3],
+                           void* d_x0, float* d_xy, float* d_zero, int n_zero, int which, const PixelLossArgs* pl, void* stream,
+                           const char* who) {
   if (n_p < 1 || k < 1 || n_zero < 0 || n_zero > 256 || which < 0 || which > 2) {
-    set_error("npp_trunk_patch_in: bad n_p=%d k=%d n_zero=%d which=%d", n_p, k, n_zero, which);
+    set_error("%s: bad n_p=%d k=%d n_zero=%d which=%d", who, n_p, k, n_zero, which);
     return NPP_ERR_ARG;
   }
   const int N = (which ? 1 : 2) * n_p * k;
-  int rc = conv_geom_check(N, P, P, "npp_trunk_patch_in");
+  int rc = conv_geom_check(N, P, P, who);
   if (rc) return rc;
   const bool need_x = which != 2, need_y = which != 1;
   if ((need_x && !d_pred_rows) || (need_y && !d_real) || !d_rmask || !d_x0 || !scale || !shift ||
       (need_x && comp && (!d_fake || !d_fmask)) || (n_zero && !d_zero)) {
-    set_error("npp_trunk_patch_in: null pointer");
+    set_error("%s: null pointer", who);
+    return NPP_ERR_ARG;
+  }
+  if (pl && (pl->N <= 0 || !pl->pred || !pl->gt || !pl->latents || !pl->spline || !pl->loss_out || !pl->dpred || !pl->dlatent ||
+             pl->n_knots < 2)) {
+    set_error("%s: bad pixel-loss arguments (N=%lld)", who, (long long)(pl ? pl->N : 0));
     return NPP_ERR_ARG;
   }
   const int64_t nr = conv_npos_round(N, P, P);
-  hipLaunchKernelGGL(trunk_patch_in_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_pred_rows,
-                     d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale[0], scale[1], scale[2], shift[0], shift[1],
-                     shift[2], (f16x8*)d_x0, conv_nposp(N, P, P), nr, d_xy, d_zero, n_zero, which);
-  return check_launch("npp_trunk_patch_in");
+  const int nb_loss = pl ? pixel_loss_blocks(pl->N) : 0;
+  hipLaunchKernelGGL(trunk_patch_in_kernel, dim3((unsigned)((nr + 255) / 256 + nb_loss)), dim3(256), 0, (hipStream_t)stream,
+                     d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale[0], scale[1], scale[2], shift[0], shift[1],
+                     shift[2], (f16x8*)d_x0, conv_nposp(N, P, P), nr, d_xy, d_zero, n_zero, which, pl ? *pl : PixelLossArgs{}, nb_loss);
+  return check_launch(who);
+}
+
+extern "C" int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                                  const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3],
+                                  const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, int which,
+                                  void* stream) {
+  return patch_in_launch(d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale, shift, d_x0, d_xy, d_zero, n_zero,
+                         which, nullptr, stream, "npp_trunk_patch_in");
+}
+
+// npp_trunk_patch_in + npp_pixel_loss in ONE launch (both read the prediction of the forward launch before them).
+extern "C" int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                                       const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3],
+                                       const float shift[3], void* d_x0, float* d_xy, float* d_zero, int n_zero, int which,
+                                       const npp_pixel_loss_args* loss, void* stream) {
+  if (!loss) { set_error("npp_trunk_patch_in_loss: null pixel-loss arguments"); return NPP_ERR_ARG; }
+  const PixelLossArgs pl{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
+                         loss->weight, loss->loss, loss->dpred, loss->dlatent};
+  return patch_in_launch(d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale, shift, d_x0, d_xy, d_zero, n_zero,
+                         which, &pl, stream, "npp_trunk_patch_in_loss");
 }
 
 template <int CT, int PT, int S>

@@ -13,61 +13,8 @@
 
 namespace npp {
 
-// One thread per row (3 channels), grid-stride; block reduction via wave shuffles, then
-// one atomicAdd per block per output (7 floats).
-__global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ pred,
-                                                         const float* __restrict__ gt,
-                                                         const float* __restrict__ mask, int64_t N,
-                                                         const float* __restrict__ latents,
-                                                         const float* __restrict__ spline, int n_knots,
-                                                         float x_scale, float weight,
-                                                         float* __restrict__ loss_out,
-                                                         float* __restrict__ dpred,
-                                                         float* __restrict__ dlatent) {
-  __shared__ ChanParams cp[3];
-  __shared__ float red[4][7];
-  if (threadIdx.x < 3) cp[threadIdx.x] = chan_params(latents[threadIdx.x], latents[3 + threadIdx.x], spline, n_knots, x_scale);
-  __syncthreads();
-  const float inv = 1.0f / (3.0f * (float)N);
-  float acc[7] = {0, 0, 0, 0, 0, 0, 0};   // loss, dalpha[3], dc[3]
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
-    const float m = mask ? mask[r] : 1.0f;
-    const float w = m + (1.0f - m) * 0.3f;          // mse_calculator.py:17
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const ChanParams p = cp[ch];
-      const float d0 = pred[r * 3 + ch] - gt[r * 3 + ch];
-      const float x = mask ? d0 * m + (1.0f - m) * d0 * 0.3f : d0;
-      const float xs = x / p.c, ssx = xs * xs;
-      const float u = ssx / p.beta + 1.0f;
-      const float e = 0.5f * p.alpha;
-      const float lnu = logf(u);
-      const float ue = expf(e * lnu);               // pow(u, e), u >= 1
-      const float ue1 = ue / u;
-      const float rho = (p.beta / p.alpha) * (ue - 1.0f);
-      acc[0] += rho + p.logc_plus_logz;
-      dpred[r * 3 + ch] = weight * inv * w * (x / (p.c * p.c)) * ue1;
-      acc[1 + ch] += -(2.0f / (p.alpha * p.alpha)) * (ue - 1.0f) +
-                     (p.beta / p.alpha) * ue * (0.5f * lnu + e * ssx / (p.beta * p.beta * u)) + p.dlogz;
-      acc[4 + ch] += -(x * x) / (p.c * p.c * p.c) * ue1 + 1.0f / p.c;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    float v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 7) {
-    const int k = threadIdx.x;
-    float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    if (k == 0) atomicAdd(loss_out, v * inv);
-    else if (k < 4) atomicAdd(dlatent + (k - 1), weight * inv * v * cp[k - 1].dalpha_dl);
-    else atomicAdd(dlatent + 3 + (k - 4), weight * inv * v * cp[k - 4].dc_dl);
-  }
-}
+// (body: pixel_loss_body in npp_common.h -- shared with the fused patch-in launch of npp_conv.hip)
+__global__ __launch_bounds__(256) void pixel_loss_kernel(PixelLossArgs a) { pixel_loss_body(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // torch.optim.Adam single-tensor maths (helpers.py:164): the gradient is the sum of the
 // split-K slabs written by npp_mlp_wgrad, so this kernel is also the wgrad reduction.
@@ -197,10 +144,8 @@ extern "C" int npp_pixel_loss(const float* d_pred, const float* d_gt, const floa
     set_error("npp_pixel_loss: bad arguments (N=%lld, n_knots=%d)", (long long)N, n_knots);
     return NPP_ERR_ARG;
   }
-  int64_t blocks = (N + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(pixel_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pred, d_gt,
-                     d_mask, N, d_latents, d_spline, n_knots, x_scale, weight, d_loss, d_dpred, d_dlatent);
+  const PixelLossArgs a{d_pred, d_gt, d_mask, N, d_latents, d_spline, n_knots, x_scale, weight, d_loss, d_dpred, d_dlatent};
+  hipLaunchKernelGGL(pixel_loss_kernel, dim3((unsigned)pixel_loss_blocks(N)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("npp_pixel_loss");
 }
 

@@ -29,6 +29,16 @@ struct BwdArgs {
   const char* actF;        // forward stash: fp16 z fragments of the snake layers (W-format)
   char* dzF;
   int32_t out_act;         // output nonlinearity the forward applied: 0 raw, 1 sigmoid, 2 tanh
+  // npp_mlp_bwd_patch: dL/dpred of the patch rows [pg_row0, pg_row0 + n_p P^2) is FORMED here from the patch losses' image
+  // gradients (what npp_patch_compose_bwd computes, csrc/npp_patch.hip) instead of being read -- one launch less per
+  // iteration; the rows are also written to dpred so the buffer stays what loss.backward() would have left there
+  const float* pg_dxa;     // (n_p k, 3, P, P) or null = plain npp_mlp_bwd
+  const float* pg_dxb;     // nullable second gradient (LPIPS / style branch)
+  const float* pg_fmask;   // (n_p, P, P)
+  const float* pg_rmask;   // (n_p k, P, P)
+  float* dpred_out;
+  int64_t pg_row0;
+  int32_t pg_np, pg_k, pg_P, pg_comp;
 };
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
@@ -131,7 +141,25 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     const float pr = A.pred[(row0 + row) * 3 + c];
     // helpers.py:55-60: sigmoid (1), tanh (2) or the raw network output (0, npp_mlp_bwd_act only)
     const float dact = A.out_act == 1 ? pr * (1.0f - pr) : (A.out_act == 2 ? 1.0f - pr * pr : 1.0f);
-    const float g = A.dpred[(row0 + row) * 3 + c] * dact;
+    float dp;
+    const int64_t prow = row0 + row - A.pg_row0;
+    const int64_t pp = (int64_t)A.pg_P * A.pg_P;
+    if (A.pg_dxa && prow >= 0 && prow < (int64_t)A.pg_np * pp) {       // train.py:200-236 backwards (npp_patch_compose_bwd's sum)
+      const int p = (int)(prow / pp);
+      const int64_t q = prow - (int64_t)p * pp;
+      const float gm = A.pg_comp ? 1.0f - A.pg_fmask[prow] : 1.0f;
+      dp = 0.0f;
+      for (int kk = 0; kk < A.pg_k; ++kk) {
+        const int64_t pk = (int64_t)p * A.pg_k + kk;
+        float dd = A.pg_dxa[(pk * 3 + c) * pp + q];
+        if (A.pg_dxb) dd += A.pg_dxb[(pk * 3 + c) * pp + q];
+        dp = fmaf(dd, A.pg_rmask[pk * pp + q] * gm, dp);
+      }
+      A.dpred_out[(row0 + row) * 3 + c] = dp;
+    } else {
+      dp = A.dpred[(row0 + row) * 3 + c];
+    }
+    const float g = dp * dact;
     sDraw[L.tid] = g;
   }
   wg_barrier();
@@ -220,13 +248,24 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 using namespace npp;
 
 static int bwd_launch(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
-                      const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream) {
+                      const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream,
+                      const npp_patch_grad* pg = nullptr) {
   if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_bwd: K=%d", K); return NPP_ERR_ARG; }
   if (width != NPP_WIDTH) { set_error("npp_mlp_bwd: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile) { set_error("npp_mlp_bwd: Bp=%lld must be a positive multiple of %d", (long long)Bp, kRowTile); return NPP_ERR_ARG; }
   if (!d_dpred || !d_pred || !d_wb || !d_params || !d_actT || !d_dzT) { set_error("npp_mlp_bwd: null pointer"); return NPP_ERR_ARG; }
   if (out_act < 0 || out_act > 2) { set_error("npp_mlp_bwd: out_act=%d", out_act); return NPP_ERR_ARG; }
   BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const char*)d_actT, (char*)d_dzT, out_act};
+  if (pg) {
+    if (!pg->dx_a || !pg->fmask || !pg->rmask || pg->n_p < 1 || pg->k < 1 || pg->P < 1 || pg->row0 < 0 ||
+        pg->row0 + (int64_t)pg->n_p * pg->P * pg->P > Bp) {
+      set_error("npp_mlp_bwd_patch: bad patch-gradient description (n_p=%d k=%d P=%d row0=%lld)", pg->n_p, pg->k, pg->P, (long long)pg->row0);
+      return NPP_ERR_ARG;
+    }
+    A.pg_dxa = pg->dx_a; A.pg_dxb = pg->dx_b; A.pg_fmask = pg->fmask; A.pg_rmask = pg->rmask;
+    A.dpred_out = const_cast<float*>(d_dpred);
+    A.pg_row0 = pg->row0; A.pg_np = pg->n_p; A.pg_k = pg->k; A.pg_P = pg->P; A.pg_comp = pg->comp;
+  }
   const NetDesc d = make_desc(K);
   const BwdDesc bd = make_bwd_desc(K);
   const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);
@@ -252,4 +291,10 @@ extern "C" int npp_mlp_bwd(const float* d_dpred, const float* d_pred, int64_t Bp
 extern "C" int npp_mlp_bwd_act(const float* d_dout, const float* d_out, int64_t Bp, int K, int width, const void* d_wb,
                                const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream) {
   return bwd_launch(d_dout, d_out, Bp, K, width, d_wb, d_params, d_actT, d_dzT, out_act, stream);
+}
+
+extern "C" int npp_mlp_bwd_patch(float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                                 const float* d_params, const void* d_actT, void* d_dzT, const npp_patch_grad* pg, void* stream) {
+  if (!pg) { set_error("npp_mlp_bwd_patch: null patch-gradient description"); return NPP_ERR_ARG; }
+  return bwd_launch(d_dpred, d_pred, Bp, K, width, d_wb, d_params, d_actT, d_dzT, 1, stream, pg);
 }

@@ -8,6 +8,8 @@ ground-truth colours (torch indexing: glue) and sequences the kernels.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -42,6 +44,7 @@ class CompletionFit:
             raise ValueError("rng_mode must be 'reference', 'numpy' or 'fast'")
         if task not in ("completion", "remapping", "segmentation"):
             raise ValueError("task must be 'completion', 'remapping' or 'segmentation'")
+        self.fold_launches = os.environ.get("NPP_FIT_UNFUSED", "0") != "1"     # see step_from
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
@@ -284,10 +287,15 @@ class CompletionFit:
         # joins before npp_patch_compose_bwd (1.30 -> 1.17 ms).  Measured negative (event record / wait costs more than is
         # hidden): the 12 us pixel loss on a side stream (0.742 -> 0.762 ms per 'val' iteration); the real half of the
         # contextual batch through its own trunk instance on a side stream beside the MLP forward (0.767 -> 0.776 ms).
-        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
-        # one launch: patch plumbing -> the contextual trunk's flat fp16 input (normalised) and the patch-loss accumulator cleared
+        # one launch: the adaptive pixel loss of the pixel rows + patch plumbing -> the contextual trunk's flat fp16 input
+        # (normalised), the patch-loss accumulator cleared on the way (fold_launches = False: the separate launches, kept as
+        # the comparator of tests/test_gpu_parity.py and for A/B timing)
+        fold = self.fold_launches
+        if not fold:
+            net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
-                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf)
+                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf,
+                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask")) if fold else None)
         dx_b = None
         if with_lp:                                                                                 # train.py:241-250
             self._s_lp.wait_stream(main)
@@ -300,10 +308,14 @@ class CompletionFit:
             self.style.zero_latent_grads()
             dx_s = self.style.fused(xy, nk, self.style_w, self.patch_loss_buf)
             dx_b = dx_s if dx_b is None else dx_b.add_(dx_s)
-        ops.patch_compose_bwd(dx_a, dx_b, raw["fmask"], raw["rmask"], n_p, k, P, comp, ws["dpred"][n_pix:n])
         self.last_patch_loss = self.patch_loss_buf
         lr_used = net.lr
-        net.backward(bp)
+        # npp_patch_compose_bwd folded into the backward launch: dL/dpred of the patch rows is formed (and written) there
+        if fold:
+            net.backward(bp, patch=(dx_a, dx_b, raw["fmask"], raw["rmask"], n_pix, n_p, k, P, comp))
+        else:
+            ops.patch_compose_bwd(dx_a, dx_b, raw["fmask"], raw["rmask"], n_p, k, P, comp, ws["dpred"][n_pix:n])
+            net.backward(bp)
         net.optimizer_step(bp)
         if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
             self.percepLoss.adam_step(lr_used)

@@ -135,10 +135,14 @@ class NPPNet:
         ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["actT"], self.width)
         return ws["pred"]
 
-    def backward(self, Bp):
-        """loss.backward() through the MLP: consumes ws['dpred'] (rows beyond the batch 0)."""
+    def backward(self, Bp, patch=None):
+        """loss.backward() through the MLP: consumes ws['dpred'] (rows beyond the batch 0).  patch = (dx_a, dx_b, fmask, rmask,
+        row0, n_p, k, P, comp): the patch rows' dL/dpred is formed inside the launch from the patch losses' image gradients."""
         ws = self._ws[Bp]
-        ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], self.width)
+        if patch is not None:
+            ops.mlp_bwd_patch(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], *patch, width=self.width)
+        else:
+            ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], self.width)
         ops.mlp_wgrad(ws["dzT"], ws["actT"], Bp, self.K, self.ksplit, ws["gslabs"], self.width)
 
     def pixel_loss(self, Bp, n_rows, gt, mask=None, weight=1.0):
@@ -147,6 +151,12 @@ class NPPNet:
         ws = self._ws[Bp]
         ops.pixel_loss(ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale,
                        weight, self.loss_buf, ws["dpred"][:n_rows], self.dlatent)
+
+    def pixel_loss_args(self, Bp, n_rows, gt, mask=None, weight=1.0):
+        """The argument tuple of pixel_loss() for a launch that carries the loss along (ops.trunk_patch_in(loss=...))."""
+        ws = self._ws[Bp]
+        return (ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale, weight, self.loss_buf,
+                ws["dpred"][:n_rows], self.dlatent)
 
     def optimizer_step(self, Bp):
         """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""

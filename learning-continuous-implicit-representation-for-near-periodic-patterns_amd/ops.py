@@ -199,6 +199,27 @@ def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
                             _stream()), "npp_mlp_bwd", width)
 
 
+def mlp_bwd_patch(dpred, pred, K, wb, params, actF, dzF, dx_a, dx_b, fmask, rmask, row0, n_p, k, P, comp, width=NPP_WIDTH):
+    """mlp_bwd with the patch rows' dL/dpred formed in the launch (patch_compose_bwd folded in; rows [row0, row0 + n_p P^2) of
+    dpred are written)."""
+    from ._lib import PatchGrad
+    _req(dpred, torch.float32, "dpred")
+    _req(pred, torch.float32, "pred", dpred.shape)
+    for nm, t in (("dx_a", dx_a), ("dx_b", dx_b)):                  # the leading n_p k images are read (a [x | y] batch gradient is fine)
+        if t is not None:
+            _req(t, torch.float32, nm)
+            if t.dim() != 4 or t.shape[0] < n_p * k or tuple(t.shape[1:]) != (3, P, P):
+                raise ValueError(f"{nm}: expected (>= {n_p * k}, 3, {P}, {P}), got {tuple(t.shape)}")
+    _req(fmask, torch.float32, "fmask")
+    _req(rmask, torch.float32, "rmask")
+    if fmask.numel() != n_p * P * P or rmask.numel() != n_p * k * P * P:
+        raise ValueError("fmask / rmask: expected (n_p,1,P,P) / (n_p k,1,P,P)")
+    pg = PatchGrad(dx_a.data_ptr(), dx_b.data_ptr() if dx_b is not None else None, fmask.data_ptr(), rmask.data_ptr(), int(row0),
+                   int(n_p), int(k), int(P), int(bool(comp)))
+    check(lib(width).npp_mlp_bwd_patch(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                                       C.byref(pg), _stream()), "npp_mlp_bwd_patch", width)
+
+
 def auto_ksplit(K, device, width=NPP_WIDTH):
     """Split-K factor that makes the grouped weight-gradient launch (tiles x ksplit workgroups, one per CU) fill the
     chip in exactly one round."""
@@ -379,10 +400,10 @@ def trunk_image_in(img, scale, shift, x0):
     check(lib().npp_trunk_image_in(_p(img), N, H, W, s, b, _p(x0), _stream()), "npp_trunk_image_in")
 
 
-def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, x0, xy=None, zero=None, which=0):
+def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, x0, xy=None, zero=None, which=0, loss=None):
     """npp_patch_compose_fwd + npp_trunk_image_in in one launch: [x | y] -> flat trunk input x0 (and fp32 xy when given);
     zero (small fp32 tensor) is cleared on the way.  which: 0 both halves, 1 prediction half only, 2 real half only
-    (x0 then holds n_p*k images)."""
+    (x0 then holds n_p*k images).  loss = the argument tuple of pixel_loss(): that loss rides in the same launch."""
     if which != 2:
         _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
     if which != 1:
@@ -395,6 +416,18 @@ def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, 
         _req(xy, torch.float32, "xy", (2 * n_p * k, 3, P, P))
     s = (C.c_float * 3)(*[float(v) for v in scale])
     b = (C.c_float * 3)(*[float(v) for v in shift])
+    if loss is not None:
+        from ._lib import PixelLossArgs
+        pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent = loss
+        _req(pred, torch.float32, "pred")
+        _req(gt, torch.float32, "gt", pred.shape)
+        la = PixelLossArgs(pred.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), pred.shape[0], latents.data_ptr(),
+                           spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
+                           dlatent.data_ptr())
+        check(lib().npp_trunk_patch_in_loss(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
+                                            _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), int(which), C.byref(la),
+                                            _stream()), "npp_trunk_patch_in_loss")
+        return
     check(lib().npp_trunk_patch_in(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
                                    _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), int(which), _stream()),
           "npp_trunk_patch_in")
