@@ -53,6 +53,11 @@ def test_bad_arguments_are_reported_not_crashed():
     L5 = npp_amd.lib(512)
     assert L5.npp_pack_bytes(3, 256, 0) < 0 and b"width" in L5.npp_last_error_string()
     assert L5.npp_pack_bytes(3, 512, 0) > 4 * L.npp_pack_bytes(3, 256, 0) // 2
+    # the folded-launch entry points validate on the host before anything is launched
+    assert L.npp_mlp_bwd_patch(None, None, 64, 3, 256, None, None, None, None, None, None) < 0
+    assert b"patch" in L.npp_last_error_string()
+    three = (C.c_float * 3)(1, 1, 1)
+    assert L.npp_trunk_patch_in_loss(None, None, None, None, None, 2, 3, 64, 0, three, three, None, None, None, 0, 0, None, None) < 0
     sizes = (C.c_int64 * 4)()
     assert L.npp_train_workspace(3, 256, 100, 4, sizes) < 0   # Bp not a multiple of 64
     assert L.npp_train_workspace(3, 256, 128, 4, sizes) == 0
