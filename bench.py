@@ -367,6 +367,12 @@ def main():
         import glob
         pq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))[-1]))
         mfma_pmc = {k_: pq["kernels"][v_].get("mfma_pipe_busy_frac") for k_, v_ in pmc_key.items() if v_ in pq["kernels"]}
+        # the inference render (one 0.7-ms dispatch, long enough for GRBM_GUI_ACTIVE / 8 / wall to be the clock the chip held:
+        # MI355X_MICROARCH.md 'DVFS give-back'): pipe-busy fraction AT that clock, next to the FLOP fraction of the 2.4-GHz peak
+        rk = pq["kernels"].get("npp::mlp_fwd_kernel<false, true, false>")
+        if rk:
+            mfma_pmc["render_fwd_512sq"] = rk.get("mfma_pipe_busy_frac")
+            mfma_pmc["render_effective_clock_GHz"] = rk.get("effective_clock_GHz")
     except (OSError, IndexError, KeyError, ValueError):
         mfma_pmc = None
     roofline = {"bound": "mfma", "kernel": dom, "achieved": tf[dom], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
