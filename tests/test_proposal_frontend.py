@@ -180,3 +180,14 @@ def test_search_driver_writes_a_loadable_detected_dir(tmp_path):
     assert min(abs(c[0] - true_p[0]) + abs(c[1] - true_p[1]) for c in cand) <= 12.0, (cand, true_p)
     with pytest.raises(SystemExit, match="exists"):
         search.main(["--datadir", str(src), "--outdir", str(out), "--random-trunks"])
+
+
+def test_search_flags_keep_the_reference_store_false_semantics():
+    """options/arg_config.py:122-126: --gray_only / --edge_searching are store_false switches, so the reference's default run is
+    gray features + Canny edges and passing --gray_only turns the AlexNet features ON."""
+    from npp_amd import search
+    a = search.parse(["--datadir", "x"])
+    assert a.gray_only is True and a.edge_searching is True and tuple(a.search_range) == (1, 10, 1)
+    assert a.N_iters == 300 and a.N_rand == 2048 and a.netdepth == 4 and a.perceptual_weight == 30 and a.topk_detection == 10
+    b = search.parse(["--datadir", "x", "--gray_only", "--edge_searching"])
+    assert b.gray_only is False and b.edge_searching is False
