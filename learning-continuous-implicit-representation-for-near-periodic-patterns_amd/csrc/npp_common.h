@@ -85,6 +85,25 @@ __device__ __forceinline__ float warp_value(const EmbedDev& e, int p, int i, flo
   }
 }
 
+// Both functions of one argument from ONE reduction (bitwise the values sincos_pi2(x, false) / (x, true) return): the
+// precise embedder needs sin(f v) and cos(f v) of every (frequency, coordinate) pair.
+__device__ __forceinline__ void sincos_pi2_both(float x, float& sn, float& cs) {
+  const float jf = rintf(x * 0.636619772367581343f);
+  float y = fmaf(-jf, 1.5703125f, x);
+  y = fmaf(-jf, 4.837512969970703125e-4f, y);
+  y = fmaf(-jf, 7.54978995489188e-8f, y);
+  const int q = (int)jf;
+  const float z = y * y;
+  const float s = fmaf(y * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), y);
+  const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                       fmaf(z, -0.5f, 1.0f));
+  const float rs = (q & 1) ? c : s;
+  sn = (q & 2) ? -rs : rs;
+  const int qc = q + 1;
+  const float rc = (qc & 1) ? c : s;
+  cs = (qc & 2) ? -rc : rc;
+}
+
 // ---- a6: snake and its derivative (models/activations.py:29-35, a = 1) -----------
 __device__ __forceinline__ float snake_fast(float z) {
   const float s = __builtin_amdgcn_sinf(z * kInv2Pi);

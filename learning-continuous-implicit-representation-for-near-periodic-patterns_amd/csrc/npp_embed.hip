@@ -43,8 +43,16 @@ int check_embed_cfg(const npp_embed_cfg* c, const char* who) {
   return NPP_OK;
 }
 
-constexpr int kEmbRows = 64;     // rows per workgroup (one per lane in phase 1)
+#ifndef NPP_EMB_ROWS
+#define NPP_EMB_ROWS 32
+#endif
+constexpr int kEmbRows = NPP_EMB_ROWS;     // rows per workgroup (one per lane in phase 1; 32: the upper half-waves idle there)
 constexpr int kEmbThreads = 256;
+#ifndef NPP_EMB_STAGE
+#define NPP_EMB_STAGE 2
+#endif
+constexpr int kEmbStage = NPP_EMB_STAGE;     // rows staged in LDS per pass of the exact-fp32 form (2 x 5 x 462 floats = 18 KiB; measured
+                                              // 1024^2 K=3: 2 rows 1.47 ms, 4 rows 1.62, 8 rows 2.69 -- occupancy; 64 rows per workgroup 1.56)
 constexpr int kSvStride = NPP_MAX_K * 22 + 1;   // odd stride: conflict-free row-per-lane writes
 
 // Per output column (reference order, models/embedder.py:41-44,56): index of its warped coordinate,
@@ -61,8 +69,11 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
                                                             int64_t N, EmbedDev e,
                                                             void* __restrict__ out) {
   __shared__ float sv[kEmbRows * kSvStride];
-  __shared__ ColEnt tab[NPP_MAX_K * kE];
+  constexpr bool kPairForm = PRECISE && !BF16OUT;             // exact-fp32 form: units instead of the column table
+  __shared__ ColEnt tab[kPairForm ? 1 : NPP_MAX_K * kE];
   __shared__ float sfreq[NPP_N_FREQ];   // lane-varying index: keep it out of the kernarg struct
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  __shared__ __attribute__((aligned(16))) float sstage[kPairForm ? kEmbStage * NPP_MAX_K * kE : 4];
   const int tid = threadIdx.x;
   if (tid == 0) {
 #pragma unroll
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
   }
   __syncthreads();
   const int K = e.K;
-  for (int c = tid; c < K * kE; c += kEmbThreads) {
+  for (int c = tid; !kPairForm && c < K * kE; c += kEmbThreads) {
     const int p = c / kE, cc = c - p * kE, blk = cc / 22, i = cc - blk * 22;
     ColEnt en;
     en.code = (p * 22 + i) | (blk == 0 ? 1 << 16 : 0) | ((blk > 0 && ((blk - 1) & 1)) ? 1 << 17 : 0);
@@ -82,16 +93,61 @@ __global__ __launch_bounds__(kEmbThreads) void embed_kernel(const int32_t* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int64_t r = row0 + lane;
-    const int2 c = r < N ? ((const int2*)coords)[r] : make_int2(0, 0);
+    const int2 c = (r < N && lane < kEmbRows) ? ((const int2*)coords)[r] : make_int2(0, 0);
     const float y = (float)c.x, x = (float)c.y;   // (row=y, col=x): first member is y
     for (int job = wave; job < K * 22; job += 4)
-      sv[lane * kSvStride + job] = warp_value<PRECISE>(e, job / 22, job % 22, y, x);
+      if (lane < kEmbRows) sv[lane * kSvStride + job] = warp_value<PRECISE>(e, job / 22, job % 22, y, x);
   }
   __syncthreads();
+  if (PRECISE && !BF16OUT) {
+    // Phase 2, exact-fp32 form (BASELINE config c4): the arithmetic, not the stores, bounded this path (2.4 -> 3.3 TB/s with
+    // the branch-free polynomial; ~20 vector instructions per value).  sin(f v) and cos(f v) of one (frequency, coordinate)
+    // pair sit 22 columns apart in a row, so a thread takes a UNIT = (row, proposal, block, coordinate pair i, i + 1) and
+    // produces both functions of both arguments from two range reductions: 11 instead of 20 instructions per value.  The
+    // values of kEmbStage rows are staged in LDS (the 8-byte pieces of a unit are 88 bytes apart: written straight to
+    // memory they ran at 1.9 TB/s) and leave as the same 16-byte streaming stores as the other forms: 3.3 -> 4.0 TB/s.
+    typedef __attribute__((ext_vector_type(2))) float f32x2v;
+    float* stage = sstage;
+    const int rowlen = K * kE;
+    const int upr = K * 121;                                  // units per row: per proposal 11 identity pairs + 10 x 11
+    for (int r0 = 0; r0 < kEmbRows; r0 += kEmbStage) {
+      int t = tid, rr = 0;
+      while (t >= upr) { t -= upr; ++rr; }
+      while (rr < kEmbStage) {
+        const int p = t / 121, tt = t - p * 121, blk = tt / 11, i = 2 * (tt - blk * 11);
+        const float v0 = sv[(r0 + rr) * kSvStride + p * 22 + i], v1 = sv[(r0 + rr) * kSvStride + p * 22 + i + 1];
+        float* orow = stage + rr * rowlen + p * kE;
+        if (blk == 0) {
+          *(f32x2v*)(orow + i) = f32x2v{v0, v1};
+        } else {
+          const float fr = sfreq[blk - 1];
+          float s0, c0, s1, c1;
+          sincos_pi2_both(v0 * fr, s0, c0);
+          sincos_pi2_both(v1 * fr, s1, c1);
+          *(f32x2v*)(orow + (2 * blk - 1) * 22 + i) = f32x2v{s0, s1};
+          *(f32x2v*)(orow + (2 * blk) * 22 + i) = f32x2v{c0, c1};
+        }
+        t += kEmbThreads;
+        while (t >= upr) { t -= upr; ++rr; }
+      }
+      __syncthreads();
+      const int n4 = kEmbStage * rowlen / 4;                   // rowlen is even, kEmbStage a multiple of 2
+      const int64_t base = (row0 + r0) * (int64_t)rowlen;
+      const int64_t lim = N * (int64_t)rowlen;
+      for (int q = tid; q < n4; q += kEmbThreads) {
+        const f32x4v w = *(const f32x4v*)(stage + 4 * q);
+        if (base + 4 * q + 3 < lim) __builtin_nontemporal_store(w, (f32x4v*)((float*)out + base + 4 * q));
+        else
+          for (int u = 0; u < 4; ++u)
+            if (base + 4 * q + u < lim) ((float*)out)[base + 4 * q + u] = w[u];
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // Phase 2: the 64 x (K*462) outputs of this workgroup are one contiguous range of the output
   // array: each thread produces 4 consecutive values (16-byte fp32 / 8-byte bf16 streaming stores,
   // no ragged last pass over a row); (row, column) advance incrementally, without divisions.
-  typedef __attribute__((ext_vector_type(4))) float f32x4v;
   const int rowlen = K * kE;
   const int total = kEmbRows * rowlen;                       // multiple of 4 (64 rows)
   int f = 4 * tid;
