@@ -125,7 +125,18 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& acc, int s) {
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+#ifdef NPP_DIAG_MFMA16     // timing-only diagnostic (wrong results): the same FLOPs as two v_mfma_f32_16x16x32_bf16 on quarter tiles
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x16 r = c;
+  f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[8], c[9], c[10], c[11]};
+  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+  r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2]; r[3] = c0[3];
+  r[8] = c1[0]; r[9] = c1[1]; r[10] = c1[2]; r[11] = c1[3];
+  return r;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }

@@ -54,6 +54,26 @@ int check_embed_cfg(const npp_embed_cfg* c, const char* who);
 #define NPP_FWD_OVERLAP_PROLOGUE 0
 #endif
 constexpr bool kOverlapPro = NPP_FWD_OVERLAP_PROLOGUE != 0;
+// MFMA shape of the forward chain.  1 (default at W = 256): v_mfma_f32_16x16x32_bf16 -- the same FLOPs per cycle as 32x32x16, but
+// the chip holds a higher clock on it under load (MI355X_MICROARCH.md 'DVFS give-back' item 7).  Measured, same-box A/B, 1024^2
+// K = 3 render: 2.510 -> 2.434 ms (-3 %; a timing-only substitution that kept the old operand registers had promised -8 %), the
+// training forward unchanged (89-90 us: bound by its stores and the row quantisation); at W = 512 the render is unchanged and the
+// training kernel reaches the 256-register limit (21 spills, 239 -> 264 us), so that build keeps 32x32x16.  Nothing outside this
+// file changes: LDS fragments, weight pack and stash
+// keep the 32x32x16 slot layout (16 bytes = 8 features of one row); the 16x16x32 operands GATHER slots from two consecutive
+// k-steps (lane (n, g): row 16 rt + n, k-step 2 KB + (g >> 1), half g & 1), and an accumulator tile (4 neurons 4 g + r of 16
+// rows per lane) becomes next-layer slots after ONE v_permlane32_swap per dword (the two halves of a slot sit in lanes l, l + 32).
+// A wave's f32x16 accumulator [nt][bt] is reinterpreted as four 16 x 16 tiles: element 4 (2 mi + ri) + r = neuron
+// 32 nt + 16 mi + 4 g + r of row 32 bt + 16 ri + (lane & 15).
+#ifndef NPP_FWD_MFMA16
+#define NPP_FWD_MFMA16 (NPP_WIDTH == 256)
+#endif
+constexpr bool kM16 = NPP_FWD_MFMA16 != 0;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// neuron (within the wave's 32-neuron tile) of accumulator element idx for this lane
+__device__ __forceinline__ int acc_nrow(int idx, const Lane& L) {
+  return kM16 ? 16 * (idx >> 3) + 4 * (L.lane >> 4) + (idx & 3) : acc_row(idx, L.h);
+}
 constexpr int kWavesF = NPP_FWD_WAVES;
 constexpr int kNTW = kNT / kWavesF;                             // neuron tiles per wave in 256-wide layers
 constexpr int kThreads = 64 * kWavesF;
@@ -121,7 +141,7 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][kNB], const float* 
   for (int nt = 0; nt < NTW; ++nt) {
     f32x16 bv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = bias[(nt0 + nt) * 32 + acc_row(r, L.h)];
+    for (int r = 0; r < 16; ++r) bv[r] = bias[(nt0 + nt) * 32 + acc_nrow(r, L)];
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = bv;
   }
@@ -135,7 +155,7 @@ __device__ __forceinline__ void bias_fetch(BiasPre<NTW>& bp, const float* __rest
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bp.v[nt][r] = bias[(nt0 + nt) * 32 + acc_row(r, L.h)];
+    for (int r = 0; r < 16; ++r) bp.v[nt][r] = bias[(nt0 + nt) * 32 + acc_nrow(r, L)];
 }
 template <int NTW>
 __device__ __forceinline__ void bias_apply(f32x16 (&acc)[NTW][kNB], const BiasPre<NTW>& bp) {
@@ -149,6 +169,90 @@ __device__ __forceinline__ void bias_apply(f32x16 (&acc)[NTW][kNB], const BiasPr
 
 // The 22 warped coordinates (a1, models/embedder.py:110-133) of proposal p for the 64 rows ->
 // sV[i][row] (fp32).  Table-driven: wave w takes i = w, w+4, ...; the entry is wave-uniform.
+// ---- 16x16x32 form of the weight ring and of mma_ring (npp_common.h holds the 32x32x16 originals, which the backward chain uses)
+// The ring keeps its 4 k-steps x NTW fragments of storage; fragment (k-step pair KB, 16-neuron tile mt) lives in
+// w[2 (KB & 1) + (mt & 1)][mt >> 1] and is ONE buffer load that gathers 4 runs of 16 slots from the pack's k-steps 2 KB, 2 KB + 1.
+template <int NTW, int NT>
+__device__ __forceinline__ void wpair_load(WRing<NTW>& r, int half, wptr_t wp, int ks /*even*/, int nt0, const Lane& L) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const int n16 = L.lane & 15, g = L.lane >> 4;
+  const int voff = (n16 + 32 * (g & 1)) * 16 + (g >> 1) * NT * 1024;          // lane part: slot, and the second k-step of the pair
+#pragma unroll
+  for (int mt = 0; mt < 2 * NTW; ++mt) {
+    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(
+        r.rsrc, voff + (mt & 1) * 256, (int)((wp + (uint32_t)((ks * NT + nt0 + (mt >> 1)) * 64)) * 16u), 0);
+    r.w[2 * half + (mt & 1)][mt >> 1] = __builtin_bit_cast(bf16x8, raw);
+  }
+}
+template <int NTW, int NT>
+__device__ __forceinline__ void wring_fill16(WRing<NTW>& r, wptr_t wp, int nt0, const Lane& L) {
+  wpair_load<NTW, NT>(r, 0, wp, 0, nt0, L);
+  wpair_load<NTW, NT>(r, 1, wp, 2, nt0, L);
+}
+// B operand of k-step pair starting at LDS k-step ks (even), 16-row tile rt
+__device__ __forceinline__ bf16x8 lds_frag16(const char* region, int ks, int rt, const Lane& L) {
+  const int n16 = L.lane & 15, g = L.lane >> 4;
+  return *(const bf16x8*)(region + ((ks + (g >> 1)) * kNB + (rt >> 1)) * 1024 + (16 * (rt & 1) + n16 + 32 * (g & 1)) * 16);
+}
+__device__ __forceinline__ void mfma16_sub(f32x16& c, int q, const bf16x8& a, const bf16x8& b) {
+  f32x4 t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
+  c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
+}
+// Same contract as mma_ring (positions in 32x32x16 k-steps, all even here; hook called once per k-step position).
+template <int KS0, int KS1, int KSREAL, int KSTOT, int NTW, int NT, typename Hook = NoHook, bool SLICED = false>
+__device__ __forceinline__ void mma_ring16(f32x16 (&acc)[NTW][kNB], const char* region, int ks_lds0,
+                                           wptr_t wp, wptr_t next_wp, int nt0,
+                                           const Lane& L, WRing<NTW>& ring, const Hook& hook = Hook()) {
+  static_assert(KS0 % 2 == 0 && KS1 % 2 == 0 && KSREAL % 2 == 0 && KSTOT % kRD == 0 && kRD == 4 && KSREAL <= KSTOT && KS1 <= KSTOT,
+                "ring schedule (k-step pairs)");
+  constexpr int KSE = KS1 < KSREAL ? KS1 : KSREAL;
+  constexpr int RT = 2 * kNB;
+  bf16x8 xn[RT];
+  if (KS0 < KSE) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) xn[rt] = lds_frag16(region, ks_lds0, rt, L);
+  }
+#pragma unroll
+  for (int ks = KS0; ks < KS1; ks += 2) {
+    const int half = (ks >> 1) & 1;
+    if (ks < KSREAL) {
+      bf16x8 x[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) x[rt] = xn[rt];
+      if (ks + 2 < KSE) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xn[rt] = lds_frag16(region, ks_lds0 + ks + 2 - KS0, rt, L);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2 * NTW; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          mfma16_sub(acc[mt >> 1][rt >> 1], 2 * (mt & 1) + (rt & 1), ring.w[2 * half + (mt & 1)][mt >> 1], x[rt]);
+    }
+    hook(ks - KS0);
+    hook(ks + 1 - KS0);
+    if (ks + kRD < KSREAL) wpair_load<NTW, NT>(ring, half, wp, ks + kRD, nt0, L);
+    else if (ks + kRD >= KSTOT && next_wp != kNoW) wpair_load<NTW, NT>(ring, half, next_wp, ks + kRD - KSTOT, nt0, L);
+    if (SLICED && ks < KSREAL) {
+#pragma unroll
+      for (int gq = 0; gq < 4 * NTW * kNB; ++gq) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (NPP_SLICE_VALU_PER_GAP + 1) / 2, 0);
+        if (gq & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+#if NPP_FWD_MFMA16
+#define MMA_RING mma_ring16
+#define WRING_FILL(NTW_, NT_, ring_, wp_, nt0_, L_) wring_fill16<NTW_, NT_>(ring_, wp_, nt0_, L_)
+#else
+#define MMA_RING mma_ring
+#define WRING_FILL(NTW_, NT_, ring_, wp_, nt0_, L_) wring_fill<NTW_, NT_>(ring_, wp_, nt0_, (L_).lane)
+#endif
+
 constexpr int kWarpPer = (22 + kWavesF - 1) / kWavesF;        // warped coordinates computed by one wave (6 or 3)
 __device__ __forceinline__ void gen_warp(const WarpEnt* tw, int p, float* sV, const float* sY, const float* sX,
                                          const Lane& L, int q_only = -1) {
@@ -253,7 +357,7 @@ __device__ __forceinline__ void load_emb_pair(const float* __restrict__ emb, int
 }
 
 // The generator cut into slices of one QUAD (slots 2 JP, 2 JP + 1 of both batch tiles = 4 values: one ds_read2 per slot,
-// 4 fma, 4 v_sin, 2 packs) so that mma_ring<..., SLICED> can thread it through the MFMAs of one schedule position.  The LDS
+// 4 fma, 4 v_sin, 2 packs) so that MMA_RING<..., SLICED> can thread it through the MFMAs of one schedule position.  The LDS
 // reads of a quad are issued one position before its arithmetic.  Only for chunks whose k-steps are all regular
 // (k-step < 28, hence < kKSEmb): no branch anywhere, so a position stays one scheduling region.
 template <bool STORE_EMB, int KPER>
@@ -404,31 +508,31 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   if (!EMB_IN) {
     const auto g1 = sliced_for(1);
     g1.prologue();
-    mma_ring<0, 8, kKSEmb, 32, NTW, NT, decltype(g1), true>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, g1);
+    MMA_RING<0, 8, kKSEmb, 32, NTW, NT, decltype(g1), true>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, g1);
     STAMP(55);
     wg_barrier();
     STAMP(56);
     const auto g2 = sliced_for(2);
     g2.prologue();
-    mma_ring<8, 16, kKSEmb, 32, NTW, NT, decltype(g2), true>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, g2);
+    MMA_RING<8, 16, kKSEmb, 32, NTW, NT, decltype(g2), true>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, g2);
     wg_barrier();
   } else
 #endif
   {
-    mma_ring<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
+    MMA_RING<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
     STAMP(55);
     wg_barrier();
     STAMP(56);
-    mma_ring<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
+    MMA_RING<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
     wg_barrier();
   }
-  mma_ring<16, 24, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(3));
+  MMA_RING<16, 24, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(3));
   wg_barrier();
   if (!EMB_IN && next_warp_p >= 0) {
     auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, next_warp_p, sV, sY, sX, L, pos); };
-    mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, warp_hook);
+    MMA_RING<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, warp_hook);
   } else {
-    mma_ring<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
+    MMA_RING<24, 32, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring);
   }
   wg_barrier();
 }
@@ -448,16 +552,39 @@ __device__ __forceinline__ void mma_plain_gen_chunk0(f32x16 (&acc)[NTW][kNB], co
   g.lane = L.lane; g.ksl0 = kPer * L.wave; g.ks0 = kPer * L.wave;
   g.ph = L.h ? 0.25f : 0.0f;
   g.prologue();
-  mma_ring<KS0, KS1, kKSAct, kKSAct, NTW, NT, decltype(g), NPP_FWD_SLICED_PLAIN != 0>(acc, region, KS0, wp, next_wp, nt0, L, ring, g);
+  MMA_RING<KS0, KS1, kKSAct, kKSAct, NTW, NT, decltype(g), NPP_FWD_SLICED_PLAIN != 0>(acc, region, KS0, wp, next_wp, nt0, L, ring, g);
 }
 
 // Epilogue of a 256-wide (NTW=2 per wave) or 128-wide (NTW=1) layer.
 //  SNAKE: apply x + sin^2 x; else linear.   out: LDS region that receives the bf16
 //  fragments (k-step 2*ntile+s of the next layer), may be null.
 //  TRAIN: stash z (fp16, snake layers) or the linear output (bf16) in W-format.
+// 16x16x32 accumulator layout: the two halves (elements 0..3 | 4..7) of a next-layer slot sit in lanes l and l + 32, for the row
+// tiles ri = 0 and ri = 1 alike: one v_permlane32_swap per dword gives the lower lanes the whole slot of tile ri = 0 and the upper
+// lanes that of ri = 1 (cdna_hip_programming.md T21), i.e. slot 16 (g >> 1) + (lane & 15) + 32 (g & 1) of fragment
+// (k-step 2 ntg + mi, batch tile bt): one 16-byte LDS / stash store per lane and fragment, as in the 32x32x16 form.
+template <typename E2>   // E2 = 2-element vector of __bf16 or _Float16
+__device__ __forceinline__ void slot_from_halves(const float (&lo)[4], const float (&hi)[4], uint32_t (&slot)[4]) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  uint32_t pa[2], pb[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    pa[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v{lo[2 * d], lo[2 * d + 1]}), E2));
+    pb[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v{hi[2 * d], hi[2 * d + 1]}), E2));
+    const auto r = __builtin_amdgcn_permlane32_swap(pa[d], pb[d], false, false);
+    pa[d] = r[0];
+    pb[d] = r[1];
+  }
+  slot[0] = pa[0]; slot[1] = pa[1]; slot[2] = pb[0]; slot[3] = pb[1];
+}
+
 template <bool SNAKE, bool TRAIN, int NTW>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int nt0, int ntl /*tiles in layer*/,
                                          char* stash_array, int wg, const Lane& L, bf16x8 (*keep)[kNB][2] = nullptr) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+  const int g16 = L.lane >> 4;
+  const int slot_lane = 16 * (g16 >> 1) + (L.lane & 15) + 32 * (g16 & 1);       // kM16: the slot this lane ends up holding
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int ntg = nt0 + nt;
@@ -465,8 +592,18 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
     for (int bt = 0; bt < kNB; ++bt) {
       if (TRAIN && SNAKE) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-          stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), pack_acc_f16(acc[nt][bt], s));
+        for (int s = 0; s < 2; ++s) {
+          if (kM16) {
+            float lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lo[r] = acc[nt][bt][8 * s + r]; hi[r] = acc[nt][bt][8 * s + 4 + r]; }
+            uint32_t sl[4];
+            slot_from_halves<f16x2v>(lo, hi, sl);
+            stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, slot_lane & 31, slot_lane >> 5), __builtin_bit_cast(f16x8, sl));
+          } else {
+            stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), pack_acc_f16(acc[nt][bt], s));
+          }
+        }
       }
       // snake on aligned register pairs: v_pk_mul (z / 2pi), 2 x v_sin, v_pk_fma (s*s + z), v_cvt_pk
       f32x16 a;
@@ -488,10 +625,22 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
       acc[nt][bt] = a;   // callers that need the fp32 activation (P -> rgb) read it back
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 f = pack_acc(a, s);
-        if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
+        bf16x8 f;
+        int sl_lane = L.lane;
+        if (kM16) {          // s = mi: elements 8 mi + 0..3 belong to row tile ri = 0, 8 mi + 4..7 to ri = 1
+          float lo[4], hi[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { lo[r] = a[8 * s + r]; hi[r] = a[8 * s + 4 + r]; }
+          uint32_t sl[4];
+          slot_from_halves<bf16x2v>(lo, hi, sl);
+          f = __builtin_bit_cast(bf16x8, sl);
+          sl_lane = slot_lane;
+        } else {
+          f = pack_acc(a, s);
+        }
+        if (out) lds_store_frag(out, 2 * ntg + s, bt, sl_lane, f);
         if (keep) keep[nt][bt][s] = f;
-        if (TRAIN && !SNAKE) stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, L.b, L.h), f);
+        if (TRAIN && !SNAKE) stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, sl_lane & 31, sl_lane >> 5), f);
       }
     }
   }
@@ -565,7 +714,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 
   STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
-  wring_fill<kNTW, kNT>(ring, wl(L0), nt0, L.lane);
+  WRING_FILL(kNTW, kNT, ring, wl(L0), nt0, L);
   init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
   mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
   STAMP(1);
@@ -583,7 +732,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     char* in = (l & 1) ? R0 : R1;
     char* out = (l & 1) ? R1 : R0;
     bias_apply<kNTW>(acc, bn);
-    mma_ring<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), (l == L4 && !EMB_IN && kOverlapPro) ? wl(L5) + kKSEmb * U : wl(l + 1), nt0, L, ring);
+    MMA_RING<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), (l == L4 && !EMB_IN && kOverlapPro) ? wl(L5) + kKSEmb * U : wl(l + 1), nt0, L, ring);
     STAMP(4 * l);
     bias_fetch<kNTW>(bn, P + d.b_off[l + 1], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
@@ -605,7 +754,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   } else {
     mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
     STAMP(20);
-    mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
+    MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   }
   STAMP(21);
   bias_fetch<kNTW>(bn, P + d.b_off[L6], nt0, L);
@@ -615,12 +764,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
   bias_apply<kNTW>(acc, bn);
-  mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
+  MMA_RING<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
   bias_fetch<kNTW>(bn, P + d.b_off[L7], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(6), wg, L);
   wg_barrier();
   bias_apply<kNTW>(acc, bn);
-  mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
+  MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
   bias_fetch<kNTW>(bn, P + d.b_off[LF1], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(7), wg, L);
   wg_barrier();
@@ -628,9 +777,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
   //      registers because P needs f1 again after S and F2 have recycled the regions.
   bias_apply<kNTW>(acc, bn);
-  mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
+  MMA_RING<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF1), MULTI ? wl(LS) : kNoW, nt0, L, ring);
   const bool p_wave = L.wave < kNT / 2;            // P has 4 neuron tiles: with 8 waves the upper four only keep the barriers
-  if (!MULTI && p_wave) wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+  if (!MULTI && p_wave) WRING_FILL(1, kNT / 2, ringp, wl(LP), L.wave, L);
   if (MULTI) bias_fetch<kNTW>(bn, P + d.b_off[LS], nt0, L);
   else if (p_wave) bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
   epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L);
@@ -644,12 +793,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       // f1 part: proposal 1's warped coordinates are computed in the gaps of its first half (sV is idle since L5), a
       // barrier publishes them, chunk 0 of proposal 1 is generated in the gaps of the second half
       auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, 1, sV, sY, sX, L, pos); };
-      mma_ring<0, A / 2, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring, warp_hook);
+      MMA_RING<0, A / 2, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring, warp_hook);
       wg_barrier();
       mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, A_.actF, wg, L, ring);
       wg_barrier();
     } else {
-      mma_ring<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
+      MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
     }
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
@@ -657,15 +806,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
                                    A_.actF, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
                                    /*next_warp_p=*/(kOverlapPro && p + 1 < d.K) ? p + 1 : -1);
     }
-    wring_fill<kNTW, kNT>(ring, wl(LF2), nt0, L.lane);        // flies under the epilogue
+    WRING_FILL(kNTW, kNT, ring, wl(LF2), nt0, L);        // flies under the epilogue
     bias_fetch<kNTW>(bn, P + d.b_off[LF2], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
     bias_apply<kNTW>(acc, bn);
-    mma_ring<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
+    MMA_RING<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(LF2), kNoW, nt0, L, ring);
     if (p_wave) {
-      wring_fill<1, kNT / 2>(ringp, wl(LP), L.wave, L.lane);
+      WRING_FILL(1, kNT / 2, ringp, wl(LP), L.wave, L);
       bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
     }
     // P needs f1 again, and this epilogue recycles its region: the wave takes ITS f1 fragments (the only ones its own f2 stores
@@ -691,13 +840,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     // ---- P = pos_linears[0]: [f1 (R1), f2 (R0)] -> 128, snake; one neuron tile per wave
     if (p_wave) {
       bias_apply<1>(accp, bnp);
-      mma_ring<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
-      mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
+      MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R1, 0, wl(LP), wl(LP) + A * UP, L.wave, L, ringp);
+      MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP) + A * UP, kNoW, L.wave, L, ringp);
     }
   } else if (p_wave) {
     // ---- NPP_Net_top1: P reads f1 (R0) directly (networks.py:162-170)
     bias_apply<1>(accp, bnp);
-    mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
+    MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   if (p_wave)
     epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
@@ -709,28 +858,41 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   wg_barrier();       // every wave is done with R0 / R1: R0 now carries the rgb partial sums
   if (p_wave) {
     const float* Wr = P + d.w_off[LRGB];
-    float part[kNB][3];
+    // partial dot of this lane's 16 P-neurons per output row it holds: 32x32x16 form: one row per batch tile (reduce over the
+    // two lane halves); 16x16x32 form: rows 16 ri + (lane & 15) of each batch tile (reduce over the four 16-lane groups)
+    constexpr int RI = kM16 ? 2 : 1;
+    float part[kNB][RI][3];
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) part[bt][c] = 0.0f;
+      for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[bt][ri][c] = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int k = L.wave * 32 + acc_row(r, L.h);
+      const int k = L.wave * 32 + acc_nrow(r, L);
+      const int ri = kM16 ? (r >> 2) & 1 : 0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float w = Wr[c * (kW / 2) + k];
 #pragma unroll
-        for (int bt = 0; bt < kNB; ++bt) part[bt][c] = fmaf(w, accp[0][bt][r], part[bt][c]);
+        for (int bt = 0; bt < kNB; ++bt) part[bt][ri][c] = fmaf(w, accp[0][bt][r], part[bt][ri][c]);
       }
     }
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = part[bt][c] + __shfl_xor(part[bt][c], 32, 64);
-        if (L.h == 0) sRGB[(L.wave * kRowTile + bt * 32 + L.b) * 3 + c] = v;
-      }
+      for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float v = part[bt][ri][c] + __shfl_xor(part[bt][ri][c], 32, 64);
+          if (kM16) {
+            v += __shfl_xor(v, 16, 64);
+            if ((L.lane >> 4) == 0) sRGB[(L.wave * kRowTile + bt * 32 + ri * 16 + (L.lane & 15)) * 3 + c] = v;
+          } else if (L.h == 0) {
+            sRGB[(L.wave * kRowTile + bt * 32 + L.b) * 3 + c] = v;
+          }
+        }
   }
   {
     wg_barrier();
