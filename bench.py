@@ -555,7 +555,7 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t4
         two_fits = {"rows_per_s": 2 * 100 * n_rows / dt2, "ms_per_iteration_each": dt2 / 200 * 1e3,
-                    "note": "2 images per GPU, complete iterations interleaved on 2 streams by one host thread (host-enqueue-bound)"}
+                    "note": "2 images per GPU, complete iterations interleaved on 2 streams by one host thread (the launch queue stays full: device-bound, tools/host_probe.py)"}
 
     # ---- the one collective of the job: gather the fitted images -------------------------
     gather_ms = None
