@@ -207,7 +207,9 @@ class CompletionFit:
 
     def materialise_batch(self, d):
         """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists."""
-        real, rmask, fake, fmask, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False)
+        # (want_tuple=False: the loop reads the contiguous crops of last_raw; the reference-shaped views / tiled copies of the
+        #  8-tuple would cost two more launches per iteration)
+        _, _, _, _, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False, want_tuple=False)
         if k == 0:
             return None
         # coordinates of all rows (N_rand pixel rows, then the fake patches' rows, zero padding) + the pixel rows' colours:
@@ -217,8 +219,8 @@ class CompletionFit:
         bp = ops.pad_rows(n)
         allc, gt, pm = ops.batch_assemble(self.i_train_dev, ops.h2d(d["pix"], self.device), self.patch_sampler.last_cen_dev, P, bp,
                                           self.masked_img, self.pixel_mask)
-        return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, real=real, rmask=rmask,
-                    fake=fake, fmask=fmask, source=source, k=k, P=P, n_p=d["n_p"], raw=self.patch_sampler.last_raw, pmask=pm)
+        return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, source=source, k=k, P=P, n_p=d["n_p"],
+                    raw=self.patch_sampler.last_raw, pmask=pm)
 
     def sample_batch(self):
         """Host-side sampling of one iteration + its device half.  None when no valid real patch exists."""
@@ -336,9 +338,10 @@ class CompletionFit:
         net.pixel_loss(bp, n_pix, b["gt"])
         pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
         pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
-        real_p = b["real"].reshape(n_p, k, P, P, 3).permute(0, 1, 4, 2, 3).reshape(-1, 3, P, P)
-        rm = b["rmask"].permute(0, 1, 4, 2, 3).reshape(-1, 1, P, P)
-        fk, fm = b["fake"].reshape(-1, 3, P, P), b["fmask"].reshape(-1, 1, P, P)
+        raw = b["raw"]                                    # contiguous crops: real (n_p k,3,P,P), rmask (n_p k,1,P,P), fake / fmask (n_p,..)
+        real_p, rm = raw["real"].reshape(-1, 3, P, P), raw["rmask"].reshape(-1, 1, P, P)
+        fk = raw["fake"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 3, P, P)             # train.py:219-226 tiling
+        fm = raw["fmask"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 1, P, P)
         x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
         loss_patch = self.contextualLoss(x_in, real_p * rm, None) * self.cx_w
         if source == "same" and self.use_perceptual_loss:

@@ -206,9 +206,9 @@ class GridPatchSampler:
         return d
 
     # ---- device half: crops of exactly the patches that are returned (npp_patch_gather) ----------------------------
-    def materialise(self, d, want_coords=True):
+    def materialise(self, d, want_coords=True, want_tuple=True):
         """-> the reference's 8-tuple (sampler.py:297-354) from a draw(); also sets self.last_raw (contiguous crops for
-        the fused plumbing kernels)."""
+        the fused plumbing kernels).  want_tuple=False: only last_raw, source, k and the weights are produced (entries 0..3 None)."""
         if d["k"] == 0:
             return None, None, None, None, None, None, 0, None
         n, k, P = d["n"], d["k"], d["P"]
@@ -221,18 +221,21 @@ class GridPatchSampler:
         # fake_coords (n,P,P,2) of the 8-tuple (sampler.py:269-279); the fused loop builds its input rows from the centres
         # (npp_batch_assemble) and skips it
         coords = self._coords(self.last_cen_dev, P) if want_coords else None
+        real = rmask = None
         if d["source"] == "same":
-            real, rmask = fake.permute(0, 2, 3, 1)[:, None].clone(), fmask.permute(0, 2, 3, 1)[:, None].clone()
+            if want_tuple:
+                real, rmask = fake.permute(0, 2, 3, 1)[:, None].clone(), fmask.permute(0, 2, 3, 1)[:, None].clone()
             raw_real = (fake, fmask)
         else:
             rgb, m = rgb_all[n:], m_all[n:]
             raw_real = (rgb, m)                                                              # contiguous (n*k,3,P,P), (n*k,1,P,P)
-            real = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                         # (n,k,P,P,3)
-            rmask = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
+            if want_tuple:
+                real = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                     # (n,k,P,P,3)
+                rmask = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
         weight = None if d["weights"] is None else ops.h2d(d["weights"], self.device)   # random mode: no weights (:228)
         self.last_raw = dict(fake=fake, fmask=fmask, real=raw_real[0], rmask=raw_real[1])
-        fake_t = fake[:, None].tile([1, k, 1, 1, 1])
-        fmask_t = fmask[:, None].tile([1, k, 1, 1, 1])
+        fake_t = fake[:, None].tile([1, k, 1, 1, 1]) if want_tuple else None
+        fmask_t = fmask[:, None].tile([1, k, 1, 1, 1]) if want_tuple else None
         self.last_centres = d["cen"]
         return real, rmask, fake_t, fmask_t, coords, d["source"], k, weight
 
