@@ -6,11 +6,12 @@
 //
 // Structure: one 256-thread workgroup owns 64 pixel rows (two
 // 32-column batch tiles).  The GEMMs are computed TRANSPOSED, Z^T[n][b] = W[n][k] X^T[k][b],
-// with v_mfma_f32_32x32x16_bf16: the weights are the A operand (pre-packed in fragment
+// with bf16 MFMAs: the weights are the A operand (pre-packed in fragment
 // order, streamed straight from L2 with one coalesced 1-KiB load per fragment), the
 // activations are the B operand.  A 32x32 accumulator tile converted to bf16 IS the B
 // operand of the next layer's k-steps (no transpose), so activations move between layers
-// as 16-byte-per-lane fragments through LDS: each of the 4 waves owns 2 of the 8 neuron
+// as 16-byte-per-lane fragments through LDS (slot layout of v_mfma_f32_32x32x16_bf16; the W = 256
+// build issues the same work as v_mfma_f32_16x16x32_bf16 on gathered slots, see NPP_FWD_MFMA16 below): each of the 4 waves owns 2 of the 8 neuron
 // tiles and needs the other waves' tiles as its next input.  The 462-wide embedding
 // inputs are never materialised: per proposal the 22 warped coordinates of the 64 rows
 // go to LDS (fp32) and sin/cos Fourier fragments are generated chunk-wise (8 k-steps)
