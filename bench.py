@@ -327,7 +327,7 @@ def main():
         "mlp_bwd_chain": timed(lambda: ops.mlp_bwd(ws["dpred"], ws["pred"], K, net.wb, net.params, ws["actT"], ws["dzT"])),
         "mlp_wgrad": timed(lambda: ops.mlp_wgrad(ws["dzT"], ws["actT"], bp, K, net.ksplit, ws["gslabs"])),
         "pixel_loss": timed(lambda: net.pixel_loss(bp, n_rows, gt0)),
-        "adam+repack": timed(lambda: (ops.adam_step(net.params, net.m, net.v, ws["gslabs"], net.ksplit, net.n_params, 0.0, 1),
+        "adam+repack": timed(lambda: (ops.adam_step(net.params, net.m, net.v, ws["gslabs"], net.ksplit, ws["gslabs"].numel() // net.ksplit, 0.0, 1),
                                       net.repack())),
         "render_fwd_512sq": timed(lambda: net.render(fit.i_all_dev), reps=5),
     }

@@ -279,7 +279,7 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
   sizes[0] = 0;   // (the separate snake-derivative stash is gone: npp_mlp_bwd reads z from actF)
   sizes[1] = (int64_t)act_total_ks(K) * (Bp / kRowTile) * 2048;
   sizes[2] = (int64_t)kDzTotalKs * (Bp / kRowTile) * 2048;
-  sizes[3] = (int64_t)ksplit * make_desc(K).total_params * 4;
+  sizes[3] = (int64_t)ksplit * slab_stride_of(make_desc(K).total_params) * 4;      // ksplit slabs, see slab_stride_of
   return NPP_OK;
 }
 

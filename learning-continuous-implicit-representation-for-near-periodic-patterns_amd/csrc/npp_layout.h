@@ -229,6 +229,9 @@ constexpr int kDzF1 = 8, kDzS = 9, kDzF2 = 10;
 constexpr int kDzKsP = 11 * kKSAct;                          // dz_p (8 k-steps)
 constexpr int kDzKsRgb = kDzKsP + kKSAct / 2;                // dz_rgb: 2 k-steps, 3 features used
 constexpr int kDzTotalKs = kDzKsRgb + 2;
+// split-K slabs of the weight gradient: slab s starts at s * slab_stride_of(total parameters) floats -- rounded up to a multiple
+// of 4 so that every slab is 16-byte aligned (wgrad stores and Adam loads whole float4s; the parameter count itself is odd)
+NPP_HD int64_t slab_stride_of(int64_t total) { return (total + 3) / 4 * 4; }
 NPP_HD int64_t wfmt_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_off * n_wg * 2048; }
 // inverse of perm16 on the 16 columns of a k-step: column c -> (hh, j)
 NPP_HD int unperm_hh(int c) { return (c >> 2) & 1; }

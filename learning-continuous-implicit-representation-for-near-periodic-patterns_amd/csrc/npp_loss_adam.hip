@@ -56,6 +56,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (i >= n) return;
+  if (VEC > 1 && i + VEC > n) {                            // the last n % VEC elements (the parameter count is odd): scalar
+    for (int64_t e = i; e < n; ++e) {
+      float ge = 0.0f;
+      for (int sl = 0; sl < n_slabs; ++sl) ge += g[(int64_t)sl * slab_stride + e];
+      const float me = b1 * m[e] + (1.0f - b1) * ge;
+      const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+      m[e] = me;
+      v[e] = ve;
+      p[e] = p[e] - step_size * (me / (sqrtf(ve) * inv_sqrt_bc2 + eps));
+    }
+    return;
+  }
   auto ld = [&](int sl) { return *(const vec_t*)(g + (int64_t)sl * slab_stride + i); };
   vec_t gi = (vec_t)(0.0f);
   int sl = 0;
@@ -83,9 +95,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 static void adam_launch(float* p, float* m, float* v, const float* g, int64_t n, int n_slabs, int64_t slab_stride,
                         float step_size, float b1, float b2, float inv_sqrt_bc2, float eps, const float* hp,
                         const AdamTail& tail, bool with_tail, hipStream_t s) {
-  const bool vec = n % 4 == 0 && slab_stride % 4 == 0 &&
-                   (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0;
-  const int64_t threads = vec ? n / 4 : n;
+  const bool vec = slab_stride % 4 == 0 && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g) & 15) == 0;
+  const int64_t threads = vec ? (n + 3) / 4 : n;
   const dim3 grid((unsigned)((threads + 255) / 256 + (with_tail ? 1 : 0)));
   if (vec)
     hipLaunchKernelGGL(adam_kernel<4>, grid, dim3(256), 0, s, p, m, v, g, n, n_slabs, slab_stride, step_size, b1, b2,

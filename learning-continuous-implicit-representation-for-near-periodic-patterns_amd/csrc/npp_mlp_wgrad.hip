@@ -29,6 +29,9 @@ constexpr int kWPairs = kWT / 32;   // k-step pairs (32 features) per operand ti
 constexpr int kWTileBytes = kWT * kWBK * 2;          // 32 KiB per operand tile
 constexpr int kSmemW = 4 * kWTileBytes;              // A,B double buffered = 128 KiB
 constexpr int kMaxJobs = 24;
+#ifndef NPP_WGRAD_NT_SLABS
+#define NPP_WGRAD_NT_SLABS 0
+#endif
 #ifndef NPP_WGRAD_XCD
 #define NPP_WGRAD_XCD 1
 #endif
@@ -245,8 +248,55 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     else wgrad_loop<false, false>(acc, bsum, smem, ra, rb, a_stride, b_stride, g0, g1, tid, pf_a, offA, offB);
   }
 
-  // ---- epilogue: plain stores into this split's slab, reference layout
+  // ---- epilogue: stores into this split's slab, reference layout
   float* slab = A.gslabs + (int64_t)split_id * A.slab_stride;
+#ifndef NPP_DIAG_WGRAD_NOEPI
+  if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {        // (every layer of this network has an even input width)
+    // Plain-column jobs (17 of 21 tiles at K = 3): the accumulator holds one column per lane, i.e. 4-byte stores, 128 per wave
+    // -- the tail was bound by store INSTRUCTIONS, not bytes (cdna_hip_programming.md T21).  Each wave transposes its 32 x 128
+    // strips through its 16 KiB of the (now idle) operand buffers and stores float4s (two float2s where the reference rows
+    // are only 8-byte aligned: ld or col0 not a multiple of 4): 16-32 store instructions per strip instead of 64.
+    float* stg = (float*)(smem + wave * 16384);
+    const bool a16 = ((J.ld | J.col0) & 3) == 0;            // (w_off and the slab stride are multiples of 4 floats)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * 128 + 32 * j + m_l] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // same wave: the writes have landed before other lanes' elements are read
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int row = 2 * p + h, c4 = 4 * m_l;
+        const float4 v = *(const float4*)(stg + row * 128 + c4);
+        const int mrow = tm * kWT + wm * 64 + i * 32 + row;
+        const int n_idx = tn * kWT + wn * 128 + c4;
+        if (mrow < J.m && n_idx < J.n) {                    // J.n is a multiple of 4 for these jobs
+          float* dst = slab + J.w_off + (int64_t)mrow * J.ld + J.col0 + n_idx;
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          typedef float f2v __attribute__((ext_vector_type(2)));
+#if NPP_WGRAD_NT_SLABS
+          if (a16) {
+            __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, (f4v*)dst);
+          } else {
+            __builtin_nontemporal_store((f2v){v.x, v.y}, (f2v*)dst);
+            __builtin_nontemporal_store((f2v){v.z, v.w}, (f2v*)(dst + 2));
+          }
+#else
+          if (a16) {
+            *(f4v*)dst = (f4v){v.x, v.y, v.z, v.w};
+          } else {
+            *(f2v*)dst = (f2v){v.x, v.y};
+            *(f2v*)(dst + 2) = (f2v){v.z, v.w};
+          }
+#endif
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next strip overwrites the staging area
+    }
+  } else
+#endif
+  {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n_idx = tn * kWT + wn * 128 + j * 32 + m_l;     // accumulator column = lane & 31
@@ -272,6 +322,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #endif
       }
     }
+  }
   }
   if (do_bias) {
 #pragma unroll
@@ -353,7 +404,7 @@ extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, 
   A.dz_bytes = wfmt_array_base(kDzTotalKs, A.n_wg);
   A.act_bytes = wfmt_array_base(act_total_ks(K), A.n_wg);
   A.gslabs = d_gslabs;
-  A.slab_stride = make_desc(K).total_params;
+  A.slab_stride = slab_stride_of(make_desc(K).total_params);
   const int ntiles = build_jobs(K, A);
   A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
   static SmemOnce once;

@@ -76,7 +76,7 @@ class NPPNet:
 
     def grads(self):
         """Sum of the split-K slabs, as a reference-named dict (for tests)."""
-        g = self._ws_last["gslabs"].view(self.ksplit, self.n_params).sum(0).cpu().numpy()
+        g = self._ws_last["gslabs"].view(self.ksplit, -1)[:, :self.n_params].sum(0).cpu().numpy()     # slab stride = n_params rounded up to 4
         out = {}
         for name, off, rows, cols in self.layout:
             a = g[off:off + rows * cols]
@@ -163,7 +163,7 @@ class NPPNet:
         ws = self._ws[Bp]
         self.opt_step += 1
         idle = self._loss_bufs[1 - self._loss_idx:2 - self._loss_idx]
-        ops.adam_step_net(self.params, self.m, self.v, ws["gslabs"], self.ksplit, self.n_params, self.latents,
+        ops.adam_step_net(self.params, self.m, self.v, ws["gslabs"], self.ksplit, ws["gslabs"].numel() // self.ksplit, self.latents,
                           self.lat_m, self.lat_v, self.dlatent, idle, self.lr, self.opt_step)
         self._clean = True
         self.repack()

@@ -179,7 +179,8 @@ def mlp_bwd_act(dout, out, K, wb, params, actF, dzF, out_act, width=NPP_WIDTH):
 
 def grad_reduce(gslabs, n_slabs, n, grad, accumulate=False):
     """grad (+)= sum of the split-K slabs (the blob-shaped .grad a torch optimiser consumes)."""
-    check(lib().npp_grad_reduce(_p(gslabs), n_slabs, n, n, _p(grad), int(bool(accumulate)), _stream()), "npp_grad_reduce")
+    check(lib().npp_grad_reduce(_p(gslabs), n_slabs, gslabs.numel() // n_slabs, n, _p(grad), int(bool(accumulate)), _stream()),
+          "npp_grad_reduce")
 
 
 def fourier_fwd(x, freqs, include_input=True):

@@ -55,7 +55,7 @@ for W in (256, 512):
     t_b = timed(lambda: ops.mlp_bwd(ws["dpred"], ws["pred"], net.K, net.wb, net.params, ws["actT"], ws["dzT"], W), reps=20)
     t_w = {}
     for ks in sorted({net.ksplit, 2, 3, 4, 6, 8, 12}):
-        gs = torch.empty(ks * net.n_params, dtype=torch.float32, device=dev)
+        gs = torch.empty(ops.train_workspace(net.K, B, ks, W)[3] // 4, dtype=torch.float32, device=dev)
         t_w[ks] = timed(lambda: ops.mlp_wgrad(ws["dzT"], ws["actT"], B, net.K, ks, gs, W), reps=20) * 1e6
     t_a = timed(lambda: net.optimizer_step(B), reps=20)
     out[f"W{W}"] = {"ksplit": net.ksplit, "render_512sq_ms": t_r * 1e3, "render_mfma_frac": 2 * fwd_macs * H * H / t_r / PEAK,
