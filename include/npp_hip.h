@@ -110,7 +110,7 @@ int npp_warp_fwd(const int32_t* d_coords_yx, int64_t N, const npp_embed_cfg* cfg
  *  sizes[1] actF   forward stash, 16-byte fragments in W-format (csrc/npp_layout.h): fp16
  *                  pre-activations of the snake layers, bf16 f1 / f2, bf16 embedding slots
  *  sizes[2] dzF    pre-activation gradients, bf16 fragments in W-format
- *  sizes[3] grad slabs (ksplit * param floats * 4) */
+ *  sizes[3] grad slabs (ksplit * S * 4 bytes, S = the parameter count rounded up to a multiple of 4 floats: the slab stride) */
 int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]);
 
 /* Replaces render() -> run_network -> NPP_Net.forward -> sigmoid
@@ -158,7 +158,8 @@ int npp_mlp_bwd_act(const float* d_dout, const float* d_out, int64_t Bp, int K, 
                     int out_act, void* stream);
 
 /* Weight/bias gradients: ksplit partial slabs in the parameter-blob layout
- * (slab s at d_gslabs + s * total floats); npp_adam_step sums them. */
+ * (slab s at d_gslabs + s * S floats, S = sizes[3] / (4 * ksplit) of npp_train_workspace: 16-byte aligned slabs);
+ * npp_adam_step sums them (pass S as its slab_stride). */
 int npp_mlp_wgrad(const void* d_dzF, const void* d_actF, int64_t Bp, int K, int width,
                   int ksplit, float* d_gslabs, void* stream);
 
