@@ -20,7 +20,7 @@ from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_
 import oracle  # noqa: E402  (only for the synthetic image / periodicity definition)
 
 
-def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300)):
+def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300), W=256):
     """K = 1: NPP_Net_top1 (g8_fit.npz).  K = 3: NPP_Net with the coarse-level proposals of the synthetic lattice, BASELINE
     config c2's network (g8k3_fit.npz; models/networks.py:56-95, table = cat of the K proposals' embeddings, train.py:103-105)."""
     R = import_reference()
@@ -37,7 +37,7 @@ def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30,
     eps = [emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[k]), selected_periods=torch.Tensor(periods[k]),
                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)[0] for k in range(K)]
     torch.manual_seed(0)                                                         # weights: seed-0 default init (tests/refinit.py)
-    net = _net(R, K, 256, int(freq_nerf))
+    net = _net(R, K, W, int(freq_nerf))                                         # W = 512: the reference's default --netwidth
     adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
     opt = torch.optim.Adam(list(net.parameters()) + list(adaptive.parameters()), lr=5e-4, betas=(0.9, 0.999))
     with torch.no_grad():
@@ -71,12 +71,14 @@ def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30,
         if i in checkpoints:
             traj.append([i] + psnr() + [float(loss)])
             print(traj[-1], f"{time.time() - t0:.0f}s", flush=True)
-    np.savez_compressed(os.path.join(OUT, out_name), K=np.int64(K), traj=np.array(traj, np.float64), freqs=freqs, H=np.int64(H), N_rand=np.int64(N_rand),
+    np.savez_compressed(os.path.join(OUT, out_name), K=np.int64(K), W=np.int64(W), traj=np.array(traj, np.float64), freqs=freqs, H=np.int64(H), N_rand=np.int64(N_rand),
                         latent_alpha=adaptive.latent_alpha.detach().numpy(), latent_scale=adaptive.latent_scale.detach().numpy())
 
 
 if __name__ == "__main__":
-    if "--k3" in sys.argv:
+    if "--w512" in sys.argv:                      # g8w512_fit.npz: NPP_Net K = 3 at the reference's default width
+        main(K=3, n_iters=100, out_name="g8w512_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100), W=512)
+    elif "--k3" in sys.argv:
         main(K=3, n_iters=150, out_name="g8k3_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100, 150))
     else:
         main()

@@ -536,6 +536,34 @@ def test_fit_trajectory_vs_reference_g8k3(dev, golden):
                                atol=3e-3)
 
 
+def test_fit_trajectory_vs_reference_g8w512(dev, golden):
+    """g8k3's recipe at the reference's DEFAULT width (--netwidth 512, options/arg_config.py:57): the reference's NPP_Net(W = 512)
+    driven like train.py:164-263 for 100 iterations (g8w512_fit.npz, tests/golden/make_golden_fit.py --w512) against the fused
+    chain of libnpp_hip_w512.so from the same initial weights, frequencies and NumPy stream."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8w512_fit.npz")
+    H, N_rand, K, Wn = int(g["H"]), int(g["N_rand"]), int(g["K"]), int(g["W"])
+    assert (K, Wn) == (3, 512)
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, _ = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(K, W=Wn), device=dev, N_rand=N_rand, seed=0,
+                        rng_mode="reference", width=Wn)
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    got = {}
+    for i in range(1, max(traj) + 1):
+        fit.step()
+        if i in traj:
+            got[i] = (fit.psnr("known"), fit.psnr("unknown"))
+    for i, (pk, pu) in got.items():
+        assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i][:2])       # BASELINE: within 0.1 dB
+    np.testing.assert_allclose(fit.net.latents.cpu().numpy(), np.concatenate([g["latent_alpha"], g["latent_scale"]], 1).reshape(-1),
+                               atol=3e-3)
+
+
 def test_full_loop_with_lpips_trajectory_vs_reference_g8c(dev, golden):
     """g8b with the LPIPS term ON (VERDICT r1 #5a): the reference's own LPIPS.forward (externel_lib/lpips/lpips.py:92-133, the
     vendored lin weights, its per-layer AdaptiveLossFunction latents in the SAME Adam as the network, helpers.py:147-151)
