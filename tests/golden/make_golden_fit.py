@@ -78,6 +78,8 @@ def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30,
 if __name__ == "__main__":
     if "--w512" in sys.argv:                      # g8w512_fit.npz: NPP_Net K = 3 at the reference's default width
         main(K=3, n_iters=100, out_name="g8w512_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100), W=512)
+    elif "--k5" in sys.argv:                      # g8k5_fit.npz: BASELINE config c5's network (top-5 proposals)
+        main(K=5, n_iters=100, out_name="g8k5_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100))
     elif "--k3" in sys.argv:
         main(K=3, n_iters=150, out_name="g8k3_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100, 150))
     else:
