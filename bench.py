@@ -557,6 +557,36 @@ def main():
         two_fits = {"rows_per_s": 2 * 100 * n_rows / dt2, "ms_per_iteration_each": dt2 / 200 * 1e3,
                     "note": "2 images per GPU, complete iterations interleaved on 2 streams by one host thread (the launch queue stays full: device-bound, tools/host_probe.py)"}
 
+    # ---- extra: BASELINE config c4's TASK -- the remapping variant (NPP_remapping/train.py: whole image trained, clear-region
+    #      sampler mask, 0.3-weighted blurry pixels, contextual + Gram style loss) on a 1024^2 image, complete iterations ----
+    remap = None
+    if rank == 0 and not args.no_extras:
+        Hr = 1024
+        im_r, _ = syn.synthetic_image(Hr, seed=7)
+        a_r, p_r, sh_r = syn.synthetic_periodicity(Hr, K)
+        clear = np.ones((Hr, Hr, 1), np.float32)
+        clear[Hr // 3:Hr // 2] = 0.0                              # a blurry band (the reference finds it with blur_detection.py)
+        remap = {"workload": f"remapping task, {Hr}x{Hr}, K={K}: complete iterations incl. host sampling (contextual + style loss, "
+                             f"whole image = {Hr * Hr} known pixels)"}
+        for mode, pf in (("reference", 4), ("fast", 0)):
+            fr = CompletionFit(im_r, np.ones((Hr, Hr, 1), np.float32), a_r, p_r, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
+                               N_rand=8192, seed=0, shifts=sh_r, task="remapping", clear_mask=clear, prefetch=pf, rng_mode=mode,
+                               contextual_weight=0.01, style_weight=1.0, use_perceptual_loss=False)
+            for _ in range(20):
+                fr.step_full()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(60):
+                fr.step_full()
+            torch.cuda.synchronize()
+            dt5 = (time.perf_counter() - t5) / 60
+            rows_r = fr.N_rand + fr.patch_num * fr.patch_size ** 2
+            remap[f"rng_{mode}"] = {"ms_per_iter": dt5 * 1e3, "rows_per_iter": rows_r, "rows_per_s": rows_r / dt5}
+            fr.close()
+            del fr
+        remap["note"] = ("rng_reference reproduces np.random.choice(1 048 576, 8192, replace=False) draw for draw: one full permutation of "
+                         "the pixel pool per iteration on the host (3.5 ms, the loop is host-bound); rng_fast is device-bound")
+
     # ---- the one collective of the job: gather the fitted images -------------------------
     gather_ms = None
     if dist is not None:
@@ -598,7 +628,7 @@ def main():
                                                      "ranks": dist.get_world_size()},
             "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
-            "netwidth_512_fused": w512,
+            "netwidth_512_fused": w512, "remapping_task_1024sq": remap,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
