@@ -117,7 +117,11 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (int)((uint32_t)((cot0 + ct) * KS + ks) * 1024u), 0);
       A[slot][ct] = __builtin_bit_cast(frag_t, raw);
     }
+#ifdef NPP_DIAG_CONV_BSAME      // timing-only diagnostic (wrong results): every tap re-reads tap 0's operand (L1 hits): an upper
+    const int shift = 0;         // bound on what staging the activation window in LDS could save
+#else
     const int shift = (tap / 3) * a.Wp + (tap % 3);
+#endif
     const uint32_t soff = (uint32_t)(((int64_t)2 * ci * a.nposp + shift) * 16);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
