@@ -338,6 +338,11 @@ int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const
 int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
                 const void* d_pack, const float* d_bias, int mode, const void* d_mask, void* d_y,
                 float* d_tap, int Ctap, const float* tap_scale, void* stream);
+/* The same, additionally requesting the weight pack of the launch that follows into L2 (d_next_pack may be NULL). */
+int npp_conv3x3_pf(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
+                const void* d_pack, const float* d_bias, int mode, const void* d_mask, void* d_y,
+                float* d_tap, int Ctap, const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes,
+                   void* stream);
 
 /* nn.MaxPool2d(2,2) on flat tensors, and its backward fused with the ReLU gate of the pooled
  * layer: dz = (route(dy) + addend) * [x > 0]; the gradient goes to the first maximum of each

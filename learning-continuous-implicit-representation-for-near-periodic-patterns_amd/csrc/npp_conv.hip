@@ -68,6 +68,8 @@ struct ConvArgs {
   int32_t N, H, W, Wp, S, CI, cout_chunks, Ctap, has_scale, pos_tiles;
   int64_t nposp, npos_valid;
   uint32_t x_bytes, pack_bytes;
+  const char* pf;        // optional: the NEXT launch's weight pack, requested into this XCD's L2 (one dword per 128-byte line)
+  int64_t pf_bytes;
 };
 
 __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   int bid = blockIdx.x;
   const int nb = gridDim.x;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  // The next layer's weights were last read an iteration ago (1.1 GB of stash traffic since): its first workgroups would
+  // take them from HBM.  Every XCD's workgroups of THIS launch together touch one dword per line of that pack; the value is
+  // consumed at the very end (loads return in order, so it costs no extra wait).
+  uint32_t pf_val = 0;
+  if (a.pf) {
+    const int64_t line = ((int64_t)((blockIdx.x >> 3) + blockIdx.y * ((gridDim.x + 7) >> 3)) * blockDim.x + threadIdx.x) * 128;
+    if (line < a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
+  }
   const int tile0 = bid * PT;
   const int cot0 = blockIdx.y * CT;
   const int KS = a.CI * 9;
@@ -111,7 +121,11 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 
   frag_t A[kConvRing][CT], B[kConvRing][PT];
   auto load = [&](int slot, int ci, int tap) {
+#ifdef NPP_DIAG_CONV_ASAME      // timing-only diagnostic (wrong results): the weight stream collapsed onto k-step 0 of the tile
+    const int ks = 0;
+#else
     const int ks = ci * 9 + tap;
+#endif
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (int)((uint32_t)((cot0 + ct) * KS + ks) * 1024u), 0);
@@ -239,6 +253,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       finish(v, t / PT, t % PT, q);
     }
   }
+  asm volatile("" :: "v"(pf_val));
 }
 
 // ---- weight packers (run once per trunk: the weights are frozen) -------------------------
@@ -635,9 +650,24 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
 // mode 1: y = conv_T(x) * [mask > 0]          (data gradient through a conv into a ReLU layer's pre-activation)
 // mode 2: y = conv_T(x)                       (data gradient into a pooled tensor / the image)
 // N_total fixes the geometry of the buffers, n_run <= N_total the leading images actually computed.
+static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                        const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
+                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
 extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
                            const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
                            const float* tap_scale, void* stream) {
+  return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, d_bias, mode, d_mask, d_y, d_tap, Ctap, tap_scale, nullptr, 0, stream);
+}
+// The same launch additionally requesting the weight pack of the launch that FOLLOWS it into L2 (d_next_pack, bytes).
+extern "C" int npp_conv3x3_pf(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                              const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
+                              const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
+  return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, d_bias, mode, d_mask, d_y, d_tap, Ctap, tap_scale, d_next_pack,
+                      next_pack_bytes, stream);
+}
+static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                        const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
+                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
   int rc = conv_geom_check(N_total, H, W, "npp_conv3x3");
   if (rc) return rc;
   if (!d_x || !d_pack || (!d_y && !d_tap) || mode < 0 || mode > 2 || n_run < 1 || n_run > N_total) {
@@ -663,6 +693,8 @@ extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W
   a.x_bytes = (uint32_t)((int64_t)(Cin / 8) * a.nposp * 16);
   const int cot_n = (Cout + 31) / 32;
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
+  a.pf = (const char*)d_next_pack;
+  a.pf_bytes = d_next_pack ? next_pack_bytes : 0;
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: the largest output tile per workgroup (fewest operand bytes per MFMA) that still yields about one
   // workgroup per CU, with the contraction split over S waves (CI % S == 0).  NPP_CONV_TILE="ct,pt,s" forces one

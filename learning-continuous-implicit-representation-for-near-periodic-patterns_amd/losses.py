@@ -13,6 +13,8 @@ npp_maxpool2_* on flat padded bf16 tensors, forward and data gradient); `_Trunk`
 stack through torch.nn (fp32, MIOpen) and is kept only as the comparator of the GPU tests.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -136,6 +138,13 @@ class HipTrunk:
                 nxt = self.layers[j + 1]["kind"] if j + 1 < len(self.layers) else None
                 L["tap_ok"] = nxt in (None, "pool")
         self._buf, self._gen = {}, 0
+        self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
+
+    def _pb_below(self, j):
+        """The backward pack of the next convolution layer below layer j (what the data-gradient pass runs next)."""
+        if not self.prefetch_next:
+            return None
+        return next((self.layers[i]["pb"] for i in range(j - 1, -1, -1) if self.layers[i]["kind"] == "conv"), None)
 
     def _flat(self, tag, N, C, H, W):
         key = (tag, N, C, H, W)
@@ -168,7 +177,9 @@ class HipTrunk:
                 if L["relu_idx"] in self.taps:
                     tap = torch.empty((N, L["cout"], H, W), dtype=torch.float32, device=self.device)
                     outs.append(tap)
-                ops.conv3x3(cur, N, N, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0)
+                nxt = next((M["pf"] for M in self.layers[j + 1:] if M["kind"] == "conv"), None) if self.prefetch_next else None
+                ops.conv3x3(cur, N, N, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0,
+                            next_pack=nxt)
                 c = L["cout"]
             else:
                 y = self._flat(("a", j), N, c, H // 2, W // 2)
@@ -237,12 +248,12 @@ class HipTrunk:
                     raise NotImplementedError("HipTrunk: gradient tap below a conv layer")
                 yp, cp, _, _ = self._geom[j - 1]
                 dzp = gbuf(cp, H, W)
-                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp)
+                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp, next_pack=self._pb_below(j))
                 cur, j = dzp, j - 1
             else:                                                    # pool at j-1: ungated gradient w.r.t. the pooled tensor
                 _, cp, _, _ = self._geom[j - 1]
                 g = gbuf(cp, H, W)
-                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 2, None, g)
+                ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 2, None, g, next_pack=self._pb_below(j))
                 if (j - 1) in tap_of:
                     ops.trunk_grad_in(tap_of[j - 1], None, N, n, cp, H, W, g, accumulate=True)
                 cur, j, state = g, j - 1, "gp"

@@ -434,8 +434,13 @@ def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, 
           "npp_trunk_patch_in")
 
 
-def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=None, ctap=0, tap_scale=None):
+def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=None, ctap=0, tap_scale=None, next_pack=None):
+    """next_pack: the weight pack of the launch that follows (its lines are requested into L2 by this one)."""
     ts = None if tap_scale is None else (C.c_float * len(tap_scale))(*[float(v) for v in tap_scale])
+    if next_pack is not None:
+        check(lib().npp_conv3x3_pf(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), mode, _p(mask), _p(y), _p(tap),
+                                   ctap, ts, _p(next_pack), next_pack.numel() * next_pack.element_size(), _stream()), "npp_conv3x3_pf")
+        return
     check(lib().npp_conv3x3(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), mode, _p(mask), _p(y), _p(tap),
                             ctap, ts, _stream()), "npp_conv3x3")
 
