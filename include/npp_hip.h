@@ -356,6 +356,10 @@ int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, in
  * (a tap on a tensor that also feeds the next layer).  Also the generic fp32 -> flat importer. */
 int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C,
                       int H, int W, void* d_dz, int as_f16, int accumulate, void* stream);
+/* the same, also requesting the weight pack of the data-gradient launch that follows into L2 (like npp_conv3x3_pf) */
+int npp_trunk_grad_in_pf(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C,
+                         int H, int W, void* d_dz, int as_f16, int accumulate, const void* d_next_pack,
+                         int64_t next_pack_bytes, void* stream);
 /* flat (fp16 activations when is_f16, else bf16 gradients) -> (n_run, C, H, W) fp32 */
 int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W,
                      float* d_out_nchw, int is_f16, void* stream);

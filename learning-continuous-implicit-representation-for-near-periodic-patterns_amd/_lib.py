@@ -136,6 +136,7 @@ SYMBOLS = {
     "npp_maxpool2_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "npp_maxpool2_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "npp_trunk_grad_in": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "npp_trunk_grad_in_pf": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "npp_gram_fwd": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "npp_gram_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "npp_robust_elem_workspace_bytes": (_i64, [_i32]),

@@ -464,11 +464,16 @@ __global__ void maxpool2_bwd_kernel(const bf16x8* __restrict__ dy, const f16x8* 
 // ---- tap gradient in: df (Ng,C,H,W) fp32 -> flat bf16; gated by [y > 0] when y is given ------------
 template <bool F16OUT>
 __global__ void trunk_grad_in_kernel(const float* __restrict__ df, const f16x8* __restrict__ yact, int Ng, int C, int H,
-                                     int W, int64_t nposp, int64_t npos_range, void* __restrict__ dz_, int accumulate) {
+                                     int W, int64_t nposp, int64_t npos_range, void* __restrict__ dz_, int accumulate,
+                                     const char* pf, int64_t pf_bytes) {
   typedef typename OpT<F16OUT>::frag frag_t;
   typedef typename OpT<F16OUT>::elem elem_t;
   frag_t* dz = (frag_t*)dz_;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pf) {              // the first data-gradient layer's weight pack -> every XCD's L2 (see conv3x3_kernel)
+    const int64_t line = ((int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x) * 128;
+    if (line < pf_bytes) { const uint32_t v = *(const volatile uint32_t*)(pf + line); asm volatile("" :: "v"(v)); }
+  }
   const int chunks = C / 8;
   if (t >= npos_range * chunks) return;
   const int c8 = (int)(t / npos_range);
@@ -755,8 +760,19 @@ extern "C" int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d
   return check_launch("npp_maxpool2_bwd");
 }
 
+static int grad_in_impl(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W, void* d_dz, int as_f16,
+                        int accumulate, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
 extern "C" int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W,
                                  void* d_dz, int as_f16, int accumulate, void* stream) {
+  return grad_in_impl(d_df_nchw, d_y, N_total, n_run, C, H, W, d_dz, as_f16, accumulate, nullptr, 0, stream);
+}
+extern "C" int npp_trunk_grad_in_pf(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W,
+                                    void* d_dz, int as_f16, int accumulate, const void* d_next_pack, int64_t next_pack_bytes,
+                                    void* stream) {
+  return grad_in_impl(d_df_nchw, d_y, N_total, n_run, C, H, W, d_dz, as_f16, accumulate, d_next_pack, next_pack_bytes, stream);
+}
+static int grad_in_impl(const float* d_df_nchw, const void* d_y, int N_total, int n_run, int C, int H, int W, void* d_dz, int as_f16,
+                        int accumulate, const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
   int rc = conv_geom_check(N_total, H, W, "npp_trunk_grad_in");
   if (rc) return rc;
   if (!d_df_nchw || !d_dz || C % 16 || n_run < 1 || n_run > N_total) { set_error("npp_trunk_grad_in: bad argument"); return NPP_ERR_ARG; }
@@ -765,10 +781,12 @@ extern "C" int npp_trunk_grad_in(const float* d_df_nchw, const void* d_y, int N_
   const int64_t n = range * (C / 8);
   if (as_f16)
     hipLaunchKernelGGL(trunk_grad_in_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
-                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate);
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate, (const char*)d_next_pack,
+                       d_next_pack ? next_pack_bytes : 0);
   else
     hipLaunchKernelGGL(trunk_grad_in_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_df_nchw,
-                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate);
+                       (const f16x8*)d_y, n_run, C, H, W, conv_nposp(N_total, H, W), range, d_dz, accumulate, (const char*)d_next_pack,
+                       d_next_pack ? next_pack_bytes : 0);
   return check_launch("npp_trunk_grad_in");
 }
 

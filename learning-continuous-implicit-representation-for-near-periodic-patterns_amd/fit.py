@@ -303,6 +303,7 @@ class CompletionFit:
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
                 dx_b = self.percepLoss.fused(xy, nk, self.lp_w, self.patch_loss_buf, normalize=True)
+        cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
         dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, x0_ready=True)       # train.py:238-239
         if dx_b is not None:
             main.wait_stream(self._s_lp)

@@ -138,6 +138,7 @@ class HipTrunk:
                 nxt = self.layers[j + 1]["kind"] if j + 1 < len(self.layers) else None
                 L["tap_ok"] = nxt in (None, "pool")
         self._buf, self._gen = {}, 0
+        self.final_next_pack = None
         self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
 
     def _pb_below(self, j):
@@ -222,7 +223,8 @@ class HipTrunk:
         y, c, H, W = self._geom[j]
         cur = gbuf(c, H, W)
         if self.layers[j]["kind"] == "conv":
-            ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur)         # dz_j = dL/dtap * [y > 0]
+            ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur,         # dz_j = dL/dtap * [y > 0]
+                              next_pack=self.layers[j]["pb"] if self.prefetch_next else None)
             state = "dz"
         else:
             ops.trunk_grad_in(tap_of[j], None, N, n, c, H, W, cur)
@@ -240,7 +242,9 @@ class HipTrunk:
                 cur, j, H, W, state = dzp, j - 1, Hp, Wp, "dz"
                 continue
             if j == 0:                                               # dz of the image layer -> dL/dimage (fp32, times input scale)
-                ops.conv3x3(cur, N, n, H, W, L["cout"], 16, L["pb"], None, 2, None, None, dimg, 3, scale)
+                # (final_next_pack: what the launch AFTER this pass streams first -- the loop sets it to the MLP's backward pack)
+                ops.conv3x3(cur, N, n, H, W, L["cout"], 16, L["pb"], None, 2, None, None, dimg, 3, scale,
+                            next_pack=self.final_next_pack if self.prefetch_next else None)
                 return dimg
             prev = self.layers[j - 1]
             if prev["kind"] == "conv":

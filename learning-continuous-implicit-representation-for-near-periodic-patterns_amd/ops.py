@@ -453,8 +453,12 @@ def maxpool2_bwd(dy, x, addend, N_total, n_run, H, W, c, dz):
     check(lib().npp_maxpool2_bwd(_p(dy), _p(x), _p(addend), N_total, n_run, H, W, c, _p(dz), _stream()), "npp_maxpool2_bwd")
 
 
-def trunk_grad_in(df, y, N_total, n_run, c, H, W, dz, as_f16=False, accumulate=False):
+def trunk_grad_in(df, y, N_total, n_run, c, H, W, dz, as_f16=False, accumulate=False, next_pack=None):
     _req(df, torch.float32, "df", (n_run, c, H, W))
+    if next_pack is not None:
+        check(lib().npp_trunk_grad_in_pf(_p(df), _p(y), N_total, n_run, c, H, W, _p(dz), int(bool(as_f16)), int(bool(accumulate)),
+                                         _p(next_pack), next_pack.numel() * next_pack.element_size(), _stream()), "npp_trunk_grad_in_pf")
+        return
     check(lib().npp_trunk_grad_in(_p(df), _p(y), N_total, n_run, c, H, W, _p(dz), int(bool(as_f16)), int(bool(accumulate)), _stream()),
           "npp_trunk_grad_in")
 
