@@ -114,6 +114,17 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
   // Everything the prologue needs from memory is requested first (weight ring of the first dgrad, the rgb weights, the cold
   // z fragments of P), so that ONE latency is paid instead of one per dependent section.
+  // the backward pack is cold like the forward one (npp_mlp_fwd.hip, NPP_FWD_PREFETCH_LINES): the workgroups of each XCD
+  // request it whole at entry (the loop also has the preceding trunk launch request it: npp_conv3x3_pf)
+  uint32_t pfv[2];
+  {
+    const int64_t lines = ((int64_t)d.wb_total16 * 16 + 127) / 128;
+    const int64_t per_xcd_threads = (int64_t)((gridDim.x + 7) >> 3) * kThreadsB;
+    int64_t line = (int64_t)(blockIdx.x >> 3) * kThreadsB + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 2; ++q, line += per_xcd_threads)
+      pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)A.wb + line * 128) : 0u;
+  }
   WRing<2> ring;                                        // weight-stream ring, chained across layers
   ring.rsrc = make_wrsrc(A.wb, d.wb_total16);
   auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
     bwd_epilogue<true>(acc, v == B1 ? nullptr : out, &zpre, dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }
+  asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]));
 }
 
 }  // namespace npp
