@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   uint32_t pf_val = 0;
   if (a.pf) {
     const int64_t line = ((int64_t)((blockIdx.x >> 3) + blockIdx.y * ((gridDim.x + 7) >> 3)) * blockDim.x + threadIdx.x) * 128;
-    if (line < a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
+    if (line + 4 <= a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
   }
   const int tile0 = bid * PT;
   const int cot0 = blockIdx.y * CT;
@@ -472,7 +472,7 @@ __global__ void trunk_grad_in_kernel(const float* __restrict__ df, const f16x8* 
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pf) {              // the first data-gradient layer's weight pack -> every XCD's L2 (see conv3x3_kernel)
     const int64_t line = ((int64_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x) * 128;
-    if (line < pf_bytes) { const uint32_t v = *(const volatile uint32_t*)(pf + line); asm volatile("" :: "v"(v)); }
+    if (line + 4 <= pf_bytes) { const uint32_t v = *(const volatile uint32_t*)(pf + line); asm volatile("" :: "v"(v)); }
   }
   const int chunks = C / 8;
   if (t >= npos_range * chunks) return;
