@@ -209,15 +209,22 @@ class CompletionFit:
         """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists."""
         # (want_tuple=False: the loop reads the contiguous crops of last_raw; the reference-shaped views / tiled copies of the
         #  8-tuple would cost two more launches per iteration)
-        _, _, _, _, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False, want_tuple=False)
-        if k == 0:
+        if d["k"] == 0:
             return None
+        # ONE host -> device transfer per iteration: [pixel-row indices (int64) | patch centres (int32)] through one pinned block
+        pix = np.ascontiguousarray(d["pix"], np.int64)
+        cen = self.patch_sampler.centres_i32(d)
+        blob = np.concatenate([pix.view(np.uint8).reshape(-1), cen.view(np.uint8).reshape(-1)])
+        blob_dev = ops.h2d(blob, self.device)
+        pix_dev = blob_dev[:pix.nbytes].view(torch.int64)
+        cen_dev = blob_dev[pix.nbytes:].view(torch.int32).reshape(-1, 2)
+        _, _, _, _, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False, want_tuple=False, cen_dev=cen_dev)
         # coordinates of all rows (N_rand pixel rows, then the fake patches' rows, zero padding) + the pixel rows' colours:
         # one launch (npp_batch_assemble) instead of two index gathers, two concatenations and the colour / mask gathers
         n_pix, P, n_p = d["pix"].shape[0], d["P"], d["cen"].shape[0]
         n = n_pix + n_p * P * P
         bp = ops.pad_rows(n)
-        allc, gt, pm = ops.batch_assemble(self.i_train_dev, ops.h2d(d["pix"], self.device), self.patch_sampler.last_cen_dev, P, bp,
+        allc, gt, pm = ops.batch_assemble(self.i_train_dev, pix_dev, self.patch_sampler.last_cen_dev, P, bp,
                                           self.masked_img, self.pixel_mask)
         return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, source=source, k=k, P=P, n_p=d["n_p"],
                     raw=self.patch_sampler.last_raw, pmask=pm)

@@ -206,15 +206,20 @@ class GridPatchSampler:
         return d
 
     # ---- device half: crops of exactly the patches that are returned (npp_patch_gather) ----------------------------
-    def materialise(self, d, want_coords=True, want_tuple=True):
+    @staticmethod
+    def centres_i32(d):
+        """All patch centres of a draw (fake, then real) as the int32 (row, col) array the gather kernel takes."""
+        return np.rint(d["cen"] if d["real_cen"] is None else np.concatenate([d["cen"], d["real_cen"]], 0)).astype(np.int32)
+
+    def materialise(self, d, want_coords=True, want_tuple=True, cen_dev=None):
         """-> the reference's 8-tuple (sampler.py:297-354) from a draw(); also sets self.last_raw (contiguous crops for
         the fused plumbing kernels).  want_tuple=False: only last_raw, source, k and the weights are produced (entries 0..3 None)."""
         if d["k"] == 0:
             return None, None, None, None, None, None, 0, None
         n, k, P = d["n"], d["k"], d["P"]
         # ONE host -> device transfer of all centres (fake, then real) and ONE gather launch for all crops
-        cen_all = np.rint(d["cen"] if d["real_cen"] is None else np.concatenate([d["cen"], d["real_cen"]], 0)).astype(np.int32)
-        c_dev = ops.h2d(cen_all, self.device)
+        # (cen_dev: the caller uploaded centres_i32(d) itself, together with its other per-iteration indices)
+        c_dev = cen_dev if cen_dev is not None else ops.h2d(self.centres_i32(d), self.device)
         self.last_cen_dev = c_dev[:n]
         rgb_all, m_all = ops.patch_gather(self.img, self.mask, c_dev, P)
         fake, fmask = rgb_all[:n], m_all[:n]
@@ -232,7 +237,7 @@ class GridPatchSampler:
             if want_tuple:
                 real = rgb.reshape(n, k, 3, P, P).permute(0, 1, 3, 4, 2)                     # (n,k,P,P,3)
                 rmask = m.reshape(n, k, 1, P, P).permute(0, 1, 3, 4, 2)
-        weight = None if d["weights"] is None else ops.h2d(d["weights"], self.device)   # random mode: no weights (:228)
+        weight = None if (d["weights"] is None or not want_tuple) else ops.h2d(d["weights"], self.device)   # random mode: none (:228)
         self.last_raw = dict(fake=fake, fmask=fmask, real=raw_real[0], rmask=raw_real[1])
         fake_t = fake[:, None].tile([1, k, 1, 1, 1]) if want_tuple else None
         fmask_t = fmask[:, None].tile([1, k, 1, 1, 1]) if want_tuple else None
