@@ -34,7 +34,8 @@
 
 namespace npp {
 
-constexpr int kConvGuard = 256;       // zero units before / after the position axis (>= W + 3)
+constexpr int kConvGuard = 1024;      // zero units before / after the position axis (>= W + 3): images up to 1021 wide
+                                      // (the loop's patches are <= 160; the proposal ranking scores crops of whole images)
 // k-steps of operand fragments in flight per wave (3 or 9: must divide the 9 taps).  9 = a whole input-channel step ahead.
 // Timed alone in a loop (operands warm in L2) the depth makes no difference; INSIDE the iteration, where a layer's weights
 // were last touched 0.7 ms / 1.5 GB of traffic ago and its input was just written from another XCD, depth 9 is worth

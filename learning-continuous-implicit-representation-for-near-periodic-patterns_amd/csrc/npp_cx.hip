@@ -272,6 +272,58 @@ __global__ __launch_bounds__(256) void cx_rows_fwd_kernel(int N, int hw, float i
   }
 }
 
+// The same row pass for hw > 64 * kCxMaxCols (whole-image crops of the proposal ranking, NPP_proposal/search.py:180-197): the
+// row sums first (per lane over j = lane + 64 q ascending, then the same butterfly -- the summation order of the kernel
+// above), then the columns in chunks of 64 * kCxMaxCols with the chunk's running maxima in registers.
+__global__ __launch_bounds__(256) void cx_rows_fwd_big_kernel(int N, int hw, float inv_h, CxWs w) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int groups = (hw + kCxRows - 1) / kCxRows;
+  const int64_t gid = (int64_t)blockIdx.x * 4 + wave;
+  if (gid >= (int64_t)N * groups) return;
+  const int n = (int)(gid / groups), r0 = (int)(gid - (int64_t)n * groups) * kCxRows;
+  float inv[kCxRows], dmr[kCxRows];
+#pragma unroll
+  for (int rr = 0; rr < kCxRows; ++rr) {
+    inv[rr] = 0.0f; dmr[rr] = 1.0f;
+    if (r0 + rr < hw) {
+      const int64_t row = (int64_t)n * hw + r0 + rr;
+      const float dm = __uint_as_float(w.dmin[row]) + 1e-5f;
+      const float* Dr = w.D + row * hw;
+      float s = 0.0f;
+      for (int j = lane; j < hw; j += 64) s += __expf((1.0f - Dr[j] / dm) * inv_h);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0) w.s[row] = s;
+      inv[rr] = 1.0f / s; dmr[rr] = dm;
+    }
+  }
+  for (int c0 = 0; c0 < hw; c0 += 64 * kCxMaxCols) {
+    float cmaxv[kCxMaxCols];
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) cmaxv[q] = 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < kCxRows; ++rr) {
+      if (r0 + rr >= hw) continue;
+      const int64_t row = (int64_t)n * hw + r0 + rr;
+      const float* Dr = w.D + row * hw;
+      float* cr = w.cx + row * hw;
+#pragma unroll
+      for (int q = 0; q < kCxMaxCols; ++q) {
+        const int j = c0 + lane + 64 * q;
+        if (j < hw) {
+          const float c = __expf((1.0f - Dr[j] / dmr[rr]) * inv_h) * inv[rr];
+          cr[j] = c;
+          cmaxv[q] = fmaxf(cmaxv[q], c);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kCxMaxCols; ++q) {
+      const int j = c0 + lane + 64 * q;
+      if (j < hw) atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(cmaxv[q]));
+    }
+  }
+}
+
 // per sample: cxn = mean_j cmax ; loss += scale * (-log(cxn [* weight] + 1e-5)) [/ N] ; g = dL/dcxn / J
 __global__ void cx_loss_kernel(int N, int hw, const float* __restrict__ weight, float scale, float* __restrict__ loss,
                                CxWs w) {
@@ -597,8 +649,9 @@ extern "C" int64_t npp_cx_workspace_bytes(int N, int C, int hw) {
 extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
                               const float* d_weight, float scale, float* d_loss, float* d_dfx, void* d_workspace,
                               int64_t workspace_bytes, void* stream) {
-  if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f) || hw > 64 * kCxMaxCols) {
-    set_error("npp_cx_fwd_bwd: bad arguments (N=%d C=%d hw=%d; hw <= 2048)", N, C, hw);
+  if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f) ||
+      (int64_t)N * hw * hw > 0x7fffffffLL * 8) {
+    set_error("npp_cx_fwd_bwd: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
     return NPP_ERR_ARG;
   }
   if (workspace_bytes < 4 * cx_ws_floats(N, C, hw)) { set_error("npp_cx_fwd_bwd: workspace too small"); return NPP_ERR_ARG; }
@@ -610,7 +663,8 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
   hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N,
                      C, hw, w);
   const int tiles = (hw + 63) / 64;
-  const bool fast = (hw % 32) == 0;          // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
+  const bool big = hw > 64 * kCxMaxCols;     // whole-image crops: the generic kernels, column-chunked row pass
+  const bool fast = !big && (hw % 32) == 0;  // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
   const int t32 = hw / 32;
   if (fast) {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
@@ -624,7 +678,8 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
   } else {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
     const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
-    hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+    if (big) hipLaunchKernelGGL(cx_rows_fwd_big_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+    else hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
   }
   hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, w);
   if (d_dfx) {

@@ -297,6 +297,23 @@ def test_cx_core_realistic_size(dev):
     assert rel_l2(dx.cpu().numpy(), dxo) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 47, 50), (2, 64, 33, 65)])
+def test_cx_core_whole_image_crop_size(dev, shape):
+    """hw > 2048 positions (the crops the proposal ranking scores, NPP_proposal/search.py:180-197, are whole-image sized):
+    the column-chunked row pass, value and gradient against the oracle."""
+    from npp_amd import ops
+    rng = np.random.RandomState(3)
+    y = np.maximum(rng.randn(*shape), 0).astype(np.float32)
+    x = np.maximum(0.7 * y + 0.7 * rng.randn(*shape), 0).astype(np.float32)
+    assert shape[2] * shape[3] > 2048
+    loss, dx = ops.cx_fwd_bwd(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    lo, dxo = oracle.cx_backward(x, y)
+    assert abs(loss.item() - lo) < 1e-3 * abs(lo)
+    assert rel_l2(dx.cpu().numpy(), dxo) < 1e-2
+    loss2, none = ops.cx_fwd_bwd(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), want_grad=False)
+    assert none is None and loss2.item() == loss.item()
+
+
 def test_lpips_head_golden(dev, golden):
     from npp_amd import ops
     g = golden("g7_lpips.npz")

@@ -187,6 +187,24 @@ def test_full_trunk_vs_torch_fp32(dev, name, P, n, ntot):
     assert rel_l2(dh[:n], dr[:n]) < 8e-2
 
 
+@pytest.mark.parametrize("name,H,W", [("vgg19", 72, 340), ("vgg16", 291, 330)])
+def test_trunk_on_whole_image_sized_inputs(dev, name, H, W):
+    """Inputs wider than the loop's 160-pixel patches (the proposal ranking feeds crops of whole images, the reference's own
+    samples are 291 x 340 ... 520 x 323): features against torch fp32."""
+    from npp_amd.losses import HipTrunk
+    cfg, taps = ((oracle.VGG19_CX_CFG, oracle.VGG19_CX_TAPS) if name == "vgg19" else (oracle.VGG16_LPIPS_CFG, oracle.VGG16_LPIPS_TAPS))
+    rng = np.random.RandomState(6)
+    sd = _state_dict(cfg, rng)
+    hip, ref = HipTrunk(cfg, taps, state_dict=sd, device=dev), _torch_ref(cfg, taps, sd, dev)
+    x = torch.from_numpy(rng.rand(2, 3, H, W).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        got, want = hip(x, 0, (4.3, 4.4, 4.5), (-2.1, -2.0, -1.8)), ref(x * torch.tensor((4.3, 4.4, 4.5), device=dev).view(1, 3, 1, 1)
+                                                                      + torch.tensor((-2.1, -2.0, -1.8), device=dev).view(1, 3, 1, 1))
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert rel_l2(g.cpu().numpy(), w.cpu().numpy()) < 3e-3
+
+
 def test_contextual_loss_hip_trunk_vs_torch_trunk(dev):
     """ContextualLoss(use_vgg=True) end to end (normalisation, trunk, CX core): HIP trunk vs the torch trunk."""
     from npp_amd.losses import ContextualLoss
@@ -211,6 +229,8 @@ def test_trunk_error_paths(dev):
         ops.conv3x3(torch.zeros(16, device=dev), 1, 1, 8, 8, 24, 32, torch.zeros(16, device=dev), None, 0, None, torch.zeros(16, device=dev))
     with pytest.raises(NppError):
         ops.trunk_alloc(0, 16, 8, 8, dev)
+    with pytest.raises(NppError, match="W <= 1021"):                   # the guard band of the flat layout bounds the width
+        ops.trunk_image_in(torch.zeros(1, 3, 4, 1022, device=dev), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), ops.trunk_alloc(1, 16, 4, 1021, dev))
 
 
 def test_explicit_loop_matches_autograd_loop(dev):
@@ -329,7 +349,10 @@ def test_fused_patch_in_equals_compose_then_image_in(dev, comp, n_p, k, P):
     acc = torch.full((1,), 5.0, device=dev)
     ops.trunk_patch_in(pred, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, b, xy, acc)
     assert torch.equal(xy, xy_ref) and float(acc) == 0.0
-    G = 256                                                            # guard units at both ends are never written
+    from npp_amd._lib import lib
+    npos = N * (P + 2) * (P + 2)
+    G = (int(lib().npp_trunk_nposp(N, P, P)) - (npos + 511) // 512 * 512) // 2      # guard units at both ends are never written
+    assert G >= P + 3
     va, vb = a.view(torch.int16).reshape(2, -1, 8), b.view(torch.int16).reshape(2, -1, 8)
     assert torch.equal(va[:, G:-G], vb[:, G:-G])
     # without the optional outputs
