@@ -250,7 +250,9 @@ int npp_patch_compose_bwd(const float* d_dx_a, const float* d_dx_b, const float*
 /* Replaces contextual_loss(x, y, band_width, weight, 'cosine') and its backward w.r.t. x
  * (externel_lib/contextual_loss/functional.py:9-63,127-163) on feature tensors (N,C,h*w) fp32
  * NCHW (C a multiple of 32).  d_loss[0] += scale * loss ; d_dfx (N,C,hw) = scale * dL/dx or
- * NULL for forward only.  d_weight: per-sample weights (functional.py:55-57) or NULL. */
+ * NULL for forward only.  d_weight: per-sample weights (functional.py:55-57) or NULL.  Any hw: the loop's
+ * patches give hw <= 1600; the whole-image crops of the proposal ranking (NPP_proposal/search.py:180-197)
+ * go through a column-chunked row pass (workspace = 2 N hw^2 floats + O(N hw)). */
 int64_t npp_cx_workspace_bytes(int N, int C, int hw);
 int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
                    const float* d_weight, float scale, float* d_loss, float* d_dfx,
@@ -282,7 +284,8 @@ int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
  * reference's trunks in), gradient tensors and gradient packs are bf16; accumulation is fp32.  Buffers must be
  * ZERO-INITIALISED by the caller once (kernels rewrite only the position range they compute and
  * keep borders zero).  N_total fixes a buffer's geometry; n_run <= N_total restricts a backward
- * launch to the leading images (the ones that need a gradient). */
+ * launch to the leading images (the ones that need a gradient).  Limits: W <= 1021 (the guard band of
+ * the flat layout), 512 * npp_trunk_nposp * 16 bytes < 2 GiB per tensor; NPP_ERR_ARG beyond them. */
 int64_t npp_trunk_nposp(int N, int H, int W);                /* 16-byte units per channel chunk */
 int64_t npp_trunk_act_bytes(int N, int C, int H, int W);     /* bytes of a flat tensor (C padded to 16) */
 

@@ -1,22 +1,39 @@
-"""End-to-end soak of the command lines on a GPU box: train at both widths and the periodicity search on a synthetic image."""
-import os, sys, subprocess, tempfile, numpy as np
+"""End-to-end soak of the command lines on a GPU box, on a non-square synthetic image of the size of the reference's samples
+(300 x 340): train (completion at both widths, remapping, segmentation) and the periodicity search."""
+import os, sys, subprocess, tempfile
+import numpy as np
 sys.path.insert(0, os.getcwd())
 from npp_amd import io as nio, synthetic as syn
+
 tmp = tempfile.mkdtemp()
-H, K = 256, 3
-img, mask = syn.synthetic_image(H)
-a, p, sh = syn.synthetic_periodicity(H, K)
+S, K, H, W = 384, 3, 300, 340
+img, mask = syn.synthetic_image(S)
+img, mask = img[:H, :W], mask[:H, :W]
+a, p, sh = syn.synthetic_periodicity(S, K)
 d = nio.write_detected_dir(os.path.join(tmp, "detected", "lat"), img, mask, np.ones_like(mask), a, p, sh)
-for W in (256, 512):
-    r = subprocess.run([sys.executable, "-m", "npp_amd.train", "--datadir", d, "--basedir", os.path.join(tmp, "res"), "--expname", f"w{W}", "--p_topk", "3",
-                        "--N_iters", "201", "--i_testset", "200", "--i_print", "100", "--netwidth", str(W), "--random-trunks"], capture_output=True, text=True)
-    print("train W", W, "rc", r.returncode, r.stdout.strip().splitlines()[-2:] if r.stdout else r.stderr[-300:])
+yy, xx = np.mgrid[:H, :W]
+blob = ((yy - 150) ** 2 + (xx - 200) ** 2 < 40 ** 2).astype(np.float64)
+nio.imsave(os.path.join(d, "non_period_mask.png"), np.repeat(blob[..., None], 3, 2))
+nio.imsave(os.path.join(d, "period_mask.png"), np.repeat(1.0 - blob[..., None], 3, 2))
+
+
+def run(what, argv):
+    r = subprocess.run([sys.executable, "-m"] + argv, capture_output=True, text=True)
+    print(what, "rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-2:], r.stderr[-1500:] if r.returncode else "", flush=True)
     assert r.returncode == 0
+
+
+common = ["npp_amd.train", "--datadir", d, "--basedir", os.path.join(tmp, "res"), "--p_topk", "3", "--N_iters", "201", "--i_testset", "200",
+          "--i_print", "100", "--random-trunks"]
+for Wn in (256, 512):
+    run(f"completion W={Wn}", common + ["--expname", f"w{Wn}", "--netwidth", str(Wn)])
+run("remapping", common + ["--task", "remapping"])
+run("segmentation", common + ["--task", "segmentation"])
 out = [f for _, _, fs in os.walk(os.path.join(tmp, "res")) for f in fs]
-print(len(out), "files written;", sorted(set(out))[:6])
+print(len(out), "files written")
 src = os.path.join(tmp, "input", "lat")
 nio.write_detected_dir(src, img, mask, np.ones_like(mask), [[0, 0]], [[1, 1]], [[[1, 0], [0, 1]]])
-r = subprocess.run([sys.executable, "-m", "npp_amd.search", "--datadir", src, "--outdir", os.path.join(tmp, "det2"), "--N_iters", "60", "--search_range", "2", "9", "3",
-                    "--topk_detection", "3", "--random-trunks"], capture_output=True, text=True)
-print("search rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-1], r.stderr[-1500:] if r.returncode else "")
-assert r.returncode == 0
+run("search", ["npp_amd.search", "--datadir", src, "--outdir", os.path.join(tmp, "det2"), "--N_iters", "60", "--search_range", "2", "9", "3",
+               "--topk_detection", "3", "--random-trunks"])
+run("search alexnet", ["npp_amd.search", "--datadir", src, "--outdir", os.path.join(tmp, "det3"), "--N_iters", "60", "--search_range", "2", "9", "3",
+                       "--topk_detection", "3", "--random-trunks", "--gray_only"])
