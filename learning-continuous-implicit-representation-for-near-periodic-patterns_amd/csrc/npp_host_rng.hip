@@ -13,6 +13,8 @@
 
 #include "npp_hip.h"
 
+namespace npp { void set_error(const char* fmt, ...); }   // npp_api.hip
+
 namespace {
 
 struct MT {
@@ -284,15 +286,22 @@ extern "C" int npp_sampler_set_patch(void* h, int patch_size, int n_samples, int
 extern "C" int npp_sampler_draw(void* h, void* rng, int topk, double invalid_ratio, int32_t* source, int32_t* k_out,
                                 int32_t* cen, double* real_cen, float* weights) {
   Sampler* S = (Sampler*)h;
-  if (!S || !rng || topk < 1 || topk > 16 || !source || !k_out || !cen || !real_cen || !weights || S->half < 1) return NPP_ERR_ARG;
+  if (!S || !rng || topk < 1 || topk > 16 || !source || !k_out || !cen || !real_cen || !weights || S->half < 1) {
+    npp::set_error("npp_sampler_draw: bad arguments (topk=%d in [1, 16], patch size set?)", topk);
+    return NPP_ERR_ARG;
+  }
   const int n = S->n_samples, P = 2 * S->half;
   const double prob = npp_rng_uniform(rng, 0.0, 1.0);
   const int src = prob < 0.5 ? 0 : ((0.5 < prob && prob < 0.8) ? 1 : 2);          // sampler.py:326-331
   *source = src;
   const int which = src == 0 ? 1 : 0;                                                // 'val' -> pool_val, else pool_train
-  if (S->pool_n[which] < n) return NPP_ERR_ARG;
+  if (S->pool_n[which] < n) {            // np.random.choice(pool, [n], replace=False) raises ValueError in the reference
+    npp::set_error("npp_sampler_draw: %lld %s centres are at least half a patch (%d) from the border, %d patches asked for "
+                   "(patch larger than the image region it samples?)", (long long)S->pool_n[which], which ? "unknown-region" : "known-region", S->half, n);
+    return NPP_ERR_ARG;
+  }
   int64_t sel[64];
-  if (n > 64) return NPP_ERR_UNSUPPORTED;
+  if (n > 64) { npp::set_error("npp_sampler_draw: %d patches per iteration (<= 64)", n); return NPP_ERR_UNSUPPORTED; }
   int rc = npp_rng_choice_noreplace(rng, S->pool_n[which], n, S->scratch, sel);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) {

@@ -75,9 +75,51 @@ def load_npp_completion(datadir, p_topk=3, invalid_as_unknown=False, normalize_t
                 patch_size=patch_size_from_period(periods[0]), info=info)
 
 
-def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, distances=None):
+def mask2ltrb(mask):
+    """utils/miscs.py:17-20: (left, top, right, bottom) of the non-zero pixels of an (H,W) mask."""
+    ys, xs = np.nonzero(np.asarray(mask).reshape(np.asarray(mask).shape[0], -1))
+    return int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())
+
+
+def draw_lattice(image_u8, base_xy, first_shift_xy, second_shift_xy, thickness=2):
+    """utils/periodicity_visualizer.py:30-66 (GridProgram.gen_ij / draw at the image's own resolution): the two families of
+    lattice lines base + i * first + [j_min, j_max] * second and base + j * second + [i_min, i_max] * first over the index range that
+    covers the canvas corners, drawn `thickness` wide.  Like the reference (which slices off the LAST channel of its RGB input
+    before drawing and puts it back afterwards) the lines set R = G = 255 and leave B alone.  PIL's line rasteriser stands in for
+    cv2.line: a visualisation, not pixel-pinned."""
+    from PIL import Image, ImageDraw
+    img = np.asarray(image_u8, np.uint8)
+    base = np.asarray(base_xy, np.float64)
+    s1, s2 = np.asarray(first_shift_xy, np.float64), np.asarray(second_shift_xy, np.float64)
+    H, W = img.shape[:2]
+    corners = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], np.float64) * np.array([W, H], np.float64) - base
+    ij = np.linalg.inv(np.stack([s1, s2], 1)) @ corners.T
+    i_min, j_min = np.floor(ij.min(1)).astype(int)
+    i_max, j_max = np.ceil(ij.max(1)).astype(int)
+    lines = []
+    for i in range(i_min, i_max):
+        p = base + i * s1
+        lines.append(np.concatenate([p + j_min * s2, p + j_max * s2]))
+    for j in range(j_min, j_max):
+        p = base + j * s2
+        lines.append(np.concatenate([p + i_min * s1, p + i_max * s1]))
+    layer = Image.new("L", (W, H), 0)
+    dr = ImageDraw.Draw(layer)
+    for x0, y0, x1, y1 in np.round(np.asarray(lines)).astype(np.int64).tolist() if lines else []:
+        dr.line([(x0, y0), (x1, y1)], fill=255, width=thickness)
+    hit = np.asarray(layer) > 0
+    out = img.copy()
+    out[..., 0][hit] = 255
+    out[..., 1][hit] = 255
+    return out
+
+
+def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, distances=None, masked_img=None, draw=False):
     """Write what NPP_proposal/search.py:228-280 leaves behind for one image (config.odgt + the four PNGs), e.g. for a
-    synthetic image whose periodicity is known.  img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) with 1 = known / valid."""
+    synthetic image whose periodicity is known.  img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) with 1 = known / valid.
+    masked_img: the input's own masked image (search.py writes it through unchanged; default img * mask).  draw: also the
+    reg_img_<i>.png lattice visualisations of :251-270 and their `fpath_reg_img_<i>` entries (one-element lists: the reference
+    stores 1-tuples)."""
     from PIL import Image
     os.makedirs(outdir, exist_ok=True)
     img = np.asarray(img, np.float64)
@@ -87,13 +129,23 @@ def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, d
              "fpath_gt_img": "gt_img.png"}
     gt8 = np.uint8(img * 255)                                         # search.py:249-252 truncating casts
     Image.fromarray(gt8).save(os.path.join(outdir, names["fpath_gt_img"]))
-    Image.fromarray(np.uint8(img * mask[..., None] * 255)).save(os.path.join(outdir, names["fpath_masked_img"]))
+    masked8 = np.uint8((img * mask[..., None] if masked_img is None else np.asarray(masked_img, np.float64)) * 255)
+    Image.fromarray(masked8).save(os.path.join(outdir, names["fpath_masked_img"]))
     Image.fromarray(np.uint8(valid * 255)).save(os.path.join(outdir, names["fpath_valid_mask"]))
     Image.fromarray(np.uint8(mask * 255)).save(os.path.join(outdir, names["fpath_mask"]))
     odgt = {k: os.path.join(outdir, v) for k, v in names.items()}
     odgt.update(selected_angles=np.asarray(angles, np.float64).tolist(), selected_periods=np.asarray(periods, np.float64).tolist(),
                 selected_shifts=[[list(map(float, s)) for s in sh] for sh in shifts],
                 distances=list(distances) if distances is not None else [0.0] * len(shifts))
+    if draw:
+        left, top = mask2ltrb(valid)[:2]
+        for i, sh in enumerate(shifts):
+            path = os.path.join(outdir, f"reg_img_{i}.png")
+            try:
+                Image.fromarray(draw_lattice(masked8, (left, top), sh[0], sh[1])).save(path)
+            except np.linalg.LinAlgError:                             # collinear displacement pair: nothing to draw
+                continue
+            odgt[f"fpath_reg_img_{i}"] = [path]
     with open(os.path.join(outdir, "config.odgt"), "w") as f:
         json.dump(odgt, f)
         f.write("\n")

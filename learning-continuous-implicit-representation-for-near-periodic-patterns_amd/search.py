@@ -120,8 +120,8 @@ def main(argv=None):
     out = os.path.join(args.outdir, name)
     if os.path.exists(out):
         raise SystemExit("Searching: file exists, exit!!")                           # search.py:42-44
-    rd = lambda f: nio._imread_rgb(os.path.join(args.datadir, f)).astype(np.float64) / 255.0      # noqa: E731
-    rg = lambda f: nio._imread_gray(os.path.join(args.datadir, f)).astype(np.float64) / 255.0     # noqa: E731
+    rd = lambda f: nio._imread_rgb(os.path.join(args.datadir, f))                   # noqa: E731  ([0, 1], loaders/loaders.py:17-25)
+    rg = lambda f: nio._imread_gray(os.path.join(args.datadir, f))                  # noqa: E731
     masked_img, img, mask, valid = rd("masked_img.png"), rd("gt_img.png"), rg("unknown_mask.png"), rg("valid_mask.png")
 
     def load(path):
@@ -135,7 +135,8 @@ def main(argv=None):
         conv1 = AlexConv1(load(args.alexnet), device=args.device, allow_random=args.random_trunks)
     res = search_image(masked_img.astype(np.float32), mask, valid, args, conv1,
                        {"vgg19": load(args.vgg19), "vgg16": load(args.vgg16), "lin": lin})
-    nio.write_detected_dir(out, img, mask, valid, res["angles"], res["periods"], res["shifts"], res["distances"])
+    nio.write_detected_dir(out, img, mask, valid, res["angles"], res["periods"], res["shifts"], res["distances"], masked_img=masked_img,
+                           draw=True)
     with open(os.path.join(out, "config.odgt")) as f:
         odgt = json.loads(f.readline())
     odgt.update(search_range=list(args.search_range), epoch=args.N_iters)           # search.py:236-237
