@@ -108,13 +108,8 @@ def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
 def main(argv=None):
     args = parse(argv)
     from . import io as nio
-    need = {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
-    if not args.gray_only:
-        need["--alexnet"] = args.alexnet
-    lacking = [k for k, v in need.items() if v is None]
-    if lacking and not args.random_trunks:
-        raise SystemExit(f"missing pretrained weights {lacking} (ranking: torchvision VGG19 / VGG16 + lpips v0.1 lin layers; features: "
-                         f"torchvision AlexNet); supply them or pass --random-trunks for a synthetic run")
+    from . import weights
+    weights.resolve(args, ["vgg19", "vgg16"] + ([] if args.gray_only else ["alexnet"]), args.random_trunks)
     torch.cuda.set_device(torch.device(args.device))
     name = os.path.basename(os.path.normpath(args.datadir))
     out = os.path.join(args.outdir, name)
@@ -126,9 +121,7 @@ def main(argv=None):
 
     def load(path):
         return None if path is None else torch.load(path, map_location="cpu")
-    lin = load(args.lpips_lin)
-    if lin is not None:
-        lin = [lin[f"lin{i}.model.1.weight"].reshape(-1).numpy() for i in range(5)]
+    lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
     conv1 = None
     if not args.gray_only:
         from .proposal import AlexConv1

@@ -91,16 +91,9 @@ def main(argv=None):
         raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
-    need = {"--vgg19": args.vgg19} if (remap_task or seg_task) else {"--vgg19": args.vgg19, "--vgg16": args.vgg16, "--lpips_lin": args.lpips_lin}
-    if remap_task:
-        need["--vgg16"] = args.vgg16                         # the style loss runs on VGG16 features (models/style_loss.py:11)
-    if seg_task:
-        need.update({"--alexnet": args.alexnet, "--lpips_alex_lin": args.lpips_alex_lin})
-    lacking = [k for k, v in need.items() if v is None]
-    if lacking and not args.random_trunks:
-        raise SystemExit(f"missing pretrained weights {lacking}: the reference's contextual / LPIPS / style losses use torchvision's "
-                         f"pretrained VGG trunks and the lpips v0.1 lin layers; supply them, or pass --random-trunks to run on "
-                         f"fixed-seed random trunks (synthetic / bench runs)")
+    from . import weights
+    names = ["vgg19"] + ([] if seg_task else ["vgg16"]) + (["alexnet"] if seg_task else [])    # remapping: VGG16 is the style trunk
+    weights.resolve(args, names, args.random_trunks)
     torch.cuda.set_device(torch.device(args.device))
     from . import io as nio
     from ._lib import param_layout
@@ -124,9 +117,7 @@ def main(argv=None):
 
     def load(path):
         return None if path is None else torch.load(path, map_location="cpu")
-    lin = load(args.lpips_lin)
-    if lin is not None:                                                                    # lin0.model.1.weight ... (1,C,1,1)
-        lin = [lin[f"lin{i}.model.1.weight"].reshape(-1).numpy() for i in range(5)]
+    lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
     fit = CompletionFit(d["img"], d["mask"], d["angles"], d["periods"], freqs, params, device=args.device, N_rand=args.N_rand,
                         seed=args.seed, lrate=args.lrate, lrate_decay=args.lrate_decay, valid_mask=d["valid_mask"],
                         shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
@@ -150,9 +141,7 @@ def main(argv=None):
             if seg:                                                                         # NPP_segmentation/train.py:337-406
                 from . import segment
                 alex = segment.AlexFeatures(load(args.alexnet), device=args.device)
-                al = load(args.lpips_alex_lin)
-                lins = ([al[f"lin{j}.model.1.weight"].reshape(-1).numpy() for j in range(5)] if al is not None
-                        else [np.full(c, 1.0 / c, np.float32) for c in (64, 192, 384, 256, 256)])
+                lins = weights.lpips_lin("alex", args.lpips_alex_lin)
                 r = segment.segmentation_eval(pred * d["valid_mask"], d["blur_img"], d["valid_mask"], d["non_period_mask"], alex, lins,
                                               args.l1_thresh, args.lpips_thresh, args.lpips_layers)
                 tdir = os.path.join(outroot, f"testset_{i:06d}")

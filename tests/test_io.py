@@ -126,3 +126,33 @@ def test_blur_map_vs_reference(golden):
     bm, clear = nio.get_blur_map(g["img"], thresh=50)
     np.testing.assert_allclose(bm, g["blur_map"], atol=1e-9)
     assert np.array_equal(clear, g["clear"])
+
+
+def test_pretrained_weight_discovery(tmp_path, monkeypatch):
+    """npp_amd.weights: the torchvision checkpoints are looked up where the reference's `pretrained=True` / README leave them (working
+    directory, torch hub cache); an explicit path wins; the LPIPS lin layers ship with the package and equal the ones the reference's
+    own LPIPS module carried when the g7 golden was generated."""
+    import argparse
+    from npp_amd import weights
+    hub = tmp_path / "th" / "hub" / "checkpoints"
+    hub.mkdir(parents=True)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "th"))
+    monkeypatch.chdir(tmp_path)
+    assert weights.find_checkpoint("vgg19") is None
+    (hub / "vgg19-dcbb9e9d.pth").write_bytes(b"x")
+    (tmp_path / "alexnet-owt-4df8aa71.pth").write_bytes(b"x")
+    assert weights.find_checkpoint("vgg19") == str(hub / "vgg19-dcbb9e9d.pth")
+    assert weights.find_checkpoint("alexnet") == str(tmp_path / "alexnet-owt-4df8aa71.pth")
+    other = tmp_path / "mine.pth"
+    other.write_bytes(b"y")
+    assert weights.find_checkpoint("vgg19", str(other)) == str(other)
+    with pytest.raises(FileNotFoundError):
+        weights.find_checkpoint("vgg16", str(tmp_path / "absent.pth"))
+    args = argparse.Namespace(vgg19=None, vgg16=None)
+    with pytest.raises(SystemExit, match="vgg16"):
+        weights.resolve(args, ["vgg19", "vgg16"], random_ok=False)
+    assert weights.resolve(args, ["vgg19", "vgg16"], random_ok=True) == ["vgg16"] and args.vgg19.endswith("vgg19-dcbb9e9d.pth")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_lpips.npz"))
+    for k, lin in enumerate(weights.lpips_lin("vgg")):
+        assert np.array_equal(lin, g[f"lin{k}"].reshape(-1))
+    assert [v.shape[0] for v in weights.lpips_lin("alex")] == [64, 192, 384, 256, 256]
