@@ -26,7 +26,7 @@ class CompletionFit:
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
-                 vgg16_style_state_dict=None, masked_img=None, width=256):
+                 vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
         masked_img = img * mask is what the loop trains on (train.py:173).
@@ -108,7 +108,7 @@ class CompletionFit:
             self.patch_sampler = GridPatchSampler(
                 img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
                 height=self.H, width=self.W, pool_train=self.i_train, pool_val=self.i_val, selected_shifts=shifts,
-                no_reg_sampling=False, rng=self.rng, fast_rng=self.fast_rng)
+                no_reg_sampling=bool(no_reg_sampling), rng=self.rng, fast_rng=self.fast_rng)
             self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, trunk=trunk, device=self.device).to(self.device)
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
                                     device=self.device, trunk=trunk)

@@ -42,7 +42,22 @@ def parse(argv=None):
     ap.add_argument("--N_rand", type=int, default=8192)
     ap.add_argument("--lrate", type=float, default=5e-4)
     ap.add_argument("--lrate_decay", type=int, default=500)
-    ap.add_argument("--netwidth", type=int, default=256)
+    ap.add_argument("--netwidth", type=int, default=512, help="512: the reference's default (arg_config.py:57); 256: the BASELINE.json configurations")
+    ap.add_argument("--netdepth", type=int, default=8)
+    ap.add_argument("--activation", default="snake")
+    ap.add_argument("--loss_type", default="robust_loss_adaptive")
+    ap.add_argument("--normalize_type", type=int, default=1)
+    # the reference's ablation switches (arg_config.py:78-92), with its store_false / store_true quirks kept
+    ap.add_argument("--no_reg_sampling", action="store_true", help="real patches drawn at random instead of along the lattice (sampler.py:219-228)")
+    ap.add_argument("--use_comp", action="store_false", help="(store_false) pass it to NOT paste the known region into 'val' patches")
+    ap.add_argument("--use_perceptual_loss", action="store_true",
+                    help="toggles the task's default: completion has LPIPS on 'same' iterations ON (store_false there, :84), "
+                         "segmentation / remapping have it OFF (store_true, :190,274)")
+    ap.add_argument("--perceptual_weight", type=float, default=1e-3)
+    ap.add_argument("--use_contextual_loss", action="store_false", help="(store_false) ablation: not built, refused")
+    ap.add_argument("--use_adaptive_perceptual_loss", action="store_false", help="(store_false) ablation: not built, refused")
+    ap.add_argument("--use_patch_weight", action="store_true", help="ablation: not built, refused")
+    ap.add_argument("--no_pix_loss", action="store_true", help="ablation: not built, refused")
     ap.add_argument("--patch_num", type=int, default=2)
     ap.add_argument("--num_real_patch_per_sample", type=int, default=3)
     ap.add_argument("--invalid_ratio", type=float, default=0.3)
@@ -89,6 +104,15 @@ def main(argv=None):
         args.i_testset = {"remapping": 400, "segmentation": 600}.get(args.task, 500)
     if args.netwidth not in (256, 512):
         raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
+    refused = [n for n, bad in (("--netdepth != 8", args.netdepth != 8), ("--activation != snake", args.activation != "snake"),
+                                ("--loss_type != robust_loss_adaptive", args.loss_type != "robust_loss_adaptive"),
+                                ("--normalize_type != 1", args.normalize_type != 1), ("--use_contextual_loss", not args.use_contextual_loss),
+                                ("--use_adaptive_perceptual_loss", not args.use_adaptive_perceptual_loss),
+                                ("--use_patch_weight", args.use_patch_weight), ("--no_pix_loss", args.no_pix_loss)) if bad]
+    if refused:
+        raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (it is the "
+                         f"reference's default configuration: D = 8, snake, adaptive robust pixel loss, contextual loss on, adaptive "
+                         f"LPIPS, unweighted patches); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     from . import weights
@@ -127,7 +151,9 @@ def main(argv=None):
                         task=args.task, clear_mask=d["clear_mask"] if remap else None,
                         masked_img=None if remap else d.get("masked_img"),
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
-                        style_weight=args.style_weight if remap else None, use_perceptual_loss=not (remap or seg), width=args.netwidth)
+                        style_weight=args.style_weight if remap else None,
+                        use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
+                        use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, width=args.netwidth)
     name = os.path.basename(os.path.normpath(args.datadir))
     expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
     outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)

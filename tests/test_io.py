@@ -85,6 +85,35 @@ def test_train_driver_end_to_end(tmp_path):
     assert fit.psnr() > 26.0                               # torch-default init + freshly drawn Fourier frequencies
 
 
+@pytest.mark.gpu
+def test_train_driver_ablation_switches(tmp_path):
+    """The switches of options/arg_config.py:78-92 the loop is built for, in the reference's store_false / store_true senses: random
+    real patches (--no_reg_sampling), no known-region paste (--use_comp), LPIPS off (--use_perceptual_loss on the completion task),
+    at the reference's default width (no --netwidth: 512)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from npp_amd import io as nio, train
+    H, K = 256, 3
+    img, mask = oracle.synthetic_image(H)
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    d = nio.write_detected_dir(str(tmp_path / "detected" / "syn"), img, mask, np.ones_like(mask), a, p, s)
+    fit = train.main(["--datadir", d, "--basedir", str(tmp_path / "results"), "--N_iters", "121", "--i_testset", "120", "--i_print", "60",
+                      "--random-trunks", "--no_reg_sampling", "--use_comp", "--use_perceptual_loss"])
+    assert fit.net.width == 512 and fit.patch_sampler.no_reg_sampling and not fit.use_comp and not fit.use_perceptual_loss
+    assert fit.skipped < 60 and fit.psnr() > 24.0 and np.isfinite(float(fit.last_patch_loss[0]))
+
+
+def test_train_driver_refuses_unbuilt_ablations(tmp_path):
+    from npp_amd import train
+    for flags in (["--no_pix_loss"], ["--use_patch_weight"], ["--use_contextual_loss"], ["--use_adaptive_perceptual_loss"],
+                  ["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"]):
+        with pytest.raises(SystemExit, match="ablation"):
+            train.main(["--datadir", str(tmp_path), "--random-trunks"] + flags)
+    a = train.parse(["--datadir", "x"])
+    assert a.netwidth == 512 and a.use_comp is True and a.use_perceptual_loss is False and a.no_reg_sampling is False
+
+
 def test_train_driver_requires_trunk_weights(tmp_path):
     """Without pretrained VGG / LPIPS weights the driver refuses to run unless --random-trunks is given."""
     from npp_amd import train
