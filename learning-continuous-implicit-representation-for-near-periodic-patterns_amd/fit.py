@@ -26,9 +26,12 @@ class CompletionFit:
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
-                 vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False):
+                 vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False, use_patch_weight=False,
+                 no_pix_loss=False, use_contextual_loss=True):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
+        Ablation switches of arg_config.py:78-92: no_reg_sampling (random real patches), use_patch_weight (1/d lattice weights:
+        weighted-sum forms of the contextual and LPIPS terms, train.py:224-250), no_pix_loss (:197), use_contextual_loss.
         masked_img = img * mask is what the loop trains on (train.py:173).
         rng_mode: "reference" (default) keeps the reference's NumPy random stream call by call
         (np.random.uniform, np.random.choice(replace=False) for the patch centres and the N_rand pixel rows:
@@ -74,6 +77,8 @@ class CompletionFit:
             self.i_val = np.stack(np.nonzero(mask[..., 0] * valid[..., 0]), 1).astype(np.int32)
             pixel_mask = mask
             train_img = img
+        self.pix_w = 0.0 if no_pix_loss else 1.0                      # train.py:197-198 `loss = 0`: the pixel term weighs nothing
+        self.use_patch_weight, self.use_contextual_loss = bool(use_patch_weight), bool(use_contextual_loss)
         self.img = torch.from_numpy(img).to(self.device)
         self.mask = torch.from_numpy(mask).to(self.device)
         self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
@@ -226,8 +231,9 @@ class CompletionFit:
         bp = ops.pad_rows(n)
         allc, gt, pm = ops.batch_assemble(self.i_train_dev, pix_dev, self.patch_sampler.last_cen_dev, P, bp,
                                           self.masked_img, self.pixel_mask)
+        w_dev = ops.h2d(np.ascontiguousarray(d["weights"], np.float32), self.device) if (self.use_patch_weight and d["weights"] is not None) else None
         return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, source=source, k=k, P=P, n_p=d["n_p"],
-                    raw=self.patch_sampler.last_raw, pmask=pm)
+                    raw=self.patch_sampler.last_raw, pmask=pm, weight=w_dev)
 
     def sample_batch(self):
         """Host-side sampling of one iteration + its device half.  None when no valid real patch exists."""
@@ -301,17 +307,23 @@ class CompletionFit:
         # the comparator of tests/test_gpu_parity.py and for A/B timing)
         fold = self.fold_launches
         if not fold:
-            net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"))
+            net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
                            cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf,
-                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask")) if fold else None)
+                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if fold else None)
         dx_b = None
+        # use_patch_weight (train.py:224-250): contextual term sum_i -log(cx_i w_i + 1e-5) (the core's weighted form), LPIPS term
+        # sum_i d_i w_i -- on 'same' iterations the weights are all 1 (sampler.py:338), i.e. nk times the mean
+        weight = b.get("weight")
         if with_lp:                                                                                 # train.py:241-250
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
-                dx_b = self.percepLoss.fused(xy, nk, self.lp_w, self.patch_loss_buf, normalize=True)
+                dx_b = self.percepLoss.fused(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf, normalize=True)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
-        dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, x0_ready=True)       # train.py:238-239
+        if self.use_contextual_loss:
+            dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, weight=weight, x0_ready=True)   # train.py:238-239
+        else:                                                                                       # ablation: no contextual term
+            dx_a = torch.zeros((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
         if dx_b is not None:
             main.wait_stream(self._s_lp)
         if self.style is not None:                                                                  # NPP_remapping/train.py:253-261
@@ -343,7 +355,7 @@ class CompletionFit:
         pred = net.forward_train(b["coords"])
         ws["dpred"][n:].zero_()
         ws["n_rows"] = n
-        net.pixel_loss(bp, n_pix, b["gt"])
+        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
         pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
         pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
         raw = b["raw"]                                    # contiguous crops: real (n_p k,3,P,P), rmask (n_p k,1,P,P), fake / fmask (n_p,..)
@@ -351,9 +363,12 @@ class CompletionFit:
         fk = raw["fake"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 3, P, P)             # train.py:219-226 tiling
         fm = raw["fmask"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 1, P, P)
         x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
-        loss_patch = self.contextualLoss(x_in, real_p * rm, None) * self.cx_w
+        nk_ = n_p * k
+        weight = b.get("weight")
+        loss_patch = self.contextualLoss(x_in, real_p * rm, weight) * self.cx_w if self.use_contextual_loss else pp_leaf.sum() * 0.0
         if source == "same" and self.use_perceptual_loss:
-            loss_patch = loss_patch + self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True) * self.lp_w
+            lp = self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True)                 # mean over the nk samples
+            loss_patch = loss_patch + lp * (nk_ if weight is not None else 1) * self.lp_w
         loss_patch.backward()
         ws["dpred"][n_pix:n].copy_(pp_leaf.grad)
         self.last_patch_loss = loss_patch.detach().reshape(1)

@@ -54,10 +54,10 @@ def parse(argv=None):
                     help="toggles the task's default: completion has LPIPS on 'same' iterations ON (store_false there, :84), "
                          "segmentation / remapping have it OFF (store_true, :190,274)")
     ap.add_argument("--perceptual_weight", type=float, default=1e-3)
-    ap.add_argument("--use_contextual_loss", action="store_false", help="(store_false) ablation: not built, refused")
+    ap.add_argument("--use_contextual_loss", action="store_false", help="(store_false) pass it to drop the contextual term")
     ap.add_argument("--use_adaptive_perceptual_loss", action="store_false", help="(store_false) ablation: not built, refused")
-    ap.add_argument("--use_patch_weight", action="store_true", help="ablation: not built, refused")
-    ap.add_argument("--no_pix_loss", action="store_true", help="ablation: not built, refused")
+    ap.add_argument("--use_patch_weight", action="store_true", help="1/d lattice weights on the patch terms (train.py:224-250)")
+    ap.add_argument("--no_pix_loss", action="store_true", help="no pixel loss (train.py:197-198)")
     ap.add_argument("--patch_num", type=int, default=2)
     ap.add_argument("--num_real_patch_per_sample", type=int, default=3)
     ap.add_argument("--invalid_ratio", type=float, default=0.3)
@@ -106,13 +106,11 @@ def main(argv=None):
         raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
     refused = [n for n, bad in (("--netdepth != 8", args.netdepth != 8), ("--activation != snake", args.activation != "snake"),
                                 ("--loss_type != robust_loss_adaptive", args.loss_type != "robust_loss_adaptive"),
-                                ("--normalize_type != 1", args.normalize_type != 1), ("--use_contextual_loss", not args.use_contextual_loss),
-                                ("--use_adaptive_perceptual_loss", not args.use_adaptive_perceptual_loss),
-                                ("--use_patch_weight", args.use_patch_weight), ("--no_pix_loss", args.no_pix_loss)) if bad]
+                                ("--normalize_type != 1", args.normalize_type != 1),
+                                ("--use_adaptive_perceptual_loss", not args.use_adaptive_perceptual_loss)) if bad]
     if refused:
         raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (it is the "
-                         f"reference's default configuration: D = 8, snake, adaptive robust pixel loss, contextual loss on, adaptive "
-                         f"LPIPS, unweighted patches); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
+                         f"reference's default configuration: D = 8, snake, adaptive robust pixel loss, adaptive LPIPS); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     from . import weights
@@ -153,7 +151,8 @@ def main(argv=None):
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
                         style_weight=args.style_weight if remap else None,
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
-                        use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, width=args.netwidth)
+                        use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
+                        no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth)
     name = os.path.basename(os.path.normpath(args.datadir))
     expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
     outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)

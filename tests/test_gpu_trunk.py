@@ -233,13 +233,16 @@ def test_trunk_error_paths(dev):
         ops.trunk_image_in(torch.zeros(1, 3, 4, 1022, device=dev), (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), ops.trunk_alloc(1, 16, 4, 1021, dev))
 
 
-def test_explicit_loop_matches_autograd_loop(dev):
+@pytest.mark.parametrize("switches", [{}, dict(use_patch_weight=True), dict(no_pix_loss=True, use_comp=False), dict(no_reg_sampling=True),
+                                      dict(use_contextual_loss=False)])
+def test_explicit_loop_matches_autograd_loop(dev, switches):
     """CompletionFit.step_from (explicit launches: npp_patch_compose_* + HipTrunk._forward/_backward + CX / LPIPS
     kernels) against step_from_autograd (train.py:200-251 written line by line over the torch.autograd wrappers), on
     the same batches from the same state, for every patch source: the patch loss and the parameters after the step
     agree to float round-off; dL/dpred of the patch rows to 6e-3 -- the explicit path folds the 1e-3 loss weight into
     the CX / LPIPS kernels, i.e. BEFORE the tap gradient is rounded to bf16 for the trunk's data-gradient, the autograd
-    path multiplies after it (one bf16 ulp = 2^-8 per element either way)."""
+    path multiplies after it (one bf16 ulp = 2^-8 per element either way).  `switches`: the reference's ablation flags
+    (options/arg_config.py:78-92; train.py:197-250) through both forms."""
     from npp_amd.fit import CompletionFit
     H, K = 256, 3
     img, mask = oracle.synthetic_image(H)
@@ -247,7 +250,7 @@ def test_explicit_loop_matches_autograd_loop(dev):
 
     def make():
         return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev,
-                             N_rand=2048, ksplit=4, seed=3, shifts=shifts)
+                             N_rand=2048, ksplit=4, seed=3, shifts=shifts, **switches)
     src_fit = make()
     by_source = {}
     for _ in range(60):
@@ -263,9 +266,15 @@ def test_explicit_loop_matches_autograd_loop(dev):
         b.step_from_autograd(batch)
         n_pix, n, bp = batch["n_pix"], batch["n"], batch["bp"]
         da, db = a.net.workspace(bp)["dpred"].cpu().numpy(), b.net.workspace(bp)["dpred"].cpu().numpy()
-        assert np.abs(db[n_pix:n]).max() > 0
-        assert rel_l2(da[n_pix:n], db[n_pix:n]) < 6e-3, source
+        if switches.get("use_contextual_loss", True) or source == "same":
+            assert np.abs(db[n_pix:n]).max() > 0
+            assert rel_l2(da[n_pix:n], db[n_pix:n]) < 6e-3, source
+        else:                                                       # no contextual term and no LPIPS on this source: no patch gradient
+            assert np.abs(da[n_pix:n]).max() == 0 and np.abs(db[n_pix:n]).max() == 0
         np.testing.assert_array_equal(da[:n_pix], db[:n_pix])
+        assert (np.abs(da[:n_pix]).max() == 0) == bool(switches.get("no_pix_loss", False))
+        if switches.get("use_patch_weight") and source != "same":
+            assert batch["weight"] is not None and abs(float(batch["weight"].sum()) - batch["n_p"]) < 1e-4     # 1/d weights, normalised per fake patch
         assert abs(float(a.last_patch_loss[0]) - float(b.last_patch_loss[0])) < 1e-5 * abs(float(b.last_patch_loss[0])) + 1e-9
         assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4   # Adam normalises: tiny-gradient entries move by +-lr
         if source == "same":

@@ -99,15 +99,15 @@ def test_train_driver_ablation_switches(tmp_path):
     a, p, s = oracle.synthetic_periodicity(H, K)
     d = nio.write_detected_dir(str(tmp_path / "detected" / "syn"), img, mask, np.ones_like(mask), a, p, s)
     fit = train.main(["--datadir", d, "--basedir", str(tmp_path / "results"), "--N_iters", "121", "--i_testset", "120", "--i_print", "60",
-                      "--random-trunks", "--no_reg_sampling", "--use_comp", "--use_perceptual_loss"])
+                      "--random-trunks", "--no_reg_sampling", "--use_comp", "--use_perceptual_loss", "--use_patch_weight"])
     assert fit.net.width == 512 and fit.patch_sampler.no_reg_sampling and not fit.use_comp and not fit.use_perceptual_loss
     assert fit.skipped < 60 and fit.psnr() > 24.0 and np.isfinite(float(fit.last_patch_loss[0]))
 
 
 def test_train_driver_refuses_unbuilt_ablations(tmp_path):
     from npp_amd import train
-    for flags in (["--no_pix_loss"], ["--use_patch_weight"], ["--use_contextual_loss"], ["--use_adaptive_perceptual_loss"],
-                  ["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"]):
+    for flags in (["--use_adaptive_perceptual_loss"], ["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"],
+                  ["--loss_type", "mse"]):
         with pytest.raises(SystemExit, match="ablation"):
             train.main(["--datadir", str(tmp_path), "--random-trunks"] + flags)
     a = train.parse(["--datadir", "x"])
