@@ -130,6 +130,16 @@ def main(argv=None):
         d["mask"], d["masked_img"] = d["period_mask"], d["blur_img"]
     else:
         d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
+    name = os.path.basename(os.path.normpath(args.datadir))
+    expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
+    outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)
+    if os.path.exists(outroot):                                                             # train.py:42-44: results are never overwritten
+        print(f"{args.task.capitalize()}: file exists, exit!!")
+        return None
+    os.makedirs(outroot, exist_ok=True)
+    print("Loaded NPP", d["img"].shape, args.datadir)
+    print("selected_angles: " + str(np.asarray(d["angles"]).tolist()))
+    print("selected_periods: " + str(np.asarray(d["periods"]).tolist()))
     K = len(d["angles"])
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
@@ -153,9 +163,6 @@ def main(argv=None):
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
                         use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
                         no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth)
-    name = os.path.basename(os.path.normpath(args.datadir))
-    expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
-    outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)
     t0 = time.time()
     for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
         fit.step_full()

@@ -83,6 +83,8 @@ def test_train_driver_end_to_end(tmp_path):
     assert sorted(os.listdir(out)) == ["testset_000060", "testset_000120"]
     assert len(os.listdir(out / "testset_000120")) == 6
     assert fit.psnr() > 26.0                               # torch-default init + freshly drawn Fourier frequencies
+    again = train.main(["--datadir", d, "--basedir", str(tmp_path / "results"), "--p_topk", "3", "--N_iters", "121", "--random-trunks"])
+    assert again is None                                   # train.py:42-44: an existing result directory is never overwritten
 
 
 @pytest.mark.gpu
