@@ -211,21 +211,36 @@ class ProposalRanker:
             freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()
             torch.random.set_rng_state(g)
         self.freqs = np.asarray(freqs, np.float32)
+        self._draws = None
         self.percep = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device)
         self.cx = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device)
+
+    def _pixel_draws(self):
+        """(N_iters, n_rand) int64 on the device: the pixel rows of every iteration.  search.py:92-93 reseeds NumPy with 0 before EVERY
+        candidate, so all candidates of an image walk the same index sequence: drawn once (np.random.choice(n_train, [n_rand],
+        replace=False) per iteration -- a full permutation of the known pixels each, 1.3 ms of host time per iteration on a
+        676 x 494 image, three times the device time of the iteration) and uploaded once, instead of per candidate and iteration."""
+        if self._draws is None:
+            n_train = self.i_train.shape[0]
+            n_rand = min(self.N_rand, n_train)
+            if self.rng_mode == "fast":
+                g = np.random.default_rng(0)
+                sel = [g.choice(n_train, n_rand, replace=False) for _ in range(self.N_iters)]
+            else:
+                from .host_rng import NativeRandomState                                              # np.random.RandomState(0)'s stream, GIL-free
+                g = NativeRandomState(0)
+                sel = [g.choice(n_train, size=[n_rand], replace=False) for _ in range(self.N_iters)]
+            self._draws = torch.from_numpy(np.ascontiguousarray(np.stack(sel), np.int64)).to(self.device)   # once per image: plain copy
+        return self._draws
 
     def fit_candidate(self, angles_deg, periods, params=None):
         net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
                           params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
                           device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
         x_pos_all, x_per_all = net.embed(self.i_train_dev)                                           # search.py:104-108 tables
-        rng = np.random.RandomState(0)                                                               # np.random.seed(0), :93
-        fast = np.random.default_rng(0) if self.rng_mode == "fast" else None
-        n_train = self.i_train.shape[0]
-        n_rand = min(self.N_rand, n_train)
-        for _ in range(self.N_iters):
-            sel = fast.choice(n_train, n_rand, replace=False) if fast is not None else rng.choice(n_train, size=[n_rand], replace=False)
-            idx = ops.h2d(sel.astype(np.int64), self.device)
+        draws = self._pixel_draws()
+        for it in range(self.N_iters):
+            idx = draws[it]
             c = self.i_train_dev[idx]
             gt = self.img[c[:, 0].long(), c[:, 1].long()].contiguous()
             net.train_step(x_pos_all[idx].contiguous(), x_per_all[idx].contiguous(), gt)

@@ -1,0 +1,82 @@
+"""`python -m npp_amd.run --task completion|segmentation|remapping`: the reference's run_completion.sh / run_segmentation.sh /
+run_remapping.sh -- for every directory under data/<task>/input: the periodicity search (NPP_proposal/search.py ->
+data/<task>/detected/<name>), then the task's fit (NPP_<task>/train.py -> results/<task>_top<k>/<name>) -- as ONE process per GPU that
+keeps the library, the packed loss trunks' code and the CUDA context across images instead of two interpreter starts per image.
+Launched under torch.distributed.run (one rank per GPU; or `--gpus N`, which starts the ranks itself) the image directories are
+sharded over the ranks (parallel.shard_units): independent images, no data-path collective, no process group.
+An image whose search / fit output already exists is skipped like in the reference (search.py:42-44, train.py:42-44); an image that
+fails is reported and the loop goes on (the shell loop's behaviour); exit status 1 if any failed."""
+import argparse
+import glob
+import os
+import shlex
+import sys
+import time
+import traceback
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="completion", choices=["completion", "segmentation", "remapping"])
+    ap.add_argument("--input_path", default=None, help="default data/<task>/input")
+    ap.add_argument("--detected_path", default=None, help="default data/<task>/detected")
+    ap.add_argument("--basedir", default="./results")
+    ap.add_argument("--p_topk", type=int, default=3)
+    ap.add_argument("--random-trunks", action="store_true", help="passed to both stages (synthetic runs)")
+    ap.add_argument("--search-args", default="", help="extra flags for npp_amd.search, one quoted string")
+    ap.add_argument("--train-args", default="", help="extra flags for npp_amd.train, one quoted string")
+    ap.add_argument("--gpus", type=int, default=None, help="start this many ranks (one per GPU) unless already under torch.distributed.run")
+    return ap.parse_args(argv)
+
+
+def my_share(items):
+    """The image directories of this rank (RANK / WORLD_SIZE of torch.distributed.run; everything when not launched by it)."""
+    from .parallel import shard_units
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    return [items[i] for i in shard_units(len(items), rank, world)], rank, world
+
+
+def main(argv=None, search_main=None, train_main=None):
+    args = parse(argv)
+    if args.gpus and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from .parallel import launch_ranks                      # fresh child processes: this one has not touched the GPU
+        me = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "run_ranks.py")
+        return launch_ranks(me, args.gpus, list(sys.argv[1:] if argv is None else argv))
+    inp = args.input_path or os.path.join("data", args.task, "input")
+    det = args.detected_path or os.path.join("data", args.task, "detected")
+    dirs = sorted(p for p in glob.glob(os.path.join(inp, "*")) if os.path.isdir(p))
+    mine, rank, world = my_share(dirs)
+    device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    if search_main is None:
+        from .search import main as search_main
+    if train_main is None:
+        from .train import main as train_main
+    common = ["--device", device] + (["--random-trunks"] if args.random_trunks else [])
+    failed, t_all = [], time.time()
+    for src in mine:
+        name = os.path.basename(os.path.normpath(src))
+        t0 = time.time()
+        try:
+            try:
+                search_main(["--datadir", src, "--outdir", det] + common + shlex.split(args.search_args))
+            except SystemExit as e:                                # "Searching: file exists, exit!!": the detected directory is reused
+                if "exists" not in str(e):
+                    raise
+                print(e)
+            t1 = time.time()
+            fit = train_main(["--datadir", os.path.join(det, name), "--basedir", args.basedir, "--p_topk", str(args.p_topk)] + common
+                             + (["--task", args.task] if args.task != "completion" else []) + shlex.split(args.train_args))
+            if fit is not None and hasattr(fit, "close"):
+                fit.close()
+            print(f"[run rank {rank}/{world}] {args.task}/{name}: search {t1 - t0:.1f} s, fit {time.time() - t1:.1f} s", flush=True)
+        except (Exception, SystemExit) as e:                       # noqa: B014  -- report, keep going like the shell loop
+            traceback.print_exc()
+            print(f"[run rank {rank}/{world}] {args.task}/{name}: FAILED ({type(e).__name__}: {e})", flush=True)
+            failed.append(name)
+    print(f"[run rank {rank}/{world}] {len(mine) - len(failed)} of {len(mine)} images done in {time.time() - t_all:.1f} s"
+          + (f"; failed: {failed}" if failed else ""), flush=True)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -186,6 +186,7 @@ def main(argv=None):
         if i % args.i_print == 0:
             print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
                   f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
+    fit.close()                                             # the sampler's producer thread
     return fit
 
 

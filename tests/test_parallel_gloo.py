@@ -82,3 +82,41 @@ def test_shard_units_balanced():
             parts = [shard_units(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_directory_driver_shards_images_over_ranks(tmp_path, monkeypatch):
+    """npp_amd.run (the reference's run_<task>.sh loops): every image directory goes to exactly one rank, search then fit per image with
+    the rank's device, an existing detected directory is reused, a failing image does not stop the others."""
+    from npp_amd import run
+    for n in ("a", "b", "c", "d", "e"):
+        (tmp_path / "in" / n).mkdir(parents=True)
+    (tmp_path / "in" / "not_a_dir.txt").write_text("x")
+    seen = {}
+    for rank in range(2):
+        calls = []
+
+        def search_main(argv, calls=calls):
+            name = os.path.basename(argv[argv.index("--datadir") + 1])
+            if name == "b":
+                raise SystemExit("Searching: file exists, exit!!")
+            calls.append(("search", name, argv[argv.index("--device") + 1], "--random-trunks" in argv, "--N_iters" in argv))
+
+        def train_main(argv, calls=calls):
+            name = os.path.basename(argv[argv.index("--datadir") + 1])
+            if name == "c":
+                raise RuntimeError("boom")
+            calls.append(("train", name, argv[argv.index("--device") + 1], argv[argv.index("--task") + 1] if "--task" in argv else "completion",
+                          argv[argv.index("--netwidth") + 1]))
+
+        monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("LOCAL_RANK", str(rank))
+        rc = run.main(["--task", "remapping", "--input_path", str(tmp_path / "in"), "--detected_path", str(tmp_path / "det"), "--random-trunks",
+                       "--search-args", "--N_iters 20", "--train-args", "--netwidth 256"], search_main, train_main)
+        seen[rank] = (rc, calls)
+    names = [c[1] for r in seen for c in seen[r][1] if c[0] == "train"]
+    assert sorted(names) == ["a", "b", "d", "e"]                        # c failed in its fit; b's search was skipped, its fit ran
+    assert sorted(c[1] for r in seen for c in seen[r][1] if c[0] == "search") == ["a", "c", "d", "e"]
+    assert {seen[0][0], seen[1][0]} == {0, 1}                           # the rank that had image c reports failure
+    for r in seen:
+        assert all(c[2] == f"cuda:{r}" for c in seen[r][1])
+        assert all(c[3:] == (True, True) for c in seen[r][1] if c[0] == "search")
+        assert all(c[3:] == ("remapping", "256") for c in seen[r][1] if c[0] == "train")
