@@ -177,7 +177,14 @@ def main(argv=None):
                 r = segment.segmentation_eval(pred * d["valid_mask"], d["blur_img"], d["valid_mask"], d["non_period_mask"], alex, lins,
                                               args.l1_thresh, args.lpips_thresh, args.lpips_layers)
                 tdir = os.path.join(outroot, f"testset_{i:06d}")
-                nio.imsave(os.path.join(tdir, "l1_diff_img.png"), np.repeat(r["l1_img"][..., None], 3, 2))
+                import matplotlib
+                matplotlib.use("Agg")
+                import matplotlib.pyplot as plt                                             # single-channel plt.imsave: viridis, autoscaled (:356-389)
+                plt.imsave(os.path.join(tdir, "l1_diff_img.png"), r["l1_img"])
+                plt.imsave(os.path.join(tdir, "l1_img_mask.png"), ~r["l1_mask"])
+                for j, m in enumerate(r["lpips_maps"]):
+                    plt.imsave(os.path.join(tdir, f"lpips_diff_img_{j}.png"), m)
+                    plt.imsave(os.path.join(tdir, f"lpips_img_mask_{j}.png"), ~(m < args.lpips_thresh))
                 nio.imsave(os.path.join(tdir, "non_period_mask_final.png"), np.repeat(r["non_period_mask_final"].astype(np.float64), 3, 2))
                 m = r["non_period_mask_final"].astype(np.float64)
                 vis = d["img"] * 0.7 + 0.3 * (np.array([0.0, 1.0, 0.0]) * m + d["img"] * (1 - m))    # :396-404
