@@ -187,3 +187,21 @@ def test_pretrained_weight_discovery(tmp_path, monkeypatch):
     for k, lin in enumerate(weights.lpips_lin("vgg")):
         assert np.array_equal(lin, g[f"lin{k}"].reshape(-1))
     assert [v.shape[0] for v in weights.lpips_lin("alex")] == [64, 192, 384, 256, 256]
+
+
+def test_lattice_drawing_and_ltrb():
+    """io.draw_lattice (utils/periodicity_visualizer.py:30-66): both line families over the whole canvas, R = G = 255 with B untouched
+    (the reference draws on all channels but the last); io.mask2ltrb (utils/miscs.py:17-20)."""
+    from npp_amd import io as nio
+    m = np.zeros((40, 60))
+    m[5:30, 10:50] = 1
+    assert nio.mask2ltrb(m) == (10, 5, 49, 29)
+    img = np.full((64, 96, 3), 7, np.uint8)
+    out = nio.draw_lattice(img, (3, 2), (16.0, 0.0), (0.0, 12.0), thickness=1)
+    hit = (out[..., 0] == 255) & (out[..., 1] == 255)
+    assert (out[..., 2] == 7).all() and (out[~hit] == 7).all()
+    assert hit[:, 3].all() and hit[:, 19].all() and hit[:, 83].all() and hit[:, 10].sum() == len(range(2, 64, 12))   # column 10: crossings with the rows only
+    assert hit[2, :].all() and hit[14, :].all() and hit[62, :].all()
+    assert hit.sum() == 6 * 64 + 6 * 96 - 36                           # 6 vertical + 6 horizontal lines, 36 crossings counted once
+    with pytest.raises(np.linalg.LinAlgError):
+        nio.draw_lattice(img, (0, 0), (4.0, 2.0), (8.0, 4.0))          # collinear shifts span no lattice
