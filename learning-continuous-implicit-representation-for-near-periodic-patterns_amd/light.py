@@ -246,6 +246,34 @@ class ProposalRanker:
             net.train_step(x_pos_all[idx].contiguous(), x_per_all[idx].contiguous(), gt)
         return net
 
+    def fit_candidates(self, cands, n_streams=8):
+        """fit_candidate() for several candidates at once: the fits are independent and each iteration is ~20 small dependent
+        launches (0.38 ms per iteration, the chip idle between them), so the candidates advance together, iteration by iteration,
+        each on one of n_streams side streams -- the launch gaps of one fit are filled by the others.  Same arithmetic per
+        candidate as the serial form; the pixel rows and their colours (identical for every candidate, see _pixel_draws) are
+        gathered once."""
+        main = torch.cuda.current_stream(self.device)
+        draws = self._pixel_draws()
+        c_all = self.i_train_dev[draws.reshape(-1)].long()
+        gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
+        nets, tabs = [], []
+        for angles_deg, periods in cands:
+            net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img), default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
+                              device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
+            tabs.append(net.embed(self.i_train_dev))
+            nets.append(net)
+        streams = [torch.cuda.Stream(self.device) for _ in range(max(1, min(int(n_streams), len(nets))))]
+        for st in streams:
+            st.wait_stream(main)
+        for it in range(self.N_iters):
+            idx, gt = draws[it], gt_all[it]
+            for j, net in enumerate(nets):
+                with torch.cuda.stream(streams[j % len(streams)]):
+                    net.train_step(tabs[j][0][idx], tabs[j][1][idx], gt)
+        for st in streams:
+            main.wait_stream(st)
+        return nets
+
     @torch.no_grad()
     def score(self, net):
         """search.py:152-197."""
@@ -271,11 +299,8 @@ class ProposalRanker:
         from .parallel import shard_units, gather_unit_scalars
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
-        details = []
-        for ci in mine:
-            angles, periods = candidates[ci][0], candidates[ci][1]
-            net = self.fit_candidate(angles, periods)
-            details.append(self.score(net))
+        nets = self.fit_candidates([(candidates[ci][0], candidates[ci][1]) for ci in mine])
+        details = [self.score(net) for net in nets]
         if multi:
             t = torch.tensor(details, dtype=torch.float32, device=self.device).reshape(-1, 3)
             details = [tuple(r) for r in gather_unit_scalars(t, len(candidates)).cpu().tolist()]

@@ -204,6 +204,30 @@ def test_ranking_prefers_the_true_periodicity(dev):
     assert np.all(np.diff(d) >= 0) and all(np.isfinite(x[0]) for x in details)
 
 
+def test_concurrent_candidate_fits_equal_the_serial_ones(dev):
+    """ProposalRanker.fit_candidates (all candidates advanced together on side streams) against fit_candidate (one after the
+    other): the same fitted parameters (split-K float atomics in the weight gradients give run-to-run noise of ~1e-6) and the
+    same scores."""
+    from npp_amd.light import ProposalRanker
+    H = 128
+    img, mask = oracle.synthetic_image(H, noise=0.01)
+    angles, periods, _ = oracle.synthetic_periodicity(H, 1)
+    pseudo = np.ones((H, H))
+    pseudo[40:80, 50:90] = 0
+    i_train, i_val = np.stack(np.nonzero(pseudo), 1), np.stack(np.nonzero(1 - pseudo), 1)
+    ranker = ProposalRanker(img, i_train, i_val, device=dev, N_iters=40, N_rand=1024)
+    cands = [(angles[0], periods[0]), (angles[0], periods[0] * 1.37), (angles[0] + 35.0, periods[0]), (angles[0] + 10.0, periods[0] * 0.8),
+             (angles[0], periods[0] * 2.0)]
+    together = ranker.fit_candidates(cands, n_streams=3)
+    for (a, p), net in zip(cands, together):
+        alone = ranker.fit_candidate(a, p)
+        assert net.opt_step == alone.opt_step == 40
+        pa, pb = net.params.cpu().numpy(), alone.params.cpu().numpy()
+        assert np.linalg.norm(pa - pb) <= 1e-4 * np.linalg.norm(pb)
+        sa, sb = ranker.score(net), ranker.score(alone)
+        assert abs(sa[0] - sb[0]) <= 1e-3 * abs(sb[0])
+
+
 @pytest.mark.parametrize("tag,K", [("small_k3", 3), ("small_k1", 1)])
 def test_generic_width_net_vs_reference(dev, golden, tag, K):
     """NPP_Net / NPP_Net_top1 outside the fused kernels' specialisation (here W = 32, multires 2 -> 110-wide proposals) are
