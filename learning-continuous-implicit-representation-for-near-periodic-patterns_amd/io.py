@@ -127,12 +127,13 @@ def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, d
     valid = np.asarray(valid_mask, np.float64).reshape(img.shape[0], img.shape[1])
     names = {"fpath_masked_img": "masked_img.png", "fpath_valid_mask": "valid_mask.png", "fpath_mask": "unknown_mask.png",
              "fpath_gt_img": "gt_img.png"}
+    jobs = []                                                         # (path, uint8 array): PNG encoding releases the GIL -> a few threads
     gt8 = np.uint8(img * 255)                                         # search.py:249-252 truncating casts
-    Image.fromarray(gt8).save(os.path.join(outdir, names["fpath_gt_img"]))
+    jobs.append((os.path.join(outdir, names["fpath_gt_img"]), gt8))
     masked8 = np.uint8((img * mask[..., None] if masked_img is None else np.asarray(masked_img, np.float64)) * 255)
-    Image.fromarray(masked8).save(os.path.join(outdir, names["fpath_masked_img"]))
-    Image.fromarray(np.uint8(valid * 255)).save(os.path.join(outdir, names["fpath_valid_mask"]))
-    Image.fromarray(np.uint8(mask * 255)).save(os.path.join(outdir, names["fpath_mask"]))
+    jobs.append((os.path.join(outdir, names["fpath_masked_img"]), masked8))
+    jobs.append((os.path.join(outdir, names["fpath_valid_mask"]), np.uint8(valid * 255)))
+    jobs.append((os.path.join(outdir, names["fpath_mask"]), np.uint8(mask * 255)))
     odgt = {k: os.path.join(outdir, v) for k, v in names.items()}
     odgt.update(selected_angles=np.asarray(angles, np.float64).tolist(), selected_periods=np.asarray(periods, np.float64).tolist(),
                 selected_shifts=[[list(map(float, s)) for s in sh] for sh in shifts],
@@ -142,10 +143,13 @@ def write_detected_dir(outdir, img, mask, valid_mask, angles, periods, shifts, d
         for i, sh in enumerate(shifts):
             path = os.path.join(outdir, f"reg_img_{i}.png")
             try:
-                Image.fromarray(draw_lattice(masked8, (left, top), sh[0], sh[1])).save(path)
+                jobs.append((path, draw_lattice(masked8, (left, top), sh[0], sh[1])))
             except np.linalg.LinAlgError:                             # collinear displacement pair: nothing to draw
                 continue
             odgt[f"fpath_reg_img_{i}"] = [path]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(4, len(jobs))) as pool:
+        list(pool.map(lambda j: Image.fromarray(j[1]).save(j[0]), jobs))
     with open(os.path.join(outdir, "config.odgt"), "w") as f:
         json.dump(odgt, f)
         f.write("\n")

@@ -163,12 +163,17 @@ def main(argv=None):
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
                         use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
                         no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth)
+    # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
+    from concurrent.futures import ThreadPoolExecutor
+    writer, pending = ThreadPoolExecutor(1), []
     t0 = time.time()
     for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
         fit.step_full()
         if i % args.i_testset == 0:
             pred = fit.render_image().cpu().numpy()
-            nio.dump_testset(os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"], d["valid_mask"])
+            os.makedirs(os.path.join(outroot, f"testset_{i:06d}"), exist_ok=True)
+            pending.append(writer.submit(nio.dump_testset, os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"],
+                                         d["valid_mask"]))
             print(f"[EVAL] iter {i}: PSNR known {fit.psnr('known'):.2f} dB, unknown {fit.psnr('unknown'):.2f} dB")
             if seg:                                                                         # NPP_segmentation/train.py:337-406
                 from . import segment
@@ -194,6 +199,9 @@ def main(argv=None):
             print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
                   f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
     fit.close()                                             # the sampler's producer thread
+    for p in pending:
+        p.result()                                          # (re-raises a failed write)
+    writer.shutdown()
     return fit
 
 
