@@ -48,6 +48,11 @@ class CompletionFit:
         if task not in ("completion", "remapping", "segmentation"):
             raise ValueError("task must be 'completion', 'remapping' or 'segmentation'")
         self.fold_launches = os.environ.get("NPP_FIT_UNFUSED", "0") != "1"     # see step_from
+        # Row-group overlap (step_from): the pixel rows' forward / pixel loss / backward / weight gradient run on a side stream
+        # under the patch-loss chain of the patch rows ("a/b": split-K slabs of the pixel rows / of the patch rows).
+        ov = os.environ.get("NPP_FIT_OVERLAP", "0")      # measured NEGATIVE (profiles/r03_rejected_experiments.txt): default off
+        self.overlap = ov != "0"
+        self.overlap_ks = tuple(int(v) for v in os.environ.get("NPP_FIT_OVERLAP_KS", "4/12").split("/"))
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
@@ -125,6 +130,7 @@ class CompletionFit:
             self.last_source, self.skipped = None, 0
             self._xy, self._xy_key = None, None
             self._s_lp = torch.cuda.Stream(self.device)
+            self._s_pix = torch.cuda.Stream(self.device)
             self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
@@ -277,7 +283,6 @@ class CompletionFit:
         ops.check_current(self.device)
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
-        ws = net.workspace(bp)
         raw = b["raw"]
         comp = self.use_comp and source == "val"                 # train.py:230-231
         nk = n_p * k
@@ -290,10 +295,30 @@ class CompletionFit:
         xy = self._xy if (with_lp or self.style is not None) else None      # fp32 batch only when another trunk reads it
         sc, sh = cx.input_norm()
         main = torch.cuda.current_stream(self.device)
+        fold = self.fold_launches
         net.zero_grad()
         if self.percepLoss.touched:
             self.percepLoss.zero_latent_grads()
-        pred = net.forward_train(b["coords"])
+        # Two row groups (NPPNet.workspace_split): A = the pixel rows, whose whole path (forward, pixel loss, backward chain,
+        # weight gradient) is independent of the patch losses and runs on the side stream _s_pix UNDER the trunk / contextual
+        # chain of B = the patch rows -- that chain is ~30 dependent small launches that leave most of the chip idle.  The two
+        # groups write disjoint stash arrays and disjoint split-K slabs; Adam (main stream, after the join) sums all slabs.
+        split = self.overlap and fold and n_pix % 64 == 0 and 0 < n_pix < bp
+        if split:
+            ws = net.workspace_split(bp, n_pix, *self.overlap_ks)
+            gA, gB = ws["A"], ws["B"]
+            coords = b["coords"]
+            self._s_pix.wait_stream(main)                        # inputs of this iteration + the previous Adam / re-pack
+            net.group_forward(gB, coords[n_pix:])
+            with torch.cuda.stream(self._s_pix):
+                net.group_forward(gA, coords[:n_pix])
+                ops.pixel_loss(gA["pred"], b["gt"], b.get("pmask"), net.latents, net.spline, net.n_knots, net.x_scale, self.pix_w,
+                               net.loss_buf, gA["dpred"], net.dlatent)
+                net.group_backward(gA)
+            pred = ws["pred"]
+        else:
+            ws = net.workspace(bp)
+            pred = net.forward_train(b["coords"])
         if ws.get("n_rows") != n:                                # rows >= n never receive a gradient
             ws["dpred"][n:].zero_()
             ws["n_rows"] = n
@@ -305,12 +330,11 @@ class CompletionFit:
         # one launch: the adaptive pixel loss of the pixel rows + patch plumbing -> the contextual trunk's flat fp16 input
         # (normalised), the patch-loss accumulator cleared on the way (fold_launches = False: the separate launches, kept as
         # the comparator of tests/test_gpu_parity.py and for A/B timing)
-        fold = self.fold_launches
         if not fold:
             net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
                            cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf,
-                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if fold else None)
+                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if (fold and not split) else None)
         dx_b = None
         # use_patch_weight (train.py:224-250): contextual term sum_i -log(cx_i w_i + 1e-5) (the core's weighted form), LPIPS term
         # sum_i d_i w_i -- on 'same' iterations the weights are all 1 (sampler.py:338), i.e. nk times the mean
@@ -333,12 +357,17 @@ class CompletionFit:
         self.last_patch_loss = self.patch_loss_buf
         lr_used = net.lr
         # npp_patch_compose_bwd folded into the backward launch: dL/dpred of the patch rows is formed (and written) there
-        if fold:
+        if split:
+            net.group_backward(gB, patch=(dx_a, dx_b, raw["fmask"], raw["rmask"], 0, n_p, k, P, comp))
+            main.wait_stream(self._s_pix)
+            net.optimizer_step_split(ws)
+        elif fold:
             net.backward(bp, patch=(dx_a, dx_b, raw["fmask"], raw["rmask"], n_pix, n_p, k, P, comp))
+            net.optimizer_step(bp)
         else:
             ops.patch_compose_bwd(dx_a, dx_b, raw["fmask"], raw["rmask"], n_p, k, P, comp, ws["dpred"][n_pix:n])
             net.backward(bp)
-        net.optimizer_step(bp)
+            net.optimizer_step(bp)
         if self.percepLoss.touched:                               # only 'same' iterations give them a gradient
             self.percepLoss.adam_step(lr_used)
         if self.style is not None:                                # the style latents are in the same optimiser (helpers.py:153-159)
