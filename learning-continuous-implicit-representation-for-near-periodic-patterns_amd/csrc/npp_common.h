@@ -157,6 +157,17 @@ __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
   *(bf16x8*)p = v;
 #endif
 }
+// Pre-activation gradients (npp_mlp_bwd -> npp_mlp_wgrad, the next launch): NPP_DZ_NT=0 lets them allocate in the caches
+#ifndef NPP_DZ_NT
+#define NPP_DZ_NT NPP_STASH_NT
+#endif
+__device__ __forceinline__ void dz_store(void* p, const bf16x8& v) {
+#if NPP_DZ_NT
+  __builtin_nontemporal_store(v, (bf16x8*)p);
+#else
+  *(bf16x8*)p = v;
+#endif
+}
 // Pre-activations of the snake layers are stashed as fp16 (|z| is O(10); 11 significand bits):
 // the backward chain derives snake'(z) = 1 + sin 2z from them and npp_mlp_wgrad derives the layer
 // input snake(z) while staging -- ONE 16-bit array per layer instead of two.

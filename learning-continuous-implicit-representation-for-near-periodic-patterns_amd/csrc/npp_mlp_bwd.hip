@@ -86,7 +86,7 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
         if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
-        stash_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
+        dz_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
       }
     }
   }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       f[1] = (__bf16)sDraw[row * 3 + 1];
       f[2] = (__bf16)sDraw[row * 3 + 2];
     }
-    if (q1 < 2) stash_store(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
+    if (q1 < 2) dz_store(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
   }
 
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
         lds_store_frag(R0, 2 * L.wave + s, bt, L.lane, f);
-        stash_store(A.dzF + wfmt_array_base(kDzKsP, gridDim.x) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
+        dz_store(A.dzF + wfmt_array_base(kDzKsP, gridDim.x) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
       }
     }
   }

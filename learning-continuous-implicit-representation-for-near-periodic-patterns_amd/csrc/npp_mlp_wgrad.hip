@@ -3,18 +3,21 @@
 //
 // dW_l[n][k] = sum_b dz_l[n][b] * a_{l-1}[k][b]   (autograd of F.linear, networks.py:56-95)
 // db_l[n]    = sum_b dz_l[n][b]
-// The contraction runs over the batch.  Both operands arrive as the bf16 fragments the
+// The contraction runs over the batch.  Both operands arrive as the 16-bit fragments the
 // fused forward / backward kernels hold in registers (one 16-byte unit = 8 features of one
-// row; "W-format" arrays, npp_layout.h): a 128-feature operand tile of one 64-row workgroup
-// tile is a contiguous 16-KiB chunk that is copied linearly into LDS, and the MFMA operand
-// fragments (one feature, 8 consecutive rows per lane) are produced by the hardware
+// row; "W-format" arrays, npp_layout.h): the 32 batch rows x 32 features of one k-step pair are
+// a contiguous 2-KiB run that LDS-DMA (buffer_load_dwordx4 ... lds) copies straight into LDS, and
+// the MFMA operand fragments (one feature, 8 consecutive rows per lane) are produced by the hardware
 // transposing read ds_read_b64_tr_b16 -- conflict-free by construction of the line layout.
-// A job = one (dz array, input array) pair; jobs are cut into 256x256 output tiles (the kernel is
-// HBM-bound on re-reading the stash arrays: with 128x128 tiles every array was read twice, 1.0 GB
-// per pass at c2; 256x256 tiles, 8 waves of 64x128, read each array once per job) and the
-// batch is split over gridDim.y; every (tile, split) writes its partial sums with plain
+// A job = one (dz array, input array) pair; jobs are cut into 256x256 output tiles (8 waves of
+// 64x128; with 128x128 tiles every array was read twice, 1.0 GB per pass at c2) and the
+// batch is split over the grid; every (tile, split) writes its partial sums with plain
 // stores into slab `split` of the gradient buffer, in the reference's parameter layout
 // ([out][in] row-major).  npp_adam_step adds the slabs: no atomics, bit-reproducible.
+// Main loop (round 3): a five-slot LDS ring of half tiles filled by LDS-DMA with three halves in flight, counted vmcnt + raw
+// barrier per half (wgrad_loop below); snake(z) of the inputs that are stored as fp16 pre-activations is formed in place in
+// LDS under the MFMAs.  Measured at c2 (26 624 rows, in sequence): 115 -> 106-108 us; the loop now runs at the LDS-DMA
+// streaming rate of a CU (~30 GB/s, the guide's "ldsdma-fill"), i.e. the launch is memory-side-bound.
 //
 // Algorithmic work: 2 * sum_l n_out*n_in FLOP per batch row (embedding pad slots and the
 // padding of the 3-row rgb job are not counted).
@@ -27,7 +30,13 @@ constexpr int kWBK = 64;            // batch rows per main-loop step
 constexpr int kWThreads = 512;      // 8 waves: 4 (m) x 2 (n), 64 x 128 outputs each
 constexpr int kWPairs = kWT / 32;   // k-step pairs (32 features) per operand tile
 constexpr int kWTileBytes = kWT * kWBK * 2;          // 32 KiB per operand tile
-constexpr int kSmemW = 4 * kWTileBytes;              // A,B double buffered = 128 KiB
+#ifndef NPP_WGRAD_VALU_PER_MFMA
+#define NPP_WGRAD_VALU_PER_MFMA 5
+#endif
+#ifndef NPP_WGRAD_SLOTS
+#define NPP_WGRAD_SLOTS 5
+#endif
+constexpr int kSmemW = NPP_WGRAD_SLOTS * kWTileBytes;   // ring of half tiles (A | B of 32 batch rows each): 5 x 32 KiB = the whole LDS of a CU
 constexpr int kMaxJobs = 24;
 #ifndef NPP_WGRAD_NT_SLABS
 #define NPP_WGRAD_NT_SLABS 0
@@ -60,119 +69,139 @@ struct WArgs {
   WJob jobs[kMaxJobs];
 };
 
-// One staged operand-tile pair (dz tile + input tile of one 64-row workgroup tile): 2048 16-byte units each, 4 per thread.
-struct WStage { u32x4 a[4], b[4]; };
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef __attribute__((address_space(3))) void lds_void;
 
-// Main loop over the 64-row workgroup tiles [g0, g1) of this split.  One barrier per tile; per tile g:
-//  * k-step t (of 4) of tile g is multiplied out of LDS buffer g & 1;
-//  * piece t of tile g+1 goes registers -> LDS buffer (g+1) & 1 between the k-steps, so the snake(z) conversion and the
-//    LDS stores issue in the shadow of the MFMAs instead of in a phase of their own, and the load of piece t of tile g+2
-//    is re-issued into the SAME registers right behind it (ONE register set, a whole tile time of flight);
-//  * one dword per 128-byte line of tile g+3 is requested (and ignored): the stash streams from HBM with ~2 us latency
-//    under load, which this moves into L2 ahead of the real loads without holding registers for it.
-// Loads are buffer loads: one descriptor per operand (base = this tile column of the array, range = to the end of the whole
-// stash buffer), the tile's position is the SCALAR offset, the lane's 16 bytes the vector offset -- no address arithmetic in
-// vector registers and no branch around a load, so every wait the compiler places is a counted one.  The short tiles at an
-// array's end (a 224-slot embedding tile, the 128-wide dz_p, the 3-row rgb job) read whatever follows them instead of
-// zeros: those operand rows only reach accumulator rows / columns the epilogue drops (mrow >= m, n_idx >= n).
+// ---- main loop: an LDS ring of HALF tiles filled by LDS-DMA --------------------------------------------------------------
+// Unit of the ring = the 32 batch rows (one batch tile bt) of a 64-row workgroup tile, both operands: for each of the 8
+// k-step pairs tt of an operand the W-format holds those rows as ONE contiguous 2-KiB run (two 16-row k-steps of 1 KiB),
+// so wave w copies pair w of the dz tile and pair w of the input tile with two `buffer_load_dwordx4 ... lds` each
+// (1 KiB per instruction, lane-linear on both sides: the LDS image is [operand][pair][2 KiB]).  No operand byte passes
+// through a register and nothing is converted (the forward kernel stores the bf16 layer inputs a = snake(z) itself,
+// npp_layout.h kActKsA0).  4 slots x 32 KiB: while half s is multiplied (16 MFMAs per wave), halves s + 1 and s + 2 are in
+// flight and the DMA of s + 3 is issued into the slot that held s - 1, right behind the barrier that ends its reads.
+// Round 2's loop moved every tile through registers (32 VGPRs, ds_write_b128 at 79 B/clk, fp16 -> snake -> bf16 conversion of
+// the input tile) with ONE tile in flight per CU: 2.77 us per 64-row tile against 0.85-1.0 us of MFMA time, the same with the
+// stash resident in the Infinity Cache (profiles/r03_rejected_experiments.txt) -- bound by its own LDS stores and lockstep.
+// Ordering (cdna_hip_programming.md "Pipelining across barriers"): a wave waits for ITS OWN DMAs of half s with a counted
+// vmcnt (the 8 younger ones = halves s + 1, s + 2 stay in flight), then the raw barrier publishes everybody's; reads of half
+// s happen after that barrier, the refill of a slot after the barrier that follows its last read (lgkmcnt(0) before it).
+// Halves past the split's end are requested through a ZERO-length descriptor: in-order dummy loads that touch no memory and
+// keep the vmcnt arithmetic uniform (no peeled tail).
+constexpr int kHalfOp = 16 * 1024;                  // one operand's half tile: 8 pairs x 2 KiB
+constexpr int kSlot = 2 * kHalfOp;                  // A | B
+constexpr int kSlots = NPP_WGRAD_SLOTS;
+static_assert(kSlots == 5 && kSlots * kSlot == kSmemW && kSlots >= 3 && kSmemW >= 128 * 1024 && kSmemW <= 160 * 1024, "ring (the epilogue stages 8 x 16 KiB in it)");
+// offset of the first ds_read_b64_tr_b16 of fragment (32-feature tile tt, 16-row k-step q of the half) inside an operand's
+// half image; the second read is 256 B on (wfrag_offset with the pair stride 2 KiB instead of 4)
+__device__ __forceinline__ int hfrag_offset(int tt, int lane) {
+  const int g = lane >> 4, i = lane & 15, q4 = i >> 2, p = i & 3, h = g >> 1;
+  return tt * 2048 + 2 * h * 256 + (g & 1) * 128 + (p & 1) * 64 + q4 * 16 + (p >> 1) * 8;
+}
+
 template <bool ZB, bool BIAS>
 __device__ __forceinline__ void wgrad_loop(f32x16 (&acc)[2][4], float (&bsum)[2], char* smem, const rsrc_t ra, const rsrc_t rb,
-                                           uint32_t a_stride, uint32_t b_stride, int g0, int g1, int tid, bool pf_a,
-                                           const int (&offA)[2], const int (&offB)[4]) {
-  const int voff = tid * 16;
-  WStage st;
-  auto gload_piece = [&](int g, int i) {
-    st.a[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voff, (int)((uint32_t)g * a_stride) + 8192 * i, 0));
-    st.b[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, voff, (int)((uint32_t)g * b_stride) + 8192 * i, 0));
+                                           const rsrc_t rzero, uint32_t a_stride, uint32_t b_stride, int g0, int g1, int wave,
+                                           int lane, const int (&offA)[2], const int (&offB)[4]) {
+  const int nh = 2 * (g1 - g0);
+  if (nh <= 0) return;
+  const int voff = wave * 4096 + lane * 16;          // pair `wave` of the tile, this lane's 16 bytes
+  // LDS-DMA through inline asm: hipcc must not count these loads -- it would wait vmcnt(0) before every ds_read that follows a
+  // pending LDS-DMA (it cannot tell the slots apart), draining the ring at each step; completion is counted by hand below
+  // (cdna_hip_programming.md 5.7: no VGPR destination = register-safe; M0 written in the statement that uses it)
+  auto dma_half = [&](int hidx) {
+    const bool ok = hidx < nh;                       // wave-uniform
+    const int g = g0 + (hidx >> 1), bt = hidx & 1;
+    const rsrc_t xa = ok ? ra : rzero, xb = ok ? rb : rzero;
+    const int soa = ok ? (int)((uint32_t)g * a_stride) + bt * 2048 : 0;
+    const int sob = ok ? (int)((uint32_t)g * b_stride) + bt * 2048 : 0;
+    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void*)(smem + (hidx % kSlots) * kSlot + wave * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa0] offen lds\n\t"
+        "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa1] offen lds\n\t"
+        "s_mov_b32 m0, %[d2]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb0] offen lds\n\t"
+        "s_mov_b32 m0, %[d3]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb1] offen lds\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [v] "v"(voff), [xa] "s"(xa), [xb] "s"(xb), [sa0] "s"(soa), [sa1] "s"(soa + 1024), [sb0] "s"(sob), [sb1] "s"(sob + 1024),
+          [d0] "s"(d0), [d1] "s"(d0 + 1024u), [d2] "s"(d0 + (uint32_t)kHalfOp), [d3] "s"(d0 + (uint32_t)kHalfOp + 1024u)
+        : "memory");
   };
-  // L2 prefetch of a tile pair: 2 x 256 lines of 128 B, one line per thread (waves 0..3 -> dz tile, 4..7 -> input tile)
-  auto prefetch = [&](int g) -> uint32_t {
-#ifdef NPP_DIAG_WGRAD_SAMETILE
-    g = g0;
-#endif
-    const int line = (tid & 255) * 128;
-    if (pf_a) return __builtin_amdgcn_raw_buffer_load_b32(ra, line, (int)((uint32_t)g * a_stride), 0);     // wave-uniform branch
-    return __builtin_amdgcn_raw_buffer_load_b32(rb, line, (int)((uint32_t)g * b_stride), 0);
-  };
-  auto sstore_piece = [&](int buf, int i) {
-    char* sA = smem + buf * 2 * kWTileBytes;
-    char* sB = sA + kWTileBytes;
-    const int off = voff + 8192 * i;
-    *(u32x4*)(sA + off) = st.a[i];
-    if (ZB) {                      // layer input = snake(z): once per element per workgroup tile
-      const f16x8 z = __builtin_bit_cast(f16x8, st.b[i]);
+  // ZB (the input array holds the fp16 pre-activations z of a snake layer): the layer input snake(z) is formed IN PLACE in the
+  // LDS image, bf16 over fp16, one half ahead of its use -- every lane converts exactly the 2 x 16 bytes its own two DMA
+  // instructions delivered, so its wave's counted vmcnt is all the ordering the conversion needs; the barrier of the next step
+  // publishes it.  The loop is bound by the memory side (~30 GB/s of LDS-DMA per CU, MI355X_MICROARCH.md "ldsdma-fill"): the
+  // conversion's vector work and its 2 + 2 LDS accesses per lane hide under the wait for the next half.
+  auto convert_half = [&](int hidx) {
+    char* base = smem + (hidx % kSlots) * kSlot + kHalfOp + wave * 2048 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f16x8 z = *(const f16x8*)(base + q * 1024);
       bf16x8 a;
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = (__bf16)snake_fast((float)z[j]);
-      *(bf16x8*)(sB + off) = a;
-    } else {
-      *(u32x4*)(sB + off) = st.b[i];
+      *(bf16x8*)(base + q * 1024) = a;
     }
   };
-  // multiply tile `buf`; between its k-steps hand piece t of the staged tile (g + 1) to the other buffer and re-issue its
-  // load for tile g + 2
-  auto compute = [&](int buf, int g, bool store, bool load) {
-    const char* sA = smem + buf * 2 * kWTileBytes;
-    const char* sB = sA + kWTileBytes;
-#ifdef NPP_DIAG_WGRAD_SAMETILE
-    g = g0 - 2;
-#endif
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      // wfrag_offset(tt, t, lane) - wfrag_offset(tt, 0, lane) = (t>>1)*2048 + (t&1)*1024
-      const int dt = (t >> 1) * 2048 + (t & 1) * 1024;
-      bf16x8 a[2], b[4];
+  for (int i = 0; i < kSlots - 1; ++i) dma_half(i);
+  if (ZB) {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // (kSlots - 2) x 4 younger DMAs: half 0 has landed
+    convert_half(0);
+  }
+  int slot_off = 0;                                           // (s % kSlots) * kSlot, kept as a rotating scalar
+  for (int s = 0; s < nh; ++s) {
+    if (ZB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's DMAs of halves s and s + 1 have landed
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // ... of half s (halves s + 1 .. s + 3 stay in flight)
+    wg_barrier();                                             // everybody's half s is complete; every read of half s - 1 is over
+    dma_half(s + kSlots - 1);                                 // -> the slot half s - 1 occupied
+    const char* sA = smem + slot_off;
+    const char* sB = sA + kHalfOp;
+    // Source order = dependence order the compiler must keep between LDS accesses it cannot tell apart: all fragment reads of
+    // half s FIRST, then (ZB) the in-place conversion of half s + 1 -- its stores may then sink below the MFMAs and its vector
+    // work interleave with them (sched_group_barrier below); the barrier of step s + 1 publishes it.  Unconditional (no branch =
+    // one scheduling region): past the split's end it rewrites a slot nobody reads.
+    bf16x8 a[2][2], b[2][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = wfrag_read(sA, offA[i] + dt);
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = wfrag_read(sB, offB[j] + dt);
-      if (store) sstore_piece(buf ^ 1, t);
-      if (load) gload_piece(g + 2, t);
+      for (int i = 0; i < 2; ++i) a[q][i] = wfrag_read(sA, offA[0] + i * 2048 + q * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[q][j] = wfrag_read(sB, offB[0] + j * 2048 + q * 1024);
+    }
+    if (ZB) convert_half(s + 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
       if (BIAS) {
         const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 8; j += 2) {
-            const bf16x2 pr = {a[i][j], a[i][j + 1]};
+            const bf16x2 pr = {a[q][i][j], a[q][i][j + 1]};
             bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
           }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(a[q][i], b[q][j], acc[i][j]);
     }
-  };
-
-  const int n = g1 - g0;
-  if (n <= 0) return;
-  auto clampg = [&](int g) { return g < g1 ? g : g0; };     // past the split's end: re-load a valid tile nobody uses
-  // prologue: tile g0 -> LDS buffer 0, tile g0+1 -> the register set, tiles g0+1, g0+2 requested into L2
+    if (ZB) {
+      // 16 MFMAs, ~70 vector instructions of the conversion: one MFMA, then its share of the vector work
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gload_piece(g0, i);
-  uint32_t pf = prefetch(clampg(g0 + 1));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sstore_piece(0, i);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) gload_piece(clampg(g0 + 1), i);
-  asm volatile("" :: "v"(pf));
-  pf = prefetch(clampg(g0 + 2));
-  wg_barrier();
-  // steady state, two tiles per trip (static LDS buffer indices): on entry LDS[0] holds tile g, the registers tile g+1
-  for (int g = g0; g < g1; g += 2) {
-    compute(0, clampg(g + 2) - 2, g + 1 < g1, true);
-    asm volatile("" :: "v"(pf));           // the prefetch issued a tile ago has completed (in-order returns behind the loads)
-    pf = prefetch(clampg(g + 3));
-    wg_barrier();
-    if (g + 1 >= g1) break;
-    compute(1, clampg(g + 3) - 2, g + 2 < g1, true);
-    asm volatile("" :: "v"(pf));
-    pf = prefetch(clampg(g + 4));
-    wg_barrier();
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NPP_WGRAD_VALU_PER_MFMA, 0);
+      }
+    }
+    slot_off = slot_off + kSlot == kSlots * kSlot ? 0 : slot_off + kSlot;
   }
-  asm volatile("" :: "v"(pf));
+  // the dummy / tail DMAs issued by the last steps must not land in LDS after the epilogue starts staging there
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wg_barrier();
 }
 
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
@@ -213,8 +242,8 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   const int64_t a_left = A.dz_bytes - a_col, b_left = A.act_bytes - b_col;
   const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.dzF + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
   const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.actF + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
+  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.dzF), 0, 0, 0x00020000);      // every access out of range
   const uint32_t a_stride = (uint32_t)J.a_nks * 2048u, b_stride = (uint32_t)J.b_nks * 2048u;
-  const bool pf_a = wave < 4;
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -225,27 +254,25 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
   const bool do_bias = J.bias_on && tn == 0 && wn == 0;          // wave-uniform
-  const bool b_is_z = J.b_is_z != 0;                             // workgroup-uniform
-  // per-lane fragment offsets: feature tile (wm|wn)*2 + i, k-step t (4 per workgroup tile)
+  // per-lane fragment offsets inside an operand's half image: feature tile (wm|wn)*2 + i
   int offA[2], offB[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) offA[i] = wfrag_offset(wm * 2 + i, 0, lane);
+  for (int i = 0; i < 2; ++i) offA[i] = hfrag_offset(wm * 2 + i, lane);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) offB[j] = wfrag_offset(wn * 4 + j, 0, lane);
+  for (int j = 0; j < 4; ++j) offB[j] = hfrag_offset(wn * 4 + j, lane);
 
-  // The main loop exists in four straight-line forms (input array holds z or ready activations; this wave sums db or not),
-  // selected ONCE by uniform branches: no per-unit branches, so every wait the compiler places is a counted one.
+  // four straight-line forms of the loop (input array holds z or ready operands; this wave sums db or not), selected once by uniform branches
 #ifdef NPP_DIAG_WGRAD_NOLOOP
   const int g0 = (int)wg_begin, g1 = g0 + NPP_DIAG_WGRAD_NOLOOP;    // diagnostic: prologue + N tiles + epilogue only
 #else
   const int g0 = (int)wg_begin, g1 = (int)wg_end;
 #endif
-  if (b_is_z) {
-    if (do_bias) wgrad_loop<true, true>(acc, bsum, smem, ra, rb, a_stride, b_stride, g0, g1, tid, pf_a, offA, offB);
-    else wgrad_loop<true, false>(acc, bsum, smem, ra, rb, a_stride, b_stride, g0, g1, tid, pf_a, offA, offB);
+  if (J.b_is_z) {
+    if (do_bias) wgrad_loop<true, true>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
+    else wgrad_loop<true, false>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
   } else {
-    if (do_bias) wgrad_loop<false, true>(acc, bsum, smem, ra, rb, a_stride, b_stride, g0, g1, tid, pf_a, offA, offB);
-    else wgrad_loop<false, false>(acc, bsum, smem, ra, rb, a_stride, b_stride, g0, g1, tid, pf_a, offA, offB);
+    if (do_bias) wgrad_loop<false, true>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
+    else wgrad_loop<false, false>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
   }
 
   // ---- epilogue: stores into this split's slab, reference layout

@@ -70,7 +70,10 @@ def seq_times(bp, ksplit, reps=30):
 
 
 print("rows    wgs  ks  stash_MB |  step_us  us/krow |  fwd   loss   bwd   wgrad  adam  pack  (in-sequence, event-bracketed)")
-for bp, ks in ((8192, 12), (16384, 12), (24576, 12), (26624, 12), (32768, 12), (49152, 12), (65536, 12), (8192, 4), (16384, 6)):
+cases = ((8192, 12), (16384, 12), (24576, 12), (26624, 12), (32768, 12), (49152, 12), (65536, 12), (8192, 4), (16384, 6))
+if os.environ.get("R3_ROWS"):
+    cases = tuple((int(v), 12) for v in os.environ["R3_ROWS"].split(","))
+for bp, ks in cases:
     wall, t = seq_times(bp, ks)
     print(f"{bp:6d} {bp // 64:5d} {ks:3d} {bp * 15.2e-3:8.0f} | {wall:8.1f} {wall / bp * 1e3:7.2f} | "
           + " ".join(f"{t[k]:6.1f}" for k in t)
