@@ -207,6 +207,17 @@ int npp_adam_step_net(float* d_p, float* d_m, float* d_v, const float* d_gslabs,
                       float* d_lat_v, float* d_dlat, int n_lat, float* d_zero, int n_zero,
                       float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* npp_adam_step_net + npp_pack_weights in ONE launch: every updated weight is also written, as bf16, into the forward and
+ * backward MFMA packs (which npp_pack_weights must have filled once: their padding elements are not rewritten).  Replaces
+ * optimizer.step() (models/helpers.py:164; NPP_completion/train.py:253) followed by the re-pack the fused kernels need.
+ * npp_pack_scatter_host: host twin of the scatter (inverse pack maps), for tests. */
+int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,
+                           int n_slabs, int64_t slab_stride, float* d_lat, float* d_lat_m,
+                           float* d_lat_v, float* d_dlat, int n_lat, float* d_zero, int n_zero,
+                           float lr, float beta1, float beta2, float eps, int step, int K, int width,
+                           void* d_wf, void* d_wb, void* stream);
+int npp_pack_scatter_host(const float* params, void* wf, void* wb, int K, int width);
+
 /* Same step with step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) read from device memory
  * (d_hp[0], d_hp[1]): lets a captured HIP graph of one optimisation iteration be replayed. */
 int npp_adam_step_dev(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n,

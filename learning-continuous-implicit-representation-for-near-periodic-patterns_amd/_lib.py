@@ -92,6 +92,9 @@ SYMBOLS = {
     "npp_fourier_fwd": (_i32, [_vp, _i64, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
                                  _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_adam_step_net_pack": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
+                                      _f32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "npp_pack_scatter_host": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "npp_batch_assemble": (_i32, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,6 @@
 // npp_api.hip -- host-side glue of libnpp_hip.so: error plumbing, the parameter table,
 // weight packing (device kernel + host twin), and the MFMA lane-map self test.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -113,6 +114,108 @@ __global__ void pack_weights_kernel(const float* __restrict__ P, bf16x8* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = (__bf16)bwd_pack_value(P, d, b, v, ns, kt, lane, j);
       wb[ub] = r;
+    }
+  }
+}
+
+// ---- K8 + re-pack in ONE launch (round 3): optimizer.step() over the blob in parameter order (the split-K reduction of the
+// weight gradient included, like npp_adam_step) and, for every updated weight, its bf16 image scattered into the forward
+// and the backward MFMA pack through the inverse maps of npp_layout.h (fwd_pack_pos / bwd_pack_pos): 2-byte stores, 8 per
+// thread, into packs that stay L2-resident -- against a second launch that gathered the whole blob again with row-strided
+// 4-byte loads (12 us at c2).  The packs' padding elements are written once by npp_pack_weights and never again.
+struct AdamPackArgs {
+  float *p, *m, *v;
+  const float* g;
+  int64_t n;
+  int32_t n_slabs;
+  int64_t slab_stride;
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+  AdamTail tail;
+  __bf16 *wf, *wb;
+  uint32_t magic[kNumLayers];      // floor(2^32 / n_in) + 1: r / n_in = umulhi(r, magic) for r < 2^20
+};
+
+__global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a, NetDesc d_arg, BwdDesc b_arg) {
+  // the descriptors are indexed with per-lane layer numbers: LDS copies (filled with compile-time indices, so that the
+  // by-value kernel arguments never need a scratch copy)
+  __shared__ NetDesc d;
+  __shared__ BwdDesc b;
+  __shared__ uint32_t magic[kNumLayers];
+  if (threadIdx.x == 0) {
+    const uint32_t* s1 = (const uint32_t*)&d_arg;
+    uint32_t* t1 = (uint32_t*)&d;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(NetDesc) / 4); ++i) t1[i] = s1[i];
+    const uint32_t* s2 = (const uint32_t*)&b_arg;
+    uint32_t* t2 = (uint32_t*)&b;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(BwdDesc) / 4); ++i) t2[i] = s2[i];
+#pragma unroll
+    for (int i = 0; i < kNumLayers; ++i) magic[i] = a.magic[i];
+  }
+  __syncthreads();
+  if ((int64_t)blockIdx.x * blockDim.x * 4 >= a.n) {      // the extra block: latents + accumulators
+    adam_tail_block(a.tail, a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+    return;
+  }
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= a.n) return;
+  const int cnt = (int)(a.n - i < 4 ? a.n - i : 4);       // 4, or the last n % 4 parameters (the count is odd)
+  float pn[4], mi[4], vi[4], gi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (cnt == 4) {
+    auto ld = [&](int sl) { return *(const vec_t*)(a.g + (int64_t)sl * a.slab_stride + i); };
+    vec_t gs = (vec_t)(0.0f);
+    int sl = 0;
+    for (; sl + 4 <= a.n_slabs; sl += 4) {              // same summation order as adam_kernel<4>: bit-identical
+      const vec_t a0 = ld(sl), a1 = ld(sl + 1), a2 = ld(sl + 2), a3 = ld(sl + 3);
+      gs += a0; gs += a1; gs += a2; gs += a3;
+    }
+    for (; sl < a.n_slabs; ++sl) gs += ld(sl);
+    const vec_t m4 = *(const vec_t*)(a.m + i), v4 = *(const vec_t*)(a.v + i), p4 = *(const vec_t*)(a.p + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gi[e] = gs[e]; mi[e] = m4[e]; vi[e] = v4[e]; pn[e] = p4[e]; }
+  } else {
+    for (int e = 0; e < cnt; ++e) {
+      float ge = 0.0f;
+      for (int sl = 0; sl < a.n_slabs; ++sl) ge += a.g[(int64_t)sl * a.slab_stride + i + e];
+      gi[e] = ge; mi[e] = a.m[i + e]; vi[e] = a.v[i + e]; pn[e] = a.p[i + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (e < cnt) pn[e] = adam_update(pn[e], mi[e], vi[e], gi[e], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+  if (cnt == 4) {
+    *(vec_t*)(a.m + i) = (vec_t){mi[0], mi[1], mi[2], mi[3]};
+    *(vec_t*)(a.v + i) = (vec_t){vi[0], vi[1], vi[2], vi[3]};
+    *(vec_t*)(a.p + i) = (vec_t){pn[0], pn[1], pn[2], pn[3]};
+  } else {
+    for (int e = 0; e < cnt; ++e) { a.m[i + e] = mi[e]; a.v[i + e] = vi[e]; a.p[i + e] = pn[e]; }
+  }
+  // ---- scatter into the packs: locate (layer, row, column) of the first element, then walk
+  int l = 0;
+#pragma unroll
+  for (int q = 1; q < kNumLayers; ++q)
+    if (d.present[q] && i >= d.w_off[q]) l = q;
+  int64_t r = i - d.w_off[l];
+  int n = (int)__umulhi((uint32_t)r, magic[l]), k = (int)r - n * d.n_in[l];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (e < cnt) {
+      if (n < d.n_out[l]) {                               // a weight (rows beyond n_out = the layer's bias vector: not packed)
+        const __bf16 w = (__bf16)pn[e];
+        const int64_t pf = fwd_pack_pos(d, l, n, k);
+        if (pf >= 0) a.wf[pf] = w;
+        const int64_t pb = bwd_pack_pos(b, l, n, k);
+        if (pb >= 0) a.wb[pb] = w;
+      }
+      // next parameter: next column; past the row's end the next row; past the layer's end (weights + bias) the next layer
+      if (++k == d.n_in[l]) { k = 0; ++n; }
+      if (n >= d.n_out[l] && i + e + 1 >= d.b_off[l] + d.n_out[l]) {
+        do { ++l; } while (l < kNumLayers && !d.present[l]);
+        if (l >= kNumLayers) break;
+        n = 0; k = 0;
+      }
     }
   }
 }
@@ -270,6 +373,63 @@ int npp_pack_weights_host(const float* params, void* wf, void* wb, int K, int wi
     for (int j = 0; j < 8; ++j) g[u * 8 + j] = f32_to_bf16_host(bwd_pack_value(params, d, b, v, ns, kt, lane, j));
   }
   return NPP_OK;
+}
+
+int npp_pack_scatter_host(const float* params, void* wf, void* wb, int K, int width) {
+  // host twin of the scatter half of npp_adam_step_net_pack: every weight of the blob through fwd_pack_pos / bwd_pack_pos
+  // into zero-filled packs -- must reproduce npp_pack_weights_host bit for bit (tests/test_cabi_cpu.py)
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  const NetDesc d = make_desc(K);
+  const BwdDesc b = make_bwd_desc(K);
+  uint16_t* f = (uint16_t*)wf;
+  uint16_t* g = (uint16_t*)wb;
+  memset(f, 0, (size_t)d.wf_total16 * 16);
+  memset(g, 0, (size_t)bwd_total16(K) * 16);
+  for (int l = 0; l < kNumLayers; ++l) {
+    if (!d.present[l]) continue;
+    for (int n = 0; n < d.n_out[l]; ++n)
+      for (int k = 0; k < d.n_in[l]; ++k) {
+        const uint16_t w = f32_to_bf16_host(params[d.w_off[l] + (int64_t)n * d.n_in[l] + k]);
+        const int64_t pf = fwd_pack_pos(d, l, n, k), pb = bwd_pack_pos(b, l, n, k);
+        if (pf >= 0) {
+          if (pf >= d.wf_total16 * 8) { set_error("fwd_pack_pos out of range (l=%d n=%d k=%d)", l, n, k); return NPP_ERR_ARG; }
+          f[pf] = w;
+        }
+        if (pb >= 0) {
+          if (pb >= bwd_total16(K) * 8) { set_error("bwd_pack_pos out of range (l=%d n=%d k=%d)", l, n, k); return NPP_ERR_ARG; }
+          g[pb] = w;
+        }
+      }
+  }
+  return NPP_OK;
+}
+
+int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
+                           int64_t slab_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, int n_lat,
+                           float* d_zero, int n_zero, float lr, float beta1, float beta2, float eps, int step, int K,
+                           int width, void* d_wf, void* d_wb, void* stream) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  const NetDesc d = make_desc(K);
+  if (n != d.total_params || !d_p || !d_m || !d_v || !d_gslabs || !d_wf || !d_wb || n_slabs < 1 || step < 1 || n_lat < 0 ||
+      n_zero < 0 || (n_lat > 0 && (!d_lat || !d_lat_m || !d_lat_v || !d_dlat)) || (n_zero > 0 && !d_zero) || slab_stride % 4 ||
+      (((uintptr_t)d_p | (uintptr_t)d_m | (uintptr_t)d_v | (uintptr_t)d_gslabs) & 15)) {
+    set_error("npp_adam_step_net_pack: bad arguments (n=%lld, expected %lld parameters; 16-byte aligned blobs, slab stride %% 4 == 0)",
+              (long long)n, (long long)d.total_params);
+    return NPP_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamPackArgs a{};
+  a.p = d_p; a.m = d_m; a.v = d_v; a.g = d_gslabs; a.n = n; a.n_slabs = n_slabs; a.slab_stride = slab_stride;
+  a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
+  a.wf = (__bf16*)d_wf; a.wb = (__bf16*)d_wb;
+  for (int l = 0; l < kNumLayers; ++l) a.magic[l] = d.present[l] ? (uint32_t)((1ull << 32) / (uint64_t)d.n_in[l]) + 1u : 0u;
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)((threads + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, a, d,
+                     make_bwd_desc(K));
+  return check_launch("npp_adam_step_net_pack");
 }
 
 int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]) {

@@ -189,6 +189,37 @@ __device__ __forceinline__ void stash_store(void* p, const f16x8& v) {
 #endif
 }
 
+// ---- K8: torch.optim.Adam single-tensor maths (helpers.py:164), shared by npp_loss_adam.hip and the fused Adam + re-pack
+// launch of npp_api.hip.  tail (optional, handled by one extra block): a second small parameter group -- the adaptive-loss
+// latents, whose gradient accumulator is consumed and cleared -- and an accumulator to clear for the next iteration, so
+// that one launch replaces optimizer.step() over both groups plus zero_grad().
+struct AdamTail {
+  float *p, *m, *v, *g;
+  int n;
+  float* zero;
+  int n_zero;
+};
+__device__ __forceinline__ void adam_tail_block(const AdamTail& tail, float step_size, float b1, float b2, float inv_sqrt_bc2,
+                                                float eps) {
+  const int t = threadIdx.x;
+  for (int i = t; i < tail.n; i += blockDim.x) {
+    const float gi = tail.g[i];
+    const float mi = b1 * tail.m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * tail.v[i] + (1.0f - b2) * gi * gi;
+    tail.m[i] = mi;
+    tail.v[i] = vi;
+    tail.p[i] = tail.p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    tail.g[i] = 0.0f;
+  }
+  for (int i = t; i < tail.n_zero; i += blockDim.x) tail.zero[i] = 0.0f;
+}
+__device__ __forceinline__ float adam_update(float p, float& m, float& v, float g, float step_size, float b1, float b2,
+                                             float inv_sqrt_bc2, float eps) {
+  m = b1 * m + (1.0f - b1) * g;
+  v = b2 * v + (1.0f - b2) * g * g;
+  return p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+
 // Workgroup barrier for LDS hand-offs that leaves global memory traffic in flight.
 // __syncthreads() makes hipcc emit s_waitcnt vmcnt(0) first, which drains every outstanding
 // stash store and weight prefetch at each of the ~30 barriers of the fused kernels (measured:

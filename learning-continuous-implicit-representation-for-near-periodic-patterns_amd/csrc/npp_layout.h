@@ -42,6 +42,9 @@ NPP_HD int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // operands in this library use that order, so A-operand (weight) fragments are packed
 // with the same k order.
 NPP_HD int perm16(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+// inverse of perm16 on the 16 columns of a k-step: column c -> (hh, j)
+NPP_HD int unperm_hh(int c) { return (c >> 2) & 1; }
+NPP_HD int unperm_j(int c) { return ((c >> 3) << 2) | (c & 3); }
 
 // ---- embedding slot order ------------------------------------------------------
 // One proposal = 30 k-steps of 16 slots.  k-steps 0..27: t = 8*ks + j enumerates
@@ -151,6 +154,58 @@ NPP_HD int fwd_col(int K, int l, int ks, int h, int j) {
   }
 }
 
+// ---- inverse of the two bf16 packs: where parameter W_l[n][k] lives (used by the fused Adam + re-pack launch, which walks
+// the blob in parameter order and scatters every updated weight into both packs) --------------------------------------
+// slot of reference embedding column c in [0, 462): (k-step, lane half, element), inverse of emb_col
+NPP_HD void emb_slot(int c, int& ks, int& h, int& j) {
+  const int blk = c / 22, i = c - blk * 22;
+  if (blk == 0) {
+    if (i < 16) { ks = 28; h = i >> 3; j = i & 7; } else { ks = 29; h = 0; j = i - 16; }
+  } else {
+    const int t = ((blk - 1) >> 1) * 22 + i;
+    ks = t >> 3; h = (blk - 1) & 1; j = t & 7;
+  }
+}
+// forward pack: index of the 16-bit element (16-byte unit * 8 + j) holding W_l[n][k]; -1: the layer has no forward pack (rgb)
+NPP_HD int64_t fwd_pack_pos(const NetDesc& d, int l, int n, int k) {
+  if (l == LRGB || !d.present[l]) return -1;
+  int ks, h, j;
+  bool emb = false;
+  int ke = k, ks0 = 0;
+  if (l == L0) { emb = true; }
+  else if (l == L5) { if (k < kE) emb = true; else { ke = k - kE; ks0 = kKSEmb; } }
+  else if (l == LS) {
+    if (k >= kW) { const int q = k - kW, p = q / kE; emb = true; ke = q - p * kE; ks0 = kKSAct + p * kKSEmb; }
+  }
+  if (emb) { emb_slot(ke, ks, h, j); ks += ks0; }
+  else { const int c16 = ke & 15; ks = ks0 + (ke >> 4); h = unperm_hh(c16); j = unperm_j(c16); }
+  const int64_t unit = d.wf_off[l] + ((int64_t)ks * d.nt_f[l] + (n >> 5)) * 64 + (n & 31) + 32 * h;
+  return unit * 8 + j;
+}
+// backward (transposed) pack: element index of W_l[n][k], or -1 when that weight has no data-gradient use
+// (L0, the embedding columns of L5 / S, rgb)
+NPP_HD int64_t bwd_pack_pos(const BwdDesc& b, int l, int n, int k) {
+  int v = -1;
+  switch (l) {
+    case LP: v = k < kW ? BP1 : BP2; break;
+    case LF2: v = BF2; break;
+    case LS: v = k < kW ? BS : -1; break;
+    case LF1: v = BF1; break;
+    case L7: v = B7; break;
+    case L6: v = B6; break;
+    case L5: v = k >= kE ? B5 : -1; break;
+    case L4: v = B4; break;
+    case L3: v = B3; break;
+    case L2: v = B2; break;
+    case L1: v = B1; break;
+    default: break;
+  }
+  if (v < 0 || !b.present[v]) return -1;
+  const int kc = k - b.col0[v], c16 = n & 15;
+  const int64_t unit = b.off16[v] + ((int64_t)(n >> 4) * kNT + (kc >> 5)) * 64 + (kc & 31) + 32 * unperm_hh(c16);
+  return unit * 8 + unperm_j(c16);
+}
+
 // ---- exact-fp32 forward pack (npp_mlp_fwd32.hip, v_mfma_f32_32x32x2_f32) ---------------------------------
 // A k-step contracts TWO input features (lane half h = 0 / 1).  Activation k-step s of a 256-feature input: features
 // (8 (s / 4) + s % 4, that + 4) -- register r = s % 16 of accumulator tile s / 16 in both lane halves (acc_row).  Embedding
@@ -233,7 +288,4 @@ constexpr int kDzTotalKs = kDzKsRgb + 2;
 // of 4 so that every slab is 16-byte aligned (wgrad stores and Adam loads whole float4s; the parameter count itself is odd)
 NPP_HD int64_t slab_stride_of(int64_t total) { return (total + 3) / 4 * 4; }
 NPP_HD int64_t wfmt_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_off * n_wg * 2048; }
-// inverse of perm16 on the 16 columns of a k-step: column c -> (hh, j)
-NPP_HD int unperm_hh(int c) { return (c >> 2) & 1; }
-NPP_HD int unperm_j(int c) { return ((c >> 3) << 2) | (c & 3); }
 }  // namespace npp

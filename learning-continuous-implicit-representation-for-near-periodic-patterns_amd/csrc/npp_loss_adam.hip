@@ -23,12 +23,7 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(PixelLossArgs a) { pixe
 // tail (optional, handled by one extra block): a second small parameter group -- the adaptive-loss
 // latents, whose gradient accumulator is consumed and cleared -- and an accumulator to clear for the
 // next iteration, so that one launch replaces optimizer.step() over both groups plus zero_grad().
-struct AdamTail {
-  float *p, *m, *v, *g;
-  int n;
-  float* zero;
-  int n_zero;
-};
+// (AdamTail, adam_tail_block: npp_common.h -- shared with the fused Adam + re-pack launch of npp_api.hip)
 // VEC = 4: one float4 per thread and array (n, slab_stride multiples of 4, 16-byte aligned pointers), four slab loads in
 // flight before the (order-preserving, hence bit-identical) summation: the kernel is a pure HBM stream of
 // (n_slabs + 5) * 4 B per parameter.
@@ -40,17 +35,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    float eps, const float* __restrict__ hp, AdamTail tail) {
   if (hp) { step_size = hp[0]; inv_sqrt_bc2 = hp[1]; }
   if ((int64_t)blockIdx.x * blockDim.x * VEC >= n) {      // the extra block
-    const int t = threadIdx.x;
-    for (int i = t; i < tail.n; i += blockDim.x) {
-      const float gi = tail.g[i];
-      const float mi = b1 * tail.m[i] + (1.0f - b1) * gi;
-      const float vi = b2 * tail.v[i] + (1.0f - b2) * gi * gi;
-      tail.m[i] = mi;
-      tail.v[i] = vi;
-      tail.p[i] = tail.p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-      tail.g[i] = 0.0f;
-    }
-    for (int i = t; i < tail.n_zero; i += blockDim.x) tail.zero[i] = 0.0f;
+    adam_tail_block(tail, step_size, b1, b2, inv_sqrt_bc2, eps);
     return;
   }
   typedef float vec_t __attribute__((ext_vector_type(VEC)));

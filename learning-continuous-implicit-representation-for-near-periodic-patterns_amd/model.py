@@ -2,6 +2,8 @@
 create_npp_net (models/helpers.py:75-175), render (:41-62), the Adam + LR rule of
 NPP_completion/train.py:253-263, with the state kept in device buffers that the HIP
 kernels read directly.  Nothing here computes; it owns memory and calls the C ABI."""
+import os
+
 import numpy as np
 import torch
 
@@ -48,9 +50,10 @@ class NPPNet:
         self.lr_clock = True        # False: the LR clock never advances (NPP_segmentation/train.py:408: `global_step += 1` sits
                                     # outside the loop there, so that task trains at a constant lrate) -- reproduced, not fixed
         self.opt_step = 0           # Adam's per-parameter step count
-        self.wf = torch.empty(ops.pack_bytes(self.K, 0, self.width), dtype=torch.uint8, device=self.device)
-        self.wb = torch.empty(ops.pack_bytes(self.K, 1, self.width), dtype=torch.uint8, device=self.device)
+        self.wf = torch.zeros(ops.pack_bytes(self.K, 0, self.width), dtype=torch.uint8, device=self.device)
+        self.wb = torch.zeros(ops.pack_bytes(self.K, 1, self.width), dtype=torch.uint8, device=self.device)
         self._ws = {}
+        self.fused_repack = os.environ.get("NPP_FUSED_REPACK", "1") != "0"
         if params is not None:
             self.load_state_dict(params)
 
@@ -146,10 +149,7 @@ class NPPNet:
         """optimizer_step() over the slabs of both row groups."""
         self.opt_step += 1
         idle = self._loss_bufs[1 - self._loss_idx:2 - self._loss_idx]
-        ops.adam_step_net(self.params, self.m, self.v, ws["gslabs"], sum(ws["ks"]), ws["stride"], self.latents,
-                          self.lat_m, self.lat_v, self.dlatent, idle, self.lr, self.opt_step)
-        self._clean = True
-        self.repack()
+        self._adam(ws["gslabs"], sum(ws["ks"]), ws["stride"], idle)
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         if self.lr_clock:
             self.global_step += 1
@@ -214,13 +214,22 @@ class NPPNet:
         ws = self._ws[Bp]
         self.opt_step += 1
         idle = self._loss_bufs[1 - self._loss_idx:2 - self._loss_idx]
-        ops.adam_step_net(self.params, self.m, self.v, ws["gslabs"], self.ksplit, ws["gslabs"].numel() // self.ksplit, self.latents,
-                          self.lat_m, self.lat_v, self.dlatent, idle, self.lr, self.opt_step)
-        self._clean = True
-        self.repack()
+        self._adam(ws["gslabs"], self.ksplit, ws["gslabs"].numel() // self.ksplit, idle)
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         if self.lr_clock:
             self.global_step += 1
+
+    def _adam(self, gslabs, n_slabs, stride, idle):
+        """optimizer.step() over the blob + latents and the re-pack of the bf16 MFMA packs: one launch (fused_repack, default)
+        or two (npp_adam_step_net, then npp_pack_weights: the comparator)."""
+        if self.fused_repack:
+            ops.adam_step_net_pack(self.params, self.m, self.v, gslabs, n_slabs, stride, self.latents, self.lat_m, self.lat_v,
+                                   self.dlatent, idle, self.lr, self.opt_step, self.K, self.wf, self.wb, self.width)
+        else:
+            ops.adam_step_net(self.params, self.m, self.v, gslabs, n_slabs, stride, self.latents, self.lat_m, self.lat_v,
+                              self.dlatent, idle, self.lr, self.opt_step)
+            self.repack()
+        self._clean = True
 
     @property
     def loss_buf(self):

@@ -292,6 +292,15 @@ def adam_step_net(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat
                                   lr, b1, b2, eps, step, _stream()), "npp_adam_step_net")
 
 
+def adam_step_net_pack(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat, zero, lr, step, K, wf, wb, width=NPP_WIDTH,
+                       b1=0.9, b2=0.999, eps=1e-8):
+    """adam_step_net + pack_weights in one launch: the updated weights are scattered into the bf16 packs wf / wb as well."""
+    _req(p, torch.float32, "p")
+    check(lib(width).npp_adam_step_net_pack(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, _p(lat), _p(lat_m),
+                                            _p(lat_v), _p(dlat), lat.numel(), _p(zero), 0 if zero is None else zero.numel(),
+                                            lr, b1, b2, eps, step, K, width, _p(wf), _p(wb), _stream()), "npp_adam_step_net_pack", width)
+
+
 def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True):
     """extract_glimpse(mode='nearest', zeros padding) at integer centres
     (utils/extract_glimpse.py:53-79 via models/sampler.py:171-178,284-291)."""

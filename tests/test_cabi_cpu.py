@@ -213,3 +213,21 @@ def test_backward_pack_reproduces_transposed_products(K):
         ref = Wm[:, col0:col0 + 256].astype(np.float64).T @ dz.astype(np.float64)
         np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9, err_msg=f"{name}@{col0}")
     assert unit == wb.shape[0]
+
+
+@pytest.mark.parametrize("K,width", [(1, 256), (3, 256), (5, 256), (3, 512)])
+def test_pack_scatter_inverse_maps_reproduce_the_packers(K, width):
+    """npp_adam_step_net_pack scatters every updated weight into the two bf16 packs through the inverse maps of
+    csrc/npp_layout.h (fwd_pack_pos / bwd_pack_pos); their host twin must rebuild exactly what npp_pack_weights_host builds
+    (every real element hit once, padding left zero), at both compiled widths."""
+    L = npp_amd.lib(width)
+    _, total = param_layout(K, width)
+    rng = np.random.RandomState(K * 7 + width)
+    flat = (rng.randn(total) * 0.3).astype(np.float32)
+    nf, nb = L.npp_pack_bytes(K, width, 0), L.npp_pack_bytes(K, width, 1)
+    a_f, a_b = np.zeros(nf // 2, np.uint16), np.zeros(nb // 2, np.uint16)
+    s_f, s_b = np.full(nf // 2, 0x7fc0, np.uint16), np.full(nb // 2, 0x7fc0, np.uint16)
+    check(L.npp_pack_weights_host(flat.ctypes.data, a_f.ctypes.data, a_b.ctypes.data, K, width), "pack_host")
+    check(L.npp_pack_scatter_host(flat.ctypes.data, s_f.ctypes.data, s_b.ctypes.data, K, width), "pack_scatter_host")
+    assert np.array_equal(a_f, s_f)
+    assert np.array_equal(a_b, s_b)

@@ -836,3 +836,61 @@ def test_folded_launches_equal_the_separate_ones(dev, source):
     assert rel_l2(da[n_pix:n].cpu().numpy(), db[n_pix:n].cpu().numpy()) < 6e-3 and (n == bp or float(da[n:].abs().max()) == 0.0)
     assert abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) < 1e-6 * abs(float(b.net.loss_buf[0])) + 1e-9
     assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("K,width", [(3, 256), (1, 256), (5, 256), (3, 512)])
+def test_fused_adam_repack_equals_adam_then_pack(dev, K, width):
+    """npp_adam_step_net_pack (optimizer.step() + the scatter of every updated weight into both bf16 packs, one launch) against
+    npp_adam_step_net followed by npp_pack_weights: parameters, Adam moments, latents and both packs bit-identical after three
+    training steps from the same state."""
+    H, n = 256, 512
+    c = torch.from_numpy(_coords(n, H, H)).to(dev)
+    gt = torch.rand(n, 3, device=dev)
+    nets = []
+    for fused in (True, False):
+        net, *_ = _net(dev, K, ksplit=3, width=width)
+        net.fused_repack = fused
+        for _ in range(3):
+            net.zero_grad()
+            net.forward_train(c)
+            net.workspace(n)["dpred"].zero_()
+            net.pixel_loss(n, n, gt)
+            net.backward(n)
+            net.optimizer_step(n)
+        nets.append(net)
+    a, b = nets
+    for name in ("params", "m", "v", "latents", "lat_m", "lat_v", "wf", "wb"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("source", ["val", "same"])
+def test_two_row_group_step_equals_the_single_stream_step(dev, source):
+    """CompletionFit.overlap (the pixel rows' forward / pixel loss / backward / wgrad as their own row group on a side stream,
+    NPPNet.workspace_split) against the plain step on the same batch: same loss, gradients and parameters up to the summation
+    order of the split-K slabs and the float atomics of the contextual-loss kernels."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 3
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make(ov):
+        f = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev, N_rand=2048,
+                          shifts=shifts, seed=3)
+        f.overlap, f.overlap_ks = ov, (2, 3)
+        return f
+    a, b = make(True), make(False)
+    batch = None
+    for _ in range(40):
+        d = a.draw_batch()
+        if d is not None and d["source"] == source:
+            batch = a.materialise_batch(d)
+            break
+    assert batch is not None
+    a.step_from(batch)
+    b.step_from(batch)
+    torch.cuda.synchronize()
+    ga, gb = a.net.grads(), b.net.grads()
+    for k_ in ga:
+        assert rel_l2(ga[k_], gb[k_]) < 6e-3, k_
+    assert abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) < 1e-6 * abs(float(b.net.loss_buf[0])) + 1e-9
+    assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
