@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
     ap.add_argument("--ksplit", type=int, default=0, help="split-K of the weight-gradient launch; 0 = auto (CUs / tiles)")
-    ap.add_argument("--pool", type=int, default=20, help="pre-drawn sampler outputs the timed steps cycle through")
+    ap.add_argument("--pool", type=int, default=40, help="pre-drawn sampler outputs the timed steps cycle through (a multiple of 10: the "
+                    "sampler's 50 / 30 / 20 % source mix is then held exactly)")
     return ap.parse_args()
 
 
@@ -269,6 +270,29 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * n_rows * args.steps / dt
+    # the timed steps walk the pool in order: a step count that is not a multiple of the pool weighs the sources by the pool's
+    # ORDER instead of its 50 / 30 / 20 mix ('same' iterations cost 1.3x): say so in the line instead of hiding it
+    mix_timed = {s_: sum(pool[i % len(pool)]["source"] == s_ for i in range(args.steps)) for s_ in ("val", "train", "same")}
+    if args.steps % len(pool) and rank == 0:
+        print(f"bench.py: --steps {args.steps} is not a multiple of --pool {len(pool)}: timed source mix {mix_timed}", file=sys.stderr)
+
+    # ---- the one collective of the job: gather the fitted images -- directly behind the timed loop, before any rank-0-only
+    #      extra (the other ranks would sit in the all_gather meanwhile) ----
+    gather_ms = None
+    if dist is not None:
+        out = fit.render_image().contiguous()
+        bufs = [torch.empty_like(out) for _ in range(world)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.all_gather(bufs, out)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        del bufs
+    if rank != 0:                          # everything below is rank 0's report
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- extra: the same iteration without the patch losses (round-1 definition of the step) ----
     batches = [(b["coords"], fit.masked_img[b["coords"][:n_rows, 0].long(), b["coords"][:n_rows, 1].long()].contiguous()) for b in pool[:8]]
@@ -331,6 +355,31 @@ def main():
                                       net.repack())),
         "render_fwd_512sq": timed(lambda: net.render(fit.i_all_dev), reps=5),
     }
+    # ---- the same kernels IN SEQUENCE: HIP events between the launches of complete MLP-only steps (median over 30 steps).
+    #      A kernel timed back-to-back with itself has its operands hot in L2 / the Infinity Cache; inside the step the stash it
+    #      reads was written one or two launches (hundreds of MB) earlier.  `roofline` below uses THESE durations. ----
+    def seq_times(reps=30):
+        names = ["mlp_fwd_train", "pixel_loss", "mlp_bwd_chain", "mlp_wgrad", "adam+repack"]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(reps)]
+        for r_ in range(reps + 3):
+            e = evs[r_ - 3] if r_ >= 3 else None
+            net.zero_grad()
+            if e: e[0].record()
+            net.forward_train(c0)
+            if e: e[1].record()
+            net.pixel_loss(bp, n_rows, gt0)
+            if e: e[2].record()
+            ops.mlp_bwd(ws["dpred"], ws["pred"], K, net.wb, net.params, ws["actT"], ws["dzT"])
+            if e: e[3].record()
+            ops.mlp_wgrad(ws["dzT"], ws["actT"], bp, K, net.ksplit, ws["gslabs"])
+            if e: e[4].record()
+            net.optimizer_step(bp)
+            if e: e[5].record()
+        torch.cuda.synchronize()
+        t = np.array([[e[i].elapsed_time(e[i + 1]) * 1e-3 for i in range(len(names))] for e in evs])
+        return dict(zip(names, np.median(t, 0)))
+    kt_seq = seq_times()
+    ws["dpred"].zero_()
     fwd_macs, train_macs = syn.mlp_macs_per_pixel(K)
     flops = {"mlp_fwd_train": 2 * fwd_macs * n_rows,
              "mlp_bwd_chain": 2 * (train_macs - 2 * fwd_macs) * n_rows,   # dgrad = fwd - embedding part
@@ -346,21 +395,25 @@ def main():
     hbm_bytes = {"mlp_fwd_train": bp * (8 + 12 + 2 * (z_cols + lin_cols + emb_cols)) + 2.4e6,
                  "mlp_bwd_chain": bp * (24 + 2 * z_cols + 2 * dz_cols) + 1.5e6,
                  "mlp_wgrad": bp * 2 * wjob_rows + 4 * n_par * net.ksplit}
-    dom = max(flops, key=lambda k: kt[k])
-    tf = {k: flops[k] / kt[k] / 1e12 for k in flops}
-    gbs = {k: hbm_bytes[k] / kt[k] / 1e9 for k in flops}
+    dom = max(flops, key=lambda k: kt_seq[k])
+    tf = {k: flops[k] / kt_seq[k] / 1e12 for k in flops}                 # in-sequence durations
+    tf_tight = {k: flops[k] / kt[k] / 1e12 for k in flops}               # back-to-back with itself (flattering: hot operands)
+    gbs = {k: hbm_bytes[k] / kt_seq[k] / 1e9 for k in flops}
     # SURVEY.md 8(d) declares the MLP forward / backward / weight-gradient kernels MFMA-bound: `roofline` is the FLOP view
     # (algorithmic FLOPs of 8(d) x rows of one launch / the launch's average duration, against the dense bf16 MFMA peak).
     # The kernels also stream this design's 16-bit activation / gradient stash through HBM (far more than 8(d)'s
     # algorithmic 32 B/row): that byte model and the rate it implies are reported beside it as `design_traffic`.
-    measured, mfma_pmc = None, None
+    measured, mfma_pmc, traffic_source = None, None, None
     pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
                "mlp_wgrad": "npp::wgrad_kernel"}
     try:     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
              # doubled per the gfx950 note in MI355X_MICROARCH.md): the newest summary committed under profiles/
         import glob
-        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))[-1]))
+        pm_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))[-1]
+        pm = json.load(open(pm_path))
         measured = pm["kernels"][pmc_key[dom]]["hbm_bytes"]
+        traffic_source = ("profiles/" + os.path.basename(pm_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, committed; "
+                          "NOT collected in this run)")
     except (OSError, IndexError, KeyError, ValueError):
         measured = None
     try:     # matrix-pipe busy fraction of the same kernel from SQ_VALU_MFMA_BUSY_CYCLES (tools/pmc_sq.sh), same source
@@ -376,18 +429,22 @@ def main():
     except (OSError, IndexError, KeyError, ValueError):
         mfma_pmc = None
     roofline = {"bound": "mfma", "kernel": dom, "achieved": tf[dom], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf[dom] / PEAK_BF16_TFLOPS, "traffic": measured,
-                "algorithmic_flops_per_launch": flops[dom], "avg_launch_us": kt[dom] * 1e6,
+                "frac": tf[dom] / PEAK_BF16_TFLOPS, "traffic": measured, "traffic_source": traffic_source,
+                "algorithmic_flops_per_launch": flops[dom], "avg_launch_us": kt_seq[dom] * 1e6,
+                "timing": "HIP events between the launches of complete MLP-only steps (in sequence, cold operands), median of 30",
                 "design_traffic": {"note": "HBM view of the same launch: bytes of this design's stash arrays (every array once "
                                            "per job), NOT SURVEY 8(d)'s algorithmic bytes (32 B/row + weights)",
                                    "bytes_per_launch": hbm_bytes[dom], "GB_per_s": gbs[dom], "frac_of_8TBs": gbs[dom] / PEAK_HBM_GBS,
                                    "survey_8d_algorithmic_bytes_per_step": bp * 32 + 2.4e6 + 28 * n_par},
                 "mfma_pipe_busy_frac_pmc": mfma_pmc,
-                "all_kernels_us": {k: round(v * 1e6, 2) for k, v in kt.items()},
+                "all_kernels_us_in_sequence": {k: round(v * 1e6, 2) for k, v in kt_seq.items()},
+                "all_kernels_us_tight_loop": {k: round(v * 1e6, 2) for k, v in kt.items()},
                 "all_kernels_tflops": {k: round(v, 1) for k, v in tf.items()},
+                "all_kernels_tflops_tight_loop": {k: round(v, 1) for k, v in tf_tight.items()},
                 "all_kernels_design_traffic_GBs": {k: round(v, 0) for k, v in gbs.items()},
                 "all_kernels_mfma_frac": {k: round(v / PEAK_BF16_TFLOPS, 4) for k, v in tf.items()},
                 "render_mfma_frac": 2 * fwd_macs * H * H / kt["render_fwd_512sq"] / 1e12 / PEAK_BF16_TFLOPS,
+                "patch_source_mix_in_timed_steps": mix_timed,
                 "mlp_flops_over_full_step_frac": 2 * train_macs * n_rows / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
     render_px_s = H * H / kt["render_fwd_512sq"]
 
@@ -587,17 +644,6 @@ def main():
         remap["note"] = ("rng_reference reproduces np.random.choice(1 048 576, 8192, replace=False) draw for draw: one full permutation of "
                          "the pixel pool per iteration on the host (3.5 ms, the loop is host-bound); rng_fast is device-bound")
 
-    # ---- the one collective of the job: gather the fitted images -------------------------
-    gather_ms = None
-    if dist is not None:
-        out = fit.render_image().contiguous()
-        bufs = [torch.empty_like(out) for _ in range(world)]
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        dist.all_gather(bufs, out)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(K, H, patch, n_pix, fit.patch_num, fit.topk)
@@ -623,9 +669,9 @@ def main():
                                     if e2e and "same_stream_native_rng_producer_thread" in e2e else None),
             "render_pixels_per_s_per_gpu": render_px_s,
             "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters": final_psnr,
-            "final_gather_ms": gather_ms, "per_rank_rows_per_s": per_rank,
-            "collective": None if dist is None else {"backend": backend + (" (RCCL)" if backend == "nccl" else ""),
-                                                     "ranks": dist.get_world_size()},
+            "final_gather_ms": gather_ms, "per_rank_rows_per_s": per_rank if per_rank is not None else [value],
+            "collective": {"backend": None, "ranks": 1} if dist is None else {"backend": backend + (" (RCCL)" if backend == "nccl" else ""),
+                                                                              "ranks": dist.get_world_size()},
             "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
             "netwidth_512_fused": w512, "remapping_task_1024sq": remap,
@@ -634,6 +680,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -472,7 +472,7 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
   if (threadIdx.x < 7) {
     const int k = threadIdx.x;
     float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    if (k == 0) atomicAdd(a.loss_out, v * inv);
+    if (k == 0) atomicAdd(a.loss_out, weight * v * inv);      // the term as it enters the total (train.py:195-198: `loss = 0` under --no_pix_loss)
     else if (k < 4) atomicAdd(a.dlatent + (k - 1), weight * inv * v * cp[k - 1].dalpha_dl);
     else atomicAdd(a.dlatent + 3 + (k - 4), weight * inv * v * cp[k - 4].dc_dl);
   }

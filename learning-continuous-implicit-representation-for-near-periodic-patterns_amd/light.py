@@ -123,25 +123,30 @@ class NPPNetLight:
     def backward(self, B):
         """loss.backward(): consumes ws['dpred'] = dL/dpred, fills self.grad."""
         ws, W = self._ws[B], self.W
+        # the seven weight-gradient launches split their contraction and meet by atomicAdd in a zeroed output: ONE clear of the
+        # whole gradient blob + accumulate, instead of a memset per dW and per db (14 fills of ~4.4 us = 15 % of the iteration)
+        self.grad.zero_()
         ops.act_bwd(ws["dpred"], ws["pred"], _SIGMOID, ws["draw"])
-        ops.linear_bwd_weight(ws["draw"], ws["ap"], self.dw["rgb_linear"], self.db["rgb_linear"])
+        ops.linear_bwd_weight(ws["draw"], ws["ap"], self.dw["rgb_linear"], self.db["rgb_linear"], accumulate=True)
         ops.linear_bwd_data(ws["draw"], self.w["rgb_linear"], ws["dap"])
         ops.act_bwd(ws["dap"], ws["zp"], _SNAKE, ws["dzp"])
-        ops.linear_bwd_weight(ws["dzp"], ws["hp"], self.dw["pos_linears.0"], self.db["pos_linears.0"])
+        ops.linear_bwd_weight(ws["dzp"], ws["hp"], self.dw["pos_linears.0"], self.db["pos_linears.0"], accumulate=True)
         ops.linear_bwd_data(ws["dzp"], self.w["pos_linears.0"], ws["df1"], in_used=W)                    # no gradient to input_pos
-        ops.linear_bwd_weight(ws["df1"], ws["h"][self.D - 1], self.dw["feature_linear1"], self.db["feature_linear1"])
+        ops.linear_bwd_weight(ws["df1"], ws["h"][self.D - 1], self.dw["feature_linear1"], self.db["feature_linear1"], accumulate=True)
         ops.linear_bwd_data(ws["df1"], self.w["feature_linear1"], ws["dh"])
         for i in range(self.D - 1, -1, -1):
             name = f"periodic_linears.{i}"
             ops.act_bwd(ws["dh"], ws["z"][i], _SNAKE, ws["dz"])
             x_in = ws["h"][i - 1] if i > 0 else ws["x_per"]
-            ops.linear_bwd_weight(ws["dz"], x_in, self.dw[name], self.db[name])
+            ops.linear_bwd_weight(ws["dz"], x_in, self.dw[name], self.db[name], accumulate=True)
             if i > 0:
                 ops.linear_bwd_data(ws["dz"], self.w[name], ws["dh"])
 
-    def train_step(self, x_pos, x_per, gt):
+    def train_step(self, x_pos, x_per, gt, hp=None):
         """One iteration of search.py:113-147: render -> zero_grad -> img2mse(robust_loss_adaptive) -> backward -> Adam ->
-        LR rule (set after the step) -> global_step += 1."""
+        LR rule (set after the step) -> global_step += 1.  hp (2 floats on the device: lr / (1 - b1^t), 1 / sqrt(1 - b2^t)):
+        the Adam launches read their step-dependent scalars from there (npp_adam_step_dev), so that the launch sequence is
+        identical from iteration to iteration and can be replayed as a HIP graph (ProposalRanker.fit_candidate)."""
         B = x_per.shape[0]
         pred = self.forward(x_pos, x_per)
         ws = self._ws[B]
@@ -149,12 +154,33 @@ class NPPNetLight:
         self.dlatent.zero_()
         ops.pixel_loss(pred, gt, None, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, self.loss_buf, ws["dpred"], self.dlatent)
         self.backward(B)
-        self.opt_step += 1
-        ops.adam_step(self.params, self.m, self.v, self.grad, 1, self.n_params, self.lr, self.opt_step)
-        ops.adam_step(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, self.lr, self.opt_step)
+        if hp is None:
+            self.opt_step += 1
+            ops.adam_step(self.params, self.m, self.v, self.grad, 1, self.n_params, self.lr, self.opt_step)
+            ops.adam_step(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, self.lr, self.opt_step)
+            self.advance_clock()
+        else:
+            ops.adam_step_dev(self.params, self.m, self.v, self.grad, 1, self.n_params, hp)
+            ops.adam_step_dev(self.latents, self.lat_m, self.lat_v, self.dlatent, 1, 6, hp)
+        return self.loss_buf
+
+    def advance_clock(self):
+        """The host half of an optimiser step: the LR rule of search.py:139-147 (set AFTER the step) and global_step += 1."""
         self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
         self.global_step += 1
-        return self.loss_buf
+
+    def adam_scalars(self, n_steps, b1=0.9, b2=0.999):
+        """(n_steps, 2) float32: [lr_t / (1 - b1^t), 1 / sqrt(1 - b2^t)] of the NEXT n_steps optimiser steps -- exactly the values
+        npp_adam_step computes on the host from (lr, step) -- without advancing the clock."""
+        out = np.zeros((n_steps, 2), np.float32)
+        lr, gs = self.lr, self.global_step
+        for i in range(n_steps):
+            t = self.opt_step + 1 + i
+            out[i, 0] = np.float32(float(lr) / (1.0 - b1 ** t))
+            out[i, 1] = np.float32(1.0 / np.sqrt(1.0 - b2 ** t))
+            lr = self.lrate * (0.1 ** (gs / (self.lrate_decay * 100)))
+            gs += 1
+        return out
 
     @torch.no_grad()
     def render(self, coords_yx, chunk=20000):
@@ -233,17 +259,61 @@ class ProposalRanker:
             self._draws = torch.from_numpy(np.ascontiguousarray(np.stack(sel), np.int64)).to(self.device)   # once per image: plain copy
         return self._draws
 
-    def fit_candidate(self, angles_deg, periods, params=None):
+    def fit_candidate(self, angles_deg, periods, params=None, use_graph=None):
+        """search.py:85-147 for one candidate.  The iteration is ~40 small dependent launches on 2048 rows.
+        use_graph=True (or NPP_LIGHT_GRAPH=1): iterations 2 .. N replay ONE captured HIP graph (torch.cuda.CUDAGraph: the same
+        kernels in the same order; the iteration's inputs -- pixel-row indices, Adam's step-dependent scalars -- are read from
+        fixed device buffers).  Built in round 3 on the hypothesis that the host's enqueue rate bounded the loop; MEASURED: it does
+        not -- eager 0.400 ms per iteration, graph replay 0.417-0.44 (profiles/r03_rejected_experiments.txt): the device time of the
+        twenty 2048 x 256 x 256 exact-fp32 GEMM launches (14-18 us each) is the bound.  Kept as an option (parity-tested), off."""
+        import os
         net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
                           params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
                           device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
         x_pos_all, x_per_all = net.embed(self.i_train_dev)                                           # search.py:104-108 tables
         draws = self._pixel_draws()
-        for it in range(self.N_iters):
+        if use_graph is None:
+            use_graph = os.environ.get("NPP_LIGHT_GRAPH", "0") != "0"
+
+        def eager(it):
             idx = draws[it]
             c = self.i_train_dev[idx]
             gt = self.img[c[:, 0].long(), c[:, 1].long()].contiguous()
             net.train_step(x_pos_all[idx].contiguous(), x_per_all[idx].contiguous(), gt)
+        if not use_graph or self.N_iters < 3:
+            for it in range(self.N_iters):
+                eager(it)
+            return net
+        eager(0)                                                   # iteration 1 eagerly: first-call setup, workspaces
+        n_rest = self.N_iters - 1
+        # per-iteration inputs of the captured launches, one table row per iteration: [pixel-row indices | Adam scalars (as int64 bits)]
+        hp_tab = torch.from_numpy(net.adam_scalars(n_rest)).to(self.device)
+        idx_s = draws[1].clone()
+        hp_s = hp_tab[0].clone()
+
+        def body():
+            c = self.i_train_dev[idx_s]
+            gt = self.img[c[:, 0].long(), c[:, 1].long()].contiguous()
+            net.train_step(x_pos_all[idx_s].contiguous(), x_per_all[idx_s].contiguous(), gt, hp=hp_s)
+        side = torch.cuda.Stream(self.device)                      # capture needs a non-default stream; one un-captured pass warms its pool
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        snap = [t.clone() for t in (net.params, net.m, net.v, net.latents, net.lat_m, net.lat_v)]
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for t, s_ in zip((net.params, net.m, net.v, net.latents, net.lat_m, net.lat_v), snap):     # the warm-up pass was not an iteration
+            t.copy_(s_)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            body()
+        for j in range(n_rest):
+            if j:
+                idx_s.copy_(draws[1 + j])
+                hp_s.copy_(hp_tab[j])
+            graph.replay()
+            net.opt_step += 1
+            net.advance_clock()
+        self._graph_keep = (graph, idx_s, hp_s, hp_tab)            # alive until the replays have run
         return net
 
     def fit_candidates(self, cands, n_streams=8):
@@ -252,6 +322,10 @@ class ProposalRanker:
         each on one of n_streams side streams -- the launch gaps of one fit are filled by the others.  Same arithmetic per
         candidate as the serial form; the pixel rows and their colours (identical for every candidate, see _pixel_draws) are
         gathered once."""
+        import os
+        if os.environ.get("NPP_LIGHT_GRAPH", "0") != "0" and self.N_iters >= 3:
+            # graph replay makes one fit device-bound (fit_candidate): the candidates simply run one after the other
+            return [self.fit_candidate(a_, p_) for a_, p_ in cands]
         main = torch.cuda.current_stream(self.device)
         draws = self._pixel_draws()
         c_all = self.i_train_dev[draws.reshape(-1)].long()
@@ -261,7 +335,8 @@ class ProposalRanker:
             net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img), default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
                               device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
             tabs.append(net.embed(self.i_train_dev))
-            nets.append(net)
+            net._work(draws.shape[1])            # workspace allocated on the MAIN stream (score() / render() use it there after the join;
+            nets.append(net)                      # blocks first touched on a side stream would return to that stream's pool)
         streams = [torch.cuda.Stream(self.device) for _ in range(max(1, min(int(n_streams), len(nets))))]
         for st in streams:
             st.wait_stream(main)

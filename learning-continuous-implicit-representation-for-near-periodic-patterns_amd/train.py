@@ -7,8 +7,8 @@ Reads config.odgt + PNGs (npp_amd.io), builds the net with torch's default nn.Li
 frequencies drawn from torch's global generator like the reference (models/embedder.py:26, models/networks.py:40-49;
 seed with --seed), runs N_iters iterations of the complete loop body (CompletionFit.step_full) and writes
 results/<expname>_top<K>/<name>/testset_<iter>/*.png every --i_testset iterations (train.py:270-328).
-Flags keep the reference's names and defaults (options/arg_config.py:10-36,55-100) except --netwidth, whose default here
-is 256 (BASELINE.json's configuration); the reference's default 512 is the second fused build (libnpp_hip_w512.so).
+Flags keep the reference's names and defaults (options/arg_config.py:10-36,55-100), --netwidth included: the default is the
+reference's 512 (the second fused build, libnpp_hip_w512.so); BASELINE.json's configurations are --netwidth 256.
 """
 import argparse
 import os
@@ -155,7 +155,11 @@ def main(argv=None):
                         shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
                         num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
                         patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
-                        vgg16_state_dict=load(args.vgg16), lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
+                        # --vgg16: the LPIPS trunk (completion) or the STYLE trunk of the remapping task (models/style_loss.py:11,
+                        # VGG16FeatureExtractor; LPIPS is off there, NPP_remapping/train.py:253-261)
+                        vgg16_state_dict=None if remap else load(args.vgg16),
+                        vgg16_style_state_dict=load(args.vgg16) if remap else None,
+                        lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
                         task=args.task, clear_mask=d["clear_mask"] if remap else None,
                         masked_img=None if remap else d.get("masked_img"),
                         contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
@@ -167,6 +171,27 @@ def main(argv=None):
     from concurrent.futures import ThreadPoolExecutor
     writer, pending = ThreadPoolExecutor(1), []
     t0 = time.time()
+    try:
+        _train_loop(args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0)
+    except BaseException:
+        # a fit that dies mid-loop must not leave an output directory behind that a re-run would take for a finished one
+        # (`file exists, exit!!` above), nor the sampler's producer thread / the writer pool alive
+        import shutil
+        shutil.rmtree(outroot, ignore_errors=True)
+        raise
+    finally:
+        fit.close()                                         # the sampler's producer thread
+        for p in pending:
+            if not p.cancel():
+                try:
+                    p.result()
+                except Exception as e:                     # a failed write: report, keep the original exception (if any)
+                    print(f"[WARN] writing a test set failed: {e}")
+        writer.shutdown()
+    return fit
+
+
+def _train_loop(args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0):
     for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
         fit.step_full()
         if i % args.i_testset == 0:
@@ -198,11 +223,6 @@ def main(argv=None):
         if i % args.i_print == 0:
             print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
                   f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
-    fit.close()                                             # the sampler's producer thread
-    for p in pending:
-        p.result()                                          # (re-raises a failed write)
-    writer.shutdown()
-    return fit
 
 
 if __name__ == "__main__":

@@ -204,10 +204,10 @@ def test_ranking_prefers_the_true_periodicity(dev):
     assert np.all(np.diff(d) >= 0) and all(np.isfinite(x[0]) for x in details)
 
 
-def test_concurrent_candidate_fits_equal_the_serial_ones(dev):
-    """ProposalRanker.fit_candidates (all candidates advanced together on side streams) against fit_candidate (one after the
-    other): the same fitted parameters (split-K float atomics in the weight gradients give run-to-run noise of ~1e-6) and the
-    same scores."""
+def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
+    """ProposalRanker.fit_candidates -- all candidates advanced together on side streams (default), or iterations 2 .. N of each
+    fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against the eager fit_candidate loop: the same fitted
+    parameters (split-K float atomics in the weight gradients give run-to-run noise of ~1e-6), step counts, LR clock and scores."""
     from npp_amd.light import ProposalRanker
     H = 128
     img, mask = oracle.synthetic_image(H, noise=0.01)
@@ -218,14 +218,21 @@ def test_concurrent_candidate_fits_equal_the_serial_ones(dev):
     ranker = ProposalRanker(img, i_train, i_val, device=dev, N_iters=40, N_rand=1024)
     cands = [(angles[0], periods[0]), (angles[0], periods[0] * 1.37), (angles[0] + 35.0, periods[0]), (angles[0] + 10.0, periods[0] * 0.8),
              (angles[0], periods[0] * 2.0)]
+    monkeypatch.setenv("NPP_LIGHT_GRAPH", "1")
+    graphed = ranker.fit_candidates(cands)
+    monkeypatch.setenv("NPP_LIGHT_GRAPH", "0")
     together = ranker.fit_candidates(cands, n_streams=3)
-    for (a, p), net in zip(cands, together):
-        alone = ranker.fit_candidate(a, p)
-        assert net.opt_step == alone.opt_step == 40
-        pa, pb = net.params.cpu().numpy(), alone.params.cpu().numpy()
-        assert np.linalg.norm(pa - pb) <= 1e-4 * np.linalg.norm(pb)
-        sa, sb = ranker.score(net), ranker.score(alone)
-        assert abs(sa[0] - sb[0]) <= 1e-3 * abs(sb[0])
+    for (a, p), net, netg in zip(cands, together, graphed):
+        alone = ranker.fit_candidate(a, p, use_graph=False)
+        assert net.opt_step == netg.opt_step == alone.opt_step == 40
+        assert netg.global_step == alone.global_step and netg.lr == alone.lr
+        pb = alone.params.cpu().numpy()
+        for other in (net, netg):
+            assert np.linalg.norm(other.params.cpu().numpy() - pb) <= 1e-4 * np.linalg.norm(pb)
+            np.testing.assert_allclose(other.latents.cpu().numpy(), alone.latents.cpu().numpy(), atol=1e-5)
+        sb = ranker.score(alone)
+        for other in (net, netg):
+            assert abs(ranker.score(other)[0] - sb[0]) <= 1e-3 * abs(sb[0])
 
 
 @pytest.mark.parametrize("tag,K", [("small_k3", 3), ("small_k1", 1)])

@@ -894,3 +894,108 @@ def test_two_row_group_step_equals_the_single_stream_step(dev, source):
         assert rel_l2(ga[k_], gb[k_]) < 6e-3, k_
     assert abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) < 1e-6 * abs(float(b.net.loss_buf[0])) + 1e-9
     assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
+
+
+def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=30):
+    """Shared body of the g8r / g8s / g8d tests: sampler decisions call by call, weighted patch loss of the first iterations value
+    by value (the goldens use the stable tie order, tests/golden/make_golden_fit_tasks.py), PSNR checkpoints within BASELINE's
+    0.1 dB, pixel-loss latents, LR clock."""
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    ploss = {int(r[0]): r[1] for r in g["patch_loss"]}
+    code = {"val": 0, "train": 1, "same": 2}
+    n_same = 0
+    for i in range(1, n_iters + 1):
+        ok = fit.step_full()
+        d = fit.last_draw
+        assert (code[d["source"]], d["k"]) == tuple(int(v) for v in g["seq"][i - 1]), i
+        assert ok == (d["k"] > 0) == (i in ploss)
+        if ok:
+            n_same += d["source"] == "same"
+            if i <= n_loss:
+                got = float(fit.last_patch_loss[0])
+                assert abs(got - ploss[i]) < loss_tol * abs(ploss[i]), (i, d["source"], got, ploss[i])
+        if i in traj:
+            pk, pu = fit.psnr("known"), fit.psnr("unknown")
+            assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i])
+    assert fit.net.global_step == int(g["global_step"])
+    np.testing.assert_allclose(fit.net.latents.cpu().numpy(), np.concatenate([g["latent_alpha"], g["latent_scale"]], 1).reshape(-1),
+                               atol=3e-3)
+    return n_same
+
+
+def test_remapping_loop_trajectory_vs_reference_g8r(dev, golden):
+    """NPP_remapping/train.py:158-300 driven from the reference's modules (g8r_fit_remap.npz: GridPatchSampler on the clear mask,
+    img2mse with gt_mask = clear_mask, contextual_loss + VGG16FeatureExtractor.style_loss (adaptive) on comp / pred patches, all
+    latents in one Adam): the build's CompletionFit(task='remapping') from the same weights, frequencies and NumPy stream --
+    identical sampler decisions, patch loss (style + 0.01 CX) within 3 %, PSNR within 0.1 dB on the clear / blurry regions, and
+    where the style latents end up (level 0 in full, a fixed sample of the two larger levels)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8r_fit_remap.npz")
+    H, N_rand = int(g["H"]), int(g["N_rand"])
+    img, _ = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    clear = np.ones((H, H, 1), np.float32)
+    clear[H // 3:H // 2] = 0.0
+    fit = CompletionFit(img, np.ones((H, H, 1), np.float32), angles, periods, g["freqs"], reference_init(1), device=dev, N_rand=N_rand,
+                        seed=0, ksplit=4, shifts=shifts, rng_mode="reference", task="remapping", clear_mask=clear,
+                        contextual_weight=0.01, style_weight=1.0, use_perceptual_loss=False)
+    assert fit.patch_size == 64 and fit.i_train.shape[0] == H * H
+    _run_task_golden(dev, g, fit)
+    for k in range(3):
+        lat = fit.style.latents[k].cpu().numpy()
+        D = lat.size // 2
+        idx = g[f"sidx{k}"]
+        np.testing.assert_allclose(lat[:D][idx], g[f"sla{k}"], atol=3e-3)
+        np.testing.assert_allclose(lat[D:][idx], g[f"sls{k}"], atol=3e-3)
+
+
+def test_segmentation_loop_trajectory_vs_reference_g8s(dev, golden):
+    """NPP_segmentation/train.py:148-290 driven from the reference's modules (g8s_fit_segment.npz): the initial periodic region
+    is the known mask and the 'train' pool, the input image is what is trained and sampled on, contextual weight 0.005, no
+    LPIPS, and the learning rate never decays (`global_step += 1` is outside the reference's loop, :408 -- reproduced)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8s_fit_segment.npz")
+    H, N_rand = int(g["H"]), int(g["N_rand"])
+    img, _ = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
+    period = (1.0 - (((yy - 0.6 * H) ** 2 + (xx - 0.4 * H) ** 2) < (H / 8) ** 2).astype(np.float32))[..., None]
+    fit = CompletionFit(img, period, angles, periods, g["freqs"], reference_init(1), device=dev, N_rand=N_rand, seed=0, ksplit=4,
+                        shifts=shifts, rng_mode="reference", task="segmentation", masked_img=img, contextual_weight=0.005,
+                        use_perceptual_loss=False)
+    assert int(g["global_step"]) == 0 and fit.net.lr_clock is False
+    # (contextual weight 0.005 on patches the fit reproduces almost exactly by then: from ~iteration 25 on the weighted patch
+    #  loss is ~2e-6 and the fp16 trunk's rounding is 5 % of it)
+    _run_task_golden(dev, g, fit, n_loss=20)
+    assert fit.net.lr == 5e-4
+
+
+def test_full_loop_with_lpips_stable_ties_vs_reference_g8d(dev, golden):
+    """g8c with the reference's tie order DEFINED (torch.topk replaced by its stable realisation while the golden was made): the
+    weighted patch loss of 'val' / 'train' iterations is then comparable value by value too -- asserted at 3 % for every source,
+    where g8c had to allow 35 % for the backend-defined choice among equidistant lattice candidates."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8d_fit_lpips_stable.npz")
+    H, N_rand = int(g["H"]), int(g["N_rand"])
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(1), device=dev, N_rand=N_rand, seed=0, ksplit=4,
+                        shifts=shifts, rng_mode="reference", use_perceptual_loss=True,
+                        lpips_lin_weights=[g[f"lin{k}"] for k in range(5)])
+    n_same = _run_task_golden(dev, g, fit)
+    assert n_same == len(g["lpips_values"])
+    for k, lat in enumerate(fit.percepLoss.latents):
+        want = np.concatenate([g[f"la{k}"].reshape(-1), g[f"ls{k}"].reshape(-1)])
+        np.testing.assert_allclose(lat.cpu().numpy(), want, atol=2e-3)
