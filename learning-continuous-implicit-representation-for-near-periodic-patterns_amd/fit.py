@@ -52,6 +52,10 @@ class CompletionFit:
         # under the patch-loss chain of the patch rows ("a/b": split-K slabs of the pixel rows / of the patch rows).
         ov = os.environ.get("NPP_FIT_OVERLAP", "0")      # measured NEGATIVE (profiles/r03_rejected_experiments.txt): default off
         self.overlap = ov != "0"
+        # Real-half prefetch (step_from(b, next_b)): the trunk features of the NEXT iteration's real patches are computed on a
+        # side stream under this iteration's trunk / contextual chain; see ContextualLoss.prefetch_y.
+        self.prefetch_real = os.environ.get("NPP_FIT_PREFETCH_REAL", "0") != "0"      # measured NEGATIVE: default off
+        self._fy, self._lookahead = None, None
         self.overlap_ks = tuple(int(v) for v in os.environ.get("NPP_FIT_OVERLAP_KS", "4/12").split("/"))
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
@@ -131,6 +135,7 @@ class CompletionFit:
             self._xy, self._xy_key = None, None
             self._s_lp = torch.cuda.Stream(self.device)
             self._s_pix = torch.cuda.Stream(self.device)
+            self._s_y = torch.cuda.Stream(self.device)
             self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
@@ -190,6 +195,28 @@ class CompletionFit:
                 raise d
         else:
             d = self.draw_batch()
+        if self.prefetch_real and self.task == "completion" and self._prefetch > 0:     # (with the producer thread only: state_dict()
+            #                                                                           refuses there anyway, the stream being ahead)
+            # one batch of lookahead: the sampler never reads network state, so drawing and materialising iteration i + 1's
+            # batch before iteration i runs changes nothing -- and lets step_from start the next real half's trunk pass early
+            cur = self._lookahead if self._lookahead is not None else (d, self.materialise_batch(d))
+            if self._lookahead is not None:
+                nxt_d = d
+            elif self._prefetch > 0:
+                nxt_d = self._queue.get()
+                if isinstance(nxt_d, BaseException):
+                    raise nxt_d
+            else:
+                nxt_d = self.draw_batch()
+            self._lookahead = (nxt_d, self.materialise_batch(nxt_d))
+            d, batch = cur
+            self.last_draw = d
+            self.iteration += 1
+            if batch is None:
+                self.skipped += 1
+                return False
+            self.step_from(batch, self._lookahead[1])
+            return True
         self.last_draw = d                                        # host-side record of this iteration's draws (tests, logging)
         batch = self.materialise_batch(d)
         self.iteration += 1
@@ -275,11 +302,14 @@ class CompletionFit:
     def __del__(self):
         self._stop = True
 
-    def step_from(self, b):
+    def step_from(self, b, next_b=None):
         """Device side of one iteration (everything after sampling), train.py:183-264, as explicit kernel
         launches (no autograd): fused forward -> pixel loss -> patch plumbing (npp_patch_compose_fwd) -> VGG19 trunk
         -> contextual loss core -> trunk data-gradient (-> the same through VGG16 / LPIPS head on 'same' iterations)
-        -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam."""
+        -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam.
+        next_b: the batch of the NEXT iteration (when the caller has it): its real patches' trunk features are computed on a
+        side stream under this iteration's trunk / contextual chain, and that iteration then runs its trunk forward on the
+        prediction half only."""
         ops.check_current(self.device)
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
@@ -332,9 +362,31 @@ class CompletionFit:
         # the comparator of tests/test_gpu_parity.py and for A/B timing)
         if not fold:
             net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
+        # the real half's features may have been computed during the previous iteration (below): then only the prediction half
+        # goes through the trunk now.  Only on iterations whose other consumers do not need the fp32 [x | y] batch.
+        fy = None
+        if self._fy is not None and self._fy[0] is b and xy is None and self.use_contextual_loss:
+            fy, ev = self._fy[1], self._fy[2]
+            main.wait_event(ev)
+            fy.record_stream(main)
+        self._fy = None
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
-                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf,
+                           cx.hip_trunk.input_buffer((1 if fy is not None else 2) * nk, P, P), xy, self.patch_loss_buf,
+                           which=1 if fy is not None else 0,
                            loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if (fold and not split) else None)
+        if (self.prefetch_real and fold and next_b is not None and next_b["source"] != "same" and self.style is None
+                and self.use_contextual_loss and cx.trunk_kind == "hip"):
+            # next iteration's real half: starts once this iteration's forward and plumbing are out of the way (event), runs
+            # beside the chain that follows
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            self._s_y.wait_event(ev0)
+            with torch.cuda.stream(self._s_y):
+                nraw = next_b["raw"]
+                fy_next = cx.prefetch_y(nraw["real"], nraw["rmask"], next_b["n_p"], next_b["k"], next_b["P"])
+                ev1 = torch.cuda.Event()
+                ev1.record(self._s_y)
+            self._fy = (next_b, fy_next, ev1)
         dx_b = None
         # use_patch_weight (train.py:224-250): contextual term sum_i -log(cx_i w_i + 1e-5) (the core's weighted form), LPIPS term
         # sum_i d_i w_i -- on 'same' iterations the weights are all 1 (sampler.py:338), i.e. nk times the mean
@@ -344,7 +396,9 @@ class CompletionFit:
             with torch.cuda.stream(self._s_lp):
                 dx_b = self.percepLoss.fused(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf, normalize=True)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
-        if self.use_contextual_loss:
+        if fy is not None:
+            dx_a = cx.fused_x((nk, 3, P, P), fy, self.cx_w, self.patch_loss_buf, weight=weight)
+        elif self.use_contextual_loss:
             dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, weight=weight, x0_ready=True)   # train.py:238-239
         else:                                                                                       # ablation: no contextual term
             dx_a = torch.zeros((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)

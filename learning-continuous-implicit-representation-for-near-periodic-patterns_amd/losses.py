@@ -141,6 +141,14 @@ class HipTrunk:
         self.final_next_pack = None
         self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
 
+    def twin(self):
+        """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
+        two passes through the stack may then be in flight on different streams (ContextualLoss.prefetch_y)."""
+        t = HipTrunk.__new__(HipTrunk)
+        t.device, t.taps, t.layers = self.device, self.taps, self.layers
+        t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
+        return t
+
     def _pb_below(self, j):
         """The backward pack of the next convolution layer below layer j (what the data-gradient pass runs next)."""
         if not self.prefetch_next:
@@ -329,6 +337,33 @@ class ContextualLoss(nn.Module):
         f = t._forward(xy, sc, sh, x0_ready)[0]
         _, dfx = ops.cx_fwd_bwd(f[:n], f[n:], self.band_width, weight, scale, loss_buf, True)
         return t._backward([dfx], n, sc, tuple(xy) if x0_ready else tuple(xy.shape), zero_rest=False)
+
+
+    # ---- the two halves of the contextual batch as separate passes (round 3) -----------------------------------------------
+    # The REAL half of the batch (the y images: crops of the input image, train.py:206-208,235-236) does not depend on the
+    # network: its trunk features can be computed while something else runs.  CompletionFit.step_from(b, next_b) computes the
+    # features of the NEXT iteration's real patches on a side stream under the current iteration's trunk / contextual chain
+    # (both are chains of small dependent launches that leave most of the chip idle) and the next iteration then pushes only
+    # its prediction half through the trunk: the forward pass on the critical path handles n images instead of 2 n.
+    def prefetch_y(self, real, rmask, n_p, k, P):
+        """Trunk features of the real half, (n_p k, 256, P/4, P/4) fp32, on the current stream (a trunk executor of its own)."""
+        if not hasattr(self, "_trunk_y"):
+            self._trunk_y = self.hip_trunk.twin()
+        t = self._trunk_y
+        sc, sh = self.input_norm()
+        nk = n_p * k
+        ops.trunk_patch_in(None, None, None, real, rmask, n_p, k, P, False, sc, sh, t.input_buffer(nk, P, P), None, None, which=2)
+        return t._forward((nk, 3, P, P), sc, sh, True)[0]
+
+    def fused_x(self, shape_x, fy, scale, loss_buf, weight=None):
+        """fused() for a batch that holds ONLY the prediction half (its normalised flat form already written into
+        hip_trunk.input_buffer(), ops.trunk_patch_in(which=1)); fy: the real half's features from prefetch_y().
+        Returns dL/dx (n,3,P,P)."""
+        t = self.hip_trunk
+        sc, sh = self.input_norm()
+        fx = t._forward(tuple(shape_x), sc, sh, True)[0]
+        _, dfx = ops.cx_fwd_bwd(fx, fy, self.band_width, weight, scale, loss_buf, True)
+        return t._backward([dfx], shape_x[0], sc, tuple(shape_x), zero_rest=False)
 
 
 class _LPIPSLayerFunction(torch.autograd.Function):

@@ -44,6 +44,9 @@ print("split vs unsplit: worst rel-L2 gradient difference", worst, " params max 
       " loss", float(fa.net.loss_buf), float(fb.net.loss_buf))
 
 
+PIPE = os.environ.get("R3_PIPE", "0") == "1"
+
+
 def run(mode, ks, n=100):
     fit.overlap = mode
     fit.overlap_ks = ks
@@ -52,7 +55,7 @@ def run(mode, ks, n=100):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        fit.step_from(pool[i % len(pool)])
+        fit.step_from(pool[i % len(pool)], pool[(i + 1) % len(pool)] if PIPE else None)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
