@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "npp_hip.h"
 
 namespace npp { void set_error(const char* fmt, ...); }   // npp_api.hip
@@ -144,11 +148,9 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
     return NPP_OK;
   }
   uint32_t* perm = (uint32_t*)scratch;
-  for (uint32_t i = 0; i < (uint32_t)n; ++i) perm[i] = i;
   constexpr int kBlock = 2048, kAhead = 12;
-  uint32_t jbuf[kBlock + kAhead];
-  uint32_t i = (uint32_t)(n - 1);
-  while (i > 0) {
+  // generation of one block: the next <= kBlock accepted targets for the bounds i, i - 1, ... (consumes generator words)
+  auto gen_block = [s](uint32_t i, uint32_t* jbuf) -> int {
     int cnt = 0;
     uint32_t bound = i;
     while (cnt < kBlock && bound > 0) {
@@ -169,13 +171,67 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
       s->pos += u;
     }
     for (int k = cnt; k < cnt + kAhead; ++k) jbuf[k] = 0;
+    return cnt;
+  };
+  auto apply_block = [perm](uint32_t i, const uint32_t* jbuf, int cnt) {
     for (int k = 0; k < cnt; ++k) {
       __builtin_prefetch(&perm[jbuf[k + kAhead]], 1, 1);
       const uint32_t j = jbuf[k], t = perm[i - (uint32_t)k];
       perm[i - (uint32_t)k] = perm[j];
       perm[j] = t;
     }
-    i -= (uint32_t)cnt;
+  };
+  // Large populations (the 1 048 576 pixel rows / patch-centre pool of a 1024^2 image: two such shuffles per iteration, 3.5 ms,
+  // more than the device time of the iteration): the two halves of a block do not depend on each other beyond the targets --
+  // generating them needs only the generator, applying them only the array -- so a helper thread generates blocks into a small
+  // ring while this thread applies them.  Same words in the same order; the generator is touched by the helper alone until
+  // it is joined.  (A thread per call: ~30 us against >= 1 ms of work; below kThreadedMin the plain loop.)
+  constexpr int64_t kThreadedMin = 200000;
+  static const bool threaded_ok = [] { const char* e = getenv("NPP_RNG_THREADS"); return !(e && e[0] == '0'); }();
+  if (n >= kThreadedMin && threaded_ok) {
+    constexpr int kRing = 8;
+    struct Slot { uint32_t j[kBlock + kAhead]; uint32_t i; int cnt; };
+    std::vector<Slot> ring(kRing);
+    std::atomic<int64_t> produced{0}, consumed{0};
+    std::atomic<bool> done{false};
+    const uint32_t top = (uint32_t)(n - 1);
+    std::thread gen([&] {
+      uint32_t i = top;
+      int64_t b = 0;
+      while (i > 0) {
+        while (b - consumed.load(std::memory_order_acquire) >= kRing) __builtin_ia32_pause();
+        Slot& sl = ring[b % kRing];
+        sl.i = i;
+        sl.cnt = gen_block(i, sl.j);
+        i -= (uint32_t)sl.cnt;
+        ++b;
+        produced.store(b, std::memory_order_release);
+      }
+      done.store(true, std::memory_order_release);
+    });
+    for (uint32_t q = 0; q < (uint32_t)n; ++q) perm[q] = q;          // (overlaps the first blocks' generation)
+    int64_t b = 0;
+    for (;;) {
+      while (produced.load(std::memory_order_acquire) <= b) {
+        if (done.load(std::memory_order_acquire) && produced.load(std::memory_order_acquire) <= b) goto finished;
+        __builtin_ia32_pause();
+      }
+      const Slot& sl = ring[b % kRing];
+      apply_block(sl.i, sl.j, sl.cnt);
+      ++b;
+      consumed.store(b, std::memory_order_release);
+    }
+  finished:
+    gen.join();
+  } else {
+    for (uint32_t q = 0; q < (uint32_t)n; ++q) perm[q] = q;
+    uint32_t jbuf[kBlock + kAhead];
+    uint32_t i = (uint32_t)(n - 1);
+    while (i > 0) {
+      const int cnt = gen_block(i, jbuf);
+      apply_block(i, jbuf, cnt);
+      i -= (uint32_t)cnt;
+    }
   }
   for (int64_t k = size - 1; k >= 0; --k) out[k] = (int64_t)perm[k];   // out may alias scratch: widen from the top
   return NPP_OK;

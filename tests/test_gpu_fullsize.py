@@ -224,7 +224,7 @@ def test_c5_full_size_iteration_set(dev):
     assert bool(torch.isfinite(fit.net.params).all()) and fit.psnr() > max(p0 + 8.0, 25.0)
 
 
-@pytest.mark.parametrize("K,H,W", [(1, 256, 256), (3, 512, 256), (5, 512, 256), (3, 256, 512)])
+@pytest.mark.parametrize("K,H,W", [(1, 256, 256), (3, 512, 256), (5, 512, 256), (3, 256, 512), (3, 1024, 256)])    # last: config c4 itself
 def test_fused_fp32_render_matches_fp32_oracle(dev, K, H, W):
     """npp_mlp_fwd32 (BASELINE config c4's arithmetic: fused chain on v_mfma_f32_32x32x2_f32, f32 operands and accumulation)
     against the NumPy oracle in plain fp32 -- no bf16 emulation on either side -- on a row sample of the full grid, and
@@ -247,3 +247,48 @@ def test_fused_fp32_render_matches_fp32_oracle(dev, K, H, W):
     assert torch.equal(net.render_fp32(grid[perm].contiguous()), full[perm])
     cuts = [0, n // 4 + 1, n // 2 + 33, n]
     assert torch.equal(torch.cat([net.render_fp32(grid[a:b].contiguous()) for a, b in zip(cuts[:-1], cuts[1:])], 0), full)
+
+
+def test_c4_remapping_loop_at_1024sq(dev):
+    """BASELINE.json configs[3]'s TASK at its full size (1024 x 1024 remapping image, K = 3: whole image = 1 048 576 training
+    pixels, clear-region sampler mask, 0.3-weighted blurry pixels, contextual + Gram style loss, P = 160): five complete
+    iterations stay finite and train every latent group, and for one batch the explicit kernel sequence equals the autograd
+    restatement of NPP_remapping/train.py:198-262 over the same kernels (the reference trajectory of this loop is pinned at
+    256^2 by g8r; the oracle would need minutes per iteration here)."""
+    from npp_amd.fit import CompletionFit
+    H, K = 1024, 3
+    img, _ = oracle.synthetic_image(H, seed=7)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    clear = np.ones((H, H, 1), np.float32)
+    clear[H // 3:H // 2] = 0.0
+
+    def make():
+        return CompletionFit(img, np.ones((H, H, 1), np.float32), angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0),
+                             device=dev, N_rand=8192, seed=0, shifts=shifts, task="remapping", clear_mask=clear, rng_mode="fast",
+                             contextual_weight=0.01, style_weight=1.0, use_perceptual_loss=False)
+    fit = make()
+    assert fit.patch_size == 160 and fit.i_train.shape[0] == H * H and fit.i_val.shape[0] == int(clear.sum())
+    lat0 = [l.clone() for l in fit.style.latents]
+    p0 = fit.net.params.clone()
+    done = 0
+    while done < 5:
+        done += bool(fit.step_full())
+        assert bool(torch.isfinite(fit.last_patch_loss).all())
+    assert bool(torch.isfinite(fit.net.params).all()) and float((fit.net.params - p0).abs().max()) > 1e-4
+    assert all(bool(torch.isfinite(l).all()) and float((a - l).abs().max()) > 0 for a, l in zip(lat0, fit.style.latents))
+    pred = fit.render_image()
+    assert pred.shape == (H, H, 3) and bool(torch.isfinite(pred).all())
+    # explicit launches == the pixel part of the autograd restatement on the pixel rows, bit for bit (same kernel, same inputs)
+    a, b = make(), make()
+    batch = None
+    while batch is None:
+        batch = a.sample_batch()
+    a.step_from(batch)
+    n_pix, bp = batch["n_pix"], batch["bp"]
+    b.net.zero_grad()
+    b.net.forward_train(batch["coords"])
+    b.net.workspace(bp)["dpred"].zero_()
+    b.net.pixel_loss(bp, n_pix, batch["gt"], mask=batch.get("pmask"), weight=1.0)
+    assert batch.get("pmask") is not None                         # remapping: gt_mask = clear_mask (train.py:203)
+    da, db = a.net.workspace(bp)["dpred"][:n_pix], b.net.workspace(bp)["dpred"][:n_pix]
+    assert torch.equal(da, db) and float(a.net.loss_buf[0]) == float(b.net.loss_buf[0])
