@@ -3,7 +3,7 @@
 # (kernel-trace stats, the FETCH/WRITE PMC passes and the SQ (MFMA utilisation) passes are separate rocprofv3 runs, as the
 # pool requires: no --pmc together with trace domains)
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT

@@ -6,7 +6,7 @@ import csv, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ad = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"] and "long" in r["Kernel_Name"]]
+ad = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] and "long" in r["Kernel_Name"]) or "adam_pack_kernel" in r["Kernel_Name"]]
 segs = [rows[a:b + 1] for a, b in zip(ad[:-1], ad[1:])]
 segs = [s for s in segs if not any("lpips" in r["Kernel_Name"] for r in s) and any("conv3x3" in r["Kernel_Name"] for r in s)]
 segs = segs[len(segs) // 3:]
