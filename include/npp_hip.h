@@ -394,6 +394,25 @@ int npp_linear_bwd_data(const float* d_dz, int64_t lddz, const float* d_w, int64
                         float* d_dx, int64_t lddx, int in_used, int accumulate, void* stream);
 int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const float* d_x, int64_t ldx, int64_t B, int in,
                           int out, float* d_dw, float* d_db, int accumulate, void* stream);
+/* The same three forms over nbatch independent problems of ONE shape in one launch -- the proposal-ranking candidates of one
+ * image (NPP_proposal/search.py:85-147: each candidate its own NPP_Net_light, all on the same pixel rows): s*b are the element
+ * strides between the problems' arrays.  The weight-gradient form ACCUMULATES into d_dw / d_db (split contraction; caller clears).
+ * The data-gradient form optionally applies the PREVIOUS layer's activation derivative on the way out (d_zy non-null: d_dx =
+ * (d_dz w) * act'(d_zy), act / d_zy as npp_act_bwd takes them; not with accumulate): one launch instead of two per hidden layer. */
+int npp_linear_fwd_batched(const float* d_x, int64_t ldx, int64_t sxb, const float* d_w, int64_t swb, const float* d_b,
+                           int64_t sbb, int nbatch, int64_t B, int in, int out, int act, float* d_y, int64_t ldy,
+                           int64_t syb, float* d_z, int64_t ldz, int64_t szb, void* stream);
+int npp_linear_bwd_data_batched(const float* d_dz, int64_t lddz, int64_t sdzb, const float* d_w, int64_t swb, int nbatch,
+                                int64_t B, int in, int out, float* d_dx, int64_t lddx, int64_t sdxb, int in_used,
+                                int accumulate, const float* d_zy, int64_t ldzy, int64_t szyb, int act, void* stream);
+int npp_linear_bwd_weight_batched(const float* d_dz, int64_t lddz, int64_t sdzb, const float* d_x, int64_t ldx, int64_t sxb,
+                                  int nbatch, int64_t B, int in, int out, float* d_dw, int64_t sdwb, float* d_db,
+                                  int64_t sdbb, void* stream);
+/* npp_pixel_loss over nbatch problems: d_pred / d_dpred (nbatch, N, 3), d_latents / d_dlatent (nbatch, 6), d_loss (nbatch);
+ * the targets d_gt (N, 3) are shared when gt_stride == 0, else problem b reads d_gt + b * gt_stride. */
+int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,
+                           const float* d_latents, const float* d_spline, int n_knots, float x_scale, float weight,
+                           float* d_loss, float* d_dpred, float* d_dlatent, void* stream);
 int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act,
                 float* d_dz, int64_t lddz, void* stream);
 int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);

@@ -118,6 +118,10 @@ SYMBOLS = {
     "npp_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "npp_linear_bwd_data": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp]),
     "npp_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "npp_linear_fwd_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "npp_linear_bwd_data_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp]),
+    "npp_linear_bwd_weight_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "npp_pixel_loss_batched": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_act_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "npp_act_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "npp_lpips_plain_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),

@@ -23,67 +23,137 @@ struct GemmArgs {
   float* rowsum;                  // optional: rowsum[m] += sum_k A(m,k) (the bias gradient of the weight-gradient form)
   int M, N, K, act, accumulate;   // act: 0 none, 1 snake (x + sin^2 x)
   int kchunk;                     // k range per blockIdx.z (split-K: partial sums meet in C by atomicAdd, C pre-zeroed)
-  int nbatch;                     // > 1: blockIdx.z is a batch index (no split-K); element strides between batches:
-  int64_t sab, sbb, scb;
+  int nbatch;                     // > 1: independent problems in one launch, blockIdx.z = batch * splits + split; element strides
+  int64_t sab, sbb, scb;          //      between the batches' A / B / C ...
+  int64_t szb, sbiasb, srsb;      //      ... and Z / bias / rowsum
+  int splits;                     // k ranges per problem (>= 1)
+  int dbg;
+  const float* dact; int64_t lddact, sdactb; int dact_kind;   // optional: C = (A B) * act'(dact[m][n]) (kinds of act_bwd_kernel)
+  int vec_a, vec_b;               // set by the launcher: the operand's runs of 4 may be fetched as one 16-byte load
 };
 
+// act'(.) : kind 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y)); 3 tanh from its
+// output (1 - y^2); 4 relu from z ([z > 0])
+__device__ __forceinline__ float act_deriv(float v, int kind) {
+  return kind == 1 ? 1.0f + sinf(2.0f * v) : (kind == 2 ? v * (1.0f - v) : (kind == 3 ? 1.0f - v * v : (kind == 4 ? (v > 0.0f ? 1.0f : 0.0f) : 1.0f)));
+}
+
+// Operand tile in LDS: k-pairs interleaved, s[k >> 1][m][k & 1] with 66 pairs per row.  The fp32 MFMA takes A[m = lane & 31][k = lane >> 5]
+// from each lane, so the 64 lanes of a fragment read are 64 consecutive floats (conflict-free); the staging stores are conflict-free
+// in both thread maps below because 66 = 2 (mod 16).
+constexpr int kGemmLdp = 66;
+constexpr int kGemmTile = 16 * kGemmLdp * 2;          // floats of one 64 x 32 operand tile
+
+// One operand's share of a chunk per thread: 8 floats = two runs of 4 along the operand's contiguous index.
+//   KC  (k contiguous):  run r: m = (tid >> 3) + 32 r, k = 4 (tid & 7) .. + 3      -> two ds_write_b64 (two k-pairs of one m)
+//   !KC (m contiguous):  run r: k = (tid >> 4) + 16 r, m = 4 (tid & 15) .. + 3     -> four ds_write_b32
+// vec: the run is one 16-byte load (host checked alignment and that runs are all-valid or all-invalid); else four 4-byte loads.
+// Out-of-range elements are fetched from a clamped address and zeroed when the registers are STORED to LDS (gemm_sstore), a chunk
+// later: a select right behind the load would wait for it there and take the prefetch distance away.
+template <bool KC>
+__device__ __forceinline__ void gemm_gload(const float* __restrict__ P, int64_t s_m, int64_t s_k, int m0, int M, int k0, int kend, bool vec,
+                                           int tid, float (&reg)[8]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int m, k;
+    if (KC) { m = (tid >> 3) + 32 * r; k = 4 * (tid & 7); } else { k = (tid >> 4) + 16 * r; m = 4 * (tid & 15); }
+    const int gm = m0 + m, gk = k0 + k;
+    if (vec) {
+      const f32x4 v = *(const f32x4*)(P + (int64_t)min(gm, M - (KC ? 1 : 4)) * s_m + (int64_t)min(gk, kend - (KC ? 4 : 1)) * s_k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) reg[4 * r + e] = v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int em = KC ? gm : gm + e, ek = KC ? gk + e : gk;
+        reg[4 * r + e] = P[(int64_t)min(em, M - 1) * s_m + (int64_t)min(ek, kend - 1) * s_k];
+      }
+    }
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void gemm_sstore(float* __restrict__ S, int tid, const float (&reg)[8], int m0, int M, int k0, int kend) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float v[4];
+    if (KC) {
+      const int m = (tid >> 3) + 32 * r, kp = 2 * (tid & 7);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (m0 + m < M && k0 + 2 * kp + e < kend) ? reg[4 * r + e] : 0.0f;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      *(f32x2*)(S + ((kp + 0) * kGemmLdp + m) * 2) = f32x2{v[0], v[1]};
+      *(f32x2*)(S + ((kp + 1) * kGemmLdp + m) * 2) = f32x2{v[2], v[3]};
+    } else {
+      const int k = (tid >> 4) + 16 * r, m = 4 * (tid & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[((k >> 1) * kGemmLdp + m + e) * 2 + (k & 1)] = (m0 + m + e < M && k0 + k < kend) ? reg[4 * r + e] : 0.0f;
+    }
+  }
+}
+
+#ifndef NPP_GEMM_WAVES
+#define NPP_GEMM_WAVES 5
+#endif
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
-  __shared__ float sA[32][65];
-  __shared__ float sB[32][65];
+__global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g) {
+  // Occupancy is the point of the launch bound: the candidate-stacked layers of the ranking fit are 1152 workgroups; at 4 resident
+  // per CU (1024 slots) the last 128 run as a second, 12 %-full round and the launch takes two workgroup times (measured 38 us against
+  // a 15 us MFMA floor); 5 per CU hold them all.  One LDS buffer (17 KB) for the same reason.
+  __shared__ __attribute__((aligned(16))) float sA[kGemmTile];
+  __shared__ __attribute__((aligned(16))) float sB[kGemmTile];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, wm = wave >> 1, wn = wave & 1;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const bool batched = g.nbatch > 1;
-  if (batched) { g.A += (int64_t)blockIdx.z * g.sab; g.B += (int64_t)blockIdx.z * g.sbb; g.C += (int64_t)blockIdx.z * g.scb; }
-  const int kbeg = batched ? 0 : blockIdx.z * g.kchunk, kend = batched ? g.K : min(g.K, kbeg + g.kchunk);
-  const bool split = !batched && gridDim.z > 1;
-  // operand chunk k0 -> registers (the loads of chunk k0 + 32 fly under the MFMAs of chunk k0)
-  float ra[8], rb[8];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int m, k;
-      if (A_KC) { k = tid & 31; m = (tid >> 5) + 8 * r; } else { m = tid & 63; k = (tid >> 6) + 4 * r; }
-      ra[r] = (m0 + m < g.M && k0 + k < kend) ? g.A[(int64_t)(m0 + m) * g.sam + (int64_t)(k0 + k) * g.sak] : 0.0f;
-      int n, kb;
-      if (B_KC) { kb = tid & 31; n = (tid >> 5) + 8 * r; } else { n = tid & 63; kb = (tid >> 6) + 4 * r; }
-      rb[r] = (n0 + n < g.N && k0 + kb < kend) ? g.B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(n0 + n) * g.sbn] : 0.0f;
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      int m, k;
-      if (A_KC) { k = tid & 31; m = (tid >> 5) + 8 * r; } else { m = tid & 63; k = (tid >> 6) + 4 * r; }
-      sA[k][m] = ra[r];
-      int n, kb;
-      if (B_KC) { kb = tid & 31; n = (tid >> 5) + 8 * r; } else { n = tid & 63; kb = (tid >> 6) + 4 * r; }
-      sB[kb][n] = rb[r];
-    }
-  };
+  const int bz = (int)blockIdx.z / g.splits, sp = (int)blockIdx.z - bz * g.splits;
+  if (g.nbatch > 1) {
+    g.A += bz * g.sab; g.B += bz * g.sbb; g.C += bz * g.scb;
+    if (g.Z) g.Z += bz * g.szb;
+    if (g.bias) g.bias += bz * g.sbiasb;
+    if (g.rowsum) g.rowsum += bz * g.srsb;
+    if (g.dact) g.dact += bz * g.sdactb;
+  }
+  const int kbeg = sp * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const bool split = g.splits > 1;
+  const bool va = g.vec_a != 0, vb = g.vec_b != 0;
   const bool do_rowsum = g.rowsum && blockIdx.x == 0 && tid < 64;
   float rs = 0.0f;
-  if (kbeg < kend) gload(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    sstore();
-    __syncthreads();
-    if (k0 + 32 < kend) gload(k0 + 32);
-    if (do_rowsum) {
-#pragma unroll
-      for (int k = 0; k < 32; ++k) rs += sA[k][tid];
+  // chunk c of 32 k: registers <- global while the MFMAs of chunk c - 1 run, LDS <- registers between two barriers.  Branch-free:
+  // out-of-range elements read a clamped address and are zeroed on their way into LDS.
+  float ra[8], rb[8];
+  const int nchunk = (kend - kbeg + 31) / 32;
+  if (nchunk > 0) {
+    gemm_gload<A_KC>(g.A, g.sam, g.sak, m0, g.M, kbeg, kend, va, tid, ra);
+    gemm_gload<B_KC>(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, vb, tid, rb);
+  }
+  const float* __restrict__ a = sA + (wm * 32 + l31) * 2 + kh;
+  const float* __restrict__ b = sB + (wn * 32 + l31) * 2 + kh;
+  for (int c = 0; c < nchunk; ++c) {
+    if (!(g.dbg & 2)) {
+    gemm_sstore<A_KC>(sA, tid, ra, m0, g.M, kbeg + 32 * c, kend);
+    gemm_sstore<B_KC>(sB, tid, rb, n0, g.N, kbeg + 32 * c, kend);
     }
+    __syncthreads();
+    if (c + 1 < nchunk && !(g.dbg & 2)) {
+      gemm_gload<A_KC>(g.A, g.sam, g.sak, m0, g.M, kbeg + 32 * (c + 1), kend, va, tid, ra);
+      gemm_gload<B_KC>(g.B, g.sbn, g.sbk, n0, g.N, kbeg + 32 * (c + 1), kend, vb, tid, rb);
+    }
+    if (do_rowsum) {
+      const float* q = sA + tid * 2;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[2 * ks + kh][wm * 32 + l31], sB[2 * ks + kh][wn * 32 + l31], acc, 0, 0, 0);
+      for (int kp = 0; kp < 16; ++kp) rs += q[kp * kGemmLdp * 2] + q[kp * kGemmLdp * 2 + 1];
+    }
+    if (!(g.dbg & 1)) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks * kGemmLdp * 2], b[ks * kGemmLdp * 2], acc, 0, 0, 0);
+    }
     __syncthreads();
   }
   if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
   const int n = n0 + wn * 32 + l31;
   if (n >= g.N) return;
-  const float bv = (g.bias && (batched || blockIdx.z == 0)) ? g.bias[n] : 0.0f;
+  const float bv = (g.bias && sp == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + acc_row(r, kh);
@@ -91,7 +161,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(GemmArgs g) {
     float v = acc[r] + bv;
     if (split) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
     if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
-    if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
+    if (g.dact) v *= act_deriv(g.dact[(int64_t)m * g.lddact + n], g.dact_kind);
+    if (g.act == 1 && !(g.dbg & 4)) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
     else if (g.act == 2) v = fmaxf(v, 0.0f);                             // F.relu (networks.py:66-67, activation='relu')
     float* c = g.C + (int64_t)m * g.ldc + n;
     *c = g.accumulate ? *c + v : v;
@@ -106,9 +177,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const
   if (t >= B * N) return;
   const int64_t r = t / N;
   const int n = (int)(t - r * N);
-  const float v = zy[r * ldzy + n];
-  const float d = act == 1 ? 1.0f + sinf(2.0f * v) : (act == 2 ? v * (1.0f - v) : (act == 3 ? 1.0f - v * v : (act == 4 ? (v > 0.0f ? 1.0f : 0.0f) : 1.0f)));
-  dz[r * lddz + n] = dy[r * lddy + n] * d;
+  dz[r * lddz + n] = dy[r * lddy + n] * act_deriv(zy[r * ldzy + n], act);
 }
 
 // y = sigmoid(x) / tanh(x) elementwise (render's output squash, helpers.py:55-58)
@@ -208,29 +277,35 @@ __global__ void sub_kernel(const float* __restrict__ a, const float* __restrict_
   if (t < n) c[t] = a[t] - b[t];
 }
 
-static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s) {
+static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false) {
   // Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
   // be 16 workgroups looping 64 chunks each): partial sums by atomicAdd into a zeroed C.  Only for plain linear outputs
-  // written densely (ldc == N), which is what the weight-gradient form produces.
-  const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
-  if (g.nbatch > 1) {
-    g.kchunk = g.K;
-    const dim3 gridb((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)g.nbatch);
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), gridb, dim3(256), 0, s, g);
-    else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), gridb, dim3(256), 0, s, g);
-    else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), gridb, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm32_kernel<false, false>), gridb, dim3(256), 0, s, g);
-    return NPP_OK;
-  }
+  // written densely (ldc == N), which is what the weight-gradient form produces.  Batched launches (nbatch independent
+  // problems, blockIdx.z = batch * splits + split) count all the batches' tiles towards the fill target.
+  const int nb = g.nbatch > 1 ? g.nbatch : 1;
+  const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64) * nb;
   int splits = 1;
-  if (g.act == 0 && !g.Z && g.ldc == g.N && tiles < 128 && g.K >= 256) {
-    splits = min(32, min((g.K + 63) / 64, (512 + tiles - 1) / tiles));
+  if (g.act == 0 && !g.Z && g.ldc == g.N && tiles < 128 * nb && g.K >= 256 && (nb == 1 || (batch_split && g.accumulate))) {
+    static const int batch_fill = [] { const char* e = getenv("NPP_GEMM_BATCH_FILL"); return e ? atoi(e) : 640; }();
+    splits = min(32, min((g.K + 63) / 64, max(1, ((nb > 1 ? batch_fill : 512) + tiles - 1) / tiles)));
   }
   g.kchunk = ((g.K + splits - 1) / splits + 31) / 32 * 32;
   splits = (g.K + g.kchunk - 1) / g.kchunk;
-  if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
-  if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
-  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)splits);
+  g.splits = splits;
+  { static const int dbg = [] { const char* e = getenv("NPP_GEMM_DBG"); return e ? atoi(e) : 0; }(); g.dbg = dbg; }
+  // 16-byte loads along an operand's contiguous index: every run of 4 must be 16-byte aligned and whole (extent % 4 == 0)
+  auto vec_ok = [&](const float* p, int64_t s_cont, int64_t s_other, int64_t s_batch, int extent) {
+    return s_cont == 1 && (s_other % 4) == 0 && (extent % 4) == 0 && ((uintptr_t)p % 16) == 0 && (nb == 1 || (s_batch % 4) == 0);
+  };
+  g.vec_a = a_kc ? vec_ok(g.A, g.sak, g.sam, g.sab, g.K) : vec_ok(g.A, g.sam, g.sak, g.sab, g.M);
+  g.vec_b = b_kc ? vec_ok(g.B, g.sbk, g.sbn, g.sbb, g.K) : vec_ok(g.B, g.sbn, g.sbk, g.sbb, g.N);
+  if (nb == 1) {
+    if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
+    if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
+  } else if (g.rowsum && !g.accumulate) {
+    for (int b = 0; b < nb; ++b) (void)hipMemsetAsync(g.rowsum + b * g.srsb, 0, (size_t)g.M * sizeof(float), s);
+  }
+  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(splits * nb));
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, dim3(256), 0, s, g);
@@ -288,6 +363,64 @@ extern "C" int npp_linear_bwd_weight(const float* d_dz, int64_t lddz, const floa
   g.rowsum = d_db;                                   // db[n_out] = sum_rows dz[row][n_out] = row sums of A
   gemm_launch(g, false, false, (hipStream_t)stream);
   return check_launch("npp_linear_bwd_weight");
+}
+
+/* The three dense-layer forms over nbatch independent problems of one shape in ONE launch (the proposal-ranking candidates of one
+ * image: same rows, each its own weights): element strides between the problems' arrays are the s*b arguments.  The weight-gradient
+ * form splits its contraction like the single-problem form and therefore ACCUMULATES into d_dw / d_db (caller clears them). */
+extern "C" int npp_linear_fwd_batched(const float* d_x, int64_t ldx, int64_t sxb, const float* d_w, int64_t swb, const float* d_b,
+                                      int64_t sbb, int nbatch, int64_t B, int in, int out, int act, float* d_y, int64_t ldy, int64_t syb,
+                                      float* d_z, int64_t ldz, int64_t szb, void* stream) {
+  if (!d_x || !d_w || !d_y || nbatch < 1 || nbatch > 4096 || !lin_dims_ok(B, in, out) || ldx < in || ldy < out || (d_z && ldz < out) || act < 0 ||
+      act > 2) {
+    set_error("npp_linear_fwd_batched: bad argument (nbatch=%d B=%lld in=%d out=%d act=%d)", nbatch, (long long)B, in, out, act);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_x; g.sam = ldx; g.sak = 1;
+  g.B = d_w; g.sbk = 1; g.sbn = in;
+  g.C = d_y; g.ldc = ldy; g.Z = d_z; g.ldz = ldz; g.bias = d_b;
+  g.M = (int)B; g.N = out; g.K = in; g.act = act; g.accumulate = 0;
+  g.nbatch = nbatch; g.sab = sxb; g.sbb = swb; g.scb = syb; g.szb = szb; g.sbiasb = sbb;
+  gemm_launch(g, true, true, (hipStream_t)stream);
+  return check_launch("npp_linear_fwd_batched");
+}
+
+extern "C" int npp_linear_bwd_data_batched(const float* d_dz, int64_t lddz, int64_t sdzb, const float* d_w, int64_t swb, int nbatch, int64_t B,
+                                           int in, int out, float* d_dx, int64_t lddx, int64_t sdxb, int in_used, int accumulate,
+                                           const float* d_zy, int64_t ldzy, int64_t szyb, int act, void* stream) {
+  if (!d_dz || !d_w || !d_dx || nbatch < 1 || nbatch > 4096 || !lin_dims_ok(B, in, out) || lddz < out || in_used < 1 || in_used > in ||
+      lddx < in_used || (d_zy && (ldzy < in_used || act < 1 || act > 4 || accumulate))) {
+    set_error("npp_linear_bwd_data_batched: bad argument (nbatch=%d B=%lld in=%d out=%d in_used=%d)", nbatch, (long long)B, in, out, in_used);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_dz; g.sam = lddz; g.sak = 1;
+  g.B = d_w; g.sbk = in; g.sbn = 1;
+  g.C = d_dx; g.ldc = lddx;
+  g.M = (int)B; g.N = in_used; g.K = out; g.act = 0; g.accumulate = accumulate;
+  g.nbatch = nbatch; g.sab = sdzb; g.sbb = swb; g.scb = sdxb;
+  g.dact = d_zy; g.lddact = ldzy; g.sdactb = szyb; g.dact_kind = act;
+  gemm_launch(g, true, false, (hipStream_t)stream);
+  return check_launch("npp_linear_bwd_data_batched");
+}
+
+extern "C" int npp_linear_bwd_weight_batched(const float* d_dz, int64_t lddz, int64_t sdzb, const float* d_x, int64_t ldx, int64_t sxb,
+                                             int nbatch, int64_t B, int in, int out, float* d_dw, int64_t sdwb, float* d_db, int64_t sdbb,
+                                             void* stream) {
+  if (!d_dz || !d_x || !d_dw || nbatch < 1 || nbatch > 4096 || !lin_dims_ok(B, in, out) || lddz < out || ldx < in) {
+    set_error("npp_linear_bwd_weight_batched: bad argument (nbatch=%d B=%lld in=%d out=%d)", nbatch, (long long)B, in, out);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_dz; g.sam = 1; g.sak = lddz;
+  g.B = d_x; g.sbk = ldx; g.sbn = 1;
+  g.C = d_dw; g.ldc = in;
+  g.M = out; g.N = in; g.K = (int)B; g.act = 0; g.accumulate = 1;
+  g.rowsum = d_db;
+  g.nbatch = nbatch; g.sab = sdzb; g.sbb = sxb; g.scb = sdwb; g.srsb = sdbb;
+  gemm_launch(g, false, false, (hipStream_t)stream, true);
+  return check_launch("npp_linear_bwd_weight_batched");
 }
 
 extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,

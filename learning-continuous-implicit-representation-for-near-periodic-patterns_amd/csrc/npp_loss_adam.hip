@@ -15,6 +15,14 @@ namespace npp {
 
 // (body: pixel_loss_body in npp_common.h -- shared with the fused patch-in launch of npp_conv.hip)
 __global__ __launch_bounds__(256) void pixel_loss_kernel(PixelLossArgs a) { pixel_loss_body(a, (int)blockIdx.x, (int)gridDim.x); }
+// nbatch independent losses in one launch (blockIdx.y): predictions / gradients (N,3) back to back, 6 latents and one loss word
+// per problem; the targets are shared when gt_stride == 0.
+__global__ __launch_bounds__(256) void pixel_loss_batched_kernel(PixelLossArgs a, int64_t gt_stride) {
+  const int64_t b = blockIdx.y;
+  a.pred += b * a.N * 3; a.dpred += b * a.N * 3; a.gt += b * gt_stride;
+  a.latents += b * 6; a.dlatent += b * 6; a.loss_out += b;
+  pixel_loss_body(a, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // torch.optim.Adam single-tensor maths (helpers.py:164): the gradient is the sum of the
 // split-K slabs written by npp_mlp_wgrad, so this kernel is also the wgrad reduction.
@@ -143,6 +151,20 @@ extern "C" int npp_pixel_loss(const float* d_pred, const float* d_gt, const floa
   const PixelLossArgs a{d_pred, d_gt, d_mask, N, d_latents, d_spline, n_knots, x_scale, weight, d_loss, d_dpred, d_dlatent};
   hipLaunchKernelGGL(pixel_loss_kernel, dim3((unsigned)pixel_loss_blocks(N)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("npp_pixel_loss");
+}
+
+extern "C" int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,
+                                      const float* d_latents, const float* d_spline, int n_knots, float x_scale, float weight,
+                                      float* d_loss, float* d_dpred, float* d_dlatent, void* stream) {
+  if (N <= 0 || nbatch < 1 || nbatch > 65535 || !d_pred || !d_gt || !d_latents || !d_spline || !d_loss || !d_dpred || !d_dlatent ||
+      n_knots < 2 || gt_stride < 0) {
+    set_error("npp_pixel_loss_batched: bad arguments (N=%lld, nbatch=%d, n_knots=%d)", (long long)N, nbatch, n_knots);
+    return NPP_ERR_ARG;
+  }
+  const PixelLossArgs a{d_pred, d_gt, nullptr, N, d_latents, d_spline, n_knots, x_scale, weight, d_loss, d_dpred, d_dlatent};
+  hipLaunchKernelGGL(pixel_loss_batched_kernel, dim3((unsigned)pixel_loss_blocks(N), (unsigned)nbatch), dim3(256), 0, (hipStream_t)stream, a,
+                     gt_stride);
+  return check_launch("npp_pixel_loss_batched");
 }
 
 extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,

@@ -24,12 +24,23 @@ def light_layout(W=256, D=4, in_pos=42, in_per=20):
     return out
 
 
+def _stored_cols(c):
+    """Columns a weight matrix is STORED with: rounded up to 4 (zero columns; pos_linears.0 is 298 -> 300 wide).  The dense-layer
+    kernels fetch 16 bytes per lane along the contraction only when every row starts 16-byte aligned; an odd leading dimension
+    drops them to 4-byte loads (measured: the 298-wide layer took 44 us against 18 for its share of the arithmetic).  The pad
+    columns meet zero inputs, get zero gradients and stay zero under Adam; state_dict() / grads() / load_state_dict() speak the
+    reference's shapes."""
+    return (c + 3) // 4 * 4
+
+
 class NPPNetLight:
     """NPP_Net_light(D, W, activation='snake') with its two is_search embedders, Adam state and the adaptive pixel-loss
     latents.  state_dict names / layouts are the reference's; scale_linears / feature_linear2 / alpha_linear (constructed by
     the reference, never used when len(freq_scales) == 1) are not kept."""
 
-    def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500):
+    def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, storage=None):
+        """storage: optional dict of preallocated float32 device vectors (params, grad, m, v: n_params each; latents, lat_m, lat_v,
+        dlatent: 6; loss_buf: 1) -- rows of the stacked blobs of an NPPNetLightBatch."""
         self.device = ops.select_device(device)
         self.res = (int(res[0]), int(res[1]))
         self.W, self.D = int(W), int(D)
@@ -38,24 +49,34 @@ class NPPNetLight:
         self.cfg = EmbedCfg.make(np.asarray(angles_deg, np.float32).reshape(1, 2), np.asarray(periods, np.float32).reshape(1, 2),
                                  np.zeros(10, np.float32), self.res)
         self.layout = light_layout(self.W, self.D, self.in_pos, self.in_per)
-        n = sum(r * c + r for _, r, c in self.layout)
+        self.kpos = _stored_cols(self.W + self.in_pos)             # width of the [feature1 | input_pos | 0-pad] buffer
+        n = sum(r * _stored_cols(c) + r for _, r, c in self.layout)
         self.n_params = n
-        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.params)
-        self.m, self.v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        if storage is None:
+            self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.grad = torch.zeros_like(self.params)
+            self.m, self.v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        else:
+            self.params, self.grad, self.m, self.v = (storage[k] for k in ("params", "grad", "m", "v"))
+            assert all(t.shape == (n,) and t.is_contiguous() for t in (self.params, self.grad, self.m, self.v))
         self.w, self.b, self.dw, self.db = {}, {}, {}, {}
         off = 0
         for name, r, c in self.layout:
-            self.w[name], self.dw[name] = self.params[off:off + r * c].view(r, c), self.grad[off:off + r * c].view(r, c)
-            off += r * c
+            cs = _stored_cols(c)
+            self.w[name], self.dw[name] = self.params[off:off + r * cs].view(r, cs), self.grad[off:off + r * cs].view(r, cs)
+            off += r * cs
             self.b[name], self.db[name] = self.params[off:off + r], self.grad[off:off + r]
             off += r
         if params is not None:
             self.load_state_dict(params)
-        self.latents = torch.tensor([LATENT_ALPHA_INIT] * 3 + [0.0] * 3, dtype=torch.float32, device=self.device)
-        self.lat_m, self.lat_v = torch.zeros_like(self.latents), torch.zeros_like(self.latents)
-        self.dlatent = torch.zeros(6, dtype=torch.float32, device=self.device)
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        if storage is None:
+            self.latents = torch.tensor([LATENT_ALPHA_INIT] * 3 + [0.0] * 3, dtype=torch.float32, device=self.device)
+            self.lat_m, self.lat_v = torch.zeros_like(self.latents), torch.zeros_like(self.latents)
+            self.dlatent = torch.zeros(6, dtype=torch.float32, device=self.device)
+            self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        else:
+            self.latents, self.lat_m, self.lat_v, self.dlatent, self.loss_buf = (storage[k] for k in ("latents", "lat_m", "lat_v", "dlatent", "loss_buf"))
+            self.latents.copy_(torch.tensor([LATENT_ALPHA_INIT] * 3 + [0.0] * 3, dtype=torch.float32))
         self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
         self.lrate, self.lrate_decay, self.lr = float(lrate), int(lrate_decay), float(lrate)
         self.global_step, self.opt_step = 0, 0
@@ -63,21 +84,22 @@ class NPPNetLight:
 
     def load_state_dict(self, sd):
         for name, r, c in self.layout:
-            for part, dst in (("weight", self.w[name]), ("bias", self.b[name])):
+            for part, dst in (("weight", self.w[name][:, :c]), ("bias", self.b[name])):
                 a = sd[f"{name}.{part}"]
                 a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
                 dst.copy_(torch.from_numpy(np.ascontiguousarray(a, np.float32)).reshape(dst.shape))
+            self.w[name][:, c:].zero_()
 
     def state_dict(self):
         out = {}
-        for name, _, _ in self.layout:
-            out[f"{name}.weight"], out[f"{name}.bias"] = self.w[name].cpu().numpy().copy(), self.b[name].cpu().numpy().copy()
+        for name, _, c in self.layout:
+            out[f"{name}.weight"], out[f"{name}.bias"] = self.w[name][:, :c].cpu().numpy().copy(), self.b[name].cpu().numpy().copy()
         return out
 
     def grads(self):
         out = {}
-        for name, _, _ in self.layout:
-            out[f"{name}.weight"], out[f"{name}.bias"] = self.dw[name].cpu().numpy().copy(), self.db[name].cpu().numpy().copy()
+        for name, _, c in self.layout:
+            out[f"{name}.weight"], out[f"{name}.bias"] = self.dw[name][:, :c].cpu().numpy().copy(), self.db[name].cpu().numpy().copy()
         return out
 
     # ---- embedders (get_embedder(is_search=True), models/embedder.py:52-54,76-88) ----------------------
@@ -96,7 +118,8 @@ class NPPNetLight:
         if ws is None:
             f = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)      # noqa: E731
             W = self.W
-            ws = dict(z=[f(B, W) for _ in range(self.D)], h=[f(B, W) for _ in range(self.D)], hp=f(B, W + self.in_pos),
+            ws = dict(z=[f(B, W) for _ in range(self.D)], h=[f(B, W) for _ in range(self.D)],
+                      hp=torch.zeros(B, self.kpos, dtype=torch.float32, device=self.device),          # pad columns stay zero
                       zp=f(B, W // 2), ap=f(B, W // 2), raw=f(B, 3), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3), dap=f(B, W // 2),
                       dzp=f(B, W // 2), df1=f(B, W), dh=f(B, W), dz=f(B, W))
             self._ws[B] = ws
@@ -114,7 +137,7 @@ class NPPNetLight:
             h = ws["h"][i]
         W = self.W
         ops.linear_fwd(h, self.w["feature_linear1"], self.b["feature_linear1"], 0, ws["hp"][:, :W])      # cat[feature1, input_pos] :247
-        ws["hp"][:, W:].copy_(x_pos)
+        ws["hp"][:, W:W + self.in_pos].copy_(x_pos)
         ops.linear_fwd(ws["hp"], self.w["pos_linears.0"], self.b["pos_linears.0"], _SNAKE, ws["ap"], ws["zp"])
         ops.linear_fwd(ws["ap"], self.w["rgb_linear"], self.b["rgb_linear"], 0, ws["raw"])
         ops.act_fwd(ws["raw"], _SIGMOID, ws["pred"])
@@ -189,6 +212,104 @@ class NPPNetLight:
             x_pos, x_per = self.embed(coords_yx[j:j + chunk])
             out.append(self.forward(x_pos, x_per).clone())
         return torch.cat(out, 0)
+
+
+class NPPNetLightBatch:
+    """C candidates' NPP_Net_light advanced TOGETHER: every layer of every candidate in one launch (npp_linear_*_batched: the
+    candidate is a grid dimension), so that an iteration of the whole candidate set is the ~35 launches one candidate's was -- 9 x
+    128 workgroups per launch instead of 128 on a 256-CU chip.  The candidates share the pixel rows of every iteration
+    (ProposalRanker._pixel_draws) and therefore x_pos and the colours; x_per (their lattice) and all weights are their own.
+    State lives in stacked blobs (C, n_pad); .nets are ordinary NPPNetLight objects over the rows (render / score / state_dict)."""
+
+    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500):
+        self.device = ops.select_device(device)
+        self.C, self.W, self.D = len(cands), int(W), int(D)
+        C = self.C
+        in_pos = 2 * (1 + 2 * len(np.asarray(freqs).reshape(-1)))
+        self.layout = light_layout(self.W, self.D, in_pos, 20)
+        self.in_pos = in_pos
+        self.kpos = _stored_cols(self.W + in_pos)
+        n = sum(r * _stored_cols(c) + r for _, r, c in self.layout)
+        self.n_params, self.n_pad = n, (n + 3) // 4 * 4                 # rows 16-byte aligned: the flat Adam launch stays vectorised
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)      # noqa: E731
+        self.params, self.grad, self.m, self.v = z(C, self.n_pad), z(C, self.n_pad), z(C, self.n_pad), z(C, self.n_pad)
+        self.latents, self.lat_m, self.lat_v = z(C, 6), z(C, 6), z(C, 6)
+        self.nets = []
+        self._dl_c = z(C, 6)                                            # latent gradients: consumed AND cleared by the Adam launch
+        self._loss2, self._li = z(2, C), 0                              # loss words, two sets: the idle one is cleared by the Adam launch
+        for ci, (angles_deg, periods) in enumerate(cands):
+            st = dict(params=self.params[ci, :n], grad=self.grad[ci, :n], m=self.m[ci, :n], v=self.v[ci, :n], latents=self.latents[ci],
+                      lat_m=self.lat_m[ci], lat_v=self.lat_v[ci], dlatent=self._dl_c[ci], loss_buf=self._loss2[0, ci:ci + 1])
+            self.nets.append(NPPNetLight(angles_deg, periods, freqs, res, params, W=W, D=D, device=self.device, lrate=lrate,
+                                         lrate_decay=lrate_decay, storage=st))
+        self.w, self.b, self.dw, self.db = {}, {}, {}, {}
+        off = 0
+        for name, r, c in self.layout:
+            cs = _stored_cols(c)
+            self.w[name], self.dw[name] = self.params[:, off:off + r * cs].unflatten(1, (r, cs)), self.grad[:, off:off + r * cs].unflatten(1, (r, cs))
+            off += r * cs
+            self.b[name], self.db[name] = self.params[:, off:off + r], self.grad[:, off:off + r]
+            off += r
+        n0 = self.nets[0]
+        self.spline, self.n_knots, self.x_scale = n0.spline, n0.n_knots, n0.x_scale
+        self._ws = {}
+
+    def _work(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            C, W = self.C, self.W
+            f = lambda *s_: torch.empty((C,) + s_, dtype=torch.float32, device=self.device)      # noqa: E731
+            ws = dict(z=[f(B, W) for _ in range(self.D)], h=[f(B, W) for _ in range(self.D)],
+                      hp=torch.zeros(C, B, self.kpos, dtype=torch.float32, device=self.device), zp=f(B, W // 2), ap=f(B, W // 2), raw=f(B, 3), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3), dap=f(B, W // 2), dzp=f(B, W // 2),
+                      df1=f(B, W), dh=f(B, W), dz=f(B, W))
+            self._ws[B] = ws
+        return ws
+
+    def train_step(self, x_pos, x_per, gt):
+        """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20)."""
+        C, B = x_per.shape[:2]
+        ws, W, D = self._work(B), self.W, self.D
+        rows = lambda t: t.view(C * B, t.shape[2])                                                 # noqa: E731
+        # ---- forward (NPPNetLight.forward)
+        h = x_per
+        for i in range(D):
+            name = f"periodic_linears.{i}"
+            ops.linear_fwd_batched(h, self.w[name], self.b[name], _SNAKE, ws["h"][i], ws["z"][i])
+            h = ws["h"][i]
+        ops.linear_fwd_batched(h, self.w["feature_linear1"], self.b["feature_linear1"], 0, ws["hp"][:, :, :W])
+        ws["hp"][:, :, W:W + self.in_pos] = x_pos
+        ops.linear_fwd_batched(ws["hp"], self.w["pos_linears.0"], self.b["pos_linears.0"], _SNAKE, ws["ap"], ws["zp"])
+        ops.linear_fwd_batched(ws["ap"], self.w["rgb_linear"], self.b["rgb_linear"], 0, ws["raw"])
+        ops.act_fwd(ws["raw"], _SIGMOID, ws["pred"])
+        # ---- loss (its accumulators were cleared by the previous iteration's Adam launch)
+        loss = self._loss2[self._li]
+        ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
+        # ---- backward (NPPNetLight.backward)
+        self.grad.zero_()
+        # (every hidden layer's activation backward rides in the epilogue of the data-gradient launch above it)
+        ops.act_bwd(rows(ws["dpred"]), rows(ws["pred"]), _SIGMOID, rows(ws["draw"]))
+        ops.linear_bwd_weight_batched(ws["draw"], ws["ap"], self.dw["rgb_linear"], self.db["rgb_linear"])
+        ops.linear_bwd_data_batched(ws["draw"], self.w["rgb_linear"], ws["dzp"], zy=ws["zp"], act=_SNAKE)
+        ops.linear_bwd_weight_batched(ws["dzp"], ws["hp"], self.dw["pos_linears.0"], self.db["pos_linears.0"])
+        ops.linear_bwd_data_batched(ws["dzp"], self.w["pos_linears.0"], ws["df1"], in_used=W)
+        ops.linear_bwd_weight_batched(ws["df1"], ws["h"][D - 1], self.dw["feature_linear1"], self.db["feature_linear1"])
+        ops.linear_bwd_data_batched(ws["df1"], self.w["feature_linear1"], ws["dz"], zy=ws["z"][D - 1], act=_SNAKE)
+        for i in range(D - 1, -1, -1):
+            name = f"periodic_linears.{i}"
+            dz = ws["dz"] if (D - 1 - i) % 2 == 0 else ws["dh"]
+            ops.linear_bwd_weight_batched(dz, ws["h"][i - 1] if i > 0 else x_per, self.dw[name], self.db[name])
+            if i > 0:
+                ops.linear_bwd_data_batched(dz, self.w[name], ws["dh"] if dz is ws["dz"] else ws["dz"], zy=ws["z"][i - 1], act=_SNAKE)
+        # ---- Adam over the stacked blobs (the candidates share the step count and the LR clock); pad columns have zero gradient
+        n0 = self.nets[0]
+        step, lr = n0.opt_step + 1, n0.lr
+        self._li ^= 1
+        ops.adam_step_net(self.params.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), 1, self.params.numel(),
+                          self.latents.view(-1), self.lat_m.view(-1), self.lat_v.view(-1), self._dl_c.view(-1), self._loss2[self._li], lr, step)
+        for net in self.nets:
+            net.opt_step = step
+            net.advance_clock()
+        return loss
 
 
 def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
@@ -316,12 +437,15 @@ class ProposalRanker:
         self._graph_keep = (graph, idx_s, hp_s, hp_tab)            # alive until the replays have run
         return net
 
-    def fit_candidates(self, cands, n_streams=8):
-        """fit_candidate() for several candidates at once: the fits are independent and each iteration is ~20 small dependent
-        launches (0.38 ms per iteration, the chip idle between them), so the candidates advance together, iteration by iteration,
-        each on one of n_streams side streams -- the launch gaps of one fit are filled by the others.  Same arithmetic per
-        candidate as the serial form; the pixel rows and their colours (identical for every candidate, see _pixel_draws) are
-        gathered once."""
+    def fit_candidates(self, cands, n_streams=8, batched=None):
+        """fit_candidate() for several candidates at once.  The fits are independent and one fit's iteration is ~40 small dependent
+        launches that leave the chip mostly idle (128 workgroups each), so:
+        batched (default; NPP_LIGHT_BATCH=0 turns it off): every launch carries ALL the candidates (NPPNetLightBatch, the candidate
+        is a grid dimension of the dense-layer kernels) -- an iteration of the whole set costs about what one candidate's did;
+        else: the candidates advance together, iteration by iteration, each on one of n_streams side streams (round 2; bounded by
+        the host's enqueue rate: 9 x 40 launches per iteration).
+        Same arithmetic per candidate as the serial form up to the summation order of the split weight-gradient contractions; the
+        pixel rows and their colours (identical for every candidate, see _pixel_draws) are gathered once."""
         import os
         if os.environ.get("NPP_LIGHT_GRAPH", "0") != "0" and self.N_iters >= 3:
             # graph replay makes one fit device-bound (fit_candidate): the candidates simply run one after the other
@@ -330,6 +454,10 @@ class ProposalRanker:
         draws = self._pixel_draws()
         c_all = self.i_train_dev[draws.reshape(-1)].long()
         gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
+        if batched is None:
+            batched = os.environ.get("NPP_LIGHT_BATCH", "1") != "0"
+        if batched:
+            return self._fit_candidates_batched(cands, draws, gt_all)
         nets, tabs = [], []
         for angles_deg, periods in cands:
             net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img), default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
@@ -347,6 +475,25 @@ class ProposalRanker:
                     net.train_step(tabs[j][0][idx], tabs[j][1][idx], gt)
         for st in streams:
             main.wait_stream(st)
+        return nets
+
+    def _fit_candidates_batched(self, cands, draws, gt_all, group=16):
+        """All candidates of the image in ONE launch sequence (NPPNetLightBatch), `group` at a time: the default of fit_candidates."""
+        nets = []
+        init = default_light_init(self.Wn, self.D)
+        for g0 in range(0, len(cands), group):
+            part = cands[g0:g0 + group]
+            batch = NPPNetLightBatch(part, self.freqs, (self.H, self.W_img), init, W=self.Wn, D=self.D, device=self.device,
+                                     lrate=self.lrate, lrate_decay=self.lrate_decay)
+            tabs = [net.embed(self.i_train_dev) for net in batch.nets]                                # search.py:104-108 tables
+            x_pos_all = tabs[0][0]                                                                   # the same for every candidate
+            x_per_all = torch.stack([t[1] for t in tabs])                                            # (C, n_train, 20)
+            del tabs
+            for it in range(self.N_iters):
+                idx = draws[it]
+                batch.train_step(x_pos_all[idx], x_per_all[:, idx], gt_all[it])
+            self._batch_keep = batch                                                                 # the nets are views of its blobs
+            nets.extend(batch.nets)
         return nets
 
     @torch.no_grad()

@@ -531,6 +531,57 @@ def linear_bwd_weight(dz, x, dw, db=None, accumulate=False):
                                       _stream()), "npp_linear_bwd_weight")
 
 
+# ---- the same layers over several independent problems of one shape in one launch (light.NPPNetLightBatch) -----------------
+def linear_fwd_batched(x, w, b, act, y, z=None):
+    """y[c] = act(x[c] w[c]^T + b[c]): x (C,B,in), w (C,out,in), b (C,out), y / z (C,B,out); any batch strides, rows may be column
+    blocks of wider buffers.  x may be shared by the problems (stride(0) == 0)."""
+    C, B, cin = x.shape
+    cout = w.shape[1]
+    assert w.shape == (C, cout, cin) and y.shape == (C, B, cout) and b.shape == (C, cout)
+    assert x.stride(2) == 1 and y.stride(2) == 1 and w.stride(2) == 1 and w.stride(1) == cin and b.stride(1) == 1
+    assert z is None or (z.shape == y.shape and z.stride(2) == 1)
+    check(lib().npp_linear_fwd_batched(_p(x), x.stride(1), x.stride(0), _p(w), w.stride(0), _p(b), b.stride(0), C, B, cin, cout, act, _p(y),
+                                       y.stride(1), y.stride(0), _p(z), 0 if z is None else z.stride(1), 0 if z is None else z.stride(0),
+                                       _stream()), "npp_linear_fwd_batched")
+    return y
+
+
+def linear_bwd_data_batched(dz, w, dx, in_used=None, accumulate=False, zy=None, act=0):
+    """dx[c] (+)= dz[c] w[c] (first in_used input columns); with zy (C,B,in_used) and act: dx[c] = (dz[c] w[c]) * act'(zy[c]) -- the
+    activation backward of the layer below folded into this launch (act / zy as act_bwd takes them)."""
+    C, B, cout = dz.shape
+    cin = w.shape[2]
+    in_used = cin if in_used is None else in_used
+    assert w.shape == (C, cout, cin) and dx.shape == (C, B, in_used) and dz.stride(2) == 1 and dx.stride(2) == 1
+    assert w.stride(2) == 1 and w.stride(1) == cin
+    assert zy is None or (zy.shape == dx.shape and zy.stride(2) == 1)
+    check(lib().npp_linear_bwd_data_batched(_p(dz), dz.stride(1), dz.stride(0), _p(w), w.stride(0), C, B, cin, cout, _p(dx), dx.stride(1),
+                                            dx.stride(0), in_used, int(bool(accumulate)), _p(zy), 0 if zy is None else zy.stride(1),
+                                            0 if zy is None else zy.stride(0), int(act), _stream()), "npp_linear_bwd_data_batched")
+    return dx
+
+
+def linear_bwd_weight_batched(dz, x, dw, db):
+    """dw[c] += dz[c]^T x[c], db[c] += column sums of dz[c] (ACCUMULATES: the contraction is split; clear the gradients first)."""
+    C, B, cout = dz.shape
+    cin = x.shape[2]
+    assert dw.shape == (C, cout, cin) and dw.stride(2) == 1 and dw.stride(1) == cin and db.shape == (C, cout) and db.stride(1) == 1
+    assert x.shape[:2] == (C, B) and x.stride(2) == 1 and dz.stride(2) == 1
+    check(lib().npp_linear_bwd_weight_batched(_p(dz), dz.stride(1), dz.stride(0), _p(x), x.stride(1), x.stride(0), C, B, cin, cout, _p(dw),
+                                              dw.stride(0), _p(db), db.stride(0), _stream()), "npp_linear_bwd_weight_batched")
+
+
+def pixel_loss_batched(pred, gt, latents, spline, n_knots, x_scale, weight, loss, dpred, dlatent):
+    """pixel_loss() for C problems: pred / dpred (C,N,3) contiguous, latents / dlatent (C,6), loss (C); gt (N,3) shared or (C,N,3)."""
+    _req(pred, torch.float32, "pred")
+    C, n = pred.shape[:2]
+    assert pred.is_contiguous() and dpred.is_contiguous() and dpred.shape == pred.shape and gt.is_contiguous()
+    assert latents.shape == (C, 6) and dlatent.shape == (C, 6) and loss.numel() == C and latents.is_contiguous() and dlatent.is_contiguous()
+    assert gt.shape in ((n, 3), (C, n, 3))
+    check(lib().npp_pixel_loss_batched(_p(pred), _p(gt), 0 if gt.dim() == 2 else n * 3, n, C, _p(latents), _p(spline), n_knots, x_scale,
+                                       weight, _p(loss), _p(dpred), _p(dlatent), _stream()), "npp_pixel_loss_batched")
+
+
 def act_bwd(dy, zy, act, dz):
     B, n = dy.shape
     check(lib().npp_act_bwd(_p(dy), dy.stride(0), _p(zy), zy.stride(0), B, n, act, _p(dz), dz.stride(0), _stream()), "npp_act_bwd")

@@ -205,8 +205,9 @@ def test_ranking_prefers_the_true_periodicity(dev):
 
 
 def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
-    """ProposalRanker.fit_candidates -- all candidates advanced together on side streams (default), or iterations 2 .. N of each
-    fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against the eager fit_candidate loop: the same fitted
+    """ProposalRanker.fit_candidates -- all candidates in every launch (default: NPPNetLightBatch), advanced together on side
+    streams (batched=False), or iterations 2 .. N of each fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against
+    the eager fit_candidate loop: the same fitted
     parameters (split-K float atomics in the weight gradients give run-to-run noise of ~1e-6), step counts, LR clock and scores."""
     from npp_amd.light import ProposalRanker
     H = 128
@@ -221,17 +222,19 @@ def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
     monkeypatch.setenv("NPP_LIGHT_GRAPH", "1")
     graphed = ranker.fit_candidates(cands)
     monkeypatch.setenv("NPP_LIGHT_GRAPH", "0")
-    together = ranker.fit_candidates(cands, n_streams=3)
-    for (a, p), net, netg in zip(cands, together, graphed):
+    together = ranker.fit_candidates(cands, n_streams=3, batched=False)
+    stacked = ranker.fit_candidates(cands)                       # default: NPPNetLightBatch, the candidate is a grid dimension
+    assert type(ranker._batch_keep).__name__ == "NPPNetLightBatch" and stacked[0].params.data_ptr() == ranker._batch_keep.params.data_ptr()
+    for (a, p), net, netg, netb in zip(cands, together, graphed, stacked):
         alone = ranker.fit_candidate(a, p, use_graph=False)
-        assert net.opt_step == netg.opt_step == alone.opt_step == 40
-        assert netg.global_step == alone.global_step and netg.lr == alone.lr
+        assert net.opt_step == netg.opt_step == netb.opt_step == alone.opt_step == 40
+        assert netg.global_step == netb.global_step == alone.global_step and netg.lr == netb.lr == alone.lr
         pb = alone.params.cpu().numpy()
-        for other in (net, netg):
+        for other in (net, netg, netb):
             assert np.linalg.norm(other.params.cpu().numpy() - pb) <= 1e-4 * np.linalg.norm(pb)
             np.testing.assert_allclose(other.latents.cpu().numpy(), alone.latents.cpu().numpy(), atol=1e-5)
         sb = ranker.score(alone)
-        for other in (net, netg):
+        for other in (net, netg, netb):
             assert abs(ranker.score(other)[0] - sb[0]) <= 1e-3 * abs(sb[0])
 
 
