@@ -582,9 +582,26 @@ def main():
         sc = rk.score(net_l)
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t3
+        # search.py fits every candidate of an image (top-k of the detector: 9 by default) from the same weights on the same pixel
+        # rows: the product path (ProposalRanker.fit_candidates / rank) carries all of them in every launch
+        cands9 = [(angles[i % K] + 3.0 * (i // K), periods[i % K] * (1.0 + 0.11 * (i // K))) for i in range(9)]
+        rk.fit_candidates(cands9)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        nets9 = rk.fit_candidates(cands9)
+        torch.cuda.synchronize()
+        t_set = time.perf_counter() - t4
+        sc9 = [rk.score(n_) for n_ in nets9]
+        torch.cuda.synchronize()
+        t_set_all = time.perf_counter() - t4
         ranking = {"fit_ms_per_iter": t_fit / rk.N_iters * 1e3, "candidate_fit_s": t_fit, "candidate_fit_plus_score_s": t_all,
                    "rows_per_s": rk.N_iters * rk.N_rand / t_fit, "score": sc[0],
-                   "note": "NPP_Net_light D=4 W=256 on the generic exact-fp32 dense kernels; launch-bound (~40 launches per iteration)"}
+                   "candidate_set": {"n_candidates": len(cands9), "fit_s": t_set, "fit_s_per_candidate": t_set / len(cands9),
+                                     "fit_plus_score_s": t_set_all, "ms_per_iteration_of_the_set": t_set / rk.N_iters * 1e3,
+                                     "rows_per_s": len(cands9) * rk.N_iters * rk.N_rand / t_set, "best_score": min(x[0] for x in sc9),
+                                     "how": "NPPNetLightBatch: the candidate is a grid dimension of every dense-layer launch"},
+                   "note": "NPP_Net_light D=4 W=256 on the generic exact-fp32 dense kernels; candidate_fit_s is ONE candidate alone "
+                           "(~40 launches of 128 workgroups per iteration), candidate_set the 9 candidates of an image together"}
 
     # ---- extra: throughput mode -- two independent image fits interleaved on this GPU, one stream each (more images than
     #      GPUs, BASELINE config c3 style): their dependent-launch gaps and under-filled kernels overlap ----

@@ -1,15 +1,22 @@
 // npp_linear.hip -- generic dense layers in exact fp32 (v_mfma_f32_32x32x2_f32): what F.linear + SnakeActivation and
 // their autograd do for topologies the fused chain kernels are not specialised for.  First user: the proposal-ranking
 // fits of NPP_proposal/search.py:85-205 with NPP_Net_light (models/networks.py:176-263): 2048 rows x ~0.3 M parameters x
-// 300 iterations per candidate -- a launch-bound problem, so the layers stay separate launches and exact fp32.
+// 300 iterations per candidate -- a launch-bound problem for ONE candidate (128 workgroups per layer); the candidates of an
+// image are independent and share their pixel rows, so the *_batched entry points carry all of them in one launch (the candidate
+// is blockIdx.z): 9 x 2048 x 256 x 256 in 37 us = 0.41 of the fp32 MFMA peak, T(C) ~ 12 us + 2.9 us per candidate (MFMA floor 1.7).
 //
 // One GEMM kernel, C[m][n] = sum_k A(m,k) B(k,n) with arbitrary element strides, serves
 //   forward      y  = act(x W^T + b)    A = x  (k contiguous), B = W read as (k,n) (k contiguous)
 //   data grad    dx = dz W              A = dz (k contiguous), B = W read as (k=n_out, col) (col contiguous)
 //   weight grad  dW = dz^T x            A = dz read as (m=n_out, k=row) (m contiguous), B = x (col contiguous)
-// 64 x 64 output tile per workgroup (4 waves of 32 x 32), 32-wide k chunks staged through LDS as [k][m]: the fp32 MFMA
-// takes ONE float per lane and operand, so the operands cannot come straight from global memory (measured on the
-// contextual-loss kernels: texture-addresser-bound).  The staging thread map follows each operand's contiguous index.
+// 64 x 64 output tile per workgroup (4 waves of 32 x 32), 32-wide k chunks staged through LDS (k-pairs interleaved, see
+// kGemmLdp): the fp32 MFMA takes ONE float per lane and operand, so the operands cannot come straight from global memory
+// (measured on the contextual-loss kernels: texture-addresser-bound).  The staging thread map follows each operand's
+// contiguous index, 16 bytes per lane where rows are 16-byte aligned.  Measured with the phases switched off one at a time
+// (tools/r3_gemm_probe.py history, 9 stacked problems): launch + epilogue 10 us, + staging 20, + MFMAs and their LDS reads 30,
+// all 37 -- LDS traffic (stores ~190 + reads ~250-500 array cycles per workgroup-chunk) and the MFMA pipe (1024 cycles per
+// wave-chunk) add up rather than overlap; a 64 x 64 tile per WAVE with the contraction split over the waves would halve the
+// LDS reads at the price of a cross-wave reduction (not built: estimated 37 -> 31 us).
 #include "npp_common.h"
 
 namespace npp {
@@ -27,7 +34,6 @@ struct GemmArgs {
   int64_t sab, sbb, scb;          //      between the batches' A / B / C ...
   int64_t szb, sbiasb, srsb;      //      ... and Z / bias / rowsum
   int splits;                     // k ranges per problem (>= 1)
-  int dbg;
   const float* dact; int64_t lddact, sdactb; int dact_kind;   // optional: C = (A B) * act'(dact[m][n]) (kinds of act_bwd_kernel)
   int vec_a, vec_b;               // set by the launcher: the operand's runs of 4 may be fetched as one 16-byte load
 };
@@ -130,12 +136,10 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
   const float* __restrict__ a = sA + (wm * 32 + l31) * 2 + kh;
   const float* __restrict__ b = sB + (wn * 32 + l31) * 2 + kh;
   for (int c = 0; c < nchunk; ++c) {
-    if (!(g.dbg & 2)) {
     gemm_sstore<A_KC>(sA, tid, ra, m0, g.M, kbeg + 32 * c, kend);
     gemm_sstore<B_KC>(sB, tid, rb, n0, g.N, kbeg + 32 * c, kend);
-    }
     __syncthreads();
-    if (c + 1 < nchunk && !(g.dbg & 2)) {
+    if (c + 1 < nchunk) {
       gemm_gload<A_KC>(g.A, g.sam, g.sak, m0, g.M, kbeg + 32 * (c + 1), kend, va, tid, ra);
       gemm_gload<B_KC>(g.B, g.sbn, g.sbk, n0, g.N, kbeg + 32 * (c + 1), kend, vb, tid, rb);
     }
@@ -144,10 +148,8 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
 #pragma unroll
       for (int kp = 0; kp < 16; ++kp) rs += q[kp * kGemmLdp * 2] + q[kp * kGemmLdp * 2 + 1];
     }
-    if (!(g.dbg & 1)) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks * kGemmLdp * 2], b[ks * kGemmLdp * 2], acc, 0, 0, 0);
-    }
     __syncthreads();
   }
   if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
     if (split) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
     if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
     if (g.dact) v *= act_deriv(g.dact[(int64_t)m * g.lddact + n], g.dact_kind);
-    if (g.act == 1 && !(g.dbg & 4)) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
+    if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
     else if (g.act == 2) v = fmaxf(v, 0.0f);                             // F.relu (networks.py:66-67, activation='relu')
     float* c = g.C + (int64_t)m * g.ldc + n;
     *c = g.accumulate ? *c + v : v;
@@ -292,7 +294,6 @@ static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool bat
   g.kchunk = ((g.K + splits - 1) / splits + 31) / 32 * 32;
   splits = (g.K + g.kchunk - 1) / g.kchunk;
   g.splits = splits;
-  { static const int dbg = [] { const char* e = getenv("NPP_GEMM_DBG"); return e ? atoi(e) : 0; }(); g.dbg = dbg; }
   // 16-byte loads along an operand's contiguous index: every run of 4 must be 16-byte aligned and whole (extent % 4 == 0)
   auto vec_ok = [&](const float* p, int64_t s_cont, int64_t s_other, int64_t s_batch, int extent) {
     return s_cont == 1 && (s_other % 4) == 0 && (extent % 4) == 0 && ((uintptr_t)p % 16) == 0 && (nb == 1 || (s_batch % 4) == 0);

@@ -60,6 +60,68 @@ def test_dense_layer_kernels_vs_numpy(dev, B, cin, cout):
     np.testing.assert_allclose(g.cpu().numpy(), dz * (1 + np.sin(2 * zr)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("C,B,cin,cout", [(3, 70, 106, 32), (2, 257, 20, 64), (9, 2048, 256, 256), (4, 33, 300, 128), (2, 100, 128, 3)])
+def test_batched_dense_layers_equal_the_single_problem_launches(dev, C, B, cin, cout):
+    """npp_linear_*_batched (the candidate is a grid dimension) against one npp_linear_* launch per problem: forward and data
+    gradient bit-identical (same tiles, same k order), the data gradient with the fused activation derivative against
+    linear_bwd_data + act_bwd, the split weight / bias gradient to fp32 round-off; strided batches (rows of a stacked blob),
+    16-byte-aligned and unaligned leading dimensions."""
+    from npp_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(C * 1000 + B)
+    blob = (torch.randn(C, cout * cin + cout + 5, generator=g) / np.sqrt(cin)).to(dev)           # weights + biases as rows of one blob
+    w, b = blob[:, :cout * cin].unflatten(1, (cout, cin)), blob[:, cout * cin:cout * cin + cout]
+    x = torch.randn(C, B, cin, generator=g).to(dev)
+    y, z = torch.empty(C, B, cout, device=dev), torch.empty(C, B, cout, device=dev)
+    ops.linear_fwd_batched(x, w, b, 1, y, z)
+    y1, z1 = torch.empty(B, cout, device=dev), torch.empty(B, cout, device=dev)
+    for c in range(C):
+        ops.linear_fwd(x[c], w[c].contiguous(), b[c].contiguous(), 1, y1, z1)
+        assert torch.equal(y[c], y1) and torch.equal(z[c], z1)
+    xs = x[0:1].expand(C, B, cin)                                                               # one input shared by the problems
+    ops.linear_fwd_batched(xs, w, b, 2, y)
+    ops.linear_fwd(x[0], w[C - 1].contiguous(), b[C - 1].contiguous(), 2, y1)      # (a plain linear single launch may split its contraction)
+    assert torch.equal(y[C - 1], y1)
+    dz = torch.randn(C, B, cout, generator=g).to(dev)
+    zin = torch.randn(C, B, cin, generator=g).to(dev)
+    dx, dxf = torch.empty(C, B, cin, device=dev), torch.empty(C, B, cin, device=dev)
+    ops.linear_bwd_data_batched(dz, w, dx)
+    ops.linear_bwd_data_batched(dz, w, dxf, zy=zin, act=1)
+    d1, d2 = torch.empty(B, cin, device=dev), torch.empty(B, cin, device=dev)
+    for c in range(C):
+        ops.linear_bwd_data(dz[c], w[c].contiguous(), d1)
+        assert torch.equal(dx[c], d1)
+        ops.act_bwd(d1, zin[c], 1, d2)
+        assert torch.equal(dxf[c], d2)
+    gblob = torch.zeros_like(blob)
+    dw, db = gblob[:, :cout * cin].unflatten(1, (cout, cin)), gblob[:, cout * cin:cout * cin + cout]
+    ops.linear_bwd_weight_batched(dz, x, dw, db)
+    ops.linear_bwd_weight_batched(dz, x, dw, db)                                                # accumulates: twice the gradient
+    w1, b1 = torch.empty(cout, cin, device=dev), torch.empty(cout, device=dev)
+    for c in range(C):
+        ops.linear_bwd_weight(dz[c], x[c], w1, b1)
+        tol = 3e-5 * np.sqrt(B)
+        np.testing.assert_allclose(dw[c].cpu().numpy(), 2 * w1.cpu().numpy(), rtol=1e-4, atol=tol)
+        np.testing.assert_allclose(db[c].cpu().numpy(), 2 * b1.cpu().numpy(), rtol=1e-4, atol=tol)
+    assert float(gblob[:, cout * cin + cout:].abs().max()) == 0.0                                # neighbours untouched
+
+
+def test_batched_pixel_loss_equals_the_single_problem_launches(dev):
+    from npp_amd import ops
+    C, N = 5, 1000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    pred, gt = torch.rand(C, N, 3, generator=g).to(dev), torch.rand(N, 3, generator=g).to(dev)
+    lat = (torch.randn(C, 6, generator=g) * 0.5).to(dev)
+    spline, n_knots, x_scale = ops.load_spline(dev)
+    loss, dpred, dlat = torch.zeros(C, device=dev), torch.empty(C, N, 3, device=dev), torch.zeros(C, 6, device=dev)
+    ops.pixel_loss_batched(pred, gt, lat, spline, n_knots, x_scale, 1.0, loss, dpred, dlat)
+    for c in range(C):
+        l1, d1, dl1 = torch.zeros(1, device=dev), torch.empty(N, 3, device=dev), torch.zeros(6, device=dev)
+        ops.pixel_loss(pred[c], gt, None, lat[c].contiguous(), spline, n_knots, x_scale, 1.0, l1, d1, dl1)
+        assert torch.equal(dpred[c], d1)
+        np.testing.assert_allclose(float(loss[c]), float(l1), rtol=1e-5)
+        np.testing.assert_allclose(dlat[c].cpu().numpy(), dl1.cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
 def _P(g):
     return {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
 
