@@ -286,8 +286,11 @@ static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool bat
   // problems, blockIdx.z = batch * splits + split) count all the batches' tiles towards the fill target.
   const int nb = g.nbatch > 1 ? g.nbatch : 1;
   const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64) * nb;
+  // a batched launch may split when its partial sums have somewhere zeroed to meet: the caller accumulates, or the outputs of the
+  // batches are back to back (one clear)
+  const bool dense_out = g.scb == (int64_t)g.M * g.N;
   int splits = 1;
-  if (g.act == 0 && !g.Z && g.ldc == g.N && tiles < 128 * nb && g.K >= 256 && (nb == 1 || (batch_split && g.accumulate))) {
+  if (g.act == 0 && !g.Z && !g.dact && g.ldc == g.N && tiles < 128 * nb && g.K >= 256 && (nb == 1 || (batch_split && (g.accumulate || dense_out)))) {
     static const int batch_fill = [] { const char* e = getenv("NPP_GEMM_BATCH_FILL"); return e ? atoi(e) : 640; }();
     splits = min(32, min((g.K + 63) / 64, max(1, ((nb > 1 ? batch_fill : 512) + tiles - 1) / tiles)));
   }
@@ -303,8 +306,10 @@ static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool bat
   if (nb == 1) {
     if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
     if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
-  } else if (g.rowsum && !g.accumulate) {
-    for (int b = 0; b < nb; ++b) (void)hipMemsetAsync(g.rowsum + b * g.srsb, 0, (size_t)g.M * sizeof(float), s);
+  } else {
+    if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)nb * g.M * g.N * sizeof(float), s);      // dense_out
+    if (g.rowsum && !g.accumulate)
+      for (int b = 0; b < nb; ++b) (void)hipMemsetAsync(g.rowsum + b * g.srsb, 0, (size_t)g.M * sizeof(float), s);
   }
   const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(splits * nb));
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, dim3(256), 0, s, g);
@@ -463,7 +468,9 @@ extern "C" int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, 
   g.B = d_f; g.sbk = 1; g.sbn = hw;                  // B(k = pos, n = c') = F[c'][pos]
   g.C = d_g; g.ldc = C;
   g.M = C; g.N = C; g.K = hw; g.nbatch = N; g.sab = g.sbb = (int64_t)C * hw; g.scb = (int64_t)C * C;
-  gemm_launch(g, true, true, (hipStream_t)stream);
+  // C x C outputs over hw = thousands of positions: without a split this is one workgroup per 64 x 64 tile walking the whole
+  // contraction (measured at C = 64, hw = 25 600, N = 6: 6 workgroups, 235 us); split, the partial sums meet by atomicAdd
+  gemm_launch(g, true, true, (hipStream_t)stream, true);
   return check_launch("npp_gram_fwd");
 }
 

@@ -25,6 +25,29 @@ def test_state_and_stream_match_numpy(NRS, seed):
     assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]                 # same number of words consumed
 
 
+@pytest.mark.parametrize("env", [{"NPP_RNG_AVX2": "0"}, {"NPP_RNG_THREADS": "0"}, {"NPP_RNG_AVX2": "0", "NPP_RNG_THREADS": "0"}, {}])
+def test_every_shuffle_form_is_the_numpy_stream(env):
+    """The shuffle has four forms (AVX2 runs of 64 words or the scalar groups of 8; helper-thread generation for >= 200 000 elements
+    or one thread), chosen once per process: each in its own interpreter against numpy.random.RandomState, including the state
+    afterwards (same number of generator words consumed) and populations around the block / run / threshold sizes."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from npp_amd.host_rng import NativeRandomState\n"
+        "a, b = np.random.RandomState(3), NativeRandomState(3)\n"
+        "for n in (1, 2, 63, 64, 65, 2047, 2048, 2049, 4097, 199999, 200000, 262144, 1048576 + 17):\n"
+        "    assert np.array_equal(a.choice(n, size=[min(n, 300)], replace=False), b.choice(n, size=[min(n, 300)], replace=False)), n\n"
+        "    assert a.uniform(0, 1) == b.uniform(0, 1)\n"
+        "sa, sb = a.get_state(), b.get_state()\n"
+        "assert np.array_equal(sa[1], sb[1]) and sa[2] == sb[2]\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_state_exchange_with_numpy(NRS):
     a = np.random.RandomState(7)
     a.uniform(size=1000)

@@ -18,5 +18,5 @@ for mode, pf in (("reference", 4), ("fast", 0), ("reference", 4)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(60): fr.step_full()
     torch.cuda.synchronize()
-    print("NPP_RNG_THREADS=" + os.environ.get("NPP_RNG_THREADS", "1"), mode, f"{(time.perf_counter() - t0) / 60 * 1e3:.3f} ms/iter")
+    print("NPP_RNG_THREADS=" + os.environ.get("NPP_RNG_THREADS", "default"), "NPP_RNG_AVX2=" + os.environ.get("NPP_RNG_AVX2", "default"), mode, f"{(time.perf_counter() - t0) / 60 * 1e3:.3f} ms/iter")
     fr.close()
