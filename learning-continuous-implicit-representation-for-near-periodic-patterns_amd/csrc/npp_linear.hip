@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
   for (int c = 0; c < nchunk; ++c) {
     gemm_sstore<A_KC>(sA, tid, ra, m0, g.M, kbeg + 32 * c, kend);
     gemm_sstore<B_KC>(sB, tid, rb, n0, g.N, kbeg + 32 * c, kend);
-    __syncthreads();
+    wg_barrier();
     if (c + 1 < nchunk) {
       gemm_gload<A_KC>(g.A, g.sam, g.sak, m0, g.M, kbeg + 32 * (c + 1), kend, va, tid, ra);
       gemm_gload<B_KC>(g.B, g.sbn, g.sbk, n0, g.N, kbeg + 32 * (c + 1), kend, vb, tid, rb);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
     }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks * kGemmLdp * 2], b[ks * kGemmLdp * 2], acc, 0, 0, 0);
-    __syncthreads();
+    wg_barrier();
   }
   if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
   const int n = n0 + wn * 32 + l31;
