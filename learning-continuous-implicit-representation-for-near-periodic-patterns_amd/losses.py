@@ -387,6 +387,18 @@ class _LPIPSLayerFunction(torch.autograd.Function):
         return df0 * g, None, None, None
 
 
+def _latent_blobs(inits, dev):
+    """The adaptive-loss latents of several taps / levels as views of ONE blob each for the values, their gradients and the two Adam
+    moments: optimizer.step() and zero_grad() over them are one launch each instead of one per tap (found in the kernel trace of the
+    'same'-source iterations: 5 Adam launches + 5 fills of ~4.8 us for 2944 latents)."""
+    sizes = [int(t.numel()) for t in inits]
+    lat = torch.cat([t.reshape(-1).to(torch.float32) for t in inits]).to(dev)
+    blobs = (lat, torch.zeros_like(lat), torch.zeros_like(lat), torch.zeros_like(lat))
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    views = tuple([b[int(offs[i]):int(offs[i + 1])] for i in range(len(sizes))] for b in blobs)
+    return blobs, views
+
+
 class LPIPS(nn.Module):
     """LPIPS(net='vgg') with the reference's adaptive-robust head.  forward(in0, in1, use_robust,
     normalize) returns the batch MEAN as a scalar (the caller's torch.mean, train.py:249, is folded in)."""
@@ -410,10 +422,8 @@ class LPIPS(nn.Module):
             lin_weights = [np.abs(rng.randn(c)).astype(np.float32) * 0.05 for c in self.chns]
         self.lins = [torch.as_tensor(np.asarray(w, np.float32).reshape(-1)).to(dev) for w in lin_weights]
         # AdaptiveLossFunction(num_dims=chn) per tap (lpips.py:57-61): [latent_alpha(C) | latent_scale(C)]
-        self.latents = [torch.cat([torch.full((c,), 2.3841858e-07), torch.zeros(c)]).to(dev) for c in self.chns]
-        self.dlatents = [torch.zeros_like(l) for l in self.latents]
-        self.lat_m = [torch.zeros_like(l) for l in self.latents]
-        self.lat_v = [torch.zeros_like(l) for l in self.latents]
+        (self._lat, self._dlat, self._lat_m, self._lat_v), (self.latents, self.dlatents, self.lat_m, self.lat_v) = _latent_blobs(
+            [torch.cat([torch.full((c,), 2.3841858e-07), torch.zeros(c)]) for c in self.chns], dev)
         self.lat_step = 0
         self.touched = False
         self.spline, self.n_knots, self.x_scale = ops.load_spline(dev)
@@ -472,17 +482,14 @@ class LPIPS(nn.Module):
         return out
 
     def zero_latent_grads(self):
-        for d in self.dlatents:
-            d.zero_()
+        self._dlat.zero_()                              # one fill: the per-tap vectors are views of one blob (_latent_blobs)
         self.touched = False
 
     def adam_step(self, lr):
         """Adam over the robust latents; only called when they received a gradient this iteration
-        (torch skips parameters whose grad is None: their step count does not advance)."""
+        (torch skips parameters whose grad is None: their step count does not advance).  One launch over the blob of all taps."""
         self.lat_step += 1
-        for kk in range(5):
-            ops.adam_step(self.latents[kk], self.lat_m[kk], self.lat_v[kk], self.dlatents[kk], 1, self.latents[kk].numel(),
-                          lr, self.lat_step)
+        ops.adam_step(self._lat, self._lat_m, self._lat_v, self._dlat, 1, self._lat.numel(), lr, self.lat_step)
 
 
 _VGG16_STYLE = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M"]          # vgg16.features[:17]: enc_1 | enc_2 | enc_3
@@ -500,10 +507,8 @@ class StyleLoss:
         self.device = torch.device(device)
         self.hip_trunk = HipTrunk(_VGG16_STYLE, taps=(4, 9, 16), state_dict=vgg_state_dict, seed=seed, device=self.device)
         # AdaptiveLossFunction(num_dims = chn ** 2) per level (style_loss.py:23-27): [latent_alpha(D) | latent_scale(D)]
-        self.latents = [torch.cat([torch.full((c * c,), 2.3841858e-07), torch.zeros(c * c)]).to(self.device) for c in self.chns]
-        self.dlatents = [torch.zeros_like(l) for l in self.latents]
-        self.lat_m = [torch.zeros_like(l) for l in self.latents]
-        self.lat_v = [torch.zeros_like(l) for l in self.latents]
+        (self._lat, self._dlat, self._lat_m, self._lat_v), (self.latents, self.dlatents, self.lat_m, self.lat_v) = _latent_blobs(
+            [torch.cat([torch.full((c * c,), 2.3841858e-07), torch.zeros(c * c)]) for c in self.chns], self.device)
         self.lat_step = 0
         self.spline, self.n_knots, self.x_scale = ops.load_spline(self.device)
 
@@ -535,10 +540,8 @@ class StyleLoss:
         return t._backward(dfs, n, ones, tuple(xy.shape), zero_rest=False)
 
     def zero_latent_grads(self):
-        for d in self.dlatents:
-            d.zero_()
+        self._dlat.zero_()
 
     def adam_step(self, lr):
         self.lat_step += 1
-        for i in range(3):
-            ops.adam_step(self.latents[i], self.lat_m[i], self.lat_v[i], self.dlatents[i], 1, self.latents[i].numel(), lr, self.lat_step)
+        ops.adam_step(self._lat, self._lat_m, self._lat_v, self._dlat, 1, self._lat.numel(), lr, self.lat_step)

@@ -291,4 +291,5 @@ def test_c4_remapping_loop_at_1024sq(dev):
     b.net.pixel_loss(bp, n_pix, batch["gt"], mask=batch.get("pmask"), weight=1.0)
     assert batch.get("pmask") is not None                         # remapping: gt_mask = clear_mask (train.py:203)
     da, db = a.net.workspace(bp)["dpred"][:n_pix], b.net.workspace(bp)["dpred"][:n_pix]
-    assert torch.equal(da, db) and float(a.net.loss_buf[0]) == float(b.net.loss_buf[0])
+    # (the gradient rows are written once each: bit-identical; the loss word is a float atomicAdd over 232 blocks: equal to round-off)
+    assert torch.equal(da, db) and abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) <= 1e-6 * abs(float(b.net.loss_buf[0]))

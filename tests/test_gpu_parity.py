@@ -896,10 +896,12 @@ def test_two_row_group_step_equals_the_single_stream_step(dev, source):
     assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
 
 
-def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=30):
+def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20):
     """Shared body of the g8r / g8s / g8d tests: sampler decisions call by call, weighted patch loss of the first iterations value
     by value (the goldens use the stable tie order, tests/golden/make_golden_fit_tasks.py), PSNR checkpoints within BASELINE's
-    0.1 dB, pixel-loss latents, LR clock."""
+    0.1 dB, pixel-loss latents, LR clock.  The loss values are compared over the first 20 iterations: the contextual core reduces
+    with float atomics, so two runs of THIS code drift apart by a few percent of a 1e-7-sized loss by iteration 30 (seen once in
+    ~10 runs at 3.6 %); the PSNR checkpoints and latents cover the rest of the trajectory."""
     traj = {int(r[0]): r[1:] for r in g["traj"]}
     ploss = {int(r[0]): r[1] for r in g["patch_loss"]}
     code = {"val": 0, "train": 1, "same": 2}
