@@ -408,6 +408,43 @@ int npp_linear_bwd_data_batched(const float* d_dz, int64_t lddz, int64_t sdzb, c
 int npp_linear_bwd_weight_batched(const float* d_dz, int64_t lddz, int64_t sdzb, const float* d_x, int64_t ldx, int64_t sxb,
                                   int nbatch, int64_t B, int in, int out, float* d_dw, int64_t sdwb, float* d_db,
                                   int64_t sdbb, void* stream);
+/* Weight gradient of nbatch stacked dense layers with EXPLICIT operand strides: dw[b][o][i] += sum_r dz(b, r, o) x(b, r, i),
+ * db[b][o] += sum_r dz(b, r, o), where dz(b, r, o) = d_dz[b * sdzb + r * dz_sr + o * dz_so] and x(b, r, i) = d_x[b * sxb + r * x_sr +
+ * i * x_si]: row-major operands (s?r = ld, s?o / s?i = 1: the form above) or feature-major ones (s?r = 1: the stashes of the fused
+ * chains below).  x_snake != 0: d_x holds PRE-activations and the layer input is snake(d_x) = x + sin^2 x, formed while the operand is
+ * staged (the fused chains stash z only).  Accumulates (caller clears). */
+int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, int64_t dz_so, int64_t sdzb, const float* d_x, int64_t x_sr,
+                                  int64_t x_si, int64_t sxb, int x_snake, int nbatch, int64_t B, int in, int out, float* d_dw,
+                                  int64_t lddw, int64_t sdwb, float* d_db, int64_t sdbb, void* stream);
+
+/* ---- f1 fused: NPP_Net_light(D = 4, W = 256, snake) forward and data-gradient chains, all candidates of an image in one launch
+ * each, exact fp32 (models/networks.py:176-263 with len(freq_scales) == 1; NPP_proposal/search.py:113-147).  The parameter blob of
+ * candidate c starts at d_params + c * params_stride; npp_light_desc says where its seven layers live (index 0-3 periodic_linears,
+ * 4 pos_linears.0, 5 feature_linear1, 6 rgb_linear; weight [n_out][ld] with ld >= n_in, bias [n_out]).
+ * npp_light_pack: the MFMA-ordered copies of the weights the chains stream (forward and transposed), npp_light_pack_floats()
+ * floats per candidate; rebuild after every optimiser step.
+ * npp_light_fwd: x_per (C, B, 20), x_pos (B, 42) shared -> d_pred (C, B, 3) = sigmoid(raw) and the FEATURE-major stash
+ * (C, npp_light_stash_rows(), B): pre-activations z_0 .. z_3, [f1 | x_pos | 0] (304 rows), z_p -- row offsets by
+ * npp_light_stash_row(0..5) = z0 z1 z2 z3 hp zp (the activations are snake(z): recomputed by their consumers).
+ * npp_light_bwd: d_dpred (C, B, 3) = dL/dpred -> d_draw (C, B, 3) = dL/draw and the gradient stash (C, npp_light_dstash_rows(), B):
+ * d z_0 .. d z_3, d f1, d z_p (npp_light_dstash_row(0..5)).  The weight gradients are npp_linear_bwd_weight_strided over the two
+ * stashes.  B a multiple of 64. */
+typedef struct {
+  int64_t w_off[7], b_off[7];
+  int32_t n_out[7], n_in[7], ld[7];
+} npp_light_desc;
+int64_t npp_light_pack_floats(void);
+int64_t npp_light_stash_rows(void);
+int64_t npp_light_dstash_rows(void);
+int npp_light_stash_row(int which);
+int npp_light_dstash_row(int which);
+int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, float* d_pack, int64_t pack_stride,
+                   void* stream);
+int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                  const float* d_x_per, const float* d_x_pos, int C, int64_t B, float* d_stash, float* d_pred, void* stream);
+int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                  const float* d_stash, const float* d_pred, const float* d_dpred, int C, int64_t B, float* d_draw,
+                  float* d_dstash, void* stream);
 /* npp_pixel_loss over nbatch problems: d_pred / d_dpred (nbatch, N, 3), d_latents / d_dlatent (nbatch, 6), d_loss (nbatch);
  * the targets d_gt (N, 3) are shared when gt_stride == 0, else problem b reads d_gt + b * gt_stride. */
 int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,

@@ -29,6 +29,11 @@ class PatchGrad(C.Structure):
                 ("row0", C.c_int64), ("n_p", C.c_int32), ("k", C.c_int32), ("P", C.c_int32), ("comp", C.c_int32)]
 
 
+class LightDesc(C.Structure):
+    """npp_light_desc (include/npp_hip.h): where the seven layers of an NPP_Net_light live in its parameter blob."""
+    _fields_ = [("w_off", C.c_int64 * 7), ("b_off", C.c_int64 * 7), ("n_out", C.c_int32 * 7), ("n_in", C.c_int32 * 7), ("ld", C.c_int32 * 7)]
+
+
 class EmbedCfg(C.Structure):
     """npp_embed_cfg (include/npp_hip.h) == get_embedder(...) arguments, models/embedder.py:60-90."""
     _fields_ = [("K", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
@@ -121,6 +126,15 @@ SYMBOLS = {
     "npp_linear_fwd_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "npp_linear_bwd_data_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp]),
     "npp_linear_bwd_weight_batched": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "npp_linear_bwd_weight_strided": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "npp_light_pack_floats": (_i64, []),
+    "npp_light_stash_rows": (_i64, []),
+    "npp_light_dstash_rows": (_i64, []),
+    "npp_light_stash_row": (_i32, [_i32]),
+    "npp_light_dstash_row": (_i32, [_i32]),
+    "npp_light_pack": (_i32, [C.POINTER(LightDesc), _vp, _i64, _i32, _vp, _i64, _vp]),
+    "npp_light_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "npp_light_bwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "npp_pixel_loss_batched": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_act_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "npp_act_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp]),

@@ -1,0 +1,383 @@
+// npp_light.hip -- NPP_Net_light's training chains fused, exact fp32 (NPP_proposal/search.py:85-147 fits one
+// NPP_Net_light per candidate; models/networks.py:176-263 with len(freq_scales) == 1, D = 4, W = 256, snake):
+//
+//   forward   x_per(20) -> 4 x [256, snake] -> feature_linear1 (256, linear) -> [f1 | x_pos(42)] -> pos_linears.0 (128, snake)
+//             -> rgb_linear (3) -> sigmoid                                                         ONE launch
+//   backward  dpred -> d raw -> d a_p -> d z_p -> d f1 -> d z_3 .. d z_0 (the data gradients)      ONE launch
+//
+// for ALL candidates of an image (blockIdx.y = candidate, each with its own weights) on the building blocks of the fp32 render
+// chain (npp_chain32.h): a 256-thread workgroup owns 64 pixel rows, GEMMs transposed (Z^T = W X^T), weights streamed from a
+// packed fp32 buffer as the A operand, activations in one LDS region [feature][64 rows] as the B operand, every contraction on
+// v_mfma_f32_32x32x2_f32.  What the unfused path (npp_linear.hip, one launch per layer: 13 forward + data-gradient launches of
+// 20-45 us for 9 stacked candidates) loses is not arithmetic but the per-launch ramp and the LDS staging of both operands;
+// here an activation never leaves the chip between layers except as the stash the weight gradients need.
+//
+// Stashes are FEATURE-major ([feature][row], per candidate): an accumulator tile holds one row per lane, so a register of a
+// tile is 32 consecutive rows of one feature -- a coalesced 128-byte store -- and the weight-gradient GEMMs (npp_linear.hip,
+// batched, strided operands) take both operands contiguous along the rows they contract.
+#include "npp_chain32.h"
+
+namespace npp {
+
+constexpr int kLW = 256;                        // hidden width
+constexpr int kLPosOut = 128;                   // pos_linears.0 outputs
+constexpr int kLPer = 20, kLPos = 42;           // periodic / positional input widths
+constexpr int kLHp = 304;                       // [f1 (256) | x_pos (42) | 0-pad (6)]: 38 k-step groups
+constexpr int kLRegion = kLHp * kRowTile * 4;   // 77 824 B: the activation region
+constexpr int kLThreads = 256;
+
+// feature rows of the forward stash of one candidate, in order
+enum { LS_Z0 = 0, LS_Z1 = 256, LS_Z2 = 512, LS_Z3 = 768, LS_HP = 1024, LS_ZP = LS_HP + kLHp, LS_ROWS = LS_ZP + kLPosOut };
+// ... and of the gradient stash
+enum { LD_Z0 = 0, LD_Z1 = 256, LD_Z2 = 512, LD_Z3 = 768, LD_F1 = 1024, LD_ZP = 1280, LD_ROWS = LD_ZP + kLPosOut };
+
+// packed weights of one candidate (16-byte units): forward pack, then the transposed pack of the backward chain
+enum { LF_L0 = 0, LF_L1, LF_L2, LF_L3, LF_F1, LF_POS, LF_N };
+enum { LB_POS = 0, LB_F1, LB_L3, LB_L2, LB_L1, LB_N };
+struct LightPackDesc {
+  int32_t f_off[LF_N], f_groups[LF_N], f_nt[LF_N];
+  int32_t b_off[LB_N], b_groups[LB_N];
+  int32_t f_total, total;                       // units of the forward pack / of both
+};
+__host__ __device__ inline LightPackDesc light_pack_desc() {
+  LightPackDesc d{};
+  int off = 0;
+  const int fg[LF_N] = {4, 32, 32, 32, 32, kLHp / 8}, fnt[LF_N] = {8, 8, 8, 8, 8, 4};
+  for (int l = 0; l < LF_N; ++l) { d.f_off[l] = off; d.f_groups[l] = fg[l]; d.f_nt[l] = fnt[l]; off += fg[l] * fnt[l] * 64; }
+  d.f_total = off;
+  const int bg[LB_N] = {kLPosOut / 8, 32, 32, 32, 32};
+  for (int l = 0; l < LB_N; ++l) { d.b_off[l] = off; d.b_groups[l] = bg[l]; off += bg[l] * 8 * 64; }
+  d.total = off;
+  return d;
+}
+
+struct LightArgs {
+  npp_light_desc L;                             // parameter-blob offsets (include/npp_hip.h)
+  const float* params; int64_t params_stride;   // (C, params_stride) fp32
+  const float* pack; int64_t pack_stride;       // (C, pack_stride) fp32, pack_stride = 4 * LightPackDesc.total
+  const float* x_per;                           // (C, B, 20)
+  const float* x_pos;                           // (B, 42), shared
+  float* stash;                                 // (C, LS_ROWS, B)
+  float* pred;                                  // (C, B, 3)
+  const float* dpred;                           // (C, B, 3)        backward only
+  float* draw;                                  // (C, B, 3)        backward only
+  float* dstash;                                // (C, LD_ROWS, B)  backward only
+  int64_t B;
+};
+
+// ---- packs ----------------------------------------------------------------------------------------------------------------
+// unit u = [g][nt][lane]: element e = A[32 nt + (lane & 31)][8 g + e + 4 (lane >> 5)], A = W (forward) or W^T (backward),
+// zero outside the matrix
+__global__ void light_pack_kernel(LightArgs a, LightPackDesc pd, float* __restrict__ out, int64_t out_stride) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= pd.total) return;
+  const float* P = a.params + (int64_t)blockIdx.y * a.params_stride;
+  const bool bwd = u >= pd.f_total;
+  int l = 0;
+  if (!bwd) { for (int q = 1; q < LF_N; ++q) if (u >= pd.f_off[q]) l = q; }
+  else { for (int q = 1; q < LB_N; ++q) if (u >= pd.b_off[q]) l = q; }
+  const int r = u - (bwd ? pd.b_off[l] : pd.f_off[l]);
+  const int nt_n = bwd ? 8 : pd.f_nt[l];
+  const int lane = r & 63, nt = (r >> 6) % nt_n, g = (r >> 6) / nt_n;
+  const int row = nt * 32 + (lane & 31), h = lane >> 5;
+  // source matrix (out x in, leading dimension ld) of this pack entry
+  const int fwd_layer[LF_N] = {0, 1, 2, 3, 5, 4};          // npp_light_desc index: periodic 0..3, pos (4), feature1 (5), rgb (6)
+  const int bwd_layer[LB_N] = {4, 5, 3, 2, 1};
+  const int li = bwd ? bwd_layer[l] : fwd_layer[l];
+  const float* Wm = P + a.L.w_off[li];
+  const int ld = a.L.ld[li], n_out = a.L.n_out[li], n_in = a.L.n_in[li];
+  f32x4_t o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = 8 * g + e + 4 * h;
+    float v = 0.0f;
+    if (!bwd) { if (row < n_out && col < n_in) v = Wm[(int64_t)row * ld + col]; }
+    else if (row < kLW && col < n_out) v = Wm[(int64_t)col * ld + row];        // A = W^T restricted to the first 256 inputs
+    o[e] = v;
+  }
+  ((f32x4_t*)(out + (int64_t)blockIdx.y * out_stride))[u] = o;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+// epilogue of a hidden layer: z (+ bias already in acc) -> stash zT, h = snake(z) (or z) -> region (+ stash hT).  Only z is stashed for
+// the snake layers: the weight-gradient GEMM forms h = snake(z) again while it stages the operand (npp_linear_bwd_weight_strided)
+template <bool SNAKE, int NTW>
+__device__ __forceinline__ void light_epi(f32x16 (&acc)[NTW][kNB], char* region, float* __restrict__ zT, float* __restrict__ hT, uint32_t B,
+                                          uint32_t row0, int nt0, int b, int h) {
+  // 32-bit element indices off the (uniform) array bases: the launcher bounds rows x B below 2^31
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      const uint32_t f0 = (uint32_t)((nt0 + nt) * 32 + 4 * h);
+      uint32_t g = f0 * B + row0 + (uint32_t)(bt * 32 + b);
+      char* rg = region ? region + (f0 * kRowTile + bt * 32 + b) * 4 : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {            // feature f0 + (r & 3) + 8 (r >> 2)
+        const uint32_t gi = g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B;
+        float z = acc[nt][bt][r];
+        if (zT) zT[gi] = z;
+        if (SNAKE) z = snake_fast(z);
+        acc[nt][bt][r] = z;
+        if (hT) hT[gi] = z;
+        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * kRowTile * 4) = z;
+      }
+    }
+}
+
+__global__ __launch_bounds__(kLThreads, 2) void light_fwd_kernel(LightArgs a, LightPackDesc pd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R = smem;
+  const int tid = threadIdx.x, lane = tid & 63, b = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y;
+  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * kRowTile;
+  const float* P = a.params + (int64_t)c * a.params_stride;
+  float* S = a.stash + (int64_t)c * LS_ROWS * B;
+  const int nt0 = 2 * wave;
+  // x_per tile -> region features 0..31 (20 real, 12 zero: L0 is packed as 4 k-step groups)
+  {
+    const float* xp = a.x_per + ((int64_t)c * B + row0) * kLPer;
+    float* Rf = (float*)R;
+    for (int i = tid; i < 32 * kRowTile; i += kLThreads) {
+      const int f = i >> 6, row = i & 63;
+      Rf[f * kRowTile + row] = f < kLPer ? xp[row * kLPer + f] : 0.0f;
+    }
+  }
+  wg_barrier();
+  const wrsrc_t rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride, pd.total);
+  const ActSrc32 act{R + ((4 * h) * kRowTile + b) * 4};
+  f32x16 acc[2][kNB];
+#pragma unroll 1
+  for (int l = 0; l < 4; ++l) {
+    bias32<2>(acc, P + a.L.b_off[l], nt0, h);
+    part32<2, 8>(acc, rsrc, (uint32_t)pd.f_off[LF_L0 + l], pd.f_groups[LF_L0 + l], nt0, lane, act);
+    wg_barrier();                               // every wave has read its last operand of this layer
+    light_epi<true, 2>(acc, R, S + (int64_t)(LS_Z0 + 256 * l) * B, nullptr, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+    wg_barrier();
+  }
+  // feature_linear1 (linear) -> region rows 0..255 and the first 256 rows of hpT; x_pos (+ zero pad) behind it
+  bias32<2>(acc, P + a.L.b_off[5], nt0, h);
+  part32<2, 8>(acc, rsrc, (uint32_t)pd.f_off[LF_F1], pd.f_groups[LF_F1], nt0, lane, act);
+  wg_barrier();
+  light_epi<false, 2>(acc, R, nullptr, S + (int64_t)LS_HP * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+  {
+    float* Rf = (float*)R;
+    float* hp = S + (int64_t)LS_HP * B;
+    for (int i = tid; i < (kLHp - kLW) * kRowTile; i += kLThreads) {
+      const int f = i >> 6, row = i & 63;
+      const float v = f < kLPos ? a.x_pos[(row0 + row) * kLPos + f] : 0.0f;
+      Rf[(kLW + f) * kRowTile + row] = v;
+      hp[(int64_t)(kLW + f) * B + row0 + row] = v;
+    }
+  }
+  wg_barrier();
+  // pos_linears.0: 304 -> 128 (snake), one neuron tile per wave; a_p stays in registers for rgb_linear
+  f32x16 accp[1][kNB];
+  bias32<1>(accp, P + a.L.b_off[4], wave, h);
+  part32<1, 4>(accp, rsrc, (uint32_t)pd.f_off[LF_POS], pd.f_groups[LF_POS], wave, lane, act);
+  light_epi<true, 1>(accp, nullptr, S + (int64_t)LS_ZP * B, nullptr, (uint32_t)B, (uint32_t)row0, wave, b, h);
+  // rgb_linear 128 -> 3 + sigmoid (models/helpers.py:55-56)
+  wg_barrier();
+  float* sRGB = (float*)R;                      // [4 waves][64 rows][3]
+  {
+    const float* Wr = P + a.L.w_off[6];
+    const int ldr = a.L.ld[6];
+    float part[kNB][3];
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) part[bt][q] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = wave * 32 + acc_row(r, h);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float w = Wr[q * ldr + k];
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) part[bt][q] = fmaf(w, accp[0][bt][r], part[bt][q]);
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float v = part[bt][q] + __shfl_xor(part[bt][q], 32, 64);
+        if (h == 0) sRGB[(wave * kRowTile + bt * 32 + b) * 3 + q] = v;
+      }
+  }
+  wg_barrier();
+  if (tid < kRowTile * 3) {
+    const int row = tid / 3, q = tid - row * 3;
+    float z = P[a.L.b_off[6] + q];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + q];
+    a.pred[((int64_t)c * B + row0 + row) * 3 + q] = 1.0f / (1.0f + expf(-z));
+  }
+}
+
+// ---- backward (data gradients) ------------------------------------------------------------------------------------------------
+// epilogue: d h -> d z = d h * snake'(z) (z from the forward stash; DERIV false: d z = d h) -> gradient stash (+ region)
+template <bool DERIV>
+__device__ __forceinline__ void light_bepi(f32x16 (&acc)[2][kNB], char* region, const float* __restrict__ zT, float* __restrict__ dT, uint32_t B,
+                                           uint32_t row0, int nt0, int b, int h) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      const uint32_t f0 = (uint32_t)((nt0 + nt) * 32 + 4 * h);
+      const uint32_t g = f0 * B + row0 + (uint32_t)(bt * 32 + b);
+      char* rg = region ? region + (f0 * kRowTile + bt * 32 + b) * 4 : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t gi = g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B;
+        float d = acc[nt][bt][r];
+        if (DERIV) d *= 1.0f + __builtin_amdgcn_sinf(zT[gi] * (2.0f * kInv2Pi));          // activations.py:29-35: 1 + sin 2z
+        dT[gi] = d;
+        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * kRowTile * 4) = d;
+      }
+    }
+}
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][bt][r] = 0.0f;
+}
+
+__global__ __launch_bounds__(kLThreads, 2) void light_bwd_kernel(LightArgs a, LightPackDesc pd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R = smem;
+  float* sD = (float*)(smem + kLW * kRowTile * 4);          // d raw [64 rows][3] behind the 256-feature part of the region
+  const int tid = threadIdx.x, lane = tid & 63, b = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = blockIdx.y;
+  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * kRowTile;
+  const float* P = a.params + (int64_t)c * a.params_stride;
+  const float* S = a.stash + (int64_t)c * LS_ROWS * B;
+  float* D = a.dstash + (int64_t)c * LD_ROWS * B;
+  const int nt0 = 2 * wave;
+  // d raw = d pred * pred (1 - pred)
+  if (tid < kRowTile * 3) {
+    const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
+    const float p = a.pred[g], d = a.dpred[g] * p * (1.0f - p);
+    a.draw[g] = d;
+    sD[tid] = d;
+  }
+  wg_barrier();
+  // d a_p = d raw W_rgb; d z_p = d a_p * snake'(z_p) -> region rows 0..127 + stash
+  {
+    const float* Wr = P + a.L.w_off[6];
+    const int ldr = a.L.ld[6];
+    const float* zp = S + (int64_t)LS_ZP * B;
+    float* dzp = D + (int64_t)LD_ZP * B;
+    float* Rf = (float*)R;
+    for (int i = tid; i < kLPosOut * kRowTile; i += kLThreads) {
+      const int k = i >> 6, row = i & 63;
+      float d = sD[row * 3] * Wr[k];
+      d = fmaf(sD[row * 3 + 1], Wr[ldr + k], d);
+      d = fmaf(sD[row * 3 + 2], Wr[2 * ldr + k], d);
+      const int64_t g = (int64_t)k * B + row0 + row;
+      d *= 1.0f + __builtin_amdgcn_sinf(zp[g] * (2.0f * kInv2Pi));
+      dzp[g] = d;
+      Rf[k * kRowTile + row] = d;
+    }
+  }
+  wg_barrier();
+  const wrsrc_t rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride, pd.total);
+  const ActSrc32 act{R + ((4 * h) * kRowTile + b) * 4};
+  f32x16 acc[2][kNB];
+  // d f1 = W_pos[:, :256]^T d z_p   (feature_linear1 is linear: this IS its d z; x_pos gets no gradient)
+  zero_acc(acc);
+  part32<2, 8>(acc, rsrc, (uint32_t)pd.b_off[LB_POS], pd.b_groups[LB_POS], nt0, lane, act);
+  wg_barrier();
+  light_bepi<false>(acc, R, nullptr, D + (int64_t)LD_F1 * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+  wg_barrier();
+  // d z_3 = (W_f1^T d f1) * snake'(z_3), d z_2 = (W_3^T d z_3) * snake'(z_2), ..., d z_0
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    const int l = 3 - j;                        // hidden layer whose d z this step produces
+    zero_acc(acc);
+    part32<2, 8>(acc, rsrc, (uint32_t)pd.b_off[LB_F1 + j], pd.b_groups[LB_F1 + j], nt0, lane, act);
+    wg_barrier();
+    light_bepi<true>(acc, l > 0 ? R : nullptr, S + (int64_t)(LS_Z0 + 256 * l) * B, D + (int64_t)(LD_Z0 + 256 * l) * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+    wg_barrier();
+  }
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+static int light_check(const npp_light_desc* L, const void* p0, const void* p1, int C, int64_t B, const char* who) {
+  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < kRowTile || B % kRowTile || B * 512 >= 0x7fffffffLL) {
+    set_error("%s: bad argument (C=%d B=%lld; B a positive multiple of %d)", who, C, (long long)B, kRowTile);
+    return NPP_ERR_ARG;
+  }
+  const int n_out[7] = {kLW, kLW, kLW, kLW, kLPosOut, kLW, 3}, n_in[7] = {kLPer, kLW, kLW, kLW, kLW + kLPos, kLW, kLPosOut};
+  for (int i = 0; i < 7; ++i)
+    if (L->n_out[i] != n_out[i] || L->n_in[i] != n_in[i] || L->ld[i] < n_in[i] || L->w_off[i] < 0 || L->b_off[i] < 0) {
+      set_error("%s: layer %d is %d x %d (ld %d): this build fuses NPP_Net_light(D=4, W=256) with 20 / 42 input columns only", who, i,
+                L->n_out[i], L->n_in[i], L->ld[i]);
+      return NPP_ERR_UNSUPPORTED;
+    }
+  return NPP_OK;
+}
+
+extern "C" int64_t npp_light_pack_floats(void) { return 4 * (int64_t)light_pack_desc().total; }
+extern "C" int64_t npp_light_stash_rows(void) { return LS_ROWS; }
+extern "C" int64_t npp_light_dstash_rows(void) { return LD_ROWS; }
+extern "C" int npp_light_stash_row(int which) {
+  const int rows[7] = {LS_Z0, LS_Z1, LS_Z2, LS_Z3, LS_HP, LS_ZP, LS_ROWS};
+  return (which < 0 || which > 6) ? NPP_ERR_ARG : rows[which];
+}
+extern "C" int npp_light_dstash_row(int which) {
+  const int rows[7] = {LD_Z0, LD_Z1, LD_Z2, LD_Z3, LD_F1, LD_ZP, LD_ROWS};
+  return (which < 0 || which > 6) ? NPP_ERR_ARG : rows[which];
+}
+
+extern "C" int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, float* d_pack, int64_t pack_stride,
+                              void* stream) {
+  int rc = light_check(L, d_params, d_pack, C, kRowTile, "npp_light_pack");
+  if (rc) return rc;
+  const LightPackDesc pd = light_pack_desc();
+  if (pack_stride < 4 * (int64_t)pd.total || pack_stride % 4) { set_error("npp_light_pack: pack_stride %lld", (long long)pack_stride); return NPP_ERR_ARG; }
+  LightArgs a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride;
+  hipLaunchKernelGGL(light_pack_kernel, dim3((unsigned)((pd.total + 255) / 256), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd, d_pack,
+                     pack_stride);
+  return check_launch("npp_light_pack");
+}
+
+extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                             const float* d_x_per, const float* d_x_pos, int C, int64_t B, float* d_stash, float* d_pred, void* stream) {
+  int rc = light_check(L, d_params, d_pack, C, B, "npp_light_fwd");
+  if (rc) return rc;
+  if (!d_x_per || !d_x_pos || !d_stash || !d_pred) { set_error("npp_light_fwd: null argument"); return NPP_ERR_ARG; }
+  LightArgs a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
+  a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)light_fwd_kernel, kLRegion)) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(light_fwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kLThreads), kLRegion, (hipStream_t)stream, a,
+                     light_pack_desc());
+  return check_launch("npp_light_fwd");
+}
+
+extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                             const float* d_stash, const float* d_pred, const float* d_dpred, int C, int64_t B, float* d_draw, float* d_dstash,
+                             void* stream) {
+  int rc = light_check(L, d_params, d_pack, C, B, "npp_light_bwd");
+  if (rc) return rc;
+  if (!d_stash || !d_pred || !d_dpred || !d_draw || !d_dstash) { set_error("npp_light_bwd: null argument"); return NPP_ERR_ARG; }
+  LightArgs a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
+  a.stash = (float*)d_stash; a.pred = (float*)d_pred; a.dpred = d_dpred; a.draw = d_draw; a.dstash = d_dstash; a.B = B;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)light_bwd_kernel, kLRegion)) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(light_bwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kLThreads), kLRegion, (hipStream_t)stream, a,
+                     light_pack_desc());
+  return check_launch("npp_light_bwd");
+}

@@ -35,6 +35,7 @@ struct GemmArgs {
   int64_t szb, sbiasb, srsb;      //      ... and Z / bias / rowsum
   int splits;                     // k ranges per problem (>= 1)
   const float* dact; int64_t lddact, sdactb; int dact_kind;   // optional: C = (A B) * act'(dact[m][n]) (kinds of act_bwd_kernel)
+  int b_snake;                    // B operand is stored as pre-activations: snake() them on their way into LDS (fused-chain stashes)
   int vec_a, vec_b;               // set by the launcher: the operand's runs of 4 may be fetched as one 16-byte load
 };
 
@@ -78,21 +79,27 @@ __device__ __forceinline__ void gemm_gload(const float* __restrict__ P, int64_t 
   }
 }
 template <bool KC>
-__device__ __forceinline__ void gemm_sstore(float* __restrict__ S, int tid, const float (&reg)[8], int m0, int M, int k0, int kend) {
+__device__ __forceinline__ void gemm_sstore(float* __restrict__ S, int tid, const float (&reg)[8], int m0, int M, int k0, int kend, bool snake = false) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     float v[4];
     if (KC) {
       const int m = (tid >> 3) + 32 * r, kp = 2 * (tid & 7);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (m0 + m < M && k0 + 2 * kp + e < kend) ? reg[4 * r + e] : 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        const float x = snake ? snake_fast(reg[4 * r + e]) : reg[4 * r + e];
+        v[e] = (m0 + m < M && k0 + 2 * kp + e < kend) ? x : 0.0f;
+      }
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       *(f32x2*)(S + ((kp + 0) * kGemmLdp + m) * 2) = f32x2{v[0], v[1]};
       *(f32x2*)(S + ((kp + 1) * kGemmLdp + m) * 2) = f32x2{v[2], v[3]};
     } else {
       const int k = (tid >> 4) + 16 * r, m = 4 * (tid & 15);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[((k >> 1) * kGemmLdp + m + e) * 2 + (k & 1)] = (m0 + m + e < M && k0 + k < kend) ? reg[4 * r + e] : 0.0f;
+      for (int e = 0; e < 4; ++e) {
+        const float x = snake ? snake_fast(reg[4 * r + e]) : reg[4 * r + e];
+        S[((k >> 1) * kGemmLdp + m + e) * 2 + (k & 1)] = (m0 + m + e < M && k0 + k < kend) ? x : 0.0f;
+      }
     }
   }
 }
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
   const float* __restrict__ b = sB + (wn * 32 + l31) * 2 + kh;
   for (int c = 0; c < nchunk; ++c) {
     gemm_sstore<A_KC>(sA, tid, ra, m0, g.M, kbeg + 32 * c, kend);
-    gemm_sstore<B_KC>(sB, tid, rb, n0, g.N, kbeg + 32 * c, kend);
+    gemm_sstore<B_KC>(sB, tid, rb, n0, g.N, kbeg + 32 * c, kend, g.b_snake != 0);
     wg_barrier();
     if (c + 1 < nchunk) {
       gemm_gload<A_KC>(g.A, g.sam, g.sak, m0, g.M, kbeg + 32 * (c + 1), kend, va, tid, ra);
@@ -427,6 +434,25 @@ extern "C" int npp_linear_bwd_weight_batched(const float* d_dz, int64_t lddz, in
   g.nbatch = nbatch; g.sab = sdzb; g.sbb = sxb; g.scb = sdwb; g.srsb = sdbb;
   gemm_launch(g, false, false, (hipStream_t)stream, true);
   return check_launch("npp_linear_bwd_weight_batched");
+}
+
+extern "C" int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, int64_t dz_so, int64_t sdzb, const float* d_x, int64_t x_sr,
+                                             int64_t x_si, int64_t sxb, int x_snake, int nbatch, int64_t B, int in, int out, float* d_dw,
+                                             int64_t lddw, int64_t sdwb, float* d_db, int64_t sdbb, void* stream) {
+  if (!d_dz || !d_x || !d_dw || nbatch < 1 || nbatch > 4096 || !lin_dims_ok(B, in, out) || lddw < in || dz_sr < 1 || dz_so < 1 || x_sr < 1 ||
+      x_si < 1) {
+    set_error("npp_linear_bwd_weight_strided: bad argument (nbatch=%d B=%lld in=%d out=%d)", nbatch, (long long)B, in, out);
+    return NPP_ERR_ARG;
+  }
+  GemmArgs g{};
+  g.A = d_dz; g.sam = dz_so; g.sak = dz_sr;          // A(m = n_out, k = row)
+  g.B = d_x; g.sbk = x_sr; g.sbn = x_si;             // B(k = row, n = col)
+  g.C = d_dw; g.ldc = lddw;
+  g.M = out; g.N = in; g.K = (int)B; g.act = 0; g.accumulate = 1;
+  g.rowsum = d_db; g.b_snake = x_snake;
+  g.nbatch = nbatch; g.sab = sdzb; g.sbb = sxb; g.scb = sdwb; g.srsb = sdbb;
+  gemm_launch(g, dz_sr == 1, x_sr == 1, (hipStream_t)stream, true);
+  return check_launch("npp_linear_bwd_weight_strided");
 }
 
 extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,

@@ -221,7 +221,10 @@ class NPPNetLightBatch:
     (ProposalRanker._pixel_draws) and therefore x_pos and the colours; x_per (their lattice) and all weights are their own.
     State lives in stacked blobs (C, n_pad); .nets are ordinary NPPNetLight objects over the rows (render / score / state_dict)."""
 
-    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500):
+    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, fused=None):
+        """fused (default: NPP_LIGHT_FUSED != 0 and the topology is the searched one, D = 4 / W = 256 / 42 + 20 input columns): forward and
+        data-gradient chains as ONE launch each over all candidates (csrc/npp_light.hip) instead of one launch per layer."""
+        import os
         self.device = ops.select_device(device)
         self.C, self.W, self.D = len(cands), int(W), int(D)
         C = self.C
@@ -253,6 +256,62 @@ class NPPNetLightBatch:
         n0 = self.nets[0]
         self.spline, self.n_knots, self.x_scale = n0.spline, n0.n_knots, n0.x_scale
         self._ws = {}
+        can_fuse = self.W == 256 and self.D == 4 and in_pos == 42
+        if fused is None:
+            fused = can_fuse and os.environ.get("NPP_LIGHT_FUSED", "1") != "0"
+        if fused and not can_fuse:
+            raise ValueError("the fused NPP_Net_light chains are built for D = 4, W = 256, 42 positional and 20 periodic input columns")
+        self.fused = bool(fused)
+        if self.fused:
+            from ._lib import LightDesc, lib
+            order = [f"periodic_linears.{i}" for i in range(4)] + ["pos_linears.0", "feature_linear1", "rgb_linear"]
+            shapes = {name: (r, c) for name, r, c in self.layout}
+            d = LightDesc()
+            for i, name in enumerate(order):
+                d.w_off[i] = self.w[name].storage_offset() - self.params.storage_offset()
+                d.b_off[i] = self.b[name].storage_offset() - self.params.storage_offset()
+                d.n_out[i], d.n_in[i] = shapes[name]
+                d.ld[i] = self.w[name].shape[2]
+            self._desc = d
+            L = lib()
+            self._pack = z(C, int(L.npp_light_pack_floats()))
+            self._srow = [int(L.npp_light_stash_row(i)) for i in range(7)]       # z0 z1 z2 z3 hp zp | rows
+            self._drow = [int(L.npp_light_dstash_row(i)) for i in range(7)]      # dz0 dz1 dz2 dz3 df1 dzp | rows
+
+    def _work_fused(self, B):
+        ws = self._ws.get(("fused", B))
+        if ws is None:
+            C = self.C
+            f = lambda *s_: torch.empty((C,) + s_, dtype=torch.float32, device=self.device)      # noqa: E731
+            ws = dict(stash=f(self._srow[6], B), dstash=f(self._drow[6], B), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3))
+            self._ws[("fused", B)] = ws
+        return ws
+
+    def _train_step_fused(self, x_pos, x_per, gt):
+        """train_step() on the fused chains: pack -> forward -> pixel loss -> data gradients -> 7 weight-gradient launches over the
+        feature-major stashes -> Adam: 13 launches for the whole candidate set."""
+        C, B = x_per.shape[:2]
+        ws = self._work_fused(B)
+        S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
+        ops.light_pack(self._desc, self.params, self._pack)
+        ops.light_fwd(self._desc, self.params, self._pack, x_per.contiguous(), x_pos.contiguous(), S, ws["pred"])
+        loss = self._loss2[self._li]
+        ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
+        ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], ws["dpred"], ws["draw"], D_)
+        self.grad.zero_()
+        W = self.W
+        for i in range(4):                                   # periodic_linears.i: x = x_per (row-major) or snake(z_{i-1}) (feature-major)
+            name = f"periodic_linears.{i}"
+            dz = D_[:, dr[i]:dr[i] + W]
+            if i == 0:
+                ops.linear_bwd_weight_strided(dz, x_per, self.dw[name], self.db[name], True, False)
+            else:
+                ops.linear_bwd_weight_strided(dz, S[:, sr[i - 1]:sr[i - 1] + W], self.dw[name], self.db[name], True, True, x_snake=True)
+        ops.linear_bwd_weight_strided(D_[:, dr[4]:dr[4] + W], S[:, sr[3]:sr[3] + W], self.dw["feature_linear1"], self.db["feature_linear1"], True, True,
+                                      x_snake=True)
+        ops.linear_bwd_weight_strided(D_[:, dr[5]:dr[5] + W // 2], S[:, sr[4]:sr[5]], self.dw["pos_linears.0"], self.db["pos_linears.0"], True, True)
+        ops.linear_bwd_weight_strided(ws["draw"], S[:, sr[5]:sr[6]], self.dw["rgb_linear"], self.db["rgb_linear"], False, True, x_snake=True)
+        return loss
 
     def _work(self, B):
         ws = self._ws.get(B)
@@ -268,6 +327,9 @@ class NPPNetLightBatch:
     def train_step(self, x_pos, x_per, gt):
         """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20)."""
         C, B = x_per.shape[:2]
+        if self.fused and B % 64 == 0:
+            loss = self._train_step_fused(x_pos, x_per, gt)
+            return self._adam(loss)
         ws, W, D = self._work(B), self.W, self.D
         rows = lambda t: t.view(C * B, t.shape[2])                                                 # noqa: E731
         # ---- forward (NPPNetLight.forward)
@@ -300,7 +362,11 @@ class NPPNetLightBatch:
             ops.linear_bwd_weight_batched(dz, ws["h"][i - 1] if i > 0 else x_per, self.dw[name], self.db[name])
             if i > 0:
                 ops.linear_bwd_data_batched(dz, self.w[name], ws["dh"] if dz is ws["dz"] else ws["dz"], zy=ws["z"][i - 1], act=_SNAKE)
-        # ---- Adam over the stacked blobs (the candidates share the step count and the LR clock); pad columns have zero gradient
+        return self._adam(loss)
+
+    def _adam(self, loss):
+        """Adam over the stacked blobs (the candidates share the step count and the LR clock); pad columns have zero gradient."""
+        C = self.C
         n0 = self.nets[0]
         step, lr = n0.opt_step + 1, n0.lr
         self._li ^= 1

@@ -582,6 +582,48 @@ def pixel_loss_batched(pred, gt, latents, spline, n_knots, x_scale, weight, loss
                                        weight, _p(loss), _p(dpred), _p(dlatent), _stream()), "npp_pixel_loss_batched")
 
 
+def linear_bwd_weight_strided(dz, x, dw, db, feature_major_dz, feature_major_x, x_snake=False):
+    """dw[c] += dz[c]^T x[c], db[c] += column sums of dz[c], for operands that are row-major (C, B, n) or feature-major (C, n, B) --
+    the stashes of the fused NPP_Net_light chains (x_snake: x holds pre-activations, the layer input is snake(x)).  dw (C, out, ld >= in)
+    views of a blob, db (C, out)."""
+    C = dz.shape[0]
+    B, cout = (dz.shape[2], dz.shape[1]) if feature_major_dz else (dz.shape[1], dz.shape[2])
+    cin = dw.shape[2]
+    assert dz.stride(2) == 1 and x.stride(2) == 1 and dw.stride(2) == 1 and dw.shape[:2] == (C, cout) and db.shape == (C, cout) and db.stride(1) == 1
+    assert (x.shape[1] >= cin and x.shape[2] == B) if feature_major_x else (x.shape[1] == B and x.shape[2] >= cin)
+    dz_sr, dz_so = (1, dz.stride(1)) if feature_major_dz else (dz.stride(1), 1)
+    x_sr, x_si = (1, x.stride(1)) if feature_major_x else (x.stride(1), 1)
+    check(lib().npp_linear_bwd_weight_strided(_p(dz), dz_sr, dz_so, dz.stride(0), _p(x), x_sr, x_si, x.stride(0), int(bool(x_snake)), C, B, cin, cout, _p(dw),
+                                              dw.stride(1), dw.stride(0), _p(db), db.stride(0), _stream()), "npp_linear_bwd_weight_strided")
+
+
+def light_pack(desc, params, pack):
+    """MFMA-ordered weight copies of C stacked NPP_Net_light blobs (params (C, n) -> pack (C, npp_light_pack_floats()))."""
+    import ctypes
+    C = params.shape[0]
+    assert params.stride(1) == 1 and pack.stride(1) == 1 and pack.shape[0] == C
+    check(lib().npp_light_pack(ctypes.byref(desc), _p(params), params.stride(0), C, _p(pack), pack.stride(0), _stream()), "npp_light_pack")
+
+
+def light_fwd(desc, params, pack, x_per, x_pos, stash, pred):
+    """Fused NPP_Net_light forward of C candidates: x_per (C, B, 20), x_pos (B, 42) -> pred (C, B, 3), stash (C, rows, B)."""
+    import ctypes
+    C, B = x_per.shape[:2]
+    assert x_per.is_contiguous() and x_pos.is_contiguous() and stash.is_contiguous() and pred.is_contiguous()
+    assert x_per.shape == (C, B, 20) and x_pos.shape == (B, 42) and pred.shape == (C, B, 3) and stash.shape[0] == C and stash.shape[2] == B
+    check(lib().npp_light_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), C, B, _p(stash),
+                              _p(pred), _stream()), "npp_light_fwd")
+
+
+def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash):
+    """Fused data-gradient chain: dpred (C, B, 3) -> draw (C, B, 3), dstash (C, rows, B)."""
+    import ctypes
+    C, B = pred.shape[:2]
+    assert all(t.is_contiguous() for t in (stash, pred, dpred, draw, dstash)) and dstash.shape[0] == C and dstash.shape[2] == B
+    check(lib().npp_light_bwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(dpred), C, B,
+                              _p(draw), _p(dstash), _stream()), "npp_light_bwd")
+
+
 def act_bwd(dy, zy, act, dz):
     B, n = dy.shape
     check(lib().npp_act_bwd(_p(dy), dy.stride(0), _p(zy), zy.stride(0), B, n, act, _p(dz), dz.stride(0), _stream()), "npp_act_bwd")

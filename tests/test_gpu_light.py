@@ -266,6 +266,43 @@ def test_ranking_prefers_the_true_periodicity(dev):
     assert np.all(np.diff(d) >= 0) and all(np.isfinite(x[0]) for x in details)
 
 
+def test_fused_light_chains_equal_the_layer_by_layer_path(dev):
+    """csrc/npp_light.hip (forward and data-gradient chains of NPP_Net_light as one launch each over all candidates, hardware sin,
+    feature-major stashes, strided weight-gradient GEMMs) against the layer-by-layer dense path (precise sinf) from the same
+    weights on the same rows: predictions, losses, EVERY parameter gradient of every candidate, and the parameters / latents after
+    ten optimiser steps."""
+    from npp_amd.light import NPPNetLightBatch, default_light_init
+    H, B, C = 96, 256, 3
+    rng = np.random.RandomState(11)
+    angles = np.array([[0.0, 90.0], [30.0, 120.0], [10.0, 80.0]], np.float32)
+    periods = np.array([[12.0, 9.0], [7.0, 15.0], [20.0, 6.0]], np.float32)
+    freqs = (rng.randn(10) * 10).astype(np.float32)
+    init = default_light_init(256, 4)
+    nets = [NPPNetLightBatch([(angles[i], periods[i]) for i in range(C)], freqs, (H, H), init, device=dev, fused=f) for f in (True, False)]
+    assert nets[0].fused and not nets[1].fused
+    coords = torch.from_numpy(np.stack([rng.randint(0, H, 4 * B), rng.randint(0, H, 4 * B)], 1).astype(np.int32)).to(dev)
+    tabs = [n_.embed(coords) for n_ in nets[0].nets]
+    x_pos_all, x_per_all = tabs[0][0], torch.stack([t[1] for t in tabs])
+    gt_all = torch.from_numpy(rng.rand(4 * B, 3).astype(np.float32)).to(dev)
+    for it in range(10):
+        idx = torch.from_numpy(rng.permutation(4 * B)[:B]).to(dev)
+        losses = [n_.train_step(x_pos_all[idx], x_per_all[:, idx], gt_all[idx]).clone() for n_ in nets]
+        if it == 0:
+            pf, pu = nets[0]._ws[("fused", B)]["pred"], nets[1]._ws[B]["pred"]
+            np.testing.assert_allclose(pf.cpu().numpy(), pu.cpu().numpy(), atol=3e-6)
+            gf, gu = nets[0].grad.cpu().numpy(), nets[1].grad.cpu().numpy()
+            for name in nets[0].dw:
+                for part in ("dw", "db"):
+                    a, b_ = getattr(nets[0], part)[name].cpu().numpy(), getattr(nets[1], part)[name].cpu().numpy()
+                    for ci in range(C):
+                        assert rel_l2(a[ci], b_[ci]) < 2e-5, (name, part, ci, rel_l2(a[ci], b_[ci]))
+            assert rel_l2(gf, gu) < 2e-5
+        np.testing.assert_allclose(losses[0].cpu().numpy(), losses[1].cpu().numpy(), rtol=2e-5)
+    assert rel_l2(nets[0].params.cpu().numpy(), nets[1].params.cpu().numpy()) < 2e-5
+    np.testing.assert_allclose(nets[0].latents.cpu().numpy(), nets[1].latents.cpu().numpy(), atol=2e-6)
+    assert nets[0].nets[0].opt_step == nets[1].nets[0].opt_step == 10
+
+
 def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
     """ProposalRanker.fit_candidates -- all candidates in every launch (default: NPPNetLightBatch), advanced together on side
     streams (batched=False), or iterations 2 .. N of each fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against
