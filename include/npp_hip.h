@@ -428,7 +428,7 @@ int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, int64_t dz_s
  * npp_light_stash_row(0..5) = z0 z1 z2 z3 hp zp (the activations are snake(z): recomputed by their consumers).
  * npp_light_bwd: d_dpred (C, B, 3) = dL/dpred -> d_draw (C, B, 3) = dL/draw and the gradient stash (C, npp_light_dstash_rows(), B):
  * d z_0 .. d z_3, d f1, d z_p (npp_light_dstash_row(0..5)).  The weight gradients are npp_linear_bwd_weight_strided over the two
- * stashes.  B a multiple of 64. */
+ * stashes.  B a multiple of 32 (workgroups of 64 or 32 rows, whichever loads the CUs more evenly; NPP_LIGHT_ROWS forces one). */
 typedef struct {
   int64_t w_off[7], b_off[7];
   int32_t n_out[7], n_in[7], ld[7];

@@ -28,18 +28,20 @@ __device__ __forceinline__ void wg32_load(WG32<NTW>& r, const wrsrc_t& rsrc, uin
   }
 }
 
-// B operands of a k-step group from the activation region: k-step 4g + e contracts features (8g + e, 8g + e + 4)
+// B operands of a k-step group from the activation region [feature][NB * 32 rows]: k-step 4g + e contracts features
+// (8g + e, 8g + e + 4).  NB (batch tiles of 32 rows per workgroup) is deduced from the operand array.
 struct ActSrc32 {
-  const char* lane_base;     // region + ((4 h) * 64 + (lane & 31)) * 4
-  __device__ __forceinline__ void frag(int g, int e, float (&b)[kNB]) const {
+  const char* lane_base;     // region + ((4 h) * (NB * 32) + (lane & 31)) * 4
+  template <int NB>
+  __device__ __forceinline__ void frag(int g, int e, float (&b)[NB]) const {
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt) b[bt] = *(const float*)(lane_base + g * 2048 + e * 256 + bt * 128);
+    for (int bt = 0; bt < NB; ++bt) b[bt] = *(const float*)(lane_base + (g * 8 + e) * (NB * 128) + bt * 128);
   }
 };
 // acc += W[part] X over NG k-step groups (runtime loop, two groups per trip: the weight slots are named statically and
 // refilled right after the MFMAs that read them have been issued -- one group = 16 MFMAs = 1024 cycles of cover)
-template <int NTW, int NT, typename Src>
-__device__ __forceinline__ void part32(f32x16 (&acc)[NTW][kNB], const wrsrc_t& rsrc, uint32_t base16, int ngroups, int nt0, int lane,
+template <int NTW, int NT, typename Src, int NB>
+__device__ __forceinline__ void part32(f32x16 (&acc)[NTW][NB], const wrsrc_t& rsrc, uint32_t base16, int ngroups, int nt0, int lane,
                                        const Src& src) {
   WG32<NTW> w0, w1;
   wg32_load<NTW, NT>(w0, rsrc, base16, 0, nt0, lane);
@@ -47,12 +49,12 @@ __device__ __forceinline__ void part32(f32x16 (&acc)[NTW][kNB], const wrsrc_t& r
   auto group = [&](WG32<NTW>& w, int g) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float b[kNB];
+      float b[NB];
       src.frag(g, e, b);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = mfma32(w.w[nt][e], b[bt], acc[nt][bt]);
+        for (int bt = 0; bt < NB; ++bt) acc[nt][bt] = mfma32(w.w[nt][e], b[bt], acc[nt][bt]);
     }
   };
 #pragma unroll 1
@@ -64,15 +66,15 @@ __device__ __forceinline__ void part32(f32x16 (&acc)[NTW][kNB], const wrsrc_t& r
   }
 }
 
-template <int NTW>
-__device__ __forceinline__ void bias32(f32x16 (&acc)[NTW][kNB], const float* __restrict__ bias, int nt0, int h) {
+template <int NTW, int NB>
+__device__ __forceinline__ void bias32(f32x16 (&acc)[NTW][NB], const float* __restrict__ bias, int nt0, int h) {
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float bv = bias[(nt0 + nt) * 32 + acc_row(r, h)];
 #pragma unroll
-      for (int bt = 0; bt < kNB; ++bt) acc[nt][bt][r] = bv;
+      for (int bt = 0; bt < NB; ++bt) acc[nt][bt][r] = bv;
     }
 }
 

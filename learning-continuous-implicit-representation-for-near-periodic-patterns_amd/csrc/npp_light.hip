@@ -23,7 +23,7 @@ constexpr int kLW = 256;                        // hidden width
 constexpr int kLPosOut = 128;                   // pos_linears.0 outputs
 constexpr int kLPer = 20, kLPos = 42;           // periodic / positional input widths
 constexpr int kLHp = 304;                       // [f1 (256) | x_pos (42) | 0-pad (6)]: 38 k-step groups
-constexpr int kLRegion = kLHp * kRowTile * 4;   // 77 824 B: the activation region
+constexpr int light_region_bytes(int nb) { return kLHp * nb * 32 * 4; }   // the activation region: 77 824 B at 64 rows, 38 912 at 32
 constexpr int kLThreads = 256;
 
 // feature rows of the forward stash of one candidate, in order
@@ -101,17 +101,17 @@ __global__ void light_pack_kernel(LightArgs a, LightPackDesc pd, float* __restri
 // ---- forward ---------------------------------------------------------------------------------------------------------------
 // epilogue of a hidden layer: z (+ bias already in acc) -> stash zT, h = snake(z) (or z) -> region (+ stash hT).  Only z is stashed for
 // the snake layers: the weight-gradient GEMM forms h = snake(z) again while it stages the operand (npp_linear_bwd_weight_strided)
-template <bool SNAKE, int NTW>
-__device__ __forceinline__ void light_epi(f32x16 (&acc)[NTW][kNB], char* region, float* __restrict__ zT, float* __restrict__ hT, uint32_t B,
+template <bool SNAKE, int NTW, int NB>
+__device__ __forceinline__ void light_epi(f32x16 (&acc)[NTW][NB], char* region, float* __restrict__ zT, float* __restrict__ hT, uint32_t B,
                                           uint32_t row0, int nt0, int b, int h) {
   // 32-bit element indices off the (uniform) array bases: the launcher bounds rows x B below 2^31
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt) {
+    for (int bt = 0; bt < NB; ++bt) {
       const uint32_t f0 = (uint32_t)((nt0 + nt) * 32 + 4 * h);
       uint32_t g = f0 * B + row0 + (uint32_t)(bt * 32 + b);
-      char* rg = region ? region + (f0 * kRowTile + bt * 32 + b) * 4 : nullptr;
+      char* rg = region ? region + (f0 * (NB * 32) + bt * 32 + b) * 4 : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {            // feature f0 + (r & 3) + 8 (r >> 2)
         const uint32_t gi = g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B;
@@ -120,18 +120,20 @@ __device__ __forceinline__ void light_epi(f32x16 (&acc)[NTW][kNB], char* region,
         if (SNAKE) z = snake_fast(z);
         acc[nt][bt][r] = z;
         if (hT) hT[gi] = z;
-        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * kRowTile * 4) = z;
+        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * (NB * 32) * 4) = z;
       }
     }
 }
 
-__global__ __launch_bounds__(kLThreads, 2) void light_fwd_kernel(LightArgs a, LightPackDesc pd) {
+template <int NB>
+__global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(LightArgs a, LightPackDesc pd) {
+  constexpr int RT = NB * 32;                   // pixel rows per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R = smem;
   const int tid = threadIdx.x, lane = tid & 63, b = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = blockIdx.y;
-  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * kRowTile;
+  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * RT;
   const float* P = a.params + (int64_t)c * a.params_stride;
   float* S = a.stash + (int64_t)c * LS_ROWS * B;
   const int nt0 = 2 * wave;
@@ -139,53 +141,53 @@ __global__ __launch_bounds__(kLThreads, 2) void light_fwd_kernel(LightArgs a, Li
   {
     const float* xp = a.x_per + ((int64_t)c * B + row0) * kLPer;
     float* Rf = (float*)R;
-    for (int i = tid; i < 32 * kRowTile; i += kLThreads) {
-      const int f = i >> 6, row = i & 63;
-      Rf[f * kRowTile + row] = f < kLPer ? xp[row * kLPer + f] : 0.0f;
+    for (int i = tid; i < 32 * RT; i += kLThreads) {
+      const int f = i / RT, row = i % RT;
+      Rf[f * RT + row] = f < kLPer ? xp[row * kLPer + f] : 0.0f;
     }
   }
   wg_barrier();
   const wrsrc_t rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride, pd.total);
-  const ActSrc32 act{R + ((4 * h) * kRowTile + b) * 4};
-  f32x16 acc[2][kNB];
+  const ActSrc32 act{R + ((4 * h) * RT + b) * 4};
+  f32x16 acc[2][NB];
 #pragma unroll 1
   for (int l = 0; l < 4; ++l) {
-    bias32<2>(acc, P + a.L.b_off[l], nt0, h);
+    bias32(acc, P + a.L.b_off[l], nt0, h);
     part32<2, 8>(acc, rsrc, (uint32_t)pd.f_off[LF_L0 + l], pd.f_groups[LF_L0 + l], nt0, lane, act);
     wg_barrier();                               // every wave has read its last operand of this layer
-    light_epi<true, 2>(acc, R, S + (int64_t)(LS_Z0 + 256 * l) * B, nullptr, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+    light_epi<true>(acc, R, S + (int64_t)(LS_Z0 + 256 * l) * B, nullptr, (uint32_t)B, (uint32_t)row0, nt0, b, h);
     wg_barrier();
   }
   // feature_linear1 (linear) -> region rows 0..255 and the first 256 rows of hpT; x_pos (+ zero pad) behind it
-  bias32<2>(acc, P + a.L.b_off[5], nt0, h);
+  bias32(acc, P + a.L.b_off[5], nt0, h);
   part32<2, 8>(acc, rsrc, (uint32_t)pd.f_off[LF_F1], pd.f_groups[LF_F1], nt0, lane, act);
   wg_barrier();
-  light_epi<false, 2>(acc, R, nullptr, S + (int64_t)LS_HP * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+  light_epi<false>(acc, R, nullptr, S + (int64_t)LS_HP * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
   {
     float* Rf = (float*)R;
     float* hp = S + (int64_t)LS_HP * B;
-    for (int i = tid; i < (kLHp - kLW) * kRowTile; i += kLThreads) {
-      const int f = i >> 6, row = i & 63;
+    for (int i = tid; i < (kLHp - kLW) * RT; i += kLThreads) {
+      const int f = i / RT, row = i % RT;
       const float v = f < kLPos ? a.x_pos[(row0 + row) * kLPos + f] : 0.0f;
-      Rf[(kLW + f) * kRowTile + row] = v;
+      Rf[(kLW + f) * RT + row] = v;
       hp[(int64_t)(kLW + f) * B + row0 + row] = v;
     }
   }
   wg_barrier();
   // pos_linears.0: 304 -> 128 (snake), one neuron tile per wave; a_p stays in registers for rgb_linear
-  f32x16 accp[1][kNB];
-  bias32<1>(accp, P + a.L.b_off[4], wave, h);
+  f32x16 accp[1][NB];
+  bias32(accp, P + a.L.b_off[4], wave, h);
   part32<1, 4>(accp, rsrc, (uint32_t)pd.f_off[LF_POS], pd.f_groups[LF_POS], wave, lane, act);
-  light_epi<true, 1>(accp, nullptr, S + (int64_t)LS_ZP * B, nullptr, (uint32_t)B, (uint32_t)row0, wave, b, h);
+  light_epi<true>(accp, nullptr, S + (int64_t)LS_ZP * B, nullptr, (uint32_t)B, (uint32_t)row0, wave, b, h);
   // rgb_linear 128 -> 3 + sigmoid (models/helpers.py:55-56)
   wg_barrier();
   float* sRGB = (float*)R;                      // [4 waves][64 rows][3]
   {
     const float* Wr = P + a.L.w_off[6];
     const int ldr = a.L.ld[6];
-    float part[kNB][3];
+    float part[NB][3];
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt)
+    for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
       for (int q = 0; q < 3; ++q) part[bt][q] = 0.0f;
 #pragma unroll
@@ -195,72 +197,75 @@ __global__ __launch_bounds__(kLThreads, 2) void light_fwd_kernel(LightArgs a, Li
       for (int q = 0; q < 3; ++q) {
         const float w = Wr[q * ldr + k];
 #pragma unroll
-        for (int bt = 0; bt < kNB; ++bt) part[bt][q] = fmaf(w, accp[0][bt][r], part[bt][q]);
+        for (int bt = 0; bt < NB; ++bt) part[bt][q] = fmaf(w, accp[0][bt][r], part[bt][q]);
       }
     }
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt)
+    for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const float v = part[bt][q] + __shfl_xor(part[bt][q], 32, 64);
-        if (h == 0) sRGB[(wave * kRowTile + bt * 32 + b) * 3 + q] = v;
+        if (h == 0) sRGB[(wave * RT + bt * 32 + b) * 3 + q] = v;
       }
   }
   wg_barrier();
-  if (tid < kRowTile * 3) {
+  if (tid < RT * 3) {
     const int row = tid / 3, q = tid - row * 3;
     float z = P[a.L.b_off[6] + q];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + q];
+    for (int w = 0; w < 4; ++w) z += sRGB[(w * RT + row) * 3 + q];
     a.pred[((int64_t)c * B + row0 + row) * 3 + q] = 1.0f / (1.0f + expf(-z));
   }
 }
 
 // ---- backward (data gradients) ------------------------------------------------------------------------------------------------
 // epilogue: d h -> d z = d h * snake'(z) (z from the forward stash; DERIV false: d z = d h) -> gradient stash (+ region)
-template <bool DERIV>
-__device__ __forceinline__ void light_bepi(f32x16 (&acc)[2][kNB], char* region, const float* __restrict__ zT, float* __restrict__ dT, uint32_t B,
+template <bool DERIV, int NB>
+__device__ __forceinline__ void light_bepi(f32x16 (&acc)[2][NB], char* region, const float* __restrict__ zT, float* __restrict__ dT, uint32_t B,
                                            uint32_t row0, int nt0, int b, int h) {
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt) {
+    for (int bt = 0; bt < NB; ++bt) {
       const uint32_t f0 = (uint32_t)((nt0 + nt) * 32 + 4 * h);
       const uint32_t g = f0 * B + row0 + (uint32_t)(bt * 32 + b);
-      char* rg = region ? region + (f0 * kRowTile + bt * 32 + b) * 4 : nullptr;
+      char* rg = region ? region + (f0 * (NB * 32) + bt * 32 + b) * 4 : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t gi = g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B;
         float d = acc[nt][bt][r];
         if (DERIV) d *= 1.0f + __builtin_amdgcn_sinf(zT[gi] * (2.0f * kInv2Pi));          // activations.py:29-35: 1 + sin 2z
         dT[gi] = d;
-        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * kRowTile * 4) = d;
+        if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * (NB * 32) * 4) = d;
       }
     }
 }
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
+template <int NB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NB]) {
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int bt = 0; bt < kNB; ++bt)
+    for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][bt][r] = 0.0f;
 }
 
-__global__ __launch_bounds__(kLThreads, 2) void light_bwd_kernel(LightArgs a, LightPackDesc pd) {
+template <int NB>
+__global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(LightArgs a, LightPackDesc pd) {
+  constexpr int RT = NB * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R = smem;
-  float* sD = (float*)(smem + kLW * kRowTile * 4);          // d raw [64 rows][3] behind the 256-feature part of the region
+  float* sD = (float*)(smem + kLW * RT * 4);          // d raw [64 rows][3] behind the 256-feature part of the region
   const int tid = threadIdx.x, lane = tid & 63, b = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = blockIdx.y;
-  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * kRowTile;
+  const int64_t B = a.B, row0 = (int64_t)blockIdx.x * RT;
   const float* P = a.params + (int64_t)c * a.params_stride;
   const float* S = a.stash + (int64_t)c * LS_ROWS * B;
   float* D = a.dstash + (int64_t)c * LD_ROWS * B;
   const int nt0 = 2 * wave;
   // d raw = d pred * pred (1 - pred)
-  if (tid < kRowTile * 3) {
+  if (tid < RT * 3) {
     const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
     const float p = a.pred[g], d = a.dpred[g] * p * (1.0f - p);
     a.draw[g] = d;
@@ -274,21 +279,21 @@ __global__ __launch_bounds__(kLThreads, 2) void light_bwd_kernel(LightArgs a, Li
     const float* zp = S + (int64_t)LS_ZP * B;
     float* dzp = D + (int64_t)LD_ZP * B;
     float* Rf = (float*)R;
-    for (int i = tid; i < kLPosOut * kRowTile; i += kLThreads) {
-      const int k = i >> 6, row = i & 63;
+    for (int i = tid; i < kLPosOut * RT; i += kLThreads) {
+      const int k = i / RT, row = i % RT;
       float d = sD[row * 3] * Wr[k];
       d = fmaf(sD[row * 3 + 1], Wr[ldr + k], d);
       d = fmaf(sD[row * 3 + 2], Wr[2 * ldr + k], d);
       const int64_t g = (int64_t)k * B + row0 + row;
       d *= 1.0f + __builtin_amdgcn_sinf(zp[g] * (2.0f * kInv2Pi));
       dzp[g] = d;
-      Rf[k * kRowTile + row] = d;
+      Rf[k * RT + row] = d;
     }
   }
   wg_barrier();
   const wrsrc_t rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride, pd.total);
-  const ActSrc32 act{R + ((4 * h) * kRowTile + b) * 4};
-  f32x16 acc[2][kNB];
+  const ActSrc32 act{R + ((4 * h) * RT + b) * 4};
+  f32x16 acc[2][NB];
   // d f1 = W_pos[:, :256]^T d z_p   (feature_linear1 is linear: this IS its d z; x_pos gets no gradient)
   zero_acc(acc);
   part32<2, 8>(acc, rsrc, (uint32_t)pd.b_off[LB_POS], pd.b_groups[LB_POS], nt0, lane, act);
@@ -312,8 +317,8 @@ __global__ __launch_bounds__(kLThreads, 2) void light_bwd_kernel(LightArgs a, Li
 using namespace npp;
 
 static int light_check(const npp_light_desc* L, const void* p0, const void* p1, int C, int64_t B, const char* who) {
-  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < kRowTile || B % kRowTile || B * 512 >= 0x7fffffffLL) {
-    set_error("%s: bad argument (C=%d B=%lld; B a positive multiple of %d)", who, C, (long long)B, kRowTile);
+  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < 32 || B % 32 || B * 512 >= 0x7fffffffLL) {
+    set_error("%s: bad argument (C=%d B=%lld; B a positive multiple of 32)", who, C, (long long)B);
     return NPP_ERR_ARG;
   }
   const int n_out[7] = {kLW, kLW, kLW, kLW, kLPosOut, kLW, 3}, n_in[7] = {kLPer, kLW, kLW, kLW, kLW + kLPos, kLW, kLPosOut};
@@ -324,6 +329,21 @@ static int light_check(const npp_light_desc* L, const void* p0, const void* p1, 
       return NPP_ERR_UNSUPPORTED;
     }
   return NPP_OK;
+}
+
+// Rows per workgroup: 64 (two batch tiles share every weight fragment) or 32.  A chain is one long dependent sequence per workgroup
+// (forward: 98 us for 64 rows, 59 us for 32, alone on a CU), so what counts is the most loaded CU and how well the workgroups on it
+// cover each other's epilogues.  Measured, 2048 rows per candidate (tools/r3_light_chain_probe.py, us, 64 / 32 rows):
+//   candidates      1          4          8          9          12         16
+//   forward      98 / 59   114 / 76   116 / 106  165 / 139  170 / 152  183 / 225
+//   backward    117 / 64   167 / 96   168 / 121  221 / 151  249 / 174  293 / 231
+// 32 rows until the chip holds more than ~3 (forward) / ~6 (backward) of them per CU, then the weight traffic of the narrow tile
+// (every fragment feeds one MFMA instead of two) costs more than the balance gives.
+static int light_rows_per_wg(int C, int64_t B, bool backward) {
+  static const int forced = [] { const char* e = getenv("NPP_LIGHT_ROWS"); return e ? atoi(e) : 0; }();
+  if (B % 64) return 32;
+  if (forced == 32 || forced == 64) return forced;
+  return C * (B / 32) <= (backward ? 1536 : 768) ? 32 : 64;
 }
 
 extern "C" int64_t npp_light_pack_floats(void) { return 4 * (int64_t)light_pack_desc().total; }
@@ -340,7 +360,7 @@ extern "C" int npp_light_dstash_row(int which) {
 
 extern "C" int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, float* d_pack, int64_t pack_stride,
                               void* stream) {
-  int rc = light_check(L, d_params, d_pack, C, kRowTile, "npp_light_pack");
+  int rc = light_check(L, d_params, d_pack, C, 32, "npp_light_pack");
   if (rc) return rc;
   const LightPackDesc pd = light_pack_desc();
   if (pack_stride < 4 * (int64_t)pd.total || pack_stride % 4) { set_error("npp_light_pack: pack_stride %lld", (long long)pack_stride); return NPP_ERR_ARG; }
@@ -359,10 +379,17 @@ extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int
   LightArgs a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
   a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B;
-  static SmemOnce once;
-  if (!smem_attr(once, (const void*)light_fwd_kernel, kLRegion)) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
-  hipLaunchKernelGGL(light_fwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kLThreads), kLRegion, (hipStream_t)stream, a,
-                     light_pack_desc());
+  if (light_rows_per_wg(C, B, false) == 64) {
+    static SmemOnce once;
+    if (!smem_attr(once, (const void*)light_fwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
+    hipLaunchKernelGGL(light_fwd_kernel<2>, dim3((unsigned)(B / 64), (unsigned)C), dim3(kLThreads), light_region_bytes(2), (hipStream_t)stream, a,
+                       light_pack_desc());
+  } else {
+    static SmemOnce once;
+    if (!smem_attr(once, (const void*)light_fwd_kernel<1>, light_region_bytes(1))) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
+    hipLaunchKernelGGL(light_fwd_kernel<1>, dim3((unsigned)(B / 32), (unsigned)C), dim3(kLThreads), light_region_bytes(1), (hipStream_t)stream, a,
+                       light_pack_desc());
+  }
   return check_launch("npp_light_fwd");
 }
 
@@ -375,9 +402,16 @@ extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int
   LightArgs a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
   a.stash = (float*)d_stash; a.pred = (float*)d_pred; a.dpred = d_dpred; a.draw = d_draw; a.dstash = d_dstash; a.B = B;
-  static SmemOnce once;
-  if (!smem_attr(once, (const void*)light_bwd_kernel, kLRegion)) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
-  hipLaunchKernelGGL(light_bwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kLThreads), kLRegion, (hipStream_t)stream, a,
-                     light_pack_desc());
+  if (light_rows_per_wg(C, B, true) == 64) {
+    static SmemOnce once;
+    if (!smem_attr(once, (const void*)light_bwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
+    hipLaunchKernelGGL(light_bwd_kernel<2>, dim3((unsigned)(B / 64), (unsigned)C), dim3(kLThreads), light_region_bytes(2), (hipStream_t)stream, a,
+                       light_pack_desc());
+  } else {
+    static SmemOnce once;
+    if (!smem_attr(once, (const void*)light_bwd_kernel<1>, light_region_bytes(1))) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
+    hipLaunchKernelGGL(light_bwd_kernel<1>, dim3((unsigned)(B / 32), (unsigned)C), dim3(kLThreads), light_region_bytes(1), (hipStream_t)stream, a,
+                       light_pack_desc());
+  }
   return check_launch("npp_light_bwd");
 }

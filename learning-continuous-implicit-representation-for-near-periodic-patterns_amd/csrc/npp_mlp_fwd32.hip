@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   f32x16 acc[2][kNB];
   // ---- L0
   gen_warp(0);
-  bias32<2>(acc, P + d.b_off[L0], nt0, h);
+  bias32(acc, P + d.b_off[L0], nt0, h);
   wg_barrier();
   part32<2, kNT>(acc, rsrc, w32(L0), GE, nt0, lane, emb);
   epi32<true, 2>(acc, R, nt0, b, h);               // nobody reads R yet
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   // ---- L1..L4 (in place: read R, barrier, write R)
 #pragma unroll 1
   for (int l = L1; l <= L4; ++l) {
-    bias32<2>(acc, P + d.b_off[l], nt0, h);
+    bias32(acc, P + d.b_off[l], nt0, h);
     part32<2, kNT>(acc, rsrc, w32(l), GA, nt0, lane, act);
     wg_barrier();
     epi32<true, 2>(acc, R, nt0, b, h);
     wg_barrier();
   }
   // ---- L5 = [emb(p0), h]   (sV still holds proposal 0)
-  bias32<2>(acc, P + d.b_off[L5], nt0, h);
+  bias32(acc, P + d.b_off[L5], nt0, h);
   part32<2, kNT>(acc, rsrc, w32(L5), GE, nt0, lane, emb);
   part32<2, kNT>(acc, rsrc, w32(L5) + GE * U, GA, nt0, lane, act);
   wg_barrier();
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   wg_barrier();
 #pragma unroll 1
   for (int l = L6; l <= L7; ++l) {
-    bias32<2>(acc, P + d.b_off[l], nt0, h);
+    bias32(acc, P + d.b_off[l], nt0, h);
     part32<2, kNT>(acc, rsrc, w32(l), GA, nt0, lane, act);
     wg_barrier();
     epi32<true, 2>(acc, R, nt0, b, h);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   }
   // ---- F1 (linear); its tiles stay in registers: P needs f1 again after S / F2 have recycled the region
   f32x16 f1[2][kNB];
-  bias32<2>(f1, P + d.b_off[LF1], nt0, h);
+  bias32(f1, P + d.b_off[LF1], nt0, h);
   part32<2, kNT>(f1, rsrc, w32(LF1), GA, nt0, lane, act);
   wg_barrier();
   epi32<false, 2>(f1, R, nt0, b, h);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
   f32x16 accp[1][kNB];
   if (MULTI) {
     // ---- S = [f1 (R), emb(p1..)]
-    bias32<2>(acc, P + d.b_off[LS], nt0, h);
+    bias32(acc, P + d.b_off[LS], nt0, h);
     part32<2, kNT>(acc, rsrc, w32(LS), GA, nt0, lane, act);
     for (int p = 1; p < d.K; ++p) {
       wg_barrier();                                // every wave is done with the previous proposal's sV
@@ -181,20 +181,20 @@ __global__ __launch_bounds__(kT32, 2) void mlp_fwd32_kernel(Fwd32Args A_, EmbedD
     epi32<true, 2>(acc, R, nt0, b, h);             // a_s
     wg_barrier();
     // ---- F2 (linear) -> R (in place)
-    bias32<2>(acc, P + d.b_off[LF2], nt0, h);
+    bias32(acc, P + d.b_off[LF2], nt0, h);
     part32<2, kNT>(acc, rsrc, w32(LF2), GA, nt0, lane, act);
     wg_barrier();
     epi32<false, 2>(acc, R, nt0, b, h);            // f2
     wg_barrier();
     // ---- P = [f1, f2] -> 128: one neuron tile per wave; pack order: the f2 k-steps first, then f1
-    bias32<1>(accp, P + d.b_off[LP], wave, h);
+    bias32(accp, P + d.b_off[LP], wave, h);
     part32<1, kNT / 2>(accp, rsrc, w32(LP), GA, wave, lane, act);
     wg_barrier();
     epi32<false, 2>(f1, R, nt0, b, h);             // f1 back into the region
     wg_barrier();
     part32<1, kNT / 2>(accp, rsrc, w32(LP) + GA * (U / 2), GA, wave, lane, act);
   } else {
-    bias32<1>(accp, P + d.b_off[LP], wave, h);
+    bias32(accp, P + d.b_off[LP], wave, h);
     part32<1, kNT / 2>(accp, rsrc, w32(LP), GA, wave, lane, act);
   }
   epi32<true, 1>(accp, nullptr, wave, b, h);       // a_p stays in registers

@@ -327,7 +327,7 @@ class NPPNetLightBatch:
     def train_step(self, x_pos, x_per, gt):
         """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20)."""
         C, B = x_per.shape[:2]
-        if self.fused and B % 64 == 0:
+        if self.fused and B % 32 == 0:
             loss = self._train_step_fused(x_pos, x_per, gt)
             return self._adam(loss)
         ws, W, D = self._work(B), self.W, self.D
@@ -446,21 +446,31 @@ class ProposalRanker:
             self._draws = torch.from_numpy(np.ascontiguousarray(np.stack(sel), np.int64)).to(self.device)   # once per image: plain copy
         return self._draws
 
-    def fit_candidate(self, angles_deg, periods, params=None, use_graph=None):
-        """search.py:85-147 for one candidate.  The iteration is ~40 small dependent launches on 2048 rows.
+    def fit_candidate(self, angles_deg, periods, params=None, use_graph=None, fused=None):
+        """search.py:85-147 for one candidate.
+        fused (default unless NPP_LIGHT_FUSED=0 / use_graph / a topology the chains are not built for): the fused forward and
+        data-gradient chains with a candidate set of one (NPPNetLightBatch: 13 launches per iteration, 0.25 ms); else the
+        layer-by-layer path below: ~40 small dependent launches on 2048 rows, 0.39 ms per iteration.
         use_graph=True (or NPP_LIGHT_GRAPH=1): iterations 2 .. N replay ONE captured HIP graph (torch.cuda.CUDAGraph: the same
         kernels in the same order; the iteration's inputs -- pixel-row indices, Adam's step-dependent scalars -- are read from
         fixed device buffers).  Built in round 3 on the hypothesis that the host's enqueue rate bounded the loop; MEASURED: it does
         not -- eager 0.400 ms per iteration, graph replay 0.417-0.44 (profiles/r03_rejected_experiments.txt): the device time of the
         twenty 2048 x 256 x 256 exact-fp32 GEMM launches (14-18 us each) is the bound.  Kept as an option (parity-tested), off."""
         import os
+        if use_graph is None:
+            use_graph = os.environ.get("NPP_LIGHT_GRAPH", "0") != "0"
+        draws = self._pixel_draws()
+        if fused is None:
+            fused = (not use_graph and os.environ.get("NPP_LIGHT_FUSED", "1") != "0" and self.Wn == 256 and self.D == 4
+                     and len(self.freqs) == 10 and draws.shape[1] % 32 == 0)
+        if fused:
+            c_all = self.i_train_dev[draws.reshape(-1)].long()
+            gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
+            return self._fit_candidates_batched([(angles_deg, periods)], draws, gt_all, init=params)[0]
         net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
                           params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
                           device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
         x_pos_all, x_per_all = net.embed(self.i_train_dev)                                           # search.py:104-108 tables
-        draws = self._pixel_draws()
-        if use_graph is None:
-            use_graph = os.environ.get("NPP_LIGHT_GRAPH", "0") != "0"
 
         def eager(it):
             idx = draws[it]
@@ -543,10 +553,11 @@ class ProposalRanker:
             main.wait_stream(st)
         return nets
 
-    def _fit_candidates_batched(self, cands, draws, gt_all, group=16):
+    def _fit_candidates_batched(self, cands, draws, gt_all, group=16, init=None):
         """All candidates of the image in ONE launch sequence (NPPNetLightBatch), `group` at a time: the default of fit_candidates."""
         nets = []
-        init = default_light_init(self.Wn, self.D)
+        if init is None:
+            init = default_light_init(self.Wn, self.D)
         for g0 in range(0, len(cands), group):
             part = cands[g0:g0 + group]
             batch = NPPNetLightBatch(part, self.freqs, (self.H, self.W_img), init, W=self.Wn, D=self.D, device=self.device,

@@ -325,11 +325,13 @@ def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
     stacked = ranker.fit_candidates(cands)                       # default: NPPNetLightBatch, the candidate is a grid dimension
     assert type(ranker._batch_keep).__name__ == "NPPNetLightBatch" and stacked[0].params.data_ptr() == ranker._batch_keep.params.data_ptr()
     for (a, p), net, netg, netb in zip(cands, together, graphed, stacked):
-        alone = ranker.fit_candidate(a, p, use_graph=False)
+        alone = ranker.fit_candidate(a, p, use_graph=False, fused=False)          # the layer-by-layer eager loop: the comparator
+        fused1 = ranker.fit_candidate(a, p)                                        # default: the fused chains, a candidate set of one
         assert net.opt_step == netg.opt_step == netb.opt_step == alone.opt_step == 40
         assert netg.global_step == netb.global_step == alone.global_step and netg.lr == netb.lr == alone.lr
         pb = alone.params.cpu().numpy()
-        for other in (net, netg, netb):
+        assert fused1.opt_step == 40 and type(ranker._batch_keep).__name__ == "NPPNetLightBatch" and ranker._batch_keep.fused
+        for other in (net, netg, netb, fused1):
             assert np.linalg.norm(other.params.cpu().numpy() - pb) <= 1e-4 * np.linalg.norm(pb)
             np.testing.assert_allclose(other.latents.cpu().numpy(), alone.latents.cpu().numpy(), atol=1e-5)
         sb = ranker.score(alone)
