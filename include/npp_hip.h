@@ -425,10 +425,10 @@ int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, int64_t dz_s
  * floats per candidate; rebuild after every optimiser step.
  * npp_light_fwd: x_per (C, B, 20), x_pos (B, 42) shared -> d_pred (C, B, 3) = sigmoid(raw) and the FEATURE-major stash
  * (C, npp_light_stash_rows(), B): pre-activations z_0 .. z_3, [f1 | x_pos | 0] (304 rows), z_p -- row offsets by
- * npp_light_stash_row(0..5) = z0 z1 z2 z3 hp zp (the activations are snake(z): recomputed by their consumers).
+ * npp_light_stash_row(0..6) = z0 z1 z2 z3 hp zp xper^T (the activations are snake(z): recomputed by their consumers).
  * npp_light_bwd: d_dpred (C, B, 3) = dL/dpred -> d_draw (C, B, 3) = dL/draw and the gradient stash (C, npp_light_dstash_rows(), B):
- * d z_0 .. d z_3, d f1, d z_p (npp_light_dstash_row(0..5)).  The weight gradients are npp_linear_bwd_weight_strided over the two
- * stashes.  B a multiple of 32 (workgroups of 64 or 32 rows, whichever loads the CUs more evenly; NPP_LIGHT_ROWS forces one). */
+ * d z_0 .. d z_3, d f1, d z_p, d raw^T (npp_light_dstash_row(0..6)).  The weight gradients: npp_light_wgrad (or
+ * npp_linear_bwd_weight_strided layer by layer) over the two stashes.  B a multiple of 32 (workgroups of 64 or 32 rows, whichever loads the CUs more evenly; NPP_LIGHT_ROWS forces one). */
 typedef struct {
   int64_t w_off[7], b_off[7];
   int32_t n_out[7], n_in[7], ld[7];
@@ -442,6 +442,10 @@ int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t param
                    void* stream);
 int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                   const float* d_x_per, const float* d_x_pos, int C, int64_t B, float* d_stash, float* d_pred, void* stream);
+/* The seven weight / bias gradients of all candidates in one launch over the two stashes: into d_grad + c * grad_stride at the
+ * parameters' own offsets (accumulated; clear first). */
+int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                    int64_t grad_stride, void* stream);
 int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                   const float* d_stash, const float* d_pred, const float* d_dpred, int C, int64_t B, float* d_draw,
                   float* d_dstash, void* stream);

@@ -16,20 +16,12 @@
 // tile is 32 consecutive rows of one feature -- a coalesced 128-byte store -- and the weight-gradient GEMMs (npp_linear.hip,
 // batched, strided operands) take both operands contiguous along the rows they contract.
 #include "npp_chain32.h"
+#include "npp_light_layout.h"
 
 namespace npp {
 
-constexpr int kLW = 256;                        // hidden width
-constexpr int kLPosOut = 128;                   // pos_linears.0 outputs
-constexpr int kLPer = 20, kLPos = 42;           // periodic / positional input widths
-constexpr int kLHp = 304;                       // [f1 (256) | x_pos (42) | 0-pad (6)]: 38 k-step groups
 constexpr int light_region_bytes(int nb) { return kLHp * nb * 32 * 4; }   // the activation region: 77 824 B at 64 rows, 38 912 at 32
 constexpr int kLThreads = 256;
-
-// feature rows of the forward stash of one candidate, in order
-enum { LS_Z0 = 0, LS_Z1 = 256, LS_Z2 = 512, LS_Z3 = 768, LS_HP = 1024, LS_ZP = LS_HP + kLHp, LS_ROWS = LS_ZP + kLPosOut };
-// ... and of the gradient stash
-enum { LD_Z0 = 0, LD_Z1 = 256, LD_Z2 = 512, LD_Z3 = 768, LD_F1 = 1024, LD_ZP = 1280, LD_ROWS = LD_ZP + kLPosOut };
 
 // packed weights of one candidate (16-byte units): forward pack, then the transposed pack of the backward chain
 enum { LF_L0 = 0, LF_L1, LF_L2, LF_L3, LF_F1, LF_POS, LF_N };
@@ -143,7 +135,9 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
     float* Rf = (float*)R;
     for (int i = tid; i < 32 * RT; i += kLThreads) {
       const int f = i / RT, row = i % RT;
-      Rf[f * RT + row] = f < kLPer ? xp[row * kLPer + f] : 0.0f;
+      const float v = f < kLPer ? xp[row * kLPer + f] : 0.0f;
+      Rf[f * RT + row] = v;
+      if (f < kLPer) S[(int64_t)(LS_XP + f) * B + row0 + row] = v;        // x_per^T: the first layer's weight-gradient operand
     }
   }
   wg_barrier();
@@ -270,6 +264,7 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
     const float p = a.pred[g], d = a.dpred[g] * p * (1.0f - p);
     a.draw[g] = d;
     sD[tid] = d;
+    D[(int64_t)(LD_RAW + tid % 3) * B + row0 + tid / 3] = d;       // d raw^T for rgb_linear's weight gradient
   }
   wg_barrier();
   // d a_p = d raw W_rgb; d z_p = d a_p * snake'(z_p) -> region rows 0..127 + stash
@@ -350,12 +345,12 @@ extern "C" int64_t npp_light_pack_floats(void) { return 4 * (int64_t)light_pack_
 extern "C" int64_t npp_light_stash_rows(void) { return LS_ROWS; }
 extern "C" int64_t npp_light_dstash_rows(void) { return LD_ROWS; }
 extern "C" int npp_light_stash_row(int which) {
-  const int rows[7] = {LS_Z0, LS_Z1, LS_Z2, LS_Z3, LS_HP, LS_ZP, LS_ROWS};
-  return (which < 0 || which > 6) ? NPP_ERR_ARG : rows[which];
+  const int rows[8] = {LS_Z0, LS_Z1, LS_Z2, LS_Z3, LS_HP, LS_ZP, LS_XP, LS_ROWS};
+  return (which < 0 || which > 7) ? NPP_ERR_ARG : rows[which];
 }
 extern "C" int npp_light_dstash_row(int which) {
-  const int rows[7] = {LD_Z0, LD_Z1, LD_Z2, LD_Z3, LD_F1, LD_ZP, LD_ROWS};
-  return (which < 0 || which > 6) ? NPP_ERR_ARG : rows[which];
+  const int rows[8] = {LD_Z0, LD_Z1, LD_Z2, LD_Z3, LD_F1, LD_ZP, LD_RAW, LD_ROWS};
+  return (which < 0 || which > 7) ? NPP_ERR_ARG : rows[which];
 }
 
 extern "C" int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, float* d_pack, int64_t pack_stride,

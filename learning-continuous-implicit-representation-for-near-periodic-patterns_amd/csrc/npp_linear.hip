@@ -18,6 +18,7 @@
 // wave-chunk) add up rather than overlap; a 64 x 64 tile per WAVE with the contraction split over the waves would halve the
 // LDS reads at the price of a cross-wave reduction (not built: estimated 37 -> 31 us).
 #include "npp_common.h"
+#include "npp_light_layout.h"
 
 namespace npp {
 
@@ -108,18 +109,18 @@ __device__ __forceinline__ void gemm_sstore(float* __restrict__ S, int tid, cons
 #define NPP_GEMM_WAVES 5
 #endif
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm32_body(GemmArgs g, const int bx, const int by, const int bzz) {
   // Occupancy is the point of the launch bound: the candidate-stacked layers of the ranking fit are 1152 workgroups; at 4 resident
   // per CU (1024 slots) the last 128 run as a second, 12 %-full round and the launch takes two workgroup times (measured 38 us against
   // a 15 us MFMA floor); 5 per CU hold them all.  One LDS buffer (17 KB) for the same reason.
   __shared__ __attribute__((aligned(16))) float sA[kGemmTile];
   __shared__ __attribute__((aligned(16))) float sB[kGemmTile];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, wm = wave >> 1, wn = wave & 1;
+  const int m0 = by * 64, n0 = bx * 64, wm = wave >> 1, wn = wave & 1;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const int bz = (int)blockIdx.z / g.splits, sp = (int)blockIdx.z - bz * g.splits;
+  const int bz = bzz / g.splits, sp = bzz - bz * g.splits;
   if (g.nbatch > 1) {
     g.A += bz * g.sab; g.B += bz * g.sbb; g.C += bz * g.scb;
     if (g.Z) g.Z += bz * g.szb;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
   const int kbeg = sp * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
   const bool split = g.splits > 1;
   const bool va = g.vec_a != 0, vb = g.vec_b != 0;
-  const bool do_rowsum = g.rowsum && blockIdx.x == 0 && tid < 64;
+  const bool do_rowsum = g.rowsum && bx == 0 && tid < 64;
   float rs = 0.0f;
   // chunk c of 32 k: registers <- global while the MFMAs of chunk c - 1 run, LDS <- registers between two barriers.  Branch-free:
   // out-of-range elements read a clamped address and are zeroed on their way into LDS.
@@ -176,6 +177,28 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g)
     float* c = g.C + (int64_t)m * g.ldc + n;
     *c = g.accumulate ? *c + v : v;
   }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_kernel(GemmArgs g) {
+  gemm32_body<A_KC, B_KC>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several problems of one operand form in ONE launch (a 1-D grid over all their workgroups): the seven weight gradients of the
+// stacked NPP_Net_light candidates (npp_light_wgrad) -- each of them alone is a launch whose fixed ~12 us ramp is a third of its time.
+constexpr int kGemmGroupMax = 8;
+struct GemmGroup {
+  GemmArgs g[kGemmGroupMax];
+  int32_t first_wg[kGemmGroupMax + 1], gx[kGemmGroupMax], gy[kGemmGroupMax];
+  int32_t n;
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_grouped_kernel(GemmGroup G) {
+  int p = 0;
+  for (int q = 1; q < G.n; ++q) if ((int)blockIdx.x >= G.first_wg[q]) p = q;
+  const int local = (int)blockIdx.x - G.first_wg[p];
+  const int bx = local % G.gx[p], rest = local / G.gx[p];
+  gemm32_body<A_KC, B_KC>(G.g[p], bx, rest % G.gy[p], rest / G.gy[p]);
 }
 
 // dz = dy * act'(.) : act 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y));
@@ -286,11 +309,12 @@ __global__ void sub_kernel(const float* __restrict__ a, const float* __restrict_
   if (t < n) c[t] = a[t] - b[t];
 }
 
-static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false) {
-  // Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
-  // be 16 workgroups looping 64 chunks each): partial sums by atomicAdd into a zeroed C.  Only for plain linear outputs
-  // written densely (ldc == N), which is what the weight-gradient form produces.  Batched launches (nbatch independent
-  // problems, blockIdx.z = batch * splits + split) count all the batches' tiles towards the fill target.
+// Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
+// be 16 workgroups looping 64 chunks each): partial sums by atomicAdd into a zeroed C.  Only for plain linear outputs
+// written densely (ldc == N), which is what the weight-gradient form produces.  Batched launches (nbatch independent
+// problems, blockIdx.z = batch * splits + split) count all the batches' tiles towards the fill target.
+// Fills splits / kchunk / vec flags and returns the grid.
+static dim3 gemm_prepare(GemmArgs& g, bool a_kc, bool b_kc, bool batch_split) {
   const int nb = g.nbatch > 1 ? g.nbatch : 1;
   const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64) * nb;
   // a batched launch may split when its partial sums have somewhere zeroed to meet: the caller accumulates, or the outputs of the
@@ -310,15 +334,20 @@ static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool bat
   };
   g.vec_a = a_kc ? vec_ok(g.A, g.sak, g.sam, g.sab, g.K) : vec_ok(g.A, g.sam, g.sak, g.sab, g.M);
   g.vec_b = b_kc ? vec_ok(g.B, g.sbk, g.sbn, g.sbb, g.K) : vec_ok(g.B, g.sbn, g.sbk, g.sbb, g.N);
+  return dim3((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(splits * nb));
+}
+
+static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false) {
+  const dim3 grid = gemm_prepare(g, a_kc, b_kc, batch_split);
+  const int nb = g.nbatch > 1 ? g.nbatch : 1;
   if (nb == 1) {
-    if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
+    if (g.splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
     if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
   } else {
-    if (splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)nb * g.M * g.N * sizeof(float), s);      // dense_out
+    if (g.splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)nb * g.M * g.N * sizeof(float), s);      // dense_out
     if (g.rowsum && !g.accumulate)
       for (int b = 0; b < nb; ++b) (void)hipMemsetAsync(g.rowsum + b * g.srsb, 0, (size_t)g.M * sizeof(float), s);
   }
-  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(splits * nb));
   if (a_kc && b_kc) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, dim3(256), 0, s, g);
@@ -453,6 +482,42 @@ extern "C" int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, i
   g.nbatch = nbatch; g.sab = sdzb; g.sbb = sxb; g.scb = sdwb; g.srsb = sdbb;
   gemm_launch(g, dz_sr == 1, x_sr == 1, (hipStream_t)stream, true);
   return check_launch("npp_linear_bwd_weight_strided");
+}
+
+/* The seven weight (and bias) gradients of C stacked NPP_Net_light candidates in ONE launch, over the feature-major stashes of the
+ * fused chains (npp_light_fwd / npp_light_bwd): dW_l += d z_l^T x_l with x_0 = x_per, x_l = snake(z_{l-1}), x_f1 = snake(z_3),
+ * x_pos = [f1 | x_pos], x_rgb = snake(z_p); gradients go to d_grad + c * grad_stride at the offsets npp_light_desc gives the
+ * parameters (accumulated: clear the blob first). */
+extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                               int64_t grad_stride, void* stream) {
+  if (!L || !d_stash || !d_dstash || !d_grad || C < 1 || C > 4096 || B < 32 || B % 32 || B * 512 >= 0x7fffffffLL) {
+    set_error("npp_light_wgrad: bad argument (C=%d B=%lld)", C, (long long)B);
+    return NPP_ERR_ARG;
+  }
+  // npp_light_desc index -> (d z rows, x rows, x stored as pre-activation)
+  const int dz_row[7] = {LD_Z0, LD_Z1, LD_Z2, LD_Z3, LD_ZP, LD_F1, LD_RAW};
+  const int x_row[7] = {LS_XP, LS_Z0, LS_Z1, LS_Z2, LS_HP, LS_Z3, LS_ZP};
+  const int x_snake[7] = {0, 1, 1, 1, 0, 1, 1};
+  GemmGroup G{};
+  int wg = 0;
+  for (int i = 0; i < 7; ++i) {
+    GemmArgs& g = G.g[i];
+    const int out = L->n_out[i], in = L->ld[i];          // stored columns (zero-padded rows of the operand beyond n_in)
+    if (in > (i == 4 ? kLHp : (i == 0 ? kLPer : kLW)) || L->ld[i] < L->n_in[i]) { set_error("npp_light_wgrad: layer %d ld %d", i, in); return NPP_ERR_ARG; }
+    g.A = d_dstash + (int64_t)dz_row[i] * B; g.sam = B; g.sak = 1;       // A(m = n_out, k = row)
+    g.B = d_stash + (int64_t)x_row[i] * B; g.sbk = 1; g.sbn = B;         // B(k = row, n = col)
+    g.C = d_grad + L->w_off[i]; g.ldc = in;
+    g.rowsum = d_grad + L->b_off[i];
+    g.M = out; g.N = in; g.K = (int)B; g.accumulate = 1; g.b_snake = x_snake[i];
+    g.nbatch = C; g.sab = (int64_t)LD_ROWS * B; g.sbb = (int64_t)LS_ROWS * B; g.scb = grad_stride; g.srsb = grad_stride;
+    if (C == 1) g.nbatch = 1;
+    const dim3 grid = gemm_prepare(g, true, true, true);
+    G.first_wg[i] = wg; G.gx[i] = (int)grid.x; G.gy[i] = (int)grid.y;
+    wg += (int)(grid.x * grid.y * grid.z);
+  }
+  G.first_wg[7] = wg; G.n = 7;
+  hipLaunchKernelGGL((gemm32_grouped_kernel<true, true>), dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, G);
+  return check_launch("npp_light_wgrad");
 }
 
 extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,

@@ -262,6 +262,7 @@ class NPPNetLightBatch:
         if fused and not can_fuse:
             raise ValueError("the fused NPP_Net_light chains are built for D = 4, W = 256, 42 positional and 20 periodic input columns")
         self.fused = bool(fused)
+        self.grouped_wgrad = os.environ.get("NPP_LIGHT_GROUPED_WGRAD", "1") != "0"
         if self.fused:
             from ._lib import LightDesc, lib
             order = [f"periodic_linears.{i}" for i in range(4)] + ["pos_linears.0", "feature_linear1", "rgb_linear"]
@@ -275,21 +276,21 @@ class NPPNetLightBatch:
             self._desc = d
             L = lib()
             self._pack = z(C, int(L.npp_light_pack_floats()))
-            self._srow = [int(L.npp_light_stash_row(i)) for i in range(7)]       # z0 z1 z2 z3 hp zp | rows
-            self._drow = [int(L.npp_light_dstash_row(i)) for i in range(7)]      # dz0 dz1 dz2 dz3 df1 dzp | rows
+            self._srow = [int(L.npp_light_stash_row(i)) for i in range(8)]       # z0 z1 z2 z3 hp zp xperT | rows
+            self._drow = [int(L.npp_light_dstash_row(i)) for i in range(8)]      # dz0 dz1 dz2 dz3 df1 dzp drawT | rows
 
     def _work_fused(self, B):
         ws = self._ws.get(("fused", B))
         if ws is None:
             C = self.C
             f = lambda *s_: torch.empty((C,) + s_, dtype=torch.float32, device=self.device)      # noqa: E731
-            ws = dict(stash=f(self._srow[6], B), dstash=f(self._drow[6], B), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3))
+            ws = dict(stash=f(self._srow[7], B), dstash=f(self._drow[7], B), pred=f(B, 3), dpred=f(B, 3), draw=f(B, 3))
             self._ws[("fused", B)] = ws
         return ws
 
     def _train_step_fused(self, x_pos, x_per, gt):
         """train_step() on the fused chains: pack -> forward -> pixel loss -> data gradients -> 7 weight-gradient launches over the
-        feature-major stashes -> Adam: 13 launches for the whole candidate set."""
+        feature-major stashes (ONE grouped launch; NPP_LIGHT_GROUPED_WGRAD=0: seven) -> Adam: 7 launches for the whole candidate set."""
         C, B = x_per.shape[:2]
         ws = self._work_fused(B)
         S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
@@ -299,6 +300,9 @@ class NPPNetLightBatch:
         ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
         ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], ws["dpred"], ws["draw"], D_)
         self.grad.zero_()
+        if self.grouped_wgrad:
+            ops.light_wgrad(self._desc, S, D_, self.grad)   # all seven layers, one launch
+            return loss
         W = self.W
         for i in range(4):                                   # periodic_linears.i: x = x_per (row-major) or snake(z_{i-1}) (feature-major)
             name = f"periodic_linears.{i}"

@@ -615,6 +615,14 @@ def light_fwd(desc, params, pack, x_per, x_pos, stash, pred):
                               _p(pred), _stream()), "npp_light_fwd")
 
 
+def light_wgrad(desc, stash, dstash, grad):
+    """All seven weight / bias gradients of the C candidates in one launch: grad (C, n) += ... (clear first)."""
+    import ctypes
+    C, B = stash.shape[0], stash.shape[2]
+    assert stash.is_contiguous() and dstash.is_contiguous() and grad.stride(1) == 1 and grad.shape[0] == C
+    check(lib().npp_light_wgrad(ctypes.byref(desc), _p(stash), _p(dstash), C, B, _p(grad), grad.stride(0), _stream()), "npp_light_wgrad")
+
+
 def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash):
     """Fused data-gradient chain: dpred (C, B, 3) -> draw (C, B, 3), dstash (C, rows, B)."""
     import ctypes
