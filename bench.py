@@ -599,9 +599,9 @@ def main():
                    "candidate_set": {"n_candidates": len(cands9), "fit_s": t_set, "fit_s_per_candidate": t_set / len(cands9),
                                      "fit_plus_score_s": t_set_all, "ms_per_iteration_of_the_set": t_set / rk.N_iters * 1e3,
                                      "rows_per_s": len(cands9) * rk.N_iters * rk.N_rand / t_set, "best_score": min(x[0] for x in sc9),
-                                     "how": "NPPNetLightBatch: the candidate is a grid dimension of every dense-layer launch"},
-                   "note": "NPP_Net_light D=4 W=256 on the generic exact-fp32 dense kernels; candidate_fit_s is ONE candidate alone "
-                           "(~40 launches of 128 workgroups per iteration), candidate_set the 9 candidates of an image together"}
+                                     "how": "NPPNetLightBatch: fused forward / data-gradient chains (csrc/npp_light.hip) and one grouped weight-gradient launch, the candidate is a grid dimension"},
+                   "note": "NPP_Net_light D=4 W=256, exact fp32, fused chains; candidate_fit_s is ONE candidate alone (a candidate set of one: "
+                           "7 launches per iteration), candidate_set the 9 candidates of an image together (what search.py's loop amounts to)"}
 
     # ---- extra: throughput mode -- two independent image fits interleaved on this GPU, one stream each (more images than
     #      GPUs, BASELINE config c3 style): their dependent-launch gaps and under-filled kernels overlap ----
