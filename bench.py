@@ -660,8 +660,7 @@ def main():
             remap[f"rng_{mode}"] = {"ms_per_iter": dt5 * 1e3, "rows_per_iter": rows_r, "rows_per_s": rows_r / dt5}
             fr.close()
             del fr
-        remap["note"] = ("rng_reference reproduces np.random.choice(1 048 576, 8192, replace=False) draw for draw: one full permutation of the pixel pool per draw on the host (native MT19937 stream, group-wise rejection walk, AVX2 where available: ~1.2 ms per permutation, two per iteration, on a producer thread); rng_fast draws on the device"
-                         "the pixel pool per iteration on the host (3.5 ms, the loop is host-bound); rng_fast is device-bound")
+        remap["note"] = ("rng_reference reproduces np.random.choice(1 048 576, 8192, replace=False) draw for draw: one full permutation of the pixel pool per draw on the host (native MT19937 stream, group-wise rejection walk, AVX2 where available: ~1.2 ms per permutation, two per iteration, on a producer thread); rng_fast draws on the device")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
