@@ -423,10 +423,13 @@ int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, int64_t dz_s
  * 4 pos_linears.0, 5 feature_linear1, 6 rgb_linear; weight [n_out][ld] with ld >= n_in, bias [n_out]).
  * npp_light_pack: the MFMA-ordered copies of the weights the chains stream (forward and transposed), npp_light_pack_floats()
  * floats per candidate; rebuild after every optimiser step.
- * npp_light_fwd: x_per (C, B, 20), x_pos (B, 42) shared -> d_pred (C, B, 3) = sigmoid(raw) and the FEATURE-major stash
+ * npp_light_fwd: x_per (C, n_src, 20), x_pos (n_src, 42) shared; row r of the batch is table row d_idx[r] (the pixel rows drawn for
+ * this iteration, search.py:113-116; d_idx null: r itself, n_src = B) -> d_pred (C, B, 3) = sigmoid(raw) and the FEATURE-major stash
  * (C, npp_light_stash_rows(), B): pre-activations z_0 .. z_3, [f1 | x_pos | 0] (304 rows), z_p -- row offsets by
  * npp_light_stash_row(0..6) = z0 z1 z2 z3 hp zp xper^T (the activations are snake(z): recomputed by their consumers).
- * npp_light_bwd: d_dpred (C, B, 3) = dL/dpred -> d_draw (C, B, 3) = dL/draw and the gradient stash (C, npp_light_dstash_rows(), B):
+ * npp_light_bwd: d_dpred (C, B, 3) = dL/dpred -- or, with d_gt (B, 3) non-null, the adaptive robust pixel loss itself folded in
+ * (npp_pixel_loss_batched's arithmetic: d_latents (C, 6), loss words d_loss (C) and latent gradients d_dlatent (C, 6) accumulated,
+ * d_dpred unused) -> d_draw (C, B, 3) = dL/draw and the gradient stash (C, npp_light_dstash_rows(), B):
  * d z_0 .. d z_3, d f1, d z_p, d raw^T (npp_light_dstash_row(0..6)).  The weight gradients: npp_light_wgrad (or
  * npp_linear_bwd_weight_strided layer by layer) over the two stashes.  B a multiple of 32 (workgroups of 64 or 32 rows, whichever loads the CUs more evenly; NPP_LIGHT_ROWS forces one). */
 typedef struct {
@@ -441,14 +444,16 @@ int npp_light_dstash_row(int which);
 int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, float* d_pack, int64_t pack_stride,
                    void* stream);
 int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
-                  const float* d_x_per, const float* d_x_pos, int C, int64_t B, float* d_stash, float* d_pred, void* stream);
+                  const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
+                  float* d_pred, void* stream);
 /* The seven weight / bias gradients of all candidates in one launch over the two stashes: into d_grad + c * grad_stride at the
  * parameters' own offsets (accumulated; clear first). */
 int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
                     int64_t grad_stride, void* stream);
 int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
-                  const float* d_stash, const float* d_pred, const float* d_dpred, int C, int64_t B, float* d_draw,
-                  float* d_dstash, void* stream);
+                  const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
+                  const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
+                  float* d_draw, float* d_dstash, void* stream);
 /* npp_pixel_loss over nbatch problems: d_pred / d_dpred (nbatch, N, 3), d_latents / d_dlatent (nbatch, 6), d_loss (nbatch);
  * the targets d_gt (N, 3) are shared when gt_stride == 0, else problem b reads d_gt + b * gt_stride. */
 int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,

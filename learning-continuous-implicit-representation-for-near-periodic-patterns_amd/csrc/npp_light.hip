@@ -55,6 +55,10 @@ struct LightArgs {
   float* draw;                                  // (C, B, 3)        backward only
   float* dstash;                                // (C, LD_ROWS, B)  backward only
   int64_t B;
+  const int64_t* idx; int64_t n_src;            // forward: rows idx[r] of x_per (C, n_src, 20) / x_pos (n_src, 42); idx null: rows r, n_src = B
+  const float* gt;                              // backward with the pixel loss folded in: targets (B, 3) ... (null: d pred is an input)
+  const float* latents; const float* spline; int n_knots; float x_scale;      // ... its adaptive-loss latents (C, 6) and spline table
+  float* loss; float* dlatent;                  // ... and where the loss words (C) / latent gradients (C, 6) accumulate
 };
 
 // ---- packs ----------------------------------------------------------------------------------------------------------------
@@ -131,11 +135,12 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
   const int nt0 = 2 * wave;
   // x_per tile -> region features 0..31 (20 real, 12 zero: L0 is packed as 4 k-step groups)
   {
-    const float* xp = a.x_per + ((int64_t)c * B + row0) * kLPer;
+    const float* xp = a.x_per + (int64_t)c * a.n_src * kLPer;
     float* Rf = (float*)R;
     for (int i = tid; i < 32 * RT; i += kLThreads) {
       const int f = i / RT, row = i % RT;
-      const float v = f < kLPer ? xp[row * kLPer + f] : 0.0f;
+      const int64_t src = a.idx ? a.idx[row0 + row] : row0 + row;
+      const float v = f < kLPer ? xp[src * kLPer + f] : 0.0f;
       Rf[f * RT + row] = v;
       if (f < kLPer) S[(int64_t)(LS_XP + f) * B + row0 + row] = v;        // x_per^T: the first layer's weight-gradient operand
     }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
     float* hp = S + (int64_t)LS_HP * B;
     for (int i = tid; i < (kLHp - kLW) * RT; i += kLThreads) {
       const int f = i / RT, row = i % RT;
-      const float v = f < kLPos ? a.x_pos[(row0 + row) * kLPos + f] : 0.0f;
+      const float v = f < kLPos ? a.x_pos[(a.idx ? a.idx[row0 + row] : row0 + row) * kLPos + f] : 0.0f;
       Rf[(kLW + f) * RT + row] = v;
       hp[(int64_t)(kLW + f) * B + row0 + row] = v;
     }
@@ -258,15 +263,46 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
   const float* S = a.stash + (int64_t)c * LS_ROWS * B;
   float* D = a.dstash + (int64_t)c * LD_ROWS * B;
   const int nt0 = 2 * wave;
-  // d raw = d pred * pred (1 - pred)
+  // d raw = d pred * pred (1 - pred); with the pixel loss folded in (a.gt): d pred = d img2mse(robust_loss_adaptive)/d pred right here
+  // (models/mse_calculator.py:13-27 without a mask: the arithmetic of pixel_loss_body, npp_common.h), loss / latent gradients by atomics
+  __shared__ ChanParams cp[3];
+  __shared__ float sred[7];
+  if (a.gt) {
+    if (tid < 3) cp[tid] = chan_params(a.latents[c * 6 + tid], a.latents[c * 6 + 3 + tid], a.spline, a.n_knots, a.x_scale);
+    if (tid < 7) sred[tid] = 0.0f;
+    wg_barrier();
+  }
   if (tid < RT * 3) {
     const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
-    const float p = a.pred[g], d = a.dpred[g] * p * (1.0f - p);
+    const float p = a.pred[g];
+    float dp;
+    if (a.gt) {
+      const int ch = tid % 3;
+      const ChanParams q = cp[ch];
+      const float inv = 1.0f / (3.0f * (float)B);
+      const float x = p - a.gt[row0 * 3 + tid];
+      const float xs = x / q.c, ssx = xs * xs;
+      const float u = ssx / q.beta + 1.0f, e = 0.5f * q.alpha, lnu = logf(u);
+      const float ue = expf(e * lnu), ue1 = ue / u;
+      dp = inv * (x / (q.c * q.c)) * ue1;
+      atomicAdd(&sred[0], (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz);
+      atomicAdd(&sred[1 + ch], -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz);
+      atomicAdd(&sred[4 + ch], -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c);
+    } else {
+      dp = a.dpred[g];
+    }
+    const float d = dp * p * (1.0f - p);
     a.draw[g] = d;
     sD[tid] = d;
     D[(int64_t)(LD_RAW + tid % 3) * B + row0 + tid / 3] = d;       // d raw^T for rgb_linear's weight gradient
   }
   wg_barrier();
+  if (a.gt && tid < 7) {
+    const float inv = 1.0f / (3.0f * (float)B), v = sred[tid];
+    if (tid == 0) atomicAdd(a.loss + c, v * inv);
+    else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
+    else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+  }
   // d a_p = d raw W_rgb; d z_p = d a_p * snake'(z_p) -> region rows 0..127 + stash
   {
     const float* Wr = P + a.L.w_off[6];
@@ -367,13 +403,14 @@ extern "C" int npp_light_pack(const npp_light_desc* L, const float* d_params, in
 }
 
 extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
-                             const float* d_x_per, const float* d_x_pos, int C, int64_t B, float* d_stash, float* d_pred, void* stream) {
+                             const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
+                             float* d_pred, void* stream) {
   int rc = light_check(L, d_params, d_pack, C, B, "npp_light_fwd");
   if (rc) return rc;
-  if (!d_x_per || !d_x_pos || !d_stash || !d_pred) { set_error("npp_light_fwd: null argument"); return NPP_ERR_ARG; }
+  if (!d_x_per || !d_x_pos || !d_stash || !d_pred || (d_idx ? n_src < 1 : n_src != B)) { set_error("npp_light_fwd: null argument / n_src"); return NPP_ERR_ARG; }
   LightArgs a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
-  a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B;
+  a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B; a.idx = d_idx; a.n_src = n_src;
   if (light_rows_per_wg(C, B, false) == 64) {
     static SmemOnce once;
     if (!smem_attr(once, (const void*)light_fwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
@@ -389,14 +426,19 @@ extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int
 }
 
 extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
-                             const float* d_stash, const float* d_pred, const float* d_dpred, int C, int64_t B, float* d_draw, float* d_dstash,
-                             void* stream) {
+                             const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
+                             const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
+                             float* d_draw, float* d_dstash, void* stream) {
   int rc = light_check(L, d_params, d_pack, C, B, "npp_light_bwd");
   if (rc) return rc;
-  if (!d_stash || !d_pred || !d_dpred || !d_draw || !d_dstash) { set_error("npp_light_bwd: null argument"); return NPP_ERR_ARG; }
+  if (!d_stash || !d_pred || !d_draw || !d_dstash || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || !d_loss || !d_dlatent) : !d_dpred)) {
+    set_error("npp_light_bwd: null argument (d_dpred, or d_gt with latents / spline / loss / dlatent)");
+    return NPP_ERR_ARG;
+  }
   LightArgs a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
   a.stash = (float*)d_stash; a.pred = (float*)d_pred; a.dpred = d_dpred; a.draw = d_draw; a.dstash = d_dstash; a.B = B;
+  a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
   if (light_rows_per_wg(C, B, true) == 64) {
     static SmemOnce once;
     if (!smem_attr(once, (const void*)light_bwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }

@@ -314,7 +314,7 @@ __global__ void sub_kernel(const float* __restrict__ a, const float* __restrict_
 // written densely (ldc == N), which is what the weight-gradient form produces.  Batched launches (nbatch independent
 // problems, blockIdx.z = batch * splits + split) count all the batches' tiles towards the fill target.
 // Fills splits / kchunk / vec flags and returns the grid.
-static dim3 gemm_prepare(GemmArgs& g, bool a_kc, bool b_kc, bool batch_split) {
+static dim3 gemm_prepare(GemmArgs& g, bool a_kc, bool b_kc, bool batch_split, int group_fill = 0) {
   const int nb = g.nbatch > 1 ? g.nbatch : 1;
   const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64) * nb;
   // a batched launch may split when its partial sums have somewhere zeroed to meet: the caller accumulates, or the outputs of the
@@ -323,7 +323,8 @@ static dim3 gemm_prepare(GemmArgs& g, bool a_kc, bool b_kc, bool batch_split) {
   int splits = 1;
   if (g.act == 0 && !g.Z && !g.dact && g.ldc == g.N && tiles < 128 * nb && g.K >= 256 && (nb == 1 || (batch_split && (g.accumulate || dense_out)))) {
     static const int batch_fill = [] { const char* e = getenv("NPP_GEMM_BATCH_FILL"); return e ? atoi(e) : 640; }();
-    splits = min(32, min((g.K + 63) / 64, max(1, ((nb > 1 ? batch_fill : 512) + tiles - 1) / tiles)));
+    const int fill = group_fill > 0 ? group_fill : (nb > 1 ? batch_fill : 512);
+    splits = min(32, min((g.K + 63) / 64, max(1, (fill + tiles - 1) / tiles)));
   }
   g.kchunk = ((g.K + splits - 1) / splits + 31) / 32 * 32;
   splits = (g.K + g.kchunk - 1) / g.kchunk;
@@ -511,7 +512,10 @@ extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, co
     g.M = out; g.N = in; g.K = (int)B; g.accumulate = 1; g.b_snake = x_snake[i];
     g.nbatch = C; g.sab = (int64_t)LD_ROWS * B; g.sbb = (int64_t)LS_ROWS * B; g.scb = grad_stride; g.srsb = grad_stride;
     if (C == 1) g.nbatch = 1;
-    const dim3 grid = gemm_prepare(g, true, true, true);
+    // (one launch holds all seven problems: a problem needs only a few hundred workgroups of its own -- 2 ranges instead of 5 for the
+    //  stacked 256-wide layers: 481 -> 469 us per iteration of 9 candidates; a single candidate keeps the 512-workgroup target)
+    static const int gfill = [] { const char* e = getenv("NPP_LIGHT_WGRAD_FILL"); return e ? atoi(e) : 160; }();
+    const dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : 0);
     G.first_wg[i] = wg; G.gx[i] = (int)grid.x; G.gy[i] = (int)grid.y;
     wg += (int)(grid.x * grid.y * grid.z);
   }

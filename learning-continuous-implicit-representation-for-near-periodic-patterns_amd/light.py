@@ -288,17 +288,19 @@ class NPPNetLightBatch:
             self._ws[("fused", B)] = ws
         return ws
 
-    def _train_step_fused(self, x_pos, x_per, gt):
-        """train_step() on the fused chains: pack -> forward -> pixel loss -> data gradients -> 7 weight-gradient launches over the
-        feature-major stashes (ONE grouped launch; NPP_LIGHT_GROUPED_WGRAD=0: seven) -> Adam: 7 launches for the whole candidate set."""
-        C, B = x_per.shape[:2]
+    def _train_step_fused(self, x_pos, x_per, gt, idx=None):
+        """train_step() on the fused chains: pack -> forward (gathers the iteration's rows itself when idx is given) -> data gradients
+        with the pixel loss folded in -> gradient clear -> ONE grouped weight-gradient launch over the feature-major stashes
+        (NPP_LIGHT_GROUPED_WGRAD=0: seven) -> Adam: 6 launches for the whole candidate set."""
+        C = x_per.shape[0]
+        B = gt.shape[0]
         ws = self._work_fused(B)
         S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
         ops.light_pack(self._desc, self.params, self._pack)
-        ops.light_fwd(self._desc, self.params, self._pack, x_per.contiguous(), x_pos.contiguous(), S, ws["pred"])
+        ops.light_fwd(self._desc, self.params, self._pack, x_per.contiguous(), x_pos.contiguous(), S, ws["pred"], idx=idx)
         loss = self._loss2[self._li]
-        ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
-        ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], ws["dpred"], ws["draw"], D_)
+        ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], None, ws["draw"], D_,
+                      loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
         self.grad.zero_()
         if self.grouped_wgrad:
             ops.light_wgrad(self._desc, S, D_, self.grad)   # all seven layers, one launch
@@ -308,7 +310,7 @@ class NPPNetLightBatch:
             name = f"periodic_linears.{i}"
             dz = D_[:, dr[i]:dr[i] + W]
             if i == 0:
-                ops.linear_bwd_weight_strided(dz, x_per, self.dw[name], self.db[name], True, False)
+                ops.linear_bwd_weight_strided(dz, S[:, sr[6]:sr[7]], self.dw[name], self.db[name], True, True)
             else:
                 ops.linear_bwd_weight_strided(dz, S[:, sr[i - 1]:sr[i - 1] + W], self.dw[name], self.db[name], True, True, x_snake=True)
         ops.linear_bwd_weight_strided(D_[:, dr[4]:dr[4] + W], S[:, sr[3]:sr[3] + W], self.dw["feature_linear1"], self.db["feature_linear1"], True, True,
@@ -328,12 +330,15 @@ class NPPNetLightBatch:
             self._ws[B] = ws
         return ws
 
-    def train_step(self, x_pos, x_per, gt):
-        """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20)."""
-        C, B = x_per.shape[:2]
+    def train_step(self, x_pos, x_per, gt, idx=None):
+        """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20) -- or, with
+        idx (B int64), the whole tables x_pos (n, in_pos) / x_per (C, n, 20) whose rows idx are this iteration's batch."""
+        C, B = x_per.shape[0], gt.shape[0]
         if self.fused and B % 32 == 0:
-            loss = self._train_step_fused(x_pos, x_per, gt)
+            loss = self._train_step_fused(x_pos, x_per, gt, idx)
             return self._adam(loss)
+        if idx is not None:
+            x_pos, x_per = x_pos[idx], x_per[:, idx]
         ws, W, D = self._work(B), self.W, self.D
         rows = lambda t: t.view(C * B, t.shape[2])                                                 # noqa: E731
         # ---- forward (NPPNetLight.forward)
@@ -571,8 +576,7 @@ class ProposalRanker:
             x_per_all = torch.stack([t[1] for t in tabs])                                            # (C, n_train, 20)
             del tabs
             for it in range(self.N_iters):
-                idx = draws[it]
-                batch.train_step(x_pos_all[idx], x_per_all[:, idx], gt_all[it])
+                batch.train_step(x_pos_all, x_per_all, gt_all[it], idx=draws[it])
             self._batch_keep = batch                                                                 # the nets are views of its blobs
             nets.extend(batch.nets)
         return nets

@@ -605,14 +605,17 @@ def light_pack(desc, params, pack):
     check(lib().npp_light_pack(ctypes.byref(desc), _p(params), params.stride(0), C, _p(pack), pack.stride(0), _stream()), "npp_light_pack")
 
 
-def light_fwd(desc, params, pack, x_per, x_pos, stash, pred):
-    """Fused NPP_Net_light forward of C candidates: x_per (C, B, 20), x_pos (B, 42) -> pred (C, B, 3), stash (C, rows, B)."""
+def light_fwd(desc, params, pack, x_per, x_pos, stash, pred, idx=None):
+    """Fused NPP_Net_light forward of C candidates: x_per (C, n, 20), x_pos (n, 42) -> pred (C, B, 3), stash (C, rows, B); batch row r is
+    table row idx[r] (idx: B int64 on the device) or r itself (idx None, n == B)."""
     import ctypes
-    C, B = x_per.shape[:2]
+    C, n = x_per.shape[:2]
+    B = pred.shape[1]
     assert x_per.is_contiguous() and x_pos.is_contiguous() and stash.is_contiguous() and pred.is_contiguous()
-    assert x_per.shape == (C, B, 20) and x_pos.shape == (B, 42) and pred.shape == (C, B, 3) and stash.shape[0] == C and stash.shape[2] == B
-    check(lib().npp_light_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), C, B, _p(stash),
-                              _p(pred), _stream()), "npp_light_fwd")
+    assert x_per.shape == (C, n, 20) and x_pos.shape == (n, 42) and pred.shape == (C, B, 3) and stash.shape[0] == C and stash.shape[2] == B
+    assert (idx is None and n == B) or (idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B)
+    check(lib().npp_light_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n, C, B,
+                              _p(stash), _p(pred), _stream()), "npp_light_fwd")
 
 
 def light_wgrad(desc, stash, dstash, grad):
@@ -623,13 +626,22 @@ def light_wgrad(desc, stash, dstash, grad):
     check(lib().npp_light_wgrad(ctypes.byref(desc), _p(stash), _p(dstash), C, B, _p(grad), grad.stride(0), _stream()), "npp_light_wgrad")
 
 
-def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash):
-    """Fused data-gradient chain: dpred (C, B, 3) -> draw (C, B, 3), dstash (C, rows, B)."""
+def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash, loss_args=None):
+    """Fused data-gradient chain: dpred (C, B, 3) -> draw (C, B, 3), dstash (C, rows, B).  loss_args = (gt (B, 3), latents (C, 6), spline,
+    n_knots, x_scale, loss (C), dlatent (C, 6)): the adaptive robust pixel loss is evaluated inside the launch instead (dpred unused)."""
     import ctypes
     C, B = pred.shape[:2]
-    assert all(t.is_contiguous() for t in (stash, pred, dpred, draw, dstash)) and dstash.shape[0] == C and dstash.shape[2] == B
-    check(lib().npp_light_bwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(dpred), C, B,
-                              _p(draw), _p(dstash), _stream()), "npp_light_bwd")
+    assert all(t.is_contiguous() for t in (stash, pred, draw, dstash)) and dstash.shape[0] == C and dstash.shape[2] == B
+    if loss_args is None:
+        assert dpred.is_contiguous()
+        gt = lat = spl = loss = dlat = None
+        nk, xs = 0, 0.0
+    else:
+        gt, lat, spl, nk, xs, loss, dlat = loss_args
+        assert gt.shape == (B, 3) and gt.is_contiguous() and lat.shape == (C, 6) and lat.is_contiguous() and dlat.shape == (C, 6) and dlat.is_contiguous()
+        assert loss.numel() == C and loss.is_contiguous()
+    check(lib().npp_light_bwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(dpred), _p(gt),
+                              _p(lat), _p(spl), nk, xs, _p(loss), _p(dlat), C, B, _p(draw), _p(dstash), _stream()), "npp_light_bwd")
 
 
 def act_bwd(dy, zy, act, dz):
