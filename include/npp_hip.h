@@ -446,6 +446,12 @@ int npp_light_pack(const npp_light_desc* L, const float* d_params, int64_t param
 int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                   const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
                   float* d_pred, void* stream);
+/* optimizer.step() (Adam over the stacked blobs and the candidates' six latents each, npp_adam_step_net's arithmetic), zero_grad()
+ * (d_grad, d_dlat and the C loss words d_zero cleared) and the re-pack of every updated weight (npp_light_pack's layout) in ONE launch.
+ * n: live floats per candidate (<= stride). */
+int npp_light_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n, int C,
+                        float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                        float lr, float beta1, float beta2, float eps, int step, void* stream);
 /* The seven weight / bias gradients of all candidates in one launch over the two stashes: into d_grad + c * grad_stride at the
  * parameters' own offsets (accumulated; clear first). */
 int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,

@@ -134,6 +134,7 @@ SYMBOLS = {
     "npp_light_dstash_row": (_i32, [_i32]),
     "npp_light_pack": (_i32, [C.POINTER(LightDesc), _vp, _i64, _i32, _vp, _i64, _vp]),
     "npp_light_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "npp_light_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_light_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
     "npp_light_bwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "npp_pixel_loss_batched": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),

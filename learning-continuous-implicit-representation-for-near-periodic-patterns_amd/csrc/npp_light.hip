@@ -94,6 +94,53 @@ __global__ void light_pack_kernel(LightArgs a, LightPackDesc pd, float* __restri
   ((f32x4_t*)(out + (int64_t)blockIdx.y * out_stride))[u] = o;
 }
 
+// ---- optimizer.step() + zero_grad() + re-pack in one launch ---------------------------------------------------------------------
+// Adam over the stacked blobs (torch.optim.Adam single-tensor maths, adam_update in npp_common.h), every updated weight scattered into
+// the packs through the inverse of light_pack_kernel's map, the gradient cleared on the way; the extra block column (blockIdx.x ==
+// gridDim.x - 1) steps the candidate's six adaptive-loss latents and clears one loss word.
+struct LightAdamArgs {
+  npp_light_desc L;
+  float *p, *m, *v, *g; int64_t stride; int32_t n;         // (C, stride) blobs, n live floats per candidate
+  float* pack; int64_t pack_stride;
+  float *lat, *lat_m, *lat_v, *dlat, *zero;               // (C, 6) x 4, (C)
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+};
+__global__ __launch_bounds__(256) void light_adam_pack_kernel(LightAdamArgs a, LightPackDesc pd) {
+  const int c = blockIdx.y;
+  if (blockIdx.x == gridDim.x - 1) {
+    const int t = threadIdx.x;
+    if (t < 6) {
+      const int i = c * 6 + t;
+      float m = a.lat_m[i], v = a.lat_v[i];
+      a.lat[i] = adam_update(a.lat[i], m, v, a.dlat[i], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+      a.lat_m[i] = m; a.lat_v[i] = v; a.dlat[i] = 0.0f;
+    } else if (t == 6 && a.zero) a.zero[c] = 0.0f;
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t gi = (int64_t)c * a.stride + i;
+  float m = a.m[gi], v = a.v[gi];
+  const float w = adam_update(a.p[gi], m, v, a.g[gi], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+  a.p[gi] = w; a.m[gi] = m; a.v[gi] = v; a.g[gi] = 0.0f;
+  // which weight is this?  (biases and rgb_linear are read from the blob by the chains: nothing to scatter)
+  int li = -1;
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+    if (i >= a.L.w_off[q] && i < a.L.w_off[q] + (int64_t)a.L.n_out[q] * a.L.ld[q]) li = q;
+  if (li < 0) return;
+  const int off = i - (int)a.L.w_off[li], ld = a.L.ld[li];
+  const int row = off / ld, col = off - row * ld;
+  float* pk = a.pack + (int64_t)c * a.pack_stride;
+  const int lf = li < 4 ? LF_L0 + li : (li == 4 ? LF_POS : LF_F1);
+  if (col < pd.f_groups[lf] * 8)
+    pk[(int64_t)(pd.f_off[lf] + ((col >> 3) * pd.f_nt[lf] + (row >> 5)) * 64 + ((col & 7) >> 2) * 32 + (row & 31)) * 4 + (col & 3)] = w;
+  if (li >= 1 && col < kLW) {                                  // transposed pack: A[m = col][k = row]
+    const int lb = li == 4 ? LB_POS : (li == 5 ? LB_F1 : (li == 3 ? LB_L3 : (li == 2 ? LB_L2 : LB_L1)));
+    pk[(int64_t)(pd.b_off[lb] + ((row >> 3) * 8 + (col >> 5)) * 64 + ((row & 7) >> 2) * 32 + (col & 31)) * 4 + (row & 3)] = w;
+  }
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------------
 // epilogue of a hidden layer: z (+ bias already in acc) -> stash zT, h = snake(z) (or z) -> region (+ stash hT).  Only z is stashed for
 // the snake layers: the weight-gradient GEMM forms h = snake(z) again while it stages the operand (npp_linear_bwd_weight_strided)
@@ -451,4 +498,25 @@ extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int
                        light_pack_desc());
   }
   return check_launch("npp_light_bwd");
+}
+
+extern "C" int npp_light_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n, int C,
+                                   float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                                   float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  int rc = light_check(L, d_params, d_pack, C, 32, "npp_light_adam_pack");
+  if (rc) return rc;
+  const LightPackDesc pd = light_pack_desc();
+  if (!d_m || !d_v || !d_grad || !d_lat || !d_lat_m || !d_lat_v || !d_dlat || n < 1 || n > stride || n > 0x7fffffffLL || step < 1 ||
+      pack_stride < 4 * (int64_t)pd.total) {
+    set_error("npp_light_adam_pack: bad argument");
+    return NPP_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  LightAdamArgs a{};
+  a.L = *L; a.p = d_params; a.m = d_m; a.v = d_v; a.g = d_grad; a.stride = stride; a.n = (int32_t)n;
+  a.pack = d_pack; a.pack_stride = pack_stride;
+  a.lat = d_lat; a.lat_m = d_lat_m; a.lat_v = d_lat_v; a.dlat = d_dlat; a.zero = d_zero;
+  a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+  hipLaunchKernelGGL(light_adam_pack_kernel, dim3((unsigned)((n + 255) / 256 + 1), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd);
+  return check_launch("npp_light_adam_pack");
 }

@@ -263,6 +263,8 @@ class NPPNetLightBatch:
             raise ValueError("the fused NPP_Net_light chains are built for D = 4, W = 256, 42 positional and 20 periodic input columns")
         self.fused = bool(fused)
         self.grouped_wgrad = os.environ.get("NPP_LIGHT_GROUPED_WGRAD", "1") != "0"
+        self.fused_adam = self.fused and os.environ.get("NPP_LIGHT_FUSED_ADAM", "1") != "0"
+        self._pack_valid = False
         if self.fused:
             from ._lib import LightDesc, lib
             order = [f"periodic_linears.{i}" for i in range(4)] + ["pos_linears.0", "feature_linear1", "rgb_linear"]
@@ -278,6 +280,10 @@ class NPPNetLightBatch:
             self._pack = z(C, int(L.npp_light_pack_floats()))
             self._srow = [int(L.npp_light_stash_row(i)) for i in range(8)]       # z0 z1 z2 z3 hp zp xperT | rows
             self._drow = [int(L.npp_light_dstash_row(i)) for i in range(8)]      # dz0 dz1 dz2 dz3 df1 dzp drawT | rows
+
+    def invalidate_pack(self):
+        """Call after writing parameters from outside (load_state_dict on a member net): the next fused step re-packs first."""
+        self._pack_valid = False
 
     def _work_fused(self, B):
         ws = self._ws.get(("fused", B))
@@ -296,12 +302,16 @@ class NPPNetLightBatch:
         B = gt.shape[0]
         ws = self._work_fused(B)
         S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
-        ops.light_pack(self._desc, self.params, self._pack)
+        if not self._pack_valid:                            # first iteration (or after invalidate_pack()): later ones get the packs from the Adam launch
+            ops.light_pack(self._desc, self.params, self._pack)
+            if self.fused_adam:
+                self.grad.zero_()
         ops.light_fwd(self._desc, self.params, self._pack, x_per.contiguous(), x_pos.contiguous(), S, ws["pred"], idx=idx)
         loss = self._loss2[self._li]
         ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], None, ws["draw"], D_,
                       loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
-        self.grad.zero_()
+        if not self.fused_adam:
+            self.grad.zero_()
         if self.grouped_wgrad:
             ops.light_wgrad(self._desc, S, D_, self.grad)   # all seven layers, one launch
             return loss
@@ -379,8 +389,15 @@ class NPPNetLightBatch:
         n0 = self.nets[0]
         step, lr = n0.opt_step + 1, n0.lr
         self._li ^= 1
-        ops.adam_step_net(self.params.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), 1, self.params.numel(),
-                          self.latents.view(-1), self.lat_m.view(-1), self.lat_v.view(-1), self._dl_c.view(-1), self._loss2[self._li], lr, step)
+        if self.fused_adam:
+            # optimizer.step() + zero_grad() + the packs of the next forward, one launch (csrc/npp_light.hip)
+            ops.light_adam_pack(self._desc, self.params, self.m, self.v, self.grad, self.n_params, self._pack, self.latents, self.lat_m, self.lat_v,
+                                self._dl_c, self._loss2[self._li], lr, step)
+            self._pack_valid = True
+        else:
+            ops.adam_step_net(self.params.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), 1, self.params.numel(),
+                              self.latents.view(-1), self.lat_m.view(-1), self.lat_v.view(-1), self._dl_c.view(-1), self._loss2[self._li], lr, step)
+            self._pack_valid = False
         for net in self.nets:
             net.opt_step = step
             net.advance_clock()

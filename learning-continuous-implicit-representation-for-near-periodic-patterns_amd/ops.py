@@ -618,6 +618,16 @@ def light_fwd(desc, params, pack, x_per, x_pos, stash, pred, idx=None):
                               _p(stash), _p(pred), _stream()), "npp_light_fwd")
 
 
+def light_adam_pack(desc, params, m, v, grad, n, pack, lat, lat_m, lat_v, dlat, zero, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """Adam over C stacked blobs (C, stride) and their latents (C, 6) + gradient / loss-word clear + re-pack, one launch."""
+    import ctypes
+    C = params.shape[0]
+    assert all(t.shape == params.shape and t.stride() == params.stride() for t in (m, v, grad)) and params.stride(1) == 1
+    assert all(t.shape == (C, 6) and t.is_contiguous() for t in (lat, lat_m, lat_v, dlat)) and (zero is None or (zero.numel() == C and zero.is_contiguous()))
+    check(lib().npp_light_adam_pack(ctypes.byref(desc), _p(params), _p(m), _p(v), _p(grad), params.stride(0), n, C, _p(pack), pack.stride(0), _p(lat),
+                                    _p(lat_m), _p(lat_v), _p(dlat), _p(zero), lr, b1, b2, eps, step, _stream()), "npp_light_adam_pack")
+
+
 def light_wgrad(desc, stash, dstash, grad):
     """All seven weight / bias gradients of the C candidates in one launch: grad (C, n) += ... (clear first)."""
     import ctypes

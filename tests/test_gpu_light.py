@@ -268,7 +268,8 @@ def test_ranking_prefers_the_true_periodicity(dev):
 
 def test_fused_light_chains_equal_the_layer_by_layer_path(dev):
     """csrc/npp_light.hip (forward and data-gradient chains of NPP_Net_light as one launch each over all candidates, hardware sin,
-    feature-major stashes, strided weight-gradient GEMMs) against the layer-by-layer dense path (precise sinf) from the same
+    feature-major stashes, grouped weight-gradient launch, Adam + re-pack + gradient clear in one launch from iteration 1 on)
+    against the layer-by-layer dense path (precise sinf) from the same
     weights on the same rows: predictions, losses, EVERY parameter gradient of every candidate, and the parameters / latents after
     ten optimiser steps."""
     from npp_amd.light import NPPNetLightBatch, default_light_init
@@ -286,6 +287,7 @@ def test_fused_light_chains_equal_the_layer_by_layer_path(dev):
     gt_all = torch.from_numpy(rng.rand(4 * B, 3).astype(np.float32)).to(dev)
     for it in range(10):
         idx = torch.from_numpy(rng.permutation(4 * B)[:B]).to(dev)
+        nets[0].fused_adam = it > 0          # iteration 0 keeps the gradients for the comparison below (the fused Adam launch clears them)
         losses = [n_.train_step(x_pos_all[idx], x_per_all[:, idx], gt_all[idx]).clone() for n_ in nets]
         if it == 0:
             pf, pu = nets[0]._ws[("fused", B)]["pred"], nets[1]._ws[B]["pred"]
