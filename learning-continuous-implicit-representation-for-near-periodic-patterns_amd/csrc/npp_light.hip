@@ -266,9 +266,11 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
 
 // ---- backward (data gradients) ------------------------------------------------------------------------------------------------
 // epilogue: d h -> d z = d h * snake'(z) (z from the forward stash; DERIV false: d z = d h) -> gradient stash (+ region)
-template <bool DERIV, int NB>
+// PRE: the z tile was fetched into zpre before the MFMA loop of this layer (32-row workgroups: 32 registers, loads in flight under the
+// whole contraction instead of a round trip at its end)
+template <bool DERIV, bool PRE, int NB>
 __device__ __forceinline__ void light_bepi(f32x16 (&acc)[2][NB], char* region, const float* __restrict__ zT, float* __restrict__ dT, uint32_t B,
-                                           uint32_t row0, int nt0, int b, int h) {
+                                           uint32_t row0, int nt0, int b, int h, const f32x16 (&zpre)[2][NB]) {
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -280,10 +282,21 @@ __device__ __forceinline__ void light_bepi(f32x16 (&acc)[2][NB], char* region, c
       for (int r = 0; r < 16; ++r) {
         const uint32_t gi = g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B;
         float d = acc[nt][bt][r];
-        if (DERIV) d *= 1.0f + __builtin_amdgcn_sinf(zT[gi] * (2.0f * kInv2Pi));          // activations.py:29-35: 1 + sin 2z
+        if (DERIV) d *= 1.0f + __builtin_amdgcn_sinf((PRE ? zpre[nt][bt][r] : zT[gi]) * (2.0f * kInv2Pi));      // activations.py:29-35: 1 + sin 2z
         dT[gi] = d;
         if (region) *(float*)(rg + ((r & 3) + 8 * (r >> 2)) * (NB * 32) * 4) = d;
       }
+    }
+}
+template <int NB>
+__device__ __forceinline__ void light_zfetch(f32x16 (&zpre)[2][NB], const float* __restrict__ zT, uint32_t B, uint32_t row0, int nt0, int b, int h) {
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+      const uint32_t g = (uint32_t)((nt0 + nt) * 32 + 4 * h) * B + row0 + (uint32_t)(bt * 32 + b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zpre[nt][bt][r] = zT[g + (uint32_t)((r & 3) + 8 * (r >> 2)) * B];
     }
 }
 template <int NB>
@@ -376,16 +389,20 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
   zero_acc(acc);
   part32<2, 8>(acc, rsrc, (uint32_t)pd.b_off[LB_POS], pd.b_groups[LB_POS], nt0, lane, act);
   wg_barrier();
-  light_bepi<false>(acc, R, nullptr, D + (int64_t)LD_F1 * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+  f32x16 zpre[2][NB];
+  light_bepi<false, false>(acc, R, nullptr, D + (int64_t)LD_F1 * B, (uint32_t)B, (uint32_t)row0, nt0, b, h, zpre);
   wg_barrier();
   // d z_3 = (W_f1^T d f1) * snake'(z_3), d z_2 = (W_3^T d z_3) * snake'(z_2), ..., d z_0
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     const int l = 3 - j;                        // hidden layer whose d z this step produces
     zero_acc(acc);
+    constexpr bool kPre = NB == 1;
+    if (kPre) light_zfetch(zpre, S + (int64_t)(LS_Z0 + 256 * l) * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
     part32<2, 8>(acc, rsrc, (uint32_t)pd.b_off[LB_F1 + j], pd.b_groups[LB_F1 + j], nt0, lane, act);
     wg_barrier();
-    light_bepi<true>(acc, l > 0 ? R : nullptr, S + (int64_t)(LS_Z0 + 256 * l) * B, D + (int64_t)(LD_Z0 + 256 * l) * B, (uint32_t)B, (uint32_t)row0, nt0, b, h);
+    light_bepi<true, kPre>(acc, l > 0 ? R : nullptr, S + (int64_t)(LS_Z0 + 256 * l) * B, D + (int64_t)(LD_Z0 + 256 * l) * B, (uint32_t)B, (uint32_t)row0, nt0, b, h,
+                           zpre);
     wg_barrier();
   }
 }
