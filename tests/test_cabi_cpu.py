@@ -64,6 +64,34 @@ def test_bad_arguments_are_reported_not_crashed():
     assert sizes[3] == 4 * 1197316 * 4                       # 4 slabs of the parameter count rounded up to 4 floats (16-byte aligned slabs)
 
 
+def test_light_chain_entry_points_validate_on_the_host():
+    """The fused NPP_Net_light entry points refuse topologies / shapes they are not built for before anything is launched (no GPU
+    needed to see it), and their layout queries are consistent."""
+    from npp_amd._lib import LightDesc
+    L = npp_amd.lib()
+    # forward pack: 32 (20 real) x 256, four 256 x 256, 304 (298 real) x 128; transposed pack: 128 x 256 and four 256 x 256
+    assert L.npp_light_pack_floats() == (32 * 256 + 4 * 65536 + 304 * 128) + (128 * 256 + 4 * 65536)
+    rows = [L.npp_light_stash_row(i) for i in range(8)]
+    assert rows[0] == 0 and rows == sorted(rows) and rows[7] == L.npp_light_stash_rows() and L.npp_light_stash_row(8) < 0
+    drows = [L.npp_light_dstash_row(i) for i in range(8)]
+    assert drows == sorted(drows) and drows[7] == L.npp_light_dstash_rows()
+    d = LightDesc()
+    n_out, n_in = [256, 256, 256, 256, 128, 256, 3], [20, 256, 256, 256, 298, 256, 128]
+    for i in range(7):
+        d.n_out[i], d.n_in[i], d.ld[i] = n_out[i], n_in[i], (n_in[i] + 3) // 4 * 4
+    fake = C.c_void_p(64)                                             # never dereferenced: validation comes first
+    assert L.npp_light_fwd(C.byref(d), fake, 0, fake, 0, fake, fake, None, 100, 1, 100, fake, fake, None) < 0      # B not a multiple of 32
+    assert b"multiple of 32" in L.npp_last_error_string()
+    d.n_out[1] = 128                                                   # a width the chains are not built for
+    assert L.npp_light_pack(C.byref(d), fake, 0, 1, fake, L.npp_light_pack_floats(), None) < 0
+    assert b"fuses NPP_Net_light(D=4, W=256)" in L.npp_last_error_string()
+    d.n_out[1] = 256
+    assert L.npp_light_bwd(C.byref(d), fake, 0, fake, 0, fake, fake, None, None, None, None, 0, 0.0, None, None, 1, 64, fake, fake, None) < 0
+    assert b"d_dpred" in L.npp_last_error_string()                     # neither d_dpred nor the folded loss's arguments
+    assert L.npp_light_wgrad(C.byref(d), fake, fake, 0, 64, fake, 0, None) < 0
+    assert L.npp_linear_bwd_weight_strided(fake, 0, 1, 0, fake, 1, 1, 0, 0, 1, 64, 4, 4, fake, 4, 0, None, 0, None) < 0
+
+
 # ---- NumPy model of the MFMA fragment maps (cdna_hip_programming.md section 3) ----
 def perm16(h, j):
     return 8 * (j >> 2) + 4 * h + (j & 3)
