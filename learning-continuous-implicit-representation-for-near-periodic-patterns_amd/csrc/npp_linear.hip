@@ -513,9 +513,11 @@ extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, co
     g.nbatch = C; g.sab = (int64_t)LD_ROWS * B; g.sbb = (int64_t)LS_ROWS * B; g.scb = grad_stride; g.srsb = grad_stride;
     if (C == 1) g.nbatch = 1;
     // (one launch holds all seven problems: a problem needs only a few hundred workgroups of its own -- 2 ranges instead of 5 for the
-    //  stacked 256-wide layers: 481 -> 469 us per iteration of 9 candidates; a single candidate keeps the 512-workgroup target)
+    //  stacked 256-wide layers: 481 -> 469 us per iteration of 9 candidates; a single candidate: 8 ranges instead of 32 -- its 8.4 M
+    //  atomic adds were half of the launch: 215 -> 184 us per iteration)
     static const int gfill = [] { const char* e = getenv("NPP_LIGHT_WGRAD_FILL"); return e ? atoi(e) : 160; }();
-    const dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : 0);
+    static const int gfill1 = [] { const char* e = getenv("NPP_LIGHT_WGRAD_FILL1"); return e ? atoi(e) : 128; }();
+    const dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : gfill1);
     G.first_wg[i] = wg; G.gx[i] = (int)grid.x; G.gy[i] = (int)grid.y;
     wg += (int)(grid.x * grid.y * grid.z);
   }
