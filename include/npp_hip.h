@@ -38,7 +38,9 @@ extern "C" {
 #define NPP_WIDTH 256       /* or 512 (the reference's default --netwidth, options/arg_config.py:57; libnpp_hip_w512.so)  */
 #endif
 #define NPP_MAX_TENSORS 32
+#ifndef NPP_ROW_TILE
 #define NPP_ROW_TILE 64     /* rows per workgroup of the fused MLP kernels */
+#endif
 
 typedef enum {
   NPP_OK = 0,
