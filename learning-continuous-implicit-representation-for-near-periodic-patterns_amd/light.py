@@ -423,6 +423,9 @@ def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
     return {f"{k}.{p}": getattr(m, p).detach().numpy().copy() for k, m in mods.items() for p in ("weight", "bias")}
 
 
+_SCORE_TRUNKS = {}       # (device, id(weights...)) -> (LPIPS, ContextualLoss, weights): ProposalRanker's score trunks, shared between images
+
+
 class ProposalRanker:
     """The candidate loop of NPP_proposal/search.py:85-215 for one image: per candidate (angles, periods) a fresh
     NPP_Net_light is fitted for N_iters pixel-loss iterations on the known pixels, rendered over the pseudo-mask region
@@ -451,8 +454,17 @@ class ProposalRanker:
             torch.random.set_rng_state(g)
         self.freqs = np.asarray(freqs, np.float32)
         self._draws = None
-        self.percep = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device)
-        self.cx = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device)
+        # the two score trunks are the same for every image of a run (same weights): built and packed once per (device, weights)
+        key = (str(self.device), id(vgg16_state_dict), id(vgg19_state_dict), id(lpips_lin_weights))
+        hit = _SCORE_TRUNKS.get(key)
+        if hit is None or any(a is not b for a, b in zip(hit[2], (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))):
+            hit = (LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device),
+                   ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device),
+                   (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))       # (keeps the keyed objects alive: ids stay unique)
+            if len(_SCORE_TRUNKS) >= 4:
+                _SCORE_TRUNKS.clear()
+            _SCORE_TRUNKS[key] = hit
+        self.percep, self.cx = hit[0], hit[1]
 
     def _pixel_draws(self):
         """(N_iters, n_rand) int64 on the device: the pixel rows of every iteration.  search.py:92-93 reseeds NumPy with 0 before EVERY
