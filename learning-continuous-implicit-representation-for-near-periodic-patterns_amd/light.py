@@ -410,6 +410,10 @@ def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
     weights.  Draws the unused modules too, to keep the generator in step."""
     g = torch.random.get_rng_state()
     torch.manual_seed(seed)
+    # create_npp_net builds the position embedder FIRST (helpers.py:84): its Gaussian Fourier frequencies (embedder.py:26) come out of
+    # the same global generator, so the network's init starts n_freq normal draws into the stream (pinned by g10c_light_init.npz, the
+    # reference's own construction; until round 3 this function skipped them: a statistically equivalent but DIFFERENT start)
+    torch.normal(mean=0.0, std=1.0, size=((in_pos // 2 - 1) // 2, 1))
     mods = {}
     for i in range(D):
         mods[f"periodic_linears.{i}"] = torch.nn.Linear(in_per if i == 0 else W, W)      # skips=[4] is never reached for D = 4
@@ -434,7 +438,14 @@ class ProposalRanker:
 
     def __init__(self, masked_img, i_train, i_val, device="cuda", N_iters=300, N_rand=2048, W=256, D=4, lrate=5e-4, lrate_decay=500,
                  perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
-                 lpips_lin_weights=None, rng_mode="reference"):
+                 lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False):
+        """carry_latents: in the reference the adaptive pixel loss is ONE module-level object (models/helpers.py:8) that every
+        candidate's optimiser trains on (helpers.py:144), so candidate k + 1 starts from the latents candidate k left (fresh Adam
+        moments) and the ranking depends on the order of the candidates.  False (default; SURVEY 3.3 / 8 e: candidates are independent
+        units -- what lets them share launches and shard over GPUs): every candidate starts from the initial latents, as the first
+        one does in the reference.  True: the reference's behaviour, candidates fitted one after the other (tests/golden
+        g10d_light_fit.npz pins both).  record_losses: keep the per-iteration loss words (self.loss_log, one (N_iters, C) tensor per
+        launch group)."""
         from .losses import ContextualLoss, LPIPS
         self.device = ops.select_device(device)
         self.img = torch.as_tensor(np.asarray(masked_img, np.float32)).to(self.device)               # (H,W,3)
@@ -447,6 +458,7 @@ class ProposalRanker:
         self.lrate, self.lrate_decay = lrate, lrate_decay
         self.pw, self.cw = float(perceptual_weight), float(contextual_weight)
         self.rng_mode = rng_mode
+        self.carry_latents, self.record_losses, self.loss_log = bool(carry_latents), bool(record_losses), []
         if freqs is None:                                      # embedder.py:26 after torch.manual_seed(0) (search.py:92)
             g = torch.random.get_rng_state()
             torch.manual_seed(0)
@@ -570,6 +582,12 @@ class ProposalRanker:
         gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
         if batched is None:
             batched = os.environ.get("NPP_LIGHT_BATCH", "1") != "0"
+        if self.carry_latents:                                       # the reference's shared adaptive_pix: strictly one after the other
+            nets, lat = [], None
+            for cand in cands:
+                nets += self._fit_candidates_batched([cand], draws, gt_all, latents0=lat)
+                lat = nets[-1].latents.clone()
+            return nets
         if batched:
             return self._fit_candidates_batched(cands, draws, gt_all)
         nets, tabs = [], []
@@ -591,8 +609,9 @@ class ProposalRanker:
             main.wait_stream(st)
         return nets
 
-    def _fit_candidates_batched(self, cands, draws, gt_all, group=16, init=None):
-        """All candidates of the image in ONE launch sequence (NPPNetLightBatch), `group` at a time: the default of fit_candidates."""
+    def _fit_candidates_batched(self, cands, draws, gt_all, group=16, init=None, latents0=None):
+        """All candidates of the image in ONE launch sequence (NPPNetLightBatch), `group` at a time: the default of fit_candidates.
+        latents0 (6): the adaptive-loss latents every candidate of this call starts from (carry_latents)."""
         nets = []
         if init is None:
             init = default_light_init(self.Wn, self.D)
@@ -604,8 +623,15 @@ class ProposalRanker:
             x_pos_all = tabs[0][0]                                                                   # the same for every candidate
             x_per_all = torch.stack([t[1] for t in tabs])                                            # (C, n_train, 20)
             del tabs
+            if latents0 is not None:
+                batch.latents.copy_(latents0.reshape(1, 6).expand(len(part), 6))
+            log = []
             for it in range(self.N_iters):
-                batch.train_step(x_pos_all, x_per_all, gt_all[it], idx=draws[it])
+                loss = batch.train_step(x_pos_all, x_per_all, gt_all[it], idx=draws[it])
+                if self.record_losses:
+                    log.append(loss.clone())
+            if self.record_losses:
+                self.loss_log.append(torch.stack(log))
             self._batch_keep = batch                                                                 # the nets are views of its blobs
             nets.extend(batch.nets)
         return nets
@@ -634,6 +660,8 @@ class ProposalRanker:
         import torch.distributed as dist
         from .parallel import shard_units, gather_unit_scalars
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi and self.carry_latents:
+            raise ValueError("carry_latents chains the candidates through one set of adaptive-loss latents: it cannot be sharded over ranks")
         mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
         nets = self.fit_candidates([(candidates[ci][0], candidates[ci][1]) for ci in mine])
         details = [self.score(net) for net in nets]

@@ -305,6 +305,40 @@ def test_fused_light_chains_equal_the_layer_by_layer_path(dev):
     assert nets[0].nets[0].opt_step == nets[1].nets[0].opt_step == 10
 
 
+def test_candidate_loop_vs_reference_trajectory_g10d(dev, golden):
+    """The candidate loop of NPP_proposal/search.py:85-147 executed with the REFERENCE's own modules for two candidates in sequence
+    (g10d_light_fit.npz, tests/golden/make_golden_light_fit.py): reseeded init (incl. the Fourier-frequency draws that precede the
+    network's in the generator stream), np.random.choice rows, sigmoid render, adaptive robust pixel loss, Adam over net + latents,
+    the LR rule.  The reference shares ONE adaptive-loss object between the candidates (models/helpers.py:8): with carry_latents the
+    second candidate's whole trajectory is reproduced too; without it (default: independent candidates) it starts from the initial
+    latents and only the first candidate coincides."""
+    from npp_amd.light import ProposalRanker
+    g = golden("g10d_light_fit.npz")
+    cands = [(g[f"c{i}.angles"], g[f"c{i}.periods"]) for i in range(2)]
+    n_it, n_rand = int(g["n_iters"]), int(g["n_rand"])
+    i_val = np.array([[20, 30], [21, 31], [43, 59]], np.int32)             # unused by the fits
+    probe = torch.from_numpy(g["probe"]).to(dev)
+
+    def run(carry):
+        rk = ProposalRanker(g["masked_img"], g["i_train"], i_val, device=dev, N_iters=n_it, N_rand=n_rand, lrate=float(g["lrate"]),
+                            lrate_decay=int(g["lrate_decay"]), carry_latents=carry, record_losses=True)
+        np.testing.assert_array_equal(rk.freqs, g["freqs"])
+        nets = rk.fit_candidates(cands)
+        losses = torch.cat(rk.loss_log, 1).cpu().numpy()                   # (n_it, 2): one column per candidate in both modes
+        return nets, losses
+    nets_c, loss_c = run(True)
+    nets_i, loss_i = run(False)
+    for ci in range(2):
+        ref = g[f"c{ci}.loss"]
+        np.testing.assert_allclose(loss_c[:, ci], ref, rtol=2e-4)
+        np.testing.assert_allclose(nets_c[ci].latents.cpu().numpy(), g[f"c{ci}.latents1"], atol=2e-5)
+        np.testing.assert_allclose(nets_c[ci].render(probe).cpu().numpy(), g[f"c{ci}.probe_pred"], atol=2e-3)
+        assert nets_c[ci].opt_step == n_it and nets_c[ci].global_step == n_it
+    np.testing.assert_allclose(loss_i[:, 0], g["c0.loss"], rtol=2e-4)     # the first candidate is the same in both modes ...
+    np.testing.assert_allclose(nets_i[1].latents.cpu().numpy(), g["c0.latents1"], atol=1e-3)      # ... the second starts afresh (moves like the first)
+    assert np.abs(loss_i[:, 1] - g["c1.loss"]).max() > 10 * np.abs(loss_c[:, 1] - g["c1.loss"]).max()
+
+
 def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
     """ProposalRanker.fit_candidates -- all candidates in every launch (default: NPPNetLightBatch), advanced together on side
     streams (batched=False), or iterations 2 .. N of each fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against

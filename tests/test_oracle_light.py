@@ -48,3 +48,19 @@ def test_lpips_plain(golden):
     f1 = [g[f"lp_f1_{k}"] for k in range(5)]
     lins = [g[f"lp_lin{k}"] for k in range(5)]
     np.testing.assert_allclose(oracle.lpips_plain(f0, f1, lins), g["lp_val"].reshape(-1), rtol=2e-5)
+
+
+def test_default_light_init_is_the_references_generator_stream(golden):
+    """The weights a candidate fit starts from: torch.manual_seed(0), then the position embedder's 10 Gaussian frequency draws, then
+    NPP_Net_light's modules in construction order -- against the reference's own construction (g10c_light_init.npz,
+    tests/golden/make_golden_light_init.py): every tensor's shape, first 16 values (bit for bit), sum and sum of squares."""
+    from npp_amd.light import default_light_init
+    g = golden("g10c_light_init.npz")
+    sd = default_light_init(256, 4)
+    names = sorted(k[5:] for k in g.files if k.startswith("head."))
+    assert sorted(sd) == names
+    for k in names:
+        a = sd[k].astype(np.float64).reshape(-1)
+        assert tuple(g["shape." + k]) == sd[k].shape
+        np.testing.assert_array_equal(sd[k].reshape(-1)[:16], g["head." + k])
+        assert abs(a.sum() - float(g["sum." + k])) < 1e-9 and abs((a * a).sum() - float(g["sq." + k])) < 1e-9
