@@ -305,6 +305,26 @@ def test_fused_light_chains_equal_the_layer_by_layer_path(dev):
     assert nets[0].nets[0].opt_step == nets[1].nets[0].opt_step == 10
 
 
+def test_create_npp_net_is_search_consumes_the_generator_like_the_reference(dev, golden):
+    """torch.manual_seed(0); create_npp_net(..., is_search=True) (search.py:91-99) through the boundary module leaves the SAME
+    Fourier frequencies and the SAME initial weights as the reference's own construction (g10c_light_init.npz): the position embedder's
+    ten normal draws, then NPP_Net_light's modules in construction order, all from the global generator."""
+    import types
+    from npp_amd import reference_api as api
+    g = golden("g10c_light_init.npz")
+    args = types.SimpleNamespace(multires=10, i_embed=0, freq_scales=[1], freq_offsets=[0, -1, 1, 0.5, -0.5], angle_offsets=[0],
+                                 netdepth=4, netwidth=256, activation="snake", netchunk=1 << 22, lrate=5e-4, p_topk=1, normalize_type=1)
+    torch.manual_seed(0)
+    kw, _, _, _, _, emb, _ = api.create_npp_net(args, torch.tensor([80.54, 168.69]), torch.tensor([40.77, 36.48]), (211, 325),
+                                                 percep_net=None, is_search=True)
+    np.testing.assert_allclose(np.asarray(emb.freq_bands, np.float32).reshape(-1), g["freqs"], rtol=1e-6)
+    sd = {k: v.detach().cpu().numpy() for k, v in kw["network_fn"].state_dict().items()}
+    assert sorted(sd) == sorted(k[5:] for k in g.files if k.startswith("head."))
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.reshape(-1)[:16], g["head." + k])
+        assert abs(float(v.astype(np.float64).sum()) - float(g["sum." + k])) < 1e-6
+
+
 def test_candidate_loop_vs_reference_trajectory_g10d(dev, golden):
     """The candidate loop of NPP_proposal/search.py:85-147 executed with the REFERENCE's own modules for two candidates in sequence
     (g10d_light_fit.npz, tests/golden/make_golden_light_fit.py): reseeded init (incl. the Fourier-frequency draws that precede the
