@@ -298,7 +298,6 @@ class NPPNetLightBatch:
         """train_step() on the fused chains: pack -> forward (gathers the iteration's rows itself when idx is given) -> data gradients
         with the pixel loss folded in -> gradient clear -> ONE grouped weight-gradient launch over the feature-major stashes
         (NPP_LIGHT_GROUPED_WGRAD=0: seven) -> Adam: 6 launches for the whole candidate set."""
-        C = x_per.shape[0]
         B = gt.shape[0]
         ws = self._work_fused(B)
         S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
@@ -385,7 +384,6 @@ class NPPNetLightBatch:
 
     def _adam(self, loss):
         """Adam over the stacked blobs (the candidates share the step count and the LR clock); pad columns have zero gradient."""
-        C = self.C
         n0 = self.nets[0]
         step, lr = n0.opt_step + 1, n0.lr
         self._li ^= 1
