@@ -463,7 +463,7 @@ class ProposalRanker:
             freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()
             torch.random.set_rng_state(g)
         self.freqs = np.asarray(freqs, np.float32)
-        self._draws = None
+        self._draws, self._gt_all = None, None
         # the two score trunks are the same for every image of a run (same weights): built and packed once per (device, weights)
         key = (str(self.device), id(vgg16_state_dict), id(vgg19_state_dict), id(lpips_lin_weights))
         hit = _SCORE_TRUNKS.get(key)
@@ -494,6 +494,53 @@ class ProposalRanker:
             self._draws = torch.from_numpy(np.ascontiguousarray(np.stack(sel), np.int64)).to(self.device)   # once per image: plain copy
         return self._draws
 
+    def _draw_stream(self, chunk=32):
+        """The iterations' pixel rows and their colours as a stream of device chunks [(draws (n, B) int64, gt (n, B, 3))]: the first
+        fit of an image starts on chunk 0 while a helper thread (the native generator releases the GIL) draws the later ones --
+        300 shuffles of the known pixels are 50 ms of host time on a 676 x 494 image against 150 ms of device time for the whole
+        candidate set.  The assembled table is cached for the image's later fits (_pixel_draws)."""
+        if self._draws is not None:
+            if self._gt_all is None:
+                c_all = self.i_train_dev[self._draws.reshape(-1)].long()
+                self._gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(self._draws.shape[0], self._draws.shape[1], 3).contiguous()
+            yield self._draws, self._gt_all
+            return
+        import queue
+        import threading
+        n_train = self.i_train.shape[0]
+        n_rand = min(self.N_rand, n_train)
+        q = queue.Queue()
+
+        def produce():
+            try:
+                if self.rng_mode == "fast":
+                    g = np.random.default_rng(0)
+                    draw = lambda: g.choice(n_train, n_rand, replace=False)                           # noqa: E731
+                else:
+                    from .host_rng import NativeRandomState                                          # np.random.RandomState(0)'s stream
+                    g = NativeRandomState(0)
+                    draw = lambda: g.choice(n_train, size=[n_rand], replace=False)                   # noqa: E731
+                for it0 in range(0, self.N_iters, chunk):
+                    q.put(np.ascontiguousarray(np.stack([draw() for _ in range(min(chunk, self.N_iters - it0))]), np.int64))
+                q.put(None)
+            except BaseException as e:                                                               # surface generator errors in the caller
+                q.put(e)
+        threading.Thread(target=produce, name="npp-ranker-draws", daemon=True).start()
+        parts_d, parts_g = [], []
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            d = torch.from_numpy(item).to(self.device)
+            c = self.i_train_dev[d.reshape(-1)].long()
+            gt = self.img[c[:, 0], c[:, 1]].reshape(d.shape[0], d.shape[1], 3).contiguous()
+            parts_d.append(d)
+            parts_g.append(gt)
+            yield d, gt
+        self._draws, self._gt_all = torch.cat(parts_d), torch.cat(parts_g)
+
     def fit_candidate(self, angles_deg, periods, params=None, use_graph=None, fused=None):
         """search.py:85-147 for one candidate.
         fused (default unless NPP_LIGHT_FUSED=0 / use_graph / a topology the chains are not built for): the fused forward and
@@ -507,14 +554,12 @@ class ProposalRanker:
         import os
         if use_graph is None:
             use_graph = os.environ.get("NPP_LIGHT_GRAPH", "0") != "0"
-        draws = self._pixel_draws()
         if fused is None:
             fused = (not use_graph and os.environ.get("NPP_LIGHT_FUSED", "1") != "0" and self.Wn == 256 and self.D == 4
-                     and len(self.freqs) == 10 and draws.shape[1] % 32 == 0)
+                     and len(self.freqs) == 10 and min(self.N_rand, self.i_train.shape[0]) % 32 == 0)
         if fused:
-            c_all = self.i_train_dev[draws.reshape(-1)].long()
-            gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
-            return self._fit_candidates_batched([(angles_deg, periods)], draws, gt_all, init=params)[0]
+            return self._fit_candidates_batched([(angles_deg, periods)], init=params)[0]
+        draws = self._pixel_draws()
         net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
                           params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
                           device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
@@ -575,19 +620,19 @@ class ProposalRanker:
             # graph replay makes one fit device-bound (fit_candidate): the candidates simply run one after the other
             return [self.fit_candidate(a_, p_) for a_, p_ in cands]
         main = torch.cuda.current_stream(self.device)
-        draws = self._pixel_draws()
-        c_all = self.i_train_dev[draws.reshape(-1)].long()
-        gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
         if batched is None:
             batched = os.environ.get("NPP_LIGHT_BATCH", "1") != "0"
         if self.carry_latents:                                       # the reference's shared adaptive_pix: strictly one after the other
             nets, lat = [], None
             for cand in cands:
-                nets += self._fit_candidates_batched([cand], draws, gt_all, latents0=lat)
+                nets += self._fit_candidates_batched([cand], latents0=lat)
                 lat = nets[-1].latents.clone()
             return nets
         if batched:
-            return self._fit_candidates_batched(cands, draws, gt_all)
+            return self._fit_candidates_batched(cands)
+        draws = self._pixel_draws()
+        c_all = self.i_train_dev[draws.reshape(-1)].long()
+        gt_all = self.img[c_all[:, 0], c_all[:, 1]].reshape(draws.shape[0], draws.shape[1], 3).contiguous()
         nets, tabs = [], []
         for angles_deg, periods in cands:
             net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img), default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
@@ -607,9 +652,10 @@ class ProposalRanker:
             main.wait_stream(st)
         return nets
 
-    def _fit_candidates_batched(self, cands, draws, gt_all, group=16, init=None, latents0=None):
+    def _fit_candidates_batched(self, cands, group=16, init=None, latents0=None):
         """All candidates of the image in ONE launch sequence (NPPNetLightBatch), `group` at a time: the default of fit_candidates.
-        latents0 (6): the adaptive-loss latents every candidate of this call starts from (carry_latents)."""
+        latents0 (6): the adaptive-loss latents every candidate of this call starts from (carry_latents).  The pixel rows come from
+        _draw_stream(): drawn on a helper thread under the first group's iterations, cached for the rest."""
         nets = []
         if init is None:
             init = default_light_init(self.Wn, self.D)
@@ -624,10 +670,11 @@ class ProposalRanker:
             if latents0 is not None:
                 batch.latents.copy_(latents0.reshape(1, 6).expand(len(part), 6))
             log = []
-            for it in range(self.N_iters):
-                loss = batch.train_step(x_pos_all, x_per_all, gt_all[it], idx=draws[it])
-                if self.record_losses:
-                    log.append(loss.clone())
+            for draws, gt_all in self._draw_stream():
+                for j in range(draws.shape[0]):
+                    loss = batch.train_step(x_pos_all, x_per_all, gt_all[j], idx=draws[j])
+                    if self.record_losses:
+                        log.append(loss.clone())
             if self.record_losses:
                 self.loss_log.append(torch.stack(log))
             self._batch_keep = batch                                                                 # the nets are views of its blobs

@@ -19,7 +19,8 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 H, K = 512, 3
 angles, periods, shifts = syn.synthetic_periodicity(H, K)
-net = NPPNet(angles, periods, syn.SEED0_FREQS, (H, H), params=syn.init_params(K, seed=0), device=dev)
+WIDTH = int(os.environ.get("R3_WIDTH", "256"))
+net = NPPNet(angles, periods, syn.SEED0_FREQS, (H, H), params=syn.init_params(K, seed=0, width=WIDTH), device=dev, width=WIDTH)
 yy, xx = np.meshgrid(np.arange(H, dtype=np.int32), np.arange(H, dtype=np.int32), indexing="ij")
 grid = torch.from_numpy(np.stack([yy, xx], -1).reshape(-1, 2)).to(dev)
 
