@@ -54,3 +54,27 @@ def test_launch_ranks_helper_returns_child_code(tmp_path):
     bad.write_text("import sys\nsys.exit(3)\n")
     assert launch_ranks(str(ok), 2, [], timeout=240) == 0
     assert launch_ranks(str(bad), 2, [], timeout=240) != 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_initialises_rccl_on_the_card():
+    """The driver's launch form (python -m torch.distributed.run ... bench.py --gpus N) with N = 1 on a real GPU: the nccl (= RCCL)
+    process group is initialised with device_id binding, and the barrier / all_gather / all_reduce of the timing protocol run
+    through it -- the same code path as N = 8, exercised on hardware by the one rank this box has (a child process: the test
+    process itself has touched the GPU)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from npp_amd.parallel import free_port
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), BENCH, "--gpus", "1", "--steps", "40", "--warmup", "5", "--no-extras",
+                        "--no-cpu-baseline"], env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["collective"] == {"backend": "nccl (RCCL)", "ranks": 1}
+    assert j["per_rank_rows_per_s"] == [j["value"]] and j["value"] > 1e6 and j["scaling"] == "weak"

@@ -515,3 +515,36 @@ def test_shift_search_vs_reference(dev, golden, tag):
     Lb = proposal.compute_loss(big, bm, sh, True).cpu().numpy()
     want = oracle.shift_losses(big.cpu().numpy(), bm.cpu().numpy(), sh[::97], True)
     np.testing.assert_allclose(Lb[::97], want, rtol=1e-4)
+
+
+def test_ranking_over_an_rccl_process_group_on_the_card(dev):
+    """ProposalRanker.rank under an initialised nccl (= RCCL) process group -- the sharded form of search.py's candidate loop
+    (parallel.shard_units + one all_gather of the score rows) -- on real hardware with the one rank this box has, in a child process;
+    same ranking as without a group."""
+    import os
+    import subprocess
+    import sys
+    from npp_amd.parallel import free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle\n"
+        "from npp_amd.light import ProposalRanker\n"
+        "H = 96\n"
+        "img, mask = oracle.synthetic_image(H, noise=0.01)\n"
+        "angles, periods, _ = oracle.synthetic_periodicity(H, 1)\n"
+        "pseudo = np.ones((H, H)); pseudo[30:60, 40:70] = 0\n"
+        "i_train, i_val = np.stack(np.nonzero(pseudo), 1), np.stack(np.nonzero(1 - pseudo), 1)\n"
+        "cands = [(angles[0], periods[0], None), (angles[0] + 35.0, periods[0], None), (angles[0], periods[0] * 1.4, None)]\n"
+        "rk = ProposalRanker(img, i_train, i_val, device='cuda:0', N_iters=20, N_rand=512)\n"
+        "d0, o0, _ = rk.rank(cands, topk=3)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "d1, o1, det = rk.rank(cands, topk=3)\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "assert list(o0) == list(o1) and np.allclose(d0, d1, rtol=1e-3), (d0, d1)\n"
+        "print('ok', dist.is_available(), len(det))\n") % (root, os.path.join(root, "tests"))
+    env = {**os.environ, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), r.stderr[-3000:]
