@@ -14,7 +14,13 @@
 // batch is split over the grid; every (tile, split) writes its partial sums with plain
 // stores into slab `split` of the gradient buffer, in the reference's parameter layout
 // ([out][in] row-major).  npp_adam_step adds the slabs: no atomics, bit-reproducible.
-// Main loop (round 3): a five-slot LDS ring of half tiles filled by LDS-DMA with three halves in flight, counted vmcnt + raw
+// Main loop (round 4, wgrad_loop_hybrid): dz by LDS-DMA into an 8-slot ring, the layer-input operand through a 4-deep register ring
+// with snake(z) formed in the registers; bit-identical to the round-3 loop, 107.9 -> 104.0 us in sequence.  Measured with every
+// load hitting L2 (NPP_DIAG_WGRAD_SAMETILE) and the phases switched off one at a time (profiles/r04_wgrad_ablation.txt): the loop
+// is a chain of phases that ADD per step -- loads + LDS stores + barrier 0.31 us, fragment reads + conversion 0.31, MFMAs 0.36
+// (0.51 alone) per 32-row half -- and HBM costs 14 us on top: the launch is bound by its per-step dependent chain inside the CU,
+// not by the memory side.
+// Round 3: a five-slot LDS ring of half tiles filled by LDS-DMA with three halves in flight, counted vmcnt + raw
 // barrier per half (wgrad_loop below); snake(z) of the inputs that are stored as fp16 pre-activations is formed in place in
 // LDS under the MFMAs.  Measured at c2 (26 624 rows, in sequence): 115 -> 106-108 us; the loop now runs at the LDS-DMA
 // streaming rate of a CU (~30 GB/s, the guide's "ldsdma-fill"), i.e. the launch is memory-side-bound.
@@ -22,6 +28,7 @@
 // Algorithmic work: 2 * sum_l n_out*n_in FLOP per batch row (embedding pad slots and the
 // padding of the 3-row rgb job are not counted).
 #include "npp_common.h"
+#include <type_traits>
 
 namespace npp {
 
@@ -46,6 +53,12 @@ constexpr int kMaxJobs = 24;
 #endif
 // Timing-only diagnostic builds (wrong results; never shipped): NPP_DIAG_WGRAD_SAMETILE (every load hits L2),
 // NPP_DIAG_WGRAD_NOLOOP=n (prologue + n tiles + epilogue), NPP_DIAG_WGRAD_NOEPI (no slab stores) -- DESIGN.md section 4.
+
+#ifdef NPP_DIAG_WGRAD_SAMETILE
+constexpr bool kSameTile = true;      // timing-only: every half re-reads the split's first tile (all L2 hits)
+#else
+constexpr bool kSameTile = false;
+#endif
 
 struct WJob {
   int32_t a_ks0, a_nks, m;     // dz array: k-step offset inside dzF, k-steps, valid outputs
@@ -111,7 +124,7 @@ __device__ __forceinline__ void wgrad_loop(f32x16 (&acc)[2][4], float (&bsum)[2]
   // (cdna_hip_programming.md 5.7: no VGPR destination = register-safe; M0 written in the statement that uses it)
   auto dma_half = [&](int hidx) {
     const bool ok = hidx < nh;                       // wave-uniform
-    const int g = g0 + (hidx >> 1), bt = hidx & 1;
+    const int g = g0 + (kSameTile ? 0 : (hidx >> 1)), bt = hidx & 1;
     const rsrc_t xa = ok ? ra : rzero, xb = ok ? rb : rzero;
     const int soa = ok ? (int)((uint32_t)g * a_stride) + bt * 2048 : 0;
     const int sob = ok ? (int)((uint32_t)g * b_stride) + bt * 2048 : 0;
@@ -204,6 +217,207 @@ __device__ __forceinline__ void wgrad_loop(f32x16 (&acc)[2][4], float (&bsum)[2]
   wg_barrier();
 }
 
+
+// ---- hybrid ingest (round 4, NPP_WGRAD_HYBRID): dz by LDS-DMA, the layer-input operand through registers ---------------------
+// The five-slot ring above moves BOTH operands of a half by LDS-DMA: 32 KiB per half step land at the ~29 GB/s a CU's DMA path
+// delivers, 1.1 us against 0.45 us of MFMA time.  Here the dz operand keeps that path (ring of kNA 16-KiB slots, DA halves in
+// flight) and the input operand goes memory -> VGPR (2 x buffer_load_dwordx4 per lane and half, RB halves in flight in RB register
+// sets) -> [snake(z) formed IN the registers for the fp16 z arrays: no LDS round trip] -> ds_write_b128 into one of two 16-KiB B
+// slots, one half ahead of its use.  Every vector-memory instruction of the loop is inline asm and counted by hand (an LDS-DMA
+// hipcc knows about makes it wait vmcnt(0) before the next ds_read; a register load it knows about is waited for with a count
+// that ignores the DMAs in between and drains the ring): per step the issue order is [DMA dz(s + DA) x 2, load in(s + RB) x 2],
+// so `s_waitcnt vmcnt(4 (RB - 2))` at the top of step s covers this wave's in(s + 1) registers and, with DA = RB - 1, its dz(s)
+// DMAs; the raw barrier publishes them.  The loop body is unrolled RB times so that the register set of a half is a compile-time
+// name (a rotating copy of an in-flight register would read stale data: nothing interlocks a VGPR with a pending load the
+// compiler does not know about).
+#ifndef NPP_WGRAD_HYBRID
+#define NPP_WGRAD_HYBRID 1     // 0: the round-3 all-LDS-DMA ring (bit-identical results; 107.9 vs 104.0 us in sequence at c2)
+#endif
+#ifndef NPP_WGRAD_LATE_ISSUE
+#define NPP_WGRAD_LATE_ISSUE 0
+#endif
+#ifndef NPP_WGRAD_RB
+#define NPP_WGRAD_RB 4
+#endif
+constexpr int kRB = NPP_WGRAD_RB, kDA = kRB - 1;
+constexpr int kNA = 8;                                  // dz ring: 8 x 16 KiB, then the two input slots: 160 KiB in all
+constexpr int kBBase = kNA * kHalfOp;
+static_assert(kBBase + 2 * kHalfOp <= kSmemW && kNA >= kDA + 1 && kRB >= 3 && kRB <= 6, "hybrid ring");
+
+template <bool ZB, bool BIAS>
+__device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&bsum)[2], char* smem, const rsrc_t ra, const rsrc_t rb,
+                                                  const rsrc_t rzero, uint32_t a_stride, uint32_t b_stride, int g0, int g1, int wave,
+                                                  int lane, const int (&offA)[2], const int (&offB)[4]) {
+  const int nh = 2 * (g1 - g0);
+  if (nh <= 0) return;
+  const int voff = wave * 4096 + lane * 16;          // pair `wave` of the tile, this lane's 16 bytes
+  u32x4 R[kRB][2];                                   // register sets of the input operand: half h lives in R[h % kRB]
+  auto dma_a = [&](int hidx) {                       // dz half hidx -> A slot hidx % kNA (zero-length descriptor past the end)
+    const bool ok = hidx >= 0 && hidx < nh;          // wave-uniform
+    const int g = g0 + (kSameTile ? 0 : (hidx >> 1)), bt = hidx & 1;
+    const rsrc_t xa = ok ? ra : rzero;
+    const int soa = ok ? (int)((uint32_t)g * a_stride) + bt * 2048 : 0;
+    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void*)(smem + ((hidx + kNA) % kNA) * kHalfOp + wave * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa0] offen lds\n\t"
+        "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa1] offen lds\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [v] "v"(voff), [xa] "s"(xa), [sa0] "s"(soa), [sa1] "s"(soa + 1024), [d0] "s"(d0), [d1] "s"(d0 + 1024u)
+        : "memory");
+  };
+  auto load_b = [&](int hidx, u32x4 (&r)[2]) {       // input half hidx -> registers (zeros past the end)
+    const bool ok = hidx < nh;
+    const int g = g0 + (kSameTile ? 0 : (hidx >> 1)), bt = hidx & 1;
+    const rsrc_t xb = ok ? rb : rzero;
+    const int sob = ok ? (int)((uint32_t)g * b_stride) + bt * 2048 : 0;
+    asm volatile(
+        "buffer_load_dwordx4 %[r0], %[v], %[xb], %[sb] offen\n\t"
+        "buffer_load_dwordx4 %[r1], %[v], %[xb], %[sb] offen offset:1024"
+        : [r0] "=&v"(r[0]), [r1] "=&v"(r[1])
+        : [v] "v"(voff), [xb] "s"(xb), [sb] "s"(sob)
+        : "memory");
+  };
+  // registers of a landed half -> (snake) -> the B slot of that half
+  auto store_b = [&](int hidx, u32x4 (&r)[2]) {
+    char* base = smem + kBBase + (hidx & 1) * kHalfOp + wave * 2048 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#ifdef NPP_DIAG_WG_NOCONV
+      if (false) {
+#else
+      if (ZB) {
+#endif
+        const f16x8 z = __builtin_bit_cast(f16x8, r[q]);
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (__bf16)snake_fast((float)z[j]);
+        *(bf16x8*)(base + q * 1024) = a;
+      } else {
+        *(u32x4*)(base + q * 1024) = r[q];
+      }
+    }
+  };
+  // prologue = steps -kRB .. -1 of the steady-state issue pattern (dummy DMAs for the dz halves < 0 keep the count uniform)
+#pragma unroll
+  for (int t = -kRB; t < 0; ++t) {
+    dma_a(t + kDA);
+    load_b(t + kRB, R[(t + kRB) % kRB]);
+  }
+  asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(R[0][0]), "+v"(R[0][1]) : [n] "n"(4 * (kRB - 1)) : "memory");     // in(0) has landed
+  store_b(0, R[0]);
+  int a_off = 0;                                              // (s % kNA) * kHalfOp
+  // one step; I = s % kRB at compile time
+  auto step = [&](int s, auto I_) {
+    constexpr int I = decltype(I_)::value, I1 = (I + 1) % kRB;
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(R[I1][0]), "+v"(R[I1][1]) : [n] "n"(4 * (kRB - 2)) : "memory");   // in(s + 1), own dz(s)
+    wg_barrier();                                             // everybody's dz(s) and in(s); every read of step s - 1 is over
+#if !NPP_WGRAD_LATE_ISSUE
+    dma_a(s + kDA);
+    load_b(s + kRB, R[I]);
+#endif
+    const char* sA = smem + a_off;
+    const char* sB = smem + kBBase + (s & 1) * kHalfOp;
+    bf16x8 a[2][2], b[2][4];
+#ifdef NPP_DIAG_WG_NOREAD
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(a[q][i]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(b[q][j]));
+    }
+    asm volatile("" :: "s"(sA), "s"(sB));
+#else
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[q][i] = wfrag_read(sA, offA[0] + i * 2048 + q * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[q][j] = wfrag_read(sB, offB[0] + j * 2048 + q * 1024);
+    }
+#endif
+    store_b(s + 1, R[I1]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (BIAS) {
+        const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const bf16x2 pr = {a[q][i][j], a[q][i][j + 1]};
+            bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#ifdef NPP_DIAG_WG_NOMFMA
+          asm volatile("" :: "v"(a[q][i]), "v"(b[q][j]));
+#else
+          acc[i][j] = mfma_bf16(a[q][i], b[q][j], acc[i][j]);
+#endif
+        }
+#if NPP_WGRAD_LATE_ISSUE
+      // the step's memory requests go out in the shadow of the first k-step's MFMAs instead of in front of the fragment reads:
+      // an LDS-DMA piece costs its wave ~60-185 cycles of issue (MI355X_MICROARCH.md), which was exposed before every step
+      if (ZB) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NPP_WGRAD_VALU_PER_MFMA, 0);
+        }
+      }
+      if (q == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_a(s + kDA);
+        load_b(s + kRB, R[I]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
+#if !NPP_WGRAD_LATE_ISSUE
+    if (ZB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NPP_WGRAD_VALU_PER_MFMA, 0);
+      }
+    }
+#endif
+    a_off = a_off + kHalfOp == kNA * kHalfOp ? 0 : a_off + kHalfOp;
+  };
+  int s = 0;
+  for (; s + kRB <= nh; s += kRB) {
+    step(s, std::integral_constant<int, 0>{});
+    step(s + 1, std::integral_constant<int, 1>{});
+    step(s + 2, std::integral_constant<int, 2>{});
+    if constexpr (kRB > 3) step(s + 3, std::integral_constant<int, 3>{});
+    if constexpr (kRB > 4) step(s + 4, std::integral_constant<int, 4>{});
+    if constexpr (kRB > 5) step(s + 5, std::integral_constant<int, 5>{});
+  }
+  const int rem = nh - s;                                     // < kRB, wave-uniform
+  if (rem > 0) step(s, std::integral_constant<int, 0>{});
+  if (rem > 1) step(s + 1, std::integral_constant<int, 1>{});
+  if (rem > 2) step(s + 2, std::integral_constant<int, 2>{});
+  if constexpr (kRB > 4) if (rem > 3) step(s + 3, std::integral_constant<int, 3>{});
+  if constexpr (kRB > 5) if (rem > 4) step(s + 4, std::integral_constant<int, 4>{});
+  // dummy / tail DMAs and loads must have landed before the epilogue stages in LDS -- and before the register sets die: the
+  // sets are operands of this wait, so every one of them stays allocated up to here (a set the compiler considers dead is
+  // re-used at once, and the load still in flight then lands on top of the new value: seen in the tail steps, whose loads
+  // nothing consumes)
+#pragma unroll
+  for (int i = 0; i < kRB; ++i) asm volatile("" : "+v"(R[i][0]), "+v"(R[i][1]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < kRB; ++i) asm volatile("" : "+v"(R[i][0]), "+v"(R[i][1]));
+  wg_barrier();
+}
+
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -267,6 +481,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #else
   const int g0 = (int)wg_begin, g1 = (int)wg_end;
 #endif
+#if NPP_WGRAD_HYBRID
+#define wgrad_loop wgrad_loop_hybrid
+#endif
   if (J.b_is_z) {
     if (do_bias) wgrad_loop<true, true>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
     else wgrad_loop<true, false>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
@@ -274,6 +491,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     if (do_bias) wgrad_loop<false, true>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
     else wgrad_loop<false, false>(acc, bsum, smem, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB);
   }
+#if NPP_WGRAD_HYBRID
+#undef wgrad_loop
+#endif
 
   // ---- epilogue: stores into this split's slab, reference layout
   float* slab = A.gslabs + (int64_t)split_id * A.slab_stride;

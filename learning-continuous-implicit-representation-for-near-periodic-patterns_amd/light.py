@@ -704,8 +704,11 @@ class ProposalRanker:
         all-gathered once at the end; every rank returns the same ranking."""
         import torch.distributed as dist
         from .parallel import shard_units, gather_unit_scalars
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if multi and self.carry_latents:
+        # the sharded branch runs whenever a process group exists (a world of ONE rank included: shard_units / the all_gather of
+        # gather_unit_scalars are then the identity, but it is the same code path the 8-GPU node takes)
+        multi = dist.is_available() and dist.is_initialized()
+        self.last_rank_collective = None
+        if multi and dist.get_world_size() > 1 and self.carry_latents:
             raise ValueError("carry_latents chains the candidates through one set of adaptive-loss latents: it cannot be sharded over ranks")
         mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
         nets = self.fit_candidates([(candidates[ci][0], candidates[ci][1]) for ci in mine])
@@ -713,6 +716,7 @@ class ProposalRanker:
         if multi:
             t = torch.tensor(details, dtype=torch.float32, device=self.device).reshape(-1, 3)
             details = [tuple(r) for r in gather_unit_scalars(t, len(candidates)).cpu().tolist()]
+            self.last_rank_collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rows": len(details)}
         d = np.array([x[0] for x in details])
         order = np.argsort(d, kind="stable")[:min(topk, len(d))]
         return d[order], order, details

@@ -171,23 +171,31 @@ def main(argv=None):
     from concurrent.futures import ThreadPoolExecutor
     writer, pending = ThreadPoolExecutor(1), []
     t0 = time.time()
+    failed, write_error = None, None
     try:
         _train_loop(args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0)
-    except BaseException:
-        # a fit that dies mid-loop must not leave an output directory behind that a re-run would take for a finished one
-        # (`file exists, exit!!` above), nor the sampler's producer thread / the writer pool alive
-        import shutil
-        shutil.rmtree(outroot, ignore_errors=True)
+    except BaseException as e:
+        failed = e
         raise
     finally:
         fit.close()                                         # the sampler's producer thread
+        # first the writers: a queued dump_testset re-creates its directory (os.makedirs(..., exist_ok=True)), so nothing is
+        # removed while one may still run
         for p in pending:
             if not p.cancel():
                 try:
                     p.result()
-                except Exception as e:                     # a failed write: report, keep the original exception (if any)
+                except Exception as e:
+                    write_error = write_error or e
                     print(f"[WARN] writing a test set failed: {e}")
-        writer.shutdown()
+        writer.shutdown(wait=True)
+        # a fit that dies mid-loop must not leave an output directory behind that a re-run would take for a finished one
+        # (`file exists, exit!!` above) -- but an interrupted one (Ctrl-C) keeps the test sets it has already written
+        if (failed is not None and not isinstance(failed, KeyboardInterrupt)) or write_error is not None:
+            import shutil
+            shutil.rmtree(outroot, ignore_errors=True)
+    if write_error is not None:                             # the loop itself succeeded: a lost output is still a failed run
+        raise write_error
     return fit
 
 

@@ -539,9 +539,11 @@ def test_ranking_over_an_rccl_process_group_on_the_card(dev):
         "cands = [(angles[0], periods[0], None), (angles[0] + 35.0, periods[0], None), (angles[0], periods[0] * 1.4, None)]\n"
         "rk = ProposalRanker(img, i_train, i_val, device='cuda:0', N_iters=20, N_rand=512)\n"
         "d0, o0, _ = rk.rank(cands, topk=3)\n"
+        "assert rk.last_rank_collective is None\n"
         "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
         "d1, o1, det = rk.rank(cands, topk=3)\n"
         "dist.barrier(); dist.destroy_process_group()\n"
+        "assert rk.last_rank_collective == {'backend': 'nccl', 'ranks': 1, 'rows': 3}, rk.last_rank_collective\n"
         "assert list(o0) == list(o1) and np.allclose(d0, d1, rtol=1e-3), (d0, d1)\n"
         "print('ok', dist.is_available(), len(det))\n") % (root, os.path.join(root, "tests"))
     env = {**os.environ, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
