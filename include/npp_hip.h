@@ -38,6 +38,7 @@ extern "C" {
 #define NPP_WIDTH 256       /* or 512 (the reference's default --netwidth, options/arg_config.py:57; libnpp_hip_w512.so)  */
 #endif
 #define NPP_MAX_TENSORS 32
+#define NPP_MAX_STACK 16      /* images per stacked launch (npp_*_stack) */
 #ifndef NPP_ROW_TILE
 #define NPP_ROW_TILE 64     /* rows per workgroup of the fused MLP kernels */
 #endif
@@ -379,6 +380,74 @@ int npp_trunk_grad_in_pf(const float* d_df_nchw, const void* d_y, int N_total, i
 /* flat (fp16 activations when is_f16, else bf16 gradients) -> (n_run, C, H, W) fp32 */
 int npp_trunk_export(const void* d_act, int N_total, int n_run, int C, int H, int W,
                      float* d_out_nchw, int is_f16, void* stream);
+
+/* ---- stacked launches: M independent images of one shape in every launch (round 4) ---------------------------
+ * The reference fits its images one after the other (run_completion.sh:8-14: one `python train.py` per directory);
+ * the fits are independent -- own weights, own Adam state, own random stream -- so M of them can ride
+ * in ONE launch sequence: BASELINE config c3 at fewer than 8 GPUs (8 / 4 / 2 images per GPU), and the cure for the
+ * ~5 us every dependent launch of the single-image loop costs.  Every per-image buffer of the entry points above gets a
+ * leading image dimension with a fixed stride; what differs per image AND per iteration sits in a device array of M
+ * npp_stack_iter the caller uploads once per iteration.  All images share K, width, the row count Bp, n_p, P and the
+ * known-pixel row count; an image whose sampler found no valid real patch (train.py:160-161) has active = 0 and is
+ * skipped by every launch of that iteration (its Adam step count and LR clock do not advance).
+ * Work items are numbered so that an image's workgroups stay on 8 / M of the 8 XCDs (M in {1, 2, 4, 8}): every L2 then
+ * keeps one image's weight pack, as in the single-image launch. */
+typedef struct {
+  int32_t active;        /* 0: the image sits this iteration out */
+  int32_t k;             /* real patches per fake patch (models/sampler.py:297-354), 1 on 'same' iterations */
+  int32_t comp;          /* 'val' compositing (train.py:230-231) */
+  int32_t with_lp;       /* 'same' iteration with the LPIPS term (train.py:241-251) */
+  int32_t x0;            /* first image of this fit's prediction half in the stacked trunk batch [x_0..x_{M-1} | y_0..y_{M-1}] */
+  int32_t nk;            /* n_p * k (0 when inactive) */
+  int32_t same;          /* real patches := fake patches (sampler.py:338) */
+  int32_t pad1;
+  float step_size;       /* Adam: lr / (1 - beta1^t) of THIS image's step t */
+  float inv_sqrt_bc2;    /* 1 / sqrt(1 - beta2^t) */
+  float pad2, pad3;
+} npp_stack_iter;
+
+/* The embedder constants the fused kernels derive from npp_embed_cfg, as a device-memory blob (one per image of a stack):
+ * npp_embed_dev_bytes() bytes each, built on the host by npp_embed_dev_build and uploaded by the caller once per fit. */
+int npp_embed_dev_bytes(void);
+int npp_embed_dev_build(const npp_embed_cfg* cfg, void* host_out);
+/* npp_mlp_fwd over M images: coords (M, Bp, 2), pred (M, Bp, 3); image m's forward pack / parameter blob / stash at
+ * + m * stride (bytes / floats / bytes).  d_iter nullable (all active). */
+int npp_mlp_fwd_stack(const int32_t* d_coords_yx, int64_t Bp, const void* d_embed_dev, int M, int K, int width,
+                      const void* d_wf, int64_t wf_stride_bytes, const float* d_params, int64_t params_stride,
+                      float* d_pred, void* d_actF, int64_t act_stride_bytes, const void* d_iter, void* stream);
+/* npp_trunk_patch_in_loss over M images.  d_crops (M, n_p + n_p*kmax, 3, P, P): per image [fake | real] as ONE
+ * npp_patch_gather writes them; d_cmasks likewise (M, n_p + n_p*kmax, P, P).  The trunk batch is laid out
+ * [x_0 .. x_{M-1} | y_0 .. y_{M-1}] (X = sum of the nk images each) inside a flat tensor of FIXED geometry N_total
+ * (>= 2 X: 2 M n_p kmax), so the trunk launches run with n_run = 2 X (forward) / X (data gradient).  d_xy (M, 2 n_p kmax,
+ * 3, P, P), nullable: fp32 [x | y] of the images with with_lp set.  d_zero: M patch-loss accumulators, cleared.
+ * loss: the pixel-loss arguments of image 0; image m at pred / dpred + m Bp 3, gt + m gt_stride, latents / dlatent +
+ * m lat_stride, loss + m loss_stride. */
+int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, int64_t row0, const float* d_crops, int64_t crop_stride,
+                                  const float* d_cmasks, int64_t cmask_stride, int M, int n_p, int P, int X, int N_total,
+                                  const float scale[3], const float shift[3], void* d_x0, float* d_xy, int64_t xy_stride,
+                                  float* d_zero, const void* d_iter, const npp_pixel_loss_args* loss, int64_t gt_stride,
+                                  int lat_stride, int loss_stride, void* stream);
+/* npp_cx_fwd_bwd over sample groups (one per image): see csrc/npp_cx.hip. */
+int npp_cx_fwd_bwd_groups(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, float scale,
+                          float* d_loss, int loss_stride, float* d_dfx, const void* d_iter, int M, void* d_workspace,
+                          int64_t workspace_bytes, void* stream);
+/* npp_mlp_bwd_patch over M images: d_dx_a = dL/d(trunk batch) (only the leading X images are read: image m's at x0),
+ * d_dx_b (M, 2 n_p kmax, 3, P, P) nullable = the LPIPS branch's gradient of the images with with_lp set. */
+int npp_mlp_bwd_patch_stack(float* d_dpred, const float* d_pred, int64_t Bp, int M, int K, int width, const void* d_wb,
+                            int64_t wb_stride_bytes, const float* d_params, int64_t params_stride, const void* d_actF,
+                            int64_t act_stride_bytes, void* d_dzF, int64_t dz_stride_bytes, const float* d_dx_a,
+                            const float* d_dx_b, int64_t dxb_stride, const float* d_cmasks, int64_t cmask_stride,
+                            int64_t row0, int n_p, int P, const void* d_iter, void* stream);
+/* npp_mlp_wgrad over M images: image m's ksplit slabs at d_gslabs + m * slab_img_stride floats. */
+int npp_mlp_wgrad_stack(const void* d_dzF, int64_t dz_stride_bytes, const void* d_actF, int64_t act_stride_bytes,
+                        int64_t Bp, int M, int K, int width, int ksplit, float* d_gslabs, int64_t slab_img_stride,
+                        const void* d_iter, void* stream);
+/* npp_adam_step_net_pack over M images (step size / bias correction per image from d_iter). */
+int npp_adam_step_net_pack_stack(float* d_p, float* d_m, float* d_v, int64_t blob_stride, const float* d_gslabs, int64_t n,
+                                 int n_slabs, int64_t slab_stride, int64_t slab_img_stride, float* d_lat, float* d_lat_m,
+                                 float* d_lat_v, float* d_dlat, int n_lat, int lat_stride, float* d_zero, int n_zero,
+                                 int zero_stride, float beta1, float beta2, float eps, int M, int K, int width, void* d_wf,
+                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, const void* d_iter, void* stream);
 
 /* ---- generic dense layers (exact fp32), SURVEY.md 8 f1 -------------------------- */
 /* What F.linear + SnakeActivation (models/activations.py:29-35) and their autograd do for topologies the fused chain

@@ -29,6 +29,13 @@ class PatchGrad(C.Structure):
                 ("row0", C.c_int64), ("n_p", C.c_int32), ("k", C.c_int32), ("P", C.c_int32), ("comp", C.c_int32)]
 
 
+class StackIter(C.Structure):
+    """npp_stack_iter (include/npp_hip.h): what differs per image and per iteration in a stacked launch."""
+    _fields_ = [("active", C.c_int32), ("k", C.c_int32), ("comp", C.c_int32), ("with_lp", C.c_int32), ("x0", C.c_int32),
+                ("nk", C.c_int32), ("same", C.c_int32), ("pad1", C.c_int32), ("step_size", C.c_float), ("inv_sqrt_bc2", C.c_float),
+                ("pad2", C.c_float), ("pad3", C.c_float)]
+
+
 class LightDesc(C.Structure):
     """npp_light_desc (include/npp_hip.h): where the seven layers of an NPP_Net_light live in its parameter blob."""
     _fields_ = [("w_off", C.c_int64 * 7), ("b_off", C.c_int64 * 7), ("n_out", C.c_int32 * 7), ("n_in", C.c_int32 * 7), ("ld", C.c_int32 * 7)]
@@ -107,6 +114,17 @@ SYMBOLS = {
     "npp_cx_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),
     "npp_lpips_workspace_bytes": (_i64, [_i32]),
     "npp_lpips_layer": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "npp_embed_dev_bytes": (_i32, []),
+    "npp_embed_dev_build": (_i32, [_cfgp, _vp]),
+    "npp_mlp_fwd_stack": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "npp_trunk_patch_in_loss_stack": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float),
+                                             C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, C.POINTER(PixelLossArgs), _i64, _i32, _i32, _vp]),
+    "npp_cx_fwd_bwd_groups": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "npp_mlp_bwd_patch_stack": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp,
+                                       _i64, _i64, _i32, _i32, _vp, _vp]),
+    "npp_mlp_wgrad_stack": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "npp_adam_step_net_pack_stack": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32,
+                                            _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
     "npp_shift_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "npp_rng_create": (_vp, [C.c_uint32]),

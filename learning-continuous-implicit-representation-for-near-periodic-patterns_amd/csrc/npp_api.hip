@@ -133,9 +133,26 @@ struct AdamPackArgs {
   AdamTail tail;
   __bf16 *wf, *wb;
   uint32_t magic[kNumLayers];      // floor(2^32 / n_in) + 1: r / n_in = umulhi(r, magic) for r < 2^20
+  // stacked launch (npp_adam_step_net_pack_stack): blockIdx.y = image; blobs / slabs / packs / latents at + y * stride, the
+  // step's bias corrections from iter[y] (an image that skipped iterations has its own step count and learning rate)
+  const StackIter* iter;
+  int64_t blob_stride, slab_img_stride, wf_stride, wb_stride;      // floats, floats, bf16 elements, bf16 elements
+  int32_t lat_stride, zero_stride;                                 // floats
 };
 
-__global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a, NetDesc d_arg, BwdDesc b_arg) {
+__global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a_in, NetDesc d_arg, BwdDesc b_arg) {
+  AdamPackArgs a = a_in;
+  if (a.iter) {
+    const int y = (int)blockIdx.y;
+    const StackIter it = a.iter[y];
+    if (!it.active) return;
+    a.p += y * a.blob_stride; a.m += y * a.blob_stride; a.v += y * a.blob_stride;
+    a.g += y * a.slab_img_stride;
+    a.wf += y * a.wf_stride; a.wb += y * a.wb_stride;
+    a.step_size = it.step_size; a.inv_sqrt_bc2 = it.inv_sqrt_bc2;
+    a.tail.p += y * a.lat_stride; a.tail.m += y * a.lat_stride; a.tail.v += y * a.lat_stride; a.tail.g += y * a.lat_stride;
+    a.tail.zero += y * a.zero_stride;
+  }
   // the descriptors are indexed with per-lane layer numbers: LDS copies (filled with compile-time indices, so that the
   // by-value kernel arguments never need a scratch copy)
   __shared__ NetDesc d;
@@ -430,6 +447,37 @@ int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gs
   hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)((threads + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream, a, d,
                      make_bwd_desc(K));
   return check_launch("npp_adam_step_net_pack");
+}
+
+int npp_adam_step_net_pack_stack(float* d_p, float* d_m, float* d_v, int64_t blob_stride, const float* d_gslabs, int64_t n,
+                                 int n_slabs, int64_t slab_stride, int64_t slab_img_stride, float* d_lat, float* d_lat_m,
+                                 float* d_lat_v, float* d_dlat, int n_lat, int lat_stride, float* d_zero, int n_zero,
+                                 int zero_stride, float beta1, float beta2, float eps, int M, int K, int width, void* d_wf,
+                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, const void* d_iter, void* stream) {
+  int rc = check_kw(K, width);
+  if (rc) return rc;
+  const NetDesc d = make_desc(K);
+  if (n != d.total_params || !d_p || !d_m || !d_v || !d_gslabs || !d_wf || !d_wb || !d_iter || n_slabs < 1 || n_lat < 0 || n_zero < 0 ||
+      M < 1 || M > NPP_MAX_STACK || (n_lat > 0 && (!d_lat || !d_lat_m || !d_lat_v || !d_dlat)) || (n_zero > 0 && !d_zero) ||
+      slab_stride % 4 || blob_stride % 4 || slab_img_stride % 4 || blob_stride < n || wf_stride_bytes % 16 || wb_stride_bytes % 16 ||
+      (((uintptr_t)d_p | (uintptr_t)d_m | (uintptr_t)d_v | (uintptr_t)d_gslabs) & 15)) {
+    set_error("npp_adam_step_net_pack_stack: bad arguments (n=%lld, expected %lld parameters; 16-byte aligned blobs and strides)",
+              (long long)n, (long long)d.total_params);
+    return NPP_ERR_ARG;
+  }
+  AdamPackArgs a{};
+  a.p = d_p; a.m = d_m; a.v = d_v; a.g = d_gslabs; a.n = n; a.n_slabs = n_slabs; a.slab_stride = slab_stride;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
+  a.wf = (__bf16*)d_wf; a.wb = (__bf16*)d_wb;
+  a.iter = (const StackIter*)d_iter;
+  a.blob_stride = blob_stride; a.slab_img_stride = slab_img_stride; a.wf_stride = wf_stride_bytes / 2; a.wb_stride = wb_stride_bytes / 2;
+  a.lat_stride = lat_stride; a.zero_stride = zero_stride;
+  for (int l = 0; l < kNumLayers; ++l) a.magic[l] = d.present[l] ? (uint32_t)((1ull << 32) / (uint64_t)d.n_in[l]) + 1u : 0u;
+  const int64_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)((threads + 255) / 256 + 1), (unsigned)M), dim3(256), 0, (hipStream_t)stream, a, d,
+                     make_bwd_desc(K));
+  return check_launch("npp_adam_step_net_pack_stack");
 }
 
 int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]) {

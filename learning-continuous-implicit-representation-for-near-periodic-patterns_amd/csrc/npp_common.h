@@ -257,7 +257,56 @@ __device__ __forceinline__ bf16x8 wfrag_read(const char* tile, int off) {
 // ---- shared pieces of the fused MLP kernels (npp_mlp_fwd.hip, npp_mlp_bwd.hip) ------------
 struct Lane {
   int tid, wave, lane, b, h;
+  int n_wg;             // 64-row workgroup tiles of THIS image's batch (gridDim.x of a plain launch): the W-format array geometry
+  int xslot, xcount;    // this workgroup's index among / the number of the image's workgroups on its XCD (weight-pack requests)
 };
+
+// ---- stacked launches (round 4): M independent images of one shape in every launch -----------------------------------------
+// The reference loops its images serially (run_completion.sh:8-14); their fits are independent (own weights, Adam state, RNG),
+// so M of them ride in one launch sequence: every buffer of the single-image path gets a leading image dimension with a fixed
+// stride, and what differs per image and per iteration (patch source, k, Adam step) sits in a small device array the host uploads
+// once per iteration (npp_stack_iter, include/npp_hip.h).  Work items are numbered so that an image's workgroups stay on 8 / M of
+// the 8 XCDs (workgroups go round-robin over the XCDs by linear id -- observed, speed only): each XCD's 4-MiB L2 then keeps ONE
+// image's 3.9-MB weight pack, as in the single-image launch, instead of M of them.
+struct StackIter {                 // == npp_stack_iter
+  int32_t active, k, comp, with_lp;
+  int32_t x0, nk, same, pad1;      // x0: first image of this fit's prediction half in the stacked trunk batch; nk = n_p * k
+  float step_size, inv_sqrt_bc2, pad2, pad3;
+};
+static_assert(sizeof(StackIter) == 48, "npp_stack_iter layout");
+struct Stack {
+  int32_t M;                       // 0: a plain single-image launch (blockIdx.x = work item)
+  int32_t g;                       // XCDs per image (8 / M for M in {1, 2, 4, 8}), 0: images back to back in launch order
+  int32_t n_items;                 // work items per image
+  int32_t pad;
+  const StackIter* iter;           // nullable: every image active
+};
+inline Stack make_stack(int M, int n_items, const void* d_iter) {
+  Stack S{};
+  S.M = M; S.n_items = n_items; S.iter = (const StackIter*)d_iter;
+  S.g = (M == 1 || M == 2 || M == 4 || M == 8) ? 8 / M : 0;
+  return S;
+}
+inline unsigned stack_grid(const Stack& S) {
+  return S.g ? 8u * (unsigned)((S.n_items + S.g - 1) / S.g) : (unsigned)S.M * (unsigned)S.n_items;
+}
+// (image, item) of this workgroup; false: surplus workgroup of the rounded-up grid or an image that sits the iteration out
+__device__ __forceinline__ bool stack_decode(const Stack& S, int& img, int& item, int& xslot, int& xcount) {
+  const int b = (int)blockIdx.x;
+  if (S.M == 0) { img = 0; item = b; xslot = b >> 3; xcount = ((int)gridDim.x + 7) >> 3; return true; }
+  if (S.g) {
+    const int xcd = b & 7, slot = b >> 3;
+    img = xcd / S.g;
+    item = slot * S.g + xcd % S.g;
+    xslot = slot; xcount = (S.n_items + S.g - 1) / S.g;
+  } else {
+    img = b / S.n_items;
+    item = b - img * S.n_items;
+    xslot = item >> 3; xcount = (S.n_items + 7) >> 3;
+  }
+  if (item >= S.n_items) return false;
+  return S.iter == nullptr || S.iter[img].active != 0;
+}
 __device__ __forceinline__ bf16x8 lds_frag(const char* region, int ks, int bt, int lane) {
   return *(const bf16x8*)(region + ((ks * kNB + bt) * 64 + lane) * 16);
 }

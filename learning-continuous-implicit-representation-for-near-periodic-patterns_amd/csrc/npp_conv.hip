@@ -380,6 +380,89 @@ __global__ void trunk_patch_in_kernel(const float* __restrict__ pred, const floa
   out[nposp + kConvGuard + p] = z;
 }
 
+// ---- the same for M stacked images (npp_common.h "stacked launches"): the trunk batch is [x_0 .. x_{M-1} | y_0 .. y_{M-1}] (image
+// m's prediction half at batch index iter[m].x0, its real half at X + x0, X = sum of the nk), so that the data-gradient pass
+// runs on the leading X images; the flat tensor has the FIXED geometry of the largest batch (2 M n_p kmax images), of which
+// 2 X are written and run.  Crops per image: rgb [fake (n_p) | real (n_p kmax)], masks likewise; 'same' iterations take the
+// fake crops as the real ones (sampler.py:338).  The first M * nb_loss blocks are the images' adaptive pixel losses.
+struct PatchInStack {
+  const float* pred;        // (M, Bp, 3)
+  const float* crops;       // (M, n_p + n_p kmax, 3, P, P)
+  const float* cmasks;      // (M, n_p + n_p kmax, P, P)
+  int64_t Bp, row0, crop_stride, cmask_stride, xy_stride;
+  int32_t M, n_p, P, X;
+  float s0, s1, s2, b0, b1, b2;
+  f16x8* out;
+  int64_t nposp, npos_round;
+  float* xy;                // (M, 2 n_p kmax, 3, P, P) fp32 [x | y] of the images whose iter.with_lp is set (nullable)
+  float* zero;              // M patch-loss accumulators
+  const StackIter* iter;
+  PixelLossArgs pl;         // image 0; the others at + m * the strides below
+  int64_t gt_stride;
+  int32_t lat_stride, loss_stride, nb_loss, pad;
+};
+__global__ void trunk_patch_in_stack_kernel(PatchInStack a) {
+  if ((int)blockIdx.x < a.M * a.nb_loss) {
+    const int m = (int)blockIdx.x / a.nb_loss, b = (int)blockIdx.x - m * a.nb_loss;
+    if (!a.iter[m].active) return;
+    PixelLossArgs pl = a.pl;
+    pl.pred += (int64_t)m * a.Bp * 3; pl.dpred += (int64_t)m * a.Bp * 3; pl.gt += (int64_t)m * a.gt_stride;
+    pl.latents += m * a.lat_stride; pl.dlatent += m * a.lat_stride; pl.loss_out += m * a.loss_stride;
+    pixel_loss_body(pl, b, a.nb_loss);
+    return;
+  }
+  const int64_t p = (int64_t)((int)blockIdx.x - a.M * a.nb_loss) * blockDim.x + threadIdx.x;
+  if (p < a.M) a.zero[p] = 0.0f;
+  if (p >= a.npos_round) return;
+  const int P = a.P, Wp = P + 2, S = (P + 2) * Wp;
+  const int nl = (int)(p / S), r = (int)(p - (int64_t)nl * S), y = r / Wp, x = r - y * Wp;
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+  const f16x8 z = o;
+  if (nl < 2 * a.X && y >= 1 && y <= P && x >= 1 && x <= P) {
+    const bool real_half = nl >= a.X;
+    const int nb = real_half ? nl - a.X : nl;
+    int m = 0;
+    for (int j = 1; j < a.M; ++j)
+      if (a.iter[j].nk > 0 && nb >= a.iter[j].x0) m = j;          // (x0 ascending; images sitting out have nk = 0)
+    const StackIter it = a.iter[m];
+    const int pk = nb - it.x0;                                     // patch (p, kk) of image m, < nk
+    const int64_t pp = (int64_t)P * P, q = (int64_t)(y - 1) * P + (x - 1);
+    const float* fake = a.crops + (int64_t)m * a.crop_stride;
+    const float* fmask = a.cmasks + (int64_t)m * a.cmask_stride;
+    const float* real = it.same ? fake : fake + (int64_t)a.n_p * 3 * pp;
+    const float* rmask = it.same ? fmask : fmask + (int64_t)a.n_p * pp;
+    const float rm = rmask[(int64_t)pk * pp + q];
+    float v[3];
+    if (!real_half) {
+      const int pi = pk / it.k;
+      const float fm = it.comp ? fmask[(int64_t)pi * pp + q] : 0.0f;
+      const float* pr = a.pred + ((int64_t)m * a.Bp + a.row0) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float pv = pr[((int64_t)pi * pp + q) * 3 + c];
+        const float u = it.comp ? fake[((int64_t)pi * 3 + c) * pp + q] * fm + pv * (1.0f - fm) : pv;   // train.py:230-231
+        v[c] = u * rm;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = real[((int64_t)pk * 3 + c) * pp + q] * rm;
+    }
+    if (a.xy && it.with_lp) {
+      float* xy = a.xy + (int64_t)m * a.xy_stride;
+      const int n = real_half ? pk + it.nk : pk;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xy[((int64_t)n * 3 + c) * pp + q] = v[c];
+    }
+    o[0] = (_Float16)fmaf(v[0], a.s0, a.b0);
+    o[1] = (_Float16)fmaf(v[1], a.s1, a.b1);
+    o[2] = (_Float16)fmaf(v[2], a.s2, a.b2);
+  }
+  a.out[kConvGuard + p] = o;
+  a.out[a.nposp + kConvGuard + p] = z;
+}
+
 __device__ __forceinline__ void unit_decode(int64_t p, int H, int W, int& n, int& y, int& x) {
   const int Wp = W + 2, S = (H + 2) * Wp;
   n = (int)(p / S);
@@ -632,6 +715,43 @@ extern "C" int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_
                          loss->weight, loss->loss, loss->dpred, loss->dlatent};
   return patch_in_launch(d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale, shift, d_x0, d_xy, d_zero, n_zero,
                          which, &pl, stream, "npp_trunk_patch_in_loss");
+}
+
+// Stacked form of npp_trunk_patch_in_loss (M images; see trunk_patch_in_stack_kernel).  N_total = images of the flat tensor's
+// geometry (2 M n_p kmax), X = sum of the images' n_p k this iteration (host-side sum of the npp_stack_iter entries).
+extern "C" int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, int64_t row0, const float* d_crops, int64_t crop_stride,
+                                             const float* d_cmasks, int64_t cmask_stride, int M, int n_p, int P, int X, int N_total,
+                                             const float scale[3], const float shift[3], void* d_x0, float* d_xy, int64_t xy_stride,
+                                             float* d_zero, const void* d_iter, const npp_pixel_loss_args* loss, int64_t gt_stride,
+                                             int lat_stride, int loss_stride, void* stream) {
+  const char* who = "npp_trunk_patch_in_loss_stack";
+  if (M < 1 || M > NPP_MAX_STACK || n_p < 1 || X < 0 || 2 * X > N_total || !d_pred || !d_crops || !d_cmasks || !d_x0 || !d_zero ||
+      !d_iter || !scale || !shift || !loss || row0 < 0 || row0 + (int64_t)n_p * P * P > Bp) {
+    set_error("%s: bad arguments (M=%d n_p=%d X=%d N_total=%d)", who, M, n_p, X, N_total);
+    return NPP_ERR_ARG;
+  }
+  int rc = conv_geom_check(N_total, P, P, who);
+  if (rc) return rc;
+  if (loss->N <= 0 || !loss->pred || !loss->gt || !loss->latents || !loss->spline || !loss->loss || !loss->dpred || !loss->dlatent ||
+      loss->n_knots < 2) {
+    set_error("%s: bad pixel-loss arguments (N=%lld)", who, (long long)loss->N);
+    return NPP_ERR_ARG;
+  }
+  PatchInStack a{};
+  a.pred = d_pred; a.crops = d_crops; a.cmasks = d_cmasks; a.Bp = Bp; a.row0 = row0; a.crop_stride = crop_stride;
+  a.cmask_stride = cmask_stride; a.xy_stride = xy_stride; a.M = M; a.n_p = n_p; a.P = P; a.X = X;
+  a.s0 = scale[0]; a.s1 = scale[1]; a.s2 = scale[2]; a.b0 = shift[0]; a.b1 = shift[1]; a.b2 = shift[2];
+  a.out = (f16x8*)d_x0; a.nposp = conv_nposp(N_total, P, P);
+  a.npos_round = X > 0 ? conv_npos_round(2 * X, P, P) : 0;
+  a.xy = d_xy; a.zero = d_zero; a.iter = (const StackIter*)d_iter;
+  a.pl = PixelLossArgs{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
+                       loss->weight, loss->loss, loss->dpred, loss->dlatent};
+  a.gt_stride = gt_stride; a.lat_stride = lat_stride; a.loss_stride = loss_stride;
+  a.nb_loss = pixel_loss_blocks(loss->N);
+  const int64_t nblk = (a.npos_round > M ? a.npos_round : M) ;
+  hipLaunchKernelGGL(trunk_patch_in_stack_kernel, dim3((unsigned)((nblk + 255) / 256 + (int64_t)M * a.nb_loss)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return check_launch(who);
 }
 
 template <int CT, int PT, int S>

@@ -42,35 +42,52 @@ __global__ void patch_gather_kernel(const float* __restrict__ img, const float* 
 
 // ---------------------------------------------------------------- K6 contextual loss
 struct CxWs {           // workspace carve (floats unless noted)
-  float* mu;            // [C]
+  float* mu;            // [groups][mu_stride]: mean over the GROUP's y samples (one group = one image of a stacked launch)
   float* ssx;           // [N*hw]  sum_c (x - mu)^2   (inverse norm = 1 / max(sqrt(.), 1e-12))
   float* ssy;           // [N*hw]
   unsigned* dmin;       // [N*hw]  row min of D as float bits (D >= 0: unsigned order == float order)
   float* s;             // [N*hw]  row sum of w
   unsigned* cmax;       // [N*hw]  column max of cx as float bits
-  float* dot;           // [N*hw]  xh . dxh per position (normalisation backward)
+  float* dot;           // [dot_slots][N*hw]  xh . dxh per position, one partial per channel tile (summed in fixed order)
   float* g;             // [N]     dL/dcxn / J
   float* inx;           // [N*hw]  1 / max(sqrt(ssx), 1e-12)  (written by cx_loss_kernel, read by the backward kernels)
   float* iny;           // [N*hw]
   float* D;             // [N*hw*hw]
   float* cx;            // [N*hw*hw]  cx, then d raw
+  // sample groups (npp_cx_fwd_bwd_groups): group m = the nk samples from batch index iter[m].x0 on; iter == null: one group of N
+  const StackIter* iter;
+  int32_t M, mu_stride, N, dot_slots;
 };
-
-__host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
-  return (int64_t)C + 8LL * N * hw + N + 2LL * N * hw * hw + 64;
+// group of sample n and the group's sample count
+__device__ __forceinline__ int cx_group(const CxWs& w, int n, int& ng) {
+  if (!w.iter) { ng = w.N; return 0; }
+  int m = 0;
+  for (int j = 1; j < w.M; ++j)
+    if (w.iter[j].nk > 0 && n >= w.iter[j].x0) m = j;
+  ng = w.iter[m].nk;
+  return m;
+}
+__device__ __forceinline__ const float* cx_mu(const CxWs& w, int n) {
+  int ng;
+  return w.mu + (int64_t)cx_group(w, n, ng) * w.mu_stride;
 }
 
-__host__ inline CxWs carve(float* base, int N, int C, int hw) {
+__host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
+  return (int64_t)NPP_MAX_STACK * (C + 16) + (7LL + C / 32) * N * hw + N + 2LL * N * hw * hw + 64;
+}
+
+__host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter = nullptr, int M = 0) {
   CxWs w;
   float* p = base;
-  w.mu = p; p += (C + 15) / 16 * 16;
+  w.iter = (const StackIter*)iter; w.M = M; w.N = N; w.mu_stride = (C + 15) / 16 * 16; w.dot_slots = C / 32;
+  w.mu = p; p += (int64_t)(M > 0 ? M : 1) * w.mu_stride;
   const int64_t nh = (int64_t)N * hw;
   w.ssx = p; p += nh;
   w.ssy = p; p += nh;
   w.dmin = (unsigned*)p; p += nh;
   w.s = p; p += nh;
   w.cmax = (unsigned*)p; p += nh;
-  w.dot = p; p += nh;
+  w.dot = p; p += nh * w.dot_slots;
   w.g = p; p += (N + 15) / 16 * 16;
   w.inx = p; p += nh;
   w.iny = p; p += nh;
@@ -96,23 +113,25 @@ __device__ __forceinline__ int xcd_block(int nb) {
 // also clear the per-position accumulators of this call.
 __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw, CxWs w) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, grp = blockIdx.y;
+  const int n0 = w.iter ? w.iter[grp].x0 : 0, ng = w.iter ? w.iter[grp].nk : N;
   float acc = 0.0f;
-  for (int n = 0; n < N; ++n)
+  for (int n = n0; n < n0 + ng; ++n)
     for (int p = threadIdx.x; p < hw; p += blockDim.x) acc += y[((int64_t)n * C + c) * hw + p];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) w.mu[c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)N * hw);
+  if (threadIdx.x == 0 && ng > 0) w.mu[(int64_t)grp * w.mu_stride + c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)ng * hw);
+  if (grp) return;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)N * hw; t += (int64_t)gridDim.x * blockDim.x) {
-    w.ssx[t] = 0.0f; w.ssy[t] = 0.0f; w.dot[t] = 0.0f;
     w.dmin[t] = 0x7f800000u;   // +inf
     w.cmax[t] = 0u;
   }
 }
 
-// sum over channels of (x - mu)^2, (y - mu)^2 per position: block = 64 positions x 4 channel
-// lanes, grid.y = channel groups of 64; partial sums meet in two float atomics per position.
+// sum over channels of (x - mu)^2, (y - mu)^2 per position: block = 64 positions x 4 channel lanes walking ALL channels
+// (round 4: the partial sums of four channel-group blocks used to meet in float atomics, whose order made the whole
+// iteration irreproducible to the last bit; one block per position tile sums in a fixed order).
 __global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
                                                        int C, int hw, CxWs w) {
   __shared__ float red[2][4][64];
@@ -121,10 +140,10 @@ __global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__
   const bool live = t < (int64_t)N * hw;
   const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
   float sx = 0.0f, sy = 0.0f;
-  const int c0 = blockIdx.y * 64;
+  const float* mu = cx_mu(w, n);
   if (live)
-    for (int c = c0 + cl; c < min(C, c0 + 64); c += 4) {
-      const float m = w.mu[c];
+    for (int c = cl; c < C; c += 4) {
+      const float m = mu[c];
       const float a = x[((int64_t)n * C + c) * hw + p] - m, b = y[((int64_t)n * C + c) * hw + p] - m;
       sx = fmaf(a, a, sx);
       sy = fmaf(b, b, sy);
@@ -133,8 +152,8 @@ __global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__
   red[1][cl][pl] = sy;
   __syncthreads();
   if (cl == 0 && live) {
-    atomicAdd(&w.ssx[t], red[0][0][pl] + red[0][1][pl] + red[0][2][pl] + red[0][3][pl]);
-    atomicAdd(&w.ssy[t], red[1][0][pl] + red[1][1][pl] + red[1][2][pl] + red[1][3][pl]);
+    w.ssx[t] = red[0][0][pl] + red[0][1][pl] + red[0][2][pl] + red[0][3][pl];
+    w.ssy[t] = red[1][0][pl] + red[1][1][pl] + red[1][2][pl] + red[1][3][pl];
   }
 }
 
@@ -158,13 +177,14 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   const float* xn = x + (int64_t)n * C * hw;
   const float* yn = y + (int64_t)n * C * hw;
   const bool vec = (hw & 3) == 0;
+  const float* mu = cx_mu(w, n);
   float4 ra[2], rb[2];
   auto gload = [&](int c0) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
       const int c = c0 + row;
-      const float m = c < C ? w.mu[c] : 0.0f;
+      const float m = c < C ? mu[c] : 0.0f;
       float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
       if (c < C) {
         if (vec && i0 + col + 3 < hw) { const float4 q = *(const float4*)(xn + (int64_t)c * hw + i0 + col); va[0] = q.x; va[1] = q.y; va[2] = q.z; va[3] = q.w; }
@@ -324,34 +344,42 @@ __global__ __launch_bounds__(256) void cx_rows_fwd_big_kernel(int N, int hw, flo
   }
 }
 
-// per sample: cxn = mean_j cmax ; loss += scale * (-log(cxn [* weight] + 1e-5)) [/ N] ; g = dL/dcxn / J
+// per group: for each of its samples cxn = mean_j cmax, l_n = -log(cxn [* weight] + 1e-5) [/ N_group], g = dL/dcxn / J; the group's
+// loss is summed over its samples in index order and added to loss[group * loss_stride] ONCE (round 4: one atomic per sample from
+// N blocks summed in arrival order).  Also the inverse norms of every position, once instead of once per use.
 __global__ void cx_loss_kernel(int N, int hw, const float* __restrict__ weight, float scale, float* __restrict__ loss,
-                               CxWs w) {
+                               int loss_stride, CxWs w) {
   __shared__ float red[4];
-  const int n = blockIdx.x;
-  float acc = 0.0f;
-  for (int j = threadIdx.x; j < hw; j += blockDim.x) {
-    acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
-    w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);      // once per position instead of once per use
-    w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float cxn = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
-    float l, dcxn;
-    if (weight) {                       // functional.py:55-57: sum(-log(cx * w + 1e-5))
-      const float wt = weight[n];
-      l = -logf(cxn * wt + 1e-5f);
-      dcxn = -wt / (cxn * wt + 1e-5f);
-    } else {                            // mean over samples
-      l = -logf(cxn + 1e-5f) / (float)N;
-      dcxn = -1.0f / ((float)N * (cxn + 1e-5f));
+  const int grp = blockIdx.x;
+  const int n0 = w.iter ? w.iter[grp].x0 : 0, ng = w.iter ? w.iter[grp].nk : N;
+  float total = 0.0f;
+  for (int n = n0; n < n0 + ng; ++n) {
+    float acc = 0.0f;
+    for (int j = threadIdx.x; j < hw; j += blockDim.x) {
+      acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
+      w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);
+      w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
     }
-    atomicAdd(loss, scale * l);
-    w.g[n] = scale * dcxn / (float)hw;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __syncthreads();                                    // (red is re-used from sample to sample)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float cxn = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
+      float l, dcxn;
+      if (weight) {                       // functional.py:55-57: sum(-log(cx * w + 1e-5))
+        const float wt = weight[n];
+        l = -logf(cxn * wt + 1e-5f);
+        dcxn = -wt / (cxn * wt + 1e-5f);
+      } else {                            // mean over samples
+        l = -logf(cxn + 1e-5f) / (float)ng;
+        dcxn = -1.0f / ((float)ng * (cxn + 1e-5f));
+      }
+      total += scale * l;
+      w.g[n] = scale * dcxn / (float)hw;
+    }
   }
+  if (threadIdx.x == 0 && ng > 0) atomicAdd(loss + (int64_t)grp * loss_stride, total);
 }
 
 // one wave per row: cx row -> d raw row (in place).
@@ -412,6 +440,7 @@ __global__ __launch_bounds__(256) void cx_dx_kernel(const float* __restrict__ x,
   const int wc = wave >> 1, wi = wave & 1, l31 = lane & 31, kh = lane >> 5;
   const bool vec = (hw & 3) == 0;
   const float* iny_ss = w.ssy + (int64_t)n * hw;
+  const float* mup = cx_mu(w, n);
   float4 ra[2], rb[2];
   auto gload = [&](int j0) {
 #pragma unroll
@@ -421,7 +450,7 @@ __global__ __launch_bounds__(256) void cx_dx_kernel(const float* __restrict__ x,
       float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
       const int c = c0 + row, i = i0 + row;
       if (c < C) {
-        const float m = w.mu[c];
+        const float m = mup[c];
         const float* yr = y + ((int64_t)n * C + c) * hw;
         if (vec && j + 3 < hw) { const float4 q = *(const float4*)(yr + j); va[0] = q.x - m; va[1] = q.y - m; va[2] = q.z - m; va[3] = q.w - m; }
         else for (int e = 0; e < 4; ++e) if (j + e < hw) va[e] = yr[j + e] - m;
@@ -466,31 +495,35 @@ __global__ __launch_bounds__(256) void cx_dx_kernel(const float* __restrict__ x,
   }
   // accumulator: column = position (lane & 31), rows = channels
   const int i = i0 + wi * 32 + l31;
+  float part = 0.0f;
   if (i < hw) {
     const float inx = inv_norm(w.ssx[(int64_t)n * hw + i]);
-    float part = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = c0 + wc * 32 + acc_row(r, kh);
       if (c < C) {
         const int64_t o = ((int64_t)n * C + c) * hw + i;
         dxh[o] = acc[r];
-        part = fmaf((x[o] - w.mu[c]) * inx, acc[r], part);
+        part = fmaf((x[o] - mup[c]) * inx, acc[r], part);
       }
     }
-    atomicAdd(&w.dot[(int64_t)n * hw + i], part);
   }
+  part += __shfl_xor(part, 32, 64);
+  const int slot = c0 / 32 + wc;                       // one partial per 32-channel tile, summed in order by cx_dx_finish
+  if (kh == 0 && i < hw && slot < w.dot_slots) w.dot[(int64_t)slot * N * hw + (int64_t)n * hw + i] = part;
 }
 
 // dx = (dxh - xh (xh . dxh)) * inx, xh = (x - mu) inx ; elementwise, in place on dxh
-__global__ void cx_dx_finish_kernel(const float* __restrict__ x, int N, int C, int hw, CxWs w, float* __restrict__ dx) {
+__global__ void cx_dx_finish_kernel(const float* __restrict__ x, int N, int C, int hw, CxWs w, float* __restrict__ dx, int n_dot) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)N * C * hw) return;
   const int p = (int)(t % hw);
   const int64_t nc = t / hw;
   const int c = (int)(nc % C), n = (int)(nc / C);
   const float inx = inv_norm(w.ssx[(int64_t)n * hw + p]);
-  dx[t] = (dx[t] - (x[t] - w.mu[c]) * inx * w.dot[(int64_t)n * hw + p]) * inx;
+  float dot = 0.0f;
+  for (int q = 0; q < n_dot; ++q) dot += w.dot[(int64_t)q * N * hw + (int64_t)n * hw + p];     // fixed order
+  dx[t] = (dx[t] - (x[t] - cx_mu(w, n)[c]) * inx * dot) * inx;
 }
 
 // ---- second-generation backward contraction and row pass (hw % 32 == 0) ---------------------------------------
@@ -519,7 +552,8 @@ __global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ 
   const int ti = rem / cg, tc = (rem - ti * cg) * 4 + wave;
   if (tc >= ct) return;
   const int i0 = ti * 32, c0 = tc * 32;
-  const float mu = w.mu[c0 + l31];
+  const float* mup = cx_mu(w, n);
+  const float mu = mup[c0 + l31];
   const float4* yr = (const float4*)(y + ((int64_t)n * C + c0 + l31) * hw) + kh;       // float4 index 2t + kh
   const float4* dr = (const float4*)(w.cx + ((int64_t)n * hw + i0 + l31) * hw) + kh;
   const float4* sr = (const float4*)(w.iny + (int64_t)n * hw) + kh;
@@ -555,10 +589,10 @@ __global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ 
     const int c = c0 + acc_row(r, kh);
     const int64_t o = ((int64_t)n * C + c) * hw + i;
     dxh[o] = acc[r];
-    part = fmaf((x[o] - w.mu[c]) * inx, acc[r], part);
+    part = fmaf((x[o] - mup[c]) * inx, acc[r], part);
   }
   part += __shfl_xor(part, 32, 64);
-  if (kh == 0) atomicAdd(&w.dot[(int64_t)n * hw + i], part);
+  if (kh == 0) w.dot[(int64_t)tc * N * hw + (int64_t)n * hw + i] = part;        // one partial per channel tile, summed by cx_dx_finish
 }
 
 // Row pass, block-parallel: 16 waves x 1 row = 16 consecutive rows of one sample per block (all rows of the matrix are
@@ -646,22 +680,22 @@ extern "C" int64_t npp_cx_workspace_bytes(int N, int C, int hw) {
   return 4 * cx_ws_floats(N, C, hw);
 }
 
-extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
-                              const float* d_weight, float scale, float* d_loss, float* d_dfx, void* d_workspace,
-                              int64_t workspace_bytes, void* stream) {
+static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, const float* d_weight,
+                     float scale, float* d_loss, int loss_stride, float* d_dfx, void* d_workspace, int64_t workspace_bytes,
+                     const void* d_iter, int M, void* stream, const char* who) {
   if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f) ||
-      (int64_t)N * hw * hw > 0x7fffffffLL * 8) {
-    set_error("npp_cx_fwd_bwd: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
+      (int64_t)N * hw * hw > 0x7fffffffLL * 8 || M < 0 || M > NPP_MAX_STACK || (M > 0 && !d_iter)) {
+    set_error("%s: bad arguments (N=%d C=%d hw=%d M=%d)", who, N, C, hw, M);
     return NPP_ERR_ARG;
   }
-  if (workspace_bytes < 4 * cx_ws_floats(N, C, hw)) { set_error("npp_cx_fwd_bwd: workspace too small"); return NPP_ERR_ARG; }
+  if (workspace_bytes < 4 * cx_ws_floats(N, C, hw)) { set_error("%s: workspace too small", who); return NPP_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  const CxWs w = carve((float*)d_workspace, N, C, hw);
+  const CxWs w = carve((float*)d_workspace, N, C, hw, d_iter, M);
+  const int groups = M > 0 ? M : 1;
   const int64_t nh = (int64_t)N * hw;
   const float inv_h = 1.0f / band_width;
-  hipLaunchKernelGGL(cx_mean_kernel, dim3(C), dim3(256), 0, s, d_fy, N, C, hw, w);
-  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N,
-                     C, hw, w);
+  hipLaunchKernelGGL(cx_mean_kernel, dim3(C, groups), dim3(256), 0, s, d_fy, N, C, hw, w);
+  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
   const int tiles = (hw + 63) / 64;
   const bool big = hw > 64 * kCxMaxCols;     // whole-image crops: the generic kernels, column-chunked row pass
   const bool fast = !big && (hw % 32) == 0;  // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
@@ -671,7 +705,7 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
     static SmemOnce once;
     const size_t smem = (size_t)kCxRowWaves * hw * sizeof(float);
     if (smem > 48 * 1024 && !smem_attr(once, (const void*)cx_rows_fwd32_kernel, kCxRowWaves * 64 * kCxMaxCols * 4)) {
-      set_error("npp_cx_fwd_bwd: smem attribute"); return NPP_ERR_LAUNCH;
+      set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(cx_rows_fwd32_kernel, dim3((unsigned)((int64_t)N * ((hw + kCxRowWaves - 1) / kCxRowWaves))), dim3(64 * kCxRowWaves), smem, s, N,
                        hw, inv_h, w);
@@ -681,7 +715,7 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
     if (big) hipLaunchKernelGGL(cx_rows_fwd_big_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     else hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
   }
-  hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, w);
+  hipLaunchKernelGGL(cx_loss_kernel, dim3(groups), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, loss_stride, w);
   if (d_dfx) {
     hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     const int ctiles = (C + 63) / 64;
@@ -693,7 +727,25 @@ extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C
       hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,
                          d_dfx);
     const int64_t ne = nh * C;
-    hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx);
+    hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx, C / 32);
   }
-  return check_launch("npp_cx_fwd_bwd");
+  return check_launch(who);
+}
+
+extern "C" int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width,
+                              const float* d_weight, float scale, float* d_loss, float* d_dfx, void* d_workspace,
+                              int64_t workspace_bytes, void* stream) {
+  return cx_launch(d_fx, d_fy, N, C, hw, band_width, d_weight, scale, d_loss, 0, d_dfx, d_workspace, workspace_bytes, nullptr, 0,
+                   stream, "npp_cx_fwd_bwd");
+}
+
+// The same over sample GROUPS (stacked launches: one group per image, M groups): group m = the iter[m].nk samples from index
+// iter[m].x0 on, in BOTH tensors (d_fy = the real halves in the same order); the mean over y, the 1 / N of the loss and the
+// loss accumulator (d_loss[m * loss_stride]) are per group; samples of different groups never meet.
+extern "C" int npp_cx_fwd_bwd_groups(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, float scale,
+                                     float* d_loss, int loss_stride, float* d_dfx, const void* d_iter, int M, void* d_workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  if (M < 1) { set_error("npp_cx_fwd_bwd_groups: M=%d", M); return NPP_ERR_ARG; }
+  return cx_launch(d_fx, d_fy, N, C, hw, band_width, nullptr, scale, d_loss, loss_stride, d_dfx, d_workspace, workspace_bytes, d_iter,
+                   M, stream, "npp_cx_fwd_bwd_groups");
 }

@@ -39,6 +39,11 @@ struct BwdArgs {
   float* dpred_out;
   int64_t pg_row0;
   int32_t pg_np, pg_k, pg_P, pg_comp;
+  // stacked launch (npp_mlp_bwd_patch_stack): image m at + m * stride; k / comp / the position of its patches in the stacked
+  // trunk batch come from S.iter[m]; pg_dxb (LPIPS branch) is per image (2 n_p kmax, 3, P, P) and read when iter[m].with_lp
+  Stack S;
+  int64_t wb_stride16, params_stride, act_stride, dz_stride;
+  int64_t crop_stride, cmask_stride, dxb_stride;   // floats per image: rgb crops [fake | real], mask crops, LPIPS gradient
 };
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
@@ -93,8 +98,30 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDesc d, BwdDesc bd) {
+__global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, NetDesc d, BwdDesc bd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  BwdArgs A = A_in;
+  int img_, wg, xslot_, xcount_;
+  if (!stack_decode(A.S, img_, wg, xslot_, xcount_)) return;
+  const int n_wg_ = A.S.M ? A.S.n_items : (int)gridDim.x;
+  if (A.S.M) {
+    const StackIter it = A.S.iter[img_];
+    A.dpred += (int64_t)img_ * A.Bp * 3;
+    A.pred += (int64_t)img_ * A.Bp * 3;
+    A.wb += (int64_t)img_ * A.wb_stride16;
+    A.params += (int64_t)img_ * A.params_stride;
+    A.actF += (int64_t)img_ * A.act_stride;
+    A.dzF += (int64_t)img_ * A.dz_stride;
+    if (A.pg_dxa) {
+      const int64_t pp = (int64_t)A.pg_P * A.pg_P;
+      A.dpred_out += (int64_t)img_ * A.Bp * 3;
+      A.pg_dxa += (int64_t)it.x0 * 3 * pp;                              // this image's prediction half in the stacked batch
+      A.pg_dxb = it.with_lp ? A.pg_dxb + (int64_t)img_ * A.dxb_stride : nullptr;
+      A.pg_fmask += (int64_t)img_ * A.cmask_stride;                     // mask crops: [fake (n_p) | real (n_p kmax)]
+      A.pg_rmask = it.same ? A.pg_fmask : A.pg_fmask + (int64_t)A.pg_np * pp;
+      A.pg_k = it.k; A.pg_comp = it.comp;
+    }
+  }
   char* R0 = smem;
   char* R1 = smem + kRegionBytesB;
   float* sDraw = (float*)(smem + 2 * kRegionBytesB);   // [64 rows][3]
@@ -105,12 +132,12 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   L.lane = threadIdx.x & 63;
   L.b = L.lane & 31;
   L.h = L.lane >> 5;
-  const int wg = blockIdx.x;
+  L.n_wg = n_wg_; L.xslot = xslot_; L.xcount = xcount_;
   const int64_t row0 = (int64_t)wg * kRowTile, Bp = A.Bp;
   const float* P = A.params;
   const int kt0 = 2 * L.wave;
-  auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, gridDim.x); };   // z of layer idx
-  auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, gridDim.x); };
+  auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, L.n_wg); };   // z of layer idx
+  auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, L.n_wg); };
 
   // Everything the prologue needs from memory is requested first (weight ring of the first dgrad, the rgb weights, the cold
   // z fragments of P), so that ONE latency is paid instead of one per dependent section.
@@ -119,8 +146,8 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   uint32_t pfv[2];
   {
     const int64_t lines = ((int64_t)d.wb_total16 * 16 + 127) / 128;
-    const int64_t per_xcd_threads = (int64_t)((gridDim.x + 7) >> 3) * kThreadsB;
-    int64_t line = (int64_t)(blockIdx.x >> 3) * kThreadsB + threadIdx.x;
+    const int64_t per_xcd_threads = (int64_t)L.xcount * kThreadsB;
+    int64_t line = (int64_t)L.xslot * kThreadsB + threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 2; ++q, line += per_xcd_threads)
       pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)A.wb + line * 128) : 0u;
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
   wring_fill<2, kNT>(ring, wbl(BP1), kt0, L.lane);
   f16x8 zp_pre[kNB][2];
   {
-    const char* zp = A.actF + wfmt_array_base(kActKsAP, gridDim.x);
+    const char* zp = A.actF + wfmt_array_base(kActKsAP, L.n_wg);
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       f[1] = (__bf16)sDraw[row * 3 + 1];
       f[2] = (__bf16)sDraw[row * 3 + 2];
     }
-    if (q1 < 2) dz_store(A.dzF + wfmt_array_base(kDzKsRgb, gridDim.x) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
+    if (q1 < 2) dz_store(A.dzF + wfmt_array_base(kDzKsRgb, L.n_wg) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
   }
 
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
@@ -208,7 +235,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
         lds_store_frag(R0, 2 * L.wave + s, bt, L.lane, f);
-        dz_store(A.dzF + wfmt_array_base(kDzKsP, gridDim.x) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
+        dz_store(A.dzF + wfmt_array_base(kDzKsP, L.n_wg) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
       }
     }
   }
@@ -259,6 +286,8 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A, NetDes
 
 using namespace npp;
 
+static int bwd_go(const BwdArgs& A, int K, void* stream);
+
 static int bwd_launch(const float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
                       const float* d_params, const void* d_actT, void* d_dzT, int out_act, void* stream,
                       const npp_patch_grad* pg = nullptr) {
@@ -278,9 +307,13 @@ static int bwd_launch(const float* d_dpred, const float* d_pred, int64_t Bp, int
     A.dpred_out = const_cast<float*>(d_dpred);
     A.pg_row0 = pg->row0; A.pg_np = pg->n_p; A.pg_k = pg->k; A.pg_P = pg->P; A.pg_comp = pg->comp;
   }
+  return bwd_go(A, K, stream);
+}
+
+static int bwd_go(const BwdArgs& A, int K, void* stream) {
   const NetDesc d = make_desc(K);
   const BwdDesc bd = make_bwd_desc(K);
-  const dim3 grid((unsigned)(Bp / kRowTile)), block(kThreadsB);
+  const dim3 grid(A.S.M ? stack_grid(A.S) : (unsigned)(A.Bp / kRowTile)), block(kThreadsB);
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH_B(M)                                                                            \
   do {                                                                                             \
@@ -309,4 +342,27 @@ extern "C" int npp_mlp_bwd_patch(float* d_dpred, const float* d_pred, int64_t Bp
                                  const float* d_params, const void* d_actT, void* d_dzT, const npp_patch_grad* pg, void* stream) {
   if (!pg) { set_error("npp_mlp_bwd_patch: null patch-gradient description"); return NPP_ERR_ARG; }
   return bwd_launch(d_dpred, d_pred, Bp, K, width, d_wb, d_params, d_actT, d_dzT, 1, stream, pg);
+}
+
+// stacked form: M images per launch (npp_common.h "stacked launches"); always the patch form (npp_mlp_bwd_patch)
+extern "C" int npp_mlp_bwd_patch_stack(float* d_dpred, const float* d_pred, int64_t Bp, int M, int K, int width, const void* d_wb,
+                                       int64_t wb_stride_bytes, const float* d_params, int64_t params_stride, const void* d_actT,
+                                       int64_t act_stride_bytes, void* d_dzT, int64_t dz_stride_bytes, const float* d_dx_a,
+                                       const float* d_dx_b, int64_t dxb_stride, const float* d_cmask, int64_t cmask_stride,
+                                       int64_t row0, int n_p, int P, const void* d_iter, void* stream) {
+  if (K < 1 || K > NPP_MAX_K || M < 1 || M > NPP_MAX_STACK) { set_error("npp_mlp_bwd_patch_stack: K=%d M=%d", K, M); return NPP_ERR_ARG; }
+  if (width != NPP_WIDTH) { set_error("npp_mlp_bwd_patch_stack: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
+  if (Bp <= 0 || Bp % kRowTile || !d_dpred || !d_pred || !d_wb || !d_params || !d_actT || !d_dzT || !d_dx_a || !d_cmask || !d_iter ||
+      n_p < 1 || P < 1 || row0 < 0 || row0 + (int64_t)n_p * P * P > Bp || wb_stride_bytes % 16 || act_stride_bytes % 16 ||
+      dz_stride_bytes % 16) {
+    set_error("npp_mlp_bwd_patch_stack: bad arguments (Bp=%lld n_p=%d P=%d row0=%lld)", (long long)Bp, n_p, P, (long long)row0);
+    return NPP_ERR_ARG;
+  }
+  BwdArgs A{d_dpred, d_pred, Bp, (const bf16x8*)d_wb, d_params, (const char*)d_actT, (char*)d_dzT, 1};
+  A.pg_dxa = d_dx_a; A.pg_dxb = d_dx_b; A.pg_fmask = d_cmask; A.pg_rmask = d_cmask; A.dpred_out = d_dpred;
+  A.pg_row0 = row0; A.pg_np = n_p; A.pg_k = 1; A.pg_P = P; A.pg_comp = 0;
+  A.S = make_stack(M, (int)(Bp / kRowTile), d_iter);
+  A.wb_stride16 = wb_stride_bytes / 16; A.params_stride = params_stride; A.act_stride = act_stride_bytes; A.dz_stride = dz_stride_bytes;
+  A.cmask_stride = cmask_stride; A.dxb_stride = dxb_stride;
+  return bwd_go(A, K, stream);
 }

@@ -27,6 +27,7 @@
 // Algorithmic work: 2 * ((K+1)*462*256 + 11*256^2 + 384) FLOP per row;
 // the zero padding of 462 -> 480 slots per proposal is not counted.
 #include "npp_common.h"
+#include <cstring>
 
 namespace npp {
 
@@ -129,6 +130,11 @@ struct FwdArgs {
   const float* emb;
   int64_t emb_ld;
   int32_t out_act;   // 0 raw, 1 sigmoid, 2 tanh
+  // stacked launch (npp_mlp_fwd_stack): image m reads / writes every array at + m * stride; its embedder constants come
+  // from estack[m] (device memory) instead of the kernel argument
+  Stack S;
+  const EmbedDev* estack;
+  int64_t wf_stride16, params_stride, act_stride;     // 16-byte units / floats / bytes per image
 };
 
 struct EmbTabs {
@@ -468,7 +474,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   }
   STAMP(51);
   // stash address = uniform (array, workgroup, k-step, batch tile) part + this lane's 32-bit offset (npp_layout.h wfmt_unit)
-  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
   const uint32_t lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
   // this wave's k-step q (0, 1) of chunk c: generate, hand to the LDS ring, stash for wgrad
   constexpr int kPer = kChunkKS / kWavesF;                       // k-steps of a chunk generated by one wave (2 or 1)
@@ -552,7 +558,7 @@ __device__ __forceinline__ void mma_plain_gen_chunk0(f32x16 (&acc)[NTW][kNB], co
   constexpr int kPer = kChunkKS / kWavesF;
   SlicedGen<STORE_EMB, kPer> g;
   g.sFr = e.freq_rev; g.vlane = sV + L.b; g.dst = lds_ring;
-  g.emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, gridDim.x) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  g.emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
   g.lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
   g.lane = L.lane; g.ksl0 = kPer * L.wave; g.ks0 = kPer * L.wave;
   g.ph = L.h ? 0.25f : 0.0f;
@@ -652,8 +658,19 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 }
 
 template <bool TRAIN, bool MULTI, bool EMB_IN = false>
-__global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
+__global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_in, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  FwdArgs A_ = A_in;
+  int img_, wg, xslot_, xcount_;
+  if (!stack_decode(A_.S, img_, wg, xslot_, xcount_)) return;
+  const int n_wg_ = A_.S.M ? A_.S.n_items : (int)gridDim.x;
+  if (A_.S.M) {
+    A_.coords += (int64_t)img_ * A_.Bp * 2;
+    A_.wf += (int64_t)img_ * A_.wf_stride16;
+    A_.params += (int64_t)img_ * A_.params_stride;
+    A_.pred += (int64_t)img_ * A_.Bp * 3;
+    if (A_.actF) A_.actF += (int64_t)img_ * A_.act_stride;
+  }
   char* R0 = smem;
   char* R1 = smem + kRegionBytes;
   float* sV = (float*)(smem + 2 * kRegionBytes);
@@ -666,10 +683,16 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   WarpEnt* tWarp = (WarpEnt*)((char*)&ed + kSmemE);
   float* sRGB = (float*)R0;             // [4 waves][64 rows][3], reused after the last barrier
   if (threadIdx.x == 0) {
-    const uint32_t* src = (const uint32_t*)&e_arg;
     uint32_t* dst = (uint32_t*)&ed;
+    if (A_.S.M) {
+      const uint32_t* src = (const uint32_t*)(A_.estack + img_);
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
+      for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
+    } else {
+      const uint32_t* src = (const uint32_t*)&e_arg;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
+    }
   }
   wg_barrier();
   for (int wi = threadIdx.x; wi < ed.K * 22; wi += kThreads) {
@@ -693,7 +716,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   L.lane = threadIdx.x & 63;
   L.b = L.lane & 31;
   L.h = L.lane >> 5;
-  const int wg = blockIdx.x;
+  L.n_wg = n_wg_; L.xslot = xslot_; L.xcount = xcount_;
   const int64_t row0 = (int64_t)wg * kRowTile;
   const int64_t Bp = A_.Bp;
   const float* P = A_.params;
@@ -706,7 +729,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   }
   wg_barrier();
 
-  auto arow = [&](int idx) -> char* { return TRAIN ? A_.actF + wfmt_array_base(idx * kKSAct, gridDim.x) : nullptr; };
+  auto arow = [&](int idx) -> char* { return TRAIN ? A_.actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr; };
 
   f32x16 acc[kNTW][kNB];
   WRing<kNTW> ring;                           // weight-stream register ring, live across layers
@@ -724,8 +747,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   uint32_t pfv[NPP_FWD_PREFETCH_LINES > 0 ? NPP_FWD_PREFETCH_LINES : 1] = {0};
   {
     const int64_t lines = ((int64_t)d.wf_total16 * 16 + 127) / 128;
-    const int64_t per_xcd_threads = (int64_t)((gridDim.x + 7) >> 3) * kThreads;
-    int64_t line = (int64_t)(blockIdx.x >> 3) * kThreads + L.tid;
+    const int64_t per_xcd_threads = (int64_t)L.xcount * kThreads;
+    int64_t line = (int64_t)L.xslot * kThreads + L.tid;
 #pragma unroll
     for (int q = 0; q < NPP_FWD_PREFETCH_LINES; ++q, line += per_xcd_threads)
       pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)A_.wf + line * 128) : 0u;
@@ -867,7 +890,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   if (p_wave)
-    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, gridDim.x) : nullptr,
+    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
                              wg, L);
 
   STAMP(40);
@@ -940,7 +963,7 @@ extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
 #endif
 
 static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, bool emb_in, void* stream, const char* who) {
-  const dim3 grid((unsigned)(A.Bp / kRowTile)), block(kThreads);
+  const dim3 grid(A.S.M ? stack_grid(A.S) : (unsigned)(A.Bp / kRowTile)), block(kThreads);
   const bool train = A.actF != nullptr, multi = d.K > 1;
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH(T, M, E)                                                                       \
@@ -996,4 +1019,37 @@ extern "C" int npp_mlp_fwd_emb(const float* d_emb, int64_t ld, int64_t Bp, int K
   EmbedDev e{};
   e.K = K;
   return fwd_launch(A, e, make_desc(K), true, stream, "npp_mlp_fwd_emb");
+}
+
+// ---- stacked form: M images per launch (npp_common.h "stacked launches") ----------------------------------------------------
+extern "C" int npp_embed_dev_bytes(void) { return (int)sizeof(EmbedDev); }
+
+extern "C" int npp_embed_dev_build(const npp_embed_cfg* cfg, void* host_out) {
+  int rc = check_embed_cfg(cfg, "npp_embed_dev_build");
+  if (rc) return rc;
+  if (!host_out) { set_error("npp_embed_dev_build: null pointer"); return NPP_ERR_ARG; }
+  const EmbedDev e = make_embed_dev(*cfg);
+  memcpy(host_out, &e, sizeof(e));
+  return NPP_OK;
+}
+
+extern "C" int npp_mlp_fwd_stack(const int32_t* d_coords_yx, int64_t Bp, const void* d_embed_dev, int M, int K, int width,
+                                 const void* d_wf, int64_t wf_stride_bytes, const float* d_params, int64_t params_stride,
+                                 float* d_pred, void* d_actT, int64_t act_stride_bytes, const void* d_iter, void* stream) {
+  int rc = fwd_check(Bp, width, d_coords_yx, d_wf, d_params, d_pred, "npp_mlp_fwd_stack");
+  if (rc) return rc;
+  if (M < 1 || M > NPP_MAX_STACK || K < 1 || K > NPP_MAX_K || !d_embed_dev || wf_stride_bytes % 16 || act_stride_bytes % 16 ||
+      wf_stride_bytes < 16 * make_desc(K).wf_total16 || params_stride < make_desc(K).total_params) {
+    set_error("npp_mlp_fwd_stack: bad M=%d / K=%d / strides", M, K);
+    return NPP_ERR_ARG;
+  }
+  FwdArgs A{};
+  A.coords = d_coords_yx; A.Bp = Bp; A.wf = (const bf16x8*)d_wf; A.params = d_params; A.pred = d_pred;
+  A.actF = (char*)d_actT; A.out_act = 1;
+  A.S = make_stack(M, (int)(Bp / kRowTile), d_iter);
+  A.estack = (const EmbedDev*)d_embed_dev;
+  A.wf_stride16 = wf_stride_bytes / 16; A.params_stride = params_stride; A.act_stride = act_stride_bytes;
+  EmbedDev e{};
+  e.K = K;
+  return fwd_launch(A, e, make_desc(K), false, stream, "npp_mlp_fwd_stack");
 }

@@ -79,6 +79,9 @@ struct WArgs {
   int64_t slab_stride;
   int32_t njobs, wg_chunk;     // workgroup tiles per split
   int32_t ntiles, ksplit;
+  // stacked launch (npp_mlp_wgrad_stack): image m reads its stash at + m * stride and writes its own ksplit slabs
+  Stack S;
+  int64_t dz_img_stride, act_img_stride, slab_img_stride;      // bytes, bytes, floats
   WJob jobs[kMaxJobs];
 };
 
@@ -419,6 +422,9 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
 }
 
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
+  const char* dzF_ = A.dzF;
+  const char* actF_ = A.actF;
+  float* gslabs_ = A.gslabs;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -430,13 +436,30 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   // every group owns a CONTIGUOUS range of them = all tiles of one batch split (+ part of the next): the tiles of a split
   // that read the same dz / input array (3 tiles share dz_5, 5 share dz_S, emb_0 feeds L0 and L5, f1 feeds S and P) then
   // stream it through ONE L2 at about the same time instead of each fetching it from HBM.
+  int item;
+  if (A.S.M) {
+    // stacked: image m owns S.g XCDs (npp_common.h); inside the image the same rule -- each of its XCDs a contiguous item range
+    const int n_items = A.S.n_items, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    int img, xl, gx;
+    if (A.S.g) { img = xcd / A.S.g; xl = xcd % A.S.g; gx = A.S.g; }
+    else { img = (int)blockIdx.x / n_items; xl = 0; gx = 1; }
+    const int q_ = n_items / gx, r_ = n_items % gx;
+    const int lslot = A.S.g ? slot : (int)blockIdx.x - img * n_items;
+    if (lslot >= (xl < r_ ? q_ + 1 : q_)) return;
+    item = (xl < r_ ? xl * (q_ + 1) : r_ * (q_ + 1) + (xl - r_) * q_) + lslot;
+    if (A.S.iter && !A.S.iter[img].active) return;
+    dzF_ += (int64_t)img * A.dz_img_stride;
+    actF_ += (int64_t)img * A.act_img_stride;
+    gslabs_ += (int64_t)img * A.slab_img_stride;
+  } else {
 #if NPP_WGRAD_XCD
-  const int n_items = (int)gridDim.x, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-  const int q_ = n_items >> 3, r_ = n_items & 7;
-  const int item = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
+    const int n_items = (int)gridDim.x, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int q_ = n_items >> 3, r_ = n_items & 7;
+    item = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
 #else
-  const int item = (int)blockIdx.x;
+    item = (int)blockIdx.x;
 #endif
+  }
   const int tile_id = item % A.ntiles, split_id = item / A.ntiles;
   // locate the job of this tile: compile-time indices into the kernel-argument table so
   // it is read with scalar loads (a run-time index would force a scratch copy of it)
@@ -454,9 +477,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   const int64_t a_col = wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * kWPairs * 4096;
   const int64_t b_col = wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * kWPairs * 4096;
   const int64_t a_left = A.dz_bytes - a_col, b_left = A.act_bytes - b_col;
-  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.dzF + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
-  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.actF + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
-  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A.dzF), 0, 0, 0x00020000);      // every access out of range
+  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_ + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(actF_ + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
+  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_), 0, 0, 0x00020000);      // every access out of range
   const uint32_t a_stride = (uint32_t)J.a_nks * 2048u, b_stride = (uint32_t)J.b_nks * 2048u;
 
   f32x16 acc[2][4];
@@ -496,7 +519,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #endif
 
   // ---- epilogue: stores into this split's slab, reference layout
-  float* slab = A.gslabs + (int64_t)split_id * A.slab_stride;
+  float* slab = gslabs_ + (int64_t)split_id * A.slab_stride;
 #ifndef NPP_DIAG_WGRAD_NOEPI
   if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {        // (every layer of this network has an even input width)
     // Plain-column jobs (17 of 21 tiles at K = 3): the accumulator holds one column per lane, i.e. 4-byte stores, 128 per wave
@@ -637,8 +660,27 @@ extern "C" int npp_mlp_wgrad_tiles(int K) {
   return build_jobs(K, A);
 }
 
+static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width, int ksplit, float* d_gslabs, int M,
+                        int64_t dz_stride, int64_t act_stride, int64_t slab_stride, const void* d_iter, void* stream);
+
 extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width, int ksplit,
                              float* d_gslabs, void* stream) {
+  return wgrad_launch(d_dzT, d_actT, Bp, K, width, ksplit, d_gslabs, 0, 0, 0, 0, nullptr, stream);
+}
+
+// stacked form: M images per launch, image m's ksplit slabs at d_gslabs + m * slab_img_stride floats
+extern "C" int npp_mlp_wgrad_stack(const void* d_dzT, int64_t dz_stride_bytes, const void* d_actT, int64_t act_stride_bytes,
+                                   int64_t Bp, int M, int K, int width, int ksplit, float* d_gslabs, int64_t slab_img_stride,
+                                   const void* d_iter, void* stream) {
+  if (M < 1 || M > NPP_MAX_STACK || dz_stride_bytes % 16 || act_stride_bytes % 16 || slab_img_stride % 4) {
+    set_error("npp_mlp_wgrad_stack: bad M=%d / strides", M);
+    return NPP_ERR_ARG;
+  }
+  return wgrad_launch(d_dzT, d_actT, Bp, K, width, ksplit, d_gslabs, M, dz_stride_bytes, act_stride_bytes, slab_img_stride, d_iter, stream);
+}
+
+static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K, int width, int ksplit, float* d_gslabs, int M,
+                        int64_t dz_stride, int64_t act_stride, int64_t slab_stride, const void* d_iter, void* stream) {
   if (K < 1 || K > NPP_MAX_K) { set_error("npp_mlp_wgrad: K=%d", K); return NPP_ERR_ARG; }
   if (width != NPP_WIDTH) { set_error("npp_mlp_wgrad: width %d unsupported (build is %d)", width, NPP_WIDTH); return NPP_ERR_UNSUPPORTED; }
   if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || ksplit > 64) { set_error("npp_mlp_wgrad: bad Bp=%lld / ksplit=%d", (long long)Bp, ksplit); return NPP_ERR_ARG; }
@@ -657,6 +699,16 @@ extern "C" int npp_mlp_wgrad(const void* d_dzT, const void* d_actT, int64_t Bp, 
   static SmemOnce once;
   if (!smem_attr(once, (const void*)wgrad_kernel, kSmemW)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
   A.ntiles = ntiles; A.ksplit = ksplit;
-  hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(ntiles * ksplit)), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
+  unsigned grid = (unsigned)(ntiles * ksplit);
+  if (M) {
+    A.S = make_stack(M, ntiles * ksplit, d_iter);
+    A.dz_img_stride = dz_stride; A.act_img_stride = act_stride; A.slab_img_stride = slab_stride;
+    if (dz_stride < A.dz_bytes || act_stride < A.act_bytes || slab_stride < (int64_t)ksplit * A.slab_stride) {
+      set_error("npp_mlp_wgrad_stack: image strides smaller than one image's arrays");
+      return NPP_ERR_ARG;
+    }
+    grid = stack_grid(A.S);
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
   return check_launch("npp_mlp_wgrad");
 }

@@ -243,8 +243,9 @@ class CompletionFit:
             d["pix"] = self.draw_pixels()                         # the reference `continue`s before this draw when k == 0
         return d
 
-    def materialise_batch(self, d):
-        """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists."""
+    def materialise_batch(self, d, out=None):
+        """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists.
+        out: dict(coords, gt, crops, cmasks) of preallocated buffers (this image's slices of a StackedFit's arrays)."""
         # (want_tuple=False: the loop reads the contiguous crops of last_raw; the reference-shaped views / tiled copies of the
         #  8-tuple would cost two more launches per iteration)
         if d["k"] == 0:
@@ -256,14 +257,15 @@ class CompletionFit:
         blob_dev = ops.h2d(blob, self.device)
         pix_dev = blob_dev[:pix.nbytes].view(torch.int64)
         cen_dev = blob_dev[pix.nbytes:].view(torch.int32).reshape(-1, 2)
-        _, _, _, _, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False, want_tuple=False, cen_dev=cen_dev)
+        _, _, _, _, _, source, k, weight = self.patch_sampler.materialise(d, want_coords=False, want_tuple=False, cen_dev=cen_dev,
+                                                                          crops_out=None if out is None else (out["crops"], out["cmasks"]))
         # coordinates of all rows (N_rand pixel rows, then the fake patches' rows, zero padding) + the pixel rows' colours:
         # one launch (npp_batch_assemble) instead of two index gathers, two concatenations and the colour / mask gathers
         n_pix, P, n_p = d["pix"].shape[0], d["P"], d["cen"].shape[0]
         n = n_pix + n_p * P * P
         bp = ops.pad_rows(n)
         allc, gt, pm = ops.batch_assemble(self.i_train_dev, pix_dev, self.patch_sampler.last_cen_dev, P, bp,
-                                          self.masked_img, self.pixel_mask)
+                                          self.masked_img, self.pixel_mask, out=None if out is None else (out["coords"], out["gt"]))
         w_dev = ops.h2d(np.ascontiguousarray(d["weights"], np.float32), self.device) if (self.use_patch_weight and d["weights"] is not None) else None
         return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, source=source, k=k, P=P, n_p=d["n_p"],
                     raw=self.patch_sampler.last_raw, pmask=pm, weight=w_dev)

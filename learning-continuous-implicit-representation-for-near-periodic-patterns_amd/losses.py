@@ -170,9 +170,11 @@ class HipTrunk:
         """The flat C=16 input tensor of an (N,3,H,W) batch, for producers that write it directly (ops.trunk_patch_in)."""
         return self._flat("x0", N, 16, H, W)
 
-    def _forward(self, x, scale, shift, x0_ready=False):
-        """x: the (N,3,H,W) batch, or just its shape when the flat input was already written (x0_ready)."""
+    def _forward(self, x, scale, shift, x0_ready=False, n_run=None):
+        """x: the (N,3,H,W) batch, or just its shape when the flat input was already written (x0_ready).  n_run: only the leading
+        n_run images are computed (N fixes the buffers' geometry; rows >= n_run of the returned taps are undefined)."""
         N, _, H, W = x if x0_ready else x.shape
+        nr = N if n_run is None else int(n_run)
         self._gen += 1
         self._geom = []
         cur = self._flat("x0", N, 16, H, W)
@@ -187,7 +189,7 @@ class HipTrunk:
                     tap = torch.empty((N, L["cout"], H, W), dtype=torch.float32, device=self.device)
                     outs.append(tap)
                 nxt = next((M["pf"] for M in self.layers[j + 1:] if M["kind"] == "conv"), None) if self.prefetch_next else None
-                ops.conv3x3(cur, N, N, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0,
+                ops.conv3x3(cur, N, nr, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0,
                             next_pack=nxt)
                 c = L["cout"]
             else:

@@ -301,27 +301,39 @@ def adam_step_net_pack(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v,
                                             lr, b1, b2, eps, step, K, width, _p(wf), _p(wb), _stream()), "npp_adam_step_net_pack", width)
 
 
-def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True):
+def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True, out=None):
     """extract_glimpse(mode='nearest', zeros padding) at integer centres
-    (utils/extract_glimpse.py:53-79 via models/sampler.py:171-178,284-291)."""
+    (utils/extract_glimpse.py:53-79 via models/sampler.py:171-178,284-291).  out = (rgb, mask) buffers with room for at least
+    M crops each (contiguous; a stacked fit's slice): written in place, the returned tensors are views of them."""
     _req(img_hwc, torch.float32, "img")
     _req(centres_yx, torch.int32, "centres")
     H, W = img_hwc.shape[:2]
     M = centres_yx.shape[0]
-    rgb = torch.empty((M, 3, P, P), dtype=torch.float32, device=img_hwc.device)
-    msk = torch.empty((M, 1, P, P), dtype=torch.float32, device=img_hwc.device) if want_mask else None
+    if out is not None:
+        rgb, msk = out[0][:M], out[1][:M]
+        _req(rgb, torch.float32, "out rgb", (M, 3, P, P))
+        _req(msk, torch.float32, "out mask", (M, 1, P, P))
+    else:
+        rgb = torch.empty((M, 3, P, P), dtype=torch.float32, device=img_hwc.device)
+        msk = torch.empty((M, 1, P, P), dtype=torch.float32, device=img_hwc.device) if want_mask else None
     check(lib().npp_patch_gather(_p(img_hwc), _p(mask_hw), H, W, _p(centres_yx), M, P, _p(rgb), _p(msk), _stream()),
           "npp_patch_gather")
     return rgb, msk
 
 
-def batch_assemble(i_train, pix, cen, P, bp, img_hwc, pmask_hw=None):
-    """-> (coords int32 (bp,2), gt (n_pix,3), pmask (n_pix,) | None): the input rows of one loop iteration, train.py:166-181."""
+def batch_assemble(i_train, pix, cen, P, bp, img_hwc, pmask_hw=None, out=None):
+    """-> (coords int32 (bp,2), gt (n_pix,3), pmask (n_pix,) | None): the input rows of one loop iteration, train.py:166-181.
+    out = (coords, gt): written in place (a stacked fit's slices)."""
     n_pix, n_p = pix.shape[0], 0 if cen is None else cen.shape[0]
     H, W = img_hwc.shape[:2]
     dev = img_hwc.device
-    coords = torch.empty((bp, 2), dtype=torch.int32, device=dev)
-    gt = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
+    if out is not None:
+        coords, gt = out
+        _req(coords, torch.int32, "out coords", (bp, 2))
+        _req(gt, torch.float32, "out gt", (n_pix, 3))
+    else:
+        coords = torch.empty((bp, 2), dtype=torch.int32, device=dev)
+        gt = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
     pm = None if pmask_hw is None else torch.empty((n_pix,), dtype=torch.float32, device=dev)
     check(lib().npp_batch_assemble(_p(i_train), i_train.shape[0], _p(pix), n_pix, _p(cen), n_p, P, bp, _p(img_hwc), _p(pmask_hw), H, W,
                                    _p(coords), _p(gt), _p(pm), _stream()), "npp_batch_assemble")
@@ -705,3 +717,75 @@ def robust_elem(a, b, latents, spline, n_knots, x_scale, coef_n, loss, want_grad
     check(lib().npp_robust_elem(_p(a), _p(b), N, D, _p(latents), _p(spline), n_knots, x_scale, cf, _p(loss), _p(diff), _p(dd),
                                 _p(dlatent) if want_grad else None, _p(ws), _stream()), "npp_robust_elem")
     return dd
+
+
+# ---- stacked launches (include/npp_hip.h "stacked launches"): M images per launch -----------------------------------------
+def embed_dev_blob(cfgs, device):
+    """The fused kernels' embedder constants of M images as one device blob (npp_embed_dev_build per image)."""
+    nb = lib().npp_embed_dev_bytes()
+    host = np.zeros((len(cfgs), nb), np.uint8)
+    for i, cfg in enumerate(cfgs):
+        check(lib().npp_embed_dev_build(C.byref(cfg), host[i].ctypes.data_as(C.c_void_p)), "npp_embed_dev_build")
+    return torch.from_numpy(host).to(device)
+
+
+def mlp_fwd_stack(coords, edev, M, K, wf, params, pred, actF, it, width=NPP_WIDTH):
+    """coords (M,Bp,2) int32, wf (M, pack bytes) uint8, params (M, stride) fp32, pred (M,Bp,3), actF (M, bytes) uint8."""
+    _req(coords, torch.int32, "coords")
+    Bp = coords.shape[1]
+    check(lib(width).npp_mlp_fwd_stack(_p(coords), Bp, _p(edev), M, K, width, _p(wf), wf.stride(0), _p(params), params.stride(0), _p(pred),
+                                       _p(actF), actF.stride(0), _p(it), _stream()), "npp_mlp_fwd_stack", width)
+
+
+def trunk_patch_in_loss_stack(pred, row0, crops, cmasks, M, n_p, P, X, N_total, scale, shift, x0, xy, zero, it, loss, gt_stride,
+                              lat_stride, loss_stride):
+    from ._lib import PixelLossArgs
+    s = (C.c_float * 3)(*[float(v) for v in scale])
+    b = (C.c_float * 3)(*[float(v) for v in shift])
+    pr, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent, n_rows = loss
+    la = PixelLossArgs(pr.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), int(n_rows), latents.data_ptr(),
+                       spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
+                       dlatent.data_ptr())
+    check(lib().npp_trunk_patch_in_loss_stack(_p(pred), pred.shape[1], row0, _p(crops), crops.stride(0), _p(cmasks), cmasks.stride(0), M,
+                                              n_p, P, X, N_total, s, b, _p(x0), _p(xy), 0 if xy is None else xy.stride(0), _p(zero),
+                                              _p(it), C.byref(la), gt_stride, lat_stride, loss_stride, _stream()),
+          "npp_trunk_patch_in_loss_stack")
+
+
+def cx_fwd_bwd_groups(fx, fy, it, M, band_width, scale, loss, loss_stride=1):
+    """npp_cx_fwd_bwd over sample groups (one per image of a stack): fx / fy (X, C, h, w); loss (M * loss_stride,) accumulated."""
+    _req(fx, torch.float32, "fx")
+    _req(fy, torch.float32, "fy", fx.shape)
+    N, Cc = fx.shape[:2]
+    hw = fx.shape[2] * fx.shape[3]
+    nbytes = lib().npp_cx_workspace_bytes(N, Cc, hw)
+    check(nbytes, "npp_cx_workspace_bytes")
+    key = (fx.device, int(nbytes))
+    ws = _cx_ws.get(key)
+    if ws is None:
+        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
+    dfx = torch.empty_like(fx)
+    check(lib().npp_cx_fwd_bwd_groups(_p(fx), _p(fy), N, Cc, hw, band_width, scale, _p(loss), loss_stride, _p(dfx), _p(it), M, _p(ws),
+                                      int(nbytes), _stream()), "npp_cx_fwd_bwd_groups")
+    return dfx
+
+
+def mlp_bwd_patch_stack(dpred, pred, M, K, wb, params, actF, dzF, dx_a, dx_b, cmasks, row0, n_p, P, it, width=NPP_WIDTH):
+    check(lib(width).npp_mlp_bwd_patch_stack(_p(dpred), _p(pred), pred.shape[1], M, K, width, _p(wb), wb.stride(0), _p(params),
+                                             params.stride(0), _p(actF), actF.stride(0), _p(dzF), dzF.stride(0), _p(dx_a), _p(dx_b),
+                                             0 if dx_b is None else dx_b.stride(0), _p(cmasks), cmasks.stride(0), row0, n_p, P, _p(it),
+                                             _stream()), "npp_mlp_bwd_patch_stack", width)
+
+
+def mlp_wgrad_stack(dzF, actF, Bp, M, K, ksplit, gslabs, it, width=NPP_WIDTH):
+    check(lib(width).npp_mlp_wgrad_stack(_p(dzF), dzF.stride(0), _p(actF), actF.stride(0), Bp, M, K, width, ksplit, _p(gslabs),
+                                         gslabs.stride(0), _p(it), _stream()), "npp_mlp_wgrad_stack", width)
+
+
+def adam_step_net_pack_stack(p, m, v, n, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat, n_lat, zero, M, K, wf, wb, it,
+                             width=NPP_WIDTH, b1=0.9, b2=0.999, eps=1e-8):
+    """p / m / v (M, stride) blobs, gslabs (M, n_slabs * slab_stride), lat.. (M, >= n_lat), zero (M, n_zero): image m's idle accumulators."""
+    check(lib(width).npp_adam_step_net_pack_stack(_p(p), _p(m), _p(v), p.stride(0), _p(gslabs), n, n_slabs, slab_stride, gslabs.stride(0),
+                                                  _p(lat), _p(lat_m), _p(lat_v), _p(dlat), n_lat, lat.stride(0), _p(zero),
+                                                  zero.shape[1], zero.stride(0), b1, b2, eps, M, K, width, _p(wf), wf.stride(0), _p(wb),
+                                                  wb.stride(0), _p(it), _stream()), "npp_adam_step_net_pack_stack", width)

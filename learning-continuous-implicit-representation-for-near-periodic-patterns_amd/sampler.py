@@ -211,7 +211,7 @@ class GridPatchSampler:
         """All patch centres of a draw (fake, then real) as the int32 (row, col) array the gather kernel takes."""
         return np.rint(d["cen"] if d["real_cen"] is None else np.concatenate([d["cen"], d["real_cen"]], 0)).astype(np.int32)
 
-    def materialise(self, d, want_coords=True, want_tuple=True, cen_dev=None):
+    def materialise(self, d, want_coords=True, want_tuple=True, cen_dev=None, crops_out=None):
         """-> the reference's 8-tuple (sampler.py:297-354) from a draw(); also sets self.last_raw (contiguous crops for
         the fused plumbing kernels).  want_tuple=False: only last_raw, source, k and the weights are produced (entries 0..3 None)."""
         if d["k"] == 0:
@@ -221,7 +221,7 @@ class GridPatchSampler:
         # (cen_dev: the caller uploaded centres_i32(d) itself, together with its other per-iteration indices)
         c_dev = cen_dev if cen_dev is not None else ops.h2d(self.centres_i32(d), self.device)
         self.last_cen_dev = c_dev[:n]
-        rgb_all, m_all = ops.patch_gather(self.img, self.mask, c_dev, P)
+        rgb_all, m_all = ops.patch_gather(self.img, self.mask, c_dev, P, out=crops_out)     # crops_out: a stacked fit's buffers
         fake, fmask = rgb_all[:n], m_all[:n]
         # fake_coords (n,P,P,2) of the 8-tuple (sampler.py:269-279); the fused loop builds its input rows from the centres
         # (npp_batch_assemble) and skips it

@@ -1,0 +1,234 @@
+"""M independent images per GPU in ONE launch sequence (include/npp_hip.h "stacked launches").
+
+The reference fits its images one after the other (run_completion.sh:8-14: one `python train.py` per input directory) exactly
+like it fits its periodicity candidates (NPP_proposal/search.py:85).  The fits are independent -- own weights, own Adam state,
+own random stream -- so M of them can share every launch of the loop body (NPP_completion/train.py:133-264): the
+image becomes a grid dimension of the fused forward / backward / weight-gradient / Adam launches, and the patch-loss trunks see
+M x 12 patches per launch instead of 12.  This is BASELINE config c3's shape at fewer than 8 GPUs (8 / 4 / 2 images per GPU) and
+amortises what bounds the single-image iteration: ~34 dependent launches of ~5 us ramp each, trunk layers that fill a quarter of
+the chip, 416 workgroups on 512 slots.
+
+StackedFit takes M CompletionFit objects (each keeps its own sampler, random stream, LPIPS latents and evaluation methods),
+re-homes their network state into stacked blobs (the fits' tensors become views of them: render / psnr / state_dict keep
+working) and replaces CompletionFit.step_full for all of them.  Per image the arithmetic is the single-image path's, launch by
+launch; tests/test_gpu_stack.py compares the parameters after 20 iterations with each image's stand-alone fit.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import StackIter
+
+
+class StackedFit:
+    def __init__(self, fits, ksplit=None):
+        if not fits:
+            raise ValueError("StackedFit needs at least one CompletionFit")
+        f0 = fits[0]
+        self.fits, self.M = list(fits), len(fits)
+        self.device = f0.device
+        ops.check_current(self.device)
+        net0 = f0.net
+        self.K, self.width = net0.K, net0.width
+        for f in fits:
+            if f.patch_sampler is None or f.task != "completion" or f.style is not None:
+                raise ValueError("StackedFit: completion fits with the patch losses (shifts=...) only")
+            if (f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.device) != (self.K, self.width, f0.N_rand, f0.patch_size,
+                                                                                                  f0.patch_num, f0.topk, f0.device):
+                raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count and the device")
+            if f.use_patch_weight or not f.use_contextual_loss or f.pixel_mask is not None or f._prefetch:
+                raise ValueError("StackedFit: default loss switches, no producer thread (the stack draws for every image itself)")
+        M, dev = self.M, self.device
+        self.n_p, self.P, self.kmax, self.n_pix = f0.patch_num, f0.patch_size, f0.topk, f0.N_rand
+        self.n = self.n_pix + self.n_p * self.P * self.P
+        self.Bp = ops.pad_rows(self.n)
+        n_par = net0.n_params
+        self.n_params = n_par
+        stride = (n_par + 3) // 4 * 4
+        # Split-K of the grouped weight gradient: one round of workgroups over the chip for the whole stack
+        # (tiles x ksplit x M ~ the CU count; an image owns 8 / M of the XCDs)
+        self.ksplit = int(ksplit) if ksplit else self._pick_ksplit()
+        sizes = ops.train_workspace(self.K, self.Bp, self.ksplit, self.width)
+        u8, f32 = torch.uint8, torch.float32
+        self.params, self.m, self.v = (torch.zeros((M, stride), dtype=f32, device=dev) for _ in range(3))
+        self.wf = torch.zeros((M, net0.wf.numel()), dtype=u8, device=dev)
+        self.wb = torch.zeros((M, net0.wb.numel()), dtype=u8, device=dev)
+        self.latents, self.lat_m, self.lat_v, self.dlatent = (torch.zeros((M, 8), dtype=f32, device=dev) for _ in range(4))
+        self.loss_bufs = torch.zeros((M, 2), dtype=f32, device=dev)
+        self.patch_loss = torch.zeros(M, dtype=f32, device=dev)
+        self.actF = torch.empty((M, sizes[1]), dtype=u8, device=dev)
+        self.dzF = torch.empty((M, sizes[2]), dtype=u8, device=dev)
+        self.gslabs = torch.empty((M, sizes[3] // 4), dtype=f32, device=dev)
+        self.slab_stride = sizes[3] // 4 // self.ksplit
+        self.pred = torch.empty((M, self.Bp, 3), dtype=f32, device=dev)
+        self.dpred = torch.zeros((M, self.Bp, 3), dtype=f32, device=dev)        # rows >= n stay zero
+        self.coords = torch.zeros((M, self.Bp, 2), dtype=torch.int32, device=dev)
+        self.gt = torch.empty((M, self.n_pix, 3), dtype=f32, device=dev)
+        nc = self.n_p * (1 + self.kmax)
+        self.crops = torch.zeros((M, nc, 3, self.P, self.P), dtype=f32, device=dev)
+        self.cmasks = torch.zeros((M, nc, 1, self.P, self.P), dtype=f32, device=dev)
+        nxy = 2 * self.n_p * self.kmax
+        self.xy = torch.zeros((M, nxy, 3, self.P, self.P), dtype=f32, device=dev)
+        self.dxb = torch.zeros((M, nxy, 3, self.P, self.P), dtype=f32, device=dev)
+        self.N_total = M * nxy
+        self.edev = ops.embed_dev_blob([f.net.cfg for f in fits], dev)
+        # re-home every fit's network state: its tensors become views of the stacked blobs
+        for i, f in enumerate(fits):
+            net = f.net
+            for name, blob in (("params", self.params), ("m", self.m), ("v", self.v)):
+                blob[i, :n_par].copy_(getattr(net, name))
+                setattr(net, name, blob[i, :n_par])
+            self.wf[i].copy_(net.wf); net.wf = self.wf[i]
+            self.wb[i].copy_(net.wb); net.wb = self.wb[i]
+            for name, blob in (("latents", self.latents), ("lat_m", self.lat_m), ("lat_v", self.lat_v), ("dlatent", self.dlatent)):
+                blob[i, :6].copy_(getattr(net, name))
+                setattr(net, name, blob[i, :6])
+            self.loss_bufs[i].copy_(net._loss_bufs); net._loss_bufs = self.loss_bufs[i]
+            net._ws = {}
+        self.loss_idx = net0._loss_idx
+        for f in fits:
+            f.net._loss_idx = self.loss_idx
+        # the contextual trunk is shared (frozen weights): the stack runs it once over all images' patches
+        self.cx = f0.contextualLoss
+        self.cx_w, self.lp_w, self.use_comp = f0.cx_w, f0.lp_w, f0.use_comp
+        self._s_lp = torch.cuda.Stream(dev)
+        self.iteration = 0
+        self.last_sources = None
+        self._clean = False
+
+    def _pick_ksplit(self):
+        """Batch splits per image of the grouped weight-gradient launch: the count that minimises rounds x rows per workgroup
+        (tiles x splits x M workgroups of one CU each)."""
+        from ._lib import lib
+        tiles = lib(self.width).npp_mlp_wgrad_tiles(self.K)
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        n_wg = self.Bp // 64
+        best = min(range(1, 25), key=lambda ks: (-(-tiles * ks * self.M // cus) * -(-n_wg // ks), ks))
+        return best
+
+    # ---- host half: one draw per image (each fit's own sampler and random stream), device half into the stacked buffers ----
+    def sample(self):
+        """-> list of M batches (None for an image whose sampler found no valid real patch this iteration)."""
+        out = []
+        for i, f in enumerate(self.fits):
+            d = f.draw_batch()
+            f.last_draw = d
+            f.iteration += 1
+            b = f.materialise_batch(d, out=dict(coords=self.coords[i], gt=self.gt[i], crops=self.crops[i], cmasks=self.cmasks[i]))
+            if b is None:
+                f.skipped += 1
+            out.append(b)
+        return out
+
+    def step_full(self):
+        """One iteration of the loop body for every image of the stack.  -> number of images that took a step."""
+        return self.step_from(self.sample())
+
+    # ---- device half ---------------------------------------------------------------------------------------------------------
+    def step_from(self, batches):
+        ops.check_current(self.device)
+        M, fits = self.M, self.fits
+        it = (StackIter * M)()
+        x0 = 0
+        lr_used = [0.0] * M
+        for i, (f, b) in enumerate(zip(fits, batches)):
+            e = it[i]
+            if b is None:
+                continue
+            if (b["P"], b["n_p"], b["n_pix"], b["bp"]) != (self.P, self.n_p, self.n_pix, self.Bp):
+                raise RuntimeError("StackedFit: an image's batch left the stack's shape (patch-size decay is not stacked: rebuild the stack)")
+            net = f.net
+            src, k = b["source"], b["k"]
+            e.active, e.k, e.nk, e.x0 = 1, k, self.n_p * k, x0
+            e.comp = int(self.use_comp and src == "val")
+            e.same = int(src == "same")
+            e.with_lp = int(src == "same" and f.use_perceptual_loss)
+            net.opt_step += 1
+            step = net.opt_step
+            # npp_adam_step_net_pack's host arithmetic: float arguments widened to double, pow / sqrt in double, result to float
+            b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+            bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+            e.step_size = float(np.float32(net.lr)) / bc1
+            e.inv_sqrt_bc2 = 1.0 / math.sqrt(bc2)
+            lr_used[i] = net.lr
+            x0 += e.nk
+        X = x0
+        n_active = sum(1 for b in batches if b is not None)
+        self.last_sources = [None if b is None else b["source"] for b in batches]
+        if n_active == 0:
+            self.iteration += 1
+            return 0
+        it_dev = ops.h2d(np.frombuffer(bytes(it), np.uint8).copy(), self.device)
+        # zero_grad(): the fused Adam launch of the previous iteration cleared each active image's latent gradient and idle loss
+        # accumulator; switch to it (NPPNet.zero_grad).  Images that sat the previous iteration out are cleared here.
+        if self._clean:
+            self.loss_idx ^= 1
+            for i in self._stale:
+                self.loss_bufs[i, self.loss_idx].zero_()
+                self.dlatent[i].zero_()
+        else:
+            self.loss_bufs[:, self.loss_idx].zero_()
+            self.dlatent.zero_()
+        for f in fits:
+            f.net._loss_idx = self.loss_idx
+            if f.percepLoss.touched:
+                f.percepLoss.zero_latent_grads()
+        K, W = self.K, self.width
+        ops.mlp_fwd_stack(self.coords, self.edev, M, K, self.wf, self.params, self.pred, self.actF, it_dev, W)
+        cx = self.cx
+        sc, sh = cx.input_norm()
+        net0 = fits[0].net
+        loss = (self.pred, self.gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
+                self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix)
+        t = cx.hip_trunk
+        with_lp = [i for i, b in enumerate(batches) if b is not None and it[i].with_lp]
+        ops.trunk_patch_in_loss_stack(self.pred, self.n_pix, self.crops, self.cmasks, M, self.n_p, self.P, X, self.N_total, sc, sh,
+                                      t.input_buffer(self.N_total, self.P, self.P), self.xy if with_lp else None, self.patch_loss,
+                                      it_dev, loss, self.gt.stride(0), self.latents.stride(0), self.loss_bufs.stride(0))
+        main = torch.cuda.current_stream(self.device)
+        if with_lp:                                       # the LPIPS branch of the 'same' images beside the contextual chain
+            self._s_lp.wait_stream(main)
+            with torch.cuda.stream(self._s_lp):
+                for i in with_lp:
+                    nk = it[i].nk
+                    f = fits[i]
+                    dxb = f.percepLoss.fused(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1], normalize=True)
+                    self.dxb[i, :nk].copy_(dxb[:nk])
+        shape = (self.N_total, 3, self.P, self.P)
+        feats = t._forward(shape, sc, sh, True, n_run=2 * X)[0]
+        dfx = ops.cx_fwd_bwd_groups(feats[:X], feats[X:2 * X], it_dev, M, cx.band_width, self.cx_w, self.patch_loss)
+        dx_a = t._backward([dfx], X, sc, shape, zero_rest=False)
+        if with_lp:
+            main.wait_stream(self._s_lp)
+        ops.mlp_bwd_patch_stack(self.dpred, self.pred, M, K, self.wb, self.params, self.actF, self.dzF, dx_a,
+                                self.dxb if with_lp else None, self.cmasks, self.n_pix, self.n_p, self.P, it_dev, W)
+        ops.mlp_wgrad_stack(self.dzF, self.actF, self.Bp, M, K, self.ksplit, self.gslabs, it_dev, W)
+        idle = self.loss_bufs[:, 1 - self.loss_idx:2 - self.loss_idx]
+        ops.adam_step_net_pack_stack(self.params, self.m, self.v, self.n_params, self.gslabs, self.ksplit, self.slab_stride,
+                                     self.latents, self.lat_m, self.lat_v, self.dlatent, 6, idle, M, K, self.wf, self.wb, it_dev, W)
+        self._clean = True
+        self._stale = [i for i, b in enumerate(batches) if b is None]
+        for i, (f, b) in enumerate(zip(fits, batches)):
+            if b is None:
+                continue
+            net = f.net
+            net.lr = net.lrate * (0.1 ** (net.global_step / (net.lrate_decay * 100)))      # train.py:256-262, NPPNet.optimizer_step
+            if net.lr_clock:
+                net.global_step += 1
+            net._clean = True
+            f.last_source = b["source"]
+            f.last_patch_loss = self.patch_loss[i:i + 1]
+            if f.percepLoss.touched:                      # only 'same' iterations give the LPIPS latents a gradient
+                f.percepLoss.adam_step(lr_used[i])
+        self.iteration += 1
+        return n_active
+
+    def close(self):
+        for f in self.fits:
+            f.close()
+
+    def psnr(self, region="known"):
+        return [f.psnr(region) for f in self.fits]

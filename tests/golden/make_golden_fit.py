@@ -20,12 +20,13 @@ from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_
 import oracle  # noqa: E402  (only for the synthetic image / periodicity definition)
 
 
-def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300), W=256):
+def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 75, 100, 150, 200, 300), W=256, H=256):
     """K = 1: NPP_Net_top1 (g8_fit.npz).  K = 3: NPP_Net with the coarse-level proposals of the synthetic lattice, BASELINE
-    config c2's network (g8k3_fit.npz; models/networks.py:56-95, table = cat of the K proposals' embeddings, train.py:103-105)."""
+    config c2's network (g8k3_fit.npz; models/networks.py:56-95, table = cat of the K proposals' embeddings, train.py:103-105).
+    H = 512 with K = 3, W = 256: BASELINE config c2 at its REAL size (g8c2_fit.npz; the tables are 1.45 GB each)."""
     R = import_reference()
     emb, msec = R["emb"], R["msec"]
-    H, N_rand = 256, 8192
+    N_rand = 8192
     img, mask = oracle.synthetic_image(H)
     angles, periods, _ = oracle.synthetic_periodicity(H, K)
     masked = img * mask
@@ -76,7 +77,9 @@ def main(K=1, n_iters=300, out_name="g8_fit.npz", checkpoints=(1, 5, 10, 20, 30,
 
 
 if __name__ == "__main__":
-    if "--w512" in sys.argv:                      # g8w512_fit.npz: NPP_Net K = 3 at the reference's default width
+    if "--c2" in sys.argv:                        # g8c2_fit.npz: config c2 at full size (512^2, K = 3, W = 256), ~0.3 s per iteration
+        main(K=3, n_iters=60, out_name="g8c2_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 60), H=512)
+    elif "--w512" in sys.argv:                      # g8w512_fit.npz: NPP_Net K = 3 at the reference's default width
         main(K=3, n_iters=100, out_name="g8w512_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100), W=512)
     elif "--k5" in sys.argv:                      # g8k5_fit.npz: BASELINE config c5's network (top-5 proposals)
         main(K=5, n_iters=100, out_name="g8k5_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100))
