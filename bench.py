@@ -244,8 +244,8 @@ def main():
     ws = net.workspace(bp)
 
     def step(i):
-        # (the next pool entry is handed over like the loop's one-batch lookahead does: the trunk features of its REAL patches --
-        #  independent of the network -- are computed during this step on a side stream; every step still does one such pass)
+        # (the next pool entry rides along for the real-half prefetch of CompletionFit.step_from, an option that is OFF by default
+        #  -- measured slower, profiles/r03_rejected_experiments.txt #5 -- so the timed step is the plain single-stream iteration)
         fit.step_from(pool[i % len(pool)], pool[(i + 1) % len(pool)])
 
     def barrier():
@@ -277,6 +277,36 @@ def main():
     mix_timed = {s_: sum(pool[i % len(pool)]["source"] == s_ for i in range(args.steps)) for s_ in ("val", "train", "same")}
     if args.steps % len(pool) and rank == 0:
         print(f"bench.py: --steps {args.steps} is not a multiple of --pool {len(pool)}: timed source mix {mix_timed}", file=sys.stderr)
+
+    # ---- host time to ENQUEUE one iteration (34 C-ABI calls through ctypes), measured on a drained queue over 8 iterations (well
+    #      inside the HIP queue's depth, so no launch call blocks on the device): the loop is device-bound while this stays below
+    #      ms_per_step -- the number to watch when 8 ranks share a host ----
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for i in range(8):
+        step(i)
+    host_enqueue_ms = (time.perf_counter() - t_h) / 8 * 1e3
+    torch.cuda.synchronize()
+    # ---- the same loop INCLUDING each rank's host-side sampling (reference random stream from the native generator on a producer
+    #      thread + the sampler's device launches), on every rank at once: N producer threads + N enqueueing threads on one host ----
+    e2e_ranks = None
+    if dist is not None and world > 1:
+        fe = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=rank), device=dev, N_rand=8192,
+                           ksplit=args.ksplit, seed=rank, shifts=shifts, rng_mode="reference", prefetch=4)
+        for _ in range(20):
+            fe.step_full()
+        barrier()
+        t_e = time.perf_counter()
+        for _ in range(100):
+            fe.step_full()
+        torch.cuda.synchronize()
+        te = torch.tensor([(time.perf_counter() - t_e) / 100 * 1e3, host_enqueue_ms], dtype=torch.float64, device=dev)
+        alle = [torch.empty_like(te) for _ in range(world)]
+        dist.all_gather(alle, te)
+        e2e_ranks = {"ms_per_iter_incl_sampling": [float(x[0]) for x in alle], "host_enqueue_ms_per_iter": [float(x[1]) for x in alle],
+                     "rows_per_s_incl_sampling": sum(n_rows / (float(x[0]) * 1e-3) for x in alle)}
+        fe.close()
+        del fe
 
     # ---- the one collective of the job: gather the fitted images -- directly behind the timed loop, before any rank-0-only
     #      extra (the other ranks would sit in the all_gather meanwhile) ----
@@ -662,6 +692,43 @@ def main():
             del fr
         remap["note"] = ("rng_reference reproduces np.random.choice(1 048 576, 8192, replace=False) draw for draw: one full permutation of the pixel pool per draw on the host (native MT19937 stream, group-wise rejection walk, AVX2 where available: ~1.2 ms per permutation, two per iteration, on a producer thread); rng_fast draws on the device")
 
+    # ---- extra: M images per GPU in ONE launch sequence (npp_amd.stack.StackedFit: the image is a grid dimension of every launch) --
+    #      BASELINE config c3 at N < 8 GPUs (8 / 4 / 2 images per GPU).  device-only: fixed pre-drawn batch sets (each with its own
+    #      random mix of patch sources over the images), like `value`; e2e: step_full() incl. every image's host draw ----
+    stacked = None
+    if rank == 0 and not args.no_extras:
+        from npp_amd.stack import StackedFit
+        stacked = {"note": "rows/s of ONE GPU fitting M images at once; x_single = against this run's single-image `value` "
+                           "(device-only legs) / fast-mode end-to-end (e2e legs)"}
+        e2e1 = (e2e or {}).get("fast_mode", {}).get("ms_per_iter")
+        for M_ in (2, 4, 8):
+            fs = []
+            for i_ in range(M_):
+                im_, mk_ = syn.synthetic_image(H, seed=2000 + i_)
+                fs.append(CompletionFit(im_, mk_, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=2000 + i_), device=dev,
+                                        N_rand=8192, seed=2000 + i_, shifts=shifts, rng_mode="fast"))
+            st = StackedFit(fs)
+            for _ in range(5):
+                st.step_full()
+            ts_ = []
+            for _ in range(10):
+                bs_ = st.sample()
+                ts_.append(timed(lambda: st.step_from(bs_), reps=20))
+            t_dev = float(np.mean(ts_))
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            for _ in range(100):
+                st.step_full()
+            torch.cuda.synchronize()
+            t_e2e = (time.perf_counter() - t6) / 100
+            stacked[f"stacked_M{M_}"] = {"ms_per_stacked_iteration": t_dev * 1e3, "rows_per_s": M_ * n_rows / t_dev,
+                                         "x_single": M_ * n_rows / t_dev / value, "wgrad_ksplit_per_image": st.ksplit,
+                                         "e2e_ms_per_stacked_iteration": t_e2e * 1e3, "e2e_rows_per_s": M_ * n_rows / t_e2e,
+                                         "e2e_x_single": (M_ * e2e1 * 1e-3 / t_e2e) if e2e1 else None}
+            st.close()
+            del st, fs
+            torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(K, H, patch, n_pix, fit.patch_num, fit.topk)
@@ -692,7 +759,8 @@ def main():
                                                                               "ranks": dist.get_world_size()},
             "end_to_end_incl_host_sampling": e2e or None,
             "c4_embedder_1024sq": c4, "proposal_ranking_candidate": ranking, "throughput_mode_2_images_per_gpu": two_fits, "ms_per_iter_by_patch_source": per_source,
-            "netwidth_512_fused": w512, "remapping_task_1024sq": remap,
+            "netwidth_512_fused": w512, "remapping_task_1024sq": remap, "stacked_images_per_gpu": stacked,
+            "host_enqueue_ms_per_iter": host_enqueue_ms, "all_ranks_incl_sampling": e2e_ranks,
             "patch_loss_kernels_us": {k_: round(v_ * 1e6, 1) for k_, v_ in patch_kt.items()},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -277,8 +277,9 @@ int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, f
  * the difference, lin 1x1 conv, spatial mean) and its backward.  feats (N,C,hw) fp32 NCHW;
  * d_latents [alpha(C) | scale(C)]; d_loss[0] += scale * mean_n(...); d_df0 (N,C,hw) and
  * d_dlatent [2C] (accumulated) may both be NULL for forward only.  C in {16, 32, 64, 128, 192,
- * 256, 384, 512}.  d_workspace is no longer used (the per-channel loss parameters are derived in
- * the kernel's prologue); it stays in the signature, NULL is accepted. */
+ * 256, 384, 512}.  d_workspace: npp_lpips_workspace_bytes(C) bytes, ZEROED once by the caller and owned by one
+ * stream -- the latent gradients and the loss are then summed over the launch's blocks as fixed-point integers
+ * (order-independent, bit-reproducible); NULL: float atomics in arrival order. */
 int64_t npp_lpips_workspace_bytes(int C);
 int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
                     const float* d_lin, const float* d_latents, const float* d_spline,
@@ -331,10 +332,15 @@ int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const floa
                        float* d_zero, int n_zero, int which, void* stream);
 /* The same launch also computing npp_pixel_loss (the arguments of that entry point, in a struct): the two consumers of
  * the forward launch's prediction (train.py:195 and :200-236) are independent, so they share one launch. */
+#define NPP_PIXEL_LOSS_SCRATCH_FLOATS (1024 * 7 + 8)
 typedef struct {
   const float* pred; const float* gt; const float* mask; int64_t N;
   const float* latents; const float* spline; int32_t n_knots; float x_scale, weight;
   float* loss; float* dpred; float* dlatent;
+  /* nullable.  NPP_PIXEL_LOSS_SCRATCH_FLOATS floats, ZEROED once by the caller and then owned by ONE stream: with it the loss
+   * and the latent gradients are summed over the launch's blocks in a fixed order (bit-reproducible); without it by float
+   * atomics in arrival order. */
+  float* scratch;
 } npp_pixel_loss_args;
 int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
                             const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
@@ -421,12 +427,12 @@ int npp_mlp_fwd_stack(const int32_t* d_coords_yx, int64_t Bp, const void* d_embe
  * (>= 2 X: 2 M n_p kmax), so the trunk launches run with n_run = 2 X (forward) / X (data gradient).  d_xy (M, 2 n_p kmax,
  * 3, P, P), nullable: fp32 [x | y] of the images with with_lp set.  d_zero: M patch-loss accumulators, cleared.
  * loss: the pixel-loss arguments of image 0; image m at pred / dpred + m Bp 3, gt + m gt_stride, latents / dlatent +
- * m lat_stride, loss + m loss_stride. */
+ * m lat_stride, loss + m loss_stride, scratch + m scratch_stride. */
 int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, int64_t row0, const float* d_crops, int64_t crop_stride,
                                   const float* d_cmasks, int64_t cmask_stride, int M, int n_p, int P, int X, int N_total,
                                   const float scale[3], const float shift[3], void* d_x0, float* d_xy, int64_t xy_stride,
                                   float* d_zero, const void* d_iter, const npp_pixel_loss_args* loss, int64_t gt_stride,
-                                  int lat_stride, int loss_stride, void* stream);
+                                  int lat_stride, int loss_stride, int64_t scratch_stride, void* stream);
 /* npp_cx_fwd_bwd over sample groups (one per image): see csrc/npp_cx.hip. */
 int npp_cx_fwd_bwd_groups(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, float scale,
                           float* d_loss, int loss_stride, float* d_dfx, const void* d_iter, int M, void* d_workspace,

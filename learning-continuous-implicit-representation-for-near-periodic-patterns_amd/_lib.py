@@ -20,7 +20,7 @@ class PixelLossArgs(C.Structure):
     """npp_pixel_loss_args (include/npp_hip.h)."""
     _fields_ = [("pred", C.c_void_p), ("gt", C.c_void_p), ("mask", C.c_void_p), ("N", C.c_int64), ("latents", C.c_void_p),
                 ("spline", C.c_void_p), ("n_knots", C.c_int32), ("x_scale", C.c_float), ("weight", C.c_float), ("loss", C.c_void_p),
-                ("dpred", C.c_void_p), ("dlatent", C.c_void_p)]
+                ("dpred", C.c_void_p), ("dlatent", C.c_void_p), ("scratch", C.c_void_p)]
 
 
 class PatchGrad(C.Structure):
@@ -118,7 +118,7 @@ SYMBOLS = {
     "npp_embed_dev_build": (_i32, [_cfgp, _vp]),
     "npp_mlp_fwd_stack": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "npp_trunk_patch_in_loss_stack": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float),
-                                             C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, C.POINTER(PixelLossArgs), _i64, _i32, _i32, _vp]),
+                                             C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, C.POINTER(PixelLossArgs), _i64, _i32, _i32, _i64, _vp]),
     "npp_cx_fwd_bwd_groups": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     "npp_mlp_bwd_patch_stack": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp,
                                        _i64, _i64, _i32, _i32, _vp, _vp]),

@@ -473,7 +473,32 @@ struct PixelLossArgs {
   const float* pred; const float* gt; const float* mask; int64_t N;
   const float* latents; const float* spline; int n_knots; float x_scale, weight;
   float* loss_out; float* dpred; float* dlatent;
+  float* scratch;      // nullable: kPixelLossScratch floats, word [kPixelLossScratch - 1] a zero-initialised ticket counter
 };
+constexpr int kPixelLossScratch = 1024 * 7 + 8;
+// Cross-block reduction in a FIXED order (round 4): every block stores its partials, the block that draws the last ticket sums
+// them -- cdna_hip_programming.md "In-launch split-K reduction": plain stores, vmcnt drain, barrier, ONE agent-scope release and
+// a relaxed agent-scope ticket by lane 0; the last arriver takes one agent-scope acquire before anybody in it loads (correct
+// for any placement of the blocks over the XCDs).  Call from every thread of every block after its partial stores; true in the
+// whole block that arrived last (which also re-arms the counter).
+__device__ __forceinline__ bool block_last_arriver(unsigned* counter, int nb) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == (unsigned)nb - 1u;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  return s_last != 0;
+}
 inline int pixel_loss_blocks(int64_t N) { const int64_t b = (N + 255) / 256; return (int)(b > 1024 ? 1024 : b); }
 __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid, int nb) {
   const float* __restrict__ pred = a.pred;
@@ -518,6 +543,20 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
+  if (a.scratch) {
+    // deterministic form: per-block partials, summed in block order by the last arriver (single writer: plain accumulation)
+    if (threadIdx.x < 7) a.scratch[bid * 7 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (!block_last_arriver((unsigned*)(a.scratch + kPixelLossScratch - 1), nb)) return;
+    if (threadIdx.x < 7) {
+      const int k = threadIdx.x;
+      float v = 0.0f;
+      for (int b = 0; b < nb; ++b) v += a.scratch[b * 7 + k];
+      if (k == 0) a.loss_out[0] += weight * v * inv;
+      else if (k < 4) a.dlatent[k - 1] += weight * inv * v * cp[k - 1].dalpha_dl;
+      else a.dlatent[3 + (k - 4)] += weight * inv * v * cp[k - 4].dc_dl;
+    }
+    return;
+  }
   if (threadIdx.x < 7) {
     const int k = threadIdx.x;
     float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];

@@ -398,7 +398,7 @@ struct PatchInStack {
   float* zero;              // M patch-loss accumulators
   const StackIter* iter;
   PixelLossArgs pl;         // image 0; the others at + m * the strides below
-  int64_t gt_stride;
+  int64_t gt_stride, scratch_stride;
   int32_t lat_stride, loss_stride, nb_loss, pad;
 };
 __global__ void trunk_patch_in_stack_kernel(PatchInStack a) {
@@ -408,6 +408,7 @@ __global__ void trunk_patch_in_stack_kernel(PatchInStack a) {
     PixelLossArgs pl = a.pl;
     pl.pred += (int64_t)m * a.Bp * 3; pl.dpred += (int64_t)m * a.Bp * 3; pl.gt += (int64_t)m * a.gt_stride;
     pl.latents += m * a.lat_stride; pl.dlatent += m * a.lat_stride; pl.loss_out += m * a.loss_stride;
+    if (pl.scratch) pl.scratch += (int64_t)m * a.scratch_stride;
     pixel_loss_body(pl, b, a.nb_loss);
     return;
   }
@@ -712,7 +713,7 @@ extern "C" int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_
                                        const npp_pixel_loss_args* loss, void* stream) {
   if (!loss) { set_error("npp_trunk_patch_in_loss: null pixel-loss arguments"); return NPP_ERR_ARG; }
   const PixelLossArgs pl{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
-                         loss->weight, loss->loss, loss->dpred, loss->dlatent};
+                         loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch};
   return patch_in_launch(d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale, shift, d_x0, d_xy, d_zero, n_zero,
                          which, &pl, stream, "npp_trunk_patch_in_loss");
 }
@@ -723,7 +724,7 @@ extern "C" int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, in
                                              const float* d_cmasks, int64_t cmask_stride, int M, int n_p, int P, int X, int N_total,
                                              const float scale[3], const float shift[3], void* d_x0, float* d_xy, int64_t xy_stride,
                                              float* d_zero, const void* d_iter, const npp_pixel_loss_args* loss, int64_t gt_stride,
-                                             int lat_stride, int loss_stride, void* stream) {
+                                             int lat_stride, int loss_stride, int64_t scratch_stride, void* stream) {
   const char* who = "npp_trunk_patch_in_loss_stack";
   if (M < 1 || M > NPP_MAX_STACK || n_p < 1 || X < 0 || 2 * X > N_total || !d_pred || !d_crops || !d_cmasks || !d_x0 || !d_zero ||
       !d_iter || !scale || !shift || !loss || row0 < 0 || row0 + (int64_t)n_p * P * P > Bp) {
@@ -745,8 +746,8 @@ extern "C" int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, in
   a.npos_round = X > 0 ? conv_npos_round(2 * X, P, P) : 0;
   a.xy = d_xy; a.zero = d_zero; a.iter = (const StackIter*)d_iter;
   a.pl = PixelLossArgs{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
-                       loss->weight, loss->loss, loss->dpred, loss->dlatent};
-  a.gt_stride = gt_stride; a.lat_stride = lat_stride; a.loss_stride = loss_stride;
+                       loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch};
+  a.gt_stride = gt_stride; a.lat_stride = lat_stride; a.loss_stride = loss_stride; a.scratch_stride = scratch_stride;
   a.nb_loss = pixel_loss_blocks(loss->N);
   const int64_t nblk = (a.npos_round > M ? a.npos_round : M) ;
   hipLaunchKernelGGL(trunk_patch_in_stack_kernel, dim3((unsigned)((nblk + 255) / 256 + (int64_t)M * a.nb_loss)), dim3(256), 0,

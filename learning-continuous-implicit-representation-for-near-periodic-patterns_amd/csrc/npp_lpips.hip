@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
                                                           const float* __restrict__ latents,
                                                           const float* __restrict__ spline, int n_knots, float x_scale,
                                                           float coef, float* __restrict__ loss, float* __restrict__ df0,
-                                                          float* __restrict__ dlatent) {
+                                                          float* __restrict__ dlatent, unsigned long long* __restrict__ fix) {
   constexpr int CL = 256 / PL, C = CL * Q;
   __shared__ float red[3][CL][PL + 1];
   __shared__ float tot[4];
@@ -142,11 +142,28 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     }
   }
   __syncthreads();
-  if (df0)
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dlatent + i, sdl[i]);
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
+  if (fix) {
+    // Order-independent sums (round 4): every block adds its partials as 2^-40 fixed-point integers (integer addition is
+    // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the
+    // totals back, accumulates them into dlatent / loss and clears the accumulators for the next call.
+    auto tofix = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); };
+    if (df0)
+      for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i]));
+    if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3])));
+    if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), (int)gridDim.x)) return;
+    for (int i = threadIdx.x; i <= 2 * C; i += 256) {
+      const long long s = (long long)__hip_atomic_exchange(fix + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float v = (float)((double)s * (1.0 / 1099511627776.0));
+      if (i == 2 * C) atomicAdd(loss, v);                    // (the contextual branch adds to the same word from its own stream)
+      else if (df0) dlatent[i] += v;
+    }
+    return;
+  }
+  if (df0)
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dlatent + i, sdl[i]);
   if (threadIdx.x == 0) atomicAdd(loss, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
 
@@ -154,7 +171,8 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
 
 using namespace npp;
 
-extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)C * sizeof(ChanParams); }
+// 2 C + 1 fixed-point accumulators + the ticket counter (8 bytes each); zeroed once by the caller, owned by one stream
+extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)(2 * C + 2) * 8; }
 
 extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                                const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
@@ -164,7 +182,7 @@ extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int 
     return NPP_ERR_ARG;
   }
   if ((d_df0 == nullptr) != (d_dlatent == nullptr)) { set_error("npp_lpips_layer: df0 and dlatent go together"); return NPP_ERR_ARG; }
-  (void)d_workspace;                          // kept in the signature; the per-channel parameters now live in LDS
+  unsigned long long* fix = (unsigned long long*)d_workspace;    // nullable: float atomics in arrival order instead
   hipStream_t s = (hipStream_t)stream;
   const int64_t nh = (int64_t)N * hw;
   const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
@@ -174,7 +192,7 @@ extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int 
   const dim3 grid((unsigned)(groups < 256 ? groups : 256));
 #define NPP_LPIPS_LAUNCH(Q, PL)                                                                                      \
   hipLaunchKernelGGL((lpips_layer_kernel<Q, PL>), grid, dim3(256), 0, s, d_f0, d_f1, N, hw, d_lin, d_latents,       \
-                     d_spline, n_knots, x_scale, coef, d_loss, d_df0, d_dlatent)
+                     d_spline, n_knots, x_scale, coef, d_loss, d_df0, d_dlatent, fix)
   if (few) {
     switch (C) {
       case 64: NPP_LPIPS_LAUNCH(1, 4); break;

@@ -206,8 +206,10 @@ class NPPNet:
     def pixel_loss_args(self, Bp, n_rows, gt, mask=None, weight=1.0):
         """The argument tuple of pixel_loss() for a launch that carries the loss along (ops.trunk_patch_in(loss=...))."""
         ws = self._ws[Bp]
+        if getattr(self, "_pl_scratch", None) is None:      # per-block partials + ticket of the fixed-order reduction (one stream)
+            self._pl_scratch = torch.zeros(ops.PIXEL_LOSS_SCRATCH, dtype=torch.float32, device=self.device)
         return (ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale, weight, self.loss_buf,
-                ws["dpred"][:n_rows], self.dlatent)
+                ws["dpred"][:n_rows], self.dlatent, self._pl_scratch)
 
     def optimizer_step(self, Bp):
         """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""

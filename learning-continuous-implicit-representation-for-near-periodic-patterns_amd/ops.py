@@ -94,6 +94,9 @@ def h2d(a, device):
     return _pinned_ring(a, device)
 
 
+PIXEL_LOSS_SCRATCH = 1024 * 7 + 8       # NPP_PIXEL_LOSS_SCRATCH_FLOATS (include/npp_hip.h)
+
+
 def pad_rows(n):
     return (n + NPP_ROW_TILE - 1) // NPP_ROW_TILE * NPP_ROW_TILE
 
@@ -373,10 +376,10 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
     _req(f1, torch.float32, "f1", f0.shape)
     N, C = f0.shape[:2]
     hw = f0.shape[2] * f0.shape[3]
-    key = (f0.device, C)
+    key = (f0.device, C, _stream().value)               # (accumulators of a launch in flight: one workspace per stream)
     ws = _lp_ws.get(key)
     if ws is None:
-        ws = _lp_ws[key] = torch.empty(int(lib().npp_lpips_workspace_bytes(C)), dtype=torch.uint8, device=f0.device)
+        ws = _lp_ws[key] = torch.zeros(int(lib().npp_lpips_workspace_bytes(C)), dtype=torch.uint8, device=f0.device)
     check(lib().npp_lpips_layer(_p(f0), _p(f1), N, C, hw, _p(lin), _p(latents), _p(spline), n_knots, x_scale, scale,
                                 _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")
 
@@ -440,12 +443,13 @@ def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, 
     b = (C.c_float * 3)(*[float(v) for v in shift])
     if loss is not None:
         from ._lib import PixelLossArgs
-        pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent = loss
+        pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent = loss[:11]
+        scratch = loss[11] if len(loss) > 11 else None        # PIXEL_LOSS_SCRATCH floats: fixed-order sums (include/npp_hip.h)
         _req(pred, torch.float32, "pred")
         _req(gt, torch.float32, "gt", pred.shape)
         la = PixelLossArgs(pred.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), pred.shape[0], latents.data_ptr(),
                            spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
-                           dlatent.data_ptr())
+                           dlatent.data_ptr(), None if scratch is None else scratch.data_ptr())
         check(lib().npp_trunk_patch_in_loss(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
                                             _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), int(which), C.byref(la),
                                             _stream()), "npp_trunk_patch_in_loss")
@@ -742,13 +746,13 @@ def trunk_patch_in_loss_stack(pred, row0, crops, cmasks, M, n_p, P, X, N_total, 
     from ._lib import PixelLossArgs
     s = (C.c_float * 3)(*[float(v) for v in scale])
     b = (C.c_float * 3)(*[float(v) for v in shift])
-    pr, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent, n_rows = loss
+    pr, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent, n_rows, scratch = loss
     la = PixelLossArgs(pr.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), int(n_rows), latents.data_ptr(),
                        spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
-                       dlatent.data_ptr())
+                       dlatent.data_ptr(), scratch.data_ptr())
     check(lib().npp_trunk_patch_in_loss_stack(_p(pred), pred.shape[1], row0, _p(crops), crops.stride(0), _p(cmasks), cmasks.stride(0), M,
                                               n_p, P, X, N_total, s, b, _p(x0), _p(xy), 0 if xy is None else xy.stride(0), _p(zero),
-                                              _p(it), C.byref(la), gt_stride, lat_stride, loss_stride, _stream()),
+                                              _p(it), C.byref(la), gt_stride, lat_stride, loss_stride, scratch.stride(0), _stream()),
           "npp_trunk_patch_in_loss_stack")
 
 

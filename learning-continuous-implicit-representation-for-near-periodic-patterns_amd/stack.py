@@ -59,6 +59,7 @@ class StackedFit:
         self.latents, self.lat_m, self.lat_v, self.dlatent = (torch.zeros((M, 8), dtype=f32, device=dev) for _ in range(4))
         self.loss_bufs = torch.zeros((M, 2), dtype=f32, device=dev)
         self.patch_loss = torch.zeros(M, dtype=f32, device=dev)
+        self.pl_scratch = torch.zeros((M, ops.PIXEL_LOSS_SCRATCH), dtype=f32, device=dev)
         self.actF = torch.empty((M, sizes[1]), dtype=u8, device=dev)
         self.dzF = torch.empty((M, sizes[2]), dtype=u8, device=dev)
         self.gslabs = torch.empty((M, sizes[3] // 4), dtype=f32, device=dev)
@@ -182,7 +183,7 @@ class StackedFit:
         sc, sh = cx.input_norm()
         net0 = fits[0].net
         loss = (self.pred, self.gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
-                self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix)
+                self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix, self.pl_scratch)
         t = cx.hip_trunk
         with_lp = [i for i, b in enumerate(batches) if b is not None and it[i].with_lp]
         ops.trunk_patch_in_loss_stack(self.pred, self.n_pix, self.crops, self.cmasks, M, self.n_p, self.P, X, self.N_total, sc, sh,

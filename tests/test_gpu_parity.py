@@ -728,6 +728,30 @@ def test_training_step_is_bit_reproducible(dev):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_complete_iteration_is_bit_reproducible(dev):
+    """Round 4: no float atomics left on the path of the complete iteration -- the contextual core sums its channel-tile partials in
+    a fixed order, the pixel loss and its latent gradients are summed by the last-arriving block in block order, the LPIPS head adds
+    fixed-point integers -- so two runs of the same 30 iterations (all three patch sources, the LPIPS branch on its side stream)
+    end at identical bits: network parameters, Adam moments, pixel-loss and LPIPS latents."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 3
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    outs = []
+    for rep in range(2):
+        fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev, N_rand=4096,
+                            shifts=shifts, seed=4)
+        seen = set()
+        for _ in range(30):
+            if fit.step_full():
+                seen.add(fit.last_source)
+        torch.cuda.synchronize()
+        assert seen == {"val", "train", "same"}
+        outs.append([t.clone() for t in (fit.net.params, fit.net.m, fit.net.v, fit.net.latents, fit.percepLoss._lat)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_minimal_and_ragged_batches(dev):
     """One 64-row tile (the smallest launch) and a batch that is not a multiple of the tile."""
     K, H = 3, 256
@@ -932,7 +956,7 @@ def test_two_row_group_step_equals_the_single_stream_step(dev, source):
     assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
 
 
-def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20):
+def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20, loss_tol_all=0.05):
     """Shared body of the g8r / g8s / g8d tests: sampler decisions call by call, weighted patch loss of the first iterations value
     by value (the goldens use the stable tie order, tests/golden/make_golden_fit_tasks.py), PSNR checkpoints within BASELINE's
     0.1 dB, pixel-loss latents, LR clock.  The loss values are compared over the first 20 iterations: the contextual core reduces
@@ -942,6 +966,7 @@ def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20):
     ploss = {int(r[0]): r[1] for r in g["patch_loss"]}
     code = {"val": 0, "train": 1, "same": 2}
     n_same = 0
+    dev_all = []
     for i in range(1, n_iters + 1):
         ok = fit.step_full()
         d = fit.last_draw
@@ -949,12 +974,22 @@ def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20):
         assert ok == (d["k"] > 0) == (i in ploss)
         if ok:
             n_same += d["source"] == "same"
+            got = float(fit.last_patch_loss[0])
+            dev_all.append((abs(got - ploss[i]) / abs(ploss[i]), i, d["source"]))
             if i <= n_loss:
-                got = float(fit.last_patch_loss[0])
                 assert abs(got - ploss[i]) < loss_tol * abs(ploss[i]), (i, d["source"], got, ploss[i])
         if i in traj:
             pk, pu = fit.psnr("known"), fit.psnr("unknown")
             assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i])
+    # round 4: the contextual core, the pixel loss and the LPIPS head no longer reduce with float atomics, so the patch loss of
+    # EVERY iteration is a reproducible number of THIS code (test_complete_iteration_is_bit_reproducible).  Against the reference's
+    # values the later iterations still cannot be asserted value by value: once the loss is 1e-7-sized it is a sum over arg-max
+    # assignments that flip under fp32 round-off differences between two correct implementations (worst single iteration 70 % at
+    # iteration 40 of g8s); the median deviation over the whole run is what is asserted.
+    worst = max(dev_all)
+    med = float(np.median([v[0] for v in dev_all]))
+    print(f"patch loss vs reference over {len(dev_all)} iterations: worst {worst[0]:.3%} at iteration {worst[1]} ({worst[2]}), median {med:.3%}")
+    assert med < loss_tol_all, (med, worst)
     assert fit.net.global_step == int(g["global_step"])
     np.testing.assert_allclose(fit.net.latents.cpu().numpy(), np.concatenate([g["latent_alpha"], g["latent_scale"]], 1).reshape(-1),
                                atol=3e-3)
