@@ -218,7 +218,10 @@ int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gs
                            int n_slabs, int64_t slab_stride, float* d_lat, float* d_lat_m,
                            float* d_lat_v, float* d_dlat, int n_lat, float* d_zero, int n_zero,
                            float lr, float beta1, float beta2, float eps, int step, int K, int width,
-                           void* d_wf, void* d_wb, void* stream);
+                           void* d_wf, void* d_wb, float* d_pl_partials, float* d_loss_cur, void* stream);
+/* (d_pl_partials, nullable: the scratch of the iteration's pixel-loss launch, npp_pixel_loss_args.scratch -- its per-block sums
+ *  are added, in block order, to the latent gradients before the latents' step and to d_loss_cur[0], the iteration's pixel-loss
+ *  accumulator.) */
 int npp_pack_scatter_host(const float* params, void* wf, void* wb, int K, int width);
 
 /* Same step with step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) read from device memory
@@ -332,14 +335,15 @@ int npp_trunk_patch_in(const float* d_pred_rows, const float* d_fake, const floa
                        float* d_zero, int n_zero, int which, void* stream);
 /* The same launch also computing npp_pixel_loss (the arguments of that entry point, in a struct): the two consumers of
  * the forward launch's prediction (train.py:195 and :200-236) are independent, so they share one launch. */
-#define NPP_PIXEL_LOSS_SCRATCH_FLOATS (1024 * 7 + 8)
+#define NPP_PIXEL_LOSS_SCRATCH_FLOATS (1024 * 8 + 8)
 typedef struct {
   const float* pred; const float* gt; const float* mask; int64_t N;
   const float* latents; const float* spline; int32_t n_knots; float x_scale, weight;
   float* loss; float* dpred; float* dlatent;
-  /* nullable.  NPP_PIXEL_LOSS_SCRATCH_FLOATS floats, ZEROED once by the caller and then owned by ONE stream: with it the loss
-   * and the latent gradients are summed over the launch's blocks in a fixed order (bit-reproducible); without it by float
-   * atomics in arrival order. */
+  /* nullable.  NPP_PIXEL_LOSS_SCRATCH_FLOATS floats, ZEROED once by the caller and then owned by ONE stream.  Given: the launch
+   * leaves its per-block partial sums there and does NOT touch loss / dlatent; the Adam launch of the iteration
+   * (npp_adam_step_net_pack(_stack), d_pl_partials = this buffer) adds them in block order -- bit-reproducible, and the
+   * reduction costs no ticket, fence or launch.  NULL: float atomics onto loss / dlatent in arrival order. */
   float* scratch;
 } npp_pixel_loss_args;
 int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
@@ -437,6 +441,12 @@ int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, int64_t row0,
 int npp_cx_fwd_bwd_groups(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, float scale,
                           float* d_loss, int loss_stride, float* d_dfx, const void* d_iter, int M, void* d_workspace,
                           int64_t workspace_bytes, void* stream);
+/* npp_cx_fwd_bwd(_groups) delivering dL/dx where the trunk's data-gradient pass reads it: the flat bf16 tensor d_dz (geometry
+ * N_total x C x H x W, npp_trunk_act_bytes), gated by the ReLU of the tapped layer (d_yact: its flat fp16 output) -- one launch
+ * instead of the core's last one + npp_trunk_grad_in.  d_scratch_dfx (N, C, H*W) fp32: workspace.  M = 0: one group. */
+int npp_cx_fwd_bwd_flat(const float* d_fx, const float* d_fy, int N, int C, int H, int W, float band_width, float scale,
+                        float* d_loss, int loss_stride, float* d_scratch_dfx, const void* d_yact, void* d_dz, int N_total,
+                        const void* d_iter, int M, void* d_workspace, int64_t workspace_bytes, void* stream);
 /* npp_mlp_bwd_patch over M images: d_dx_a = dL/d(trunk batch) (only the leading X images are read: image m's at x0),
  * d_dx_b (M, 2 n_p kmax, 3, P, P) nullable = the LPIPS branch's gradient of the images with with_lp set. */
 int npp_mlp_bwd_patch_stack(float* d_dpred, const float* d_pred, int64_t Bp, int M, int K, int width, const void* d_wb,
@@ -453,7 +463,8 @@ int npp_adam_step_net_pack_stack(float* d_p, float* d_m, float* d_v, int64_t blo
                                  int n_slabs, int64_t slab_stride, int64_t slab_img_stride, float* d_lat, float* d_lat_m,
                                  float* d_lat_v, float* d_dlat, int n_lat, int lat_stride, float* d_zero, int n_zero,
                                  int zero_stride, float beta1, float beta2, float eps, int M, int K, int width, void* d_wf,
-                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, const void* d_iter, void* stream);
+                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, float* d_pl_partials,
+                                 int64_t pl_stride, float* d_loss_cur, const void* d_iter, void* stream);
 
 /* ---- generic dense layers (exact fp32), SURVEY.md 8 f1 -------------------------- */
 /* What F.linear + SnakeActivation (models/activations.py:29-35) and their autograd do for topologies the fused chain

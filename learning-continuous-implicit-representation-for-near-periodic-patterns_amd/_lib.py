@@ -105,7 +105,7 @@ SYMBOLS = {
     "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
                                  _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_adam_step_net_pack": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
-                                      _f32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp]),
+                                      _f32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_pack_scatter_host": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "npp_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "npp_patch_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
@@ -120,11 +120,12 @@ SYMBOLS = {
     "npp_trunk_patch_in_loss_stack": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float),
                                              C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, C.POINTER(PixelLossArgs), _i64, _i32, _i32, _i64, _vp]),
     "npp_cx_fwd_bwd_groups": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "npp_cx_fwd_bwd_flat": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "npp_mlp_bwd_patch_stack": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp,
                                        _i64, _i64, _i32, _i32, _vp, _vp]),
     "npp_mlp_wgrad_stack": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "npp_adam_step_net_pack_stack": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32,
-                                            _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+                                            _i32, _f32, _f32, _f32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "npp_selftest_mfma": (_i32, [_vp, _vp]),
     "npp_shift_search": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "npp_rng_create": (_vp, [C.c_uint32]),

@@ -138,6 +138,7 @@ struct AdamPackArgs {
   const StackIter* iter;
   int64_t blob_stride, slab_img_stride, wf_stride, wb_stride;      // floats, floats, bf16 elements, bf16 elements
   int32_t lat_stride, zero_stride;                                 // floats
+  int64_t pl_stride;
 };
 
 __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a_in, NetDesc d_arg, BwdDesc b_arg) {
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a_in, NetDe
     a.step_size = it.step_size; a.inv_sqrt_bc2 = it.inv_sqrt_bc2;
     a.tail.p += y * a.lat_stride; a.tail.m += y * a.lat_stride; a.tail.v += y * a.lat_stride; a.tail.g += y * a.lat_stride;
     a.tail.zero += y * a.zero_stride;
+    if (a.tail.pl_part) a.tail.pl_part += y * a.pl_stride;
+    if (a.tail.loss_cur) a.tail.loss_cur += y * a.zero_stride;
   }
   // the descriptors are indexed with per-lane layer numbers: LDS copies (filled with compile-time indices, so that the
   // by-value kernel arguments never need a scratch copy)
@@ -425,7 +428,7 @@ int npp_pack_scatter_host(const float* params, void* wf, void* wb, int K, int wi
 int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,
                            int64_t slab_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, int n_lat,
                            float* d_zero, int n_zero, float lr, float beta1, float beta2, float eps, int step, int K,
-                           int width, void* d_wf, void* d_wb, void* stream) {
+                           int width, void* d_wf, void* d_wb, float* d_pl_partials, float* d_loss_cur, void* stream) {
   int rc = check_kw(K, width);
   if (rc) return rc;
   const NetDesc d = make_desc(K);
@@ -440,7 +443,7 @@ int npp_adam_step_net_pack(float* d_p, float* d_m, float* d_v, const float* d_gs
   AdamPackArgs a{};
   a.p = d_p; a.m = d_m; a.v = d_v; a.g = d_gslabs; a.n = n; a.n_slabs = n_slabs; a.slab_stride = slab_stride;
   a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
-  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
+  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero, d_pl_partials, d_loss_cur};
   a.wf = (__bf16*)d_wf; a.wb = (__bf16*)d_wb;
   for (int l = 0; l < kNumLayers; ++l) a.magic[l] = d.present[l] ? (uint32_t)((1ull << 32) / (uint64_t)d.n_in[l]) + 1u : 0u;
   const int64_t threads = (n + 3) / 4;
@@ -453,7 +456,8 @@ int npp_adam_step_net_pack_stack(float* d_p, float* d_m, float* d_v, int64_t blo
                                  int n_slabs, int64_t slab_stride, int64_t slab_img_stride, float* d_lat, float* d_lat_m,
                                  float* d_lat_v, float* d_dlat, int n_lat, int lat_stride, float* d_zero, int n_zero,
                                  int zero_stride, float beta1, float beta2, float eps, int M, int K, int width, void* d_wf,
-                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, const void* d_iter, void* stream) {
+                                 int64_t wf_stride_bytes, void* d_wb, int64_t wb_stride_bytes, float* d_pl_partials,
+                                 int64_t pl_stride, float* d_loss_cur, const void* d_iter, void* stream) {
   int rc = check_kw(K, width);
   if (rc) return rc;
   const NetDesc d = make_desc(K);
@@ -468,7 +472,8 @@ int npp_adam_step_net_pack_stack(float* d_p, float* d_m, float* d_v, int64_t blo
   AdamPackArgs a{};
   a.p = d_p; a.m = d_m; a.v = d_v; a.g = d_gslabs; a.n = n; a.n_slabs = n_slabs; a.slab_stride = slab_stride;
   a.b1 = beta1; a.b2 = beta2; a.eps = eps;
-  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero};
+  a.tail = AdamTail{d_lat, d_lat_m, d_lat_v, d_dlat, n_lat, d_zero, n_zero, d_pl_partials, d_loss_cur};
+  a.pl_stride = pl_stride;
   a.wf = (__bf16*)d_wf; a.wb = (__bf16*)d_wb;
   a.iter = (const StackIter*)d_iter;
   a.blob_stride = blob_stride; a.slab_img_stride = slab_img_stride; a.wf_stride = wf_stride_bytes / 2; a.wb_stride = wb_stride_bytes / 2;

@@ -198,12 +198,22 @@ struct AdamTail {
   int n;
   float* zero;
   int n_zero;
+  // round 4: the pixel loss of the iteration left its per-block partial sums in `pl_part` (PixelLossArgs::scratch) instead of
+  // adding them to g / the loss word by atomics in arrival order; this block -- the consumer of g, one launch boundary later --
+  // sums them in block order: bit-reproducible and free (no ticket, no fence, no extra launch).  Nullable.
+  float* pl_part;
+  float* loss_cur;      // the iteration's pixel-loss accumulator (+= the partial losses), nullable
 };
+constexpr int kPixelLossScratch = 1024 * 8 + 8;       // [block][8] partials (7 used) + the block count in the last word
 __device__ __forceinline__ void adam_tail_block(const AdamTail& tail, float step_size, float b1, float b2, float inv_sqrt_bc2,
                                                 float eps) {
   const int t = threadIdx.x;
+  int nb = 0;
+  if (tail.pl_part) nb = (int)__float_as_uint(tail.pl_part[kPixelLossScratch - 1]);
   for (int i = t; i < tail.n; i += blockDim.x) {
-    const float gi = tail.g[i];
+    float gi = tail.g[i];
+    if (i < 6)
+      for (int b = 0; b < nb; ++b) gi += tail.pl_part[b * 8 + 1 + i];          // block order
     const float mi = b1 * tail.m[i] + (1.0f - b1) * gi;
     const float vi = b2 * tail.v[i] + (1.0f - b2) * gi * gi;
     tail.m[i] = mi;
@@ -211,7 +221,14 @@ __device__ __forceinline__ void adam_tail_block(const AdamTail& tail, float step
     tail.p[i] = tail.p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     tail.g[i] = 0.0f;
   }
+  if (nb > 0 && t == 64) {                               // (another wave than the latents': the two sums run side by side)
+    float l = 0.0f;
+    for (int b = 0; b < nb; ++b) l += tail.pl_part[b * 8];
+    if (tail.loss_cur) tail.loss_cur[0] += l;
+  }
   for (int i = t; i < tail.n_zero; i += blockDim.x) tail.zero[i] = 0.0f;
+  __syncthreads();
+  if (nb > 0 && t == 0) tail.pl_part[kPixelLossScratch - 1] = 0.0f;          // consumed
 }
 __device__ __forceinline__ float adam_update(float p, float& m, float& v, float g, float step_size, float b1, float b2,
                                              float inv_sqrt_bc2, float eps) {
@@ -473,28 +490,26 @@ struct PixelLossArgs {
   const float* pred; const float* gt; const float* mask; int64_t N;
   const float* latents; const float* spline; int n_knots; float x_scale, weight;
   float* loss_out; float* dpred; float* dlatent;
-  float* scratch;      // nullable: kPixelLossScratch floats, word [kPixelLossScratch - 1] a zero-initialised ticket counter
+  float* scratch;      // nullable: kPixelLossScratch floats.  Given: the launch leaves its per-block partial sums there (loss_out /
+                       // dlatent untouched) for the Adam launch of the iteration to add in block order (AdamTail::pl_part)
 };
-constexpr int kPixelLossScratch = 1024 * 7 + 8;
-// Cross-block reduction in a FIXED order (round 4): every block stores its partials, the block that draws the last ticket sums
-// them -- cdna_hip_programming.md "In-launch split-K reduction": plain stores, vmcnt drain, barrier, ONE agent-scope release and
-// a relaxed agent-scope ticket by lane 0; the last arriver takes one agent-scope acquire before anybody in it loads (correct
-// for any placement of the blocks over the XCDs).  Call from every thread of every block after its partial stores; true in the
-// whole block that arrived last (which also re-arms the counter).
+// Cross-block reduction in a FIXED order inside one launch: every block publishes its partials, the block that draws the last
+// ticket sums them.  cdna_hip_programming.md Guideline 16, form R1 without fences: the (few, small) partials are written with
+// relaxed agent-scope atomic stores (share_store: write-through, visible from every XCD once the storing wave's vmcnt has drained)
+// and read back with relaxed agent-scope atomic loads (share_load: past this CU's L1 and this XCD's L2) -- an agent-scope release
+// fence would write back the XCD's whole L2.  Call from every thread of every block after its share_store()s; true in the whole
+// block that arrived last (which re-arms the counter).  The counter must be zero before the first launch that uses it.
+// (Where the consumer of a sum is a LATER launch, leave the partials to it instead: AdamTail::pl_part.)
+__device__ __forceinline__ void share_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float share_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool block_last_arriver(unsigned* counter, int nb) {
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its partials have left for memory
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == (unsigned)nb - 1u;
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   return s_last != 0;
@@ -544,17 +559,13 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
   }
   __syncthreads();
   if (a.scratch) {
-    // deterministic form: per-block partials, summed in block order by the last arriver (single writer: plain accumulation)
-    if (threadIdx.x < 7) a.scratch[bid * 7 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (!block_last_arriver((unsigned*)(a.scratch + kPixelLossScratch - 1), nb)) return;
+    // deterministic form: this block's seven sums, scaled as they enter the totals, for the Adam launch to add in block order
     if (threadIdx.x < 7) {
       const int k = threadIdx.x;
-      float v = 0.0f;
-      for (int b = 0; b < nb; ++b) v += a.scratch[b * 7 + k];
-      if (k == 0) a.loss_out[0] += weight * v * inv;
-      else if (k < 4) a.dlatent[k - 1] += weight * inv * v * cp[k - 1].dalpha_dl;
-      else a.dlatent[3 + (k - 4)] += weight * inv * v * cp[k - 4].dc_dl;
+      const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      a.scratch[bid * 8 + k] = k == 0 ? weight * v * inv : k < 4 ? weight * inv * v * cp[k - 1].dalpha_dl : weight * inv * v * cp[k - 4].dc_dl;
     }
+    if (bid == 0 && threadIdx.x == 8) a.scratch[kPixelLossScratch - 1] = __uint_as_float((unsigned)nb);
     return;
   }
   if (threadIdx.x < 7) {

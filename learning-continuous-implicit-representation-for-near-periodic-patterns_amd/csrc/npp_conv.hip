@@ -31,11 +31,10 @@
 #include <string.h>
 
 #include "npp_common.h"
+#include "npp_trunk_layout.h"
 
 namespace npp {
 
-constexpr int kConvGuard = 1024;      // zero units before / after the position axis (>= W + 3): images up to 1021 wide
-                                      // (the loop's patches are <= 160; the proposal ranking scores crops of whole images)
 // k-steps of operand fragments in flight per wave (3 or 9: must divide the 9 taps).  9 = a whole input-channel step ahead.
 // Timed alone in a loop (operands warm in L2) the depth makes no difference; INSIDE the iteration, where a layer's weights
 // were last touched 0.7 ms / 1.5 GB of traffic ago and its input was just written from another XCD, depth 9 is worth
@@ -45,16 +44,6 @@ constexpr int kConvGuard = 1024;      // zero units before / after the position 
 #endif
 constexpr int kConvRing = NPP_CONV_RING;
 static_assert(kConvRing == 3 || kConvRing == 9, "ring depth");
-constexpr int kPosRound = 512;        // position count is rounded up to a multiple of this
-
-NPP_HD int64_t conv_npos_round(int N, int H, int W) {
-  const int64_t s = (int64_t)N * (H + 2) * (W + 2);
-  return (s + kPosRound - 1) / kPosRound * kPosRound;
-}
-NPP_HD int64_t conv_nposp(int N, int H, int W) { return conv_npos_round(N, H, W) + 2 * kConvGuard; }
-
-// true channel of element j of chunk c8 in the stored (accumulator) order
-NPP_HD int conv_chan(int c8, int j) { return 32 * (c8 >> 2) + 16 * ((c8 >> 1) & 1) + perm16(c8 & 1, j); }
 
 enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2 };
 

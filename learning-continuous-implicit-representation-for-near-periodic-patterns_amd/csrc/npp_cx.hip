@@ -20,6 +20,7 @@
 //   dw = (G - A_i)/s_i ; dDt = -dw w / h ; dD = dDt/(m_i + 1e-5) - [j == argmin_j D_ij] sum_j dDt D/(m_i+1e-5)^2
 //   draw = -dD on 0 < raw < 1 ; dxh = draw yh^T ; dx = (dxh - xh (xh . dxh)) / |x - mu|.
 #include "npp_common.h"
+#include "npp_trunk_layout.h"
 
 namespace npp {
 
@@ -50,6 +51,8 @@ struct CxWs {           // workspace carve (floats unless noted)
   unsigned* cmax;       // [N*hw]  column max of cx as float bits
   float* dot;           // [dot_slots][N*hw]  xh . dxh per position, one partial per channel tile (summed in fixed order)
   float* g;             // [N]     dL/dcxn / J
+  float* lsum;          // [N]     the samples' loss terms (summed per group by the last block of cx_loss_kernel)
+  unsigned* ticket;     // arrival counter of that reduction (cleared by cx_mean_kernel)
   float* inx;           // [N*hw]  1 / max(sqrt(ssx), 1e-12)  (written by cx_loss_kernel, read by the backward kernels)
   float* iny;           // [N*hw]
   float* D;             // [N*hw*hw]
@@ -73,7 +76,7 @@ __device__ __forceinline__ const float* cx_mu(const CxWs& w, int n) {
 }
 
 __host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
-  return (int64_t)NPP_MAX_STACK * (C + 16) + (7LL + C / 32) * N * hw + N + 2LL * N * hw * hw + 64;
+  return (int64_t)NPP_MAX_STACK * (C + 16) + (7LL + C / 32) * N * hw + 2LL * N + 2LL * N * hw * hw + 128;
 }
 
 __host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter = nullptr, int M = 0) {
@@ -89,6 +92,8 @@ __host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter =
   w.cmax = (unsigned*)p; p += nh;
   w.dot = p; p += nh * w.dot_slots;
   w.g = p; p += (N + 15) / 16 * 16;
+  w.lsum = p; p += (N + 15) / 16 * 16;
+  w.ticket = (unsigned*)p; p += 16;
   w.inx = p; p += nh;
   w.iny = p; p += nh;
   w.D = p; p += nh * hw;
@@ -123,6 +128,7 @@ __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw
   __syncthreads();
   if (threadIdx.x == 0 && ng > 0) w.mu[(int64_t)grp * w.mu_stride + c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)ng * hw);
   if (grp) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *w.ticket = 0u;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)N * hw; t += (int64_t)gridDim.x * blockDim.x) {
     w.dmin[t] = 0x7f800000u;   // +inf
     w.cmax[t] = 0u;
@@ -132,9 +138,10 @@ __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw
 // sum over channels of (x - mu)^2, (y - mu)^2 per position: block = 64 positions x 4 channel lanes walking ALL channels
 // (round 4: the partial sums of four channel-group blocks used to meet in float atomics, whose order made the whole
 // iteration irreproducible to the last bit; one block per position tile sums in a fixed order).
-__global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
-                                                       int C, int hw, CxWs w) {
-  __shared__ float red[2][4][64];
+constexpr int kCxSsLanes = 16;
+__global__ __launch_bounds__(64 * kCxSsLanes) void cx_sumsq_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
+                                                                  int C, int hw, CxWs w) {
+  __shared__ float red[2][kCxSsLanes][64];
   const int pl = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int64_t t = (int64_t)blockIdx.x * 64 + pl;
   const bool live = t < (int64_t)N * hw;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__
   float sx = 0.0f, sy = 0.0f;
   const float* mu = cx_mu(w, n);
   if (live)
-    for (int c = cl; c < C; c += 4) {
+    for (int c = cl; c < C; c += kCxSsLanes) {
       const float m = mu[c];
       const float a = x[((int64_t)n * C + c) * hw + p] - m, b = y[((int64_t)n * C + c) * hw + p] - m;
       sx = fmaf(a, a, sx);
@@ -151,9 +158,11 @@ __global__ __launch_bounds__(256) void cx_sumsq_kernel(const float* __restrict__
   red[0][cl][pl] = sx;
   red[1][cl][pl] = sy;
   __syncthreads();
-  if (cl == 0 && live) {
-    w.ssx[t] = red[0][0][pl] + red[0][1][pl] + red[0][2][pl] + red[0][3][pl];
-    w.ssy[t] = red[1][0][pl] + red[1][1][pl] + red[1][2][pl] + red[1][3][pl];
+  if (cl < 2 && live) {                                 // wave 0 sums x, wave 1 sums y: the 16 lanes' partials in lane order
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kCxSsLanes; ++q) v += red[cl][q][pl];
+    (cl ? w.ssy : w.ssx)[t] = v;
   }
 }
 
@@ -344,42 +353,47 @@ __global__ __launch_bounds__(256) void cx_rows_fwd_big_kernel(int N, int hw, flo
   }
 }
 
-// per group: for each of its samples cxn = mean_j cmax, l_n = -log(cxn [* weight] + 1e-5) [/ N_group], g = dL/dcxn / J; the group's
-// loss is summed over its samples in index order and added to loss[group * loss_stride] ONCE (round 4: one atomic per sample from
-// N blocks summed in arrival order).  Also the inverse norms of every position, once instead of once per use.
+// per sample (one block each): cxn = mean_j cmax, l_n = -log(cxn [* weight] + 1e-5) [/ N_group], g = dL/dcxn / J, and the inverse
+// norms of the sample's positions (once instead of once per use).  The block that arrives last adds each group's l_n in sample
+// order to loss[group * loss_stride] (round 4: one float atomic per sample in arrival order before).
 __global__ void cx_loss_kernel(int N, int hw, const float* __restrict__ weight, float scale, float* __restrict__ loss,
                                int loss_stride, CxWs w) {
   __shared__ float red[4];
-  const int grp = blockIdx.x;
-  const int n0 = w.iter ? w.iter[grp].x0 : 0, ng = w.iter ? w.iter[grp].nk : N;
-  float total = 0.0f;
-  for (int n = n0; n < n0 + ng; ++n) {
-    float acc = 0.0f;
-    for (int j = threadIdx.x; j < hw; j += blockDim.x) {
-      acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
-      w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);
-      w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    __syncthreads();                                    // (red is re-used from sample to sample)
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float cxn = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
-      float l, dcxn;
-      if (weight) {                       // functional.py:55-57: sum(-log(cx * w + 1e-5))
-        const float wt = weight[n];
-        l = -logf(cxn * wt + 1e-5f);
-        dcxn = -wt / (cxn * wt + 1e-5f);
-      } else {                            // mean over samples
-        l = -logf(cxn + 1e-5f) / (float)ng;
-        dcxn = -1.0f / ((float)ng * (cxn + 1e-5f));
-      }
-      total += scale * l;
-      w.g[n] = scale * dcxn / (float)hw;
-    }
+  const int n = blockIdx.x;
+  int ng;
+  cx_group(w, n, ng);
+  float acc = 0.0f;
+  for (int j = threadIdx.x; j < hw; j += blockDim.x) {
+    acc += __uint_as_float(w.cmax[(int64_t)n * hw + j]);
+    w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);
+    w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
   }
-  if (threadIdx.x == 0 && ng > 0) atomicAdd(loss + (int64_t)grp * loss_stride, total);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float cxn = (red[0] + red[1] + red[2] + red[3]) / (float)hw;
+    float l, dcxn;
+    if (weight) {                       // functional.py:55-57: sum(-log(cx * w + 1e-5))
+      const float wt = weight[n];
+      l = -logf(cxn * wt + 1e-5f);
+      dcxn = -wt / (cxn * wt + 1e-5f);
+    } else {                            // mean over the group's samples
+      l = -logf(cxn + 1e-5f) / (float)ng;
+      dcxn = -1.0f / ((float)ng * (cxn + 1e-5f));
+    }
+    share_store(w.lsum + n, scale * l);
+    w.g[n] = scale * dcxn / (float)hw;
+  }
+  if (!block_last_arriver(w.ticket, N)) return;
+  const int groups = w.iter ? w.M : 1;
+  if ((int)threadIdx.x < groups) {
+    const int grp = threadIdx.x;
+    const int n0 = w.iter ? w.iter[grp].x0 : 0, cnt = w.iter ? w.iter[grp].nk : N;
+    float total = 0.0f;
+    for (int q = n0; q < n0 + cnt; ++q) total += share_load(w.lsum + q);
+    if (cnt > 0) atomicAdd(loss + (int64_t)grp * loss_stride, total);
+  }
 }
 
 // one wave per row: cx row -> d raw row (in place).
@@ -524,6 +538,43 @@ __global__ void cx_dx_finish_kernel(const float* __restrict__ x, int N, int C, i
   float dot = 0.0f;
   for (int q = 0; q < n_dot; ++q) dot += w.dot[(int64_t)q * N * hw + (int64_t)n * hw + p];     // fixed order
   dx[t] = (dx[t] - (x[t] - cx_mu(w, n)[c]) * inx * dot) * inx;
+}
+
+// The same finish written STRAIGHT into the trunk's flat bf16 gradient tensor (npp_trunk_layout.h), gated by the ReLU of the tapped
+// layer: dz = dx * [y > 0] -- what cx_dx_finish_kernel + npp_trunk_grad_in did in two launches and an fp32 round trip
+// (round 4).  One thread = one 16-byte unit (8 channels of one position): the position's dot product and inverse norm are
+// formed once per unit.  Border / tail positions of the run are rewritten as zeros (the layout's invariant).
+__global__ void cx_dx_finish_flat_kernel(const float* __restrict__ x, const float* __restrict__ dxh, int N, int C, int H, int W,
+                                         CxWs w, const f16x8* __restrict__ yact, bf16x8* __restrict__ dz, int64_t nposp,
+                                         int64_t npos_range, int n_dot) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int chunks = C / 8;
+  if (t >= npos_range * chunks) return;
+  const int c8 = (int)(t / npos_range);
+  const int64_t p = t - (int64_t)c8 * npos_range;
+  const int Wp = W + 2, S = (H + 2) * Wp, hw = H * W;
+  const int n = (int)(p / S), r = (int)(p - (int64_t)n * S), yy = r / Wp, xx = r - yy * Wp;
+  const int64_t u = (int64_t)c8 * nposp + kConvGuard + p;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)0.0f;
+  if (n < N && yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+    const int pos = (yy - 1) * W + (xx - 1);
+    const int64_t np = (int64_t)n * hw + pos;
+    const float inx = inv_norm(w.ssx[np]);
+    float dot = 0.0f;
+    for (int q = 0; q < n_dot; ++q) dot += w.dot[(int64_t)q * N * hw + np];          // fixed order
+    const float* mu = cx_mu(w, n);
+    const f16x8 m = yact[u];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = conv_chan(c8, j);
+      const int64_t e = ((int64_t)n * C + c) * hw + pos;
+      const float v = (dxh[e] - (x[e] - mu[c]) * inx * dot) * inx;
+      o[j] = (__bf16)((float)m[j] > 0.0f ? v : 0.0f);
+    }
+  }
+  dz[u] = o;
 }
 
 // ---- second-generation backward contraction and row pass (hw % 32 == 0) ---------------------------------------
@@ -680,9 +731,14 @@ extern "C" int64_t npp_cx_workspace_bytes(int N, int C, int hw) {
   return 4 * cx_ws_floats(N, C, hw);
 }
 
+struct CxFlatOut {        // optional: dL/dx * [y > 0] into the trunk's flat bf16 gradient tensor instead of fp32 d_dfx
+  const void* yact;       // flat fp16 activations of the tapped layer (N_total images of H x W, C channels)
+  void* dz;               // flat bf16 gradient tensor, same geometry
+  int N_total, H, W;
+};
 static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, const float* d_weight,
                      float scale, float* d_loss, int loss_stride, float* d_dfx, void* d_workspace, int64_t workspace_bytes,
-                     const void* d_iter, int M, void* stream, const char* who) {
+                     const void* d_iter, int M, void* stream, const char* who, const CxFlatOut* flat = nullptr) {
   if (!d_fx || !d_fy || !d_loss || !d_workspace || N < 1 || C < 32 || (C % 32) || hw < 1 || !(band_width > 0.0f) ||
       (int64_t)N * hw * hw > 0x7fffffffLL * 8 || M < 0 || M > NPP_MAX_STACK || (M > 0 && !d_iter)) {
     set_error("%s: bad arguments (N=%d C=%d hw=%d M=%d)", who, N, C, hw, M);
@@ -695,7 +751,7 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
   const int64_t nh = (int64_t)N * hw;
   const float inv_h = 1.0f / band_width;
   hipLaunchKernelGGL(cx_mean_kernel, dim3(C, groups), dim3(256), 0, s, d_fy, N, C, hw, w);
-  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
+  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64 * kCxSsLanes), 0, s, d_fx, d_fy, N, C, hw, w);
   const int tiles = (hw + 63) / 64;
   const bool big = hw > 64 * kCxMaxCols;     // whole-image crops: the generic kernels, column-chunked row pass
   const bool fast = !big && (hw % 32) == 0;  // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
@@ -715,7 +771,7 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
     if (big) hipLaunchKernelGGL(cx_rows_fwd_big_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     else hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
   }
-  hipLaunchKernelGGL(cx_loss_kernel, dim3(groups), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, loss_stride, w);
+  hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, loss_stride, w);
   if (d_dfx) {
     hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     const int ctiles = (C + 63) / 64;
@@ -726,6 +782,15 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
     else
       hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,
                          d_dfx);
+    if (flat) {
+      if (!flat->yact || !flat->dz || flat->H * flat->W != hw || N > flat->N_total || C % 16) {
+        set_error("%s: bad flat-output description", who); return NPP_ERR_ARG;
+      }
+      const int64_t range = conv_npos_round(N, flat->H, flat->W), nt = range * (C / 8);
+      hipLaunchKernelGGL(cx_dx_finish_flat_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d_fx, d_dfx, N, C, flat->H, flat->W,
+                         w, (const f16x8*)flat->yact, (bf16x8*)flat->dz, conv_nposp(flat->N_total, flat->H, flat->W), range, C / 32);
+      return check_launch(who);
+    }
     const int64_t ne = nh * C;
     hipLaunchKernelGGL(cx_dx_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, d_fx, N, C, hw, w, d_dfx, C / 32);
   }
@@ -748,4 +813,17 @@ extern "C" int npp_cx_fwd_bwd_groups(const float* d_fx, const float* d_fy, int N
   if (M < 1) { set_error("npp_cx_fwd_bwd_groups: M=%d", M); return NPP_ERR_ARG; }
   return cx_launch(d_fx, d_fy, N, C, hw, band_width, nullptr, scale, d_loss, loss_stride, d_dfx, d_workspace, workspace_bytes, d_iter,
                    M, stream, "npp_cx_fwd_bwd_groups");
+}
+
+// npp_cx_fwd_bwd / npp_cx_fwd_bwd_groups with the gradient delivered where the trunk's data-gradient pass reads it: the flat bf16
+// tensor d_dz (geometry: N_total images of H x W, C channels; npp_trunk_act_bytes), already gated by the ReLU of the tapped layer
+// (d_yact = that layer's flat fp16 output) -- replaces the last launch of the core + npp_trunk_grad_in.  d_scratch_dfx (N, C, H W)
+// fp32 receives the un-normalised contraction (workspace of the call).  M = 0 / d_iter = NULL: one group of N samples.
+extern "C" int npp_cx_fwd_bwd_flat(const float* d_fx, const float* d_fy, int N, int C, int H, int W, float band_width, float scale,
+                                   float* d_loss, int loss_stride, float* d_scratch_dfx, const void* d_yact, void* d_dz, int N_total,
+                                   const void* d_iter, int M, void* d_workspace, int64_t workspace_bytes, void* stream) {
+  if (!d_scratch_dfx) { set_error("npp_cx_fwd_bwd_flat: null scratch"); return NPP_ERR_ARG; }
+  const CxFlatOut flat{d_yact, d_dz, N_total, H, W};
+  return cx_launch(d_fx, d_fy, N, C, H * W, band_width, nullptr, scale, d_loss, loss_stride, d_scratch_dfx, d_workspace, workspace_bytes,
+                   d_iter, M, stream, "npp_cx_fwd_bwd_flat", &flat);
 }

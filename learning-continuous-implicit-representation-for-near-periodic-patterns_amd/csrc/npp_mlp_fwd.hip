@@ -657,20 +657,24 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
   }
 }
 
-template <bool TRAIN, bool MULTI, bool EMB_IN = false>
-__global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_in, EmbedDev e_arg, NetDesc d) {
+// STACK: the stacked-launch form (npp_mlp_fwd_stack).  A template parameter, not a run-time branch: the plain launch keeps reading
+// its pointers from the kernel-argument segment where it needs them -- as locals they cost the training forward 3-4 us of SGPR
+// pressure in a kernel that already spills 40 of them.
+template <bool TRAIN, bool MULTI, bool EMB_IN = false, bool STACK = false>
+__global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  FwdArgs A_ = A_in;
-  int img_, wg, xslot_, xcount_;
-  if (!stack_decode(A_.S, img_, wg, xslot_, xcount_)) return;
-  const int n_wg_ = A_.S.M ? A_.S.n_items : (int)gridDim.x;
-  if (A_.S.M) {
-    A_.coords += (int64_t)img_ * A_.Bp * 2;
-    A_.wf += (int64_t)img_ * A_.wf_stride16;
-    A_.params += (int64_t)img_ * A_.params_stride;
-    A_.pred += (int64_t)img_ * A_.Bp * 3;
-    if (A_.actF) A_.actF += (int64_t)img_ * A_.act_stride;
-  }
+  int img_ = 0, wg = blockIdx.x, xslot_ = blockIdx.x >> 3, xcount_ = ((int)gridDim.x + 7) >> 3;
+  if (STACK && !stack_decode(A_.S, img_, wg, xslot_, xcount_)) return;
+  const int n_wg_ = STACK ? A_.S.n_items : (int)gridDim.x;
+  // per-image offsets of a stacked launch (compile-time zeros otherwise)
+  const int64_t o_coords = STACK ? (int64_t)img_ * A_.Bp * 2 : 0, o_wf = STACK ? (int64_t)img_ * A_.wf_stride16 : 0;
+  const int64_t o_params = STACK ? (int64_t)img_ * A_.params_stride : 0, o_pred = STACK ? (int64_t)img_ * A_.Bp * 3 : 0;
+  const int64_t o_act = STACK ? (int64_t)img_ * A_.act_stride : 0;
+#define s_coords (A_.coords + o_coords)
+#define s_wf (A_.wf + o_wf)
+#define s_params (A_.params + o_params)
+#define s_pred (A_.pred + o_pred)
+#define s_actF (A_.actF + o_act)
   char* R0 = smem;
   char* R1 = smem + kRegionBytes;
   float* sV = (float*)(smem + 2 * kRegionBytes);
@@ -684,9 +688,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   float* sRGB = (float*)R0;             // [4 waves][64 rows][3], reused after the last barrier
   if (threadIdx.x == 0) {
     uint32_t* dst = (uint32_t*)&ed;
-    if (A_.S.M) {
+    if (STACK) {
       const uint32_t* src = (const uint32_t*)(A_.estack + img_);
-#pragma unroll
+#pragma unroll 1                 // (global memory: any index will do)
       for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
     } else {
       const uint32_t* src = (const uint32_t*)&e_arg;
@@ -719,22 +723,22 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   L.n_wg = n_wg_; L.xslot = xslot_; L.xcount = xcount_;
   const int64_t row0 = (int64_t)wg * kRowTile;
   const int64_t Bp = A_.Bp;
-  const float* P = A_.params;
+  const float* P = s_params;
   const int nt0 = kNTW * L.wave;         // this wave's neuron tiles in 256-wide layers
 
   if (!EMB_IN && L.tid < kRowTile) {
-    const int2 c = ((const int2*)A_.coords)[row0 + L.tid];
+    const int2 c = ((const int2*)s_coords)[row0 + L.tid];
     sY[L.tid] = (float)c.x;              // (row=y, col=x)
     sX[L.tid] = (float)c.y;
   }
   wg_barrier();
 
-  auto arow = [&](int idx) -> char* { return TRAIN ? A_.actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr; };
+  auto arow = [&](int idx) -> char* { return TRAIN ? s_actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr; };
 
   f32x16 acc[kNTW][kNB];
   WRing<kNTW> ring;                           // weight-stream register ring, live across layers
   WRing<1> ringp;                          // same for P (one neuron tile per wave)
-  ring.rsrc = ringp.rsrc = make_wrsrc(A_.wf, d.wf_total16);
+  ring.rsrc = ringp.rsrc = make_wrsrc(s_wf, d.wf_total16);
   constexpr wptr_t U = kNT * 64;           // 16-byte units per k-step of a 256-wide layer
   constexpr wptr_t UP = (kNT / 2) * 64;
   constexpr int A = kKSAct;                // 16 k-steps per 256 features
@@ -751,13 +755,13 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     int64_t line = (int64_t)L.xslot * kThreads + L.tid;
 #pragma unroll
     for (int q = 0; q < NPP_FWD_PREFETCH_LINES; ++q, line += per_xcd_threads)
-      pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)A_.wf + line * 128) : 0u;
+      pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)s_wf + line * 128) : 0u;
   }
   STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
   WRING_FILL(kNTW, kNT, ring, wl(L0), nt0, L);
   init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
-  mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, A_.actF, wg, L, ring);
+  mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, s_actF, wg, L, ring);
   STAMP(1);
   BiasPre<kNTW> bn;
   BiasPre<1> bnp;
@@ -788,12 +792,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   if (!EMB_IN && kOverlapPro) {
     // h part FIRST: sV still holds proposal 0's warped coordinates (written for L0, nothing else touches it), so chunk 0 of
     // the embedding part is generated in the gaps of these 16 k-steps instead of in an exposed prologue
-    mma_plain_gen_chunk0<false, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, A_.actF, wg, L, ring);
+    mma_plain_gen_chunk0<false, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, s_actF, wg, L, ring);
     STAMP(20);
     wg_barrier();
-    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, A_.actF, wg, L, ring, true, true);
+    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, s_actF, wg, L, ring, true, true);
   } else {
-    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, A_.actF, wg, L, ring);
+    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, s_actF, wg, L, ring);
     STAMP(20);
     MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   }
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, 1, sV, sY, sX, L, pos); };
       MMA_RING<0, A / 2, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring, warp_hook);
       wg_barrier();
-      mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, A_.actF, wg, L, ring);
+      mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, s_actF, wg, L, ring);
       wg_barrier();
     } else {
       MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
       mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
-                                   A_.actF, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
+                                   s_actF, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
                                    /*next_warp_p=*/(kOverlapPro && p + 1 < d.K) ? p + 1 : -1);
     }
     WRING_FILL(kNTW, kNT, ring, wl(LF2), nt0, L);        // flies under the epilogue
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   if (p_wave)
-    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? A_.actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
+    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? s_actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
                              wg, L);
 
   STAMP(40);
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       for (int w = 0; w < kNT / 2; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];   // P's neuron tiles, in order
       float o = 1.0f / (1.0f + __expf(-z));                         // helpers.py:56 sigmoid
       if (EMB_IN && A_.out_act != 1) o = A_.out_act == 2 ? tanhf(z) : z;   // helpers.py:57-58 tanh / raw network output
-      A_.pred[(row0 + row) * 3 + c] = o;
+      s_pred[(row0 + row) * 3 + c] = o;
     }
   }
   STAMP(41);
@@ -961,6 +965,12 @@ extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
 }
 #endif
+
+#undef s_coords
+#undef s_wf
+#undef s_params
+#undef s_pred
+#undef s_actF
 
 static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, bool emb_in, void* stream, const char* who) {
   const dim3 grid(A.S.M ? stack_grid(A.S) : (unsigned)(A.Bp / kRowTile)), block(kThreads);
@@ -979,7 +989,16 @@ static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, boo
     if (train) { if (multi) NPP_LAUNCH(true, true, E); else NPP_LAUNCH(true, false, E); }         \
     else { if (multi) NPP_LAUNCH(false, true, E); else NPP_LAUNCH(false, false, E); }             \
   } while (0)
-  if (emb_in) NPP_LAUNCH2(true); else NPP_LAUNCH2(false);
+  if (A.S.M) {                            // stacked launch: training form, coordinates in
+    static SmemOnce once_s[2];
+    if (multi) {
+      if (!smem_attr(once_s[0], (const void*)mlp_fwd_kernel<true, true, false, true>, kSmemFwd)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
+      hipLaunchKernelGGL((mlp_fwd_kernel<true, true, false, true>), grid, block, kSmemFwd, s, A, e, d);
+    } else {
+      if (!smem_attr(once_s[1], (const void*)mlp_fwd_kernel<true, false, false, true>, kSmemFwd)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
+      hipLaunchKernelGGL((mlp_fwd_kernel<true, false, false, true>), grid, block, kSmemFwd, s, A, e, d);
+    }
+  } else if (emb_in) NPP_LAUNCH2(true); else NPP_LAUNCH2(false);
 #undef NPP_LAUNCH2
 #undef NPP_LAUNCH
   return check_launch(who);

@@ -202,9 +202,11 @@ class HipTrunk:
             cur = y
         return outs
 
-    def _backward(self, gtaps, n, scale, xshape, zero_rest=True):
+    def _backward(self, gtaps, n, scale, xshape, zero_rest=True, top_writer=None):
         """dL/dx for the first n images from the tap gradients.  zero_rest=False leaves images >= n of the
-        returned tensor uninitialised (callers that only read [:n])."""
+        returned tensor uninitialised (callers that only read [:n]).  top_writer(y, N, n, c, H, W, dz): the producer of the TOP
+        tap's gradient writes the flat gated tensor dz itself (ops.cx_fwd_bwd_flat) instead of handing over an fp32 tensor for
+        npp_trunk_grad_in; its entry in gtaps is then just a non-None placeholder."""
         N = xshape[0]
         dimg = (torch.zeros if zero_rest else torch.empty)(xshape, dtype=torch.float32, device=self.device)
         if n == 0:
@@ -233,8 +235,11 @@ class HipTrunk:
         y, c, H, W = self._geom[j]
         cur = gbuf(c, H, W)
         if self.layers[j]["kind"] == "conv":
-            ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur,         # dz_j = dL/dtap * [y > 0]
-                              next_pack=self.layers[j]["pb"] if self.prefetch_next else None)
+            if top_writer is not None:
+                top_writer(y, N, n, c, H, W, cur)
+            else:
+                ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur,     # dz_j = dL/dtap * [y > 0]
+                                  next_pack=self.layers[j]["pb"] if self.prefetch_next else None)
             state = "dz"
         else:
             ops.trunk_grad_in(tap_of[j], None, N, n, c, H, W, cur)
@@ -293,6 +298,9 @@ def contextual_loss(x, y, band_width=0.5, weight=None, loss_type="cosine"):
     return _CXFunction.apply(x, y, float(band_width), weight)
 
 
+_CX_FLAT = os.environ.get("NPP_CX_FLAT", "1") != "0"     # 0: the separate cx_dx_finish + npp_trunk_grad_in launches (comparator)
+
+
 class ContextualLoss(nn.Module):
     _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)        # contextual.py:41-46
 
@@ -337,8 +345,14 @@ class ContextualLoss(nn.Module):
         t = self.hip_trunk
         sc, sh = self.input_norm()
         f = t._forward(xy, sc, sh, x0_ready)[0]
+        shape = tuple(xy) if x0_ready else tuple(xy.shape)
+        if weight is None and _CX_FLAT:
+            # the core's last launch writes the trunk's flat gradient tensor itself (no fp32 dL/dfeatures, no npp_trunk_grad_in)
+            def top(y, N, nn, c, H, W, dz):
+                ops.cx_fwd_bwd_flat(f[:n], f[n:], y, dz, N, self.band_width, scale, loss_buf)
+            return t._backward([True], n, sc, shape, zero_rest=False, top_writer=top)
         _, dfx = ops.cx_fwd_bwd(f[:n], f[n:], self.band_width, weight, scale, loss_buf, True)
-        return t._backward([dfx], n, sc, tuple(xy) if x0_ready else tuple(xy.shape), zero_rest=False)
+        return t._backward([dfx], n, sc, shape, zero_rest=False)
 
 
     # ---- the two halves of the contextual batch as separate passes (round 3) -----------------------------------------------

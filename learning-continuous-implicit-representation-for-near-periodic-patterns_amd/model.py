@@ -206,10 +206,12 @@ class NPPNet:
     def pixel_loss_args(self, Bp, n_rows, gt, mask=None, weight=1.0):
         """The argument tuple of pixel_loss() for a launch that carries the loss along (ops.trunk_patch_in(loss=...))."""
         ws = self._ws[Bp]
-        if getattr(self, "_pl_scratch", None) is None:      # per-block partials + ticket of the fixed-order reduction (one stream)
+        if getattr(self, "_pl_scratch", None) is None and ops.DETERMINISTIC and self.fused_repack:
+            # the launch leaves its per-block partial sums here; the fused Adam launch of the iteration (_adam) adds them in block
+            # order: bit-reproducible sums at no cost (include/npp_hip.h npp_pixel_loss_args.scratch)
             self._pl_scratch = torch.zeros(ops.PIXEL_LOSS_SCRATCH, dtype=torch.float32, device=self.device)
         return (ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale, weight, self.loss_buf,
-                ws["dpred"][:n_rows], self.dlatent, self._pl_scratch)
+                ws["dpred"][:n_rows], self.dlatent, getattr(self, "_pl_scratch", None))
 
     def optimizer_step(self, Bp):
         """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""
@@ -225,8 +227,11 @@ class NPPNet:
         """optimizer.step() over the blob + latents and the re-pack of the bf16 MFMA packs: one launch (fused_repack, default)
         or two (npp_adam_step_net, then npp_pack_weights: the comparator)."""
         if self.fused_repack:
+            # (the pixel-loss launch of a folded iteration left its block partials in _pl_scratch: summed here in block order;
+            #  the buffer's count word is zero whenever no such launch ran since the last step)
             ops.adam_step_net_pack(self.params, self.m, self.v, gslabs, n_slabs, stride, self.latents, self.lat_m, self.lat_v,
-                                   self.dlatent, idle, self.lr, self.opt_step, self.K, self.wf, self.wb, self.width)
+                                   self.dlatent, idle, self.lr, self.opt_step, self.K, self.wf, self.wb, self.width,
+                                   pl_partials=getattr(self, "_pl_scratch", None), loss_cur=self.loss_buf)
         else:
             ops.adam_step_net(self.params, self.m, self.v, gslabs, n_slabs, stride, self.latents, self.lat_m, self.lat_v,
                               self.dlatent, idle, self.lr, self.opt_step)

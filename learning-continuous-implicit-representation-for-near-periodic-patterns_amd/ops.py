@@ -94,7 +94,9 @@ def h2d(a, device):
     return _pinned_ring(a, device)
 
 
-PIXEL_LOSS_SCRATCH = 1024 * 7 + 8       # NPP_PIXEL_LOSS_SCRATCH_FLOATS (include/npp_hip.h)
+PIXEL_LOSS_SCRATCH = 1024 * 8 + 8       # NPP_PIXEL_LOSS_SCRATCH_FLOATS (include/npp_hip.h)
+# 0: the float-atomic reductions of the pixel loss and the LPIPS head (arrival order; the A/B comparator of the fixed-order forms)
+DETERMINISTIC = __import__("os").environ.get("NPP_DETERMINISTIC", "1") != "0"
 
 
 def pad_rows(n):
@@ -296,12 +298,15 @@ def adam_step_net(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat
 
 
 def adam_step_net_pack(p, m, v, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat, zero, lr, step, K, wf, wb, width=NPP_WIDTH,
-                       b1=0.9, b2=0.999, eps=1e-8):
-    """adam_step_net + pack_weights in one launch: the updated weights are scattered into the bf16 packs wf / wb as well."""
+                       b1=0.9, b2=0.999, eps=1e-8, pl_partials=None, loss_cur=None):
+    """adam_step_net + pack_weights in one launch: the updated weights are scattered into the bf16 packs wf / wb as well.
+    pl_partials / loss_cur: the per-block sums the iteration's pixel-loss launch left in its scratch are added here, in block order,
+    to the latent gradients and to the iteration's loss accumulator (include/npp_hip.h npp_pixel_loss_args.scratch)."""
     _req(p, torch.float32, "p")
     check(lib(width).npp_adam_step_net_pack(_p(p), _p(m), _p(v), _p(gslabs), p.numel(), n_slabs, slab_stride, _p(lat), _p(lat_m),
                                             _p(lat_v), _p(dlat), lat.numel(), _p(zero), 0 if zero is None else zero.numel(),
-                                            lr, b1, b2, eps, step, K, width, _p(wf), _p(wb), _stream()), "npp_adam_step_net_pack", width)
+                                            lr, b1, b2, eps, step, K, width, _p(wf), _p(wb), _p(pl_partials), _p(loss_cur), _stream()),
+          "npp_adam_step_net_pack", width)
 
 
 def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True, out=None):
@@ -378,7 +383,7 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
     hw = f0.shape[2] * f0.shape[3]
     key = (f0.device, C, _stream().value)               # (accumulators of a launch in flight: one workspace per stream)
     ws = _lp_ws.get(key)
-    if ws is None:
+    if ws is None and DETERMINISTIC:
         ws = _lp_ws[key] = torch.zeros(int(lib().npp_lpips_workspace_bytes(C)), dtype=torch.uint8, device=f0.device)
     check(lib().npp_lpips_layer(_p(f0), _p(f1), N, C, hw, _p(lin), _p(latents), _p(spline), n_knots, x_scale, scale,
                                 _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")
@@ -774,6 +779,27 @@ def cx_fwd_bwd_groups(fx, fy, it, M, band_width, scale, loss, loss_stride=1):
     return dfx
 
 
+def cx_fwd_bwd_flat(fx, fy, yact, dz, N_total, band_width, scale, loss, loss_stride=1, it=None, M=0):
+    """The contextual core with dL/dx written straight into the trunk's flat bf16 gradient tensor dz, gated by [yact > 0] (yact: the
+    tapped layer's flat fp16 output; both of geometry N_total x C x H x W) -- no fp32 gradient tensor, no npp_trunk_grad_in launch.
+    it / M: sample groups of a stacked launch (cx_fwd_bwd_groups)."""
+    _req(fx, torch.float32, "fx")
+    _req(fy, torch.float32, "fy", fx.shape)
+    N, Cc, H, W = fx.shape
+    nbytes = lib().npp_cx_workspace_bytes(N, Cc, H * W)
+    check(nbytes, "npp_cx_workspace_bytes")
+    key = (fx.device, int(nbytes))
+    ws = _cx_ws.get(key)
+    if ws is None:
+        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
+    key2 = (fx.device, "dxh", N * Cc * H * W)
+    dxh = _cx_ws.get(key2)
+    if dxh is None:
+        dxh = _cx_ws[key2] = torch.empty(N * Cc * H * W, dtype=torch.float32, device=fx.device)
+    check(lib().npp_cx_fwd_bwd_flat(_p(fx), _p(fy), N, Cc, H, W, band_width, scale, _p(loss), loss_stride, _p(dxh), _p(yact), _p(dz),
+                                    N_total, _p(it), M, _p(ws), int(nbytes), _stream()), "npp_cx_fwd_bwd_flat")
+
+
 def mlp_bwd_patch_stack(dpred, pred, M, K, wb, params, actF, dzF, dx_a, dx_b, cmasks, row0, n_p, P, it, width=NPP_WIDTH):
     check(lib(width).npp_mlp_bwd_patch_stack(_p(dpred), _p(pred), pred.shape[1], M, K, width, _p(wb), wb.stride(0), _p(params),
                                              params.stride(0), _p(actF), actF.stride(0), _p(dzF), dzF.stride(0), _p(dx_a), _p(dx_b),
@@ -787,9 +813,10 @@ def mlp_wgrad_stack(dzF, actF, Bp, M, K, ksplit, gslabs, it, width=NPP_WIDTH):
 
 
 def adam_step_net_pack_stack(p, m, v, n, gslabs, n_slabs, slab_stride, lat, lat_m, lat_v, dlat, n_lat, zero, M, K, wf, wb, it,
-                             width=NPP_WIDTH, b1=0.9, b2=0.999, eps=1e-8):
+                             pl_partials, loss_cur, width=NPP_WIDTH, b1=0.9, b2=0.999, eps=1e-8):
     """p / m / v (M, stride) blobs, gslabs (M, n_slabs * slab_stride), lat.. (M, >= n_lat), zero (M, n_zero): image m's idle accumulators."""
     check(lib(width).npp_adam_step_net_pack_stack(_p(p), _p(m), _p(v), p.stride(0), _p(gslabs), n, n_slabs, slab_stride, gslabs.stride(0),
                                                   _p(lat), _p(lat_m), _p(lat_v), _p(dlat), n_lat, lat.stride(0), _p(zero),
                                                   zero.shape[1], zero.stride(0), b1, b2, eps, M, K, width, _p(wf), wf.stride(0), _p(wb),
-                                                  wb.stride(0), _p(it), _stream()), "npp_adam_step_net_pack_stack", width)
+                                                  wb.stride(0), _p(pl_partials), pl_partials.stride(0), _p(loss_cur), _p(it), _stream()),
+          "npp_adam_step_net_pack_stack", width)

@@ -200,8 +200,10 @@ class StackedFit:
                     self.dxb[i, :nk].copy_(dxb[:nk])
         shape = (self.N_total, 3, self.P, self.P)
         feats = t._forward(shape, sc, sh, True, n_run=2 * X)[0]
-        dfx = ops.cx_fwd_bwd_groups(feats[:X], feats[X:2 * X], it_dev, M, cx.band_width, self.cx_w, self.patch_loss)
-        dx_a = t._backward([dfx], X, sc, shape, zero_rest=False)
+
+        def top(y, N, nn, c, H, W, dz):                   # the core's last launch writes the trunk's flat gradient tensor itself
+            ops.cx_fwd_bwd_flat(feats[:X], feats[X:2 * X], y, dz, N, cx.band_width, self.cx_w, self.patch_loss, 1, it_dev, M)
+        dx_a = t._backward([True], X, sc, shape, zero_rest=False, top_writer=top)
         if with_lp:
             main.wait_stream(self._s_lp)
         ops.mlp_bwd_patch_stack(self.dpred, self.pred, M, K, self.wb, self.params, self.actF, self.dzF, dx_a,
@@ -209,7 +211,8 @@ class StackedFit:
         ops.mlp_wgrad_stack(self.dzF, self.actF, self.Bp, M, K, self.ksplit, self.gslabs, it_dev, W)
         idle = self.loss_bufs[:, 1 - self.loss_idx:2 - self.loss_idx]
         ops.adam_step_net_pack_stack(self.params, self.m, self.v, self.n_params, self.gslabs, self.ksplit, self.slab_stride,
-                                     self.latents, self.lat_m, self.lat_v, self.dlatent, 6, idle, M, K, self.wf, self.wb, it_dev, W)
+                                     self.latents, self.lat_m, self.lat_v, self.dlatent, 6, idle, M, K, self.wf, self.wb, it_dev,
+                                     self.pl_scratch, self.loss_bufs[:, self.loss_idx:], W)
         self._clean = True
         self._stale = [i for i, b in enumerate(batches) if b is None]
         for i, (f, b) in enumerate(zip(fits, batches)):
