@@ -76,7 +76,7 @@ __device__ __forceinline__ const float* cx_mu(const CxWs& w, int n) {
 }
 
 __host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
-  return (int64_t)NPP_MAX_STACK * (C + 16) + (7LL + C / 32) * N * hw + 2LL * N + 2LL * N * hw * hw + 128;
+  return (int64_t)NPP_MAX_STACK * (C + 16) + (7LL + C / 32) * N * hw + 3LL * N + 2LL * N * hw * hw + 160;
 }
 
 __host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter = nullptr, int M = 0) {
@@ -93,7 +93,7 @@ __host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter =
   w.dot = p; p += nh * w.dot_slots;
   w.g = p; p += (N + 15) / 16 * 16;
   w.lsum = p; p += (N + 15) / 16 * 16;
-  w.ticket = (unsigned*)p; p += 16;
+  w.ticket = (unsigned*)p; p += (N + 1 + 15) / 16 * 16;      // [0]: cx_loss_kernel, [1 + n]: sample n's row blocks
   w.inx = p; p += nh;
   w.iny = p; p += nh;
   w.D = p; p += nh * hw;
@@ -128,41 +128,11 @@ __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw
   __syncthreads();
   if (threadIdx.x == 0 && ng > 0) w.mu[(int64_t)grp * w.mu_stride + c] = (red[0] + red[1] + red[2] + red[3]) / (float)((int64_t)ng * hw);
   if (grp) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *w.ticket = 0u;
+  if (blockIdx.x == 0)
+    for (int q = threadIdx.x; q <= N; q += blockDim.x) w.ticket[q] = 0u;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (int64_t)N * hw; t += (int64_t)gridDim.x * blockDim.x) {
     w.dmin[t] = 0x7f800000u;   // +inf
     w.cmax[t] = 0u;
-  }
-}
-
-// sum over channels of (x - mu)^2, (y - mu)^2 per position: block = 64 positions x 4 channel lanes walking ALL channels
-// (round 4: the partial sums of four channel-group blocks used to meet in float atomics, whose order made the whole
-// iteration irreproducible to the last bit; one block per position tile sums in a fixed order).
-constexpr int kCxSsLanes = 16;
-__global__ __launch_bounds__(64 * kCxSsLanes) void cx_sumsq_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
-                                                                  int C, int hw, CxWs w) {
-  __shared__ float red[2][kCxSsLanes][64];
-  const int pl = threadIdx.x & 63, cl = threadIdx.x >> 6;
-  const int64_t t = (int64_t)blockIdx.x * 64 + pl;
-  const bool live = t < (int64_t)N * hw;
-  const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
-  float sx = 0.0f, sy = 0.0f;
-  const float* mu = cx_mu(w, n);
-  if (live)
-    for (int c = cl; c < C; c += kCxSsLanes) {
-      const float m = mu[c];
-      const float a = x[((int64_t)n * C + c) * hw + p] - m, b = y[((int64_t)n * C + c) * hw + p] - m;
-      sx = fmaf(a, a, sx);
-      sy = fmaf(b, b, sy);
-    }
-  red[0][cl][pl] = sx;
-  red[1][cl][pl] = sy;
-  __syncthreads();
-  if (cl < 2 && live) {                                 // wave 0 sums x, wave 1 sums y: the 16 lanes' partials in lane order
-    float v = 0.0f;
-#pragma unroll
-    for (int q = 0; q < kCxSsLanes; ++q) v += red[cl][q][pl];
-    (cl ? w.ssy : w.ssx)[t] = v;
   }
 }
 
@@ -216,13 +186,25 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  // Round 4: the squared norms sum_c (x - mu)^2, (y - mu)^2 of the tile's 64 + 64 positions are summed HERE, from the centred
+  // operands every thread stages anyway (2 rows x 4 columns per chunk), instead of in a launch of their own (cx_sumsq_kernel:
+  // 7 us of launch ramp for 0.2 us of arithmetic).  Every tile sums in the same order, so the tiles of a row agree bit for bit.
+  float qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
+  auto sq = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      qa[0] = fmaf(ra[r].x, ra[r].x, qa[0]); qa[1] = fmaf(ra[r].y, ra[r].y, qa[1]); qa[2] = fmaf(ra[r].z, ra[r].z, qa[2]); qa[3] = fmaf(ra[r].w, ra[r].w, qa[3]);
+      qb[0] = fmaf(rb[r].x, rb[r].x, qb[0]); qb[1] = fmaf(rb[r].y, rb[r].y, qb[1]); qb[2] = fmaf(rb[r].z, rb[r].z, qb[2]); qb[3] = fmaf(rb[r].w, rb[r].w, qb[3]);
+    }
+  };
   gload(0);
+  sq();
   sstore(0);
   __syncthreads();
   int buf = 0;
   for (int c0 = 0; c0 < C; c0 += kCxKc) {
     const bool has_next = c0 + kCxKc < C;
-    if (has_next) gload(c0 + kCxKc);
+    if (has_next) { gload(c0 + kCxKc); sq(); }
 #pragma unroll
     for (int ks = 0; ks < kCxKc / 2; ++ks) {
       const float a = sA[buf][2 * ks + kh][wi * 32 + l31];
@@ -233,17 +215,36 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     __syncthreads();
     buf ^= 1;
   }
+  // the 16 row classes' partials (thread tid holds rows tid >> 4 and 16 + (tid >> 4) of every chunk) meet in LDS, summed in class order
+  float* ssl = &sA[0][0][0];                           // [2][16][64] floats: the operand buffers are idle now
+  {
+    const int cls = tid >> 4, col = (tid & 15) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ssl[(0 * 16 + cls) * 64 + col + e] = qa[e]; ssl[(1 * 16 + cls) * 64 + col + e] = qb[e]; }
+  }
+  __syncthreads();
+  float* ssn = &sB[0][0][0];                           // [2][64]: the tile's squared norms (x positions | y positions)
+  if (tid < 128) {
+    const int which = tid >> 6, col = tid & 63;
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += ssl[(which * 16 + q) * 64 + col];
+    ssn[which * 64 + col] = v;
+    const int pos = (which ? j0 : i0) + col;
+    if (pos < hw && (which ? i0 : j0) == 0) (which ? w.ssy : w.ssx)[(int64_t)n * hw + pos] = v;      // one tile column / row publishes them
+  }
+  __syncthreads();
   // accumulator: column (lane & 31) = j, register r = row acc_row(r, lane >> 5) = i.  The row
   // minimum is reduced over the 32 columns of the half-wave first: one atomic per row and wave
   // instead of one per element (the element-wise form was atomic-bound: 2 M atomics per call).
   const int j = j0 + wj * 32 + l31;
-  const float sj = j < hw ? inv_norm(w.ssy[(int64_t)n * hw + j]) : 0.0f;
+  const float sj = j < hw ? inv_norm(ssn[64 + wj * 32 + l31]) : 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + wi * 32 + acc_row(r, kh);
     float d = 2.0f;                                  // neutral for the minimum (D <= 1)
     if (i < hw && j < hw) {
-      const float raw = acc[r] * inv_norm(w.ssx[(int64_t)n * hw + i]) * sj;
+      const float raw = acc[r] * inv_norm(ssn[wi * 32 + acc_row(r, kh)]) * sj;
       d = 1.0f - fminf(fmaxf(raw, 0.0f), 1.0f);
       w.D[((int64_t)n * hw + i) * hw + j] = d;
     }
@@ -397,8 +398,15 @@ __global__ void cx_loss_kernel(int N, int hw, const float* __restrict__ weight, 
 }
 
 // one wave per row: cx row -> d raw row (in place).
-__global__ __launch_bounds__(256) void cx_rows_bwd_kernel(int N, int hw, float inv_h, CxWs w) {
+__global__ __launch_bounds__(256) void cx_rows_bwd_kernel(int N, int hw, float inv_h, CxWs w, float* __restrict__ loss, int loss_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (loss && blockIdx.x == 0 && (int)threadIdx.x < (w.iter ? w.M : 1)) {     // the groups' loss sums, in sample order (lsum: previous launch)
+    const int grp = threadIdx.x;
+    const int n0 = w.iter ? w.iter[grp].x0 : 0, cnt = w.iter ? w.iter[grp].nk : N;
+    float total = 0.0f;
+    for (int q = n0; q < n0 + cnt; ++q) total += w.lsum[q];
+    if (cnt > 0) atomicAdd(loss + (int64_t)grp * loss_stride, total);
+  }
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= (int64_t)N * hw) return;
   const int n = (int)(row / hw);
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ 
 // per column and block.
 constexpr int kCxRowsPerWave = 1;
 constexpr int kCxRowWaves = 16;
-__global__ __launch_bounds__(64 * kCxRowWaves) void cx_rows_fwd32_kernel(int N, int hw, float inv_h, CxWs w) {
+__global__ __launch_bounds__(64 * kCxRowWaves) void cx_rows_fwd32_kernel(int N, int hw, float inv_h, CxWs w, float scale, int with_loss) {
   extern __shared__ float scm[];                         // [16 waves][hw]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blocks_per_n = (hw + kCxRowWaves * kCxRowsPerWave - 1) / (kCxRowWaves * kCxRowsPerWave);
@@ -706,6 +714,30 @@ __global__ __launch_bounds__(64 * kCxRowWaves) void cx_rows_fwd32_kernel(int N, 
     for (int v = 1; v < kCxRowWaves; ++v) m = fmaxf(m, scm[v * hw + j]);
     atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(m));
   }
+  if (!with_loss) return;
+  // Round 4: what cx_loss_kernel did in a launch of its own (5 us of ramp), done by the block of the sample that finishes last:
+  // the sample's column maxima are complete then -> cxn, its loss term, dL/dcxn, and the inverse norms of its positions.
+  if (!block_last_arriver(w.ticket + 1 + n, blocks_per_n)) return;
+  float acc = 0.0f;
+  for (int j = threadIdx.x; j < hw; j += 64 * kCxRowWaves) {
+    acc += __uint_as_float(__hip_atomic_load(&w.cmax[(int64_t)n * hw + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    w.inx[(int64_t)n * hw + j] = inv_norm(w.ssx[(int64_t)n * hw + j]);
+    w.iny[(int64_t)n * hw + j] = inv_norm(w.ssy[(int64_t)n * hw + j]);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __syncthreads();
+  if (lane == 0) scm[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+#pragma unroll
+    for (int v = 0; v < kCxRowWaves; ++v) tot += scm[v];
+    const float cxn = tot / (float)hw;
+    int ng;
+    cx_group(w, n, ng);
+    w.lsum[n] = scale * (-logf(cxn + 1e-5f) / (float)ng);        // (mean over the group's samples; the weighted form keeps cx_loss_kernel)
+    w.g[n] = scale * (-1.0f / ((float)ng * (cxn + 1e-5f))) / (float)hw;
+  }
 }
 
 }  // namespace npp
@@ -751,10 +783,10 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
   const int64_t nh = (int64_t)N * hw;
   const float inv_h = 1.0f / band_width;
   hipLaunchKernelGGL(cx_mean_kernel, dim3(C, groups), dim3(256), 0, s, d_fy, N, C, hw, w);
-  hipLaunchKernelGGL(cx_sumsq_kernel, dim3((unsigned)((nh + 63) / 64)), dim3(64 * kCxSsLanes), 0, s, d_fx, d_fy, N, C, hw, w);
   const int tiles = (hw + 63) / 64;
   const bool big = hw > 64 * kCxMaxCols;     // whole-image crops: the generic kernels, column-chunked row pass
   const bool fast = !big && (hw % 32) == 0;  // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
+  const bool loss_in_rows = fast && d_dfx && !d_weight;      // the loss terms ride in the row pass, their group sums in the backward row pass
   const int t32 = hw / 32;
   if (fast) {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
@@ -764,16 +796,17 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
       set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(cx_rows_fwd32_kernel, dim3((unsigned)((int64_t)N * ((hw + kCxRowWaves - 1) / kCxRowWaves))), dim3(64 * kCxRowWaves), smem, s, N,
-                       hw, inv_h, w);
+                       hw, inv_h, w, scale, (int)loss_in_rows);
   } else {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
     const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
     if (big) hipLaunchKernelGGL(cx_rows_fwd_big_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
     else hipLaunchKernelGGL(cx_rows_fwd_kernel, dim3((unsigned)((row_groups + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
   }
-  hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, loss_stride, w);
+  if (!loss_in_rows) hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, s, N, hw, d_weight, scale, d_loss, loss_stride, w);
   if (d_dfx) {
-    hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w);
+    hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w, loss_in_rows ? d_loss : nullptr,
+                       loss_stride);
     const int ctiles = (C + 63) / 64;
     if (fast) {
       const int64_t nb_dx = (int64_t)N * t32 * ((C / 32 + 3) / 4);
