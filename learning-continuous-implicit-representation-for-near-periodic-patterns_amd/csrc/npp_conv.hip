@@ -246,6 +246,174 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   asm volatile("" :: "v"(pf_val));
 }
 
+// ---- window-staged form for the position-rich layers (round 4) -----------------------------------------------
+// conv1_1 / conv1_2 / conv2_x see 30-115 k positions and only 1-8 input-channel steps: with operands straight from L2 every
+// MFMA pulls 1 KiB through L1 (0.75 at best), ~260 MB per layer at the ~70 GB/s a CU draws, i.e. the layer is bound by L2 -> CU
+// bandwidth at 4-5 x its MFMA time.  Here a workgroup of 4 waves owns CT x 32 output channels x 256 consecutive flat positions
+// and per input-channel step stages ONCE, through registers into LDS (global_load -> ds_write_b128, double buffered):
+//   * the step's CT x 9 weight fragments (CT x 9 KiB, shared by the 4 waves), and
+//   * ONE input window [p0 - (Wp + 1), p0 + 256 + (Wp + 1)) of the step's two 8-channel chunks: the 9 taps are 9 shifted
+//     ds_read_b128 of that window (a tap is a constant position shift in the flat layout) instead of 9 global fetches.
+// Global bytes per MFMA: (CT x 9 KiB + 2 x (256 + 2 Wp + 2) x 16 B) / (72 CT) = 0.23 KiB at CT = 2, Wp = 98 (1.0 before).
+// LDS per step and workgroup: 33 KiB written, 144 KiB read (256 B/clk) against 1152 cycles of MFMA per SIMD: not array-bound.
+// Round 3 built this with LDS-DMA and measured 2 x SLOWER (LDS-DMA lands ~16 GB/s per CU here); the register path was only argued
+// about.  Measured: see DESIGN.md section 7 / profiles/r04_conv_window_ab.txt.
+constexpr int kWinPos = 256;                       // positions per workgroup (8 position tiles: 2 per wave)
+constexpr int kWinMaxUnits = 640;                  // window units per chunk the register staging is sized for: Wp <= 191
+template <int CT>
+constexpr int win_lds_bytes() { return 2 * (CT * 9 * 1024 + 2 * kWinMaxUnits * 16); }
+
+template <int CT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
+  typedef typename OpT<MODE == kConvFwd>::frag frag_t;
+  typedef typename OpT<MODE == kConvFwd>::elem elem_t;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);      // consecutive position blocks (shared halo rows) on one XCD
+  uint32_t pf_val = 0;
+  if (a.pf) {
+    const int64_t line = ((int64_t)((blockIdx.x >> 3) + blockIdx.y * ((gridDim.x + 7) >> 3)) * blockDim.x + threadIdx.x) * 128;
+    if (line + 4 <= a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
+  }
+  const int tile0 = bid * (kWinPos / 32);
+  const int cot0 = blockIdx.y * CT;
+  const int KS = a.CI * 9;
+  const int halo = a.Wp + 1, WIN = kWinPos + 2 * halo;
+  constexpr int kA = CT * 9 * 1024;                               // bytes of weight fragments per step
+  constexpr int kBuf = kA + 2 * kWinMaxUnits * 16;
+  constexpr int NA = (CT * 9 * 64 + 255) / 256;                    // 16-byte units per thread: weights
+  constexpr int NW = (2 * kWinMaxUnits + 255) / 256;               // ... window (5)
+  const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack), 0, (int)a.pack_bytes, 0x00020000);
+  const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  // per-thread source offsets (bytes) of its units inside a step; -1 = no unit
+  int offA[NA], offW[NW], dstW[NW];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tid + 256 * i;                                   // unit (ct, tap, lane) of the step
+    const int ct = u / 576, r = u - ct * 576;
+    offA[i] = u < CT * 576 ? ((cot0 + ct) * KS) * 1024 + r * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int u = tid + 256 * i;
+    const int chunk = u >= WIN, pos = u - chunk * WIN;
+    const bool ok = u < 2 * WIN;
+    offW[i] = ok ? (int)((((int64_t)chunk * a.nposp) + kConvGuard + (int64_t)tile0 * 32 - halo + pos) * 16) : -1;
+    dstW[i] = kA + (chunk * kWinMaxUnits + pos) * 16;
+  }
+  u32x4_t rAv[NA], rWv[NW];
+  auto gload = [&](int ci) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (offA[i] >= 0 || NA * 256 == CT * 576) rAv[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, offA[i] < 0 ? 0 : offA[i], ci * 9 * 1024, 0);
+    const uint32_t soff = (uint32_t)((int64_t)2 * ci * a.nposp * 16);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) rWv[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, offW[i] < 0 ? 0 : offW[i], (int)soff, 0);
+  };
+  auto sstore = [&](int buf) {
+    char* base = wlds + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (offA[i] >= 0) *(u32x4_t*)(base + (tid + 256 * i) * 16) = rAv[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = rWv[i];
+  };
+  f32x16 acc[CT][2];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
+  // epilogue operands requested before the contraction (ReLU-gate units / bias values), like conv3x3_kernel
+  f16x8 gate[MODE == kConvDgradMask ? CT * 2 : 1][2];
+  float bias_r[MODE == kConvFwd ? CT : 1][16];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    if (MODE == kConvFwd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias_r[ct][r] = a.bias[32 * (cot0 + ct) + acc_row(r, h)];
+    }
+    if (MODE == kConvDgradMask) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int64_t p = (int64_t)(tile0 + 2 * wave + pt) * 32 + b;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int chunk = 4 * (cot0 + ct) + 2 * s + h;
+          if (chunk < a.cout_chunks) gate[ct * 2 + pt][s] = ((const f16x8*)a.mask)[(int64_t)chunk * a.nposp + kConvGuard + p];
+        }
+      }
+    }
+  }
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  const int posw = (kWinPos / 4) * wave + b;                        // this lane's first position inside the workgroup's 256
+  for (int ci = 0; ci < a.CI; ++ci) {
+    const bool has_next = ci + 1 < a.CI;
+    if (has_next) gload(ci + 1);
+    const char* bA = wlds + buf * kBuf;
+    const char* bW = bA + kA + h * kWinMaxUnits * 16;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int shift = (tap / 3) * a.Wp + (tap % 3);
+      frag_t A[CT], B[2];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) A[ct] = *(const frag_t*)(bA + ((ct * 9 + tap) * 64 + lane) * 16);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) B[pt] = *(const frag_t*)(bW + (posw + 32 * pt + shift) * 16);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = mfma16(A[ct], B[pt], acc[ct][pt]);
+    }
+    if (has_next) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- epilogue: the same per-tile finish as conv3x3_kernel
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int64_t p = (int64_t)(tile0 + 2 * wave + pt) * 32 + b;
+      const int n = (int)((uint32_t)p / (uint32_t)a.S);
+      const int r0 = (int)(p - (int64_t)n * a.S);
+      const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
+      const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
+      const int64_t tap_base = (((int64_t)n * a.Ctap) * a.H + (yy - 1)) * a.W + (xx - 1);
+      const int cot = cot0 + ct;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = 4 * cot + 2 * s + h;
+        if (chunk >= a.cout_chunks) continue;
+        const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
+        frag_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int co = 32 * cot + acc_row(8 * s + j, h);
+          float v = acc[ct][pt][8 * s + j];
+          if (MODE == kConvFwd) v = fminf(fmaxf(v + bias_r[ct][8 * s + j], 0.0f), 65504.0f);
+          if (MODE == kConvDgradMask) v = (float)gate[ct * 2 + pt][s][j] > 0.0f ? v : 0.0f;
+          v = interior ? v : 0.0f;
+          o[j] = (elem_t)v;
+          if (a.tap && interior && co < a.Ctap)
+            a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? v * a.tap_scale[co & 3] : v;
+        }
+        if (a.y) ((frag_t*)a.y)[unit] = o;
+      }
+    }
+  asm volatile("" :: "v"(pf_val));
+}
+
 // ---- weight packers (run once per trunk: the weights are frozen) -------------------------
 // w: torch Conv2d weight (Cout, Cin, 3, 3) fp32.
 // forward pack unit (cot, ci_step, tap, lane=(m,h)) element j = w[32 cot + m][chan_in(2 ci_step + h, j)][ky][kx]
@@ -829,6 +997,7 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
     for (const Cand& c : cands)
       if (c.ct == force[0] - '0' && c.pt == force[2] - '0' && c.s == force[4] - '0' && feasible(c)) { pick = c; found = true; }
   }
+  const bool forced = found;
   if (!found && a.CI == 1) {                    // the image layer: 9 k-steps, nothing to split
     const Cand c = {2, 1, 1, 1};
     if (feasible(c)) { pick = c; found = true; }
@@ -836,6 +1005,25 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   for (const Cand& c : cands) {
     if (found) break;
     if (feasible(c) && wgs(c) >= c.min_wgs) { pick = c; found = true; }
+  }
+  // window-staged form (conv3x3_win_kernel): few input-channel steps, many positions, 64-channel output blocks
+  static const int win_mode = getenv("NPP_CONV_WIN") ? atoi(getenv("NPP_CONV_WIN")) : 1;     // 0: never (A/B comparator)
+  const int64_t win_wgs = (int64_t)(a.pos_tiles / 8) * (cot_n / 2);
+  if (win_mode && !forced && a.CI <= 8 && cot_n % 2 == 0 && a.pos_tiles % 8 == 0 && 2 * (a.Wp + 1) + kWinPos <= kWinMaxUnits &&
+      ((win_wgs >= 200 && mode == kConvFwd && a.CI <= 4) || win_mode == 2)) {       // measured: only these layers gain (conv1_1, conv1_2, conv2_1 forward)
+    const dim3 wgrid((unsigned)(a.pos_tiles / 8), (unsigned)(cot_n / 2));
+    constexpr int smem = win_lds_bytes<2>();
+#define NPP_WIN_GO(M)                                                                                           \
+    do {                                                                                                          \
+      static SmemOnce once;                                                                                       \
+      if (!smem_attr(once, (const void*)conv3x3_win_kernel<2, M>, smem)) { set_error("npp_conv3x3: smem attribute"); return NPP_ERR_LAUNCH; } \
+      hipLaunchKernelGGL((conv3x3_win_kernel<2, M>), wgrid, dim3(256), smem, s, a);                               \
+    } while (0)
+    if (mode == kConvFwd) NPP_WIN_GO(kConvFwd);
+    else if (mode == kConvDgradMask) NPP_WIN_GO(kConvDgradMask);
+    else NPP_WIN_GO(kConvDgradLin);
+#undef NPP_WIN_GO
+    return check_launch("npp_conv3x3");
   }
   const dim3 grid((unsigned)(a.pos_tiles / pick.pt), (unsigned)(cot_n / pick.ct));
   int lrc = NPP_OK;

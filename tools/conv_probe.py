@@ -46,6 +46,12 @@ if __name__ == "__main__":
         child(int(sys.argv[1]), int(sys.argv[2]))
     else:
         N, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 96)
+        if os.environ.get("CONV_PROBE_WIN"):          # A/B of the window-staged form only: NPP_CONV_WIN = 0 | 1 | 2 (forced)
+            for win in ("0", "1", "2", "0", "1"):
+                env = dict(os.environ, CONV_PROBE_CHILD="1", NPP_CONV_TILE="", NPP_CONV_WIN=win)
+                print("win", win, end=" ", flush=True)
+                subprocess.run([sys.executable, os.path.abspath(__file__), str(N), str(P)], env=env, check=False)
+            sys.exit(0)
         for tile in ("", "2,2,4", "2,1,4", "1,1,8", "1,1,4", "2,2,1", "2,1,1", "1,1,1"):
             env = dict(os.environ, CONV_PROBE_CHILD="1", NPP_CONV_TILE=tile)
             subprocess.run([sys.executable, os.path.abspath(__file__), str(N), str(P)], env=env, check=False)
