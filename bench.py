@@ -203,6 +203,14 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if dist is not None else 0)
+    # Rehearsal of the 8-rank node's HOST side on a smaller box: NPP_BENCH_CPUS_PER_RANK=c confines this rank (its enqueueing
+    # thread, its sampler's producer thread, the native generator) to c logical CPUs of its own, like cpu_count / 8 on the node.
+    if os.environ.get("NPP_BENCH_CPUS_PER_RANK"):
+        ncpu = int(os.environ["NPP_BENCH_CPUS_PER_RANK"])
+        avail = sorted(os.sched_getaffinity(0))
+        mine = [avail[(rank * ncpu + i) % len(avail)] for i in range(ncpu)]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, ncpu))
 
     from npp_amd import ops, synthetic as syn     # (oracle/ is imported inside cpu_baseline() only)
     from npp_amd.io import patch_size_from_period

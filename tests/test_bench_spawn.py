@@ -78,3 +78,28 @@ def test_bench_under_torchrun_initialises_rccl_on_the_card():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["collective"] == {"backend": "nccl (RCCL)", "ranks": 1}
     assert j["per_rank_rows_per_s"] == [j["value"]] and j["value"] > 1e6 and j["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_card_with_a_node_share_of_cpus_each():
+    """SURVEY 8e names the risk of config c3: eight ranks' host threads (34 C-ABI calls per 0.65-ms iteration + a sampler producer
+    thread each) on shared cores.  Rehearsal on the one card a box has: 4 ranks (gloo, all on cuda:0), each confined to 2 logical
+    CPUs (= 16 / 8, the share a rank gets on the 8-GPU node).  The card is shared four ways, so the device numbers mean nothing
+    here; what is asserted is the HOST side: every rank enqueues an iteration in less time than the device needs for it on a card
+    of its own (0.65 ms), i.e. the loop stays device-bound with the node's CPU share, and every rank's sampling-inclusive loop runs."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if len(os.sched_getaffinity(0)) < 8:
+        pytest.skip("fewer than 8 CPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "40", "--warmup", "5", "--no-psnr", "--no-cpu-baseline"],
+                       env=_env(NPP_BENCH_DEVICE="0", NPP_BENCH_BACKEND="gloo", NPP_BENCH_CPUS_PER_RANK="2",
+                                HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 4 and j["collective"]["ranks"] == 4 and len(j["per_rank_rows_per_s"]) == 4
+    e = j["all_ranks_incl_sampling"]
+    assert len(e["host_enqueue_ms_per_iter"]) == 4 and len(e["ms_per_iter_incl_sampling"]) == 4
+    print("host enqueue ms per iteration, per rank:", [round(v, 3) for v in e["host_enqueue_ms_per_iter"]],
+          "| sampling-inclusive ms per iteration (card shared 4 ways):", [round(v, 3) for v in e["ms_per_iter_incl_sampling"]])
+    assert max(e["host_enqueue_ms_per_iter"]) < 0.6, e
