@@ -444,7 +444,7 @@ def main():
     # The kernels also stream this design's 16-bit activation / gradient stash through HBM (far more than 8(d)'s
     # algorithmic 32 B/row): that byte model and the rate it implies are reported beside it as `design_traffic`.
     measured, mfma_pmc, traffic_source = None, None, None
-    pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
+    pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false, false>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
                "mlp_wgrad": "npp::wgrad_kernel"}
     try:     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
              # doubled per the gfx950 note in MI355X_MICROARCH.md): the newest summary committed under profiles/
@@ -462,7 +462,7 @@ def main():
         mfma_pmc = {k_: pq["kernels"][v_].get("mfma_pipe_busy_frac") for k_, v_ in pmc_key.items() if v_ in pq["kernels"]}
         # the inference render (one 0.7-ms dispatch, long enough for GRBM_GUI_ACTIVE / 8 / wall to be the clock the chip held:
         # MI355X_MICROARCH.md 'DVFS give-back'): pipe-busy fraction AT that clock, next to the FLOP fraction of the 2.4-GHz peak
-        rk = pq["kernels"].get("npp::mlp_fwd_kernel<false, true, false>")
+        rk = pq["kernels"].get("npp::mlp_fwd_kernel<false, true, false, false>")
         if rk:
             mfma_pmc["render_fwd_512sq"] = rk.get("mfma_pipe_busy_frac")
             mfma_pmc["render_effective_clock_GHz"] = rk.get("effective_clock_GHz")
