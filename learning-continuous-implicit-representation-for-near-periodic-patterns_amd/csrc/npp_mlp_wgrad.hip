@@ -605,434 +605,6 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   }
 }
 
-// ---- two workgroups per CU (round 4, experiment; NPP_WGRAD_TILE_N=128 at run time) ---------------------------------------------
-// profiles/r04_wgrad_ablation.txt: the 256 x 256 kernel's phases ADD because the two waves of a SIMD belong to ONE workgroup and sit
-// between the same barriers.  Here a workgroup owns a 256 (dz features) x 128 (input features) tile -- 8 waves of 64 x 64, 64
-// accumulator registers, <= 128 VGPRs -- with a three-slot LDS ring of 24-KiB halves (16 KiB dz + 8 KiB inputs, all by LDS-DMA),
-// so TWO workgroups with their own barriers share a CU: one's fragment reads / waits / conversion run under the other's MFMAs.
-// Price: the dz operand is staged by both column tiles of a job (+46 % staged bytes; the second read is an L2 hit when the tiles
-// of a split run together, which the XCD-contiguous item numbering arranges) and 1 fragment read per MFMA instead of 0.75.
-constexpr int kTN2 = 128;
-constexpr int kHalfA2 = 16 * 1024, kHalfB2 = 8 * 1024, kSlot2 = kHalfA2 + kHalfB2, kSlots2 = 3, kSmemW2 = kSlots2 * kSlot2;   // 72 KiB
-__global__ __launch_bounds__(kWThreads, 4) void wgrad128_kernel(WArgs A) {
-  const char* dzF_ = A.dzF;
-  const char* actF_ = A.actF;
-  float* gslabs_ = A.gslabs;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m_l = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows [64 wm, +64), cols [64 wn, +64)
-  int item;
-  if (A.S.M) {
-    const int n_items = A.S.n_items, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    int img, xl, gx;
-    if (A.S.g) { img = xcd / A.S.g; xl = xcd % A.S.g; gx = A.S.g; }
-    else { img = (int)blockIdx.x / n_items; xl = 0; gx = 1; }
-    const int q_ = n_items / gx, r_ = n_items % gx;
-    const int lslot = A.S.g ? slot : (int)blockIdx.x - img * n_items;
-    if (lslot >= (xl < r_ ? q_ + 1 : q_)) return;
-    item = (xl < r_ ? xl * (q_ + 1) : r_ * (q_ + 1) + (xl - r_) * q_) + lslot;
-    if (A.S.iter && !A.S.iter[img].active) return;
-    dzF_ += (int64_t)img * A.dz_img_stride;
-    actF_ += (int64_t)img * A.act_img_stride;
-    gslabs_ += (int64_t)img * A.slab_img_stride;
-  } else {
-    const int n_items = A.ntiles * A.ksplit, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const int q_ = n_items >> 3, r_ = n_items & 7;
-    if (slot >= (xcd < r_ ? q_ + 1 : q_)) return;                   // (grid rounded up to a multiple of 8)
-    item = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
-  }
-  const int tile_id = item % A.ntiles, split_id = item / A.ntiles;
-  WJob J = A.jobs[0];
-#pragma unroll
-  for (int j = 1; j < kMaxJobs; ++j)
-    if (j < A.njobs && tile_id >= A.jobs[j].tile0) J = A.jobs[j];
-  const int t_local = tile_id - J.tile0;
-  const int tm = t_local / J.tiles_n, tn = t_local - tm * J.tiles_n;
-  const int64_t n_wg = A.n_wg;
-  const int64_t wg_begin = (int64_t)split_id * A.wg_chunk;
-  const int64_t wg_end = min(n_wg, wg_begin + (int64_t)A.wg_chunk);
-  const int64_t a_col = wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * kWPairs * 4096;
-  const int64_t b_col = wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * (kTN2 / 32) * 4096;
-  const int64_t a_left = A.dz_bytes - a_col, b_left = A.act_bytes - b_col;
-  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_ + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
-  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(actF_ + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
-  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_), 0, 0, 0x00020000);
-  const uint32_t a_stride = (uint32_t)J.a_nks * 2048u, b_stride = (uint32_t)J.b_nks * 2048u;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  float bsum[2] = {0.0f, 0.0f};
-  const bool do_bias = J.bias_on && tn == 0 && wn == 0;          // wave-uniform
-  const bool zb = J.b_is_z != 0;
-  int offA[2], offB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) offA[i] = hfrag_offset(wm * 2 + i, lane);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) offB[j] = hfrag_offset(wn * 2 + j, lane);
-  const int g0 = (int)wg_begin, g1 = (int)wg_end;
-  const int nh = 2 * (g1 - g0);
-  const int voff = wave * 4096 + lane * 16;
-  const bool bwave = wave < kTN2 / 32;                             // waves 0-3 also fetch a pair of the input operand (wave-uniform)
-  auto dma_half = [&](int hidx) {
-    const bool ok = hidx < nh;
-    const int g = g0 + (kSameTile ? 0 : (hidx >> 1)), bt = hidx & 1;
-    const rsrc_t xa = ok ? ra : rzero, xb = ok ? rb : rzero;        // (past the split's end: zero-length requests into a slot nobody reads)
-    const int soa = ok ? (int)((uint32_t)g * a_stride) + bt * 2048 : 0;
-    const int sob = ok ? (int)((uint32_t)g * b_stride) + bt * 2048 : 0;
-    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void*)(smem + (hidx % kSlots2) * kSlot2 + wave * 2048);
-    unsigned keep;
-    if (bwave) {                                                    // waves 0-3: their dz pair and their input pair (4 requests)
-      const uint32_t d2 = (uint32_t)(uintptr_t)(lds_void*)(smem + (hidx % kSlots2) * kSlot2 + kHalfA2 + wave * 2048);
-      asm volatile(
-          "s_mov_b32 %[keep], m0\n\t"
-          "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa0] offen lds\n\t"
-          "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa1] offen lds\n\t"
-          "s_mov_b32 m0, %[d2]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb0] offen lds\n\t"
-          "s_mov_b32 m0, %[d3]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb1] offen lds\n\t"
-          "s_mov_b32 m0, %[keep]"
-          : [keep] "=&s"(keep)
-          : [v] "v"(voff), [xa] "s"(xa), [xb] "s"(xb), [sa0] "s"(soa), [sa1] "s"(soa + 1024), [sb0] "s"(sob), [sb1] "s"(sob + 1024),
-            [d0] "s"(d0), [d1] "s"(d0 + 1024u), [d2] "s"(d2), [d3] "s"(d2 + 1024u)
-          : "memory");
-    } else {                                                        // waves 4-7: their dz pair only (2 requests)
-      asm volatile(
-          "s_mov_b32 %[keep], m0\n\t"
-          "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa0] offen lds\n\t"
-          "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa1] offen lds\n\t"
-          "s_mov_b32 m0, %[keep]"
-          : [keep] "=&s"(keep)
-          : [v] "v"(voff), [xa] "s"(xa), [sa0] "s"(soa), [sa1] "s"(soa + 1024), [d0] "s"(d0), [d1] "s"(d0 + 1024u)
-          : "memory");
-    }
-  };
-  if (nh > 0) {
-    dma_half(0);
-    dma_half(1);
-    int slot_off = 0;
-    for (int s = 0; s < nh; ++s) {
-      // this wave's requests of half s have landed; those of half s + 1 (4 or 2 of them) stay in flight
-      if (bwave) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      if (zb && bwave) {                                           // layer input = snake(z): converted in place by the lanes that fetched it
-        char* base = smem + slot_off + kHalfA2 + wave * 2048 + lane * 16;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const f16x8 z = *(const f16x8*)(base + q * 1024);
-          bf16x8 a;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] = (__bf16)snake_fast((float)z[j]);
-          *(bf16x8*)(base + q * 1024) = a;
-        }
-      }
-      wg_barrier();                                               // everybody's half s (and its conversion); every read of half s - 1 is over
-      dma_half(s + 2);                                            // -> the slot half s - 1 occupied
-      const char* sA = smem + slot_off;
-      const char* sB = sA + kHalfA2;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bf16x8 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = wfrag_read(sA, offA[0] + i * 2048 + q * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = wfrag_read(sB, offB[0] + j * 2048 + q * 1024);
-        if (do_bias) {
-          const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              const bf16x2 pr = {a[i][j], a[i][j + 1]};
-              bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
-      }
-      slot_off = slot_off + kSlot2 == kSlots2 * kSlot2 ? 0 : slot_off + kSlot2;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();
-  }
-  // ---- epilogue: as wgrad_kernel, on 64 x 64 wave tiles
-  float* slab = gslabs_ + (int64_t)split_id * A.slab_stride;
-  if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {
-    float* stg = (float*)(smem + wave * 8192);                     // 32 x 64 floats per wave
-    const bool a16 = ((J.ld | J.col0) & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * 64 + 32 * j + m_l] = acc[i][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int row = 4 * p + (lane >> 4), c4 = 4 * (lane & 15);
-        const float4 v = *(const float4*)(stg + row * 64 + c4);
-        const int mrow = tm * kWT + wm * 64 + i * 32 + row;
-        const int n_idx = tn * kTN2 + wn * 64 + c4;
-        if (mrow < J.m && n_idx < J.n) {
-          float* dst = slab + J.w_off + (int64_t)mrow * J.ld + J.col0 + n_idx;
-          typedef float f4v __attribute__((ext_vector_type(4)));
-          typedef float f2v __attribute__((ext_vector_type(2)));
-          if (a16) {
-            *(f4v*)dst = (f4v){v.x, v.y, v.z, v.w};
-          } else {
-            *(f2v*)dst = (f2v){v.x, v.y};
-            *(f2v*)(dst + 2) = (f2v){v.z, v.w};
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n_idx = tn * kTN2 + wn * 64 + j * 32 + m_l;
-      int col = -1;
-      if (n_idx < J.n) {
-        if (J.colmode == 0) col = J.col0 + n_idx;
-        else {
-          const int c16 = n_idx & 15;
-          const int c = emb_col(n_idx >> 4, unperm_hh(c16), unperm_j(c16));
-          col = c < 0 ? -1 : J.col0 + c;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int mrow = tm * kWT + wm * 64 + i * 32 + acc_row(r, h);
-          if (col >= 0 && mrow < J.m) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
-        }
-    }
-  }
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int mrow = tm * kWT + wm * 64 + i * 32 + m_l;
-      if (h == 0 && mrow < J.m) slab[J.b_off + mrow] = v;
-    }
-  }
-}
-
-// ---- sixteen waves per workgroup (round 4, experiment; NPP_WGRAD_TILE_N=16 at run time) -------------------------------------------
-// The same 256 x 256 tile (minimal bytes: every array once) by 16 waves of 64 x 64 -- 4 waves per SIMD instead of 2, <= 128
-// VGPRs -- with the round-3 ring (5 x 32 KiB halves, all LDS-DMA): waves 0-7 fetch the dz pairs, waves 8-15 the input pairs (and
-// convert them in place one half ahead when they hold z).
-__global__ __launch_bounds__(1024, 4) void wgrad16w_kernel(WArgs A) {
-  const char* dzF_ = A.dzF;
-  const char* actF_ = A.actF;
-  float* gslabs_ = A.gslabs;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m_l = lane & 31, h = lane >> 5;
-  const int wm = wave >> 2, wn = wave & 3;     // wave tile: rows [64 wm, +64), cols [64 wn, +64)
-  int item;
-  if (A.S.M) {
-    const int n_items = A.S.n_items, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    int img, xl, gx;
-    if (A.S.g) { img = xcd / A.S.g; xl = xcd % A.S.g; gx = A.S.g; }
-    else { img = (int)blockIdx.x / n_items; xl = 0; gx = 1; }
-    const int q_ = n_items / gx, r_ = n_items % gx;
-    const int lslot = A.S.g ? slot : (int)blockIdx.x - img * n_items;
-    if (lslot >= (xl < r_ ? q_ + 1 : q_)) return;
-    item = (xl < r_ ? xl * (q_ + 1) : r_ * (q_ + 1) + (xl - r_) * q_) + lslot;
-    if (A.S.iter && !A.S.iter[img].active) return;
-    dzF_ += (int64_t)img * A.dz_img_stride;
-    actF_ += (int64_t)img * A.act_img_stride;
-    gslabs_ += (int64_t)img * A.slab_img_stride;
-  } else {
-    const int n_items = (int)gridDim.x, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const int q_ = n_items >> 3, r_ = n_items & 7;
-    item = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + slot;
-  }
-  const int tile_id = item % A.ntiles, split_id = item / A.ntiles;
-  WJob J = A.jobs[0];
-#pragma unroll
-  for (int j = 1; j < kMaxJobs; ++j)
-    if (j < A.njobs && tile_id >= A.jobs[j].tile0) J = A.jobs[j];
-  const int t_local = tile_id - J.tile0;
-  const int tm = t_local / J.tiles_n, tn = t_local - tm * J.tiles_n;
-  const int64_t n_wg = A.n_wg;
-  const int64_t wg_begin = (int64_t)split_id * A.wg_chunk;
-  const int64_t wg_end = min(n_wg, wg_begin + (int64_t)A.wg_chunk);
-  const int64_t a_col = wfmt_array_base(J.a_ks0, n_wg) + (int64_t)tm * kWPairs * 4096;
-  const int64_t b_col = wfmt_array_base(J.b_ks0, n_wg) + (int64_t)tn * kWPairs * 4096;
-  const int64_t a_left = A.dz_bytes - a_col, b_left = A.act_bytes - b_col;
-  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_ + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
-  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(actF_ + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
-  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_), 0, 0, 0x00020000);
-  const uint32_t a_stride = (uint32_t)J.a_nks * 2048u, b_stride = (uint32_t)J.b_nks * 2048u;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  float bsum[2] = {0.0f, 0.0f};
-  const bool do_bias = J.bias_on && tn == 0 && wn == 0;
-  const bool bw = wave >= 8;                                        // waves 8-15 fetch (and convert) the input operand
-  const bool zb = J.b_is_z != 0 && bw;
-  int offA[2], offB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) offA[i] = hfrag_offset(wm * 2 + i, lane);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) offB[j] = hfrag_offset(wn * 2 + j, lane);
-  const int g0 = (int)wg_begin, g1 = (int)wg_end;
-  const int nh = 2 * (g1 - g0);
-  const int pair = wave & 7;
-  const int voff = pair * 4096 + lane * 16;
-  const rsrc_t rmine = bw ? rb : ra;
-  const uint32_t stride_mine = bw ? b_stride : a_stride;
-  auto dma_half = [&](int hidx) {
-    const bool ok = hidx < nh;
-    const int g = g0 + (kSameTile ? 0 : (hidx >> 1)), bt = hidx & 1;
-    const rsrc_t x = ok ? rmine : rzero;
-    const int so = ok ? (int)((uint32_t)g * stride_mine) + bt * 2048 : 0;
-    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void*)(smem + (hidx % kSlots) * kSlot + (bw ? kHalfOp : 0) + pair * 2048);
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %[keep], m0\n\t"
-        "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[x], %[s0] offen lds\n\t"
-        "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[x], %[s1] offen lds\n\t"
-        "s_mov_b32 m0, %[keep]"
-        : [keep] "=&s"(keep)
-        : [v] "v"(voff), [x] "s"(x), [s0] "s"(so), [s1] "s"(so + 1024), [d0] "s"(d0), [d1] "s"(d0 + 1024u)
-        : "memory");
-  };
-  auto convert_half = [&](int hidx) {
-    char* base = smem + (hidx % kSlots) * kSlot + kHalfOp + pair * 2048 + lane * 16;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f16x8 z = *(const f16x8*)(base + q * 1024);
-      bf16x8 a;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = (__bf16)snake_fast((float)z[j]);
-      *(bf16x8*)(base + q * 1024) = a;
-    }
-  };
-  if (nh > 0) {
-#pragma unroll
-    for (int i = 0; i < kSlots - 1; ++i) dma_half(i);
-    if (zb) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // half 0 has landed (3 younger halves x 2 requests)
-      convert_half(0);
-    }
-    int slot_off = 0;
-    for (int s = 0; s < nh; ++s) {
-      if (zb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's halves s and s + 1 have landed
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // ... half s
-      wg_barrier();
-      dma_half(s + kSlots - 1);
-      const char* sA = smem + slot_off;
-      const char* sB = sA + kHalfOp;
-      bf16x8 a[2][2], b[2][2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[q][i] = wfrag_read(sA, offA[0] + i * 2048 + q * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[q][j] = wfrag_read(sB, offB[0] + j * 2048 + q * 1024);
-      }
-      if (zb) convert_half(s + 1);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (do_bias) {
-          const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              const bf16x2 pr = {a[q][i][j], a[q][i][j + 1]};
-              bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[i], false);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(a[q][i], b[q][j], acc[i][j]);
-      }
-      slot_off = slot_off + kSlot == kSlots * kSlot ? 0 : slot_off + kSlot;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wg_barrier();
-  }
-  float* slab = gslabs_ + (int64_t)split_id * A.slab_stride;
-  if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {
-    float* stg = (float*)(smem + wave * 8192);                     // 32 x 64 floats per wave
-    const bool a16 = ((J.ld | J.col0) & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * 64 + 32 * j + m_l] = acc[i][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int row = 4 * p + (lane >> 4), c4 = 4 * (lane & 15);
-        const float4 v = *(const float4*)(stg + row * 64 + c4);
-        const int mrow = tm * kWT + wm * 64 + i * 32 + row;
-        const int n_idx = tn * kWT + wn * 64 + c4;
-        if (mrow < J.m && n_idx < J.n) {
-          float* dst = slab + J.w_off + (int64_t)mrow * J.ld + J.col0 + n_idx;
-          typedef float f4v __attribute__((ext_vector_type(4)));
-          typedef float f2v __attribute__((ext_vector_type(2)));
-          if (a16) {
-            *(f4v*)dst = (f4v){v.x, v.y, v.z, v.w};
-          } else {
-            *(f2v*)dst = (f2v){v.x, v.y};
-            *(f2v*)(dst + 2) = (f2v){v.z, v.w};
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n_idx = tn * kWT + wn * 64 + j * 32 + m_l;
-      int col = -1;
-      if (n_idx < J.n) {
-        if (J.colmode == 0) col = J.col0 + n_idx;
-        else {
-          const int c16 = n_idx & 15;
-          const int c = emb_col(n_idx >> 4, unperm_hh(c16), unperm_j(c16));
-          col = c < 0 ? -1 : J.col0 + c;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int mrow = tm * kWT + wm * 64 + i * 32 + acc_row(r, h);
-          if (col >= 0 && mrow < J.m) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
-        }
-    }
-  }
-  if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int mrow = tm * kWT + wm * 64 + i * 32 + m_l;
-      if (h == 0 && mrow < J.m) slab[J.b_off + mrow] = v;
-    }
-  }
-}
-
 // Build the job table for NPP_Net (K>1) / NPP_Net_top1 (K==1).
 static int build_jobs(int K, WArgs& A, int tile_n = kWT) {
   const NetDesc d = make_desc(K);
@@ -1123,17 +695,9 @@ static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K
   A.act_bytes = wfmt_array_base(act_total_ks(K), A.n_wg);
   A.gslabs = d_gslabs;
   A.slab_stride = slab_stride_of(make_desc(K).total_params);
-  static const int tile_n = getenv("NPP_WGRAD_TILE_N") ? atoi(getenv("NPP_WGRAD_TILE_N")) : kWT;     // 128: wgrad128_kernel (two workgroups per CU)
-  const bool two_wg = tile_n == kTN2;
-  const int ntiles = build_jobs(K, A, two_wg ? kTN2 : kWT);
+  const int ntiles = build_jobs(K, A);
   A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
-  static SmemOnce once, once2, once3;
-  const bool w16 = tile_n == 16;
-  if (w16) {
-    if (!smem_attr(once3, (const void*)wgrad16w_kernel, kSmemW)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
-  } else if (two_wg) {
-    if (!smem_attr(once2, (const void*)wgrad128_kernel, kSmemW2)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
-  } else
+  static SmemOnce once;
   if (!smem_attr(once, (const void*)wgrad_kernel, kSmemW)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
   A.ntiles = ntiles; A.ksplit = ksplit;
   unsigned grid = (unsigned)(ntiles * ksplit);
@@ -1146,12 +710,6 @@ static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K
     }
     grid = stack_grid(A.S);
   }
-  if (w16) {
-    hipLaunchKernelGGL(wgrad16w_kernel, dim3(grid), dim3(1024), kSmemW, (hipStream_t)stream, A);
-  } else if (two_wg) {
-    if (!M) grid = (grid + 7) / 8 * 8;                      // its XCD item numbering wants whole rounds of 8 (surplus workgroups exit)
-    hipLaunchKernelGGL(wgrad128_kernel, dim3(grid), dim3(kWThreads), kSmemW2, (hipStream_t)stream, A);
-  } else
   hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
   return check_launch("npp_mlp_wgrad");
 }
