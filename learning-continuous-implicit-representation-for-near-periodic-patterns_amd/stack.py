@@ -23,6 +23,11 @@ from . import ops
 from ._lib import StackIter
 
 
+class _Batches(list):
+    """The M batches of one stacked iteration + the buffer set (`set`) the sampler filled for them."""
+    set = 0
+
+
 class StackedFit:
     def __init__(self, fits, ksplit=None):
         if not fits:
@@ -66,11 +71,16 @@ class StackedFit:
         self.slab_stride = sizes[3] // 4 // self.ksplit
         self.pred = torch.empty((M, self.Bp, 3), dtype=f32, device=dev)
         self.dpred = torch.zeros((M, self.Bp, 3), dtype=f32, device=dev)        # rows >= n stay zero
-        self.coords = torch.zeros((M, self.Bp, 2), dtype=torch.int32, device=dev)
-        self.gt = torch.empty((M, self.n_pix, 3), dtype=f32, device=dev)
+        # the sampler's outputs, TWO sets: while the launches of iteration i read one, the sampler's host draws and device half
+        # (one upload, one crop gather, one row assembly per image) of iteration i + 1 fill the other on a side stream
         nc = self.n_p * (1 + self.kmax)
-        self.crops = torch.zeros((M, nc, 3, self.P, self.P), dtype=f32, device=dev)
-        self.cmasks = torch.zeros((M, nc, 1, self.P, self.P), dtype=f32, device=dev)
+        self._sets = [dict(coords=torch.zeros((M, self.Bp, 2), dtype=torch.int32, device=dev),
+                           gt=torch.empty((M, self.n_pix, 3), dtype=f32, device=dev),
+                           crops=torch.zeros((M, nc, 3, self.P, self.P), dtype=f32, device=dev),
+                           cmasks=torch.zeros((M, nc, 1, self.P, self.P), dtype=f32, device=dev),
+                           filled=None, free=None) for _ in range(2)]
+        self._wset, self._ahead = 0, None
+        self._s_smp = torch.cuda.Stream(dev)
         nxy = 2 * self.n_p * self.kmax
         self.xy = torch.zeros((M, nxy, 3, self.P, self.P), dtype=f32, device=dev)
         self.dxb = torch.zeros((M, nxy, 3, self.P, self.P), dtype=f32, device=dev)
@@ -112,26 +122,49 @@ class StackedFit:
 
     # ---- host half: one draw per image (each fit's own sampler and random stream), device half into the stacked buffers ----
     def sample(self):
-        """-> list of M batches (None for an image whose sampler found no valid real patch this iteration)."""
-        out = []
-        for i, f in enumerate(self.fits):
-            d = f.draw_batch()
-            f.last_draw = d
-            f.iteration += 1
-            b = f.materialise_batch(d, out=dict(coords=self.coords[i], gt=self.gt[i], crops=self.crops[i], cmasks=self.cmasks[i]))
-            if b is None:
-                f.skipped += 1
-            out.append(b)
+        """-> list of M batches (None for an image whose sampler found no valid real patch this iteration), materialised on the
+        sampler stream into the buffer set that is not in use; the list carries that set (step_from waits for it)."""
+        w = self._wset
+        self._wset ^= 1
+        st = self._sets[w]
+        out = _Batches()
+        out.set = w
+        main = torch.cuda.current_stream(self.device)
+        if st["free"] is not None:
+            self._s_smp.wait_event(st["free"])            # the iteration that read this set last has been enqueued AND must finish first
+        else:
+            self._s_smp.wait_stream(main)                 # first use: behind the constructor's copies
+        with torch.cuda.stream(self._s_smp):
+            for i, f in enumerate(self.fits):
+                d = f.draw_batch()
+                f.last_draw = d
+                f.iteration += 1
+                b = f.materialise_batch(d, out=dict(coords=st["coords"][i], gt=st["gt"][i], crops=st["crops"][i], cmasks=st["cmasks"][i]))
+                if b is None:
+                    f.skipped += 1
+                out.append(b)
+            ev = torch.cuda.Event()
+            ev.record(self._s_smp)
+        st["filled"] = ev
         return out
 
     def step_full(self):
-        """One iteration of the loop body for every image of the stack.  -> number of images that took a step."""
-        return self.step_from(self.sample())
+        """One iteration of the loop body for every image of the stack.  -> number of images that took a step.  The NEXT
+        iteration's sampling (host draws + device half) is issued right behind this one's launches: it never reads network state, so
+        the random streams and the results are those of the serial order; it runs on a side stream under this iteration's kernels."""
+        b = self._ahead if self._ahead is not None else self.sample()
+        n = self.step_from(b)
+        self._ahead = self.sample()
+        return n
 
     # ---- device half ---------------------------------------------------------------------------------------------------------
     def step_from(self, batches):
         ops.check_current(self.device)
         M, fits = self.M, self.fits
+        st = self._sets[getattr(batches, "set", 0)]
+        coords, gt, crops, cmasks = st["coords"], st["gt"], st["crops"], st["cmasks"]
+        if st["filled"] is not None:
+            torch.cuda.current_stream(self.device).wait_event(st["filled"])
         it = (StackIter * M)()
         x0 = 0
         lr_used = [0.0] * M
@@ -161,6 +194,7 @@ class StackedFit:
         self.last_sources = [None if b is None else b["source"] for b in batches]
         if n_active == 0:
             self.iteration += 1
+            st["free"] = st["filled"]
             return 0
         it_dev = ops.h2d(np.frombuffer(bytes(it), np.uint8).copy(), self.device)
         # zero_grad(): the fused Adam launch of the previous iteration cleared each active image's latent gradient and idle loss
@@ -178,17 +212,17 @@ class StackedFit:
             if f.percepLoss.touched:
                 f.percepLoss.zero_latent_grads()
         K, W = self.K, self.width
-        ops.mlp_fwd_stack(self.coords, self.edev, M, K, self.wf, self.params, self.pred, self.actF, it_dev, W)
+        ops.mlp_fwd_stack(coords, self.edev, M, K, self.wf, self.params, self.pred, self.actF, it_dev, W)
         cx = self.cx
         sc, sh = cx.input_norm()
         net0 = fits[0].net
-        loss = (self.pred, self.gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
+        loss = (self.pred, gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
                 self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix, self.pl_scratch)
         t = cx.hip_trunk
         with_lp = [i for i, b in enumerate(batches) if b is not None and it[i].with_lp]
-        ops.trunk_patch_in_loss_stack(self.pred, self.n_pix, self.crops, self.cmasks, M, self.n_p, self.P, X, self.N_total, sc, sh,
+        ops.trunk_patch_in_loss_stack(self.pred, self.n_pix, crops, cmasks, M, self.n_p, self.P, X, self.N_total, sc, sh,
                                       t.input_buffer(self.N_total, self.P, self.P), self.xy if with_lp else None, self.patch_loss,
-                                      it_dev, loss, self.gt.stride(0), self.latents.stride(0), self.loss_bufs.stride(0))
+                                      it_dev, loss, gt.stride(0), self.latents.stride(0), self.loss_bufs.stride(0))
         main = torch.cuda.current_stream(self.device)
         if with_lp:                                       # the LPIPS branch of the 'same' images beside the contextual chain
             self._s_lp.wait_stream(main)
@@ -207,13 +241,16 @@ class StackedFit:
         if with_lp:
             main.wait_stream(self._s_lp)
         ops.mlp_bwd_patch_stack(self.dpred, self.pred, M, K, self.wb, self.params, self.actF, self.dzF, dx_a,
-                                self.dxb if with_lp else None, self.cmasks, self.n_pix, self.n_p, self.P, it_dev, W)
+                                self.dxb if with_lp else None, cmasks, self.n_pix, self.n_p, self.P, it_dev, W)
         ops.mlp_wgrad_stack(self.dzF, self.actF, self.Bp, M, K, self.ksplit, self.gslabs, it_dev, W)
         idle = self.loss_bufs[:, 1 - self.loss_idx:2 - self.loss_idx]
         ops.adam_step_net_pack_stack(self.params, self.m, self.v, self.n_params, self.gslabs, self.ksplit, self.slab_stride,
                                      self.latents, self.lat_m, self.lat_v, self.dlatent, 6, idle, M, K, self.wf, self.wb, it_dev,
                                      self.pl_scratch, self.loss_bufs[:, self.loss_idx:], W)
         self._clean = True
+        free = torch.cuda.Event()                          # the sampler may refill this set once everything above has run
+        free.record(torch.cuda.current_stream(self.device))
+        st["free"] = free
         self._stale = [i for i, b in enumerate(batches) if b is None]
         for i, (f, b) in enumerate(zip(fits, batches)):
             if b is None:
