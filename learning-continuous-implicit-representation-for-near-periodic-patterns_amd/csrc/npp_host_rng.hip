@@ -11,7 +11,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#define NPP_HOST_X86 1
+#else
+#define NPP_HOST_X86 0          // other hosts: the scalar forms (bit-identical), std::this_thread::yield() in the spin loops
+#endif
 
 #include <atomic>
 #include <thread>
@@ -91,6 +96,7 @@ inline uint64_t interval(MT* s, uint64_t max) {   // legacy random_interval: mas
   return value;
 }
 
+#if NPP_HOST_X86
 // ---- AVX2 forms (x86 hosts that have it; chosen once at run time, NPP_RNG_AVX2=0 turns them off) -----------------------------
 __attribute__((target("avx2"))) void mt_gen_avx2(MT* s) {      // mt_gen + mt_temper, the same loops compiled 8 wide
   const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
@@ -164,6 +170,19 @@ __attribute__((target("avx2"))) int compact_runs_avx2(const uint32_t* w, int ava
   *bound_io = bound;
   return u;
 }
+#else
+static void mt_gen_avx2(MT*) {}
+static int compact_runs_avx2(const uint32_t*, int, uint32_t, uint32_t, uint32_t*, int*, uint32_t*, int) { return 0; }
+#endif
+static inline void cpu_relax() {              // spin politely: pause, and every 1024th spin give the core away (the other side
+  static thread_local unsigned spins = 0;   // of the hand-off may be waiting for it on a host with few cores per rank)
+  if ((++spins & 1023u) == 0) { std::this_thread::yield(); return; }
+#if NPP_HOST_X86
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 
 }  // namespace
 
@@ -233,7 +252,11 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
   uint32_t* perm = (uint32_t*)scratch;
   constexpr int kBlock = 2048, kAhead = 32;
   // generation of one block: the next <= kBlock accepted targets for the bounds i, i - 1, ... (consumes generator words)
+#if NPP_HOST_X86
   static const bool have_avx2 = [] { const char* e = getenv("NPP_RNG_AVX2"); return !(e && e[0] == '0') && __builtin_cpu_supports("avx2"); }();
+#else
+  static const bool have_avx2 = false;
+#endif
   auto gen_block = [s](uint32_t i, uint32_t* jbuf) -> int {
     int cnt = 0;
     uint32_t bound = i;
@@ -298,18 +321,24 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
   // (2.0 vs 1.75 ... on the build container's Xeon 3.0 vs 4.1).  Default: helper thread only where generation is the scalar form;
   // NPP_RNG_THREADS=0 / 1 force it off / on.
   static const bool threaded_ok = [] { const char* e = getenv("NPP_RNG_THREADS"); return e ? e[0] != '0' : !have_avx2; }();
-  if (n >= kThreadedMin && threaded_ok) {
-    constexpr int kRing = 8;
-    struct Slot { uint32_t j[kBlock + kAhead]; uint32_t i; int cnt; };
-    std::vector<Slot> ring(kRing);
-    std::atomic<int64_t> produced{0}, consumed{0};
-    std::atomic<bool> done{false};
-    const uint32_t top = (uint32_t)(n - 1);
-    std::thread gen([&] {
+  constexpr int kRing = 8;
+  struct Slot { uint32_t j[kBlock + kAhead]; uint32_t i; int cnt; };
+  std::vector<Slot> ring;
+  std::atomic<int64_t> produced{0}, consumed{0};
+  std::atomic<bool> done{false};
+  const uint32_t top = (uint32_t)(n - 1);
+  bool threaded = n >= kThreadedMin && threaded_ok;
+  std::thread gen;
+  if (threaded) {
+    // (an extern "C" entry point must not let an exception escape: if the helper thread cannot be started -- EAGAIN under a
+    //  container's pid limit -- or its ring not be allocated, the single-thread loop below does the same work)
+    try {
+      ring.resize(kRing);
+      gen = std::thread([&] {
       uint32_t i = top;
       int64_t b = 0;
       while (i > 0) {
-        while (b - consumed.load(std::memory_order_acquire) >= kRing) __builtin_ia32_pause();
+        while (b - consumed.load(std::memory_order_acquire) >= kRing) cpu_relax();
         Slot& sl = ring[b % kRing];
         sl.i = i;
         sl.cnt = gen_block(i, sl.j);
@@ -318,13 +347,18 @@ extern "C" int npp_rng_choice_noreplace(void* h, int64_t n, int64_t size, int64_
         produced.store(b, std::memory_order_release);
       }
       done.store(true, std::memory_order_release);
-    });
+      });
+    } catch (...) {
+      threaded = false;
+    }
+  }
+  if (threaded) {
     for (uint32_t q = 0; q < (uint32_t)n; ++q) perm[q] = q;          // (overlaps the first blocks' generation)
     int64_t b = 0;
     for (;;) {
       while (produced.load(std::memory_order_acquire) <= b) {
         if (done.load(std::memory_order_acquire) && produced.load(std::memory_order_acquire) <= b) goto finished;
-        __builtin_ia32_pause();
+        cpu_relax();
       }
       const Slot& sl = ring[b % kRing];
       apply_block(sl.i, sl.j, sl.cnt);

@@ -426,6 +426,7 @@ def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
 
 
 _SCORE_TRUNKS = {}       # (device, id(weights...)) -> (LPIPS, ContextualLoss, weights): ProposalRanker's score trunks, shared between images
+_SCORE_LOCK = __import__("threading").Lock()      # the cache and the shared trunks' workspaces belong to one ranker at a time
 
 
 class ProposalRanker:
@@ -466,14 +467,20 @@ class ProposalRanker:
         self._draws, self._gt_all = None, None
         # the two score trunks are the same for every image of a run (same weights): built and packed once per (device, weights)
         key = (str(self.device), id(vgg16_state_dict), id(vgg19_state_dict), id(lpips_lin_weights))
-        hit = _SCORE_TRUNKS.get(key)
-        if hit is None or any(a is not b for a, b in zip(hit[2], (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))):
-            hit = (LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device),
-                   ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device),
-                   (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))       # (keeps the keyed objects alive: ids stay unique)
-            if len(_SCORE_TRUNKS) >= 4:
-                _SCORE_TRUNKS.clear()
-            _SCORE_TRUNKS[key] = hit
+        with _SCORE_LOCK:
+            hit = _SCORE_TRUNKS.get(key)
+            if hit is None or any(a is not b for a, b in zip(hit[2], (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))):
+                hit = (LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device),
+                       ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device),
+                       (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))       # (keeps the keyed objects alive: ids stay unique)
+                if len(_SCORE_TRUNKS) >= 4:
+                    _SCORE_TRUNKS.clear()
+                _SCORE_TRUNKS[key] = hit
+            else:
+                # every image scores a crop of its own size: the trunks' per-shape activation buffers of the previous image are
+                # dropped (they were never evicted: a directory run grew by a VGG16 + VGG19 activation set per image)
+                for t in (hit[0].hip_trunk, hit[1].hip_trunk):
+                    t._buf.clear()
         self.percep, self.cx = hit[0], hit[1]
 
     def _pixel_draws(self):

@@ -136,6 +136,10 @@ def main(argv=None):
     with open(os.path.join(out, "config.odgt")) as f:
         odgt = json.loads(f.readline())
     odgt.update(search_range=list(args.search_range), epoch=args.N_iters)           # search.py:236-237
+    # (not a reference field) how the candidates' adaptive-loss latents were handled: the reference trains ONE module-level
+    # adaptive_pix through all candidates in order (models/helpers.py:8,144), so its distances depend on the candidate order; the
+    # default here starts every candidate from the initial latents.  Recorded so that rankings are compared like with like.
+    odgt.update(carry_adaptive_latents=bool(args.carry_adaptive_latents))
     with open(os.path.join(out, "config.odgt"), "w") as f:
         json.dump(odgt, f)
         f.write("\n")
