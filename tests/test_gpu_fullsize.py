@@ -293,3 +293,40 @@ def test_c4_remapping_loop_at_1024sq(dev):
     da, db = a.net.workspace(bp)["dpred"][:n_pix], b.net.workspace(bp)["dpred"][:n_pix]
     # (the gradient rows are written once each: bit-identical; the loss word is a float atomicAdd over 232 blocks: equal to round-off)
     assert torch.equal(da, db) and abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) <= 1e-6 * abs(float(b.net.loss_buf[0]))
+
+
+def test_c3_eight_images_on_one_gpu(dev):
+    """BASELINE config c3's workload -- eight independent 512 x 512 completion images, top-3 proposals -- on the ONE GPU a box has:
+    what a node with fewer than eight GPUs runs per GPU (8 / 4 / 2 images), as one stacked launch sequence (npp_amd.stack).  Every
+    image has its own noise field, initial weights and sampler stream; after 60 complete iterations each one has converged like
+    the single-image fit of config c2 (28 dB on the known pixels after 40 iterations there), their random streams stayed apart,
+    and the first image equals its stand-alone fit (same split-K) to the tolerance of tests/test_gpu_stack.py."""
+    from npp_amd.fit import CompletionFit
+    from npp_amd.stack import StackedFit
+    H, K, M = 512, 3, 8
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def fit(i, ks=None):
+        img, mask = oracle.synthetic_image(H, seed=i)
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=i), device=dev, N_rand=8192,
+                             shifts=shifts, seed=100 + i, ksplit=ks)
+    st = StackedFit([fit(i) for i in range(M)])
+    assert st.Bp == 26624 and st.P == 96
+    seqs = [[] for _ in range(M)]
+    for _ in range(60):
+        assert st.step_full() == M
+        for i in range(M):
+            seqs[i].append(st.last_sources[i])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(st.params).all())
+    assert len({tuple(s) for s in seqs}) == M                               # eight different sampler streams
+    ps = st.psnr("known")
+    print("PSNR on the known pixels after 60 stacked iterations:", [round(p, 2) for p in ps])
+    assert min(ps) > 27.5, ps
+    alone = fit(0, st.ksplit)
+    for _ in range(60):
+        alone.step_full()
+    a, b = alone.net.params.cpu().numpy(), st.fits[0].net.params.cpu().numpy()
+    e = float(np.linalg.norm(a - b) / np.linalg.norm(a))
+    print(f"image 0 stacked vs alone after 60 iterations: rel-L2 {e:.2e}, PSNR {alone.psnr('known'):.2f} vs {ps[0]:.2f}")
+    assert e < 3e-3 and abs(alone.psnr("known") - ps[0]) < 0.1
