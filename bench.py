@@ -672,12 +672,32 @@ def main():
         sc9 = [rk.score(n_) for n_ in nets9]
         torch.cuda.synchronize()
         t_set_all = time.perf_counter() - t4
+        # the same set on the 16-bit matrix pipe (csrc/npp_light16.hip: bf16 operands, fp32 accumulation / master weights / Adam)
+        rk16 = ProposalRanker(img * mask, np.stack(np.nonzero(pseudo * mask[..., 0]), 1), np.stack(np.nonzero((1 - pseudo) * mask[..., 0]), 1),
+                              device=dev, rng_mode="fast", precision="bf16")
+        rk16.fit_candidates(cands9)
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        nets16 = rk16.fit_candidates(cands9)
+        torch.cuda.synchronize()
+        t_set16 = time.perf_counter() - t5
+        sc16 = [rk16.score(n_) for n_ in nets16]
+        torch.cuda.synchronize()
+        t_set16_all = time.perf_counter() - t5
+        set16 = {"n_candidates": len(cands9), "fit_s": t_set16, "fit_s_per_candidate": t_set16 / len(cands9), "fit_plus_score_s": t_set16_all,
+                 "ms_per_iteration_of_the_set": t_set16 / rk16.N_iters * 1e3, "rows_per_s": len(cands9) * rk16.N_iters * rk16.N_rand / t_set16,
+                 "best_score": min(x[0] for x in sc16), "speedup_vs_fp32_set": t_set / t_set16,
+                 "ranking_order_fp32": [int(i) for i in np.argsort([x[0] for x in sc9], kind="stable")],
+                 "ranking_order_bf16": [int(i) for i in np.argsort([x[0] for x in sc16], kind="stable")],
+                 "how": "4 launches per iteration of the set: fused bf16 forward / data-gradient chains, the main loop's grouped split-K "
+                        "weight-gradient kernel over a light job table (candidate = image of a stacked launch), Adam + bf16 re-pack"}
         ranking = {"fit_ms_per_iter": t_fit / rk.N_iters * 1e3, "candidate_fit_s": t_fit, "candidate_fit_plus_score_s": t_all,
                    "rows_per_s": rk.N_iters * rk.N_rand / t_fit, "score": sc[0],
                    "candidate_set": {"n_candidates": len(cands9), "fit_s": t_set, "fit_s_per_candidate": t_set / len(cands9),
                                      "fit_plus_score_s": t_set_all, "ms_per_iteration_of_the_set": t_set / rk.N_iters * 1e3,
                                      "rows_per_s": len(cands9) * rk.N_iters * rk.N_rand / t_set, "best_score": min(x[0] for x in sc9),
                                      "how": "NPPNetLightBatch: fused forward / data-gradient chains (csrc/npp_light.hip) and one grouped weight-gradient launch, the candidate is a grid dimension"},
+                   "candidate_set_bf16": set16,
                    "note": "NPP_Net_light D=4 W=256, exact fp32, fused chains; candidate_fit_s is ONE candidate alone (a candidate set of one: "
                            "7 launches per iteration), candidate_set the 9 candidates of an image together (what search.py's loop amounts to)"}
 

@@ -548,6 +548,36 @@ int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params
                   const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
                   const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
                   float* d_draw, float* d_dstash, void* stream);
+/* ---- f1 on the 16-bit matrix pipe (csrc/npp_light16.hip): the same chains with bf16 operands, fp32 accumulation and fp32 master
+ * weights -- the numeric contract of the main loop's coordinate MLP (npp_mlp_fwd / npp_mlp_bwd / npp_mlp_wgrad), models/networks.py:176-263,
+ * NPP_proposal/search.py:113-147.  B a multiple of 64.  Per candidate: a bf16 pack of npp_light16_pack_bytes() bytes (forward and
+ * transposed weights), a forward stash of npp_light16_stash_bytes(B, 0) bytes (W-format fragment arrays: fp16 pre-activations z_0..z_3,
+ * z_p, bf16 [f1 | x_pos], x_per) and a gradient stash of npp_light16_stash_bytes(B, 1) bytes (bf16 d z_0..d z_3, d f1, d z_p, d raw);
+ * the strides (bytes, multiples of 16) place candidate c at + c * stride.
+ * npp_light16_fwd: as npp_light_fwd.  npp_light16_bwd: as npp_light_bwd (d_gt non-null folds the adaptive robust pixel loss in).
+ * npp_light16_wgrad: all seven weight / bias gradients of the C <= NPP_MAX_STACK candidates in ONE launch of the main loop's grouped
+ * split-K kernel: candidate c's ksplit partial sums land, by plain stores, in d_gslabs + c * slab_cand_stride + s * slab_stride
+ * (s < ksplit) at the parameters' own offsets (npp_light_desc; leading dimensions and offsets multiples of 4, pos_linears.0 stored 300
+ * wide).  npp_light16_adam_pack: optimizer.step() over the stacked fp32 blobs with gradient = the slabs summed in slab order
+ * (bit-reproducible), the six latents per candidate (d_dlat consumed and cleared, loss words d_zero cleared) and the re-pack of every
+ * updated weight into the bf16 packs, one launch. */
+int64_t npp_light16_pack_bytes(void);
+int64_t npp_light16_stash_bytes(int64_t B, int which);
+int npp_light16_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, void* d_pack, int64_t pack_stride_bytes,
+                     void* stream);
+int npp_light16_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack, int64_t pack_stride_bytes,
+                    const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, void* d_actF,
+                    int64_t act_stride_bytes, float* d_pred, void* stream);
+int npp_light16_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack, int64_t pack_stride_bytes,
+                    const void* d_actF, int64_t act_stride_bytes, const float* d_pred, const float* d_dpred, const float* d_gt,
+                    const float* d_latents, const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C,
+                    int64_t B, void* d_dzF, int64_t dz_stride_bytes, void* stream);
+int npp_light16_wgrad(const npp_light_desc* L, const void* d_actF, int64_t act_stride_bytes, const void* d_dzF, int64_t dz_stride_bytes,
+                      int C, int64_t B, int ksplit, float* d_gslabs, int64_t slab_stride, int64_t slab_cand_stride, void* stream);
+int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                          const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                          int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero, float lr,
+                          float beta1, float beta2, float eps, int step, void* stream);
 /* npp_pixel_loss over nbatch problems: d_pred / d_dpred (nbatch, N, 3), d_latents / d_dlatent (nbatch, 6), d_loss (nbatch);
  * the targets d_gt (N, 3) are shared when gt_stride == 0, else problem b reads d_gt + b * gt_stride. */
 int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,

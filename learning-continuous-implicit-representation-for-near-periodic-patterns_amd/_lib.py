@@ -155,6 +155,13 @@ SYMBOLS = {
     "npp_light_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "npp_light_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_light_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "npp_light16_pack_bytes": (_i64, []),
+    "npp_light16_stash_bytes": (_i64, [_i64, _i32]),
+    "npp_light16_pack": (_i32, [C.POINTER(LightDesc), _vp, _i64, _i32, _vp, _i64, _vp]),
+    "npp_light16_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp]),
+    "npp_light16_bwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "npp_light16_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _i64, _vp]),
+    "npp_light16_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_light_bwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "npp_pixel_loss_batched": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "npp_act_bwd": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),

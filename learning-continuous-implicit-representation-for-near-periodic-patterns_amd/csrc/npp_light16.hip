@@ -1,0 +1,601 @@
+// npp_light16.hip -- NPP_Net_light's training chains on the 16-bit matrix pipe (VERDICT r3 "f1 in 16-bit"):
+// the proposal-ranking fits of NPP_proposal/search.py:85-147 (one NPP_Net_light per candidate, models/networks.py:176-263 with
+// len(freq_scales) == 1, D = 4, W = 256, snake) with bf16 operands, fp32 accumulation and fp32 master weights -- the numeric
+// contract of the main loop's coordinate MLP (npp_mlp_fwd.hip / npp_mlp_bwd.hip), whose building blocks these kernels share
+// (npp_common.h: weight-stream ring, mma_ring, fragment regions in LDS, W-format stashes).  npp_light.hip is the exact-fp32
+// form of the same chains (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak); this one runs v_mfma_f32_32x32x16_bf16.
+//
+//   forward   x_per(20) -> 4 x [256, snake] -> feature_linear1 (256, linear) -> [f1 | x_pos(42)] -> pos_linears.0 (128, snake)
+//             -> rgb_linear (3) -> sigmoid                                                         ONE launch, all candidates
+//   backward  pixel loss -> d raw -> d z_p -> d f1 -> d z_3 .. d z_0 (the data gradients)          ONE launch
+//   weight gradients: the main loop's grouped split-K launch (npp_mlp_wgrad.hip) over a job table for this network,
+//   candidate = image of a stacked launch;  Adam + re-pack of both 16-bit packs: ONE launch
+//
+// A 256-thread workgroup owns 64 pixel rows of one candidate (blockIdx.y); GEMMs transposed (Z^T = W X^T), weights = A operand
+// streamed from the candidate's bf16 pack through a 4-k-step register ring, activations = B operand as 16-byte fragments in LDS
+// (an accumulator tile converted to bf16 IS two fragments of the next layer).  Stashes: W-format arrays (npp_layout.h): fp16
+// pre-activations z of the snake layers (the backward derives 1 + sin 2z, the weight-gradient launch snake(z)), bf16 for the
+// linear ones.
+#include "npp_common.h"
+#include "npp_light_layout.h"
+
+namespace npp {
+
+static_assert(kW == 256 && kNB == 2 && kNT == 8 && kRD == 4, "the 16-bit light chains are built for W = 256, 64-row workgroups");
+
+constexpr int kL16Threads = 256;
+constexpr int kL16Region = kKSAct * kNB * 1024;           // 32 KiB: 256 features x 64 rows of bf16 fragments
+constexpr int kL16RegionX = 4 * kNB * 1024;               // x_pos: 4 k-steps
+constexpr int kL16SmemF = 2 * kL16Region + kL16RegionX;
+constexpr int kL16SmemB = 2 * kL16Region + kRowTile * 3 * 4;
+
+// packs of one candidate, 16-byte units: forward [layer][k-step][neuron tile][lane], then the transposed packs of the backward chain
+enum { HF_L0 = 0, HF_L1, HF_L2, HF_L3, HF_F1, HF_POS, HF_N };
+enum { HB_POS = 0, HB_F1, HB_L3, HB_L2, HB_L1, HB_N };
+struct L16Pack {
+  int32_t f_off[HF_N], f_ks[HF_N], f_nt[HF_N];
+  int32_t b_off[HB_N], b_ks[HB_N];
+  int32_t f_total, total;
+};
+__host__ __device__ inline L16Pack l16_pack_desc() {
+  L16Pack d{};
+  int off = 0;
+  const int ks[HF_N] = {2, kKSAct, kKSAct, kKSAct, kKSAct, kL16KsHp}, nt[HF_N] = {kNT, kNT, kNT, kNT, kNT, kNT / 2};
+  for (int l = 0; l < HF_N; ++l) { d.f_off[l] = off; d.f_ks[l] = ks[l]; d.f_nt[l] = nt[l]; off += ks[l] * nt[l] * 64; }
+  d.f_total = off;
+  const int bk[HB_N] = {kLPosOut / 16, kKSAct, kKSAct, kKSAct, kKSAct};
+  for (int l = 0; l < HB_N; ++l) { d.b_off[l] = off; d.b_ks[l] = bk[l]; off += bk[l] * kNT * 64; }
+  d.total = off;
+  return d;
+}
+// npp_light_desc index of a pack entry: periodic 0..3, pos (4), feature1 (5), rgb (6)
+__host__ __device__ inline int l16_fwd_layer(int l) { return l < 4 ? l : (l == HF_F1 ? 5 : 4); }
+__host__ __device__ inline int l16_bwd_layer(int l) { return l == HB_POS ? 4 : (l == HB_F1 ? 5 : (l == HB_L3 ? 3 : (l == HB_L2 ? 2 : 1))); }
+
+struct L16Args {
+  npp_light_desc L;
+  const float* params; int64_t params_stride;       // (C, params_stride) fp32 master weights
+  const bf16x8* pack; int64_t pack_stride16;         // 16-byte units per candidate
+  const float* x_per; const float* x_pos; const int64_t* idx; int64_t n_src;
+  char* actF; int64_t act_stride;                    // forward stash, bytes per candidate
+  char* dzF; int64_t dz_stride;                      // gradient stash
+  float* pred;                                       // (C, B, 3)
+  const float* dpred;                                // (C, B, 3), backward without the folded loss
+  int64_t B;
+  const float* gt; const float* latents; const float* spline; int n_knots; float x_scale;
+  float* loss; float* dlatent;
+};
+
+// ---- packs ----------------------------------------------------------------------------------------------------------------
+// forward unit (k-step ks, tile nt, lane (m, hh)) element j = W[32 nt + m][16 ks + perm16(hh, j)]; backward unit (ks, tile t, lane)
+// element j = W[16 ks + perm16(hh, j)][32 t + m]; zero outside the matrix
+__global__ void light16_pack_kernel(L16Args a, L16Pack pd, bf16x8* __restrict__ out, int64_t out_stride16) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= pd.total) return;
+  const float* P = a.params + (int64_t)blockIdx.y * a.params_stride;
+  const bool bwd = u >= pd.f_total;
+  int l = 0;
+  if (!bwd) { for (int q = 1; q < HF_N; ++q) if (u >= pd.f_off[q]) l = q; }
+  else { for (int q = 1; q < HB_N; ++q) if (u >= pd.b_off[q]) l = q; }
+  const int r = u - (bwd ? pd.b_off[l] : pd.f_off[l]);
+  const int nt_n = bwd ? kNT : pd.f_nt[l];
+  const int lane = r & 63, nt = (r >> 6) % nt_n, ks = (r >> 6) / nt_n;
+  const int m = nt * 32 + (lane & 31), hh = lane >> 5;
+  const int li = bwd ? l16_bwd_layer(l) : l16_fwd_layer(l);
+  const float* Wm = P + a.L.w_off[li];
+  const int ld = a.L.ld[li], n_out = a.L.n_out[li], n_in = a.L.n_in[li];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * ks + perm16(hh, j);
+    float v = 0.0f;
+    if (!bwd) { if (m < n_out && k < n_in) v = Wm[(int64_t)m * ld + k]; }
+    else if (k < n_out && m < kLW) v = Wm[(int64_t)k * ld + m];
+    o[j] = (__bf16)v;
+  }
+  out[(int64_t)blockIdx.y * out_stride16 + u] = o;
+}
+
+// ---- optimizer.step() + the packs of the next forward / backward in one launch ----------------------------------------------------
+// Adam over the stacked fp32 blobs (adam_update, npp_common.h); the gradient of a parameter is the sum of the weight-gradient
+// launch's split-K slabs in slab order (plain stores there, no atomics: bit-reproducible); every updated weight is scattered as bf16
+// into both packs through the inverse of light16_pack_kernel's map.  The extra block column steps the candidate's six
+// adaptive-loss latents and clears one loss word.
+struct L16AdamArgs {
+  npp_light_desc L;
+  float *p, *m, *v; int64_t stride; int32_t n;
+  const float* gslabs; int32_t n_slabs; int64_t slab_stride, slab_cand_stride;
+  __bf16* pack; int64_t pack_stride16;
+  float *lat, *lat_m, *lat_v, *dlat, *zero;
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+};
+__global__ __launch_bounds__(256) void light16_adam_pack_kernel(L16AdamArgs a, L16Pack pd) {
+  const int c = blockIdx.y;
+  if (blockIdx.x == gridDim.x - 1) {
+    const int t = threadIdx.x;
+    if (t < 6) {
+      const int i = c * 6 + t;
+      float m = a.lat_m[i], v = a.lat_v[i];
+      a.lat[i] = adam_update(a.lat[i], m, v, a.dlat[i], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+      a.lat_m[i] = m; a.lat_v[i] = v; a.dlat[i] = 0.0f;
+    } else if (t == 6 && a.zero) a.zero[c] = 0.0f;
+    return;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t gi = (int64_t)c * a.stride + i;
+  const float* gs = a.gslabs + (int64_t)c * a.slab_cand_stride + i;
+  float g = gs[0];
+  for (int s = 1; s < a.n_slabs; ++s) g += gs[(int64_t)s * a.slab_stride];
+  float m = a.m[gi], v = a.v[gi];
+  const float w = adam_update(a.p[gi], m, v, g, a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+  a.p[gi] = w; a.m[gi] = m; a.v[gi] = v;
+  int li = -1;
+#pragma unroll
+  for (int q = 0; q < 6; ++q)          // (biases and rgb_linear are read from the blob by the chains: nothing to scatter)
+    if (i >= a.L.w_off[q] && i < a.L.w_off[q] + (int64_t)a.L.n_out[q] * a.L.ld[q]) li = q;
+  if (li < 0) return;
+  const int off = i - (int)a.L.w_off[li], ld = a.L.ld[li];
+  const int row = off / ld, col = off - row * ld;
+  if (col >= a.L.n_in[li]) return;                        // pad column of the stored matrix
+  __bf16* pk = a.pack + (int64_t)c * a.pack_stride16 * 8;
+  const __bf16 wb = (__bf16)w;
+  const int lf = li < 4 ? HF_L0 + li : (li == 4 ? HF_POS : HF_F1);
+  {
+    const int c16 = col & 15;
+    const int64_t unit = pd.f_off[lf] + ((int64_t)(col >> 4) * pd.f_nt[lf] + (row >> 5)) * 64 + (row & 31) + 32 * unperm_hh(c16);
+    pk[unit * 8 + unperm_j(c16)] = wb;
+  }
+  if (li >= 1 && col < kLW) {                               // transposed pack: A[m = col][k = row]
+    const int lb = li == 4 ? HB_POS : (li == 5 ? HB_F1 : (li == 3 ? HB_L3 : (li == 2 ? HB_L2 : HB_L1)));
+    const int c16 = row & 15;
+    const int64_t unit = pd.b_off[lb] + ((int64_t)(row >> 4) * kNT + (col >> 5)) * 64 + (col & 31) + 32 * unperm_hh(c16);
+    pk[unit * 8 + unperm_j(c16)] = wb;
+  }
+}
+
+// ---- shared pieces ----------------------------------------------------------------------------------------------------------------
+template <int NTW>
+__device__ __forceinline__ void l16_bias(f32x16 (&acc)[NTW][kNB], const float* __restrict__ bias, int nt0, const Lane& L) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    f32x16 bv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = bias[(nt0 + nt) * 32 + acc_row(r, L.h)];
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) acc[nt][bt] = bv;
+  }
+}
+// forward epilogue: SNAKE: z -> fp16 stash, a = snake(z) -> fragments of the next layer; linear: the bf16 fragments are the stash.
+// acc keeps the fp32 activation (pos_linears.0 -> rgb_linear reads it back)
+template <bool SNAKE, int NTW>
+__device__ __forceinline__ void l16_epi(f32x16 (&acc)[NTW][kNB], char* out, int nt0, char* arr, int arr_nks, int wg, const Lane& L) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int ntg = nt0 + nt;
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      if (SNAKE) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) stash_store(arr + wfmt_unit(arr_nks, wg, 2 * ntg + s, bt, L.b, L.h), pack_acc_f16(acc[nt][bt], s));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][bt][r] = snake_fast(acc[nt][bt][r]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 f = pack_acc(acc[nt][bt], s);
+        if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
+        if (!SNAKE) stash_store(arr + wfmt_unit(arr_nks, wg, 2 * ntg + s, bt, L.b, L.h), f);
+      }
+    }
+  }
+}
+// one input fragment built from a row-major fp32 table: slot j of unit (k-step ks, lane half hh) = column 16 ks + perm16(hh, j)
+__device__ __forceinline__ bf16x8 l16_in_frag(const float* __restrict__ row, int ks, int hh, int ncol) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = 16 * ks + perm16(hh, j);
+    f[j] = (__bf16)(col < ncol ? row[col] : 0.0f);
+  }
+  return f;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, L16Pack pd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R0 = smem;
+  char* R1 = smem + kL16Region;
+  char* RX = smem + 2 * kL16Region;
+  Lane L;
+  L.tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  L.lane = threadIdx.x & 63;
+  L.b = L.lane & 31;
+  L.h = L.lane >> 5;
+  L.n_wg = (int)gridDim.x; L.xslot = 0; L.xcount = 1;
+  const int c = blockIdx.y, wg = blockIdx.x;
+  const int64_t B = a.B, row0 = (int64_t)wg * kRowTile;
+  const float* P = a.params + (int64_t)c * a.params_stride;
+  char* actF = a.actF + (int64_t)c * a.act_stride;
+  const int nt0 = 2 * L.wave;
+  auto arr = [&](int ks_off) -> char* { return actF + wfmt_array_base(ks_off, L.n_wg); };
+
+  WRing<2> ring;
+  WRing<1> ringp;
+  ring.rsrc = ringp.rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride16, pd.total);
+  wring_fill<2, kNT>(ring, (wptr_t)pd.f_off[HF_L0], nt0, L.lane);
+
+  // inputs -> fragments: x_per (2 k-steps, region R1) and x_pos (4 k-steps, region RX), both also into their stash arrays
+  {
+    const int ks = L.tid >> 7, bt = (L.tid >> 6) & 1;
+    const int64_t r = row0 + bt * 32 + L.b, src = a.idx ? a.idx[r] : r;
+    const bf16x8 f = l16_in_frag(a.x_per + ((int64_t)c * a.n_src + src) * kLPer, ks, L.h, kLPer);
+    lds_store_frag(R1, ks, bt, L.lane, f);
+    stash_store(arr(L16A_XP) + wfmt_unit(2, wg, ks, bt, L.b, L.h), f);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ksl = 2 * q + ks;
+      const bf16x8 g = l16_in_frag(a.x_pos + src * kLPos, ksl, L.h, kLPos);
+      lds_store_frag(RX, ksl, bt, L.lane, g);
+      stash_store(arr(L16A_HP) + wfmt_unit(kL16KsHp, wg, kKSAct + ksl, bt, L.b, L.h), g);
+    }
+  }
+  wg_barrier();
+
+  f32x16 acc[2][kNB];
+  constexpr int A = kKSAct;
+  // periodic_linears.0: 20 (32 slots) -> 256, snake: R1 -> R0
+  l16_bias<2>(acc, P + a.L.b_off[0], nt0, L);
+  mma_ring<0, 4, 2, 4, 2, kNT>(acc, R1, 0, (wptr_t)pd.f_off[HF_L0], (wptr_t)pd.f_off[HF_L1], nt0, L, ring);
+  l16_epi<true, 2>(acc, R0, nt0, arr(L16A_Z0), A, wg, L);
+  wg_barrier();
+  // periodic_linears.1 .. 3: R0 -> R1 -> R0 -> R1
+#pragma unroll
+  for (int l = 1; l <= 3; ++l) {
+    char* in = (l & 1) ? R0 : R1;
+    char* out = (l & 1) ? R1 : R0;
+    l16_bias<2>(acc, P + a.L.b_off[l], nt0, L);
+    mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, (wptr_t)pd.f_off[HF_L0 + l], (wptr_t)pd.f_off[HF_L0 + l + 1], nt0, L, ring);
+    l16_epi<true, 2>(acc, out, nt0, arr(L16A_Z0 + A * l), A, wg, L);
+    wg_barrier();
+  }
+  // feature_linear1 (linear): R1 -> R0, also the first 16 k-steps of the [f1 | x_pos] stash
+  l16_bias<2>(acc, P + a.L.b_off[5], nt0, L);
+  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, (wptr_t)pd.f_off[HF_F1], kNoW, nt0, L, ring);
+  wring_fill<1, kNT / 2>(ringp, (wptr_t)pd.f_off[HF_POS], L.wave, L.lane);
+  l16_epi<false, 2>(acc, R0, nt0, arr(L16A_HP), kL16KsHp, wg, L);
+  wg_barrier();
+  // pos_linears.0: [f1 (R0) | x_pos (RX)] -> 128, snake; one neuron tile per wave
+  f32x16 accp[1][kNB];
+  constexpr wptr_t UP = (kNT / 2) * 64;
+  l16_bias<1>(accp, P + a.L.b_off[4], L.wave, L);
+  mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, (wptr_t)pd.f_off[HF_POS], (wptr_t)pd.f_off[HF_POS] + A * UP, L.wave, L, ringp);
+  mma_ring<0, 4, 4, 4, 1, kNT / 2>(accp, RX, 0, (wptr_t)pd.f_off[HF_POS] + A * UP, kNoW, L.wave, L, ringp);
+  l16_epi<true, 1>(accp, nullptr, L.wave, arr(L16A_ZP), kLPosOut / 16, wg, L);
+  // rgb_linear 128 -> 3 + sigmoid (models/helpers.py:55-56): per-lane partial dot over its 16 neurons, lane halves by shuffle,
+  // the four waves through LDS
+  wg_barrier();                                  // every wave is done with R0 / RX
+  float* sRGB = (float*)R0;                      // [4 waves][64 rows][3]
+  {
+    const float* Wr = P + a.L.w_off[6];
+    const int ldr = a.L.ld[6];
+    float part[kNB][3];
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) part[bt][q] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = L.wave * 32 + acc_row(r, L.h);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float w = Wr[q * ldr + k];
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) part[bt][q] = fmaf(w, accp[0][bt][r], part[bt][q]);
+      }
+    }
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float v = part[bt][q] + __shfl_xor(part[bt][q], 32, 64);
+        if (L.h == 0) sRGB[(L.wave * kRowTile + bt * 32 + L.b) * 3 + q] = v;
+      }
+  }
+  wg_barrier();
+  if (L.tid < kRowTile * 3) {
+    const int row = L.tid / 3, q = L.tid - row * 3;
+    float z = P[a.L.b_off[6] + q];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) z += sRGB[(w * kRowTile + row) * 3 + q];
+    a.pred[((int64_t)c * B + row0 + row) * 3 + q] = 1.0f / (1.0f + expf(-z));
+  }
+}
+
+// ---- backward (data gradients) ------------------------------------------------------------------------------------------------
+struct L16ZPre { f16x8 z[2][kNB][2]; };
+__device__ __forceinline__ void l16_zfetch(L16ZPre& zp, const char* z_array, int wg, int kt0, const Lane& L) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) zp.z[t][bt][s] = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * (kt0 + t) + s, bt, L.b, L.h));
+}
+template <bool DERIV>
+__device__ __forceinline__ void l16_bepi(f32x16 (&acc)[2][kNB], char* out, const L16ZPre* zp, char* dz_array, int wg, int kt0, const Lane& L) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ntg = kt0 + t;
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt) {
+      f32x16 g = acc[t][bt];
+      if (DERIV) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f16x8 zf = zp->z[t][bt][s];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));     // activations.py:29-35: 1 + sin 2z
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 f = pack_acc(g, s);
+        if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
+        dz_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void l16_zero(f32x16 (&acc)[2][kNB]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
+}
+
+__global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, L16Pack pd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R0 = smem;
+  char* R1 = smem + kL16Region;
+  float* sD = (float*)(smem + 2 * kL16Region);       // d raw [64 rows][3]
+  Lane L;
+  L.tid = threadIdx.x;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  L.lane = threadIdx.x & 63;
+  L.b = L.lane & 31;
+  L.h = L.lane >> 5;
+  L.n_wg = (int)gridDim.x; L.xslot = 0; L.xcount = 1;
+  const int c = blockIdx.y, wg = blockIdx.x, tid = L.tid;
+  const int64_t B = a.B, row0 = (int64_t)wg * kRowTile;
+  const float* P = a.params + (int64_t)c * a.params_stride;
+  const char* actF = a.actF + (int64_t)c * a.act_stride;
+  char* dzF = a.dzF + (int64_t)c * a.dz_stride;
+  const int kt0 = 2 * L.wave;
+  auto zs = [&](int ks_off) { return actF + wfmt_array_base(ks_off, L.n_wg); };
+  auto dzr = [&](int ks_off) { return dzF + wfmt_array_base(ks_off, L.n_wg); };
+
+  // everything the prologue needs from memory first: the weight ring of the first data-gradient part, rgb_linear's rows, z_p
+  WRing<2> ring;
+  ring.rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride16, pd.total);
+  wring_fill<2, kNT>(ring, (wptr_t)pd.b_off[HB_POS], kt0, L.lane);
+  f16x8 zp_pre[kNB][2];
+#pragma unroll
+  for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) zp_pre[bt][s] = *(const f16x8*)(zs(L16A_ZP) + wfmt_unit(kLPosOut / 16, wg, 2 * L.wave + s, bt, L.b, L.h));
+  float wr[3][16];
+  {
+    const float* Wr = P + a.L.w_off[6];
+    const int ldr = a.L.ld[6];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wr[q][r] = Wr[q * ldr + L.wave * 32 + acc_row(r, L.h)];
+  }
+
+  // d raw = d pred * pred (1 - pred); with the pixel loss folded in (a.gt): d pred = d img2mse(robust_loss_adaptive)/d pred right here
+  // (models/mse_calculator.py:13-27 without a mask: the arithmetic of pixel_loss_body, npp_common.h), loss / latent gradients by atomics
+  __shared__ ChanParams cp[3];
+  __shared__ float sred[7];
+  if (a.gt) {
+    if (tid < 3) cp[tid] = chan_params(a.latents[c * 6 + tid], a.latents[c * 6 + 3 + tid], a.spline, a.n_knots, a.x_scale);
+    if (tid < 7) sred[tid] = 0.0f;
+    wg_barrier();
+  }
+  if (tid < kRowTile * 3) {
+    const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
+    const float p = a.pred[g];
+    float dp;
+    if (a.gt) {
+      const int ch = tid % 3;
+      const ChanParams q = cp[ch];
+      const float inv = 1.0f / (3.0f * (float)B);
+      const float x = p - a.gt[row0 * 3 + tid];
+      const float xs = x / q.c, ssx = xs * xs;
+      const float u = ssx / q.beta + 1.0f, e = 0.5f * q.alpha, lnu = logf(u);
+      const float ue = expf(e * lnu), ue1 = ue / u;
+      dp = inv * (x / (q.c * q.c)) * ue1;
+      atomicAdd(&sred[0], (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz);
+      atomicAdd(&sred[1 + ch], -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz);
+      atomicAdd(&sred[4 + ch], -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c);
+    } else {
+      dp = a.dpred[g];
+    }
+    sD[tid] = dp * p * (1.0f - p);
+  }
+  wg_barrier();
+  if (a.gt && tid < 7) {
+    const float inv = 1.0f / (3.0f * (float)B), v = sred[tid];
+    if (tid == 0) atomicAdd(a.loss + c, v * inv);
+    else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
+    else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+  }
+  // d raw as a 2-k-step W-format array (rgb_linear's weight gradient): features 0..2 real, the rest zero
+  {
+    const int q1 = tid >> 7, bt = (tid >> 6) & 1, row = bt * 32 + L.b;
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+    if (q1 == 0 && L.h == 0) {
+      f[0] = (__bf16)sD[row * 3 + 0];
+      f[1] = (__bf16)sD[row * 3 + 1];
+      f[2] = (__bf16)sD[row * 3 + 2];
+    }
+    dz_store(dzr(L16D_RAW) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
+  }
+  // d a_p = d raw W_rgb, d z_p = d a_p * snake'(z_p): wave w owns pos_linears.0's neuron tile w -> fragments in R0 + the stash
+#pragma unroll
+  for (int bt = 0; bt < kNB; ++bt) {
+    const int row = bt * 32 + L.b;
+    const float g0 = sD[row * 3 + 0], g1 = sD[row * 3 + 1], g2 = sD[row * 3 + 2];
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const f16x8 zf = zp_pre[bt][s];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 f = pack_acc(g, s);
+      lds_store_frag(R0, 2 * L.wave + s, bt, L.lane, f);
+      dz_store(dzr(L16D_ZP) + wfmt_unit(kLPosOut / 16, wg, 2 * L.wave + s, bt, L.b, L.h), f);
+    }
+  }
+  wg_barrier();
+
+  f32x16 acc[2][kNB];
+  L16ZPre zpre;
+  constexpr int KP = kLPosOut / 16, A = kKSAct;
+  // d f1 = W_pos[:, :256]^T d z_p  (feature_linear1 is linear: this IS its d z; x_pos gets no gradient): R0 -> R1
+  l16_zero(acc);
+  mma_ring<0, KP, KP, KP, 2, kNT>(acc, R0, 0, (wptr_t)pd.b_off[HB_POS], (wptr_t)pd.b_off[HB_F1], kt0, L, ring);
+  l16_bepi<false>(acc, R1, nullptr, dzr(L16D_F1), wg, kt0, L);
+  wg_barrier();
+  // d z_3 = (W_f1^T d f1) * snake'(z_3), d z_2 = (W_3^T d z_3) * snake'(z_2), ..., d z_0: R1 -> R0 -> R1 -> R0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int l = 3 - j;                           // hidden layer whose d z this step produces
+    char* in = (j & 1) ? R0 : R1;
+    char* out = (j & 1) ? R1 : R0;
+    l16_zero(acc);
+    l16_zfetch(zpre, zs(L16A_Z0 + A * l), wg, kt0, L);
+    mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, (wptr_t)pd.b_off[HB_F1 + j], j == 3 ? kNoW : (wptr_t)pd.b_off[HB_F1 + j + 1], kt0, L, ring);
+    l16_bepi<true>(acc, j == 3 ? nullptr : out, &zpre, dzr(L16D_Z0 + A * l), wg, kt0, L);
+    if (j != 3) wg_barrier();
+  }
+}
+
+}  // namespace npp
+
+using namespace npp;
+
+static int l16_check(const npp_light_desc* L, const void* p0, const void* p1, int C, int64_t B, const char* who) {
+  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < kRowTile || B % kRowTile || B / kRowTile > 65535) {
+    set_error("%s: bad argument (C=%d B=%lld; B a positive multiple of %d)", who, C, (long long)B, kRowTile);
+    return NPP_ERR_ARG;
+  }
+  const int n_out[7] = {kLW, kLW, kLW, kLW, kLPosOut, kLW, 3}, n_in[7] = {kLPer, kLW, kLW, kLW, kLW + kLPos, kLW, kLPosOut};
+  for (int i = 0; i < 7; ++i)
+    if (L->n_out[i] != n_out[i] || L->n_in[i] != n_in[i] || L->ld[i] < n_in[i] || L->w_off[i] < 0 || L->b_off[i] < 0) {
+      set_error("%s: layer %d is %d x %d (ld %d): this build fuses NPP_Net_light(D=4, W=256) with 20 / 42 input columns only", who, i,
+                L->n_out[i], L->n_in[i], L->ld[i]);
+      return NPP_ERR_UNSUPPORTED;
+    }
+  return NPP_OK;
+}
+
+extern "C" int64_t npp_light16_pack_bytes(void) { return 16 * (int64_t)l16_pack_desc().total; }
+extern "C" int64_t npp_light16_stash_bytes(int64_t B, int which) {
+  if (B < kRowTile || B % kRowTile || which < 0 || which > 1) return NPP_ERR_ARG;
+  return wfmt_array_base(which ? L16D_TOTAL : L16A_TOTAL, B / kRowTile);
+}
+
+extern "C" int npp_light16_pack(const npp_light_desc* L, const float* d_params, int64_t params_stride, int C, void* d_pack,
+                                int64_t pack_stride_bytes, void* stream) {
+  int rc = l16_check(L, d_params, d_pack, C, kRowTile, "npp_light16_pack");
+  if (rc) return rc;
+  const L16Pack pd = l16_pack_desc();
+  if (pack_stride_bytes < 16 * (int64_t)pd.total || pack_stride_bytes % 16) { set_error("npp_light16_pack: pack stride %lld", (long long)pack_stride_bytes); return NPP_ERR_ARG; }
+  L16Args a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride;
+  hipLaunchKernelGGL(light16_pack_kernel, dim3((unsigned)((pd.total + 255) / 256), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd,
+                     (bf16x8*)d_pack, pack_stride_bytes / 16);
+  return check_launch("npp_light16_pack");
+}
+
+extern "C" int npp_light16_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                               int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
+                               int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, void* stream) {
+  int rc = l16_check(L, d_params, d_pack, C, B, "npp_light16_fwd");
+  if (rc) return rc;
+  if (!d_x_per || !d_x_pos || !d_actF || !d_pred || (d_idx ? n_src < 1 : n_src != B) || pack_stride_bytes % 16 || act_stride_bytes % 16 ||
+      act_stride_bytes < wfmt_array_base(L16A_TOTAL, B / kRowTile)) {
+    set_error("npp_light16_fwd: null argument / n_src / strides");
+    return NPP_ERR_ARG;
+  }
+  L16Args a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = (const bf16x8*)d_pack; a.pack_stride16 = pack_stride_bytes / 16;
+  a.x_per = d_x_per; a.x_pos = d_x_pos; a.idx = d_idx; a.n_src = n_src; a.actF = (char*)d_actF; a.act_stride = act_stride_bytes;
+  a.pred = d_pred; a.B = B;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)light16_fwd_kernel, kL16SmemF)) { set_error("npp_light16_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(light16_fwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kL16Threads), kL16SmemF, (hipStream_t)stream, a,
+                     l16_pack_desc());
+  return check_launch("npp_light16_fwd");
+}
+
+extern "C" int npp_light16_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                               int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
+                               const float* d_dpred, const float* d_gt, const float* d_latents, const float* d_spline, int n_knots,
+                               float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes,
+                               void* stream) {
+  int rc = l16_check(L, d_params, d_pack, C, B, "npp_light16_bwd");
+  if (rc) return rc;
+  if (!d_actF || !d_pred || !d_dzF || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || !d_loss || !d_dlatent) : !d_dpred) ||
+      pack_stride_bytes % 16 || act_stride_bytes % 16 || dz_stride_bytes % 16 || act_stride_bytes < wfmt_array_base(L16A_TOTAL, B / kRowTile) ||
+      dz_stride_bytes < wfmt_array_base(L16D_TOTAL, B / kRowTile)) {
+    set_error("npp_light16_bwd: null argument (d_dpred, or d_gt with latents / spline / loss / dlatent) / strides");
+    return NPP_ERR_ARG;
+  }
+  L16Args a{};
+  a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = (const bf16x8*)d_pack; a.pack_stride16 = pack_stride_bytes / 16;
+  a.actF = (char*)d_actF; a.act_stride = act_stride_bytes; a.dzF = (char*)d_dzF; a.dz_stride = dz_stride_bytes;
+  a.pred = (float*)d_pred; a.dpred = d_dpred; a.B = B;
+  a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)light16_bwd_kernel, kL16SmemB)) { set_error("npp_light16_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(light16_bwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kL16Threads), kL16SmemB, (hipStream_t)stream, a,
+                     l16_pack_desc());
+  return check_launch("npp_light16_bwd");
+}
+
+extern "C" int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                                     const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                                     int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                                     float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  int rc = l16_check(L, d_params, d_pack, C, kRowTile, "npp_light16_adam_pack");
+  if (rc) return rc;
+  const L16Pack pd = l16_pack_desc();
+  if (!d_m || !d_v || !d_gslabs || !d_lat || !d_lat_m || !d_lat_v || !d_dlat || n < 1 || n > stride || n > 0x7fffffffLL || step < 1 ||
+      n_slabs < 1 || slab_stride < n || slab_cand_stride < (int64_t)n_slabs * slab_stride || pack_stride_bytes < 16 * (int64_t)pd.total ||
+      pack_stride_bytes % 16) {
+    set_error("npp_light16_adam_pack: bad argument");
+    return NPP_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  L16AdamArgs a{};
+  a.L = *L; a.p = d_params; a.m = d_m; a.v = d_v; a.stride = stride; a.n = (int32_t)n;
+  a.gslabs = d_gslabs; a.n_slabs = n_slabs; a.slab_stride = slab_stride; a.slab_cand_stride = slab_cand_stride;
+  a.pack = (__bf16*)d_pack; a.pack_stride16 = pack_stride_bytes / 16;
+  a.lat = d_lat; a.lat_m = d_lat_m; a.lat_v = d_lat_v; a.dlat = d_dlat; a.zero = d_zero;
+  a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+  hipLaunchKernelGGL(light16_adam_pack_kernel, dim3((unsigned)((n + 255) / 256 + 1), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd);
+  return check_launch("npp_light16_adam_pack");
+}

@@ -28,6 +28,7 @@
 // Algorithmic work: 2 * sum_l n_out*n_in FLOP per batch row (embedding pad slots and the
 // padding of the 3-row rgb job are not counted).
 #include "npp_common.h"
+#include "npp_light_layout.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -712,4 +713,66 @@ static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K
   }
   hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
   return check_launch("npp_mlp_wgrad");
+}
+
+// ---- the same launch over NPP_Net_light's 16-bit stashes (csrc/npp_light16.hip): seven jobs per candidate, candidate =
+// image of a stacked launch.  d_gslabs: (C, ksplit, slab_stride) floats in the light blob's own layout (npp_light_desc offsets, stored
+// leading dimensions); every weight and bias of the blob is written by plain stores (pad columns of the stored matrices meet zero
+// inputs), so the buffer needs no clearing.
+extern "C" int npp_light16_wgrad(const npp_light_desc* L, const void* d_actF, int64_t act_stride_bytes, const void* d_dzF,
+                                 int64_t dz_stride_bytes, int C, int64_t B, int ksplit, float* d_gslabs, int64_t slab_stride,
+                                 int64_t slab_cand_stride, void* stream) {
+#if NPP_WIDTH != 256
+  set_error("npp_light16_wgrad: built for W = 256 only");
+  return NPP_ERR_UNSUPPORTED;
+#else
+  if (!L || !d_actF || !d_dzF || !d_gslabs || C < 1 || C > NPP_MAX_STACK || B < kRowTile || B % kRowTile || B / kRowTile > 65536 || ksplit < 1 ||
+      ksplit > 64 || act_stride_bytes % 16 || dz_stride_bytes % 16 || slab_stride % 4 || slab_cand_stride % 4 ||
+      slab_cand_stride < (int64_t)ksplit * slab_stride) {
+    set_error("npp_light16_wgrad: bad arguments (C=%d <= %d, B=%lld a multiple of %d, ksplit=%d)", C, NPP_MAX_STACK, (long long)B, kRowTile, ksplit);
+    return NPP_ERR_ARG;
+  }
+  for (int i = 0; i < 7; ++i)
+    if (L->ld[i] % 4 || L->w_off[i] % 4 || L->ld[i] < L->n_in[i] || L->w_off[i] + (int64_t)L->n_out[i] * L->ld[i] > slab_stride ||
+        L->b_off[i] + L->n_out[i] > slab_stride) {
+      set_error("npp_light16_wgrad: layer %d: leading dimension %d / offset %lld must be multiples of 4 inside the slab", i, L->ld[i], (long long)L->w_off[i]);
+      return NPP_ERR_ARG;
+    }
+  WArgs A{};
+  A.dzF = (const char*)d_dzF;
+  A.actF = (const char*)d_actF;
+  A.n_wg = B / kRowTile;
+  A.dz_bytes = wfmt_array_base(L16D_TOTAL, A.n_wg);
+  A.act_bytes = wfmt_array_base(L16A_TOTAL, A.n_wg);
+  if (dz_stride_bytes < A.dz_bytes || act_stride_bytes < A.act_bytes) { set_error("npp_light16_wgrad: candidate strides smaller than one candidate's arrays"); return NPP_ERR_ARG; }
+  A.gslabs = d_gslabs;
+  A.slab_stride = slab_stride;
+  int nj = 0, tile = 0;
+  auto add = [&](int li, int a_ks0, int a_nks, int b_ks0, int b_nks, int n, int b_is_z) {
+    WJob& j = A.jobs[nj++];
+    j.a_ks0 = a_ks0; j.a_nks = a_nks; j.m = L->n_out[li];
+    j.b_ks0 = b_ks0; j.b_nks = b_nks; j.n = n;
+    j.colmode = 0; j.col0 = 0; j.ld = L->ld[li]; j.bias_on = 1; j.b_is_z = b_is_z;
+    j.w_off = L->w_off[li]; j.b_off = L->b_off[li];
+    j.tile0 = tile;
+    j.tiles_n = (n + kWT - 1) / kWT;
+    tile += ((j.m + kWT - 1) / kWT) * j.tiles_n;
+  };
+  const int A16 = kKSAct;
+  add(0, L16D_Z0, A16, L16A_XP, 2, kLPer, 0);                                            // periodic_linears.0: x_per
+  for (int l = 1; l <= 3; ++l) add(l, L16D_Z0 + A16 * l, A16, L16A_Z0 + A16 * (l - 1), A16, kLW, 1);     // snake(z_{l-1})
+  add(5, L16D_F1, A16, L16A_Z0 + A16 * 3, A16, kLW, 1);                                   // feature_linear1: snake(z_3)
+  add(4, L16D_ZP, kLPosOut / 16, L16A_HP, kL16KsHp, (kLW + kLPos + 3) / 4 * 4, 0);         // pos_linears.0: [f1 | x_pos | 0 0]
+  add(6, L16D_RAW, 2, L16A_ZP, kLPosOut / 16, kLPosOut, 1);                               // rgb_linear: snake(z_p)
+  if (L->ld[4] < (kLW + kLPos + 3) / 4 * 4) { set_error("npp_light16_wgrad: pos_linears.0 must be stored %d wide", (kLW + kLPos + 3) / 4 * 4); return NPP_ERR_ARG; }
+  A.njobs = nj;
+  A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)wgrad_kernel, kSmemW)) { set_error("npp_light16_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
+  A.ntiles = tile; A.ksplit = ksplit;
+  A.S = make_stack(C, tile * ksplit, nullptr);
+  A.dz_img_stride = dz_stride_bytes; A.act_img_stride = act_stride_bytes; A.slab_img_stride = slab_cand_stride;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(stack_grid(A.S)), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
+  return check_launch("npp_light16_wgrad");
+#endif
 }

@@ -221,9 +221,12 @@ class NPPNetLightBatch:
     (ProposalRanker._pixel_draws) and therefore x_pos and the colours; x_per (their lattice) and all weights are their own.
     State lives in stacked blobs (C, n_pad); .nets are ordinary NPPNetLight objects over the rows (render / score / state_dict)."""
 
-    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, fused=None):
+    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, fused=None, precision=None):
         """fused (default: NPP_LIGHT_FUSED != 0 and the topology is the searched one, D = 4 / W = 256 / 42 + 20 input columns): forward and
-        data-gradient chains as ONE launch each over all candidates (csrc/npp_light.hip) instead of one launch per layer."""
+        data-gradient chains as ONE launch each over all candidates (csrc/npp_light.hip) instead of one launch per layer.
+        precision: "fp32" (exact fp32 MFMA everywhere) or "bf16" (csrc/npp_light16.hip: bf16 operands, fp32 accumulation, fp32 master
+        weights and Adam -- the numeric contract of the main loop's MLP; fused topology, at most 16 candidates, batches of a multiple of
+        64 rows; anything else falls back to fp32).  Default: NPP_LIGHT_PRECISION, else "fp32"."""
         import os
         self.device = ops.select_device(device)
         self.C, self.W, self.D = len(cands), int(W), int(D)
@@ -264,7 +267,12 @@ class NPPNetLightBatch:
         self.fused = bool(fused)
         self.grouped_wgrad = os.environ.get("NPP_LIGHT_GROUPED_WGRAD", "1") != "0"
         self.fused_adam = self.fused and os.environ.get("NPP_LIGHT_FUSED_ADAM", "1") != "0"
-        self._pack_valid = False
+        self._pack_valid = self._pack16_valid = False
+        if precision is None:
+            precision = os.environ.get("NPP_LIGHT_PRECISION", "fp32")
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision {precision!r}: 'fp32' or 'bf16'")
+        self.bf16 = precision == "bf16" and self.fused and self.fused_adam and self.C <= 16
         if self.fused:
             from ._lib import LightDesc, lib
             order = [f"periodic_linears.{i}" for i in range(4)] + ["pos_linears.0", "feature_linear1", "rgb_linear"]
@@ -281,9 +289,48 @@ class NPPNetLightBatch:
             self._srow = [int(L.npp_light_stash_row(i)) for i in range(8)]       # z0 z1 z2 z3 hp zp xperT | rows
             self._drow = [int(L.npp_light_dstash_row(i)) for i in range(8)]      # dz0 dz1 dz2 dz3 df1 dzp drawT | rows
 
+    # ---- the 16-bit chains (csrc/npp_light16.hip)
+    def _work16(self, B):
+        ws = self._ws.get(("bf16", B))
+        if ws is None:
+            C = self.C
+            pb, ab, db = ops.light16_sizes(B)
+            u8 = lambda nb: torch.zeros(C, nb, dtype=torch.uint8, device=self.device)          # noqa: E731
+            n_wg = B // 64
+            ks = max(1, min(8, n_wg // 8))                      # split-K of the weight-gradient launch: >= 8 workgroup tiles per split
+            ws = dict(actF=u8(ab), dzF=u8(db), pred=torch.empty(C, B, 3, dtype=torch.float32, device=self.device),
+                      gslabs=torch.zeros(C, ks, self.n_pad, dtype=torch.float32, device=self.device))
+            if getattr(self, "_pack16", None) is None:
+                self._pack16 = u8(pb)
+            self._ws[("bf16", B)] = ws
+        return ws
+
+    def _train_step_bf16(self, x_pos, x_per, gt, idx=None):
+        """train_step() on the 16-bit chains: forward -> data gradients with the pixel loss folded in -> ONE grouped split-K
+        weight-gradient launch (partial sums by plain stores) -> Adam + bf16 re-pack: 4 launches for the whole candidate set."""
+        B = gt.shape[0]
+        ws = self._work16(B)
+        if not self._pack16_valid:
+            ops.light16_pack(self._desc, self.params, self._pack16)
+        ops.light16_fwd(self._desc, self.params, self._pack16, x_per.contiguous(), x_pos.contiguous(), ws["actF"], ws["pred"], idx=idx)
+        loss = self._loss2[self._li]
+        ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], None, ws["dzF"],
+                        loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
+        ops.light16_wgrad(self._desc, ws["actF"], ws["dzF"], B, ws["gslabs"])
+        n0 = self.nets[0]
+        step, lr = n0.opt_step + 1, n0.lr
+        self._li ^= 1
+        ops.light16_adam_pack(self._desc, self.params, self.m, self.v, self.n_params, ws["gslabs"], self._pack16, self.latents, self.lat_m,
+                              self.lat_v, self._dl_c, self._loss2[self._li], lr, step)
+        self._pack16_valid, self._pack_valid = True, False
+        for net in self.nets:
+            net.opt_step = step
+            net.advance_clock()
+        return loss
+
     def invalidate_pack(self):
         """Call after writing parameters from outside (load_state_dict on a member net): the next fused step re-packs first."""
-        self._pack_valid = False
+        self._pack_valid = self._pack16_valid = False
 
     def _work_fused(self, B):
         ws = self._ws.get(("fused", B))
@@ -343,6 +390,8 @@ class NPPNetLightBatch:
         """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20) -- or, with
         idx (B int64), the whole tables x_pos (n, in_pos) / x_per (C, n, 20) whose rows idx are this iteration's batch."""
         C, B = x_per.shape[0], gt.shape[0]
+        if self.bf16 and B % 64 == 0:
+            return self._train_step_bf16(x_pos, x_per, gt, idx)
         if self.fused and B % 32 == 0:
             loss = self._train_step_fused(x_pos, x_per, gt, idx)
             return self._adam(loss)
@@ -391,11 +440,11 @@ class NPPNetLightBatch:
             # optimizer.step() + zero_grad() + the packs of the next forward, one launch (csrc/npp_light.hip)
             ops.light_adam_pack(self._desc, self.params, self.m, self.v, self.grad, self.n_params, self._pack, self.latents, self.lat_m, self.lat_v,
                                 self._dl_c, self._loss2[self._li], lr, step)
-            self._pack_valid = True
+            self._pack_valid, self._pack16_valid = True, False
         else:
             ops.adam_step_net(self.params.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), 1, self.params.numel(),
                               self.latents.view(-1), self.lat_m.view(-1), self.lat_v.view(-1), self._dl_c.view(-1), self._loss2[self._li], lr, step)
-            self._pack_valid = False
+            self._pack_valid = self._pack16_valid = False
         for net in self.nets:
             net.opt_step = step
             net.advance_clock()
@@ -437,8 +486,9 @@ class ProposalRanker:
 
     def __init__(self, masked_img, i_train, i_val, device="cuda", N_iters=300, N_rand=2048, W=256, D=4, lrate=5e-4, lrate_decay=500,
                  perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
-                 lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False):
-        """carry_latents: in the reference the adaptive pixel loss is ONE module-level object (models/helpers.py:8) that every
+                 lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False, precision=None):
+        """precision: "fp32" | "bf16" | None (NPP_LIGHT_PRECISION, else fp32): the arithmetic of the candidate fits (NPPNetLightBatch).
+        carry_latents: in the reference the adaptive pixel loss is ONE module-level object (models/helpers.py:8) that every
         candidate's optimiser trains on (helpers.py:144), so candidate k + 1 starts from the latents candidate k left (fresh Adam
         moments) and the ranking depends on the order of the candidates.  False (default; SURVEY 3.3 / 8 e: candidates are independent
         units -- what lets them share launches and shard over GPUs): every candidate starts from the initial latents, as the first
@@ -458,6 +508,7 @@ class ProposalRanker:
         self.pw, self.cw = float(perceptual_weight), float(contextual_weight)
         self.rng_mode = rng_mode
         self.carry_latents, self.record_losses, self.loss_log = bool(carry_latents), bool(record_losses), []
+        self.precision = precision
         if freqs is None:                                      # embedder.py:26 after torch.manual_seed(0) (search.py:92)
             g = torch.random.get_rng_state()
             torch.manual_seed(0)
@@ -669,7 +720,7 @@ class ProposalRanker:
         for g0 in range(0, len(cands), group):
             part = cands[g0:g0 + group]
             batch = NPPNetLightBatch(part, self.freqs, (self.H, self.W_img), init, W=self.Wn, D=self.D, device=self.device,
-                                     lrate=self.lrate, lrate_decay=self.lrate_decay)
+                                     lrate=self.lrate, lrate_decay=self.lrate_decay, precision=self.precision)
             tabs = [net.embed(self.i_train_dev) for net in batch.nets]                                # search.py:104-108 tables
             x_pos_all = tabs[0][0]                                                                   # the same for every candidate
             x_per_all = torch.stack([t[1] for t in tabs])                                            # (C, n_train, 20)

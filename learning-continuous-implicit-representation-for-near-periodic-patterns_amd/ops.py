@@ -675,6 +675,83 @@ def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash, loss_args=No
                               _p(lat), _p(spl), nk, xs, _p(loss), _p(dlat), C, B, _p(draw), _p(dstash), _stream()), "npp_light_bwd")
 
 
+# ---- f1 on the 16-bit matrix pipe (csrc/npp_light16.hip) ------------------------------------------------------------------------
+def light16_sizes(B):
+    """(pack bytes, forward-stash bytes, gradient-stash bytes) per candidate for batches of B rows (a multiple of 64)."""
+    L = lib()
+    return int(L.npp_light16_pack_bytes()), int(L.npp_light16_stash_bytes(B, 0)), int(L.npp_light16_stash_bytes(B, 1))
+
+
+def _bytes2d(t, name):
+    assert t.dtype == torch.uint8 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 16 == 0 and t.data_ptr() % 16 == 0, name
+
+
+def light16_pack(desc, params, pack):
+    """bf16 MFMA-ordered copies (forward + transposed) of C stacked NPP_Net_light blobs: params (C, n) fp32 -> pack (C, bytes) uint8."""
+    import ctypes
+    C = params.shape[0]
+    _bytes2d(pack, "pack")
+    assert params.stride(1) == 1 and pack.shape[0] == C
+    check(lib().npp_light16_pack(ctypes.byref(desc), _p(params), params.stride(0), C, _p(pack), pack.stride(0), _stream()), "npp_light16_pack")
+
+
+def light16_fwd(desc, params, pack, x_per, x_pos, actF, pred, idx=None):
+    """light_fwd on bf16 operands: pred (C, B, 3) fp32 and the W-format forward stash actF (C, bytes) uint8."""
+    import ctypes
+    C, n = x_per.shape[:2]
+    B = pred.shape[1]
+    _bytes2d(pack, "pack")
+    _bytes2d(actF, "actF")
+    assert x_per.is_contiguous() and x_pos.is_contiguous() and pred.is_contiguous()
+    assert x_per.shape == (C, n, 20) and x_pos.shape == (n, 42) and pred.shape == (C, B, 3) and actF.shape[0] == C
+    assert (idx is None and n == B) or (idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B)
+    check(lib().npp_light16_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n, C, B,
+                                _p(actF), actF.stride(0), _p(pred), _stream()), "npp_light16_fwd")
+
+
+def light16_bwd(desc, params, pack, actF, pred, dpred, dzF, loss_args=None):
+    """light_bwd on bf16 operands: the W-format gradient stash dzF (C, bytes) uint8; loss_args as light_bwd."""
+    import ctypes
+    C, B = pred.shape[:2]
+    _bytes2d(pack, "pack")
+    _bytes2d(actF, "actF")
+    _bytes2d(dzF, "dzF")
+    assert pred.is_contiguous() and dzF.shape[0] == C
+    if loss_args is None:
+        assert dpred.is_contiguous()
+        gt = lat = spl = loss = dlat = None
+        nk, xs = 0, 0.0
+    else:
+        gt, lat, spl, nk, xs, loss, dlat = loss_args
+        assert gt.shape == (B, 3) and gt.is_contiguous() and lat.shape == (C, 6) and lat.is_contiguous() and dlat.shape == (C, 6) and dlat.is_contiguous()
+        assert loss.numel() == C and loss.is_contiguous()
+    check(lib().npp_light16_bwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(actF), actF.stride(0), _p(pred),
+                                _p(dpred), _p(gt), _p(lat), _p(spl), nk, xs, _p(loss), _p(dlat), C, B, _p(dzF), dzF.stride(0), _stream()),
+          "npp_light16_bwd")
+
+
+def light16_wgrad(desc, actF, dzF, B, gslabs):
+    """All seven weight / bias gradients of the C candidates in one launch of the grouped split-K kernel: gslabs (C, ksplit, n) fp32
+    receives the ksplit partial sums (plain stores: no clearing needed, bit-reproducible)."""
+    import ctypes
+    C, ks, n = gslabs.shape
+    assert gslabs.is_contiguous() and gslabs.dtype == torch.float32 and actF.shape[0] == C and dzF.shape[0] == C
+    check(lib().npp_light16_wgrad(ctypes.byref(desc), _p(actF), actF.stride(0), _p(dzF), dzF.stride(0), C, B, ks, _p(gslabs), n, ks * n, _stream()),
+          "npp_light16_wgrad")
+
+
+def light16_adam_pack(desc, params, m, v, n, gslabs, pack, lat, lat_m, lat_v, dlat, zero, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """Adam over C stacked blobs (gradient = the slabs summed in order) and their latents + loss-word clear + bf16 re-pack, one launch."""
+    import ctypes
+    C, ks, ns = gslabs.shape
+    _bytes2d(pack, "pack")
+    assert all(t.shape == params.shape and t.stride() == params.stride() for t in (m, v)) and params.stride(1) == 1 and params.shape[0] == C
+    assert all(t.shape == (C, 6) and t.is_contiguous() for t in (lat, lat_m, lat_v, dlat)) and (zero is None or (zero.numel() == C and zero.is_contiguous()))
+    check(lib().npp_light16_adam_pack(ctypes.byref(desc), _p(params), _p(m), _p(v), params.stride(0), n, C, _p(gslabs), ks, ns, ks * ns, _p(pack),
+                                      pack.stride(0), _p(lat), _p(lat_m), _p(lat_v), _p(dlat), _p(zero), lr, b1, b2, eps, step, _stream()),
+          "npp_light16_adam_pack")
+
+
 def act_bwd(dy, zy, act, dz):
     B, n = dy.shape
     check(lib().npp_act_bwd(_p(dy), dy.stride(0), _p(zy), zy.stride(0), B, n, act, _p(dz), dz.stride(0), _stream()), "npp_act_bwd")
