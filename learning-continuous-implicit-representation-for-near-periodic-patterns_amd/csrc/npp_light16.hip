@@ -16,6 +16,8 @@
 // (an accumulator tile converted to bf16 IS two fragments of the next layer).  Stashes: W-format arrays (npp_layout.h): fp16
 // pre-activations z of the snake layers (the backward derives 1 + sin 2z, the weight-gradient launch snake(z)), bf16 for the
 // linear ones.
+#include <stdlib.h>
+
 #include "npp_common.h"
 #include "npp_light_layout.h"
 
@@ -153,6 +155,11 @@ __global__ __launch_bounds__(256) void light16_adam_pack_kernel(L16AdamArgs a, L
     pk[unit * 8 + unperm_j(c16)] = wb;
   }
 }
+
+// (Measured and dropped, round 4: a form with 16-byte pack stores -- a wave owns a 32-neuron x 16-column block = the 64 fragments of one
+// forward k-step and, through a 1-KiB LDS transpose, 64 whole fragments of the transposed pack -- took 41 us for 9 candidates against
+// 27 us for this element-wise kernel: its loads are 64-byte pieces of 32 different rows per instruction, and that costs more than the
+// 2-byte scattered stores it removes.)
 
 // ---- shared pieces ----------------------------------------------------------------------------------------------------------------
 template <int NTW>

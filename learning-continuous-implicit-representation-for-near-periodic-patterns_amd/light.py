@@ -6,6 +6,8 @@ the same kernels as the main loop, the score through the trunk / LPIPS / context
 The problem is tiny (2048 rows x 0.3 M parameters x 300 iterations per candidate) and launch-bound; candidates are
 independent, so they shard one per GPU exactly like images do (parallel.py).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -297,7 +299,13 @@ class NPPNetLightBatch:
             pb, ab, db = ops.light16_sizes(B)
             u8 = lambda nb: torch.zeros(C, nb, dtype=torch.uint8, device=self.device)          # noqa: E731
             n_wg = B // 64
-            ks = max(1, min(8, n_wg // 8))                      # split-K of the weight-gradient launch: >= 8 workgroup tiles per split
+            # split-K of the weight-gradient launch.  Its workgroups take a whole CU's LDS each (one per CU, 256 at a time) and cost
+            # ~1 us per 32-row half step plus ~8 us of prologue / epilogue; 9 output tiles per candidate.  Measured, 9 candidates x 2048
+            # rows: ksplit 1 / 2 / 4 / 8 = 66 / 42 / 56 / 64 us (4 and 8 need a second / third round of workgroups)
+            cost = lambda k: -(-9 * C * k // 256) * (2 * -(-n_wg // k) + 8)                      # noqa: E731
+            ks = min(range(1, min(8, n_wg) + 1), key=cost)
+            if os.environ.get("NPP_LIGHT16_KSPLIT"):
+                ks = max(1, min(n_wg, int(os.environ["NPP_LIGHT16_KSPLIT"])))
             ws = dict(actF=u8(ab), dzF=u8(db), pred=torch.empty(C, B, 3, dtype=torch.float32, device=self.device),
                       gslabs=torch.zeros(C, ks, self.n_pad, dtype=torch.float32, device=self.device))
             if getattr(self, "_pack16", None) is None:
