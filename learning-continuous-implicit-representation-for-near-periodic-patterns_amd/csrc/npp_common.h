@@ -162,6 +162,10 @@ __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
 #define NPP_DZ_NT NPP_STASH_NT
 #endif
 __device__ __forceinline__ void dz_store(void* p, const bf16x8& v) {
+#ifdef NPP_DIAG_NOSTASH      // timing-only diagnostic, as in stash_store
+  asm volatile("" :: "v"(v), "v"(p));
+  return;
+#endif
 #if NPP_DZ_NT
   __builtin_nontemporal_store(v, (bf16x8*)p);
 #else

@@ -23,7 +23,7 @@
 
 namespace npp {
 
-static_assert(kW == 256 && kNB == 2 && kNT == 8 && kRD == 4, "the 16-bit light chains are built for W = 256, 64-row workgroups");
+static_assert(kW == 256 && kNB == 2 && kNT == 8, "the 16-bit light chains are built for W = 256, 64-row workgroups");
 
 constexpr int kL16Threads = 256;
 constexpr int kL16Region = kKSAct * kNB * 1024;           // 32 KiB: 256 features x 64 rows of bf16 fragments
@@ -208,8 +208,101 @@ __device__ __forceinline__ bf16x8 l16_in_frag(const float* __restrict__ row, int
   return f;
 }
 
+// Work item (candidate, 64-row tile) of a workgroup.  Workgroups go round-robin over the 8 XCDs by linear id (observed, speed only); the
+// items are numbered so that every XCD owns a CONTIGUOUS range of them in candidate-major order: an XCD then streams ~C / 8 candidates'
+// packs (1.2 MB each) through its 4-MiB L2 instead of all C of them (11 MB at C = 9: every k-step of every layer a miss).  The grid
+// is C * n_wg rounded up to a multiple of 8; surplus workgroups exit before any barrier.
+__device__ __forceinline__ bool l16_item(int n_wg, int C, int& c, int& wg) {
+  const int total = n_wg * C, per = (total + 7) >> 3;
+  const int l = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || l >= total) return false;
+  c = l / n_wg;
+  wg = l - c * n_wg;
+  return true;
+}
+// The weight-stream ring of npp_common.h (WRing / mma_ring) with the depth as a parameter.  What bounds these chains, measured with
+// timing-only builds on 9 candidates x 2048 rows (288 workgroups; forward / backward launch, us):  as shipped 31.6 / 40.3;  no stash
+// stores (NPP_DIAG_NOSTASH) 27.6 / 27.8;  no MFMAs (NPP_DIAG_L16_NOMFMA) 27.4 / 38.2;  neither 23.2 / 26.6;  ring depth 8 instead of
+// 4, candidate-contiguous XCD numbering, bias prefetch: no change each.  I.e. the skeleton -- every workgroup streams its candidate's
+// whole pack (0.7 MB forward) through one CU's L2 -> register path (~70 GB/s per CU: ~10 us), the 32 CUs that hold two of the 288
+// workgroups take twice that -- not latency, not the matrix pipe (4 us) and, in the forward, not the stores; the backward's 53 MB of
+// dz stores cost 12 us.  Next: 128-row workgroups (144 of them: one per CU, half the weight bytes per row).
+#ifndef NPP_LIGHT16_RING
+#define NPP_LIGHT16_RING 4
+#endif
+constexpr int kLRD = NPP_LIGHT16_RING;
+template <int NTW> struct LRing { bf16x8 w[kLRD][NTW]; wrsrc_t rsrc; };
+template <int NTW, int NT>
+__device__ __forceinline__ void lslot_load(LRing<NTW>& r, int slot, wptr_t wp, int ks, int nt0, int lane) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane * 16, (int)((wp + (uint32_t)((ks * NT + nt0 + nt) * 64)) * 16u), 0);
+    r.w[slot][nt] = __builtin_bit_cast(bf16x8, raw);
+  }
+}
+template <int NTW, int NT>
+__device__ __forceinline__ void lring_fill(LRing<NTW>& r, wptr_t wp, int nt0, int lane) {
+#pragma unroll
+  for (int q = 0; q < kLRD; ++q) lslot_load<NTW, NT>(r, q, wp, q, nt0, lane);
+}
+// schedule positions [0, KSTOT) of a part with KSREAL real k-steps (KSTOT a multiple of the depth, so that every part starts at slot 0);
+// after the MFMAs of position ks its slot is refilled with this part's k-step ks + depth or, past the part's end, the next part's
+template <int KSREAL, int KSTOT, int NTW, int NT>
+__device__ __forceinline__ void lmma(f32x16 (&acc)[NTW][kNB], const char* region, wptr_t wp, wptr_t next_wp, int nt0, const Lane& L, LRing<NTW>& ring) {
+  static_assert(KSTOT % kLRD == 0 && KSREAL <= KSTOT, "ring schedule");
+  bf16x8 xn[kNB];
+#pragma unroll
+  for (int bt = 0; bt < kNB; ++bt) xn[bt] = lds_frag(region, 0, bt, L.lane);
+#pragma unroll
+  for (int ks = 0; ks < KSTOT; ++ks) {
+    const int slot = ks % kLRD;
+    if (ks < KSREAL) {
+      bf16x8 x[kNB];
+#pragma unroll
+      for (int bt = 0; bt < kNB; ++bt) x[bt] = xn[bt];
+      if (ks + 1 < KSREAL) {
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) xn[bt] = lds_frag(region, ks + 1, bt, L.lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int bt = 0; bt < kNB; ++bt) {
+#ifdef NPP_DIAG_L16_NOMFMA      // timing-only diagnostic (wrong results): operands stay live, the MFMA is not issued
+          asm volatile("" :: "v"(ring.w[slot][nt]), "v"(x[bt]));
+#else
+          acc[nt][bt] = mfma_bf16(ring.w[slot][nt], x[bt], acc[nt][bt]);
+#endif
+        }
+    }
+    if (ks + kLRD < KSREAL) lslot_load<NTW, NT>(ring, slot, wp, ks + kLRD, nt0, L.lane);
+    else if (ks + kLRD >= KSTOT && next_wp != kNoW) lslot_load<NTW, NT>(ring, slot, next_wp, ks + kLRD - KSTOT, nt0, L.lane);
+    asm volatile("" ::: "memory");   // pin the refill here: no hoisting of later loads
+  }
+}
+constexpr int l16_tot(int ks) { return (ks + kLRD - 1) / kLRD * kLRD; }
+
+template <int NTW> struct L16Bias { float v[NTW][16]; };
+template <int NTW>
+__device__ __forceinline__ void l16_bias_fetch(L16Bias<NTW>& bp, const float* __restrict__ bias, int nt0, const Lane& L) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bp.v[nt][r] = bias[(nt0 + nt) * 32 + acc_row(r, L.h)];
+}
+template <int NTW>
+__device__ __forceinline__ void l16_bias_apply(f32x16 (&acc)[NTW][kNB], const L16Bias<NTW>& bp) {
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int bt = 0; bt < kNB; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][bt][r] = bp.v[nt][r];
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, L16Pack pd) {
+__global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, L16Pack pd, int n_wg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R0 = smem;
   char* R1 = smem + kL16Region;
@@ -220,18 +313,19 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, 
   L.lane = threadIdx.x & 63;
   L.b = L.lane & 31;
   L.h = L.lane >> 5;
-  L.n_wg = (int)gridDim.x; L.xslot = 0; L.xcount = 1;
-  const int c = blockIdx.y, wg = blockIdx.x;
+  L.n_wg = n_wg; L.xslot = 0; L.xcount = 1;
+  int c, wg;
+  if (!l16_item(n_wg, C, c, wg)) return;
   const int64_t B = a.B, row0 = (int64_t)wg * kRowTile;
   const float* P = a.params + (int64_t)c * a.params_stride;
   char* actF = a.actF + (int64_t)c * a.act_stride;
   const int nt0 = 2 * L.wave;
   auto arr = [&](int ks_off) -> char* { return actF + wfmt_array_base(ks_off, L.n_wg); };
 
-  WRing<2> ring;
-  WRing<1> ringp;
+  LRing<2> ring;
+  LRing<1> ringp;
   ring.rsrc = ringp.rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride16, pd.total);
-  wring_fill<2, kNT>(ring, (wptr_t)pd.f_off[HF_L0], nt0, L.lane);
+  lring_fill<2, kNT>(ring, (wptr_t)pd.f_off[HF_L0], nt0, L.lane);
 
   // inputs -> fragments: x_per (2 k-steps, region R1) and x_pos (4 k-steps, region RX), both also into their stash arrays
   {
@@ -252,9 +346,13 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, 
 
   f32x16 acc[2][kNB];
   constexpr int A = kKSAct;
+  // (the NEXT layer's bias values are fetched before the current layer's epilogue: their L2 latency hides under it and the barrier)
+  L16Bias<2> bn;
+  L16Bias<1> bnp;
   // periodic_linears.0: 20 (32 slots) -> 256, snake: R1 -> R0
   l16_bias<2>(acc, P + a.L.b_off[0], nt0, L);
-  mma_ring<0, 4, 2, 4, 2, kNT>(acc, R1, 0, (wptr_t)pd.f_off[HF_L0], (wptr_t)pd.f_off[HF_L1], nt0, L, ring);
+  lmma<2, l16_tot(2), 2, kNT>(acc, R1, (wptr_t)pd.f_off[HF_L0], (wptr_t)pd.f_off[HF_L1], nt0, L, ring);
+  l16_bias_fetch<2>(bn, P + a.L.b_off[1], nt0, L);
   l16_epi<true, 2>(acc, R0, nt0, arr(L16A_Z0), A, wg, L);
   wg_barrier();
   // periodic_linears.1 .. 3: R0 -> R1 -> R0 -> R1
@@ -262,23 +360,25 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, 
   for (int l = 1; l <= 3; ++l) {
     char* in = (l & 1) ? R0 : R1;
     char* out = (l & 1) ? R1 : R0;
-    l16_bias<2>(acc, P + a.L.b_off[l], nt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, (wptr_t)pd.f_off[HF_L0 + l], (wptr_t)pd.f_off[HF_L0 + l + 1], nt0, L, ring);
+    l16_bias_apply<2>(acc, bn);
+    lmma<A, l16_tot(A), 2, kNT>(acc, in, (wptr_t)pd.f_off[HF_L0 + l], (wptr_t)pd.f_off[HF_L0 + l + 1], nt0, L, ring);
+    l16_bias_fetch<2>(bn, P + a.L.b_off[l == 3 ? 5 : l + 1], nt0, L);
     l16_epi<true, 2>(acc, out, nt0, arr(L16A_Z0 + A * l), A, wg, L);
     wg_barrier();
   }
   // feature_linear1 (linear): R1 -> R0, also the first 16 k-steps of the [f1 | x_pos] stash
-  l16_bias<2>(acc, P + a.L.b_off[5], nt0, L);
-  mma_ring<0, A, A, A, 2, kNT>(acc, R1, 0, (wptr_t)pd.f_off[HF_F1], kNoW, nt0, L, ring);
-  wring_fill<1, kNT / 2>(ringp, (wptr_t)pd.f_off[HF_POS], L.wave, L.lane);
+  l16_bias_apply<2>(acc, bn);
+  lmma<A, l16_tot(A), 2, kNT>(acc, R1, (wptr_t)pd.f_off[HF_F1], kNoW, nt0, L, ring);
+  lring_fill<1, kNT / 2>(ringp, (wptr_t)pd.f_off[HF_POS], L.wave, L.lane);
+  l16_bias_fetch<1>(bnp, P + a.L.b_off[4], L.wave, L);
   l16_epi<false, 2>(acc, R0, nt0, arr(L16A_HP), kL16KsHp, wg, L);
   wg_barrier();
   // pos_linears.0: [f1 (R0) | x_pos (RX)] -> 128, snake; one neuron tile per wave
   f32x16 accp[1][kNB];
   constexpr wptr_t UP = (kNT / 2) * 64;
-  l16_bias<1>(accp, P + a.L.b_off[4], L.wave, L);
-  mma_ring<0, A, A, A, 1, kNT / 2>(accp, R0, 0, (wptr_t)pd.f_off[HF_POS], (wptr_t)pd.f_off[HF_POS] + A * UP, L.wave, L, ringp);
-  mma_ring<0, 4, 4, 4, 1, kNT / 2>(accp, RX, 0, (wptr_t)pd.f_off[HF_POS] + A * UP, kNoW, L.wave, L, ringp);
+  l16_bias_apply<1>(accp, bnp);
+  lmma<A, l16_tot(A), 1, kNT / 2>(accp, R0, (wptr_t)pd.f_off[HF_POS], (wptr_t)pd.f_off[HF_POS] + A * UP, L.wave, L, ringp);
+  lmma<4, l16_tot(4), 1, kNT / 2>(accp, RX, (wptr_t)pd.f_off[HF_POS] + A * UP, kNoW, L.wave, L, ringp);
   l16_epi<true, 1>(accp, nullptr, L.wave, arr(L16A_ZP), kLPosOut / 16, wg, L);
   // rgb_linear 128 -> 3 + sigmoid (models/helpers.py:55-56): per-lane partial dot over its 16 neurons, lane halves by shuffle,
   // the four waves through LDS
@@ -364,7 +464,7 @@ __device__ __forceinline__ void l16_zero(f32x16 (&acc)[2][kNB]) {
       for (int r = 0; r < 16; ++r) acc[t][bt][r] = 0.0f;
 }
 
-__global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, L16Pack pd) {
+__global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, L16Pack pd, int n_wg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R0 = smem;
   char* R1 = smem + kL16Region;
@@ -375,8 +475,10 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
   L.lane = threadIdx.x & 63;
   L.b = L.lane & 31;
   L.h = L.lane >> 5;
-  L.n_wg = (int)gridDim.x; L.xslot = 0; L.xcount = 1;
-  const int c = blockIdx.y, wg = blockIdx.x, tid = L.tid;
+  L.n_wg = n_wg; L.xslot = 0; L.xcount = 1;
+  const int tid = L.tid;
+  int c, wg;
+  if (!l16_item(n_wg, C, c, wg)) return;
   const int64_t B = a.B, row0 = (int64_t)wg * kRowTile;
   const float* P = a.params + (int64_t)c * a.params_stride;
   const char* actF = a.actF + (int64_t)c * a.act_stride;
@@ -386,9 +488,9 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
   auto dzr = [&](int ks_off) { return dzF + wfmt_array_base(ks_off, L.n_wg); };
 
   // everything the prologue needs from memory first: the weight ring of the first data-gradient part, rgb_linear's rows, z_p
-  WRing<2> ring;
+  LRing<2> ring;
   ring.rsrc = make_wrsrc(a.pack + (int64_t)c * a.pack_stride16, pd.total);
-  wring_fill<2, kNT>(ring, (wptr_t)pd.b_off[HB_POS], kt0, L.lane);
+  lring_fill<2, kNT>(ring, (wptr_t)pd.b_off[HB_POS], kt0, L.lane);
   f16x8 zp_pre[kNB][2];
 #pragma unroll
   for (int bt = 0; bt < kNB; ++bt)
@@ -482,7 +584,7 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
   constexpr int KP = kLPosOut / 16, A = kKSAct;
   // d f1 = W_pos[:, :256]^T d z_p  (feature_linear1 is linear: this IS its d z; x_pos gets no gradient): R0 -> R1
   l16_zero(acc);
-  mma_ring<0, KP, KP, KP, 2, kNT>(acc, R0, 0, (wptr_t)pd.b_off[HB_POS], (wptr_t)pd.b_off[HB_F1], kt0, L, ring);
+  lmma<KP, l16_tot(KP), 2, kNT>(acc, R0, (wptr_t)pd.b_off[HB_POS], (wptr_t)pd.b_off[HB_F1], kt0, L, ring);
   l16_bepi<false>(acc, R1, nullptr, dzr(L16D_F1), wg, kt0, L);
   wg_barrier();
   // d z_3 = (W_f1^T d f1) * snake'(z_3), d z_2 = (W_3^T d z_3) * snake'(z_2), ..., d z_0: R1 -> R0 -> R1 -> R0
@@ -493,7 +595,7 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
     char* out = (j & 1) ? R1 : R0;
     l16_zero(acc);
     l16_zfetch(zpre, zs(L16A_Z0 + A * l), wg, kt0, L);
-    mma_ring<0, A, A, A, 2, kNT>(acc, in, 0, (wptr_t)pd.b_off[HB_F1 + j], j == 3 ? kNoW : (wptr_t)pd.b_off[HB_F1 + j + 1], kt0, L, ring);
+    lmma<A, l16_tot(A), 2, kNT>(acc, in, (wptr_t)pd.b_off[HB_F1 + j], j == 3 ? kNoW : (wptr_t)pd.b_off[HB_F1 + j + 1], kt0, L, ring);
     l16_bepi<true>(acc, j == 3 ? nullptr : out, &zpre, dzr(L16D_Z0 + A * l), wg, kt0, L);
     if (j != 3) wg_barrier();
   }
@@ -504,7 +606,7 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
 using namespace npp;
 
 static int l16_check(const npp_light_desc* L, const void* p0, const void* p1, int C, int64_t B, const char* who) {
-  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < kRowTile || B % kRowTile || B / kRowTile > 65535) {
+  if (!L || !p0 || !p1 || C < 1 || C > 65535 || B < kRowTile || B % kRowTile || B / kRowTile > 65535 || (B / kRowTile) * C > 0x3fffffff) {
     set_error("%s: bad argument (C=%d B=%lld; B a positive multiple of %d)", who, C, (long long)B, kRowTile);
     return NPP_ERR_ARG;
   }
@@ -553,8 +655,9 @@ extern "C" int npp_light16_fwd(const npp_light_desc* L, const float* d_params, i
   a.pred = d_pred; a.B = B;
   static SmemOnce once;
   if (!smem_attr(once, (const void*)light16_fwd_kernel, kL16SmemF)) { set_error("npp_light16_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
-  hipLaunchKernelGGL(light16_fwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kL16Threads), kL16SmemF, (hipStream_t)stream, a,
-                     l16_pack_desc());
+  const int n_wg = (int)(B / kRowTile);
+  hipLaunchKernelGGL(light16_fwd_kernel, dim3((unsigned)((n_wg * C + 7) / 8 * 8)), dim3(kL16Threads), kL16SmemF, (hipStream_t)stream, a,
+                     l16_pack_desc(), n_wg, C);
   return check_launch("npp_light16_fwd");
 }
 
@@ -578,8 +681,9 @@ extern "C" int npp_light16_bwd(const npp_light_desc* L, const float* d_params, i
   a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
   static SmemOnce once;
   if (!smem_attr(once, (const void*)light16_bwd_kernel, kL16SmemB)) { set_error("npp_light16_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
-  hipLaunchKernelGGL(light16_bwd_kernel, dim3((unsigned)(B / kRowTile), (unsigned)C), dim3(kL16Threads), kL16SmemB, (hipStream_t)stream, a,
-                     l16_pack_desc());
+  const int n_wg = (int)(B / kRowTile);
+  hipLaunchKernelGGL(light16_bwd_kernel, dim3((unsigned)((n_wg * C + 7) / 8 * 8)), dim3(kL16Threads), kL16SmemB, (hipStream_t)stream, a,
+                     l16_pack_desc(), n_wg, C);
   return check_launch("npp_light16_bwd");
 }
 
