@@ -686,17 +686,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   EmbedDev& ed = *(EmbedDev*)(sX + kRowTile);
   WarpEnt* tWarp = (WarpEnt*)((char*)&ed + kSmemE);
   float* sRGB = (float*)R0;             // [4 waves][64 rows][3], reused after the last barrier
-  if (threadIdx.x == 0) {
+  if (STACK) {
+    // the image's constants come from global memory: one dword per thread, ONE load latency (thread 0 alone walked them in a rolled
+    // loop of dependent load -> LDS store round trips: ~0.2 us each x sizeof / 4 on the critical path of every workgroup)
     uint32_t* dst = (uint32_t*)&ed;
-    if (STACK) {
-      const uint32_t* src = (const uint32_t*)(A_.estack + img_);
-#pragma unroll 1                 // (global memory: any index will do)
-      for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
-    } else {
-      const uint32_t* src = (const uint32_t*)&e_arg;
+    const uint32_t* src = (const uint32_t*)(A_.estack + img_);
+    for (int i = threadIdx.x; i < (int)(sizeof(EmbedDev) / 4); i += kThreads) dst[i] = src[i];
+  } else if (threadIdx.x == 0) {
+    uint32_t* dst = (uint32_t*)&ed;
+    const uint32_t* src = (const uint32_t*)&e_arg;
 #pragma unroll
-      for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
-    }
+    for (int i = 0; i < (int)(sizeof(EmbedDev) / 4); ++i) dst[i] = src[i];
   }
   wg_barrier();
   for (int wi = threadIdx.x; wi < ed.K * 22; wi += kThreads) {

@@ -336,6 +336,56 @@ class NPPNetLightBatch:
             net.advance_clock()
         return loss
 
+    def fit_loop_bf16(self, x_pos_all, x_per_all, draws, gt_all, log=None):
+        """draws.shape[0] iterations of _train_step_bf16 (iteration j: batch rows draws[j] (B int64) of the tables, targets gt_all[j] (B, 3)) with
+        the host's share stripped down: the four entry points are called with arguments marshalled ONCE (only the two row pointers, the loss
+        word and Adam's (lr, step) change), the nets' clocks are advanced together at the end.  The same launches with the same arguments
+        as the step-by-step path -- 4 x ~9 us of Python per iteration were a fifth of the set's wall time.  log: list that receives a
+        copy of every iteration's loss words."""
+        import ctypes as C_
+        from ._lib import lib
+        n_it, B = draws.shape
+        assert self.bf16 and B % 64 == 0 and draws.dtype == torch.int64 and draws.is_contiguous() and gt_all.is_contiguous()
+        assert gt_all.shape == (n_it, B, 3) and gt_all.dtype == torch.float32 and x_per_all.is_contiguous() and x_pos_all.is_contiguous()
+        ws = self._work16(B)
+        if not self._pack16_valid:
+            ops.light16_pack(self._desc, self.params, self._pack16)
+        Lb = lib()
+        vp = lambda t: C_.c_void_p(t.data_ptr())                                                # noqa: E731
+        desc, st = C_.byref(self._desc), ops._stream()
+        n_src, Cn = x_per_all.shape[1], self.C
+        assert x_per_all.shape == (Cn, n_src, 20) and x_pos_all.shape == (n_src, 42)
+        par, pst, pk, pks = vp(self.params), self.params.stride(0), vp(self._pack16), self._pack16.stride(0)
+        act, acs, dz, dzs, pred = vp(ws["actF"]), ws["actF"].stride(0), vp(ws["dzF"]), ws["dzF"].stride(0), vp(ws["pred"])
+        xper, xpos = vp(x_per_all), vp(x_pos_all)
+        lat, latm, latv, dl, spl = vp(self.latents), vp(self.lat_m), vp(self.lat_v), vp(self._dl_c), vp(self.spline)
+        m_, v_ = vp(self.m), vp(self.v)
+        gs = ws["gslabs"]
+        gsl, ks, ns = vp(gs), gs.shape[1], gs.shape[2]
+        loss_p = [vp(self._loss2[0]), vp(self._loss2[1])]
+        d0, dstep, g0, gstep = draws.data_ptr(), draws.stride(0) * 8, gt_all.data_ptr(), gt_all.stride(0) * 4
+        n0 = self.nets[0]
+        step, lr, gstp, li = n0.opt_step, n0.lr, n0.global_step, self._li
+        fwd, bwd, wg, adam = Lb.npp_light16_fwd, Lb.npp_light16_bwd, Lb.npp_light16_wgrad, Lb.npp_light16_adam_pack
+        nk, xs, npar = self.n_knots, self.x_scale, self.n_params
+        for j in range(n_it):
+            rc = fwd(desc, par, pst, pk, pks, xper, xpos, C_.c_void_p(d0 + j * dstep), n_src, Cn, B, act, acs, pred, st)
+            rc = rc or bwd(desc, par, pst, pk, pks, act, acs, pred, None, C_.c_void_p(g0 + j * gstep), lat, spl, nk, xs, loss_p[li], dl, Cn, B, dz, dzs, st)
+            rc = rc or wg(desc, act, acs, dz, dzs, Cn, B, ks, gsl, ns, ks * ns, st)
+            step += 1
+            rc = rc or adam(desc, par, m_, v_, pst, npar, Cn, gsl, ks, ns, ks * ns, pk, pks, lat, latm, latv, dl, loss_p[li ^ 1], lr, 0.9, 0.999, 1e-8, step, st)
+            if rc:
+                ops.check(rc, "npp_light16_* (fit_loop_bf16)")
+            if log is not None:
+                log.append(self._loss2[li].clone())
+            li ^= 1
+            lr = n0.lrate * (0.1 ** (gstp / (n0.lrate_decay * 100)))                          # NPPNetLight.advance_clock
+            gstp += 1
+        self._li = li
+        self._pack16_valid, self._pack_valid = True, False
+        for net in self.nets:
+            net.opt_step, net.lr, net.global_step = step, lr, gstp
+
     def invalidate_pack(self):
         """Call after writing parameters from outside (load_state_dict on a member net): the next fused step re-packs first."""
         self._pack_valid = self._pack16_valid = False
@@ -737,6 +787,9 @@ class ProposalRanker:
                 batch.latents.copy_(latents0.reshape(1, 6).expand(len(part), 6))
             log = []
             for draws, gt_all in self._draw_stream():
+                if batch.bf16 and draws.shape[1] % 64 == 0:
+                    batch.fit_loop_bf16(x_pos_all, x_per_all, draws.contiguous(), gt_all.contiguous(), log if self.record_losses else None)
+                    continue
                 for j in range(draws.shape[0]):
                     loss = batch.train_step(x_pos_all, x_per_all, gt_all[j], idx=draws[j])
                     if self.record_losses:
