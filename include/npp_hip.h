@@ -345,6 +345,10 @@ typedef struct {
    * (npp_adam_step_net_pack(_stack), d_pl_partials = this buffer) adds them in block order -- bit-reproducible, and the
    * reduction costs no ticket, fence or launch.  NULL: float atomics onto loss / dlatent in arrival order. */
   float* scratch;
+  /* 0: robust_loss_adaptive (the reference's default).  > 0: the non-adaptive switches of models/mse_calculator.py:19-23, both of the
+   * form quad * mean(x^2): --loss_type l2 (quad = 1) and robust_loss = lossfun(x, alpha = 2, scale = 0.1) (quad = 50); latents, spline
+   * and dlatent are then unused (may be NULL). */
+  float quad;
 } npp_pixel_loss_args;
 int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_fake, const float* d_fmask,
                             const float* d_real, const float* d_rmask, int n_p, int k, int P, int comp,
@@ -578,6 +582,11 @@ int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, 
                           const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
                           int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero, float lr,
                           float beta1, float beta2, float eps, int step, void* stream);
+/* img2mse with --loss_type l2 (coef = 1) or robust_loss (coef = 50: lossfun(diff, alpha = 2, scale = 0.1) = 0.5 (diff / 0.1)^2),
+ * models/mse_calculator.py:13-27, for nbatch problems: d_loss[b] += weight * coef * mean(x^2), d_dpred = its gradient; the (N) mask
+ * (nullable) is shared, the targets too when gt_stride == 0. */
+int npp_pixel_loss_quad(const float* d_pred, const float* d_gt, int64_t gt_stride, const float* d_mask, int64_t N, int nbatch, float coef,
+                        float weight, float* d_loss, float* d_dpred, void* stream);
 /* npp_pixel_loss over nbatch problems: d_pred / d_dpred (nbatch, N, 3), d_latents / d_dlatent (nbatch, 6), d_loss (nbatch);
  * the targets d_gt (N, 3) are shared when gt_stride == 0, else problem b reads d_gt + b * gt_stride. */
 int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, int64_t gt_stride, int64_t N, int nbatch,

@@ -20,7 +20,7 @@ class PixelLossArgs(C.Structure):
     """npp_pixel_loss_args (include/npp_hip.h)."""
     _fields_ = [("pred", C.c_void_p), ("gt", C.c_void_p), ("mask", C.c_void_p), ("N", C.c_int64), ("latents", C.c_void_p),
                 ("spline", C.c_void_p), ("n_knots", C.c_int32), ("x_scale", C.c_float), ("weight", C.c_float), ("loss", C.c_void_p),
-                ("dpred", C.c_void_p), ("dlatent", C.c_void_p), ("scratch", C.c_void_p)]
+                ("dpred", C.c_void_p), ("dlatent", C.c_void_p), ("scratch", C.c_void_p), ("quad", C.c_float)]
 
 
 class PatchGrad(C.Structure):
@@ -155,6 +155,7 @@ SYMBOLS = {
     "npp_light_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "npp_light_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_light_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "npp_pixel_loss_quad": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
     "npp_light16_pack_bytes": (_i64, []),
     "npp_light16_stash_bytes": (_i64, [_i64, _i32]),
     "npp_light16_pack": (_i32, [C.POINTER(LightDesc), _vp, _i64, _i32, _vp, _i64, _vp]),

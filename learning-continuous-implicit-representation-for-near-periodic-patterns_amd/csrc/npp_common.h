@@ -496,6 +496,9 @@ struct PixelLossArgs {
   float* loss_out; float* dpred; float* dlatent;
   float* scratch;      // nullable: kPixelLossScratch floats.  Given: the launch leaves its per-block partial sums there (loss_out /
                        // dlatent untouched) for the Adam launch of the iteration to add in block order (AdamTail::pl_part)
+  float quad;          // 0: robust_loss_adaptive.  > 0: the non-adaptive switches of models/mse_calculator.py:19-23, both quadratic:
+                       // loss = quad * mean(x^2) -- 'l2' (quad = 1) and 'robust_loss' = lossfun(x, alpha = 2, scale = 0.1) = 0.5 (x / 0.1)^2
+                       // (quad = 50); latents / spline unused (may be null), no latent gradient
 };
 // Cross-block reduction in a FIXED order inside one launch: every block publishes its partials, the block that draws the last
 // ticket sums them.  cdna_hip_programming.md Guideline 16, form R1 without fences: the (few, small) partials are written with
@@ -528,7 +531,11 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
   const float weight = a.weight;
   __shared__ ChanParams cp[3];
   __shared__ float red[4][7];
-  if (threadIdx.x < 3) cp[threadIdx.x] = chan_params(a.latents[threadIdx.x], a.latents[3 + threadIdx.x], a.spline, a.n_knots, a.x_scale);
+  const float quad = a.quad;
+  if (threadIdx.x < 3) {
+    if (quad > 0.0f) cp[threadIdx.x] = ChanParams{2.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    else cp[threadIdx.x] = chan_params(a.latents[threadIdx.x], a.latents[3 + threadIdx.x], a.spline, a.n_knots, a.x_scale);
+  }
   __syncthreads();
   const float inv = 1.0f / (3.0f * (float)N);
   float acc[7] = {0, 0, 0, 0, 0, 0, 0};   // loss, dalpha[3], dc[3]
@@ -540,6 +547,11 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
       const ChanParams p = cp[ch];
       const float d0 = pred[r * 3 + ch] - gt[r * 3 + ch];
       const float x = mask ? d0 * m + (1.0f - m) * d0 * 0.3f : d0;
+      if (quad > 0.0f) {                            // (uniform branch) mse_calculator.py:19-23: 'l2' / 'robust_loss'
+        acc[0] += quad * x * x;
+        dpred[r * 3 + ch] = weight * inv * w * 2.0f * quad * x;
+        continue;
+      }
       const float xs = x / p.c, ssx = xs * xs;
       const float u = ssx / p.beta + 1.0f;
       const float e = 0.5f * p.alpha;
@@ -576,6 +588,7 @@ __device__ __forceinline__ void pixel_loss_body(const PixelLossArgs& a, int bid,
     const int k = threadIdx.x;
     float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     if (k == 0) atomicAdd(a.loss_out, weight * v * inv);      // the term as it enters the total (train.py:195-198: `loss = 0` under --no_pix_loss)
+    else if (quad > 0.0f) {}                                  // (no latents in the quadratic forms)
     else if (k < 4) atomicAdd(a.dlatent + (k - 1), weight * inv * v * cp[k - 1].dalpha_dl);
     else atomicAdd(a.dlatent + 3 + (k - 4), weight * inv * v * cp[k - 4].dc_dl);
   }

@@ -842,8 +842,8 @@ static int patch_in_launch(const float* d_pred_rows, const float* d_fake, const 
     set_error("%s: null pointer", who);
     return NPP_ERR_ARG;
   }
-  if (pl && (pl->N <= 0 || !pl->pred || !pl->gt || !pl->latents || !pl->spline || !pl->loss_out || !pl->dpred || !pl->dlatent ||
-             pl->n_knots < 2)) {
+  if (pl && (pl->N <= 0 || !pl->pred || !pl->gt || !pl->loss_out || !pl->dpred || pl->quad < 0.0f ||
+             (pl->quad == 0.0f && (!pl->latents || !pl->spline || !pl->dlatent || pl->n_knots < 2)))) {
     set_error("%s: bad pixel-loss arguments (N=%lld)", who, (long long)(pl ? pl->N : 0));
     return NPP_ERR_ARG;
   }
@@ -870,7 +870,7 @@ extern "C" int npp_trunk_patch_in_loss(const float* d_pred_rows, const float* d_
                                        const npp_pixel_loss_args* loss, void* stream) {
   if (!loss) { set_error("npp_trunk_patch_in_loss: null pixel-loss arguments"); return NPP_ERR_ARG; }
   const PixelLossArgs pl{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
-                         loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch};
+                         loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch, loss->quad};
   return patch_in_launch(d_pred_rows, d_fake, d_fmask, d_real, d_rmask, n_p, k, P, comp, scale, shift, d_x0, d_xy, d_zero, n_zero,
                          which, &pl, stream, "npp_trunk_patch_in_loss");
 }
@@ -890,8 +890,8 @@ extern "C" int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, in
   }
   int rc = conv_geom_check(N_total, P, P, who);
   if (rc) return rc;
-  if (loss->N <= 0 || !loss->pred || !loss->gt || !loss->latents || !loss->spline || !loss->loss || !loss->dpred || !loss->dlatent ||
-      loss->n_knots < 2) {
+  if (loss->N <= 0 || !loss->pred || !loss->gt || !loss->loss || !loss->dpred || loss->quad < 0.0f ||
+      (loss->quad == 0.0f && (!loss->latents || !loss->spline || !loss->dlatent || loss->n_knots < 2))) {
     set_error("%s: bad pixel-loss arguments (N=%lld)", who, (long long)loss->N);
     return NPP_ERR_ARG;
   }
@@ -903,7 +903,7 @@ extern "C" int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, in
   a.npos_round = X > 0 ? conv_npos_round(2 * X, P, P) : 0;
   a.xy = d_xy; a.zero = d_zero; a.iter = (const StackIter*)d_iter;
   a.pl = PixelLossArgs{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
-                       loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch};
+                       loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch, loss->quad};
   a.gt_stride = gt_stride; a.lat_stride = lat_stride; a.loss_stride = loss_stride; a.scratch_stride = scratch_stride;
   a.nb_loss = pixel_loss_blocks(loss->N);
   const int64_t nblk = (a.npos_round > M ? a.npos_round : M) ;

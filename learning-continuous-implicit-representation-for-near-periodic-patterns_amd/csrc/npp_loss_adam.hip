@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(PixelLossArgs a) { pixe
 __global__ __launch_bounds__(256) void pixel_loss_batched_kernel(PixelLossArgs a, int64_t gt_stride) {
   const int64_t b = blockIdx.y;
   a.pred += b * a.N * 3; a.dpred += b * a.N * 3; a.gt += b * gt_stride;
-  a.latents += b * 6; a.dlatent += b * 6; a.loss_out += b;
+  if (a.latents) { a.latents += b * 6; a.dlatent += b * 6; }
+  a.loss_out += b;
   pixel_loss_body(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -165,6 +166,21 @@ extern "C" int npp_pixel_loss_batched(const float* d_pred, const float* d_gt, in
   hipLaunchKernelGGL(pixel_loss_batched_kernel, dim3((unsigned)pixel_loss_blocks(N), (unsigned)nbatch), dim3(256), 0, (hipStream_t)stream, a,
                      gt_stride);
   return check_launch("npp_pixel_loss_batched");
+}
+
+// The non-adaptive switches of img2mse (models/mse_calculator.py:19-23) -- 'l2': coef = 1; 'robust_loss' = lossfun(diff, alpha = 2,
+// scale = 0.1) = 0.5 (diff / 0.1)^2: coef = 50 -- for nbatch problems: loss[b] += weight * coef * mean(x^2), dpred = its gradient;
+// x = diff * mask + (1 - mask) * diff * 0.3 with the (N) mask shared by the problems (nullable).
+extern "C" int npp_pixel_loss_quad(const float* d_pred, const float* d_gt, int64_t gt_stride, const float* d_mask, int64_t N, int nbatch,
+                                   float coef, float weight, float* d_loss, float* d_dpred, void* stream) {
+  if (N <= 0 || nbatch < 1 || nbatch > 65535 || !d_pred || !d_gt || !d_loss || !d_dpred || gt_stride < 0 || !(coef > 0.0f)) {
+    set_error("npp_pixel_loss_quad: bad arguments (N=%lld, nbatch=%d, coef=%g)", (long long)N, nbatch, (double)coef);
+    return NPP_ERR_ARG;
+  }
+  PixelLossArgs a{d_pred, d_gt, d_mask, N, nullptr, nullptr, 0, 0.0f, weight, d_loss, d_dpred, nullptr, nullptr, coef};
+  hipLaunchKernelGGL(pixel_loss_batched_kernel, dim3((unsigned)pixel_loss_blocks(N), (unsigned)nbatch), dim3(256), 0, (hipStream_t)stream, a,
+                     gt_stride);
+  return check_launch("npp_pixel_loss_quad");
 }
 
 extern "C" int npp_adam_step(float* d_p, float* d_m, float* d_v, const float* d_gslabs, int64_t n, int n_slabs,

@@ -27,9 +27,10 @@ class CompletionFit:
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
                  vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False, use_patch_weight=False,
-                 no_pix_loss=False, use_contextual_loss=True):
+                 no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive"):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
+        loss_type: --loss_type (arg_config.py:34; models/mse_calculator.py:19-23): 'robust_loss_adaptive' | 'l2' | 'robust_loss'.
         Ablation switches of arg_config.py:78-92: no_reg_sampling (random real patches), use_patch_weight (1/d lattice weights:
         weighted-sum forms of the contextual and LPIPS terms, train.py:224-250), no_pix_loss (:197), use_contextual_loss.
         masked_img = img * mask is what the loop trains on (train.py:173).
@@ -93,7 +94,7 @@ class CompletionFit:
         self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
         self.pixel_mask = None if pixel_mask is None else torch.from_numpy(pixel_mask[..., 0].copy()).to(self.device)
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
-                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay, width=width)
+                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay, width=width, loss_type=loss_type)
         if task == "segmentation":
             self.net.lr_clock = False                              # NPP_segmentation/train.py:408 (see NPPNet.lr_clock)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))
@@ -345,7 +346,7 @@ class CompletionFit:
             with torch.cuda.stream(self._s_pix):
                 net.group_forward(gA, coords[:n_pix])
                 ops.pixel_loss(gA["pred"], b["gt"], b.get("pmask"), net.latents, net.spline, net.n_knots, net.x_scale, self.pix_w,
-                               net.loss_buf, gA["dpred"], net.dlatent)
+                               net.loss_buf, gA["dpred"], net.dlatent, quad=net.quad)
                 net.group_backward(gA)
             pred = ws["pred"]
         else:

@@ -40,10 +40,12 @@ class NPPNetLight:
     latents.  state_dict names / layouts are the reference's; scale_linears / feature_linear2 / alpha_linear (constructed by
     the reference, never used when len(freq_scales) == 1) are not kept."""
 
-    def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, storage=None):
+    def __init__(self, angles_deg, periods, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, storage=None,
+                 loss_type="robust_loss_adaptive"):
         """storage: optional dict of preallocated float32 device vectors (params, grad, m, v: n_params each; latents, lat_m, lat_v,
         dlatent: 6; loss_buf: 1) -- rows of the stacked blobs of an NPPNetLightBatch."""
         self.device = ops.select_device(device)
+        self.quad = ops.quad_coef(loss_type)              # --loss_type (models/mse_calculator.py:19-23): 0 = the adaptive robust loss
         self.res = (int(res[0]), int(res[1]))
         self.W, self.D = int(W), int(D)
         self.freqs = [float(f) for f in np.asarray(freqs).reshape(-1)]
@@ -177,7 +179,8 @@ class NPPNetLight:
         ws = self._ws[B]
         self.loss_buf.zero_()
         self.dlatent.zero_()
-        ops.pixel_loss(pred, gt, None, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, self.loss_buf, ws["dpred"], self.dlatent)
+        ops.pixel_loss(pred, gt, None, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, self.loss_buf, ws["dpred"], self.dlatent,
+                       quad=self.quad)
         self.backward(B)
         if hp is None:
             self.opt_step += 1
@@ -223,7 +226,8 @@ class NPPNetLightBatch:
     (ProposalRanker._pixel_draws) and therefore x_pos and the colours; x_per (their lattice) and all weights are their own.
     State lives in stacked blobs (C, n_pad); .nets are ordinary NPPNetLight objects over the rows (render / score / state_dict)."""
 
-    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, fused=None, precision=None):
+    def __init__(self, cands, freqs, res, params, W=256, D=4, device="cuda", lrate=5e-4, lrate_decay=500, fused=None, precision=None,
+                 loss_type="robust_loss_adaptive"):
         """fused (default: NPP_LIGHT_FUSED != 0 and the topology is the searched one, D = 4 / W = 256 / 42 + 20 input columns): forward and
         data-gradient chains as ONE launch each over all candidates (csrc/npp_light.hip) instead of one launch per layer.
         precision: "fp32" (exact fp32 MFMA everywhere) or "bf16" (csrc/npp_light16.hip: bf16 operands, fp32 accumulation, fp32 master
@@ -231,6 +235,7 @@ class NPPNetLightBatch:
         64 rows; anything else falls back to fp32).  Default: NPP_LIGHT_PRECISION, else "fp32"."""
         import os
         self.device = ops.select_device(device)
+        self.quad = ops.quad_coef(loss_type)              # --loss_type: 0 = adaptive; > 0: 'l2' / 'robust_loss' (no latent gradient)
         self.C, self.W, self.D = len(cands), int(W), int(D)
         C = self.C
         in_pos = 2 * (1 + 2 * len(np.asarray(freqs).reshape(-1)))
@@ -249,7 +254,7 @@ class NPPNetLightBatch:
             st = dict(params=self.params[ci, :n], grad=self.grad[ci, :n], m=self.m[ci, :n], v=self.v[ci, :n], latents=self.latents[ci],
                       lat_m=self.lat_m[ci], lat_v=self.lat_v[ci], dlatent=self._dl_c[ci], loss_buf=self._loss2[0, ci:ci + 1])
             self.nets.append(NPPNetLight(angles_deg, periods, freqs, res, params, W=W, D=D, device=self.device, lrate=lrate,
-                                         lrate_decay=lrate_decay, storage=st))
+                                         lrate_decay=lrate_decay, storage=st, loss_type=loss_type))
         self.w, self.b, self.dw, self.db = {}, {}, {}, {}
         off = 0
         for name, r, c in self.layout:
@@ -322,8 +327,13 @@ class NPPNetLightBatch:
             ops.light16_pack(self._desc, self.params, self._pack16)
         ops.light16_fwd(self._desc, self.params, self._pack16, x_per.contiguous(), x_pos.contiguous(), ws["actF"], ws["pred"], idx=idx)
         loss = self._loss2[self._li]
-        ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], None, ws["dzF"],
-                        loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
+        if self.quad > 0:                                   # non-adaptive pixel loss: its own launch, d pred handed to the chain
+            dp = ws.setdefault("dpred", torch.empty_like(ws["pred"]))
+            ops.pixel_loss_quad(ws["pred"], gt, None, self.quad, 1.0, loss, dp)
+            ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], dp, ws["dzF"])
+        else:
+            ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], None, ws["dzF"],
+                            loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
         ops.light16_wgrad(self._desc, ws["actF"], ws["dzF"], B, ws["gslabs"])
         n0 = self.nets[0]
         step, lr = n0.opt_step + 1, n0.lr
@@ -412,8 +422,12 @@ class NPPNetLightBatch:
                 self.grad.zero_()
         ops.light_fwd(self._desc, self.params, self._pack, x_per.contiguous(), x_pos.contiguous(), S, ws["pred"], idx=idx)
         loss = self._loss2[self._li]
-        ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], None, ws["draw"], D_,
-                      loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
+        if self.quad > 0:
+            ops.pixel_loss_quad(ws["pred"], gt, None, self.quad, 1.0, loss, ws["dpred"])
+            ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], ws["dpred"], ws["draw"], D_)
+        else:
+            ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], None, ws["draw"], D_,
+                          loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
         if not self.fused_adam:
             self.grad.zero_()
         if self.grouped_wgrad:
@@ -470,7 +484,10 @@ class NPPNetLightBatch:
         ops.act_fwd(ws["raw"], _SIGMOID, ws["pred"])
         # ---- loss (its accumulators were cleared by the previous iteration's Adam launch)
         loss = self._loss2[self._li]
-        ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
+        if self.quad > 0:
+            ops.pixel_loss_quad(ws["pred"], gt, None, self.quad, 1.0, loss, ws["dpred"])
+        else:
+            ops.pixel_loss_batched(ws["pred"], gt, self.latents, self.spline, self.n_knots, self.x_scale, 1.0, loss, ws["dpred"], self._dl_c)
         # ---- backward (NPPNetLight.backward)
         self.grad.zero_()
         # (every hidden layer's activation backward rides in the epilogue of the data-gradient launch above it)
@@ -544,7 +561,8 @@ class ProposalRanker:
 
     def __init__(self, masked_img, i_train, i_val, device="cuda", N_iters=300, N_rand=2048, W=256, D=4, lrate=5e-4, lrate_decay=500,
                  perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
-                 lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False, precision=None):
+                 lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False, precision=None,
+                 loss_type="robust_loss_adaptive"):
         """precision: "fp32" | "bf16" | None (NPP_LIGHT_PRECISION, else fp32): the arithmetic of the candidate fits (NPPNetLightBatch).
         carry_latents: in the reference the adaptive pixel loss is ONE module-level object (models/helpers.py:8) that every
         candidate's optimiser trains on (helpers.py:144), so candidate k + 1 starts from the latents candidate k left (fresh Adam
@@ -566,7 +584,8 @@ class ProposalRanker:
         self.pw, self.cw = float(perceptual_weight), float(contextual_weight)
         self.rng_mode = rng_mode
         self.carry_latents, self.record_losses, self.loss_log = bool(carry_latents), bool(record_losses), []
-        self.precision = precision
+        self.precision, self.loss_type = precision, loss_type
+        ops.quad_coef(loss_type)
         if freqs is None:                                      # embedder.py:26 after torch.manual_seed(0) (search.py:92)
             g = torch.random.get_rng_state()
             torch.manual_seed(0)
@@ -678,7 +697,7 @@ class ProposalRanker:
         draws = self._pixel_draws()
         net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img),
                           params if params is not None else default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
-                          device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
+                          device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay, loss_type=self.loss_type)
         x_pos_all, x_per_all = net.embed(self.i_train_dev)                                           # search.py:104-108 tables
 
         def eager(it):
@@ -752,7 +771,7 @@ class ProposalRanker:
         nets, tabs = [], []
         for angles_deg, periods in cands:
             net = NPPNetLight(angles_deg, periods, self.freqs, (self.H, self.W_img), default_light_init(self.Wn, self.D), W=self.Wn, D=self.D,
-                              device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay)
+                              device=self.device, lrate=self.lrate, lrate_decay=self.lrate_decay, loss_type=self.loss_type)
             tabs.append(net.embed(self.i_train_dev))
             net._work(draws.shape[1])            # workspace allocated on the MAIN stream (score() / render() use it there after the join;
             nets.append(net)                      # blocks first touched on a side stream would return to that stream's pool)
@@ -778,7 +797,7 @@ class ProposalRanker:
         for g0 in range(0, len(cands), group):
             part = cands[g0:g0 + group]
             batch = NPPNetLightBatch(part, self.freqs, (self.H, self.W_img), init, W=self.Wn, D=self.D, device=self.device,
-                                     lrate=self.lrate, lrate_decay=self.lrate_decay, precision=self.precision)
+                                     lrate=self.lrate, lrate_decay=self.lrate_decay, precision=self.precision, loss_type=self.loss_type)
             tabs = [net.embed(self.i_train_dev) for net in batch.nets]                                # search.py:104-108 tables
             x_pos_all = tabs[0][0]                                                                   # the same for every candidate
             x_per_all = torch.stack([t[1] for t in tabs])                                            # (C, n_train, 20)
@@ -787,7 +806,7 @@ class ProposalRanker:
                 batch.latents.copy_(latents0.reshape(1, 6).expand(len(part), 6))
             log = []
             for draws, gt_all in self._draw_stream():
-                if batch.bf16 and draws.shape[1] % 64 == 0:
+                if batch.bf16 and batch.quad == 0 and draws.shape[1] % 64 == 0:
                     batch.fit_loop_bf16(x_pos_all, x_per_all, draws.contiguous(), gt_all.contiguous(), log if self.record_losses else None)
                     continue
                 for j in range(draws.shape[0]):

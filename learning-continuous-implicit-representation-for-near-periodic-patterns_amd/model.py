@@ -23,7 +23,10 @@ class NPPNet:
     """
 
     def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=None,
-                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5), width=NPP_WIDTH):
+                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5), width=NPP_WIDTH, loss_type="robust_loss_adaptive"):
+        """loss_type: --loss_type of options/arg_config.py:34 (models/mse_calculator.py:19-23): 'robust_loss_adaptive' (default), 'l2',
+        'robust_loss' (the two non-adaptive forms leave the adaptive latents untouched: no gradient reaches them)."""
+        self.loss_type, self.quad = loss_type, ops.quad_coef(loss_type)
         self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
         self.K = int(self.cfg.K)
         self.width = int(width)      # 256 (BASELINE configs) or 512 (the reference's default --netwidth): one fused library each
@@ -201,7 +204,7 @@ class NPPNet:
         writes dL/dpred for those rows and accumulates the latent gradients."""
         ws = self._ws[Bp]
         ops.pixel_loss(ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale,
-                       weight, self.loss_buf, ws["dpred"][:n_rows], self.dlatent)
+                       weight, self.loss_buf, ws["dpred"][:n_rows], self.dlatent, quad=self.quad)
 
     def pixel_loss_args(self, Bp, n_rows, gt, mask=None, weight=1.0):
         """The argument tuple of pixel_loss() for a launch that carries the loss along (ops.trunk_patch_in(loss=...))."""
@@ -211,7 +214,7 @@ class NPPNet:
             # order: bit-reproducible sums at no cost (include/npp_hip.h npp_pixel_loss_args.scratch)
             self._pl_scratch = torch.zeros(ops.PIXEL_LOSS_SCRATCH, dtype=torch.float32, device=self.device)
         return (ws["pred"][:n_rows], gt, mask, self.latents, self.spline, self.n_knots, self.x_scale, weight, self.loss_buf,
-                ws["dpred"][:n_rows], self.dlatent, getattr(self, "_pl_scratch", None))
+                ws["dpred"][:n_rows], self.dlatent, getattr(self, "_pl_scratch", None), self.quad)
 
     def optimizer_step(self, Bp):
         """optimizer.step() + the LR rule of train.py:253-263 + global_step += 1 (:337)."""

@@ -270,12 +270,37 @@ def load_spline(device):
     return t, int(vals.shape[0]), xs
 
 
-def pixel_loss(pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss, dpred, dlatent):
+QUAD_COEF = {"robust_loss_adaptive": 0.0, "l2": 1.0, "robust_loss": 50.0}
+
+
+def quad_coef(loss_type):
+    """--loss_type (options/arg_config.py:34, models/mse_calculator.py:19-23) -> the `quad` switch of the pixel-loss kernels: 0 = the
+    adaptive robust loss; 'l2' = mean(x^2); 'robust_loss' = lossfun(x, alpha = 2, scale = 0.1) = 0.5 (x / 0.1)^2 = 50 x^2."""
+    if loss_type not in QUAD_COEF:
+        raise ValueError(f"loss_type {loss_type!r}: one of {sorted(QUAD_COEF)}")
+    return QUAD_COEF[loss_type]
+
+
+def pixel_loss_quad(pred, gt, mask, coef, weight, loss, dpred):
+    """img2mse(pred, gt, 'l2' | 'robust_loss', None, mask) + backward for one (N, 3) problem or C stacked ones (pred / dpred (C, N, 3),
+    gt (N, 3) shared or (C, N, 3), loss (C)); loss is accumulated into."""
+    _req(pred, torch.float32, "pred")
+    _req(dpred, torch.float32, "dpred", pred.shape)
+    nb = 1 if pred.dim() == 2 else pred.shape[0]
+    n = pred.shape[-2]
+    assert gt.is_contiguous() and gt.shape[-2:] == (n, 3) and loss.numel() >= nb and (mask is None or mask.numel() == n)
+    check(lib().npp_pixel_loss_quad(_p(pred), _p(gt), 0 if gt.dim() == 2 else n * 3, _p(mask), n, nb, float(coef), float(weight), _p(loss),
+                                    _p(dpred), _stream()), "npp_pixel_loss_quad")
+
+
+def pixel_loss(pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss, dpred, dlatent, quad=0.0):
     """img2mse(pred, gt, 'robust_loss_adaptive', adaptive_pix, mask) + backward
-    (models/mse_calculator.py:13-27).  loss / dlatent are accumulated into (caller zeroes)."""
+    (models/mse_calculator.py:13-27).  loss / dlatent are accumulated into (caller zeroes).  quad > 0: the non-adaptive forms."""
     _req(pred, torch.float32, "pred")
     _req(gt, torch.float32, "gt", pred.shape)
     n = pred.shape[0]
+    if quad > 0:
+        return pixel_loss_quad(pred, gt, mask, quad, weight, loss, dpred)
     check(lib().npp_pixel_loss(_p(pred), _p(gt), _p(mask), n, _p(latents), _p(spline), n_knots, x_scale, weight,
                                _p(loss), _p(dpred), _p(dlatent), _stream()), "npp_pixel_loss")
 
@@ -450,11 +475,12 @@ def trunk_patch_in(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, 
         from ._lib import PixelLossArgs
         pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent = loss[:11]
         scratch = loss[11] if len(loss) > 11 else None        # PIXEL_LOSS_SCRATCH floats: fixed-order sums (include/npp_hip.h)
+        quad = float(loss[12]) if len(loss) > 12 else 0.0     # > 0: --loss_type l2 / robust_loss (quad_coef)
         _req(pred, torch.float32, "pred")
         _req(gt, torch.float32, "gt", pred.shape)
         la = PixelLossArgs(pred.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), pred.shape[0], latents.data_ptr(),
                            spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
-                           dlatent.data_ptr(), None if scratch is None else scratch.data_ptr())
+                           dlatent.data_ptr(), None if scratch is None else scratch.data_ptr(), quad)
         check(lib().npp_trunk_patch_in_loss(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b,
                                             _p(x0), _p(xy), _p(zero), 0 if zero is None else zero.numel(), int(which), C.byref(la),
                                             _stream()), "npp_trunk_patch_in_loss")
@@ -828,10 +854,10 @@ def trunk_patch_in_loss_stack(pred, row0, crops, cmasks, M, n_p, P, X, N_total, 
     from ._lib import PixelLossArgs
     s = (C.c_float * 3)(*[float(v) for v in scale])
     b = (C.c_float * 3)(*[float(v) for v in shift])
-    pr, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent, n_rows, scratch = loss
+    pr, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent, n_rows, scratch = loss[:13]
     la = PixelLossArgs(pr.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), int(n_rows), latents.data_ptr(),
                        spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
-                       dlatent.data_ptr(), scratch.data_ptr())
+                       dlatent.data_ptr(), scratch.data_ptr(), float(loss[13]) if len(loss) > 13 else 0.0)
     check(lib().npp_trunk_patch_in_loss_stack(_p(pred), pred.shape[1], row0, _p(crops), crops.stride(0), _p(cmasks), cmasks.stride(0), M,
                                               n_p, P, X, N_total, s, b, _p(x0), _p(xy), 0 if xy is None else xy.stride(0), _p(zero),
                                               _p(it), C.byref(la), gt_stride, lat_stride, loss_stride, scratch.stride(0), _stream()),

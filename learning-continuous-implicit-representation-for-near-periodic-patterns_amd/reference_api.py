@@ -396,10 +396,31 @@ class AdaptiveLossFunction(nn.Module):
         return (1 - 1e-5) * torch.nn.functional.softplus(self.latent_scale + 0.54132485) + 1e-5
 
 
+class _QuadLossFunction(torch.autograd.Function):
+    """img2mse with loss_type 'l2' / 'robust_loss' (mse_calculator.py:19-23): coef * mean(x^2) on npp_pixel_loss_quad."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask, coef):
+        x2 = x.detach().reshape(-1, 3).contiguous()
+        y2 = y.detach().reshape(-1, 3).contiguous()
+        m = None if mask is None else mask.detach().reshape(-1).contiguous().float()
+        loss = torch.zeros(1, dtype=torch.float32, device=x2.device)
+        dpred = torch.empty_like(x2)
+        ops.pixel_loss_quad(x2, y2, m, coef, 1.0, loss, dpred)
+        ctx.save_for_backward(dpred)
+        ctx.shape = x.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (g * dpred).reshape(ctx.shape), (-g * dpred).reshape(ctx.shape), None, None
+
+
 def img2mse(x, y, loss_type, adaptive, mask=None):
-    """models/mse_calculator.py:13-27 for loss_type == 'robust_loss_adaptive' (the reference's setting)."""
+    """models/mse_calculator.py:13-27: 'robust_loss_adaptive' (the reference's setting, train.py:195), 'l2', 'robust_loss'."""
     if loss_type != "robust_loss_adaptive":
-        raise NotImplementedError("only 'robust_loss_adaptive' (train.py:195) is on the hot path")
+        return _QuadLossFunction.apply(x, y, mask, ops.quad_coef(loss_type))
     return _PixelLossFunction.apply(x, y, mask, adaptive.latent_alpha, adaptive.latent_scale, adaptive)
 
 

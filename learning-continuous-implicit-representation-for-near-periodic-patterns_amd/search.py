@@ -44,6 +44,9 @@ def parse(argv=None):
     ap.add_argument("--carry_adaptive_latents", action="store_true",
                     help="fit the candidates one after the other through ONE set of adaptive pixel-loss latents, like the reference's module-level "
                          "adaptive_pix (models/helpers.py:8); default: every candidate starts from the initial latents (independent, batched, shardable)")
+    ap.add_argument("--loss_type", default="robust_loss_adaptive", choices=["robust_loss_adaptive", "l2", "robust_loss"],
+                    help="options/arg_config.py:34 (models/mse_calculator.py:19-23): the pixel loss of the candidate fits")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"], help="arithmetic of the candidate fits (default: NPP_LIGHT_PRECISION, else fp32)")
     ap.add_argument("--device", default="cuda:0")
     return ap.parse_args(argv)
 
@@ -99,7 +102,8 @@ def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
     ranker = ProposalRanker(masked_img, i_train, i_val, device=args.device, N_iters=args.N_iters, N_rand=args.N_rand, W=args.netwidth,
                             D=args.netdepth, lrate=args.lrate, lrate_decay=args.lrate_decay, perceptual_weight=args.perceptual_weight,
                             contextual_weight=args.contextual_weight, vgg19_state_dict=t.get("vgg19"), vgg16_state_dict=t.get("vgg16"),
-                            lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode, carry_latents=args.carry_adaptive_latents)
+                            lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode, carry_latents=args.carry_adaptive_latents,
+                            loss_type=getattr(args, "loss_type", "robust_loss_adaptive"), precision=getattr(args, "precision", None))
     cands = list(zip(angles, periods, shifts))
     dist, order, details = ranker.rank(cands, topk=args.topk_detection)
     return {"angles": [np.asarray(angles[i], np.float64).tolist() for i in order],

@@ -41,9 +41,9 @@ class StackedFit:
         for f in fits:
             if f.patch_sampler is None or f.task != "completion" or f.style is not None:
                 raise ValueError("StackedFit: completion fits with the patch losses (shifts=...) only")
-            if (f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.device) != (self.K, self.width, f0.N_rand, f0.patch_size,
-                                                                                                  f0.patch_num, f0.topk, f0.device):
-                raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count and the device")
+            if (f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.device, f.net.quad) != (
+                    self.K, self.width, f0.N_rand, f0.patch_size, f0.patch_num, f0.topk, f0.device, net0.quad):
+                raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count, loss_type and the device")
             if f.use_patch_weight or not f.use_contextual_loss or f.pixel_mask is not None or f._prefetch:
                 raise ValueError("StackedFit: default loss switches, no producer thread (the stack draws for every image itself)")
         M, dev = self.M, self.device
@@ -217,7 +217,7 @@ class StackedFit:
         sc, sh = cx.input_norm()
         net0 = fits[0].net
         loss = (self.pred, gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
-                self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix, self.pl_scratch)
+                self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix, self.pl_scratch, net0.quad)
         t = cx.hip_trunk
         with_lp = [i for i, b in enumerate(batches) if b is not None and it[i].with_lp]
         ops.trunk_patch_in_loss_stack(self.pred, self.n_pix, crops, cmasks, M, self.n_p, self.P, X, self.N_total, sc, sh,

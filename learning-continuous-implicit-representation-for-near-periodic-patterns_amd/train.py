@@ -105,7 +105,7 @@ def main(argv=None):
     if args.netwidth not in (256, 512):
         raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
     refused = [n for n, bad in (("--netdepth != 8", args.netdepth != 8), ("--activation != snake", args.activation != "snake"),
-                                ("--loss_type != robust_loss_adaptive", args.loss_type != "robust_loss_adaptive"),
+                                ("--loss_type not in robust_loss_adaptive / l2 / robust_loss", args.loss_type not in ("robust_loss_adaptive", "l2", "robust_loss")),
                                 ("--normalize_type != 1", args.normalize_type != 1),
                                 ("--use_adaptive_perceptual_loss", not args.use_adaptive_perceptual_loss)) if bad]
     if refused:
@@ -166,7 +166,8 @@ def main(argv=None):
                         style_weight=args.style_weight if remap else None,
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
                         use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
-                        no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth)
+                        no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth,
+                        loss_type=args.loss_type)
     # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
     from concurrent.futures import ThreadPoolExecutor
     writer, pending = ThreadPoolExecutor(1), []

@@ -24,7 +24,7 @@ __all__ = [
     "periodic_warp", "fourier_features", "embed", "snake", "snake_grad",
     "param_shapes", "init_params", "mlp_forward", "mlp_backward", "render",
     "sigmoid", "load_partition_spline", "adaptive_params", "robust_nll",
-    "robust_nll_grads", "img2mse", "img2mse_grads", "adam_init", "adam_step",
+    "robust_nll_grads", "img2mse", "img2mse_grads", "img2mse_quad_grads", "adam_init", "adam_step",
     "lr_schedule", "psnr", "synthetic_image", "synthetic_periodicity",
     "patch_size_from_period", "mlp_macs_per_pixel",
 ]
@@ -445,6 +445,18 @@ def img2mse_grads(pred, gt, latent_alpha, latent_scale, mask=None, spline=None):
 # --------------------------------------------------------------------------
 # a14: Adam + LR schedule (models/helpers.py:164, NPP_completion/train.py:253-263,337)
 # --------------------------------------------------------------------------
+def img2mse_quad_grads(pred, gt, loss_type, mask=None):
+    """img2mse for the non-adaptive --loss_type switches (models/mse_calculator.py:13-27): 'l2' -> mean(diff^2);
+    'robust_loss' -> mean(lossfun(diff, alpha = 2, scale = 0.1)) with robust_loss_pytorch/general.py:88-91,116: for alpha == 2 the general
+    loss IS 0.5 (x / scale)^2.  diff = x * mask + (1 - mask) * x * 0.3 (:16-17).  -> (loss, d loss / d pred)."""
+    coef = {"l2": 1.0, "robust_loss": 0.5 / (0.1 * 0.1)}[loss_type]
+    pred, gt = np.asarray(pred, np.float64), np.asarray(gt, np.float64)
+    d0 = pred - gt
+    w = 1.0 if mask is None else np.asarray(mask, np.float64) + (1.0 - np.asarray(mask, np.float64)) * 0.3
+    x = d0 * w
+    return float(coef * np.mean(x * x)), (2.0 * coef * x * w / x.size).astype(np.float32)
+
+
 def adam_init(P):
     return {"step": 0, "m": {k: np.zeros_like(v) for k, v in P.items()},
             "v": {k: np.zeros_like(v) for k, v in P.items()}}

@@ -149,3 +149,35 @@ def test_g10d_candidates_rank_the_same_in_bf16(dev, golden):
     np.testing.assert_allclose(tail16, tail32, rtol=2e-2, atol=2e-3)
     assert np.argsort(tail16).tolist() == np.argsort(tail32).tolist()
     np.testing.assert_allclose(res["fp32"][:, 0], g["c0.loss"], rtol=2e-4)       # (the fp32 path is the pinned one)
+
+
+@pytest.mark.parametrize("lt", ["l2", "robust_loss"])
+def test_candidate_fits_with_a_quadratic_pixel_loss(dev, lt):
+    """--loss_type l2 / robust_loss (models/mse_calculator.py:19-23) in the candidate fits: the fused fp32 chains, the layer-by-layer path
+    and the 16-bit chains take the non-adaptive loss through its own launch (d pred handed to the data-gradient chain); the latents stay."""
+    from npp_amd.light import NPPNetLightBatch, default_light_init
+    H, B, C = 96, 256, 3
+    rng = np.random.RandomState(5)
+    angles = np.array([[0.0, 90.0], [30.0, 120.0], [10.0, 80.0]], np.float32)
+    periods = np.array([[12.0, 9.0], [7.0, 15.0], [20.0, 6.0]], np.float32)
+    freqs = (rng.randn(10) * 10).astype(np.float32)
+    init = default_light_init(256, 4)
+    cands = [(angles[i], periods[i]) for i in range(C)]
+    mk = lambda **kw: NPPNetLightBatch(cands, freqs, (H, H), init, device=dev, loss_type=lt, **kw)      # noqa: E731
+    nets = [mk(fused=True, precision="fp32"), mk(fused=False), mk(fused=True, precision="bf16")]
+    coords = torch.from_numpy(np.stack([rng.randint(0, H, 2 * B), rng.randint(0, H, 2 * B)], 1).astype(np.int32)).to(dev)
+    tabs = [n_.embed(coords) for n_ in nets[0].nets]
+    x_pos_all, x_per_all = tabs[0][0], torch.stack([t[1] for t in tabs])
+    gt_all = torch.from_numpy(rng.rand(2 * B, 3).astype(np.float32)).to(dev)
+    lat0 = nets[0].latents.clone()
+    for it in range(8):
+        idx = torch.from_numpy(rng.permutation(2 * B)[:B]).to(dev)
+        losses = [n_.train_step(x_pos_all[idx].contiguous(), x_per_all[:, idx].contiguous(), gt_all[idx]).clone() for n_ in nets]
+        np.testing.assert_allclose(losses[0].cpu().numpy(), losses[1].cpu().numpy(), rtol=2e-5)
+        np.testing.assert_allclose(losses[2].cpu().numpy(), losses[0].cpu().numpy(), rtol=2e-2)
+        ref = oracle.img2mse_quad_grads(nets[1]._ws[B]["pred"][0].cpu().numpy(), gt_all[idx].cpu().numpy(), lt)[0] if it == 0 else None
+        if ref is not None:
+            np.testing.assert_allclose(losses[1][0].item(), ref, rtol=2e-5)
+    assert rel_l2(nets[0].params.cpu().numpy(), nets[1].params.cpu().numpy()) < 2e-5
+    for n_ in nets:
+        assert torch.equal(n_.latents, lat0)

@@ -116,6 +116,66 @@ def test_pixel_loss_golden(dev, golden, tag, use_mask):
     np.testing.assert_allclose(dlat[3:].cpu().numpy(), g[f"{k}_dls"].ravel(), rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("lt", ["l2", "robust_loss"])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_pixel_loss_quadratic_switches_golden(dev, golden, lt, use_mask):
+    """--loss_type l2 / robust_loss (models/mse_calculator.py:19-23; g4b_quad.npz = the reference's img2mse + autograd): the flat entry
+    point (one problem and three stacked ones), the boundary module's img2mse, and the form that rides in the patch-in launch."""
+    from npp_amd import ops, reference_api as api
+    g = golden("g4b_quad.npz")
+    k = f"{lt}_{'mask' if use_mask else 'nomask'}"
+    pred = torch.from_numpy(g["pred"]).to(dev)
+    gt = torch.from_numpy(g["gt"]).to(dev)
+    mask = torch.from_numpy(g["mask"]).to(dev).reshape(-1).contiguous() if use_mask else None
+    coef = ops.quad_coef(lt)
+    loss, dpred = torch.zeros(1, device=dev), torch.empty_like(pred)
+    ops.pixel_loss_quad(pred, gt, mask, coef, 1.0, loss, dpred)
+    np.testing.assert_allclose(loss.item(), g[f"{k}_loss"], rtol=2e-5)
+    np.testing.assert_allclose(dpred.cpu().numpy(), g[f"{k}_dpred"], rtol=2e-5, atol=1e-9)
+    p3 = torch.stack([pred, pred * 0.5, gt]).contiguous()                   # three problems, shared targets
+    l3, d3 = torch.zeros(3, device=dev), torch.empty_like(p3)
+    ops.pixel_loss_quad(p3, gt, mask, coef, 2.0, l3, d3)
+    np.testing.assert_allclose(l3[0].item(), 2.0 * g[f"{k}_loss"], rtol=2e-5)
+    np.testing.assert_allclose(d3[0].cpu().numpy(), 2.0 * g[f"{k}_dpred"], rtol=2e-5, atol=1e-9)
+    assert l3[2].item() == 0.0 and float(d3[2].abs().max()) == 0.0
+    ref_l, ref_d = oracle.img2mse_quad_grads(p3[1].cpu().numpy(), g["gt"], lt, g["mask"] if use_mask else None)
+    np.testing.assert_allclose(l3[1].item(), 2.0 * ref_l, rtol=2e-5)
+    np.testing.assert_allclose(d3[1].cpu().numpy(), 2.0 * ref_d, rtol=2e-5, atol=1e-9)
+    x = pred.clone().requires_grad_(True)                                   # the reference's call signature (mse_calculator.py:13)
+    out = api.img2mse(x, gt, lt, None, None if mask is None else mask.reshape(-1, 1))
+    out.backward()
+    np.testing.assert_allclose(out.item(), g[f"{k}_loss"], rtol=2e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{k}_dpred"], rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("lt", ["l2", "robust_loss"])
+def test_fit_with_a_quadratic_pixel_loss(dev, lt):
+    """CompletionFit(loss_type=...): the loss rides in the patch-in launch like the adaptive one (folded form == separate launches, bit
+    for bit on the MLP half), the adaptive latents stay where they were (no gradient reaches them: torch's Adam skips them in the
+    reference), and the fit converges."""
+    from npp_amd.fit import CompletionFit
+    H, K = 128, 1
+    img, mask = oracle.synthetic_image(H, seed=3)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make():
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=1), device=dev, N_rand=2048, shifts=shifts,
+                             seed=4, loss_type=lt, contextual_weight=0.0, perceptual_weight=0.0)
+    a, b = make(), make()
+    b.fold_launches = False
+    lat0 = a.net.latents.clone()
+    p0 = a.psnr("known")
+    for _ in range(60):
+        a.step_full()
+        b.step_full()
+    torch.cuda.synchronize()
+    assert torch.equal(a.net.params, b.net.params)
+    assert torch.equal(a.net.latents, lat0)
+    p1 = a.psnr("known")
+    print(f"{lt}: PSNR {p0:.2f} -> {p1:.2f} dB after 60 iterations")
+    assert p1 > p0 + 5.0
+
+
 def test_adam_golden(dev, golden):
     from npp_amd import ops
     g = golden("g9_adam.npz")

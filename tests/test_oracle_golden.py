@@ -115,6 +115,16 @@ def test_g4_robust(golden, tag, mtag):
     np.testing.assert_allclose(dls, g[f"{k}_dls"], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("lt", ["l2", "robust_loss"])
+@pytest.mark.parametrize("mtag", ["nomask", "mask"])
+def test_g4b_quadratic_loss_switches(golden, lt, mtag):
+    """--loss_type l2 / robust_loss (models/mse_calculator.py:19-23) by the reference's own autograd (make_golden_quad.py)."""
+    g = golden("g4b_quad.npz")
+    loss, dpred = oracle.img2mse_quad_grads(g["pred"], g["gt"], lt, g["mask"] if mtag == "mask" else None)
+    np.testing.assert_allclose(loss, g[f"{lt}_{mtag}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(dpred, g[f"{lt}_{mtag}_dpred"], rtol=1e-5, atol=1e-9)
+
+
 def test_g9_adam(golden):
     g = golden("g9_adam.npz")
     P = {"p0": g["p0_init"].copy(), "p1": g["p1_init"].copy()}
