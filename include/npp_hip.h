@@ -282,7 +282,9 @@ int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, f
  * d_dlatent [2C] (accumulated) may both be NULL for forward only.  C in {16, 32, 64, 128, 192,
  * 256, 384, 512}.  d_workspace: npp_lpips_workspace_bytes(C) bytes, ZEROED once by the caller and owned by one
  * stream -- the latent gradients and the loss are then summed over the launch's blocks as fixed-point integers
- * (order-independent, bit-reproducible); NULL: float atomics in arrival order. */
+ * (order-independent, bit-reproducible); NULL: float atomics in arrival order.
+ * d_latents == NULL: the PLAIN head, LPIPS.forward(use_robust=False) (lpips.py:108-109: diffs = (feats0 - feats1)^2) -- the in-loop
+ * form under --use_adaptive_perceptual_loss off (train.py:241-251) -- with its gradient d_df0 (d_spline, d_dlatent NULL). */
 int64_t npp_lpips_workspace_bytes(int C);
 int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
                     const float* d_lin, const float* d_latents, const float* d_spline,

@@ -46,8 +46,13 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
   __shared__ LpChan scp[C];
   __shared__ float slin[C];
   const int pl = threadIdx.x % PL, cl = threadIdx.x / PL;
+  // latents == nullptr: LPIPS.forward(use_robust=False) (lpips.py:108-109: diffs = (feats0 - feats1)^2) with its gradient -- the
+  // non-adaptive in-loop form (--use_adaptive_perceptual_loss off, train.py:241-251); no latents, no latent gradient
+  const bool plain = latents == nullptr;
   for (int i = threadIdx.x; i < 2 * C; i += 256) sdl[i] = 0.0f;
   for (int c = threadIdx.x; c < C; c += 256) {
+    slin[c] = lin[c];
+    if (plain) continue;
     const ChanParams P = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
     LpChan L;
     L.e = 0.5f * P.alpha;
@@ -60,7 +65,6 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     L.e_inv_b2 = L.e / (P.beta * P.beta);
     L.logc_plus_logz = P.logc_plus_logz; L.dlogz = P.dlogz; L.dalpha_dl = P.dalpha_dl; L.dc_dl = P.dc_dl;
     scp[c] = L;
-    slin[c] = lin[c];
   }
   __syncthreads();
   const int64_t npos = (int64_t)N * hw;
@@ -103,7 +107,15 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
       const float l = slin[c];
       float da = 0.0f, dc = 0.0f;
       dd[q] = 0.0f;
-      if (live) {
+      if (live && plain) {
+        const float x = u[q] * i0 - v[q] * i1;
+        val += l * x * x;
+        if (g0) {
+          const float d = l * coef * 2.0f * x;
+          dd[q] = d;
+          dot = fmaf(d, u[q], dot);
+        }
+      } else if (live) {
         const float x = u[q] * i0 - v[q] * i1;
         const float xs = x * P.inv_c, ssx = xs * xs;
         const float uu = fmaf(ssx, P.inv_beta, 1.0f), lnu = __logf(uu);
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
           dc = l * coef * (-(x * x) * P.x2_inv_c3 * ue1 + P.inv_c);
         }
       }
-      if (df0) {                                                         // uniform branch
+      if (df0 && !plain) {                                               // uniform branch
 #pragma unroll
         for (int off = PL / 2; off > 0; off >>= 1) {                     // the PL positions of this channel lane
           da += __shfl_xor(da, off, 64);
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the
     // totals back, accumulates them into dlatent / loss and clears the accumulators for the next call.
     auto tofix = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); };
-    if (df0)
+    if (df0 && !plain)
       for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i]));
     if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3])));
     if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), (int)gridDim.x)) return;
@@ -158,11 +170,11 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
       const long long s = (long long)__hip_atomic_exchange(fix + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float v = (float)((double)s * (1.0 / 1099511627776.0));
       if (i == 2 * C) atomicAdd(loss, v);                    // (the contextual branch adds to the same word from its own stream)
-      else if (df0) dlatent[i] += v;
+      else if (df0 && !plain) dlatent[i] += v;
     }
     return;
   }
-  if (df0)
+  if (df0 && !plain)
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dlatent + i, sdl[i]);
   if (threadIdx.x == 0) atomicAdd(loss, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
@@ -177,11 +189,16 @@ extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)(2 * C + 2
 extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                                const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
                                float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
-  if (!d_f0 || !d_f1 || !d_lin || !d_latents || !d_spline || !d_loss || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 || n_knots < 2) {
+  if (!d_f0 || !d_f1 || !d_lin || !d_loss || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 ||
+      (d_latents && (!d_spline || n_knots < 2))) {
     set_error("npp_lpips_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
     return NPP_ERR_ARG;
   }
-  if ((d_df0 == nullptr) != (d_dlatent == nullptr)) { set_error("npp_lpips_layer: df0 and dlatent go together"); return NPP_ERR_ARG; }
+  // d_latents == NULL: the plain head (use_robust=False), with its gradient when d_df0 is given
+  if (d_latents ? (d_df0 == nullptr) != (d_dlatent == nullptr) : d_dlatent != nullptr) {
+    set_error("npp_lpips_layer: df0 and dlatent go together (no dlatent for the plain head)");
+    return NPP_ERR_ARG;
+  }
   unsigned long long* fix = (unsigned long long*)d_workspace;    // nullable: float atomics in arrival order instead
   hipStream_t s = (hipStream_t)stream;
   const int64_t nh = (int64_t)N * hw;

@@ -27,9 +27,10 @@ class CompletionFit:
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
                  vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False, use_patch_weight=False,
-                 no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive"):
+                 no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive", use_adaptive_perceptual_loss=True):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
         width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
+        use_adaptive_perceptual_loss: False = LPIPS(use_robust=False) in the loop (arg_config.py:78, train.py:241-246).
         loss_type: --loss_type (arg_config.py:34; models/mse_calculator.py:19-23): 'robust_loss_adaptive' | 'l2' | 'robust_loss'.
         Ablation switches of arg_config.py:78-92: no_reg_sampling (random real patches), use_patch_weight (1/d lattice weights:
         weighted-sum forms of the contextual and LPIPS terms, train.py:224-250), no_pix_loss (:197), use_contextual_loss.
@@ -89,6 +90,7 @@ class CompletionFit:
             train_img = img
         self.pix_w = 0.0 if no_pix_loss else 1.0                      # train.py:197-198 `loss = 0`: the pixel term weighs nothing
         self.use_patch_weight, self.use_contextual_loss = bool(use_patch_weight), bool(use_contextual_loss)
+        self.lp_robust = bool(use_adaptive_perceptual_loss)
         self.img = torch.from_numpy(img).to(self.device)
         self.mask = torch.from_numpy(mask).to(self.device)
         self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
@@ -397,7 +399,8 @@ class CompletionFit:
         if with_lp:                                                                                 # train.py:241-250
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
-                dx_b = self.percepLoss.fused(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf, normalize=True)
+                dx_b = self.percepLoss.fused(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf, normalize=True,
+                                            use_robust=self.lp_robust)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
         if fy is not None:
             dx_a = cx.fused_x((nk, 3, P, P), fy, self.cx_w, self.patch_loss_buf, weight=weight)
@@ -453,7 +456,7 @@ class CompletionFit:
         weight = b.get("weight")
         loss_patch = self.contextualLoss(x_in, real_p * rm, weight) * self.cx_w if self.use_contextual_loss else pp_leaf.sum() * 0.0
         if source == "same" and self.use_perceptual_loss:
-            lp = self.percepLoss(pp * rm, fk * rm, use_robust=True, normalize=True)                 # mean over the nk samples
+            lp = self.percepLoss(pp * rm, fk * rm, use_robust=self.lp_robust, normalize=True)       # mean over the nk samples
             loss_patch = loss_patch + lp * (nk_ if weight is not None else 1) * self.lp_w
         loss_patch.backward()
         ws["dpred"][n_pix:n].copy_(pp_leaf.grad)

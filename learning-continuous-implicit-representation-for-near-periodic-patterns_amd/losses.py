@@ -384,23 +384,24 @@ class ContextualLoss(nn.Module):
 
 class _LPIPSLayerFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f0, f1, owner, kk):
+    def forward(ctx, f0, f1, owner, kk, robust=True):
         loss = torch.zeros(1, dtype=torch.float32, device=f0.device)
         need = f0.requires_grad
         df0 = torch.empty_like(f0) if need else None
-        dlat = torch.zeros_like(owner.latents[kk]) if need else None
-        ops.lpips_layer(f0.contiguous(), f1.contiguous(), owner.lins[kk], owner.latents[kk], owner.spline, owner.n_knots,
+        dlat = torch.zeros_like(owner.latents[kk]) if (need and robust) else None
+        ops.lpips_layer(f0.contiguous(), f1.contiguous(), owner.lins[kk], owner.latents[kk] if robust else None, owner.spline, owner.n_knots,
                         owner.x_scale, 1.0, loss, df0, dlat)
-        ctx.owner, ctx.kk = owner, kk
-        ctx.save_for_backward(df0 if need else torch.empty(0), dlat if need else torch.empty(0))
+        ctx.owner, ctx.kk, ctx.robust = owner, kk, robust
+        ctx.save_for_backward(df0 if need else torch.empty(0), dlat if dlat is not None else torch.empty(0))
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         df0, dlat = ctx.saved_tensors
-        ctx.owner.dlatents[ctx.kk].add_(dlat * g)           # the reference's list of AdaptiveLossFunction params
-        ctx.owner.touched = True
-        return df0 * g, None, None, None
+        if ctx.robust:
+            ctx.owner.dlatents[ctx.kk].add_(dlat * g)       # the reference's list of AdaptiveLossFunction params
+            ctx.owner.touched = True
+        return df0 * g, None, None, None, None
 
 
 def _latent_blobs(inits, dev):
@@ -446,7 +447,8 @@ class LPIPS(nn.Module):
         self.to(dev)
 
     def forward(self, in0, in1, use_robust=True, retPerLayer=False, normalize=False):
-        assert use_robust and not retPerLayer, "only the use_robust=True path of the loop is built"
+        """use_robust=False: the plain head (lpips.py:108-109) with its gradient -- the loop under --use_adaptive_perceptual_loss off."""
+        assert not retPerLayer, "retPerLayer is not on the built path"
         if self.trunk_kind == "hip":       # 2x-1 (lpips.py:96-98) and the scaling layer are folded into the image-in kernel
             a = 2.0 if normalize else 1.0
             n = in0.shape[0]
@@ -462,11 +464,11 @@ class LPIPS(nn.Module):
                 outs1 = self.net(in1)
         val = 0
         for kk in range(5):
-            val = val + _LPIPSLayerFunction.apply(outs0[kk], outs1[kk], self, kk)
+            val = val + _LPIPSLayerFunction.apply(outs0[kk], outs1[kk], self, kk, bool(use_robust))
         return val
 
-    def fused(self, xy, n, scale, loss_buf, normalize=True):
-        """Explicit forward + backward of `scale * self(xy[:n], xy[n:], use_robust=True, normalize)` (batch mean)
+    def fused(self, xy, n, scale, loss_buf, normalize=True, use_robust=True):
+        """Explicit forward + backward of `scale * self(xy[:n], xy[n:], use_robust, normalize)` (batch mean)
         without autograd: accumulates into loss_buf[0] and self.dlatents, returns dL/dxy ([:n] defined)."""
         a = 2.0 if normalize else 1.0
         sc = [a / s for s in self._SCALE]
@@ -476,10 +478,10 @@ class LPIPS(nn.Module):
         dfs = []
         for kk, f in enumerate(feats):
             df0 = torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device)
-            ops.lpips_layer(f[:n], f[n:], self.lins[kk], self.latents[kk], self.spline, self.n_knots, self.x_scale, scale,
+            ops.lpips_layer(f[:n], f[n:], self.lins[kk], self.latents[kk] if use_robust else None, self.spline, self.n_knots, self.x_scale, scale,
                             loss_buf, df0, self.dlatents[kk])
             dfs.append(df0)
-        self.touched = True
+        self.touched = self.touched or bool(use_robust)        # (the plain head gives the latents no gradient: Adam skips them)
         return t._backward(dfs, n, sc, tuple(xy.shape), zero_rest=False)
 
     @torch.no_grad()

@@ -401,7 +401,10 @@ _lp_ws = {}
 
 
 def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0=None, dlatent=None):
-    """One VGG16 tap of LPIPS.forward(use_robust=True) (externel_lib/lpips/lpips.py:99-121,130)."""
+    """One VGG16 tap of LPIPS.forward(use_robust=True) (externel_lib/lpips/lpips.py:99-121,130); latents None: the plain head
+    (use_robust=False, lpips.py:108-109) with its gradient df0 (spline / dlatent unused)."""
+    if latents is None:
+        spline, n_knots, x_scale, dlatent = None, 0, 0.0, None
     _req(f0, torch.float32, "f0")
     _req(f1, torch.float32, "f1", f0.shape)
     N, C = f0.shape[:2]

@@ -55,7 +55,8 @@ def parse(argv=None):
                          "segmentation / remapping have it OFF (store_true, :190,274)")
     ap.add_argument("--perceptual_weight", type=float, default=1e-3)
     ap.add_argument("--use_contextual_loss", action="store_false", help="(store_false) pass it to drop the contextual term")
-    ap.add_argument("--use_adaptive_perceptual_loss", action="store_false", help="(store_false) ablation: not built, refused")
+    ap.add_argument("--use_adaptive_perceptual_loss", action="store_false",
+                    help="(store_false, as in arg_config.py:78) given: LPIPS(use_robust=False) in the loop instead of the adaptive-robust head")
     ap.add_argument("--use_patch_weight", action="store_true", help="1/d lattice weights on the patch terms (train.py:224-250)")
     ap.add_argument("--no_pix_loss", action="store_true", help="no pixel loss (train.py:197-198)")
     ap.add_argument("--patch_num", type=int, default=2)
@@ -107,10 +108,9 @@ def main(argv=None):
     refused = [n for n, bad in (("--netdepth != 8", args.netdepth != 8), ("--activation != snake", args.activation != "snake"),
                                 ("--loss_type not in robust_loss_adaptive / l2 / robust_loss", args.loss_type not in ("robust_loss_adaptive", "l2", "robust_loss")),
                                 ("--normalize_type != 1", args.normalize_type != 1),
-                                ("--use_adaptive_perceptual_loss", not args.use_adaptive_perceptual_loss)) if bad]
+                                ) if bad]
     if refused:
-        raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (it is the "
-                         f"reference's default configuration: D = 8, snake, adaptive robust pixel loss, adaptive LPIPS); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
+        raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (D = 8, snake, sigmoid output); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     from . import weights
@@ -167,7 +167,7 @@ def main(argv=None):
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
                         use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
                         no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth,
-                        loss_type=args.loss_type)
+                        loss_type=args.loss_type, use_adaptive_perceptual_loss=args.use_adaptive_perceptual_loss)
     # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
     from concurrent.futures import ThreadPoolExecutor
     writer, pending = ThreadPoolExecutor(1), []

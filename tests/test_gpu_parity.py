@@ -176,6 +176,71 @@ def test_fit_with_a_quadratic_pixel_loss(dev, lt):
     assert p1 > p0 + 5.0
 
 
+def _lpips_plain_head_torch(f0, f1, lin):
+    """lpips.py:99-133 with use_robust=False in plain torch: normalize_tensor (eps 1e-10), squared difference, lin 1x1 conv,
+    spatial mean, summed over the batch."""
+    n0 = f0 / (f0.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    n1 = f1 / (f1.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    return ((n0 - n1).pow(2) * lin[None, :, None, None]).sum(1).mean((1, 2)).sum()
+
+
+@pytest.mark.parametrize("C,hw", [(64, 24), (256, 12), (512, 6)])
+def test_lpips_plain_head_with_gradient(dev, C, hw):
+    """npp_lpips_layer with no latents = LPIPS.forward(use_robust=False) (lpips.py:108-109) -- the in-loop head under
+    --use_adaptive_perceptual_loss off: value against the forward-only kernel the ranking score uses (pinned to the reference by g10)
+    and against torch fp32, gradient against torch autograd."""
+    from npp_amd import ops
+    g = torch.Generator().manual_seed(C)
+    N = 3
+    f0 = torch.rand(N, C, hw, hw, generator=g).to(dev)
+    f1 = torch.rand(N, C, hw, hw, generator=g).to(dev)
+    lin = (torch.rand(C, generator=g) * 0.1).to(dev)
+    loss, ref_fwd, df0 = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.empty_like(f0)
+    ops.lpips_layer(f0, f1, lin, None, None, 0, 0.0, 2.0 * N, loss, df0, None)           # scale / N = 2: twice the batch sum
+    ops.lpips_plain_layer(f0, f1, lin, 2.0, ref_fwd)
+    x = f0.clone().requires_grad_(True)
+    ref = 2.0 * _lpips_plain_head_torch(x, f1, lin)
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref_fwd.item(), rtol=2e-5)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    assert rel_l2(df0.cpu().numpy(), x.grad.cpu().numpy()) < 2e-5
+    fwd_only = torch.zeros(1, device=dev)
+    ops.lpips_layer(f0, f1, lin, None, None, 0, 0.0, 2.0 * N, fwd_only)
+    assert fwd_only.item() == loss.item() or abs(fwd_only.item() - loss.item()) < 1e-6 * abs(loss.item())
+
+
+def test_fit_with_the_plain_lpips_head(dev):
+    """CompletionFit(use_adaptive_perceptual_loss=False): on a 'same' iteration the explicit loop's gradients equal the autograd loop's,
+    the LPIPS latents never move (no gradient reaches them: torch's Adam skips them in the reference), the fit stays finite."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H, seed=2)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make():
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=2), device=dev, N_rand=2048, shifts=shifts,
+                             seed=7, use_adaptive_perceptual_loss=False, perceptual_weight=1e-2)
+    a, b = make(), make()
+    lat0 = a.percepLoss._lat.clone()
+    batch = None
+    for _ in range(200):                                   # the first 'same' batch of the stream (20 % of the draws)
+        batch = a.sample_batch()
+        if batch is not None and batch["source"] == "same":
+            break
+    assert batch is not None and batch["source"] == "same"
+    a.step_from(batch)
+    b.step_from_autograd(batch)
+    ga, gb = a.net.grads(), b.net.grads()
+    for name in ga:
+        assert rel_l2(ga[name], gb[name]) < 2e-3, name
+    np.testing.assert_allclose(float(a.last_patch_loss[0]), float(b.last_patch_loss[0]), rtol=2e-3)
+    for _ in range(30):
+        a.step_full()
+    torch.cuda.synchronize()
+    assert torch.equal(a.percepLoss._lat, lat0) and torch.equal(b.percepLoss._lat, lat0) and a.percepLoss.lat_step == 0
+    assert bool(torch.isfinite(a.net.params).all())
+
+
 def test_adam_golden(dev, golden):
     from npp_amd import ops
     g = golden("g9_adam.npz")

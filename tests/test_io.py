@@ -108,11 +108,13 @@ def test_train_driver_ablation_switches(tmp_path):
 
 def test_train_driver_refuses_unbuilt_ablations(tmp_path):
     from npp_amd import train
-    for flags in (["--use_adaptive_perceptual_loss"], ["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"],
-                  ["--loss_type", "mse"]):
+    for flags in (["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"], ["--loss_type", "mse"]):
         with pytest.raises(SystemExit, match="ablation"):
             train.main(["--datadir", str(tmp_path), "--random-trunks"] + flags)
+    a = train.parse(["--datadir", "x", "--loss_type", "l2", "--use_adaptive_perceptual_loss"])      # built in round 4
+    assert a.loss_type == "l2" and a.use_adaptive_perceptual_loss is False
     a = train.parse(["--datadir", "x"])
+    assert a.loss_type == "robust_loss_adaptive" and a.use_adaptive_perceptual_loss is True
     assert a.netwidth == 512 and a.use_comp is True and a.use_perceptual_loss is False and a.no_reg_sampling is False
 
 
