@@ -126,6 +126,10 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
 int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg,
                 int width, const void* d_wf, const float* d_params, float* d_pred,
                 void* d_actF, void* stream);
+/* The same with render()'s output nonlinearity as an argument (models/helpers.py:55-60): out_act 1 = sigmoid (npp_mlp_fwd), 2 = tanh
+ * (--normalize_type 2: images scaled to [-1, 1], loaders/loaders.py:56,111), 0 = the raw network output. */
+int npp_mlp_fwd_act(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width, const void* d_wf,
+                    const float* d_params, float* d_pred, void* d_actT, int out_act, void* stream);
 
 /* Backward of the same (what loss.backward() does through networks.py:56-95):
  * d_dpred (Bp,3) = dL/dpred (rows >= the real batch must be 0).  Reads actF, writes dzF. */
@@ -147,6 +151,10 @@ typedef struct {
 int npp_mlp_bwd_patch(float* d_dpred, const float* d_pred, int64_t Bp, int K, int width,
                       const void* d_wb, const float* d_params, const void* d_actF,
                       void* d_dzF, const npp_patch_grad* patch, void* stream);
+/* npp_mlp_bwd_patch behind out_act (see npp_mlp_fwd_act). */
+int npp_mlp_bwd_patch_act(float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                          const float* d_params, const void* d_actT, void* d_dzT, const npp_patch_grad* pg, int out_act,
+                          void* stream);
 
 /* Compatibility forms at the reference's module boundary.  NPP_Net(...).forward(None, x_periodic)
  * (models/networks.py:56-95, NPP_Net_top1 :134-173) receives a MATERIALISED embedding:

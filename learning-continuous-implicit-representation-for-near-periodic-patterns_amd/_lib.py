@@ -92,6 +92,7 @@ SYMBOLS = {
     "npp_warp_fwd": (_i32, [_vp, _i64, _cfgp, _vp, _vp]),
     "npp_train_workspace": (_i32, [_i32, _i32, _i64, _i32, C.POINTER(_i64)]),
     "npp_mlp_fwd": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "npp_mlp_fwd_act": (_i32, [_vp, _i64, _cfgp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "npp_mlp_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "npp_mlp_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "npp_mlp_wgrad_tiles": (_i32, [_i32]),
@@ -100,6 +101,7 @@ SYMBOLS = {
     "npp_mlp_fwd_emb": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "npp_mlp_bwd_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "npp_mlp_bwd_patch": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "npp_mlp_bwd_patch_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "npp_grad_reduce": (_i32, [_vp, _i32, _i64, _i64, _vp, _i32, _vp]),
     "npp_fourier_fwd": (_i32, [_vp, _i64, _i32, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
     "npp_adam_step_net": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32,

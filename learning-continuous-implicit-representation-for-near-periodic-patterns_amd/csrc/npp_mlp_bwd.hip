@@ -344,6 +344,14 @@ extern "C" int npp_mlp_bwd_patch(float* d_dpred, const float* d_pred, int64_t Bp
   return bwd_launch(d_dpred, d_pred, Bp, K, width, d_wb, d_params, d_actT, d_dzT, 1, stream, pg);
 }
 
+// npp_mlp_bwd_patch behind another output nonlinearity (out_act: 1 sigmoid = npp_mlp_bwd_patch, 2 tanh, 0 none)
+extern "C" int npp_mlp_bwd_patch_act(float* d_dpred, const float* d_pred, int64_t Bp, int K, int width, const void* d_wb,
+                                     const float* d_params, const void* d_actT, void* d_dzT, const npp_patch_grad* pg, int out_act,
+                                     void* stream) {
+  if (!pg) { set_error("npp_mlp_bwd_patch_act: null patch-gradient description"); return NPP_ERR_ARG; }
+  return bwd_launch(d_dpred, d_pred, Bp, K, width, d_wb, d_params, d_actT, d_dzT, out_act, stream, pg);
+}
+
 // stacked form: M images per launch (npp_common.h "stacked launches"); always the patch form (npp_mlp_bwd_patch)
 extern "C" int npp_mlp_bwd_patch_stack(float* d_dpred, const float* d_pred, int64_t Bp, int M, int K, int width, const void* d_wb,
                                        int64_t wb_stride_bytes, const float* d_params, int64_t params_stride, const void* d_actT,

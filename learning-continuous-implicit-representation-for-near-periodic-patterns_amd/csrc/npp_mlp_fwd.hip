@@ -660,7 +660,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 // STACK: the stacked-launch form (npp_mlp_fwd_stack).  A template parameter, not a run-time branch: the plain launch keeps reading
 // its pointers from the kernel-argument segment where it needs them -- as locals they cost the training forward 3-4 us of SGPR
 // pressure in a kernel that already spills 40 of them.
-template <bool TRAIN, bool MULTI, bool EMB_IN = false, bool STACK = false>
+// ACT: the output nonlinearity is read from A_.out_act (npp_mlp_fwd_act: tanh / raw); false = the sigmoid, compiled in -- a template
+// parameter for the same reason as STACK (the run-time test cost the default launch 0.9 us in a same-box A/B)
+template <bool TRAIN, bool MULTI, bool EMB_IN = false, bool STACK = false, bool ACT = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int img_ = 0, wg = blockIdx.x, xslot_ = blockIdx.x >> 3, xcount_ = ((int)gridDim.x + 7) >> 3;
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 #pragma unroll
       for (int w = 0; w < kNT / 2; ++w) z += sRGB[(w * kRowTile + row) * 3 + c];   // P's neuron tiles, in order
       float o = 1.0f / (1.0f + __expf(-z));                         // helpers.py:56 sigmoid
-      if (EMB_IN && A_.out_act != 1) o = A_.out_act == 2 ? tanhf(z) : z;   // helpers.py:57-58 tanh / raw network output
+      if ((EMB_IN || ACT) && A_.out_act != 1) o = A_.out_act == 2 ? tanhf(z) : z;   // helpers.py:57-58 tanh (--normalize_type 2) / raw network output
       s_pred[(row0 + row) * 3 + c] = o;
     }
   }
@@ -998,7 +1000,20 @@ static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, boo
       if (!smem_attr(once_s[1], (const void*)mlp_fwd_kernel<true, false, false, true>, kSmemFwd)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
       hipLaunchKernelGGL((mlp_fwd_kernel<true, false, false, true>), grid, block, kSmemFwd, s, A, e, d);
     }
-  } else if (emb_in) NPP_LAUNCH2(true); else NPP_LAUNCH2(false);
+  } else if (emb_in) NPP_LAUNCH2(true);
+  else if (A.out_act != 1) {               // npp_mlp_fwd_act: the instantiations that read the nonlinearity from the arguments
+#define NPP_LAUNCH_ACT(T, M)                                                                                   \
+    do {                                                                                                         \
+      static SmemOnce once;                                                                                      \
+      if (!smem_attr(once, (const void*)mlp_fwd_kernel<T, M, false, false, true>, kSmemFwd)) {                   \
+        set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH;                                             \
+      }                                                                                                          \
+      hipLaunchKernelGGL((mlp_fwd_kernel<T, M, false, false, true>), grid, block, kSmemFwd, s, A, e, d);         \
+    } while (0)
+    if (train) { if (multi) NPP_LAUNCH_ACT(true, true); else NPP_LAUNCH_ACT(true, false); }
+    else { if (multi) NPP_LAUNCH_ACT(false, true); else NPP_LAUNCH_ACT(false, false); }
+#undef NPP_LAUNCH_ACT
+  } else NPP_LAUNCH2(false);
 #undef NPP_LAUNCH2
 #undef NPP_LAUNCH
   return check_launch(who);
@@ -1022,6 +1037,20 @@ extern "C" int npp_mlp_fwd(const int32_t* d_coords_yx, int64_t Bp, const npp_emb
   A.coords = d_coords_yx; A.Bp = Bp; A.wf = (const bf16x8*)d_wf; A.params = d_params; A.pred = d_pred;
   A.actF = (char*)d_actT; A.out_act = 1;
   return fwd_launch(A, make_embed_dev(*cfg), make_desc(cfg->K), false, stream, "npp_mlp_fwd");
+}
+
+// npp_mlp_fwd with the output nonlinearity of render() as an argument (models/helpers.py:55-60): 1 sigmoid (--normalize_type 1, what
+// npp_mlp_fwd applies), 2 tanh (--normalize_type 2: images in [-1, 1], loaders.py:56), 0 the raw network output
+extern "C" int npp_mlp_fwd_act(const int32_t* d_coords_yx, int64_t Bp, const npp_embed_cfg* cfg, int width, const void* d_wf,
+                               const float* d_params, float* d_pred, void* d_actT, int out_act, void* stream) {
+  int rc = check_embed_cfg(cfg, "npp_mlp_fwd_act");
+  if (rc) return rc;
+  if ((rc = fwd_check(Bp, width, d_coords_yx, d_wf, d_params, d_pred, "npp_mlp_fwd_act"))) return rc;
+  if (out_act < 0 || out_act > 2) { set_error("npp_mlp_fwd_act: out_act=%d", out_act); return NPP_ERR_ARG; }
+  FwdArgs A{};
+  A.coords = d_coords_yx; A.Bp = Bp; A.wf = (const bf16x8*)d_wf; A.params = d_params; A.pred = d_pred;
+  A.actF = (char*)d_actT; A.out_act = out_act;
+  return fwd_launch(A, make_embed_dev(*cfg), make_desc(cfg->K), false, stream, "npp_mlp_fwd_act");
 }
 
 extern "C" int npp_mlp_fwd_emb(const float* d_emb, int64_t ld, int64_t Bp, int K, int width, const void* d_wf,

@@ -23,10 +23,13 @@ class NPPNet:
     """
 
     def __init__(self, angles_deg, periods, freqs, res, params=None, device="cuda", ksplit=None,
-                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5), width=NPP_WIDTH, loss_type="robust_loss_adaptive"):
+                 lrate=5e-4, lrate_decay=500, offsets=(0.0, -1.0, 1.0, 0.5, -0.5), width=NPP_WIDTH, loss_type="robust_loss_adaptive", out_act=1):
         """loss_type: --loss_type of options/arg_config.py:34 (models/mse_calculator.py:19-23): 'robust_loss_adaptive' (default), 'l2',
         'robust_loss' (the two non-adaptive forms leave the adaptive latents untouched: no gradient reaches them)."""
         self.loss_type, self.quad = loss_type, ops.quad_coef(loss_type)
+        if out_act not in (1, 2):
+            raise ValueError("out_act: 1 (sigmoid, --normalize_type 1) or 2 (tanh, --normalize_type 2: images in [-1, 1]; helpers.py:55-58)")
+        self.out_act = int(out_act)
         self.cfg = EmbedCfg.make(angles_deg, periods, freqs, res, offsets)
         self.K = int(self.cfg.K)
         self.width = int(width)      # 256 (BASELINE configs) or 512 (the reference's default --netwidth): one fused library each
@@ -138,13 +141,13 @@ class NPPNet:
         return ws
 
     def group_forward(self, g, coords_rows):
-        ops.mlp_fwd(coords_rows, self.cfg, self.wf, self.params, g["pred"], g["actT"], self.width)
+        ops.mlp_fwd(coords_rows, self.cfg, self.wf, self.params, g["pred"], g["actT"], self.width, out_act=self.out_act)
 
     def group_backward(self, g, patch=None, wgrad=True):
         if patch is not None:
-            ops.mlp_bwd_patch(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], *patch, width=self.width)
+            ops.mlp_bwd_patch(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], *patch, width=self.width, out_act=self.out_act)
         else:
-            ops.mlp_bwd(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], self.width)
+            ops.mlp_bwd(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], self.width, out_act=self.out_act)
         if wgrad:
             ops.mlp_wgrad(g["dzT"], g["actT"], g["rows"], self.K, g["ks"], g["gslabs"], self.width)
 
@@ -166,7 +169,7 @@ class NPPNet:
         if bp != n:
             pad = torch.zeros((bp - n, 2), dtype=torch.int32, device=coords.device)
             coords = torch.cat([coords, pad], 0)
-        pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params, width=self.width)
+        pred = ops.mlp_fwd(coords.contiguous(), self.cfg, self.wf, self.params, width=self.width, out_act=self.out_act)
         return pred[:n]
 
     def render_fp32(self, coords):
@@ -181,12 +184,12 @@ class NPPNet:
         if getattr(self, "_w32_stamp", None) != stamp:
             self._w32 = ops.pack_weights32(self.params, self.K, getattr(self, "_w32", None), self.width)
             self._w32_stamp = stamp
-        return ops.mlp_fwd32(coords.contiguous(), self.cfg, self._w32, self.params, width=self.width)[:n]
+        return ops.mlp_fwd32(coords.contiguous(), self.cfg, self._w32, self.params, out_act=self.out_act, width=self.width)[:n]
 
     def forward_train(self, coords_padded):
         """Forward with stashes; coords must already be padded to a multiple of 64 rows."""
         ws = self.workspace(coords_padded.shape[0])
-        ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["actT"], self.width)
+        ops.mlp_fwd(coords_padded, self.cfg, self.wf, self.params, ws["pred"], ws["actT"], self.width, out_act=self.out_act)
         return ws["pred"]
 
     def backward(self, Bp, patch=None):
@@ -194,9 +197,9 @@ class NPPNet:
         row0, n_p, k, P, comp): the patch rows' dL/dpred is formed inside the launch from the patch losses' image gradients."""
         ws = self._ws[Bp]
         if patch is not None:
-            ops.mlp_bwd_patch(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], *patch, width=self.width)
+            ops.mlp_bwd_patch(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], *patch, width=self.width, out_act=self.out_act)
         else:
-            ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], self.width)
+            ops.mlp_bwd(ws["dpred"], ws["pred"], self.K, self.wb, self.params, ws["actT"], ws["dzT"], self.width, out_act=self.out_act)
         ops.mlp_wgrad(ws["dzT"], ws["actT"], Bp, self.K, self.ksplit, ws["gslabs"], self.width)
 
     def pixel_loss(self, Bp, n_rows, gt, mask=None, weight=1.0):

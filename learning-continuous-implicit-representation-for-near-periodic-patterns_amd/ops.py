@@ -151,13 +151,17 @@ def train_workspace(K, Bp, ksplit, width=NPP_WIDTH):
     return [int(s) for s in sizes]
 
 
-def mlp_fwd(coords, cfg, wf, params, pred=None, actF=None, width=NPP_WIDTH):
+def mlp_fwd(coords, cfg, wf, params, pred=None, actF=None, width=NPP_WIDTH, out_act=1):
     """Fused embedder + MLP + sigmoid: coords (Bp,2) -> pred (Bp,3).  Replaces the table
-    gather + render() (train.py:166-189; helpers.py:41-62; networks.py:56-95)."""
+    gather + render() (train.py:166-189; helpers.py:41-62; networks.py:56-95).  out_act: 1 sigmoid, 2 tanh (--normalize_type 2), 0 raw."""
     _req(coords, torch.int32, "coords")
     bp = coords.shape[0]
     if pred is None:
         pred = torch.empty((bp, 3), dtype=torch.float32, device=coords.device)
+    if out_act != 1:
+        check(lib(width).npp_mlp_fwd_act(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(actF), int(out_act), _stream()),
+              "npp_mlp_fwd_act", width)
+        return pred
     check(lib(width).npp_mlp_fwd(_p(coords), bp, C.byref(cfg), width, _p(wf), _p(params), _p(pred), _p(actF), _stream()),
           "npp_mlp_fwd", width)
     return pred
@@ -198,14 +202,16 @@ def fourier_fwd(x, freqs, include_input=True):
     return out
 
 
-def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH):
+def mlp_bwd(dpred, pred, K, wb, params, actF, dzF, width=NPP_WIDTH, out_act=1):
     _req(dpred, torch.float32, "dpred")
     _req(pred, torch.float32, "pred", dpred.shape)
+    if out_act != 1:
+        return mlp_bwd_act(dpred, pred, K, wb, params, actF, dzF, out_act, width)
     check(lib(width).npp_mlp_bwd(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
                             _stream()), "npp_mlp_bwd", width)
 
 
-def mlp_bwd_patch(dpred, pred, K, wb, params, actF, dzF, dx_a, dx_b, fmask, rmask, row0, n_p, k, P, comp, width=NPP_WIDTH):
+def mlp_bwd_patch(dpred, pred, K, wb, params, actF, dzF, dx_a, dx_b, fmask, rmask, row0, n_p, k, P, comp, width=NPP_WIDTH, out_act=1):
     """mlp_bwd with the patch rows' dL/dpred formed in the launch (patch_compose_bwd folded in; rows [row0, row0 + n_p P^2) of
     dpred are written)."""
     from ._lib import PatchGrad
@@ -222,6 +228,10 @@ def mlp_bwd_patch(dpred, pred, K, wb, params, actF, dzF, dx_a, dx_b, fmask, rmas
         raise ValueError("fmask / rmask: expected (n_p,1,P,P) / (n_p k,1,P,P)")
     pg = PatchGrad(dx_a.data_ptr(), dx_b.data_ptr() if dx_b is not None else None, fmask.data_ptr(), rmask.data_ptr(), int(row0),
                    int(n_p), int(k), int(P), int(bool(comp)))
+    if out_act != 1:
+        check(lib(width).npp_mlp_bwd_patch_act(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
+                                               C.byref(pg), int(out_act), _stream()), "npp_mlp_bwd_patch_act", width)
+        return
     check(lib(width).npp_mlp_bwd_patch(_p(dpred), _p(pred), dpred.shape[0], K, width, _p(wb), _p(params), _p(actF), _p(dzF),
                                        C.byref(pg), _stream()), "npp_mlp_bwd_patch", width)
 

@@ -241,6 +241,37 @@ def test_fit_with_the_plain_lpips_head(dev):
     assert bool(torch.isfinite(a.net.params).all())
 
 
+def test_fused_chain_with_tanh_output(dev):
+    """render()'s other output nonlinearity (models/helpers.py:57-58, --normalize_type 2) in the fused launches: npp_mlp_fwd_act
+    (tanh / raw) and npp_mlp_bwd_act behind it.  The forward against its own raw output; the backward against the sigmoid path fed a
+    d pred that gives the same d raw -- every weight gradient must then agree."""
+    from npp_amd import ops
+    from npp_amd.model import NPPNet
+    H, K, rows = 128, 3, 1024
+    angles, periods, _ = oracle.synthetic_periodicity(H, K)
+    P = oracle.init_params(K, seed=5)
+    ns = NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=2, out_act=1)
+    nt = NPPNet(angles, periods, oracle.SEED0_FREQS, (H, H), params=P, device=dev, ksplit=2, out_act=2)
+    g = torch.Generator().manual_seed(2)
+    c = torch.randint(0, H, (rows, 2), generator=g, dtype=torch.int32).to(dev)
+    raw = ops.mlp_fwd(c, ns.cfg, ns.wf, ns.params, width=ns.width, out_act=0)
+    ns.zero_grad(); nt.zero_grad()
+    ns.forward_train(c); nt.forward_train(c)
+    ws, wt = ns.workspace(rows), nt.workspace(rows)
+    np.testing.assert_allclose(ws["pred"].cpu().numpy(), torch.sigmoid(raw).cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(wt["pred"].cpu().numpy(), torch.tanh(raw).cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(nt.render(c).cpu().numpy(), torch.tanh(raw).cpu().numpy(), atol=2e-6)
+    dp = torch.randn(rows, 3, generator=g).to(dev) * 1e-3
+    s_, t_ = ws["pred"], wt["pred"]
+    ws["dpred"].copy_(dp)
+    wt["dpred"].copy_(dp * (s_ * (1 - s_)) / (1 - t_ * t_).clamp_min(1e-6))
+    ns.backward(rows); nt.backward(rows)
+    torch.cuda.synchronize()
+    gs, gt_ = ns.grads(), nt.grads()
+    for name in gs:
+        assert rel_l2(gt_[name], gs[name]) < 1e-4, (name, rel_l2(gt_[name], gs[name]))
+
+
 def test_adam_golden(dev, golden):
     from npp_amd import ops
     g = golden("g9_adam.npz")
