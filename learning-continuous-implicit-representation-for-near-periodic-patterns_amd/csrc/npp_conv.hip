@@ -29,6 +29,7 @@
 // positions, and the 3 -> 16 channel padding of the first layer, are not counted).
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "npp_common.h"
 #include "npp_trunk_layout.h"
@@ -259,6 +260,11 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 // Round 3 built this with LDS-DMA and measured 2 x SLOWER (LDS-DMA lands ~16 GB/s per CU here); the register path was only argued
 // about.  Measured: see DESIGN.md section 7 / profiles/r04_conv_window_ab.txt.
 constexpr int kWinPos = 256;                       // positions per workgroup (8 position tiles: 2 per wave)
+#ifndef NPP_CONV_WIN_DEPTH
+#define NPP_CONV_WIN_DEPTH 1       // 2 measured: no change (profiles/r04_conv_window_ab.txt 4.)
+#endif
+constexpr int kWinDepth = NPP_CONV_WIN_DEPTH;      // register stages of the operand prefetch (1 or 2)
+static_assert(kWinDepth == 1 || kWinDepth == 2, "window prefetch depth");
 constexpr int kWinMaxUnits = 640;                  // window units per chunk the register staging is sized for: Wp <= 191
 template <int CT>
 constexpr int win_lds_bytes() { return 2 * (CT * 9 * 1024 + 2 * kWinMaxUnits * 16); }
@@ -306,23 +312,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
     offW[i] = ok ? (int)((((int64_t)chunk * a.nposp) + kConvGuard + (int64_t)tile0 * 32 - halo + pos) * 16) : -1;
     dstW[i] = kA + (chunk * kWinMaxUnits + pos) * 16;
   }
-  u32x4_t rAv[NA], rWv[NW];
-  auto gload = [&](int ci) {
+  // Register stages of the operand prefetch (NPP_CONV_WIN_DEPTH): with 2 the operands of step ci + 2 are requested while step ci is
+  // multiplied.  Built on the hypothesis that a step lasts as long as its loads (the input was just written by the previous layer from
+  // other XCDs); measured in the iteration, same box: trunk forward 132.1 us with one stage, 132.2 with two -- not the bound.
+  struct Stage { u32x4_t a[NA], w[NW]; };
+  Stage st[kWinDepth];
+  auto gload = [&](int ci, Stage& r) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (offA[i] >= 0 || NA * 256 == CT * 576) rAv[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, offA[i] < 0 ? 0 : offA[i], ci * 9 * 1024, 0);
+      if (offA[i] >= 0 || NA * 256 == CT * 576) r.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, offA[i] < 0 ? 0 : offA[i], ci * 9 * 1024, 0);
     const uint32_t soff = (uint32_t)((int64_t)2 * ci * a.nposp * 16);
 #pragma unroll
-    for (int i = 0; i < NW; ++i) rWv[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, offW[i] < 0 ? 0 : offW[i], (int)soff, 0);
+    for (int i = 0; i < NW; ++i) r.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, offW[i] < 0 ? 0 : offW[i], (int)soff, 0);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const Stage& r) {
     char* base = wlds + buf * kBuf;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (offA[i] >= 0) *(u32x4_t*)(base + (tid + 256 * i) * 16) = rAv[i];
+      if (offA[i] >= 0) *(u32x4_t*)(base + (tid + 256 * i) * 16) = r.a[i];
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-      if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = rWv[i];
+      if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = r.w[i];
   };
   f32x16 acc[CT][2];
 #pragma unroll
@@ -352,14 +362,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
       }
     }
   }
-  gload(0);
-  sstore(0);
+  gload(0, st[0]);
+  if (kWinDepth > 1 && a.CI > 1) gload(1, st[kWinDepth - 1]);
+  sstore(0, st[0]);
   __syncthreads();
   int buf = 0;
   const int posw = (kWinPos / 4) * wave + b;                        // this lane's first position inside the workgroup's 256
-  for (int ci = 0; ci < a.CI; ++ci) {
+  // one step; PAR = ci % kWinDepth at compile time (the stage of an in-flight load must be a compile-time name)
+  auto step = [&](int ci, auto par_) {
+    constexpr int PAR = decltype(par_)::value, NXT = (PAR + 1) % kWinDepth;
     const bool has_next = ci + 1 < a.CI;
-    if (has_next) gload(ci + 1);
+    if (kWinDepth == 1) { if (has_next) gload(ci + 1, st[0]); }
+    else if (ci + 2 < a.CI) gload(ci + 2, st[PAR]);                 // stage PAR went to LDS before this step began
     const char* bA = wlds + buf * kBuf;
     const char* bW = bA + kA + h * kWinMaxUnits * 16;
 #pragma unroll
@@ -375,9 +389,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = mfma16(A[ct], B[pt], acc[ct][pt]);
     }
-    if (has_next) sstore(buf ^ 1);
+    if (has_next) sstore(buf ^ 1, st[NXT]);
     __syncthreads();
     buf ^= 1;
+  };
+  for (int ci = 0; ci < a.CI; ci += kWinDepth) {
+    step(ci, std::integral_constant<int, 0>{});
+    if (kWinDepth > 1 && ci + 1 < a.CI) step(ci + 1, std::integral_constant<int, kWinDepth - 1>{});
   }
   // ---- epilogue: the same per-tile finish as conv3x3_kernel
 #pragma unroll
