@@ -420,6 +420,8 @@ class _QuadLossFunction(torch.autograd.Function):
 def img2mse(x, y, loss_type, adaptive, mask=None):
     """models/mse_calculator.py:13-27: 'robust_loss_adaptive' (the reference's setting, train.py:195), 'l2', 'robust_loss'."""
     if loss_type != "robust_loss_adaptive":
+        if loss_type not in ops.QUAD_COEF:
+            raise NotImplementedError(f"loss_type {loss_type!r}: 'robust_loss_adaptive', 'l2' or 'robust_loss' (models/mse_calculator.py:19-23)")
         return _QuadLossFunction.apply(x, y, mask, ops.quad_coef(loss_type))
     return _PixelLossFunction.apply(x, y, mask, adaptive.latent_alpha, adaptive.latent_scale, adaptive)
 

@@ -71,7 +71,7 @@ def test_unsupported_configurations_fail_loudly():
         api.get_embedder(10, 0, (64, 64), selected_angles=[1.0, 2.0], selected_periods=[5.0, 6.0], freq_scales=[1, 2],
                          freq_offsets=[0, -1, 1, 0.5, -0.5], angle_offsets=[0])
     with pytest.raises(NotImplementedError):
-        api.img2mse(None, None, "l2", None)
+        api.img2mse(None, None, "mse", None)            # ('l2' and 'robust_loss' are built since round 4: mse_calculator.py:19-23)
 
 
 # ---- numbers (GPU) ------------------------------------------------------------------------------
