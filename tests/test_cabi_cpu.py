@@ -92,6 +92,48 @@ def test_light_chain_entry_points_validate_on_the_host():
     assert L.npp_linear_bwd_weight_strided(fake, 0, 1, 0, fake, 1, 1, 0, 0, 1, 64, 4, 4, fake, 4, 0, None, 0, None) < 0
 
 
+def test_light16_entry_points_validate_on_the_host():
+    """The 16-bit candidate chains (csrc/npp_light16.hip): size queries against the documented layout, and the argument checks that come
+    before any launch -- batch a multiple of 64, strides that hold one candidate's arrays, at most NPP_MAX_STACK candidates in the
+    weight-gradient launch, leading dimensions a multiple of 4 there, the plain LPIPS head without a latent gradient."""
+    from npp_amd._lib import LightDesc
+    L = npp_amd.lib()
+    fwd_units = 2 * 8 * 64 + 4 * 16 * 8 * 64 + 20 * 4 * 64          # [k-steps][neuron tiles][64 lanes] per layer: x_per, 4 x 256 wide, pos
+    bwd_units = 8 * 8 * 64 + 4 * 16 * 8 * 64                          # transposed: pos (128 neurons), feature1 + three periodic layers
+    assert L.npp_light16_pack_bytes() == 16 * (fwd_units + bwd_units)
+    assert L.npp_light16_stash_bytes(2048, 0) == 94 * (2048 // 64) * 2048      # z_0..z_3 (64 k-steps) + [f1 | x_pos] (20) + z_p (8) + x_per (2)
+    assert L.npp_light16_stash_bytes(2048, 1) == 90 * (2048 // 64) * 2048      # dz_0..dz_3 (64) + d f1 (16) + d z_p (8) + d raw (2)
+    assert L.npp_light16_stash_bytes(100, 0) < 0 and L.npp_light16_stash_bytes(64, 2) < 0
+    d = LightDesc()
+    n_out, n_in = [256, 256, 256, 256, 128, 256, 3], [20, 256, 256, 256, 298, 256, 128]
+    off = 0
+    for i in range(7):
+        d.n_out[i], d.n_in[i], d.ld[i] = n_out[i], n_in[i], (n_in[i] + 3) // 4 * 4
+        d.w_off[i] = off
+        off += n_out[i] * d.ld[i]
+        d.b_off[i] = off
+        off += n_out[i]
+    n_pad = (off + 3) // 4 * 4
+    fake = C.c_void_p(64)
+    pb, ab, db = L.npp_light16_pack_bytes(), L.npp_light16_stash_bytes(64, 0), L.npp_light16_stash_bytes(64, 1)
+    assert L.npp_light16_fwd(C.byref(d), fake, 0, fake, pb, fake, fake, None, 96, 1, 96, fake, ab, fake, None) < 0           # B = 96
+    assert b"multiple of 64" in L.npp_last_error_string()
+    assert L.npp_light16_fwd(C.byref(d), fake, 0, fake, pb, fake, fake, None, 64, 1, 64, fake, ab - 16, fake, None) < 0      # stash stride too small
+    assert L.npp_light16_bwd(C.byref(d), fake, 0, fake, pb, fake, ab, fake, None, None, None, None, 0, 0.0, None, None, 1, 64, fake, db, None) < 0
+    assert b"d_dpred" in L.npp_last_error_string()
+    assert L.npp_light16_wgrad(C.byref(d), fake, ab, fake, db, 17, 64, 1, fake, n_pad, n_pad, None) < 0                     # 17 candidates
+    assert b"<= 16" in L.npp_last_error_string()
+    d.ld[4] = 298                                                                                                           # pos_linears.0 stored 298 wide
+    assert L.npp_light16_wgrad(C.byref(d), fake, ab, fake, db, 2, 64, 1, fake, n_pad, n_pad, None) < 0
+    d.ld[4] = 300
+    assert L.npp_light16_adam_pack(C.byref(d), fake, fake, fake, n_pad, off, 1, fake, 0, n_pad, n_pad, fake, pb, fake, fake, fake, fake, None,
+                                   5e-4, 0.9, 0.999, 1e-8, 1, None) < 0                                                   # no slabs
+    assert L.npp_pixel_loss_quad(fake, fake, 0, None, 64, 1, 0.0, 1.0, fake, fake, None) < 0                                # coef must be > 0
+    assert L.npp_lpips_layer(fake, fake, 1, 64, 16, fake, None, None, 0, 0.0, 1.0, fake, fake, fake, None, None) < 0        # plain head: no dlatent
+    assert b"plain head" in L.npp_last_error_string()
+    assert L.npp_mlp_fwd_act(fake, 64, None, 256, fake, fake, fake, None, 1, None) < 0                                     # null embedder config
+
+
 # ---- NumPy model of the MFMA fragment maps (cdna_hip_programming.md section 3) ----
 def perm16(h, j):
     return 8 * (j >> 2) + 4 * h + (j & 3)
