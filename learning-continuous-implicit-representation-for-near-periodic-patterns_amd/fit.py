@@ -135,11 +135,45 @@ class CompletionFit:
                 self.style = StyleLoss(vgg_state_dict=vgg16_style_state_dict, device=self.device)
                 self.style_w = 1.0 if style_weight is None else float(style_weight)        # arg_config.py: style_weight 1
             self.last_source, self.skipped = None, 0
-            self._xy, self._xy_key = None, None
+            self._xy, self._xy_key, self._xy_bufs = None, None, {}
+            # the LPIPS branch of a 'same' iteration as ONE captured HIP graph (lpips_branch): NPP_LP_GRAPH=0 keeps the 46 launches
+            self._lp_graphs, self.lp_graph = {}, os.environ.get("NPP_LP_GRAPH", "1") != "0"
             self._s_lp = torch.cuda.Stream(self.device)
             self._s_pix = torch.cuda.Stream(self.device)
             self._s_y = torch.cuda.Stream(self.device)
             self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def lpips_branch(self, xy, nk, scale, loss_buf):
+        """percepLoss.fused(xy, nk, scale, loss_buf) on the CURRENT stream (the loop's side stream).  The branch is 46 launches at the
+        latency floor -- VGG16 on four 96 x 96 patches, 5 heads, the data-gradient pass -- and its 0.39 ms of host enqueue time made the
+        'same' iterations host-bound (0.71 ms of enqueue against 0.60 ms of device time for the other sources).  From its third use on a
+        given set of buffers it is therefore replayed as ONE captured HIP graph (torch.cuda.CUDAGraph over the same launches: arguments
+        and buffers are fixed -- xy / loss_buf / latents are persistent tensors, scale and n_p k part of the key)."""
+        lp = self.percepLoss
+        key = (xy.data_ptr(), loss_buf.data_ptr(), int(nk), float(scale), self.lp_robust)
+        ent = self._lp_graphs.get(key) if self.lp_graph else None
+        if ent is not None and ent[0] is not None:
+            ent[0].replay()
+            lp.touched = lp.touched or self.lp_robust
+            return ent[1]
+        out = lp.fused(xy, nk, scale, loss_buf, normalize=True, use_robust=self.lp_robust)
+        if not self.lp_graph or lp.trunk_kind != "hip":
+            return out
+        uses = 1 if ent is None else ent[2] + 1
+        self._lp_graphs[key] = (None, None, uses)
+        if uses == 2:                                           # two eager passes have warmed every buffer / workspace: capture for the next use
+            s = torch.cuda.current_stream(self.device)
+            g = torch.cuda.CUDAGraph()
+            try:                                                # (a capture only RECORDS the launches: nothing runs, no state changes)
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                    gout = lp.fused(xy, nk, scale, loss_buf, normalize=True, use_robust=self.lp_robust)
+            except Exception as e:                             # a runtime that cannot capture: stay eager, say so once
+                import warnings
+                warnings.warn(f"npp_amd.fit: LPIPS branch not captured as a HIP graph ({e}); keeping the launch-by-launch form")
+                self.lp_graph = False
+                return out
+            self._lp_graphs[key] = (g, gout, uses)
+        return out
 
     # ---- sampling (train.py:172-181) -------------------------------------------------
     def draw_pixels(self):
@@ -322,9 +356,13 @@ class CompletionFit:
         comp = self.use_comp and source == "val"                 # train.py:230-231
         nk = n_p * k
         key = (nk, P)
-        if self._xy is None or self._xy_key != key:
-            self._xy = torch.empty((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
-            self._xy_key = key
+        if self._xy_key != key:                                   # one fp32 batch buffer per (n_p k, P): fixed addresses (see lpips_branch)
+            if key not in self._xy_bufs:
+                if len(self._xy_bufs) >= 8:                       # (the patch size changes every patch_size_decay iterations)
+                    self._xy_bufs.clear()
+                    self._lp_graphs.clear()
+                self._xy_bufs[key] = torch.empty((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
+            self._xy, self._xy_key = self._xy_bufs[key], key
         with_lp = source == "same" and self.use_perceptual_loss
         cx = self.contextualLoss
         xy = self._xy if (with_lp or self.style is not None) else None      # fp32 batch only when another trunk reads it
@@ -399,8 +437,7 @@ class CompletionFit:
         if with_lp:                                                                                 # train.py:241-250
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
-                dx_b = self.percepLoss.fused(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf, normalize=True,
-                                            use_robust=self.lp_robust)
+                dx_b = self.lpips_branch(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
         if fy is not None:
             dx_a = cx.fused_x((nk, 3, P, P), fy, self.cx_w, self.patch_loss_buf, weight=weight)

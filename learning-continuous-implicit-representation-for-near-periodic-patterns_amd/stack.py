@@ -230,7 +230,7 @@ class StackedFit:
                 for i in with_lp:
                     nk = it[i].nk
                     f = fits[i]
-                    dxb = f.percepLoss.fused(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1], normalize=True, use_robust=f.lp_robust)
+                    dxb = f.lpips_branch(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1])     # (a captured graph from its third use on)
                     self.dxb[i, :nk].copy_(dxb[:nk])
         shape = (self.N_total, 3, self.P, self.P)
         feats = t._forward(shape, sc, sh, True, n_run=2 * X)[0]

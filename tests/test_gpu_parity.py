@@ -241,6 +241,43 @@ def test_fit_with_the_plain_lpips_head(dev):
     assert bool(torch.isfinite(a.net.params).all())
 
 
+def test_lpips_branch_as_a_captured_graph_equals_its_launches(dev):
+    """CompletionFit.lpips_branch: from its third use on a set of buffers the LPIPS branch of a 'same' iteration (46 launches) is replayed
+    as one captured HIP graph -- the same launches with the same arguments: parameters, LPIPS latents and the patch loss must come out
+    bit for bit as from the launch-by-launch form."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 1
+    img, mask = oracle.synthetic_image(H, seed=4)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make(graph):
+        f = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=3), device=dev, N_rand=2048, shifts=shifts,
+                          seed=9, perceptual_weight=1e-2)
+        f.lp_graph = graph
+        return f
+    a, b = make(True), make(False)
+    same, losses = 0, []
+    for it in range(60):
+        ba = None
+        while ba is None:
+            ba = a.sample_batch()
+            bb = b.sample_batch()
+        a.step_from(ba)
+        b.step_from(bb)
+        if ba["source"] == "same":
+            same += 1
+            losses.append((float(a.last_patch_loss[0]), float(b.last_patch_loss[0])))
+    torch.cuda.synchronize()
+    replays = [e for e in a._lp_graphs.values() if e[0] is not None]
+    print(f"{same} 'same' iterations, {len(replays)} captured graph(s)")
+    assert same >= 5 and len(replays) >= 1 and not b._lp_graphs
+    # (the reported loss WORD is the sum of the two branches' terms in arrival order -- two streams add to it -- so it may differ in
+    # its last bit between any two runs; what is trained on, the gradients, is order-independent)
+    assert all(abs(x - y) <= 2e-7 * abs(y) for x, y in losses), losses
+    assert torch.equal(a.net.params, b.net.params)
+    assert torch.equal(a.percepLoss._lat, b.percepLoss._lat) and a.percepLoss.lat_step == b.percepLoss.lat_step == same
+
+
 def test_fused_chain_with_tanh_output(dev):
     """render()'s other output nonlinearity (models/helpers.py:57-58, --normalize_type 2) in the fused launches: npp_mlp_fwd_act
     (tanh / raw) and npp_mlp_bwd_act behind it.  The forward against its own raw output; the backward against the sigmoid path fed a
