@@ -294,6 +294,14 @@ int npp_cx_fwd_bwd(const float* d_fx, const float* d_fy, int N, int C, int hw, f
  * d_latents == NULL: the PLAIN head, LPIPS.forward(use_robust=False) (lpips.py:108-109: diffs = (feats0 - feats1)^2) -- the in-loop
  * form under --use_adaptive_perceptual_loss off (train.py:241-251) -- with its gradient d_df0 (d_spline, d_dlatent NULL). */
 int64_t npp_lpips_workspace_bytes(int C);
+/* All taps of LPIPS.forward in ONE launch (lpips.py:99-133: the heads are independent, `val` is their sum): taps[i] = the per-tap
+ * arguments of npp_lpips_layer (host array, n_taps <= 5); a tap's workspace must not be shared with another tap of the call. */
+typedef struct {
+  const float* f0; const float* f1; int32_t C, hw; const float* lin; const float* latents;
+  float* df0; float* dlatent; void* workspace;
+} npp_lpips_tap;
+int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, const float* d_spline, int n_knots, float x_scale, float scale,
+                     float* d_loss, void* stream);
 int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw,
                     const float* d_lin, const float* d_latents, const float* d_spline,
                     int n_knots, float x_scale, float scale, float* d_loss, float* d_df0,

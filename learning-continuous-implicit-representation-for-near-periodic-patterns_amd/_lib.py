@@ -23,6 +23,12 @@ class PixelLossArgs(C.Structure):
                 ("dpred", C.c_void_p), ("dlatent", C.c_void_p), ("scratch", C.c_void_p), ("quad", C.c_float)]
 
 
+class LpipsTap(C.Structure):
+    """npp_lpips_tap (include/npp_hip.h): the per-tap arguments of npp_lpips_layers."""
+    _fields_ = [("f0", C.c_void_p), ("f1", C.c_void_p), ("C", C.c_int32), ("hw", C.c_int32), ("lin", C.c_void_p), ("latents", C.c_void_p),
+                ("df0", C.c_void_p), ("dlatent", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class PatchGrad(C.Structure):
     """npp_patch_grad (include/npp_hip.h)."""
     _fields_ = [("dx_a", C.c_void_p), ("dx_b", C.c_void_p), ("fmask", C.c_void_p), ("rmask", C.c_void_p),
@@ -157,6 +163,7 @@ SYMBOLS = {
     "npp_light_fwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "npp_light_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
     "npp_light_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "npp_lpips_layers": (_i32, [_i32, C.POINTER(LpipsTap), _i32, _vp, _i32, _f32, _f32, _vp, _vp]),
     "npp_pixel_loss_quad": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
     "npp_light16_pack_bytes": (_i64, []),
     "npp_light16_stash_bytes": (_i64, [_i64, _i32]),

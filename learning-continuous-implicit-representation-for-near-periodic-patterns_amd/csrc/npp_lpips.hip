@@ -32,19 +32,39 @@ constexpr int kLpipsMaxC = 512;
 struct LpChan {
   float e, inv_c, inv_c2, x2_inv_c3, inv_beta, boa, toa2, e_inv_b2, logc_plus_logz, dlogz, dalpha_dl, dc_dl;
 };
+struct LpTap {
+  const float* f0; const float* f1; const float* lin; const float* latents;
+  float* df0; float* dlatent; unsigned long long* fix;
+  int32_t hw, C, few, nb;            // few: the 4-position block shape; nb: blocks of this tap (blockIdx.x >= nb exit)
+  float coef;
+};
+constexpr int kLpMaxTaps = 5;
+struct LpMulti {
+  LpTap t[kLpMaxTaps];
+  const float* spline; float* loss;
+  int32_t n_taps, N, n_knots; float x_scale;
+};
+// LDS of one tap's block (dynamic: the taps of a grouped launch differ): red[3][CL][PL + 1] | tot[4] | sdl[2 C] | slin[C] | scp[C]
+constexpr int lp_smem_bytes(int C, int PL) { return (3 * (256 / PL) * (PL + 1) + 4 + 3 * C) * 4 + C * (int)sizeof(LpChan); }
+
 template <int Q, int PL>
-__global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
-                                                          int N, int hw, const float* __restrict__ lin,
-                                                          const float* __restrict__ latents,
-                                                          const float* __restrict__ spline, int n_knots, float x_scale,
-                                                          float coef, float* __restrict__ loss, float* __restrict__ df0,
-                                                          float* __restrict__ dlatent, unsigned long long* __restrict__ fix) {
+__device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const float* __restrict__ spline, int n_knots, float x_scale,
+                                                 float* __restrict__ loss, char* smem, int bid, int nb) {
   constexpr int CL = 256 / PL, C = CL * Q;
-  __shared__ float red[3][CL][PL + 1];
-  __shared__ float tot[4];
-  __shared__ float sdl[2 * C];
-  __shared__ LpChan scp[C];
-  __shared__ float slin[C];
+  const float* __restrict__ f0 = T.f0;
+  const float* __restrict__ f1 = T.f1;
+  const float* __restrict__ lin = T.lin;
+  const float* __restrict__ latents = T.latents;
+  float* __restrict__ df0 = T.df0;
+  float* __restrict__ dlatent = T.dlatent;
+  unsigned long long* __restrict__ fix = T.fix;
+  const int hw = T.hw;
+  const float coef = T.coef;
+  float (*red)[CL][PL + 1] = (float (*)[CL][PL + 1])smem;
+  float* tot = (float*)smem + 3 * CL * (PL + 1);
+  float* sdl = tot + 4;
+  float* slin = sdl + 2 * C;
+  LpChan* scp = (LpChan*)(slin + C);
   const int pl = threadIdx.x % PL, cl = threadIdx.x / PL;
   // latents == nullptr: LPIPS.forward(use_robust=False) (lpips.py:108-109: diffs = (feats0 - feats1)^2) with its gradient -- the
   // non-adaptive in-loop form (--use_adaptive_perceptual_loss off, train.py:241-251); no latents, no latent gradient
@@ -70,7 +90,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
   const int64_t npos = (int64_t)N * hw;
   const int64_t ngroups = (npos + PL - 1) / PL;
   float val = 0.0f;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int64_t grp = bid; grp < ngroups; grp += nb) {
     const int64_t t = grp * PL + pl;
     const bool live = t < npos;
     const int n = live ? (int)(t / hw) : 0, p = live ? (int)(t - (int64_t)n * hw) : 0;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
     if (df0 && !plain)
       for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i]));
     if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3])));
-    if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), (int)gridDim.x)) return;
+    if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), nb)) return;
     for (int i = threadIdx.x; i <= 2 * C; i += 256) {
       const long long s = (long long)__hip_atomic_exchange(fix + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float v = (float)((double)s * (1.0 / 1099511627776.0));
@@ -179,6 +199,42 @@ __global__ __launch_bounds__(256) void lpips_layer_kernel(const float* __restric
   if (threadIdx.x == 0) atomicAdd(loss, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
 
+// One launch for up to five taps (blockIdx.y = tap): the heads of LPIPS.forward are independent of each other, and in a row they were
+// 100 us (15-25 us each) of the 'same' iteration's longer chain.
+__global__ __launch_bounds__(256) void lpips_multi_kernel(LpMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char lp_smem[];
+  const int y = blockIdx.y;
+  LpTap T = m.t[0];
+#pragma unroll
+  for (int q = 1; q < kLpMaxTaps; ++q)
+    if (q == y) T = m.t[q];
+  const int bid = blockIdx.x;
+  if (bid >= T.nb) return;                                 // (whole block: no barrier is skipped)
+#define NPP_LP_CASE(Q, PL) lpips_layer_body<Q, PL>(T, m.N, m.spline, m.n_knots, m.x_scale, m.loss, lp_smem, bid, T.nb)
+  if (T.few) {
+    switch (T.C) {
+      case 64: NPP_LP_CASE(1, 4); break;
+      case 128: NPP_LP_CASE(2, 4); break;
+      case 192: NPP_LP_CASE(3, 4); break;
+      case 256: NPP_LP_CASE(4, 4); break;
+      case 384: NPP_LP_CASE(6, 4); break;
+      default: NPP_LP_CASE(8, 4); break;
+    }
+  } else {
+    switch (T.C) {
+      case 16: NPP_LP_CASE(1, 16); break;
+      case 32: NPP_LP_CASE(2, 16); break;
+      case 64: NPP_LP_CASE(4, 16); break;
+      case 128: NPP_LP_CASE(8, 16); break;
+      case 192: NPP_LP_CASE(12, 16); break;
+      case 256: NPP_LP_CASE(16, 16); break;
+      case 384: NPP_LP_CASE(24, 16); break;
+      default: NPP_LP_CASE(32, 16); break;
+    }
+  }
+#undef NPP_LP_CASE
+}
+
 }  // namespace npp
 
 using namespace npp;
@@ -186,55 +242,65 @@ using namespace npp;
 // 2 C + 1 fixed-point accumulators + the ticket counter (8 bytes each); zeroed once by the caller, owned by one stream
 extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)(2 * C + 2) * 8; }
 
-extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
-                               const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
-                               float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
-  if (!d_f0 || !d_f1 || !d_lin || !d_loss || N < 1 || C < 16 || (C % 16) || C > kLpipsMaxC || hw < 1 ||
-      (d_latents && (!d_spline || n_knots < 2))) {
-    set_error("npp_lpips_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
+static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int hw, const float* lin, const float* latents, float scale,
+                   float* df0, float* dlatent, void* ws, const char* who) {
+  if (!f0 || !f1 || !lin || N < 1 || hw < 1 || C < 16 || C > kLpipsMaxC ||
+      !(C == 16 || C == 32 || C == 64 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512)) {
+    set_error("%s: bad arguments (N=%d C=%d hw=%d; C one of 16, 32, 64, 128, 192, 256, 384, 512)", who, N, C, hw);
     return NPP_ERR_ARG;
   }
-  // d_latents == NULL: the plain head (use_robust=False), with its gradient when d_df0 is given
-  if (d_latents ? (d_df0 == nullptr) != (d_dlatent == nullptr) : d_dlatent != nullptr) {
-    set_error("npp_lpips_layer: df0 and dlatent go together (no dlatent for the plain head)");
+  // latents == NULL: the plain head (use_robust=False), with its gradient when df0 is given
+  if (latents ? (df0 == nullptr) != (dlatent == nullptr) : dlatent != nullptr) {
+    set_error("%s: df0 and dlatent go together (no dlatent for the plain head)", who);
     return NPP_ERR_ARG;
   }
-  unsigned long long* fix = (unsigned long long*)d_workspace;    // nullable: float atomics in arrival order instead
-  hipStream_t s = (hipStream_t)stream;
   const int64_t nh = (int64_t)N * hw;
-  const float coef = scale / (float)nh;     // spatial mean and batch mean folded with the caller's weight
   const bool few = nh <= 1024 && (C % 64) == 0;           // deep taps: 4 positions x 64 channel lanes per block
   const int PLr = few ? 4 : 16;
   const int64_t groups = (nh + PLr - 1) / PLr;
-  const dim3 grid((unsigned)(groups < 256 ? groups : 256));
-#define NPP_LPIPS_LAUNCH(Q, PL)                                                                                      \
-  hipLaunchKernelGGL((lpips_layer_kernel<Q, PL>), grid, dim3(256), 0, s, d_f0, d_f1, N, hw, d_lin, d_latents,       \
-                     d_spline, n_knots, x_scale, coef, d_loss, d_df0, d_dlatent, fix)
-  if (few) {
-    switch (C) {
-      case 64: NPP_LPIPS_LAUNCH(1, 4); break;
-      case 128: NPP_LPIPS_LAUNCH(2, 4); break;
-      case 192: NPP_LPIPS_LAUNCH(3, 4); break;
-      case 256: NPP_LPIPS_LAUNCH(4, 4); break;
-      case 384: NPP_LPIPS_LAUNCH(6, 4); break;
-      case 512: NPP_LPIPS_LAUNCH(8, 4); break;
-      default: set_error("npp_lpips_layer: C=%d not instantiated", C); return NPP_ERR_UNSUPPORTED;
-    }
-  } else {
-    switch (C) {
-      case 16: NPP_LPIPS_LAUNCH(1, 16); break;
-      case 32: NPP_LPIPS_LAUNCH(2, 16); break;
-      case 64: NPP_LPIPS_LAUNCH(4, 16); break;
-      case 128: NPP_LPIPS_LAUNCH(8, 16); break;
-      case 192: NPP_LPIPS_LAUNCH(12, 16); break;
-      case 256: NPP_LPIPS_LAUNCH(16, 16); break;
-      case 384: NPP_LPIPS_LAUNCH(24, 16); break;
-      case 512: NPP_LPIPS_LAUNCH(32, 16); break;
-      default:
-        set_error("npp_lpips_layer: C=%d not instantiated (16, 32, 64, 128, 192, 256, 384, 512)", C);
-        return NPP_ERR_UNSUPPORTED;
-    }
+  T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
+  T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)(groups < 256 ? groups : 256);
+  T.coef = scale / (float)nh;                             // spatial mean and batch mean folded with the caller's weight
+  return NPP_OK;
+}
+static int lp_launch(LpMulti& m, void* stream, const char* who) {
+  int nb = 0, smem = 0;
+  for (int i = 0; i < m.n_taps; ++i) {
+    nb = m.t[i].nb > nb ? m.t[i].nb : nb;
+    const int b = lp_smem_bytes(m.t[i].C, m.t[i].few ? 4 : 16);
+    smem = b > smem ? b : smem;
   }
-#undef NPP_LPIPS_LAUNCH
-  return check_launch("npp_lpips_layer");
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)lpips_multi_kernel, lp_smem_bytes(kLpipsMaxC, 4))) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(lpips_multi_kernel, dim3((unsigned)nb, (unsigned)m.n_taps), dim3(256), (size_t)smem, (hipStream_t)stream, m);
+  return check_launch(who);
+}
+
+extern "C" int npp_lpips_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
+                               const float* d_latents, const float* d_spline, int n_knots, float x_scale, float scale,
+                               float* d_loss, float* d_df0, float* d_dlatent, void* d_workspace, void* stream) {
+  if (!d_loss || (d_latents && (!d_spline || n_knots < 2))) { set_error("npp_lpips_layer: bad arguments (loss / spline)"); return NPP_ERR_ARG; }
+  LpMulti m{};
+  int rc = lp_fill(m.t[0], d_f0, d_f1, N, C, hw, d_lin, d_latents, scale, d_df0, d_dlatent, d_workspace, "npp_lpips_layer");
+  if (rc) return rc;
+  m.spline = d_spline; m.loss = d_loss; m.n_taps = 1; m.N = N; m.n_knots = n_knots; m.x_scale = x_scale;
+  return lp_launch(m, stream, "npp_lpips_layer");
+}
+
+// All taps of LPIPS.forward in ONE launch (lpips.py:99-133: the five heads are independent; `val` is their sum): taps[i] as the
+// arguments of npp_lpips_layer for tap i; every tap needs a workspace of its OWN when workspaces are used (they run side by side).
+extern "C" int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, const float* d_spline, int n_knots, float x_scale, float scale,
+                                float* d_loss, void* stream) {
+  if (n_taps < 1 || n_taps > kLpMaxTaps || !taps || !d_loss) { set_error("npp_lpips_layers: n_taps=%d (1..%d)", n_taps, kLpMaxTaps); return NPP_ERR_ARG; }
+  LpMulti m{};
+  for (int i = 0; i < n_taps; ++i) {
+    const npp_lpips_tap& t = taps[i];
+    if (t.latents && (!d_spline || n_knots < 2)) { set_error("npp_lpips_layers: spline"); return NPP_ERR_ARG; }
+    for (int j = 0; j < i; ++j)
+      if (t.workspace && t.workspace == taps[j].workspace) { set_error("npp_lpips_layers: taps %d and %d share a workspace", j, i); return NPP_ERR_ARG; }
+    int rc = lp_fill(m.t[i], t.f0, t.f1, N, t.C, t.hw, t.lin, t.latents, scale, t.df0, t.dlatent, t.workspace, "npp_lpips_layers");
+    if (rc) return rc;
+  }
+  m.spline = d_spline; m.loss = d_loss; m.n_taps = n_taps; m.N = N; m.n_knots = n_knots; m.x_scale = x_scale;
+  return lp_launch(m, stream, "npp_lpips_layers");
 }

@@ -443,6 +443,7 @@ class LPIPS(nn.Module):
             [torch.cat([torch.full((c,), 2.3841858e-07), torch.zeros(c)]) for c in self.chns], dev)
         self.lat_step = 0
         self.touched = False
+        self.grouped_heads = os.environ.get("NPP_LP_GROUPED_HEADS", "1") != "0"
         self.spline, self.n_knots, self.x_scale = ops.load_spline(dev)
         self.to(dev)
 
@@ -484,8 +485,13 @@ class LPIPS(nn.Module):
         # (Measured and dropped, round 4: the five heads -- 15-25 us each, 100 us in a row behind the trunk -- on a helper stream beside
         # the deeper layers of the forward pass: the 'same' iteration went 0.791 -> 0.811 ms; the branch is not what the device waits for.)
         feats = t._forward(xy, sc, sh)
-        for kk, f in enumerate(feats):
-            head(kk, f)
+        if self.grouped_heads:                                  # the five heads in ONE launch (they are independent: 100 us in a row before)
+            dfs = [torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device) for f in feats]
+            ops.lpips_layers([f[:n] for f in feats], [f[n:] for f in feats], self.lins, self.latents if use_robust else None, self.spline,
+                             self.n_knots, self.x_scale, scale, loss_buf, dfs, self.dlatents)
+        else:
+            for kk, f in enumerate(feats):
+                head(kk, f)
         self.touched = self.touched or bool(use_robust)        # (the plain head gives the latents no gradient: Adam skips them)
         return t._backward(dfs, n, sc, tuple(xy.shape), zero_rest=False)
 

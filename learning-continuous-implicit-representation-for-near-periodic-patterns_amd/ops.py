@@ -427,6 +427,32 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
                                 _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")
 
 
+def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss, df0s=None, dlatents=None):
+    """All taps of LPIPS.forward in ONE launch (the heads are independent of each other): lists per tap of the arguments of lpips_layer
+    (latents None: the plain head for every tap)."""
+    from ._lib import LpipsTap
+    n = len(f0s)
+    N = f0s[0].shape[0]
+    arr = (LpipsTap * n)()
+    st = _stream()
+    for i in range(n):
+        f0, f1 = f0s[i], f1s[i]
+        _req(f0, torch.float32, "f0")
+        _req(f1, torch.float32, "f1", f0.shape)
+        Cc = f0.shape[1]
+        ws = None
+        if DETERMINISTIC:
+            key = (f0.device, Cc, st.value, i)             # one workspace per (stream, tap): the taps of the launch run side by side
+            ws = _lp_ws.get(key)
+            if ws is None:
+                ws = _lp_ws[key] = torch.zeros(int(lib().npp_lpips_workspace_bytes(Cc)), dtype=torch.uint8, device=f0.device)
+        arr[i] = LpipsTap(f0.data_ptr(), f1.data_ptr(), Cc, f0.shape[2] * f0.shape[3], lins[i].data_ptr(),
+                          None if latents is None else latents[i].data_ptr(), None if df0s is None else df0s[i].data_ptr(),
+                          None if (dlatents is None or latents is None) else dlatents[i].data_ptr(), None if ws is None else ws.data_ptr())
+    check(lib().npp_lpips_layers(n, arr, N, None if latents is None else _p(spline), n_knots if latents is not None else 0,
+                                 x_scale if latents is not None else 0.0, scale, _p(loss), st), "npp_lpips_layers")
+
+
 def adam_step_dev(p, m, v, gslabs, n_slabs, slab_stride, hp, b1=0.9, b2=0.999, eps=1e-8):
     """Adam step whose step_size / bias correction come from the device tensor hp[0:2]
     (graph-replayable form of adam_step)."""

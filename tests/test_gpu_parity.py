@@ -209,6 +209,35 @@ def test_lpips_plain_head_with_gradient(dev, C, hw):
     assert fwd_only.item() == loss.item() or abs(fwd_only.item() - loss.item()) < 1e-6 * abs(loss.item())
 
 
+def test_lpips_heads_in_one_launch_equal_the_five_launches(dev):
+    """npp_lpips_layers (blockIdx.y = tap) against five npp_lpips_layer calls on VGG16-shaped taps: loss word (the fixed-point sums are
+    order-independent), feature gradients and latent gradients bit for bit; adaptive and plain heads."""
+    from npp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, shapes = 2, [(64, 96), (128, 48), (256, 24), (512, 12), (512, 6)]
+    f0s = [torch.rand(N, C, h, h, generator=g).to(dev) for C, h in shapes]
+    f1s = [torch.rand(N, C, h, h, generator=g).to(dev) for C, h in shapes]
+    lins = [(torch.rand(C, generator=g) * 0.1).to(dev) for C, _ in shapes]
+    lats = [torch.cat([torch.randn(C, generator=g) * 0.5, torch.randn(C, generator=g) * 0.3]).to(dev) for C, _ in shapes]
+    spline, n_knots, xs = ops.load_spline(dev)
+    for robust in (True, False):
+        la = lats if robust else None
+        l1, l5 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        d1 = [torch.empty_like(f) for f in f0s]
+        d5 = [torch.empty_like(f) for f in f0s]
+        g1 = [torch.zeros_like(t) for t in lats]
+        g5 = [torch.zeros_like(t) for t in lats]
+        for k in range(5):
+            ops.lpips_layer(f0s[k], f1s[k], lins[k], la[k] if robust else None, spline, n_knots, xs, 0.7, l1, d1[k], g1[k] if robust else None)
+        ops.lpips_layers(f0s, f1s, lins, la, spline, n_knots, xs, 0.7, l5, d5, g5)
+        torch.cuda.synchronize()
+        assert abs(l1.item() - l5.item()) <= 1e-6 * abs(l1.item())            # (five float additions in another order)
+        for k in range(5):
+            assert torch.equal(d1[k], d5[k]), k
+            if robust:
+                assert torch.equal(g1[k], g5[k]), k
+
+
 def test_fit_with_the_plain_lpips_head(dev):
     """CompletionFit(use_adaptive_perceptual_loss=False): on a 'same' iteration the explicit loop's gradients equal the autograd loop's,
     the LPIPS latents never move (no gradient reaches them: torch's Adam skips them in the reference), the fit stays finite."""
