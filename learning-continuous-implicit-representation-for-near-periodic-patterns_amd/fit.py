@@ -150,7 +150,9 @@ class CompletionFit:
         given set of buffers it is therefore replayed as ONE captured HIP graph (torch.cuda.CUDAGraph over the same launches: arguments
         and buffers are fixed -- xy / loss_buf / latents are persistent tensors, scale and n_p k part of the key)."""
         lp = self.percepLoss
-        key = (xy.data_ptr(), loss_buf.data_ptr(), int(nk), float(scale), self.lp_robust)
+        # (every address and scalar a captured launch holds is part of the key: re-homed latents or buffers get a capture of their own)
+        key = (xy.data_ptr(), loss_buf.data_ptr(), int(nk), float(scale), self.lp_robust, lp._lat.data_ptr(), lp._dlat.data_ptr(),
+               lp.lins[0].data_ptr(), lp.grouped_heads)
         ent = self._lp_graphs.get(key) if self.lp_graph else None
         if ent is not None and ent[0] is not None:
             ent[0].replay()
