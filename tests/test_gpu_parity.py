@@ -5,12 +5,15 @@ operand rounding emulated at the same points and (b) loosely against the plain f
 oracle, the quantity the 0.1 dB end-to-end PSNR budget of BASELINE.json rests on."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 torch = pytest.importorskip("torch")
 
 
@@ -207,6 +210,44 @@ def test_lpips_plain_head_with_gradient(dev, C, hw):
     fwd_only = torch.zeros(1, device=dev)
     ops.lpips_layer(f0, f1, lin, None, None, 0, 0.0, 2.0 * N, fwd_only)
     assert fwd_only.item() == loss.item() or abs(fwd_only.item() - loss.item()) < 1e-6 * abs(loss.item())
+
+
+_CX_FLAT_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from npp_amd import ops
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(21)
+N, C, H = 3, 256, 24
+fx = torch.rand(N, C, H, H, generator=g).to(dev)
+fy = torch.rand(N, C, H, H, generator=g).to(dev)
+yact = ops.trunk_alloc(2 * N, C, H, H, dev)
+yact.view(torch.int16)[:] = torch.randint(0, 2, (yact.numel() // 2,), generator=g, dtype=torch.int16).to(dev) * 0x3c00   # fp16 0 / 1: the ReLU gates
+dz = ops.trunk_alloc(2 * N, C, H, H, dev)
+loss = torch.zeros(1, device=dev)
+ops.cx_fwd_bwd_flat(fx, fy, yact, dz, 2 * N, 0.5, 1.0, loss)
+torch.cuda.synchronize()
+np.savez(sys.argv[2], dz=dz.cpu().numpy(), loss=loss.cpu().numpy())
+"""
+
+
+def test_cx_core_five_launch_form_equals_the_six_launch_form(dev, tmp_path):
+    """NPP_CX_DX_FUSED=1 (cx_dx32_flat_kernel: the backward contraction with the normalisation backward, ReLU gate and flat bf16 store in
+    its epilogue) against the shipped six-launch form: the flat gradient tensor bit for bit on its interior, zero elsewhere.  The
+    switch is read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"cx{flag}.npz")
+        env = dict(os.environ, NPP_CX_DX_FUSED=flag)
+        r = subprocess.run([sys.executable, "-c", _CX_FLAT_SNIPPET, ROOT, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0]["loss"] == outs[1]["loss"]
+    a, b = outs[0]["dz"], outs[1]["dz"]
+    assert np.array_equal(a, b) and np.any(a != 0)
 
 
 def test_lpips_heads_in_one_launch_equal_the_five_launches(dev):
