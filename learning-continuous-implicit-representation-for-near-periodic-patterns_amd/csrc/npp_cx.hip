@@ -621,7 +621,10 @@ __global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  constexpr int PF = 8;                                 // blocks of 8 columns in flight (32 MFMAs = 2048 cycles of cover)
+#ifndef NPP_CX_DX_PF
+#define NPP_CX_DX_PF 8
+#endif
+  constexpr int PF = NPP_CX_DX_PF;                      // blocks of 8 columns in flight (8: 32 MFMAs = 2048 cycles of cover)
   float4 ya[PF], da[PF], sa[PF];
   const int nt = hw / 8;
 #pragma unroll
