@@ -19,7 +19,8 @@ H, K = 512, 3
 angles, periods, shifts = syn.synthetic_periodicity(H, K)
 img, mask = syn.synthetic_image(H, seed=0)
 f = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev, N_rand=8192, shifts=shifts, seed=0,
-                  rng_mode="fast")
+                  rng_mode="fast", use_perceptual_loss=os.environ.get("R4_NO_LPIPS", "0") == "0",
+                  use_contextual_loss=os.environ.get("R4_NO_CX", "0") == "0")
 pool = []
 while len(pool) < 8:
     b = f.sample_batch()
