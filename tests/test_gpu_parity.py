@@ -609,6 +609,29 @@ def test_lpips_head_golden(dev, golden):
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=5e-5)
 
 
+def test_lpips_plain_head_golden(dev, golden):
+    """LPIPS.forward(use_robust=False, normalize=True) + autograd by the reference's own code (g7b_lpips_plain.npz: the features and
+    vendored lin weights of g7, tests/golden/make_golden_lpips_plain.py): value and feature gradients of the plain head, tap by tap and
+    all five taps in one launch."""
+    from npp_amd import ops
+    g, gp = golden("g7_lpips.npz"), golden("g7b_lpips_plain.npz")
+    N = g["f0_0"].shape[0]
+    f0s = [torch.from_numpy(g[f"f0_{k}"]).to(dev) for k in range(5)]
+    f1s = [torch.from_numpy(g[f"f1_{k}"]).to(dev) for k in range(5)]
+    lins = [torch.from_numpy(g[f"lin{k}"]).to(dev) for k in range(5)]
+    loss1, loss5 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    d5 = [torch.empty_like(f) for f in f0s]
+    for k in range(5):
+        df0 = torch.empty_like(f0s[k])
+        ops.lpips_layer(f0s[k], f1s[k], lins[k], None, None, 0, 0.0, 1.0, loss1, df0)
+        assert rel_l2(df0.cpu().numpy(), gp[f"df0_{k}"]) < 1e-4, k
+    ops.lpips_layers(f0s, f1s, lins, None, None, 0, 0.0, 1.0, loss5, d5)
+    for k in range(5):
+        assert rel_l2(d5[k].cpu().numpy(), gp[f"df0_{k}"]) < 1e-4, k
+    np.testing.assert_allclose(loss1.item(), gp["loss"], rtol=2e-5)
+    np.testing.assert_allclose(loss5.item(), gp["loss"], rtol=2e-5)
+
+
 def test_sampler_reproduces_reference_sequence(dev, golden):
     """The product sampler (summed-area counts + HIP gather) against the reference's own
     24-call sequence: modes, k, centres, crops, weights and RNG consumption."""
