@@ -90,6 +90,15 @@ def test_lpips_head(golden):
     assert all((l >= 0).all() for l in lins)          # vendored lin weights are non-negative
 
 
+def test_lpips_plain_oracle_vs_reference(golden):
+    """oracle.lpips_plain (the ranking score's and the non-adaptive loop's head) against the reference's LPIPS.forward(use_robust=False)
+    on g7's features (g7b_lpips_plain.npz)."""
+    g, gp = golden("g7_lpips.npz"), golden("g7b_lpips_plain.npz")
+    val = oracle.lpips_plain([g[f"f0_{k}"] for k in range(5)], [g[f"f1_{k}"] for k in range(5)], [g[f"lin{k}"] for k in range(5)])
+    np.testing.assert_allclose(val, gp["val"].ravel(), rtol=2e-5)
+    np.testing.assert_allclose(val.mean(), gp["loss"], rtol=2e-5)
+
+
 def test_style_loss_oracle_vs_reference(golden):
     """oracle.style_loss_grads against models/style_loss.py:37-74 (g12_style.npz: the reference class fed prepared features)."""
     import oracle
