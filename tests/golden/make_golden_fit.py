@@ -81,6 +81,8 @@ if __name__ == "__main__":
         main(K=3, n_iters=60, out_name="g8c2_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 60), H=512)
     elif "--c5" in sys.argv:                      # g8c5_fit.npz: config c5's network at its real size (512^2, top-5 proposals, W = 256)
         main(K=5, n_iters=60, out_name="g8c5_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40, 50, 60), H=512)
+    elif "--s1024" in sys.argv:                   # g8s1024_fit.npz: a 1024^2 image (configs c2 / c4's grid size), K = 3, W = 256
+        main(K=3, n_iters=40, out_name="g8s1024_fit.npz", checkpoints=(1, 5, 10, 20, 30, 40), H=1024)
     elif "--w512" in sys.argv:                      # g8w512_fit.npz: NPP_Net K = 3 at the reference's default width
         main(K=3, n_iters=100, out_name="g8w512_fit.npz", checkpoints=(1, 5, 10, 20, 30, 50, 75, 100), W=512)
     elif "--k5" in sys.argv:                      # g8k5_fit.npz: BASELINE config c5's network (top-5 proposals)

@@ -900,6 +900,31 @@ def test_fit_trajectory_vs_reference_g8c5_full_size(dev, golden):
                                atol=3e-3)
 
 
+def test_fit_trajectory_vs_reference_g8s1024(dev, golden):
+    """A 1024 x 1024 image (the grid size of BASELINE configs c2 / c4: coordinates beyond 512, 1 M-pixel renders), top-3 proposals,
+    W = 256: 40 iterations of the reference's own modules (g8s1024_fit.npz, make_golden_fit.py --s1024), PSNR within 0.1 dB at every
+    checkpoint, latents 3e-3."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8s1024_fit.npz")
+    H, N_rand, K = int(g["H"]), int(g["N_rand"]), int(g["K"])
+    assert (H, K, int(g["W"])) == (1024, 3, 256)
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, _ = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(K), device=dev, N_rand=N_rand, seed=0, rng_mode="reference")
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    for i in range(1, max(traj) + 1):
+        fit.step()
+        if i in traj:
+            pk, pu = fit.psnr("known"), fit.psnr("unknown")
+            assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i][:2])
+    np.testing.assert_allclose(fit.net.latents.cpu().numpy(), np.concatenate([g["latent_alpha"], g["latent_scale"]], 1).reshape(-1),
+                               atol=3e-3)
+
+
 def test_fit_trajectory_vs_reference_g8k5(dev, golden):
     """g8k3's recipe for BASELINE config c5's network: NPP_Net with top-5 proposals (a 4-proposal scale layer, 2310 inputs), the
     reference's own modules for 100 iterations (g8k5_fit.npz, make_golden_fit.py --k5)."""
