@@ -49,14 +49,17 @@ def reference_lpips(R):
     return obj
 
 
-def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoints=(10, 25, 50, 75, 100)):
+def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoints=(10, 25, 50, 75, 100), H=256, K=1):
+    """H = 512, K = 3 (--c2): BASELINE config c2's COMPLETE iteration at its real size -- NPP_Net with top-3 proposals, 8192 pixel rows
+    + 2 patches of 96^2 against 3 real patches each, contextual loss every iteration, LPIPS on 'same' ones (g8c2_loop.npz)."""
     R = import_reference()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
     from npp_amd.losses import _Trunk, _VGG19                                   # the VGG19[0:18]-shaped stand-in, seed 1234
     percep = reference_lpips(R) if with_lpips else None
-    H, N_rand, P, n_p, topk = 256, 8192, 64, 2, 3
+    N_rand, n_p, topk = 8192, 2, 3
     img, mask = oracle.synthetic_image(H)
-    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    P = 64 if H == 256 else int(oracle.patch_size_from_period(periods[0]))
     masked = img * mask
     i_train = np.stack(np.nonzero(mask[..., 0]), 1)
     i_val = np.stack(np.nonzero(1 - mask[..., 0]), 1)
@@ -64,10 +67,10 @@ def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoint
     torch.manual_seed(0)
     embedder, freq_nerf = emb.get_embedder(10, 0, (H, H))
     freqs = np.array([float(fn.__defaults__[1]) for fn in embedder.embed_fns[1::2]], np.float32)
-    ep, _ = emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[0]), selected_periods=torch.Tensor(periods[0]),
-                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)
+    eps = [emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[k_]), selected_periods=torch.Tensor(periods[k_]),
+                            freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)[0] for k_ in range(K)]
     torch.manual_seed(0)
-    net = _net(R, 1, 256, int(freq_nerf))
+    net = _net(R, K, 256, int(freq_nerf))
     adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
     grad_vars = list(net.parameters()) + list(adaptive.parameters())
     if percep is not None:                                                        # helpers.py:147-151
@@ -78,8 +81,8 @@ def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoint
     mean = torch.tensor([0.485, 0.456, 0.406]).reshape(3, 1, 1)                  # contextual.py:41-46
     std = torch.tensor([0.229, 0.224, 0.225]).reshape(3, 1, 1)
     with torch.no_grad():
-        tab_train = embedder.embed(ep.embed(torch.Tensor(i_train)))
-        tab_all = embedder.embed(ep.embed(torch.Tensor(i_all))).reshape(H, H, -1)   # train.py:103-105 i_all table
+        tab_train = torch.cat([embedder.embed(ep.embed(torch.Tensor(i_train))) for ep in eps], 1)            # train.py:93-105
+        tab_all = torch.cat([embedder.embed(ep.embed(torch.Tensor(i_all))) for ep in eps], 1).reshape(H, H, -1)   # :103-105 i_all table
     masked_t, img_t, mask_t = torch.Tensor(masked), torch.Tensor(img), torch.Tensor(mask)
     np.random.seed(0)
     S = R["sampler"].GridPatchSampler(img=masked_t[None], mask=mask_t[None], N_samples=n_p, patch_size=P, height=H, width=H,
@@ -140,11 +143,13 @@ def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoint
             extra[f"ls{kk}"] = a_.latent_scale.detach().numpy()
             extra[f"lin{kk}"] = percep.lins[kk].model[1].weight.detach().numpy().reshape(-1)
     np.savez_compressed(os.path.join(OUT, out_name), traj=np.array(traj, np.float64), seq=np.array(seq, np.int64), freqs=freqs,
-                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step), **extra)
+                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step), K=np.int64(K), P=np.int64(P), **extra)
 
 
 if __name__ == "__main__":
-    if "--lpips" in sys.argv:
+    if "--c2" in sys.argv:                       # g8c2_loop.npz: config c2's complete iteration at 512^2, K = 3 (~1.5 s per iteration)
+        main(with_lpips=True, n_iters=60, out_name="g8c2_loop.npz", checkpoints=(10, 20, 40, 60), H=512, K=3)
+    elif "--lpips" in sys.argv:
         main(with_lpips=True, n_iters=100, out_name="g8c_fit_lpips.npz")
     else:
         main()

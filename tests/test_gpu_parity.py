@@ -1022,6 +1022,48 @@ def test_full_loop_with_lpips_trajectory_vs_reference_g8c(dev, golden):
         np.testing.assert_allclose(lat.cpu().numpy(), want, atol=2e-3)
 
 
+def test_complete_iteration_at_c2_size_vs_reference_g8c2(dev, golden):
+    """g8c at BASELINE config c2's REAL size: 512^2, NPP_Net with the top-3 proposals, 8192 pixel rows + 2 patches of 96^2 against
+    3 real patches, the contextual loss every iteration and the reference's LPIPS.forward on 'same' ones -- 60 iterations of
+    train.py:166-266 run by the reference itself (tests/golden/make_golden_fit_patch.py --c2).  The bench's workload, pinned."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8c2_loop.npz")
+    H, N_rand, K = int(g["H"]), int(g["N_rand"]), int(g["K"])
+    assert (H, K) == (512, 3)
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(K), device=dev, N_rand=N_rand, seed=0, ksplit=4,
+                        shifts=shifts, rng_mode="reference", use_perceptual_loss=True,
+                        lpips_lin_weights=[g[f"lin{k}"] for k in range(5)])
+    assert fit.patch_size == int(g["P"]) == 96
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    ploss = {int(r[0]): r[1] for r in g["patch_loss"]}
+    code = {"val": 0, "train": 1, "same": 2}
+    n_same = 0
+    for i in range(1, 61):
+        ok = fit.step_full()
+        d = fit.last_draw
+        assert (code[d["source"]], d["k"]) == tuple(int(v) for v in g["seq"][i - 1]), i
+        assert ok == (d["k"] > 0) == (i in ploss)
+        if ok:
+            n_same += d["source"] == "same"
+            if i <= 20:
+                got = float(fit.last_patch_loss[0])
+                tol = 3e-2 if d["source"] == "same" else 0.35           # see g8c: topk ties on the other sources
+                assert abs(got - ploss[i]) < tol * abs(ploss[i]), (i, d["source"], got, ploss[i])
+        if i in traj:
+            pk, pu = fit.psnr("known"), fit.psnr("unknown")
+            assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i])
+    assert n_same == len(g["lpips_values"]) and fit.net.global_step == int(g["global_step"])
+    for k, lat in enumerate(fit.percepLoss.latents):
+        want = np.concatenate([g[f"la{k}"].reshape(-1), g[f"ls{k}"].reshape(-1)])
+        np.testing.assert_allclose(lat.cpu().numpy(), want, atol=2e-3)
+
+
 def test_native_stream_and_prefetch_reproduce_numpy_sequence(dev):
     """rng_mode='reference' (the library's MT19937) draws exactly what rng_mode='numpy' (np.random.RandomState) draws, with
     and without the producer thread: same patch sources, centres, pixel rows, skipped iterations -- the reference's stream
