@@ -399,6 +399,15 @@ int npp_conv3x3_pf(const void* d_x, int N_total, int n_run, int H, int W, int Ci
 int npp_maxpool2_fwd(const void* d_x, int N, int H, int W, int C, void* d_y, void* stream);
 int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, int N_total,
                      int n_run, int H, int W, int C, void* d_dz, void* stream);
+/* npp_conv3x3 mode 2 INTO a pooled tensor followed by npp_maxpool2_bwd, as ONE launch (the pool's backward, the pre-pool
+ * ReLU gate and the optional tap gradient ride in the convolution's epilogue; results bit-identical to the two launches).
+ * H, W: the pooled geometry (= this convolution's); d_xpre (fp16 activation of the pre-pool layer), d_addend (nullable) and
+ * d_dz: flat tensors of geometry (N_total, Cout, 2H, 2W); d_dz's border must be zero (npp_trunk_act buffers are) and is not
+ * written.  Replaces the autograd nodes of nn.MaxPool2d + nn.ReLU in the reference's trunks
+ * (externel_lib/contextual_loss/modules/vgg.py:20-27, externel_lib/lpips/pretrained_networks.py:96-130). */
+int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
+                           const void* d_pack, const void* d_xpre, const void* d_addend, void* d_dz,
+                           const void* d_next_pack, int64_t next_pack_bytes, void* stream);
 
 /* Tap gradient (n_run, C, H, W) fp32 -> flat (bf16, or fp16 when as_f16), gated by [y > 0]
  * when the fp16 activation tensor d_y is given; accumulate != 0 adds it onto the gradient already in d_dz

@@ -61,6 +61,14 @@ struct ConvArgs {
   uint32_t x_bytes, pack_bytes;
   const char* pf;        // optional: the NEXT launch's weight pack, requested into this XCD's L2 (one dword per 128-byte line)
   int64_t pf_bytes;
+  // dgrad-lin with the max-pool backward folded into the epilogue (npp_conv3x3_dgrad_pool): this launch's output is the gradient
+  // of a POOLED tensor; instead of storing it, every interior position routes its value to the first maximum of its 2 x 2
+  // window of the pre-pool activation pool_x (fp16, (2H, 2W) geometry), adds the optional tap gradient pool_add and applies the
+  // pre-pool ReLU gate -- what maxpool2_bwd_kernel does in a launch of its own, bit for bit (the value is rounded to bf16 first).
+  const void* pool_x;
+  const void* pool_add;
+  void* pool_dz;
+  int64_t pool_nposp;
 };
 
 __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -150,6 +158,10 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   constexpr int NF = S == 1 ? NT : (NT + S - 1) / S;          // tiles finished by one wave
   f16x8 gate[MODE == kConvDgradMask ? NF : 1][2];
   float bias_r[MODE == kConvFwd ? NF : 1][16];
+  constexpr bool kPoolable = MODE == kConvDgradLin;
+  f16x8 pwin[kPoolable ? NF : 1][2][4];                    // folded pool backward: the four pre-pool units of my window per chunk
+  bf16x8 padd[kPoolable ? NF : 1][2][4];
+  const bool pool_fold = kPoolable && a.pool_x != nullptr;
 #pragma unroll
   for (int q = 0; q < NF; ++q) {
     const int t = S == 1 ? q : wave + q * S;
@@ -166,6 +178,28 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       if (MODE == kConvFwd) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias_r[q][r] = a.bias[32 * (cot0 + ct) + acc_row(r, h)];
+      }
+      if (kPoolable && pool_fold) {
+        const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
+        const int n = (int)((uint32_t)p / (uint32_t)a.S);
+        const int r0 = (int)(p - (int64_t)n * a.S);
+        const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
+        const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
+        const int Wf = 2 * a.W + 2;
+        const int64_t qpos = (int64_t)n * (2 * a.H + 2) * Wf + (int64_t)(2 * yy - 1) * Wf + (2 * xx - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int chunk = 4 * (cot0 + ct) + 2 * s + h;
+          if (interior && chunk < a.cout_chunks) {
+            const int64_t u0 = (int64_t)chunk * a.pool_nposp + kConvGuard + qpos;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int64_t u = u0 + (k >> 1) * Wf + (k & 1);
+              pwin[q][s][k] = ((const f16x8*)a.pool_x)[u];
+              if (a.pool_add) padd[q][s][k] = ((const bf16x8*)a.pool_add)[u];
+            }
+          }
+        }
       }
     }
   }
@@ -200,6 +234,33 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       const int chunk = 4 * cot + 2 * s + h;
       if (chunk >= a.cout_chunks) continue;
       const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
+      if (kPoolable && pool_fold) {
+        if (!interior) continue;                              // the pre-pool tensor's border stays as it is: zero
+        const int Wf = 2 * a.W + 2;
+        const int64_t u0 = (int64_t)chunk * a.pool_nposp + kConvGuard + (int64_t)n * (2 * a.H + 2) * Wf +
+                           (int64_t)(2 * yy - 1) * Wf + (2 * xx - 1);
+        bf16x8 o4[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)(__bf16)v16[8 * s + j];      // what the separate launch reads back from the pooled gradient tensor
+          const float v0 = (float)pwin[q][s][0][j], v1 = (float)pwin[q][s][1][j], v2 = (float)pwin[q][s][2][j],
+                      v3 = (float)pwin[q][s][3][j];
+          int am = 0;
+          float mx = v0;
+          if (v1 > mx) { mx = v1; am = 1; }
+          if (v2 > mx) { mx = v2; am = 2; }
+          if (v3 > mx) { mx = v3; am = 3; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float g = am == k ? d : 0.0f;
+            if (a.pool_add) g += (float)padd[q][s][k][j];
+            o4[k][j] = (__bf16)((float)pwin[q][s][k][j] > 0.0f ? g : 0.0f);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((bf16x8*)a.pool_dz)[u0 + (k >> 1) * Wf + (k & 1)] = o4[k];
+        continue;
+      }
       f16x8 m;
       if (MODE == kConvDgradMask) m = gate[q][s];
       frag_t o;
@@ -952,9 +1013,11 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
 // mode 1: y = conv_T(x) * [mask > 0]          (data gradient through a conv into a ReLU layer's pre-activation)
 // mode 2: y = conv_T(x)                       (data gradient into a pooled tensor / the image)
 // N_total fixes the geometry of the buffers, n_run <= N_total the leading images actually computed.
+struct PoolFold { const void* x; const void* add; void* dz; };
 static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
                         const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
-                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
+                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream,
+                        const PoolFold* fold = nullptr);
 extern "C" int npp_conv3x3(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
                            const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
                            const float* tap_scale, void* stream) {
@@ -967,9 +1030,24 @@ extern "C" int npp_conv3x3_pf(const void* d_x, int N_total, int n_run, int H, in
   return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, d_bias, mode, d_mask, d_y, d_tap, Ctap, tap_scale, d_next_pack,
                       next_pack_bytes, stream);
 }
+// The data gradient of a convolution whose input is a POOLED tensor, with MaxPool2d(2,2)'s backward, the pre-pool layer's ReLU
+// gate and its optional tap gradient folded into the epilogue (= npp_conv3x3 mode 2 into a scratch tensor followed by
+// npp_maxpool2_bwd, bit for bit, in one launch).  H, W: the pooled geometry (this convolution's); d_xpre / d_addend / d_dz: flat
+// tensors of the pre-pool layer, geometry (N_total, Cout, 2H, 2W); d_dz's border must be zero and stays untouched.
+extern "C" int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                                      const void* d_xpre, const void* d_addend, void* d_dz, const void* d_next_pack,
+                                      int64_t next_pack_bytes, void* stream) {
+  if (!d_xpre || !d_dz) { set_error("npp_conv3x3_dgrad_pool: null pre-pool tensor"); return NPP_ERR_ARG; }
+  int rc = conv_geom_check(N_total, 2 * H, 2 * W, "npp_conv3x3_dgrad_pool");
+  if (rc) return rc;
+  const PoolFold f{d_xpre, d_addend, d_dz};
+  return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, nullptr, kConvDgradLin, nullptr, d_dz, nullptr, 0, nullptr,
+                      d_next_pack, d_next_pack ? next_pack_bytes : 0, stream, &f);
+}
 static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
                         const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
-                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
+                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream,
+                        const PoolFold* fold) {
   int rc = conv_geom_check(N_total, H, W, "npp_conv3x3");
   if (rc) return rc;
   if (!d_x || !d_pack || (!d_y && !d_tap) || mode < 0 || mode > 2 || n_run < 1 || n_run > N_total) {
@@ -997,6 +1075,11 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
   a.pf = (const char*)d_next_pack;
   a.pf_bytes = d_next_pack ? next_pack_bytes : 0;
+  if (fold) {
+    a.pool_x = fold->x; a.pool_add = fold->add; a.pool_dz = fold->dz;
+    a.pool_nposp = conv_nposp(N_total, 2 * H, 2 * W);
+    a.y = nullptr;
+  }
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: the largest output tile per workgroup (fewest operand bytes per MFMA) that still yields about one
   // workgroup per CU, with the contraction split over S waves (CI % S == 0).  NPP_CONV_TILE="ct,pt,s" forces one
@@ -1027,7 +1110,7 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   // window-staged form (conv3x3_win_kernel): few input-channel steps, many positions, 64-channel output blocks
   static const int win_mode = getenv("NPP_CONV_WIN") ? atoi(getenv("NPP_CONV_WIN")) : 1;     // 0: never (A/B comparator)
   const int64_t win_wgs = (int64_t)(a.pos_tiles / 8) * (cot_n / 2);
-  if (win_mode && !forced && a.CI <= 8 && cot_n % 2 == 0 && a.pos_tiles % 8 == 0 && 2 * (a.Wp + 1) + kWinPos <= kWinMaxUnits &&
+  if (win_mode && !forced && !fold && a.CI <= 8 && cot_n % 2 == 0 && a.pos_tiles % 8 == 0 && 2 * (a.Wp + 1) + kWinPos <= kWinMaxUnits &&
       ((win_wgs >= 200 && mode == kConvFwd && a.CI <= 4) || win_mode == 2)) {       // measured: only these layers gain (conv1_1, conv1_2, conv2_1 forward)
     const dim3 wgrid((unsigned)(a.pos_tiles / 8), (unsigned)(cot_n / 2));
     constexpr int smem = win_lds_bytes<2>();

@@ -140,13 +140,14 @@ class HipTrunk:
         self._buf, self._gen = {}, 0
         self.final_next_pack = None
         self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
+        self.fold_pool_bwd = os.environ.get("NPP_POOL_FOLD_BWD", "1") != "0"      # max-pool backward in the data-gradient launch above it
 
     def twin(self):
         """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
         two passes through the stack may then be in flight on different streams (ContextualLoss.prefetch_y)."""
         t = HipTrunk.__new__(HipTrunk)
         t.device, t.taps, t.layers = self.device, self.taps, self.layers
-        t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
+        t._buf, t._gen, t.final_next_pack, t.prefetch_next, t.fold_pool_bwd = {}, 0, None, self.prefetch_next, self.fold_pool_bwd
         return t
 
     def _pb_below(self, j):
@@ -269,6 +270,17 @@ class HipTrunk:
                 dzp = gbuf(cp, H, W)
                 ops.conv3x3(cur, N, n, H, W, L["cout"], cp, L["pb"], None, 1, yp, dzp, next_pack=self._pb_below(j))
                 cur, j = dzp, j - 1
+            elif self.fold_pool_bwd and (j - 1) not in tap_of and j >= 2 and self.layers[j - 2]["kind"] == "conv":
+                # pool at j-1, conv at j-2: the data gradient, the pool's backward, layer j-2's ReLU gate and its tap gradient in
+                # ONE launch (ops.conv3x3_dgrad_pool) -- no pooled gradient tensor, no maxpool2_bwd launch
+                yp, cp, Hp, Wp = self._geom[j - 2]
+                add = None
+                if (j - 2) in tap_of:
+                    add = self._flat("tapadd", N, cp, Hp, Wp)
+                    ops.trunk_grad_in(tap_of[j - 2], None, N, n, cp, Hp, Wp, add)
+                dzp = gbuf(cp, Hp, Wp)
+                ops.conv3x3_dgrad_pool(cur, N, n, H, W, L["cout"], cp, L["pb"], yp, add, dzp, next_pack=self._pb_below(j))
+                cur, j, H, W, state = dzp, j - 2, Hp, Wp, "dz"
             else:                                                    # pool at j-1: ungated gradient w.r.t. the pooled tensor
                 _, cp, _, _ = self._geom[j - 1]
                 g = gbuf(cp, H, W)

@@ -540,6 +540,14 @@ def conv3x3(x, N_total, n_run, H, W, cin, cout, pack, bias, mode, mask, y, tap=N
                             ctap, ts, _stream()), "npp_conv3x3")
 
 
+def conv3x3_dgrad_pool(x, N_total, n_run, H, W, cin, cout, pack, xpre, addend, dz, next_pack=None):
+    """Data gradient of a convolution that reads a pooled tensor + the pool's backward + the pre-pool ReLU gate (+ tap gradient)
+    in one launch; H, W: the pooled geometry, xpre / addend / dz: the pre-pool layer's flat tensors."""
+    nb = 0 if next_pack is None else next_pack.numel() * next_pack.element_size()
+    check(lib().npp_conv3x3_dgrad_pool(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(xpre), _p(addend), _p(dz),
+                                       _p(next_pack), nb, _stream()), "npp_conv3x3_dgrad_pool")
+
+
 def maxpool2_fwd(x, N, H, W, c, y):
     check(lib().npp_maxpool2_fwd(_p(x), N, H, W, c, _p(y), _stream()), "npp_maxpool2_fwd")
 
