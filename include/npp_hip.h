@@ -405,6 +405,13 @@ int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, in
  * d_dz: flat tensors of geometry (N_total, Cout, 2H, 2W); d_dz's border must be zero (npp_trunk_act buffers are) and is not
  * written.  Replaces the autograd nodes of nn.MaxPool2d + nn.ReLU in the reference's trunks
  * (externel_lib/contextual_loss/modules/vgg.py:20-27, externel_lib/lpips/pretrained_networks.py:96-130). */
+/* npp_conv3x3 mode 0 followed by npp_maxpool2_fwd as ONE launch: d_y = relu(conv(x) + bias) (flat fp16, + the optional fp32
+ * tap as in npp_conv3x3) and d_ypool = maxpool2x2(d_y), geometry (N_total, Cout, H/2, W/2); H, W even.  Only the n_run leading
+ * images are computed / pooled; the borders of both outputs must be zero (npp_trunk_act buffers are) and are not written.
+ * Bit-identical to the two launches. */
+int npp_conv3x3_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
+                     const void* d_pack, const float* d_bias, void* d_y, void* d_ypool, float* d_tap, int Ctap,
+                     const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
 int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
                            const void* d_pack, const void* d_xpre, const void* d_addend, void* d_dz,
                            const void* d_next_pack, int64_t next_pack_bytes, void* stream);

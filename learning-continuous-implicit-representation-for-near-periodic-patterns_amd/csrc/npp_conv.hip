@@ -46,7 +46,7 @@ namespace npp {
 constexpr int kConvRing = NPP_CONV_RING;
 static_assert(kConvRing == 3 || kConvRing == 9, "ring depth");
 
-enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2 };
+enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2, kConvFwdPool = 3 };   // 3: internal (npp_conv3x3_pool)
 
 struct ConvArgs {
   const void* x;         // flat input, Cin channels
@@ -69,6 +69,10 @@ struct ConvArgs {
   const void* pool_add;
   void* pool_dz;
   int64_t pool_nposp;
+  // forward with MaxPool2d(2,2) folded in (kConvFwdPool, npp_conv3x3_pool): a position tile is 16 columns x 2 rows of one image
+  // (lane b: row 2 rp + 1 + (b >> 4), column 16 cb + 1 + (b & 15)), so a pool window is lanes {b, b^1, b^16, b^17} of one tile;
+  // pool_dz = the pooled fp16 tensor (geometry (H/2, W/2), pool_nposp units per chunk), pool_tiles = n_run * H/2 * pool_cbn.
+  int32_t pool_tiles, pool_cbn;
 };
 
 __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -89,8 +93,9 @@ template <> struct OpT<true> { typedef f16x8 frag; typedef _Float16 elem; };
 // with 2 x 4 tiles (0.75 KiB per MFMA) and every fragment is fetched by exactly one wave.
 template <int CT, int PT, int S, int MODE>
 __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
-  typedef typename OpT<MODE == kConvFwd>::frag frag_t;       // forward: fp16 operands; gradients: bf16
-  typedef typename OpT<MODE == kConvFwd>::elem elem_t;
+  constexpr bool FWD = MODE == kConvFwd || MODE == kConvFwdPool, FPOOL = MODE == kConvFwdPool;
+  typedef typename OpT<FWD>::frag frag_t;                    // forward: fp16 operands; gradients: bf16
+  typedef typename OpT<FWD>::elem elem_t;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [S][CT*PT][16 regs][64 lanes] when S > 1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -117,6 +122,23 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   const int voffA = lane * 16;
   const int voffB = (int)(((int64_t)h * a.nposp + kConvGuard + (int64_t)tile0 * 32 + b - (a.Wp + 1)) * 16);
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  // flat position of my column in position tile pt of this workgroup; ok: it is a position this launch owns
+  auto tile_pos = [&](int pt, bool& ok) -> int64_t {
+    if (!FPOOL) { ok = true; return (int64_t)(tile0 + pt) * 32 + b; }
+    const int T = tile0 + pt, per_img = (a.H >> 1) * a.pool_cbn;
+    const int n = T / per_img, r = T - n * per_img, rp = r / a.pool_cbn, cb = r - rp * a.pool_cbn;
+    const int row = 2 * rp + 1 + (b >> 4), col = 16 * cb + 1 + (b & 15);
+    ok = T < a.pool_tiles && col <= a.W;
+    return T < a.pool_tiles ? (int64_t)n * a.S + (int64_t)row * a.Wp + col : 0;
+  };
+  int voffBp[FPOOL ? PT : 1];
+  if (FPOOL) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      bool ok;
+      voffBp[pt] = (int)(((int64_t)h * a.nposp + kConvGuard + tile_pos(pt, ok) - (a.Wp + 1)) * 16);
+    }
+  }
 
   frag_t A[kConvRing][CT], B[kConvRing][PT];
   auto load = [&](int slot, int ci, int tap) {
@@ -138,7 +160,8 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
     const uint32_t soff = (uint32_t)(((int64_t)2 * ci * a.nposp + shift) * 16);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rB, voffB, (int)(soff + (uint32_t)pt * 512u), 0);
+      const u32x4_t raw = FPOOL ? __builtin_amdgcn_raw_buffer_load_b128(rB, voffBp[FPOOL ? pt : 0], (int)soff, 0)
+                                : __builtin_amdgcn_raw_buffer_load_b128(rB, voffB, (int)(soff + (uint32_t)pt * 512u), 0);
       B[slot][pt] = __builtin_bit_cast(frag_t, raw);
     }
   };
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   constexpr int NT = CT * PT;
   constexpr int NF = S == 1 ? NT : (NT + S - 1) / S;          // tiles finished by one wave
   f16x8 gate[MODE == kConvDgradMask ? NF : 1][2];
-  float bias_r[MODE == kConvFwd ? NF : 1][16];
+  float bias_r[FWD ? NF : 1][16];
   constexpr bool kPoolable = MODE == kConvDgradLin;
   f16x8 pwin[kPoolable ? NF : 1][2][4];                    // folded pool backward: the four pre-pool units of my window per chunk
   bf16x8 padd[kPoolable ? NF : 1][2][4];
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
           if (chunk < a.cout_chunks) gate[q][s] = ((const f16x8*)a.mask)[(int64_t)chunk * a.nposp + kConvGuard + p];
         }
       }
-      if (MODE == kConvFwd) {
+      if (FWD) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias_r[q][r] = a.bias[32 * (cot0 + ct) + acc_row(r, h)];
       }
@@ -222,11 +245,12 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 
   // ---- epilogue of one 32 x 32 tile (ct, pt): bias / ReLU / gate, 16-bit store, optional fp32 tap -------
   auto finish = [&](const f32x16& v16, int ct, int pt, int q) {
-    const int64_t p = (int64_t)(tile0 + pt) * 32 + b;
+    bool mine;
+    const int64_t p = tile_pos(pt, mine);
     const int n = (int)((uint32_t)p / (uint32_t)a.S);
     const int r0 = (int)(p - (int64_t)n * a.S);
     const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
-    const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
+    const bool interior = mine && p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
     const int64_t tap_base = (((int64_t)n * a.Ctap) * a.H + (yy - 1)) * a.W + (xx - 1);
     const int cot = cot0 + ct;
 #pragma unroll
@@ -268,14 +292,37 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       for (int j = 0; j < 8; ++j) {
         const int co = 32 * cot + acc_row(8 * s + j, h);
         float v = v16[8 * s + j];
-        if (MODE == kConvFwd) v = fminf(fmaxf(v + bias_r[q][8 * s + j], 0.0f), 65504.0f);
+        if (FWD) v = fminf(fmaxf(v + bias_r[q][8 * s + j], 0.0f), 65504.0f);
         if (MODE == kConvDgradMask) v = (float)m[j] > 0.0f ? v : 0.0f;
         v = interior ? v : 0.0f;
         o[j] = (elem_t)v;
         if (a.tap && interior && co < a.Ctap)
           a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? v * a.tap_scale[co & 3] : v;
       }
-      if (a.y) ((frag_t*)a.y)[unit] = o;
+      if (a.y && (!FPOOL || interior)) ((frag_t*)a.y)[unit] = o;     // (two-row tiles own interior positions only: borders stay zero)
+      if (FPOOL) {
+        // the 2 x 2 window's maximum: lanes b, b ^ 1 (next column), b ^ 16 (next row); values are post-ReLU fp16 (>= 0, columns
+        // beyond W hold 0), so the maximum of the rounded values is the rounded maximum: what maxpool2_fwd_kernel stores
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        i32x4_t w = __builtin_bit_cast(i32x4_t, o);
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+          i32x4_t t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = __shfl_xor(w[e], step == 0 ? 1 : 16, 64);
+          const f16x8 mine8 = __builtin_bit_cast(f16x8, w), other8 = __builtin_bit_cast(f16x8, t);
+          f16x8 mx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx[j] = other8[j] > mine8[j] ? other8[j] : mine8[j];
+          w = __builtin_bit_cast(i32x4_t, mx);
+        }
+        if (interior && (b & 17) == 0) {
+          const int Ho = a.H >> 1, Wo = a.W >> 1;
+          const int64_t up = (int64_t)chunk * a.pool_nposp + kConvGuard + (int64_t)n * (Ho + 2) * (Wo + 2) +
+                             (int64_t)((yy + 1) >> 1) * (Wo + 2) + ((xx + 1) >> 1);
+          ((f16x8*)a.pool_dz)[up] = __builtin_bit_cast(f16x8, w);
+        }
+      }
     }
   };
 
@@ -1004,6 +1051,7 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
   } while (0)
   if (mode == kConvFwd) NPP_CONV_GO(kConvFwd);
   else if (mode == kConvDgradMask) NPP_CONV_GO(kConvDgradMask);
+  else if (mode == kConvFwdPool) NPP_CONV_GO(kConvFwdPool);
   else NPP_CONV_GO(kConvDgradLin);
 #undef NPP_CONV_GO
   return NPP_OK;
@@ -1013,7 +1061,7 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
 // mode 1: y = conv_T(x) * [mask > 0]          (data gradient through a conv into a ReLU layer's pre-activation)
 // mode 2: y = conv_T(x)                       (data gradient into a pooled tensor / the image)
 // N_total fixes the geometry of the buffers, n_run <= N_total the leading images actually computed.
-struct PoolFold { const void* x; const void* add; void* dz; };
+struct PoolFold { const void* x; const void* add; void* dz; void* ypool; };
 static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
                         const float* d_bias, int mode, const void* d_mask, void* d_y, float* d_tap, int Ctap,
                         const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream,
@@ -1040,8 +1088,19 @@ extern "C" int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, i
   if (!d_xpre || !d_dz) { set_error("npp_conv3x3_dgrad_pool: null pre-pool tensor"); return NPP_ERR_ARG; }
   int rc = conv_geom_check(N_total, 2 * H, 2 * W, "npp_conv3x3_dgrad_pool");
   if (rc) return rc;
-  const PoolFold f{d_xpre, d_addend, d_dz};
+  const PoolFold f{d_xpre, d_addend, d_dz, nullptr};
   return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, nullptr, kConvDgradLin, nullptr, d_dz, nullptr, 0, nullptr,
+                      d_next_pack, d_next_pack ? next_pack_bytes : 0, stream, &f);
+}
+// Forward layer with the nn.MaxPool2d(2,2) that follows it folded in: y = relu(conv(x) + bias) as npp_conv3x3 mode 0 (flat fp16
+// tensor + optional fp32 tap) AND d_ypool = maxpool(y) (geometry (N_total, Cout, H/2, W/2)) in one launch; H and W even.  Position
+// tiles are 16 columns x 2 rows, so a pool window sits in four lanes of one tile; bit-identical to the two launches.
+extern "C" int npp_conv3x3_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
+                                const float* d_bias, void* d_y, void* d_ypool, float* d_tap, int Ctap, const float* tap_scale,
+                                const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
+  if (!d_ypool || !d_y || (H & 1) || (W & 1)) { set_error("npp_conv3x3_pool: needs d_y, d_ypool and even H, W (H=%d W=%d)", H, W); return NPP_ERR_ARG; }
+  const PoolFold f{nullptr, nullptr, nullptr, d_ypool};
+  return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, d_bias, kConvFwd, nullptr, d_y, d_tap, Ctap, tap_scale,
                       d_next_pack, d_next_pack ? next_pack_bytes : 0, stream, &f);
 }
 static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
@@ -1075,7 +1134,14 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
   a.pf = (const char*)d_next_pack;
   a.pf_bytes = d_next_pack ? next_pack_bytes : 0;
-  if (fold) {
+  if (fold && fold->ypool) {                       // forward + pool: two-row position tiles over the n_run images' interiors
+    a.pool_dz = fold->ypool;
+    a.pool_nposp = conv_nposp(N_total, H / 2, W / 2);
+    a.pool_cbn = (W + 15) / 16;
+    a.pool_tiles = n_run * (H / 2) * a.pool_cbn;
+    a.pos_tiles = (a.pool_tiles + 1) / 2 * 2;
+    mode = kConvFwdPool;
+  } else if (fold) {
     a.pool_x = fold->x; a.pool_add = fold->add; a.pool_dz = fold->dz;
     a.pool_nposp = conv_nposp(N_total, 2 * H, 2 * W);
     a.y = nullptr;

@@ -141,13 +141,16 @@ class HipTrunk:
         self.final_next_pack = None
         self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
         self.fold_pool_bwd = os.environ.get("NPP_POOL_FOLD_BWD", "1") != "0"      # max-pool backward in the data-gradient launch above it
+        self.fold_pool_fwd = os.environ.get("NPP_POOL_FOLD_FWD", "1") != "0"      # max-pool forward in the launch of the layer below it
+        self.fold_pool_fwd_min_cin = int(os.environ.get("NPP_POOL_FOLD_FWD_MIN_CIN", "128"))
 
     def twin(self):
         """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
         two passes through the stack may then be in flight on different streams (ContextualLoss.prefetch_y)."""
         t = HipTrunk.__new__(HipTrunk)
         t.device, t.taps, t.layers = self.device, self.taps, self.layers
-        t._buf, t._gen, t.final_next_pack, t.prefetch_next, t.fold_pool_bwd = {}, 0, None, self.prefetch_next, self.fold_pool_bwd
+        t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
+        t.fold_pool_bwd, t.fold_pool_fwd, t.fold_pool_fwd_min_cin = self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin
         return t
 
     def _pb_below(self, j):
@@ -181,7 +184,7 @@ class HipTrunk:
         cur = self._flat("x0", N, 16, H, W)
         if not x0_ready:
             ops.trunk_image_in(x, scale, shift, cur)
-        c, outs = 16, []
+        c, outs, pooled = 16, [], None
         for j, L in enumerate(self.layers):
             if L["kind"] == "conv":
                 y = self._flat(("a", j), N, L["cout"], H, W)
@@ -190,12 +193,24 @@ class HipTrunk:
                     tap = torch.empty((N, L["cout"], H, W), dtype=torch.float32, device=self.device)
                     outs.append(tap)
                 nxt = next((M["pf"] for M in self.layers[j + 1:] if M["kind"] == "conv"), None) if self.prefetch_next else None
-                ops.conv3x3(cur, N, nr, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0,
-                            next_pack=nxt)
+                pooled = None
+                if (self.fold_pool_fwd and j + 1 < len(self.layers) and self.layers[j + 1]["kind"] == "pool" and H % 2 == 0
+                        and W % 2 == 0 and c >= self.fold_pool_fwd_min_cin):
+                    # the pool that follows rides in this launch's epilogue (ops.conv3x3_pool): no maxpool2_fwd launch.  Measured in
+                    # the c2 iteration (profiles/r04_pool_fold_ab.txt): conv2_2 18.3 + pool 4.8 -> 20.8 us; conv1_2, whose plain
+                    # launch is the window-staged kernel (no two-row tiles there): 16.7 + 5.3 -> 22.6 us, hence c >= 128 only
+                    pooled = self._flat(("a", j + 1), N, L["cout"], H // 2, W // 2)
+                    ops.conv3x3_pool(cur, N, nr, H, W, c, L["cout"], L["pf"], L["b"], y, pooled, tap,
+                                     L["cout"] if tap is not None else 0, next_pack=nxt)
+                else:
+                    ops.conv3x3(cur, N, nr, H, W, c, L["cout"], L["pf"], L["b"], 0, None, y, tap, L["cout"] if tap is not None else 0,
+                                next_pack=nxt)
                 c = L["cout"]
             else:
                 y = self._flat(("a", j), N, c, H // 2, W // 2)
-                ops.maxpool2_fwd(cur, N, H, W, c, y)
+                if pooled is None:
+                    ops.maxpool2_fwd(cur, N, H, W, c, y)
+                pooled = None
                 H, W = H // 2, W // 2
                 if L["idx"] in self.taps:                             # a tap on a pooled tensor (models/style_loss.py:12-14)
                     outs.append(ops.trunk_export(y, N, N, c, H, W, is_f16=True))

@@ -188,27 +188,34 @@ def test_full_trunk_vs_torch_fp32(dev, name, P, n, ntot):
 
 
 @pytest.mark.parametrize("name,P,n,ntot", [("vgg19", 96, 2, 8), ("vgg16", 96, 2, 4), ("vgg16", 48, 1, 3), ("vgg19", 40, 3, 3)])
-def test_pool_backward_folded_into_the_data_gradient_is_bit_identical(dev, name, P, n, ntot):
-    """npp_conv3x3_dgrad_pool (the data gradient of the convolution above a pool + the pool's backward + the pre-pool ReLU gate +
-    the tap gradient of an LPIPS tap, one launch) against npp_conv3x3 mode 2 -> npp_maxpool2_bwd: the image gradient of the whole
-    stack is the same bit pattern, for VGG19[0:18] (two pools, one top tap) and VGG16 (four pools, taps right before them)."""
+def test_pools_folded_into_their_neighbouring_convolutions_are_bit_identical(dev, name, P, n, ntot):
+    """npp_conv3x3_pool (a forward layer + the max-pool after it, two-row position tiles) against npp_conv3x3 -> npp_maxpool2_fwd,
+    and npp_conv3x3_dgrad_pool (the data gradient of the convolution above a pool + the pool's backward + the pre-pool ReLU gate +
+    the tap gradient of an LPIPS tap) against npp_conv3x3 mode 2 -> npp_maxpool2_bwd: every feature tap and the image gradient of
+    the whole stack are the same bit patterns, for VGG19[0:18] (two pools, one top tap) and VGG16 (four pools, taps right before
+    them), with n_run < N_total and a width that is not a multiple of 16."""
     from npp_amd.losses import HipTrunk
     cfg, taps = ((oracle.VGG19_CX_CFG, oracle.VGG19_CX_TAPS) if name == "vgg19" else (oracle.VGG16_LPIPS_CFG, oracle.VGG16_LPIPS_TAPS))
     rng = np.random.RandomState(11)
     sd = _state_dict(cfg, rng)
     x = torch.from_numpy(rng.rand(ntot, 3, P, P).astype(np.float32)).to(dev)
-    grads = []
+    grads, feats = [], []
     gs = None
     for fold in (True, False):
         hip = HipTrunk(cfg, taps, state_dict=sd, device=dev)
-        hip.fold_pool_bwd = fold
+        hip.fold_pool_bwd = hip.fold_pool_fwd = fold
+        hip.fold_pool_fwd_min_cin = 32                         # every pool of the stack, conv1_2's too
         xh = x.clone().requires_grad_(True)
         got = hip(xh, n, (4.3, 4.4, 4.5), (-2.1, -2.0, -1.8))
         if gs is None:
             gs = [torch.from_numpy(rng.randn(n, *g.shape[1:]).astype(np.float32)).to(dev) for g in got]
         sum((g[:n] * G).sum() for g, G in zip(got, gs)).backward()
         grads.append(xh.grad.cpu().numpy())
+        feats.append([g[:n].detach().cpu().numpy() for g in got])
     assert np.abs(grads[0]).max() > 0
+    for a, b in zip(*feats):
+        assert np.abs(a).max() > 0
+        np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(grads[0], grads[1])
 
 
