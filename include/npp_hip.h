@@ -299,6 +299,10 @@ int64_t npp_lpips_workspace_bytes(int C);
 typedef struct {
   const float* f0; const float* f1; int32_t C, hw; const float* lin; const float* latents;
   float* df0; float* dlatent; void* workspace;
+  /* optional: the gradient w.r.t. feats0 as bf16 in the trunk's flat layout (a zero-initialised npp_trunk_act buffer of geometry
+   * (N_total, C, H, W), H * W == hw) INSTEAD of df0 (then NULL): what npp_trunk_grad_in(df0, NULL, ...) would produce in a launch of
+   * its own -- the tap gradient npp_maxpool2_bwd / npp_conv3x3_dgrad_pool add in. */
+  void* dflat; int32_t N_total, H, W;
 } npp_lpips_tap;
 int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, const float* d_spline, int n_knots, float x_scale, float scale,
                      float* d_loss, void* stream);

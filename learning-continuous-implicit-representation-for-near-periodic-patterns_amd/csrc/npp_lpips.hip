@@ -9,6 +9,7 @@
 // torch.mean over the batch (NPP_completion/train.py:249) is folded into `scale`.
 // Backward: d/d feats0 (through the channel normalisation) and d/d latents (per channel).
 #include "npp_common.h"
+#include "npp_trunk_layout.h"
 
 namespace npp {
 
@@ -37,6 +38,9 @@ struct LpTap {
   float* df0; float* dlatent; unsigned long long* fix;
   int32_t hw, C, few, nb;            // few: the 4-position block shape; nb: blocks of this tap (blockIdx.x >= nb exit)
   float coef;
+  // gradient straight into the trunk's flat bf16 layout (npp_trunk_layout.h) instead of fp32 (N, C, H, W): what
+  // npp_trunk_grad_in(df0, NULL, ...) would make of df0 in a launch of its own (the tap gradient the backward pass adds in)
+  __bf16* dflat; int64_t flat_nposp; int32_t fW, fS;      // fW = W, fS = (H + 2) (W + 2)
 };
 constexpr int kLpMaxTaps = 5;
 struct LpMulti {
@@ -56,6 +60,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   const float* __restrict__ lin = T.lin;
   const float* __restrict__ latents = T.latents;
   float* __restrict__ df0 = T.df0;
+  const bool grad = T.df0 != nullptr || T.dflat != nullptr;
   float* __restrict__ dlatent = T.dlatent;
   unsigned long long* __restrict__ fix = T.fix;
   const int hw = T.hw;
@@ -97,6 +102,11 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
     const float* a0 = f0 + (int64_t)n * C * hw + p;
     const float* a1 = f1 + (int64_t)n * C * hw + p;
     float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
+    __bf16* gf = nullptr;
+    if (T.dflat) {
+      const int yy = p / T.fW, xx = p - yy * T.fW;
+      gf = T.dflat + (kConvGuard + (int64_t)n * T.fS + (int64_t)(yy + 1) * (T.fW + 2) + xx + 1) * 8;
+    }
     float u[Q], v[Q], dd[Q];
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
@@ -130,7 +140,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
       if (live && plain) {
         const float x = u[q] * i0 - v[q] * i1;
         val += l * x * x;
-        if (g0) {
+        if (grad) {
           const float d = l * coef * 2.0f * x;
           dd[q] = d;
           dot = fmaf(d, u[q], dot);
@@ -141,7 +151,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
         const float uu = fmaf(ssx, P.inv_beta, 1.0f), lnu = __logf(uu);
         const float ue = __expf(P.e * lnu), ue1 = ue / uu;
         val += l * (P.boa * (ue - 1.0f) + P.logc_plus_logz);
-        if (g0) {
+        if (grad) {
           const float d = l * coef * (x * P.inv_c2) * ue1;              // dL/d(normalised f0)_c
           dd[q] = d;
           dot = fmaf(d, u[q], dot);
@@ -149,7 +159,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
           dc = l * coef * (-(x * x) * P.x2_inv_c3 * ue1 + P.inv_c);
         }
       }
-      if (df0 && !plain) {                                               // uniform branch
+      if (grad && !plain) {                                              // uniform branch
 #pragma unroll
         for (int off = PL / 2; off > 0; off >>= 1) {                     // the PL positions of this channel lane
           da += __shfl_xor(da, off, 64);
@@ -163,14 +173,22 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
     }
     red[2][cl][pl] = dot;
     __syncthreads();
-    if (g0 && live) {
+    if (grad && live) {
       dot = 0.0f;
 #pragma unroll 16
       for (int q = 0; q < CL; ++q) dot += red[2][q][pl];
       const float se = n0 + 1e-10f;
       const float k = dot / (fmaxf(n0, 1e-30f) * se * se);
 #pragma unroll
-      for (int q = 0; q < Q; ++q) g0[(int64_t)(cl + CL * q) * hw] = dd[q] * i0 - u[q] * k;
+      for (int q = 0; q < Q; ++q) {
+        const int c = cl + CL * q;
+        const float g = dd[q] * i0 - u[q] * k;
+        if (gf) {                                   // inverse of conv_chan(): channel c -> (chunk, element) in the stored order
+          const int r = c & 15, c8 = 4 * (c >> 5) + 2 * ((c >> 4) & 1) + ((r >> 2) & 1), j = ((r >> 3) << 2) | (r & 3);
+          gf[(int64_t)c8 * T.flat_nposp * 8 + j] = (__bf16)g;
+        }
+        else g0[(int64_t)c * hw] = g;
+      }
     }
   }
   __syncthreads();
@@ -182,7 +200,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
     // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the
     // totals back, accumulates them into dlatent / loss and clears the accumulators for the next call.
     auto tofix = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); };
-    if (df0 && !plain)
+    if (grad && !plain)
       for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i]));
     if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3])));
     if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), nb)) return;
@@ -190,11 +208,11 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
       const long long s = (long long)__hip_atomic_exchange(fix + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float v = (float)((double)s * (1.0 / 1099511627776.0));
       if (i == 2 * C) atomicAdd(loss, v);                    // (the contextual branch adds to the same word from its own stream)
-      else if (df0 && !plain) dlatent[i] += v;
+      else if (grad && !plain) dlatent[i] += v;
     }
     return;
   }
-  if (df0 && !plain)
+  if (grad && !plain)
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dlatent + i, sdl[i]);
   if (threadIdx.x == 0) atomicAdd(loss, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
 }
@@ -243,15 +261,21 @@ using namespace npp;
 extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)(2 * C + 2) * 8; }
 
 static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int hw, const float* lin, const float* latents, float scale,
-                   float* df0, float* dlatent, void* ws, const char* who) {
+                   float* df0, float* dlatent, void* ws, const char* who, void* dflat = nullptr, int N_total = 0, int H = 0, int W = 0) {
   if (!f0 || !f1 || !lin || N < 1 || hw < 1 || C < 16 || C > kLpipsMaxC ||
       !(C == 16 || C == 32 || C == 64 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512)) {
     set_error("%s: bad arguments (N=%d C=%d hw=%d; C one of 16, 32, 64, 128, 192, 256, 384, 512)", who, N, C, hw);
     return NPP_ERR_ARG;
   }
   // latents == NULL: the plain head (use_robust=False), with its gradient when df0 is given
-  if (latents ? (df0 == nullptr) != (dlatent == nullptr) : dlatent != nullptr) {
+  const bool grad = df0 || dflat;
+  if (latents ? !grad != (dlatent == nullptr) : dlatent != nullptr) {
     set_error("%s: df0 and dlatent go together (no dlatent for the plain head)", who);
+    return NPP_ERR_ARG;
+  }
+  if (dflat && (df0 || H < 1 || W < 1 || (int64_t)H * W != hw || N_total < N || C % 16 || W > kConvGuard - 3)) {
+    set_error("%s: the flat gradient takes the place of df0 and needs the tap's geometry (N_total=%d >= N=%d, H=%d x W=%d = hw=%d, C %% 16)",
+              who, N_total, N, H, W, hw);
     return NPP_ERR_ARG;
   }
   const int64_t nh = (int64_t)N * hw;
@@ -261,6 +285,8 @@ static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int
   T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
   T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)(groups < 256 ? groups : 256);
   T.coef = scale / (float)nh;                             // spatial mean and batch mean folded with the caller's weight
+  T.dflat = (__bf16*)dflat;
+  if (dflat) { T.flat_nposp = conv_nposp(N_total, H, W); T.fW = W; T.fS = (H + 2) * (W + 2); }
   return NPP_OK;
 }
 static int lp_launch(LpMulti& m, void* stream, const char* who) {
@@ -298,7 +324,8 @@ extern "C" int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, co
     if (t.latents && (!d_spline || n_knots < 2)) { set_error("npp_lpips_layers: spline"); return NPP_ERR_ARG; }
     for (int j = 0; j < i; ++j)
       if (t.workspace && t.workspace == taps[j].workspace) { set_error("npp_lpips_layers: taps %d and %d share a workspace", j, i); return NPP_ERR_ARG; }
-    int rc = lp_fill(m.t[i], t.f0, t.f1, N, t.C, t.hw, t.lin, t.latents, scale, t.df0, t.dlatent, t.workspace, "npp_lpips_layers");
+    int rc = lp_fill(m.t[i], t.f0, t.f1, N, t.C, t.hw, t.lin, t.latents, scale, t.df0, t.dlatent, t.workspace, "npp_lpips_layers",
+                     t.dflat, t.N_total, t.H, t.W);
     if (rc) return rc;
   }
   m.spline = d_spline; m.loss = d_loss; m.n_taps = n_taps; m.N = N; m.n_knots = n_knots; m.x_scale = x_scale;

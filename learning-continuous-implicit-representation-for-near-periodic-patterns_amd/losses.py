@@ -218,6 +218,15 @@ class HipTrunk:
             cur = y
         return outs
 
+    def _tap_addend(self, g, N, n, c, H, W):
+        """A tap gradient on a pre-pool layer as the flat bf16 tensor the pool's backward adds in: g is either that tensor already
+        (uint8 storage from _flat("tapadd", ...): written by ops.lpips_layers itself) or the fp32 (n, c, H, W) gradient."""
+        if g.dtype == torch.uint8:
+            return g
+        add = self._flat("tapadd", N, c, H, W)
+        ops.trunk_grad_in(g, None, N, n, c, H, W, add)
+        return add
+
     def _backward(self, gtaps, n, scale, xshape, zero_rest=True, top_writer=None):
         """dL/dx for the first n images from the tap gradients.  zero_rest=False leaves images >= n of the
         returned tensor uninitialised (callers that only read [:n]).  top_writer(y, N, n, c, H, W, dz): the producer of the TOP
@@ -266,8 +275,7 @@ class HipTrunk:
                 yp, cp, Hp, Wp = self._geom[j - 1]
                 add = None
                 if (j - 1) in tap_of:
-                    add = self._flat("tapadd", N, cp, Hp, Wp)
-                    ops.trunk_grad_in(tap_of[j - 1], None, N, n, cp, Hp, Wp, add)
+                    add = self._tap_addend(tap_of[j - 1], N, n, cp, Hp, Wp)
                 dzp = gbuf(cp, Hp, Wp)
                 ops.maxpool2_bwd(cur, yp, add, N, n, Hp, Wp, cp, dzp)
                 cur, j, H, W, state = dzp, j - 1, Hp, Wp, "dz"
@@ -291,8 +299,7 @@ class HipTrunk:
                 yp, cp, Hp, Wp = self._geom[j - 2]
                 add = None
                 if (j - 2) in tap_of:
-                    add = self._flat("tapadd", N, cp, Hp, Wp)
-                    ops.trunk_grad_in(tap_of[j - 2], None, N, n, cp, Hp, Wp, add)
+                    add = self._tap_addend(tap_of[j - 2], N, n, cp, Hp, Wp)
                 dzp = gbuf(cp, Hp, Wp)
                 ops.conv3x3_dgrad_pool(cur, N, n, H, W, L["cout"], cp, L["pb"], yp, add, dzp, next_pack=self._pb_below(j))
                 cur, j, H, W, state = dzp, j - 2, Hp, Wp, "dz"
@@ -471,6 +478,7 @@ class LPIPS(nn.Module):
         self.lat_step = 0
         self.touched = False
         self.grouped_heads = os.environ.get("NPP_LP_GROUPED_HEADS", "1") != "0"
+        self.flat_tap_grads = os.environ.get("NPP_LP_FLAT_TAPS", "1") != "0"     # (needs grouped_heads) tap gradients written flat by the heads
         self.spline, self.n_knots, self.x_scale = ops.load_spline(dev)
         self.to(dev)
 
@@ -513,9 +521,15 @@ class LPIPS(nn.Module):
         # the deeper layers of the forward pass: the 'same' iteration went 0.791 -> 0.811 ms; the branch is not what the device waits for.)
         feats = t._forward(xy, sc, sh)
         if self.grouped_heads:                                  # the five heads in ONE launch (they are independent: 100 us in a row before)
-            dfs = [torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device) for f in feats]
+            N = xy.shape[0]
+            # the taps right before a pool hand their gradient over as the flat bf16 tensor the backward pass adds in (no fp32
+            # tensor, no npp_trunk_grad_in launch each); the top tap's goes through the ReLU gate of its own layer as before
+            flat = [self.flat_tap_grads and kk < len(feats) - 1 for kk in range(len(feats))]
+            dfl = [(t._flat("tapadd", N, f.shape[1], f.shape[2], f.shape[3]), N) if fl else None for f, fl in zip(feats, flat)]
+            dfs = [None if fl else torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device) for f, fl in zip(feats, flat)]
             ops.lpips_layers([f[:n] for f in feats], [f[n:] for f in feats], self.lins, self.latents if use_robust else None, self.spline,
-                             self.n_knots, self.x_scale, scale, loss_buf, dfs, self.dlatents)
+                             self.n_knots, self.x_scale, scale, loss_buf, dfs, self.dlatents, dflats=dfl)
+            dfs = [d[0] if d is not None else g for d, g in zip(dfl, dfs)]
         else:
             for kk, f in enumerate(feats):
                 head(kk, f)

@@ -427,9 +427,10 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
                                 _p(loss), _p(df0), _p(dlatent), _p(ws), _stream()), "npp_lpips_layer")
 
 
-def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss, df0s=None, dlatents=None):
+def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss, df0s=None, dlatents=None, dflats=None):
     """All taps of LPIPS.forward in ONE launch (the heads are independent of each other): lists per tap of the arguments of lpips_layer
-    (latents None: the plain head for every tap)."""
+    (latents None: the plain head for every tap).  dflats[i] = (flat bf16 tensor from trunk_alloc, N_total) takes the place of df0s[i]
+    (then None): the tap's gradient goes straight into the trunk's flat layout."""
     from ._lib import LpipsTap
     n = len(f0s)
     N = f0s[0].shape[0]
@@ -446,9 +447,12 @@ def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss,
             ws = _lp_ws.get(key)
             if ws is None:
                 ws = _lp_ws[key] = torch.zeros(int(lib().npp_lpips_workspace_bytes(Cc)), dtype=torch.uint8, device=f0.device)
+        fl = None if dflats is None else dflats[i]
         arr[i] = LpipsTap(f0.data_ptr(), f1.data_ptr(), Cc, f0.shape[2] * f0.shape[3], lins[i].data_ptr(),
-                          None if latents is None else latents[i].data_ptr(), None if df0s is None else df0s[i].data_ptr(),
-                          None if (dlatents is None or latents is None) else dlatents[i].data_ptr(), None if ws is None else ws.data_ptr())
+                          None if latents is None else latents[i].data_ptr(),
+                          None if (df0s is None or df0s[i] is None) else df0s[i].data_ptr(),
+                          None if (dlatents is None or latents is None) else dlatents[i].data_ptr(), None if ws is None else ws.data_ptr(),
+                          None if fl is None else fl[0].data_ptr(), 0 if fl is None else int(fl[1]), f0.shape[2], f0.shape[3])
     check(lib().npp_lpips_layers(n, arr, N, None if latents is None else _p(spline), n_knots if latents is not None else 0,
                                  x_scale if latents is not None else 0.0, scale, _p(loss), st), "npp_lpips_layers")
 

@@ -279,6 +279,50 @@ def test_lpips_heads_in_one_launch_equal_the_five_launches(dev):
                 assert torch.equal(g1[k], g5[k]), k
 
 
+def test_lpips_tap_gradients_written_flat_equal_the_imported_ones(dev):
+    """npp_lpips_layers with npp_lpips_tap.dflat (the tap gradient as bf16 straight into the trunk's flat layout) against the fp32
+    gradient pushed through npp_trunk_grad_in: the same bytes (interior, border, guard bands), with N < N_total; and LPIPS.fused with
+    and without it: dL/dx, loss and latent gradients bit for bit."""
+    from npp_amd import ops
+    from npp_amd.losses import LPIPS
+    g = torch.Generator().manual_seed(3)
+    N, Nt, shapes = 2, 4, [(64, 40), (128, 20), (512, 6)]
+    f0s = [torch.rand(N, C, h, h, generator=g).to(dev) for C, h in shapes]
+    f1s = [torch.rand(N, C, h, h, generator=g).to(dev) for C, h in shapes]
+    lins = [(torch.rand(C, generator=g) * 0.1).to(dev) for C, _ in shapes]
+    lats = [torch.cat([torch.randn(C, generator=g) * 0.5, torch.randn(C, generator=g) * 0.3]).to(dev) for C, _ in shapes]
+    spline, n_knots, xs = ops.load_spline(dev)
+    la, lb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    d = [torch.empty_like(f) for f in f0s]
+    ga, gb = [torch.zeros_like(t) for t in lats], [torch.zeros_like(t) for t in lats]
+    ops.lpips_layers(f0s, f1s, lins, lats, spline, n_knots, xs, 0.7, la, d, ga)
+    want = [ops.trunk_alloc(Nt, C, h, h, dev) for C, h in shapes]
+    for k, (C, h) in enumerate(shapes):
+        ops.trunk_grad_in(d[k], None, Nt, N, C, h, h, want[k])
+    got = [ops.trunk_alloc(Nt, C, h, h, dev) for C, h in shapes]
+    ops.lpips_layers(f0s, f1s, lins, lats, spline, n_knots, xs, 0.7, lb, [None] * 3, gb, dflats=[(t, Nt) for t in got])
+    torch.cuda.synchronize()
+    assert la.item() == lb.item()
+    for k in range(3):
+        assert float(want[k].float().abs().sum()) > 0
+        assert torch.equal(want[k], got[k]), k
+        assert torch.equal(ga[k], gb[k]), k
+    outs = []
+    for flat in (True, False):
+        torch.manual_seed(0)
+        m = LPIPS(device=dev)
+        m.flat_tap_grads = flat
+        xy = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+        loss = torch.zeros(1, device=dev)
+        dx = m.fused(xy, 2, 0.5, loss)
+        torch.cuda.synchronize()
+        outs.append((dx[:2].clone(), loss.clone(), [t.clone() for t in m.dlatents]))
+    assert float(outs[0][0].abs().sum()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+
+
 def test_fit_with_the_plain_lpips_head(dev):
     """CompletionFit(use_adaptive_perceptual_loss=False): on a 'same' iteration the explicit loop's gradients equal the autograd loop's,
     the LPIPS latents never move (no gradient reaches them: torch's Adam skips them in the reference), the fit stays finite."""
