@@ -303,6 +303,8 @@ typedef struct {
    * (N_total, C, H, W), H * W == hw) INSTEAD of df0 (then NULL): what npp_trunk_grad_in(df0, NULL, ...) would produce in a launch of
    * its own -- the tap gradient npp_maxpool2_bwd / npp_conv3x3_dgrad_pool add in. */
   void* dflat; int32_t N_total, H, W;
+  const void* yact;   /* optional with dflat: the tapped layer's own flat fp16 activation; the gradient is gated by [yact > 0]
+                       * (= npp_trunk_grad_in(df0, yact, ...): dL/d(pre-activation) of the top tap's layer) */
 } npp_lpips_tap;
 int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, const float* d_spline, int n_knots, float x_scale, float scale,
                      float* d_loss, void* stream);

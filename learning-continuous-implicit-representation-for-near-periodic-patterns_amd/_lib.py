@@ -27,7 +27,7 @@ class LpipsTap(C.Structure):
     """npp_lpips_tap (include/npp_hip.h): the per-tap arguments of npp_lpips_layers."""
     _fields_ = [("f0", C.c_void_p), ("f1", C.c_void_p), ("C", C.c_int32), ("hw", C.c_int32), ("lin", C.c_void_p), ("latents", C.c_void_p),
                 ("df0", C.c_void_p), ("dlatent", C.c_void_p), ("workspace", C.c_void_p),
-                ("dflat", C.c_void_p), ("N_total", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+                ("dflat", C.c_void_p), ("N_total", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("yact", C.c_void_p)]
 
 
 class PatchGrad(C.Structure):

@@ -41,6 +41,7 @@ struct LpTap {
   // gradient straight into the trunk's flat bf16 layout (npp_trunk_layout.h) instead of fp32 (N, C, H, W): what
   // npp_trunk_grad_in(df0, NULL, ...) would make of df0 in a launch of its own (the tap gradient the backward pass adds in)
   __bf16* dflat; int64_t flat_nposp; int32_t fW, fS;      // fW = W, fS = (H + 2) (W + 2)
+  const _Float16* yact;                                    // optional ReLU gate of the tapped layer itself: dflat *= [yact > 0]
 };
 constexpr int kLpMaxTaps = 5;
 struct LpMulti {
@@ -103,9 +104,12 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
     const float* a1 = f1 + (int64_t)n * C * hw + p;
     float* g0 = df0 ? df0 + (int64_t)n * C * hw + p : nullptr;
     __bf16* gf = nullptr;
+    const _Float16* gy = nullptr;
     if (T.dflat) {
       const int yy = p / T.fW, xx = p - yy * T.fW;
-      gf = T.dflat + (kConvGuard + (int64_t)n * T.fS + (int64_t)(yy + 1) * (T.fW + 2) + xx + 1) * 8;
+      const int64_t e = (kConvGuard + (int64_t)n * T.fS + (int64_t)(yy + 1) * (T.fW + 2) + xx + 1) * 8;
+      gf = T.dflat + e;
+      if (T.yact) gy = T.yact + e;
     }
     float u[Q], v[Q], dd[Q];
     float s0 = 0.0f, s1 = 0.0f;
@@ -185,7 +189,8 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
         const float g = dd[q] * i0 - u[q] * k;
         if (gf) {                                   // inverse of conv_chan(): channel c -> (chunk, element) in the stored order
           const int r = c & 15, c8 = 4 * (c >> 5) + 2 * ((c >> 4) & 1) + ((r >> 2) & 1), j = ((r >> 3) << 2) | (r & 3);
-          gf[(int64_t)c8 * T.flat_nposp * 8 + j] = (__bf16)g;
+          const int64_t e = (int64_t)c8 * T.flat_nposp * 8 + j;
+          gf[e] = (__bf16)((!gy || (float)gy[e] > 0.0f) ? g : 0.0f);
         }
         else g0[(int64_t)c * hw] = g;
       }
@@ -261,7 +266,8 @@ using namespace npp;
 extern "C" int64_t npp_lpips_workspace_bytes(int C) { return (int64_t)(2 * C + 2) * 8; }
 
 static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int hw, const float* lin, const float* latents, float scale,
-                   float* df0, float* dlatent, void* ws, const char* who, void* dflat = nullptr, int N_total = 0, int H = 0, int W = 0) {
+                   float* df0, float* dlatent, void* ws, const char* who, void* dflat = nullptr, int N_total = 0, int H = 0, int W = 0,
+                   const void* yact = nullptr) {
   if (!f0 || !f1 || !lin || N < 1 || hw < 1 || C < 16 || C > kLpipsMaxC ||
       !(C == 16 || C == 32 || C == 64 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512)) {
     set_error("%s: bad arguments (N=%d C=%d hw=%d; C one of 16, 32, 64, 128, 192, 256, 384, 512)", who, N, C, hw);
@@ -285,7 +291,8 @@ static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int
   T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
   T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)(groups < 256 ? groups : 256);
   T.coef = scale / (float)nh;                             // spatial mean and batch mean folded with the caller's weight
-  T.dflat = (__bf16*)dflat;
+  if (yact && !dflat) { set_error("%s: yact gates the flat gradient (dflat)", who); return NPP_ERR_ARG; }
+  T.dflat = (__bf16*)dflat; T.yact = (const _Float16*)yact;
   if (dflat) { T.flat_nposp = conv_nposp(N_total, H, W); T.fW = W; T.fS = (H + 2) * (W + 2); }
   return NPP_OK;
 }
@@ -325,7 +332,7 @@ extern "C" int npp_lpips_layers(int n_taps, const npp_lpips_tap* taps, int N, co
     for (int j = 0; j < i; ++j)
       if (t.workspace && t.workspace == taps[j].workspace) { set_error("npp_lpips_layers: taps %d and %d share a workspace", j, i); return NPP_ERR_ARG; }
     int rc = lp_fill(m.t[i], t.f0, t.f1, N, t.C, t.hw, t.lin, t.latents, scale, t.df0, t.dlatent, t.workspace, "npp_lpips_layers",
-                     t.dflat, t.N_total, t.H, t.W);
+                     t.dflat, t.N_total, t.H, t.W, t.yact);
     if (rc) return rc;
   }
   m.spline = d_spline; m.loss = d_loss; m.n_taps = n_taps; m.N = N; m.n_knots = n_knots; m.x_scale = x_scale;

@@ -260,7 +260,9 @@ class HipTrunk:
         y, c, H, W = self._geom[j]
         cur = gbuf(c, H, W)
         if self.layers[j]["kind"] == "conv":
-            if top_writer is not None:
+            if tap_of[j].dtype == torch.uint8 if isinstance(tap_of[j], torch.Tensor) else False:
+                cur = tap_of[j]                                   # already dL/d(pre-activation), flat and gated (ops.lpips_layers)
+            elif top_writer is not None:
                 top_writer(y, N, n, c, H, W, cur)
             else:
                 ops.trunk_grad_in(tap_of[j], y, N, n, c, H, W, cur,     # dz_j = dL/dtap * [y > 0]
@@ -479,6 +481,7 @@ class LPIPS(nn.Module):
         self.touched = False
         self.grouped_heads = os.environ.get("NPP_LP_GROUPED_HEADS", "1") != "0"
         self.flat_tap_grads = os.environ.get("NPP_LP_FLAT_TAPS", "1") != "0"     # (needs grouped_heads) tap gradients written flat by the heads
+        self.flat_top_tap = os.environ.get("NPP_LP_FLAT_TOP", "1") != "0"
         self.spline, self.n_knots, self.x_scale = ops.load_spline(dev)
         self.to(dev)
 
@@ -524,8 +527,10 @@ class LPIPS(nn.Module):
             N = xy.shape[0]
             # the taps right before a pool hand their gradient over as the flat bf16 tensor the backward pass adds in (no fp32
             # tensor, no npp_trunk_grad_in launch each); the top tap's goes through the ReLU gate of its own layer as before
-            flat = [self.flat_tap_grads and kk < len(feats) - 1 for kk in range(len(feats))]
-            dfl = [(t._flat("tapadd", N, f.shape[1], f.shape[2], f.shape[3]), N) if fl else None for f, fl in zip(feats, flat)]
+            flat = [self.flat_tap_grads and (kk < len(feats) - 1 or self.flat_top_tap) for kk in range(len(feats))]
+            ytop = t._geom[-1][0]                                # the top tap's gradient passes its own layer's ReLU gate on the way
+            dfl = [(t._flat("tapadd", N, f.shape[1], f.shape[2], f.shape[3]), N, ytop if kk == len(feats) - 1 else None) if fl else None
+                   for kk, (f, fl) in enumerate(zip(feats, flat))]
             dfs = [None if fl else torch.empty((n,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device) for f, fl in zip(feats, flat)]
             ops.lpips_layers([f[:n] for f in feats], [f[n:] for f in feats], self.lins, self.latents if use_robust else None, self.spline,
                              self.n_knots, self.x_scale, scale, loss_buf, dfs, self.dlatents, dflats=dfl)

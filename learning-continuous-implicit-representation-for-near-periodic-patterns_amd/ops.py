@@ -429,8 +429,9 @@ def lpips_layer(f0, f1, lin, latents, spline, n_knots, x_scale, scale, loss, df0
 
 def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss, df0s=None, dlatents=None, dflats=None):
     """All taps of LPIPS.forward in ONE launch (the heads are independent of each other): lists per tap of the arguments of lpips_layer
-    (latents None: the plain head for every tap).  dflats[i] = (flat bf16 tensor from trunk_alloc, N_total) takes the place of df0s[i]
-    (then None): the tap's gradient goes straight into the trunk's flat layout."""
+    (latents None: the plain head for every tap).  dflats[i] = (flat bf16 tensor from trunk_alloc, N_total[, yact]) takes the place of
+    df0s[i] (then None): the tap's gradient goes straight into the trunk's flat layout, gated by [yact > 0] when the tapped layer's
+    flat activation is given."""
     from ._lib import LpipsTap
     n = len(f0s)
     N = f0s[0].shape[0]
@@ -452,7 +453,8 @@ def lpips_layers(f0s, f1s, lins, latents, spline, n_knots, x_scale, scale, loss,
                           None if latents is None else latents[i].data_ptr(),
                           None if (df0s is None or df0s[i] is None) else df0s[i].data_ptr(),
                           None if (dlatents is None or latents is None) else dlatents[i].data_ptr(), None if ws is None else ws.data_ptr(),
-                          None if fl is None else fl[0].data_ptr(), 0 if fl is None else int(fl[1]), f0.shape[2], f0.shape[3])
+                          None if fl is None else fl[0].data_ptr(), 0 if fl is None else int(fl[1]), f0.shape[2], f0.shape[3],
+                          None if (fl is None or len(fl) < 3 or fl[2] is None) else fl[2].data_ptr())
     check(lib().npp_lpips_layers(n, arr, N, None if latents is None else _p(spline), n_knots if latents is not None else 0,
                                  x_scale if latents is not None else 0.0, scale, _p(loss), st), "npp_lpips_layers")
 
