@@ -79,7 +79,11 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   for (int c = threadIdx.x; c < C; c += 256) {
     slin[c] = lin[c];
     if (plain) continue;
+#ifdef NPP_DIAG_LP_NOPROLOGUE        // timing-only diagnostic (wrong results): the per-channel parameters from constants
+    ChanParams P{}; P.alpha = 1.5f; P.c = 0.7f; P.beta = 0.5f; P.logc_plus_logz = 0.1f; P.dlogz = 0.1f; P.dalpha_dl = 0.2f; P.dc_dl = 0.3f;
+#else
     const ChanParams P = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
+#endif
     LpChan L;
     L.e = 0.5f * P.alpha;
     L.inv_c = 1.0f / P.c;
@@ -96,6 +100,12 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   const int64_t npos = (int64_t)N * hw;
   const int64_t ngroups = (npos + PL - 1) / PL;
   float val = 0.0f;
+  // latent gradients: a thread owns the same Q channels in every group, so their sums over this block's groups stay in registers
+  // and meet the other PL position lanes ONCE after the loop (they were 2 x log2(PL) lane exchanges + an LDS update per channel and
+  // group: a quarter of the launch's vector instructions)
+  float acc_a[Q], acc_c[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { acc_a[q] = 0.0f; acc_c[q] = 0.0f; }
   for (int64_t grp = bid; grp < ngroups; grp += nb) {
     const int64_t t = grp * PL + pl;
     const bool live = t < npos;
@@ -152,28 +162,19 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
       } else if (live) {
         const float x = u[q] * i0 - v[q] * i1;
         const float xs = x * P.inv_c, ssx = xs * xs;
-        const float uu = fmaf(ssx, P.inv_beta, 1.0f), lnu = __logf(uu);
-        const float ue = __expf(P.e * lnu), ue1 = ue / uu;
+        const float uu = fmaf(ssx, P.inv_beta, 1.0f), lnu = __logf(uu), inv_uu = __builtin_amdgcn_rcpf(uu);
+        const float ue = __expf(P.e * lnu), ue1 = ue * inv_uu;
         val += l * (P.boa * (ue - 1.0f) + P.logc_plus_logz);
         if (grad) {
           const float d = l * coef * (x * P.inv_c2) * ue1;              // dL/d(normalised f0)_c
           dd[q] = d;
           dot = fmaf(d, u[q], dot);
-          da = l * coef * (-P.toa2 * (ue - 1.0f) + P.boa * ue * (0.5f * lnu + P.e_inv_b2 * ssx / uu) + P.dlogz);
+          da = l * coef * (-P.toa2 * (ue - 1.0f) + P.boa * ue * (0.5f * lnu + P.e_inv_b2 * ssx * inv_uu) + P.dlogz);
           dc = l * coef * (-(x * x) * P.x2_inv_c3 * ue1 + P.inv_c);
         }
       }
-      if (grad && !plain) {                                              // uniform branch
-#pragma unroll
-        for (int off = PL / 2; off > 0; off >>= 1) {                     // the PL positions of this channel lane
-          da += __shfl_xor(da, off, 64);
-          dc += __shfl_xor(dc, off, 64);
-        }
-        if (pl == 0) {                                                   // channel c belongs to this thread alone in the block
-          sdl[c] += da * P.dalpha_dl;
-          sdl[C + c] += dc * P.dc_dl;
-        }
-      }
+      acc_a[q] += da;
+      acc_c[q] += dc;
     }
     red[2][cl][pl] = dot;
     __syncthreads();
@@ -196,10 +197,29 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
       }
     }
   }
+  if (grad && !plain) {                                                  // uniform branch
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float da = acc_a[q], dc = acc_c[q];
+#pragma unroll
+      for (int off = PL / 2; off > 0; off >>= 1) {                       // the PL position lanes of this channel
+        da += __shfl_xor(da, off, 64);
+        dc += __shfl_xor(dc, off, 64);
+      }
+      if (pl == 0) {                                                     // channel c belongs to this thread alone in the block
+        const int c = cl + CL * q;
+        sdl[c] = da * scp[c].dalpha_dl;
+        sdl[C + c] = dc * scp[c].dc_dl;
+      }
+    }
+  }
   __syncthreads();
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
+#ifdef NPP_DIAG_LP_NOTAIL            // timing-only diagnostic (wrong results): no sums leave the block
+  return;
+#endif
   if (fix) {
     // Order-independent sums (round 4): every block adds its partials as 2^-40 fixed-point integers (integer addition is
     // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the
@@ -289,6 +309,10 @@ static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int
   const int PLr = few ? 4 : 16;
   const int64_t groups = (nh + PLr - 1) / PLr;
   T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
+  // (blocks per tap, measured on the five VGG16 taps of two 96^2 patches in one launch: cap 128 / 256 / 384 / 512 / 1024 = 58 / 64 / 68 /
+  //  68 / 82 us inside 'same' iterations -- more blocks mean more same-address atomics in the tail; 256 kept: best alone, 50.7 -> 47.3 us
+  //  after the latent-gradient exchanges left the group loop.  Timing-only builds (tools/r4_lp_heads_probe.py): without the tail
+  //  (atomics + last arriver) 38.1 us, without the per-channel prologue 42.7, neither 33.1; a tap alone 15-20 us.)
   T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)(groups < 256 ? groups : 256);
   T.coef = scale / (float)nh;                             // spatial mean and batch mean folded with the caller's weight
   if (yact && !dflat) { set_error("%s: yact gates the flat gradient (dflat)", who); return NPP_ERR_ARG; }
