@@ -143,6 +143,10 @@ class HipTrunk:
         self.fold_pool_bwd = os.environ.get("NPP_POOL_FOLD_BWD", "1") != "0"      # max-pool backward in the data-gradient launch above it
         self.fold_pool_fwd = os.environ.get("NPP_POOL_FOLD_FWD", "1") != "0"      # max-pool forward in the launch of the layer below it
         self.fold_pool_fwd_min_cin = int(os.environ.get("NPP_POOL_FOLD_FWD_MIN_CIN", "128"))
+        # max-pool forward in the operand staging of the layer above it (ops.conv3x3_poolin, the window-staged kernel): bit-identical, but
+        # measured SLOWER in the c2 iteration -- trunk forward 130.5 -> 133.8 us, same box (four strided 16-byte loads per window unit
+        # cost more than the 5.4-us pool launch they replace; profiles/r04_pool_fold_ab.txt 3.) -- hence opt-in
+        self.fold_pool_in = os.environ.get("NPP_POOL_FOLD_IN", "0") != "0"
 
     def twin(self):
         """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
@@ -151,6 +155,7 @@ class HipTrunk:
         t.device, t.taps, t.layers = self.device, self.taps, self.layers
         t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
         t.fold_pool_bwd, t.fold_pool_fwd, t.fold_pool_fwd_min_cin = self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin
+        t.fold_pool_in = self.fold_pool_in
         return t
 
     def _pb_below(self, j):
@@ -184,7 +189,7 @@ class HipTrunk:
         cur = self._flat("x0", N, 16, H, W)
         if not x0_ready:
             ops.trunk_image_in(x, scale, shift, cur)
-        c, outs, pooled = 16, [], None
+        c, outs, pooled, prepool = 16, [], None, None
         for j, L in enumerate(self.layers):
             if L["kind"] == "conv":
                 y = self._flat(("a", j), N, L["cout"], H, W)
@@ -194,7 +199,12 @@ class HipTrunk:
                     outs.append(tap)
                 nxt = next((M["pf"] for M in self.layers[j + 1:] if M["kind"] == "conv"), None) if self.prefetch_next else None
                 pooled = None
-                if (self.fold_pool_fwd and j + 1 < len(self.layers) and self.layers[j + 1]["kind"] == "pool" and H % 2 == 0
+                if prepool is not None:
+                    # the pool below rides in THIS launch's operand staging (ops.conv3x3_poolin): cur is the pre-pool tensor
+                    ops.conv3x3_poolin(prepool, N, nr, H, W, c, L["cout"], L["pf"], L["b"], y, tap, L["cout"] if tap is not None else 0,
+                                       next_pack=nxt)
+                    prepool = None
+                elif (self.fold_pool_fwd and j + 1 < len(self.layers) and self.layers[j + 1]["kind"] == "pool" and H % 2 == 0
                         and W % 2 == 0 and c >= self.fold_pool_fwd_min_cin):
                     # the pool that follows rides in this launch's epilogue (ops.conv3x3_pool): no maxpool2_fwd launch.  Measured in
                     # the c2 iteration (profiles/r04_pool_fold_ab.txt): conv2_2 18.3 + pool 4.8 -> 20.8 us; conv1_2, whose plain
@@ -208,7 +218,13 @@ class HipTrunk:
                 c = L["cout"]
             else:
                 y = self._flat(("a", j), N, c, H // 2, W // 2)
-                if pooled is None:
+                nx = self.layers[j + 1] if j + 1 < len(self.layers) else None
+                if pooled is not None:
+                    pass                                              # written by the launch of the layer below
+                elif (self.fold_pool_in and nx is not None and nx["kind"] == "conv" and L["idx"] not in self.taps and H % 2 == 0
+                        and W % 2 == 0 and ops.conv3x3_poolin_ok(N, nr, H // 2, W // 2, c, nx["cout"])):
+                    prepool = cur                                     # the layer above pools while it stages its operands; y stays unwritten
+                else:
                     ops.maxpool2_fwd(cur, N, H, W, c, y)
                 pooled = None
                 H, W = H // 2, W // 2

@@ -554,6 +554,19 @@ def conv3x3_pool(x, N_total, n_run, H, W, cin, cout, pack, bias, y, ypool, tap=N
                                  _p(next_pack), nb, _stream()), "npp_conv3x3_pool")
 
 
+def conv3x3_poolin_ok(N_total, n_run, H, W, cin, cout):
+    """Whether conv3x3_poolin takes this shape (H, W: the pooled geometry)."""
+    return bool(lib().npp_conv3x3_poolin_ok(N_total, n_run, H, W, cin, cout))
+
+
+def conv3x3_poolin(xpre, N_total, n_run, H, W, cin, cout, pack, bias, y, tap=None, ctap=0, tap_scale=None, next_pack=None):
+    """2 x 2 max-pool of xpre (geometry (2H, 2W)) + the forward layer on it in one launch (the pooled tensor is never written)."""
+    ts = None if tap_scale is None else (C.c_float * len(tap_scale))(*[float(v) for v in tap_scale])
+    nb = 0 if next_pack is None else next_pack.numel() * next_pack.element_size()
+    check(lib().npp_conv3x3_poolin(_p(xpre), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), _p(y), _p(tap), ctap, ts,
+                                   _p(next_pack), nb, _stream()), "npp_conv3x3_poolin")
+
+
 def conv3x3_dgrad_pool(x, N_total, n_run, H, W, cin, cout, pack, xpre, addend, dz, next_pack=None):
     """Data gradient of a convolution that reads a pooled tensor + the pool's backward + the pre-pool ReLU gate (+ tap gradient)
     in one launch; H, W: the pooled geometry, xpre / addend / dz: the pre-pool layer's flat tensors."""

@@ -187,7 +187,7 @@ def test_full_trunk_vs_torch_fp32(dev, name, P, n, ntot):
     assert rel_l2(dh[:n], dr[:n]) < 8e-2
 
 
-@pytest.mark.parametrize("name,P,n,ntot", [("vgg19", 96, 2, 8), ("vgg16", 96, 2, 4), ("vgg16", 48, 1, 3), ("vgg19", 40, 3, 3)])
+@pytest.mark.parametrize("name,P,n,ntot", [("vgg19", 96, 2, 12), ("vgg16", 96, 2, 4), ("vgg16", 48, 1, 3), ("vgg19", 40, 3, 3)])
 def test_pools_folded_into_their_neighbouring_convolutions_are_bit_identical(dev, name, P, n, ntot):
     """npp_conv3x3_pool (a forward layer + the max-pool after it, two-row position tiles) against npp_conv3x3 -> npp_maxpool2_fwd,
     and npp_conv3x3_dgrad_pool (the data gradient of the convolution above a pool + the pool's backward + the pre-pool ReLU gate +
@@ -203,7 +203,7 @@ def test_pools_folded_into_their_neighbouring_convolutions_are_bit_identical(dev
     gs = None
     for fold in (True, False):
         hip = HipTrunk(cfg, taps, state_dict=sd, device=dev)
-        hip.fold_pool_bwd = hip.fold_pool_fwd = fold
+        hip.fold_pool_bwd = hip.fold_pool_fwd = hip.fold_pool_in = fold
         hip.fold_pool_fwd_min_cin = 32                         # every pool of the stack, conv1_2's too
         xh = x.clone().requires_grad_(True)
         got = hip(xh, n, (4.3, 4.4, 4.5), (-2.1, -2.0, -1.8))
@@ -217,6 +217,19 @@ def test_pools_folded_into_their_neighbouring_convolutions_are_bit_identical(dev
         assert np.abs(a).max() > 0
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(grads[0], grads[1])
+    if name == "vgg19" and P == 96:
+        # at the loop's size: pool1 in the operand staging of conv2_1 (npp_conv3x3_poolin, the window-staged kernel), pool2 in
+        # conv2_2's epilogue -- against all folds off
+        from npp_amd import ops
+        assert ops.conv3x3_poolin_ok(ntot, ntot, P // 2, P // 2, 64, 128)
+        hip = HipTrunk(cfg, taps, state_dict=sd, device=dev)
+        hip.fold_pool_in = True                                  # (opt-in: measured slower than the pool launch it replaces)
+        xh = x.clone().requires_grad_(True)
+        got = hip(xh, n, (4.3, 4.4, 4.5), (-2.1, -2.0, -1.8))
+        sum((g[:n] * G).sum() for g, G in zip(got, gs)).backward()
+        for a, b in zip([g[:n].detach().cpu().numpy() for g in got], feats[1]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(xh.grad.cpu().numpy(), grads[1])
 
 
 @pytest.mark.parametrize("name,H,W", [("vgg19", 72, 340), ("vgg16", 291, 330)])
