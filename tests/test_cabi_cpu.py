@@ -301,3 +301,35 @@ def test_pack_scatter_inverse_maps_reproduce_the_packers(K, width):
     check(L.npp_pack_scatter_host(flat.ctypes.data, s_f.ctypes.data, s_b.ctypes.data, K, width), "pack_scatter_host")
     assert np.array_equal(a_f, s_f)
     assert np.array_equal(a_b, s_b)
+
+
+def test_pool_fold_entry_points_validate_on_the_host():
+    """The pools folded into their neighbouring convolutions (csrc/npp_conv.hip): the shape query of the window-staged form and the
+    argument checks that come before any launch."""
+    from npp_amd._lib import LpipsTap
+    L = npp_amd.lib()
+    fake = C.c_void_p(64)
+    # npp_conv3x3_poolin_ok: the loop's conv2_1 on twelve 96^2 patches is taken; four patches are too few workgroups, 128 input
+    # channels too many channel steps, an odd output-channel block count no 64-channel workgroup
+    assert L.npp_conv3x3_poolin_ok(12, 12, 48, 48, 64, 128) == 1
+    assert L.npp_conv3x3_poolin_ok(4, 4, 48, 48, 64, 128) == 0
+    assert L.npp_conv3x3_poolin_ok(12, 12, 24, 24, 128, 256) == 0
+    assert L.npp_conv3x3_poolin_ok(12, 12, 48, 48, 64, 96) == 0
+    assert L.npp_conv3x3_poolin_ok(12, 13, 48, 48, 64, 128) == 0
+    assert L.npp_conv3x3_poolin(fake, 4, 4, 48, 48, 64, 128, fake, fake, fake, None, 0, None, None, 0, None) < 0
+    assert b"npp_conv3x3_poolin_ok" in L.npp_last_error_string()
+    assert L.npp_conv3x3_pool(fake, 2, 2, 47, 48, 64, 64, fake, fake, fake, fake, None, 0, None, None, 0, None) < 0            # odd H
+    assert b"even" in L.npp_last_error_string()
+    assert L.npp_conv3x3_pool(fake, 2, 2, 48, 48, 64, 64, fake, fake, fake, None, None, 0, None, None, 0, None) < 0            # no pooled output
+    assert L.npp_conv3x3_dgrad_pool(fake, 2, 2, 24, 24, 128, 64, fake, None, None, fake, None, 0, None) < 0                    # no pre-pool tensor
+    assert b"pre-pool" in L.npp_last_error_string()
+    assert L.npp_conv3x3_dgrad_pool(fake, 2, 3, 24, 24, 128, 64, fake, fake, None, fake, None, 0, None) < 0                    # n_run > N_total
+    # npp_lpips_tap.dflat takes the place of df0 and needs the tap's geometry
+    t = (LpipsTap * 1)()
+    t[0] = LpipsTap(64, 64, 64, 16, 64, None, 64, None, None, 64, 2, 4, 4, None)                 # df0 AND dflat
+    assert L.npp_lpips_layers(1, t, 2, None, 0, 0.0, 1.0, fake, None) < 0
+    assert b"flat gradient" in L.npp_last_error_string()
+    t[0] = LpipsTap(64, 64, 64, 16, 64, None, None, None, None, 64, 2, 4, 5, None)               # H * W != hw
+    assert L.npp_lpips_layers(1, t, 2, None, 0, 0.0, 1.0, fake, None) < 0
+    t[0] = LpipsTap(64, 64, 64, 16, 64, None, None, None, None, None, 2, 4, 4, 64)               # yact without dflat
+    assert L.npp_lpips_layers(1, t, 2, None, 0, 0.0, 1.0, fake, None) < 0
