@@ -1242,7 +1242,10 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   }
   for (const Cand& c : cands) {
     if (found) break;
-    if (feasible(c) && wgs(c) >= c.min_wgs) { pick = c; found = true; }
+    // (two-row tiles of the pool fold waste columns on narrow maps -- 12 of 16 on VGG16's conv4_3 -- which must not push the
+    //  launch to a smaller tile than the plain layer beside it runs with: 192 workgroups of 2 x 1 tiles beat 384 of 1 x 1)
+    const int64_t need = mode == kConvFwdPool ? c.min_wgs * 9 / 10 : c.min_wgs;
+    if (feasible(c) && wgs(c) >= need) { pick = c; found = true; }
   }
   // window-staged form (conv3x3_win_kernel): few input-channel steps, many positions, 64-channel output blocks
   static const int win_mode = getenv("NPP_CONV_WIN") ? atoi(getenv("NPP_CONV_WIN")) : 1;     // 0: never (A/B comparator)
