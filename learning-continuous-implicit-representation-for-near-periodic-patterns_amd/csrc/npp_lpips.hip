@@ -244,7 +244,15 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
 
 // One launch for up to five taps (blockIdx.y = tap): the heads of LPIPS.forward are independent of each other, and in a row they were
 // 100 us (15-25 us each) of the 'same' iteration's longer chain.
-__global__ __launch_bounds__(256) void lpips_multi_kernel(LpMulti m) {
+// MAXQ: the largest number of channels per thread among the instantiations a variant carries.  A kernel's register count is the
+// maximum over everything inlined into it: with the 32-channel case in (512 channels at 16 positions per block: 256 VGPRs + 182 AGPRs)
+// EVERY tap ran at one wave per SIMD = one block per CU, and the five taps of a grouped launch queued behind each other on each CU
+// (found late in round 4 with -Rpass-analysis=kernel-resource-usage).  The host picks the smallest variant that holds all taps.
+#ifndef NPP_LP_MINBLOCKS
+#define NPP_LP_MINBLOCKS 4         // blocks per CU the 8-channel variant is compiled for (4: 128 VGPRs with 31 spilled; 3: 152, none)
+#endif
+template <int MAXQ>
+__global__ __launch_bounds__(256, MAXQ <= 8 ? NPP_LP_MINBLOCKS : 1) void lpips_multi_kernel(LpMulti m) {
   extern __shared__ __attribute__((aligned(16))) char lp_smem[];
   const int y = blockIdx.y;
   LpTap T = m.t[0];
@@ -269,10 +277,10 @@ __global__ __launch_bounds__(256) void lpips_multi_kernel(LpMulti m) {
       case 32: NPP_LP_CASE(2, 16); break;
       case 64: NPP_LP_CASE(4, 16); break;
       case 128: NPP_LP_CASE(8, 16); break;
-      case 192: NPP_LP_CASE(12, 16); break;
-      case 256: NPP_LP_CASE(16, 16); break;
-      case 384: NPP_LP_CASE(24, 16); break;
-      default: NPP_LP_CASE(32, 16); break;
+      case 192: if constexpr (MAXQ >= 16) NPP_LP_CASE(12, 16); break;
+      case 256: if constexpr (MAXQ >= 16) NPP_LP_CASE(16, 16); break;
+      case 384: if constexpr (MAXQ >= 32) NPP_LP_CASE(24, 16); break;
+      default: if constexpr (MAXQ >= 32) NPP_LP_CASE(32, 16); break;
     }
   }
 #undef NPP_LP_CASE
@@ -305,7 +313,10 @@ static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int
     return NPP_ERR_ARG;
   }
   const int64_t nh = (int64_t)N * hw;
-  const bool few = nh <= 1024 && (C % 64) == 0;           // deep taps: 4 positions x 64 channel lanes per block
+  // deep taps: 4 positions x 64 channel lanes per block.  (2048: VGG16's relu3_3 of two 96^2 patches -- 1152 positions x 256
+  // channels -- takes 288 four-position groups of 4 channels per thread instead of 72 sixteen-position groups of 16: every tap of the
+  // loop then fits the 8-channel variant of the kernel, four blocks per CU.)
+  const bool few = nh <= 2048 && (C % 64) == 0;
   const int PLr = few ? 4 : 16;
   const int64_t groups = (nh + PLr - 1) / PLr;
   T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
@@ -327,9 +338,21 @@ static int lp_launch(LpMulti& m, void* stream, const char* who) {
     const int b = lp_smem_bytes(m.t[i].C, m.t[i].few ? 4 : 16);
     smem = b > smem ? b : smem;
   }
-  static SmemOnce once;
-  if (!smem_attr(once, (const void*)lpips_multi_kernel, lp_smem_bytes(kLpipsMaxC, 4))) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
-  hipLaunchKernelGGL(lpips_multi_kernel, dim3((unsigned)nb, (unsigned)m.n_taps), dim3(256), (size_t)smem, (hipStream_t)stream, m);
+  int maxq = 8;                                             // channels per thread of the widest tap (few: C / 64, else C / 16)
+  for (int i = 0; i < m.n_taps; ++i) {
+    const int q = m.t[i].few ? m.t[i].C / 64 : m.t[i].C / 16;
+    maxq = q > maxq ? q : maxq;
+  }
+#define NPP_LP_GO(MQ)                                                                                                                  \
+  do {                                                                                                                                 \
+    static SmemOnce once;                                                                                                              \
+    if (!smem_attr(once, (const void*)lpips_multi_kernel<MQ>, lp_smem_bytes(kLpipsMaxC, 4))) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; } \
+    hipLaunchKernelGGL(lpips_multi_kernel<MQ>, dim3((unsigned)nb, (unsigned)m.n_taps), dim3(256), (size_t)smem, (hipStream_t)stream, m); \
+  } while (0)
+  if (maxq <= 8) NPP_LP_GO(8);
+  else if (maxq <= 16) NPP_LP_GO(16);
+  else NPP_LP_GO(32);
+#undef NPP_LP_GO
   return check_launch(who);
 }
 
