@@ -46,7 +46,9 @@ namespace npp {
 constexpr int kConvRing = NPP_CONV_RING;
 static_assert(kConvRing == 3 || kConvRing == 9, "ring depth");
 
-enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2, kConvFwdPool = 3 };   // 3: internal (npp_conv3x3_pool)
+enum ConvMode : int { kConvFwd = 0, kConvDgradMask = 1, kConvDgradLin = 2, kConvFwdPool = 3, kConvDgradPool = 4 };   // 3, 4: internal
+// (npp_conv3x3_pool / npp_conv3x3_dgrad_pool: instantiations of their own, so that the folds' prefetch registers -- up to 256 VGPRs in the
+// one-wave tiles -- are not carried by the plain modes)
 
 struct ConvArgs {
   const void* x;         // flat input, Cin channels
@@ -181,10 +183,10 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   constexpr int NF = S == 1 ? NT : (NT + S - 1) / S;          // tiles finished by one wave
   f16x8 gate[MODE == kConvDgradMask ? NF : 1][2];
   float bias_r[FWD ? NF : 1][16];
-  constexpr bool kPoolable = MODE == kConvDgradLin;
+  constexpr bool kPoolable = MODE == kConvDgradPool;
   f16x8 pwin[kPoolable ? NF : 1][2][4];                    // folded pool backward: the four pre-pool units of my window per chunk
   bf16x8 padd[kPoolable ? NF : 1][2][4];
-  const bool pool_fold = kPoolable && a.pool_x != nullptr;
+  constexpr bool pool_fold = kPoolable;
 #pragma unroll
   for (int q = 0; q < NF; ++q) {
     const int t = S == 1 ? q : wave + q * S;
@@ -1093,6 +1095,7 @@ static int conv_launch_mode(const ConvArgs& a, int mode, dim3 grid, hipStream_t 
   if (mode == kConvFwd) NPP_CONV_GO(kConvFwd);
   else if (mode == kConvDgradMask) NPP_CONV_GO(kConvDgradMask);
   else if (mode == kConvFwdPool) NPP_CONV_GO(kConvFwdPool);
+  else if (mode == kConvDgradPool) NPP_CONV_GO(kConvDgradPool);
   else NPP_CONV_GO(kConvDgradLin);
 #undef NPP_CONV_GO
   return NPP_OK;
@@ -1216,6 +1219,7 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
     a.pool_x = fold->x; a.pool_add = fold->add; a.pool_dz = fold->dz;
     a.pool_nposp = conv_nposp(N_total, 2 * H, 2 * W);
     a.y = nullptr;
+    mode = kConvDgradPool;
   }
   hipStream_t s = (hipStream_t)stream;
   // Tile choice: the largest output tile per workgroup (fewest operand bytes per MFMA) that still yields about one
