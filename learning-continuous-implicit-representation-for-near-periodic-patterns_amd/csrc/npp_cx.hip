@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "npp_common.h"
+#include <type_traits>
 #include "npp_trunk_layout.h"
 
 namespace npp {
@@ -142,7 +143,13 @@ __global__ void cx_mean_kernel(const float* __restrict__ y, int N, int C, int hw
 // Workgroup = 64 x 64 output tile of one sample, 4 waves of 32 x 32; the channel axis is streamed
 // through LDS in chunks of 32 ([32 c][64 pos] per operand, positions contiguous as in NCHW, so the
 // fp32 MFMA operand reads are conflict-free), double buffered.
-constexpr int kCxKc = 32;
+#ifndef NPP_CX_KC
+#define NPP_CX_KC 32
+#endif
+constexpr int kCxKc = NPP_CX_KC;           // channels per staged chunk (32 or 64: measured the same, 23.6 / 23.3 us at the loop's size;
+                                           // timing-only builds: without the MFMAs 20.6, without the D stores 23.5, without the row-minimum
+                                           // atomics 21.8 -- ~15 us of the launch are none of these, tools/r4_cx_variants.sh)
+constexpr int kCxNR = kCxKc / 16;          // rows of a chunk per thread
 __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x, const float* __restrict__ y, int N,
                                                      int C, int hw, CxWs w) {
   __shared__ __attribute__((aligned(16))) float sA[2][kCxKc][64];
@@ -159,30 +166,31 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   const float* yn = y + (int64_t)n * C * hw;
   const bool vec = (hw & 3) == 0;
   const float* mu = cx_mu(w, n);
-  float4 ra[2], rb[2];
-  auto gload = [&](int c0) {
+  // Operand staging, round 4 (late): TWO chunks in flight in registers.  The first form loaded chunk c + 1, centred it and summed its
+  // squares right away -- the first use of the loaded values sat in front of chunk c's MFMAs, so every chunk waited for its own load
+  // (the features were just written by the trunk's last layer from other XCDs: ~1.5 us each, 8 chunks in a row) and nothing
+  // overlapped.  Now the raw loads of chunk c + 2 are issued, chunk c is multiplied out of LDS, and only then chunk c + 1 (requested
+  // a whole chunk earlier) is centred, squared and stored.  Same arithmetic in the same order: bit-identical.
+  struct Raw { float4 a[kCxNR], b[kCxNR]; float m[kCxNR]; };      // (the channel means travel with the chunk: a load of their own in front of the
+                                                      //  centring would be waited for in every chunk)
+  Raw R[2];
+  auto gissue = [&](int c0, Raw& q) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kCxNR; ++r) {
       const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
       const int c = c0 + row;
-      const float m = c < C ? mu[c] : 0.0f;
       float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+      q.m[r] = 0.0f;
       if (c < C) {
-        if (vec && i0 + col + 3 < hw) { const float4 q = *(const float4*)(xn + (int64_t)c * hw + i0 + col); va[0] = q.x; va[1] = q.y; va[2] = q.z; va[3] = q.w; }
+        const float m = mu[c];
+        q.m[r] = m;
+        if (vec && i0 + col + 3 < hw) { const float4 t = *(const float4*)(xn + (int64_t)c * hw + i0 + col); va[0] = t.x; va[1] = t.y; va[2] = t.z; va[3] = t.w; }
         else for (int e = 0; e < 4; ++e) if (i0 + col + e < hw) va[e] = xn[(int64_t)c * hw + i0 + col + e]; else va[e] = m;
-        if (vec && j0 + col + 3 < hw) { const float4 q = *(const float4*)(yn + (int64_t)c * hw + j0 + col); vb[0] = q.x; vb[1] = q.y; vb[2] = q.z; vb[3] = q.w; }
+        if (vec && j0 + col + 3 < hw) { const float4 t = *(const float4*)(yn + (int64_t)c * hw + j0 + col); vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w; }
         else for (int e = 0; e < 4; ++e) if (j0 + col + e < hw) vb[e] = yn[(int64_t)c * hw + j0 + col + e]; else vb[e] = m;
       }
-      ra[r] = make_float4(va[0] - m, va[1] - m, va[2] - m, va[3] - m);
-      rb[r] = make_float4(vb[0] - m, vb[1] - m, vb[2] - m, vb[3] - m);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
-      *(float4*)&sA[buf][row][col] = ra[r];
-      *(float4*)&sB[buf][row][col] = rb[r];
+      q.a[r] = make_float4(va[0], va[1], va[2], va[3]);
+      q.b[r] = make_float4(vb[0], vb[1], vb[2], vb[3]);
     }
   };
   f32x16 acc;
@@ -192,30 +200,45 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   // operands every thread stages anyway (2 rows x 4 columns per chunk), instead of in a launch of their own (cx_sumsq_kernel:
   // 7 us of launch ramp for 0.2 us of arithmetic).  Every tile sums in the same order, so the tiles of a row agree bit for bit.
   float qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
-  auto sq = [&]() {
+  // centre chunk c0 (in q), add its squares, store it as LDS buffer buf
+  auto gfinish = [&](int c0, const Raw& q, int buf) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      qa[0] = fmaf(ra[r].x, ra[r].x, qa[0]); qa[1] = fmaf(ra[r].y, ra[r].y, qa[1]); qa[2] = fmaf(ra[r].z, ra[r].z, qa[2]); qa[3] = fmaf(ra[r].w, ra[r].w, qa[3]);
-      qb[0] = fmaf(rb[r].x, rb[r].x, qb[0]); qb[1] = fmaf(rb[r].y, rb[r].y, qb[1]); qb[2] = fmaf(rb[r].z, rb[r].z, qb[2]); qb[3] = fmaf(rb[r].w, rb[r].w, qb[3]);
+    for (int r = 0; r < kCxNR; ++r) {
+      const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
+      const float m = q.m[r];
+      const float4 ra = make_float4(q.a[r].x - m, q.a[r].y - m, q.a[r].z - m, q.a[r].w - m);
+      const float4 rb = make_float4(q.b[r].x - m, q.b[r].y - m, q.b[r].z - m, q.b[r].w - m);
+      qa[0] = fmaf(ra.x, ra.x, qa[0]); qa[1] = fmaf(ra.y, ra.y, qa[1]); qa[2] = fmaf(ra.z, ra.z, qa[2]); qa[3] = fmaf(ra.w, ra.w, qa[3]);
+      qb[0] = fmaf(rb.x, rb.x, qb[0]); qb[1] = fmaf(rb.y, rb.y, qb[1]); qb[2] = fmaf(rb.z, rb.z, qb[2]); qb[3] = fmaf(rb.w, rb.w, qb[3]);
+      *(float4*)&sA[buf][row][col] = ra;
+      *(float4*)&sB[buf][row][col] = rb;
     }
   };
-  gload(0);
-  sq();
-  sstore(0);
+  gissue(0, R[0]);
+  if (kCxKc < C) gissue(kCxKc, R[1]);
+  gfinish(0, R[0], 0);
   __syncthreads();
-  int buf = 0;
-  for (int c0 = 0; c0 < C; c0 += kCxKc) {
+  // one chunk; PAR = (c0 / kCxKc) % 2 at compile time: chunk c0 sits in LDS buffer PAR, chunk c0 + 1 in register set PAR ^ 1, set PAR is free
+  auto chunk = [&](int c0, auto par_) {
+    constexpr int PAR = decltype(par_)::value;
     const bool has_next = c0 + kCxKc < C;
-    if (has_next) { gload(c0 + kCxKc); sq(); }
+    if (c0 + 2 * kCxKc < C) gissue(c0 + 2 * kCxKc, R[PAR]);
 #pragma unroll
     for (int ks = 0; ks < kCxKc / 2; ++ks) {
-      const float a = sA[buf][2 * ks + kh][wi * 32 + l31];
-      const float b = sB[buf][2 * ks + kh][wj * 32 + l31];
+      const float a = sA[PAR][2 * ks + kh][wi * 32 + l31];
+      const float b = sB[PAR][2 * ks + kh][wj * 32 + l31];
+#ifdef NPP_DIAG_CXSIM_NOMFMA          // timing-only diagnostics (wrong results): tools/cx_probe.py under rocprofv3
+      asm volatile("" :: "v"(a), "v"(b));
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#endif
     }
-    if (has_next) sstore(buf ^ 1);
+    if (has_next) gfinish(c0 + kCxKc, R[PAR ^ 1], PAR ^ 1);
     __syncthreads();
-    buf ^= 1;
+  };
+  for (int c0 = 0; c0 < C; c0 += 2 * kCxKc) {
+    chunk(c0, std::integral_constant<int, 0>{});
+    if (c0 + kCxKc < C) chunk(c0 + kCxKc, std::integral_constant<int, 1>{});
   }
   // the 16 row classes' partials (thread tid holds rows tid >> 4 and 16 + (tid >> 4) of every chunk) meet in LDS, summed in class order
   float* ssl = &sA[0][0][0];                           // [2][16][64] floats: the operand buffers are idle now
@@ -248,12 +271,16 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     if (i < hw && j < hw) {
       const float raw = acc[r] * inv_norm(ssn[wi * 32 + acc_row(r, kh)]) * sj;
       d = 1.0f - fminf(fmaxf(raw, 0.0f), 1.0f);
+#ifndef NPP_DIAG_CXSIM_NOSTORE
       w.D[((int64_t)n * hw + i) * hw + j] = d;
+#endif
     }
     float m = d;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+#ifndef NPP_DIAG_CXSIM_NOMIN
     if (l31 == 0 && i < hw) atomicMin(&w.dmin[(int64_t)n * hw + i], __float_as_uint(m));
+#endif
   }
 }
 
