@@ -686,6 +686,97 @@ __global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ 
   if (kh == 0) w.dot[(int64_t)tc * N * hw + (int64_t)n * hw + i] = part;        // one partial per channel tile, summed by cx_dx_finish
 }
 
+// The same contraction with its operands staged through LDS (round 4, late).  In cx_dx32_kernel every lane streams ITS OWN row of both
+// operands: one load instruction touches 64 different 128-byte lines and uses 16 bytes of each, four waves per CU keep ~64 KiB of
+// half-used lines alive in a 32-KiB L1, lines are evicted before their fourth use, and the four waves of a workgroup fetch the same 32
+// rows of the contextual weights independently: 30 us for 7.7 us of dependent MFMAs per wave.  Here the workgroup stages, per block of
+// 32 contraction columns, the weights' [32 positions][32 columns] block ONCE for its four waves and each wave's [32 channels][32 columns]
+// block of centred, scaled features, with row-contiguous 128-byte global reads (8 threads per row), into k-major LDS tiles of stride 33
+// (fragment reads conflict-free), double buffered through registers.  The MFMAs consume the columns in the SAME order as
+// cx_dx32_kernel (k-step e of the 8-column group t = columns 8t + e | 8t + 4 + e): bit-identical results.
+constexpr int kDxLd = 33;
+__global__ __launch_bounds__(256) void cx_dx32s_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C,
+                                                       int hw, CxWs w, float* __restrict__ dxh) {
+  __shared__ float sY[2][4][32][kDxLd];                 // [buffer][wave's channel tile][column k][channel]
+  __shared__ float sD[2][32][kDxLd];                    // [buffer][column k][position]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+  const int t32 = hw / 32, ct = C / 32, cg = ct / 4 + (ct % 4 ? 1 : 0);    // 4 waves: 4 channel tiles of one position tile
+  const int lb = xcd_block(N * t32 * cg);
+  if (lb < 0) return;                                   // (whole block)
+  const int n = lb / (t32 * cg);
+  const int rem = lb - n * t32 * cg;
+  const int ti = rem / cg, tc0 = (rem - ti * cg) * 4, tc = tc0 + wave;
+  const int i0 = ti * 32, c0 = tc * 32;
+  const float* mup = cx_mu(w, n);
+  // staging role of this thread: row srow (a position of the weights block / a channel of every feature block), columns 4 scol .. + 3
+  const int srow = tid >> 3, scol = tid & 7;
+  const float4* dsrc = (const float4*)(w.cx + ((int64_t)n * hw + i0 + srow) * hw) + scol;
+  const float4* ssrc = (const float4*)(w.iny + (int64_t)n * hw) + scol;
+  const float4* ysrc[4];
+  float mus[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = (tc0 + q) * 32 + srow;
+    const bool ok = c < C;
+    ysrc[q] = (const float4*)(y + ((int64_t)n * C + (ok ? c : 0)) * hw) + scol;
+    mus[q] = ok ? mup[c] : 0.0f;
+  }
+  struct Raw { float4 d, s, yv[4]; };
+  Raw R;
+  auto gissue = [&](int jb) {                            // block jb = columns 32 jb .. 32 jb + 31 (float4 index 8 jb + scol)
+    R.d = dsrc[8 * jb];
+    R.s = ssrc[8 * jb];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R.yv[q] = ysrc[q][8 * jb];
+  };
+  auto sstore = [&](int buf) {
+    const int k0 = 4 * scol;
+    sD[buf][k0 + 0][srow] = R.d.x; sD[buf][k0 + 1][srow] = R.d.y; sD[buf][k0 + 2][srow] = R.d.z; sD[buf][k0 + 3][srow] = R.d.w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float m = mus[q];
+      sY[buf][q][k0 + 0][srow] = (R.yv[q].x - m) * R.s.x; sY[buf][q][k0 + 1][srow] = (R.yv[q].y - m) * R.s.y;
+      sY[buf][q][k0 + 2][srow] = (R.yv[q].z - m) * R.s.z; sY[buf][q][k0 + 3][srow] = (R.yv[q].w - m) * R.s.w;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const int nblk = hw / 32;
+  gissue(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int jb = 0; jb < nblk; ++jb) {
+    const bool has_next = jb + 1 < nblk;
+    if (has_next) gissue(jb + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 8 * t + 4 * kh + e;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sY[buf][wave][k][l31], sD[buf][k][l31], acc, 0, 0, 0);
+      }
+    if (has_next) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (tc >= ct) return;                                  // (after the last barrier)
+  // accumulator: column = position (lane & 31), rows = channels
+  const int i = i0 + l31;
+  const float inx = w.inx[(int64_t)n * hw + i];
+  float part = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + acc_row(r, kh);
+    const int64_t o = ((int64_t)n * C + c) * hw + i;
+    dxh[o] = acc[r];
+    part = fmaf((x[o] - mup[c]) * inx, acc[r], part);
+  }
+  part += __shfl_xor(part, 32, 64);
+  if (kh == 0) w.dot[(int64_t)tc * N * hw + (int64_t)n * hw + i] = part;        // one partial per channel tile, summed by cx_dx_finish
+}
+
 // cx_dx32_kernel + cx_dx_finish_flat_kernel in ONE launch for C = 256 (the loop's tap, relu3_4): a workgroup of EIGHT waves owns all
 // eight 32-channel tiles of one 32-position tile, so the per-position dot product xh . dxh is complete inside the workgroup (LDS,
 // summed in tile order like the finish kernel did) and every lane can finish its own two 16-byte units -- an accumulator tile converted
@@ -927,7 +1018,9 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
     }
     if (fast) {
       const int64_t nb_dx = (int64_t)N * t32 * ((C / 32 + 3) / 4);
-      hipLaunchKernelGGL(cx_dx32_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
+      static const bool staged = !(getenv("NPP_CX_DX_LDS") && atoi(getenv("NPP_CX_DX_LDS")) == 0);      // 0: the row-streaming form (comparator)
+      if (staged) hipLaunchKernelGGL(cx_dx32s_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
+      else hipLaunchKernelGGL(cx_dx32_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
     }
     else
       hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,

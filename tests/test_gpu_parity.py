@@ -250,6 +250,25 @@ def test_cx_core_five_launch_form_equals_the_six_launch_form(dev, tmp_path):
     assert np.array_equal(a, b) and np.any(a != 0)
 
 
+def test_cx_backward_contraction_staged_through_lds_equals_the_row_streaming_form(dev, tmp_path):
+    """cx_dx32s_kernel (the backward contraction with both operands staged through LDS: the shipped form) against cx_dx32_kernel
+    (NPP_CX_DX_LDS=0: every lane streams its own rows): same column order per MFMA, so the flat gradient tensor and the loss are the
+    same bits.  The switch is read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"cxl{flag}.npz")
+        env = dict(os.environ, NPP_CX_DX_LDS=flag, NPP_CX_DX_FUSED="0")
+        r = subprocess.run([sys.executable, "-c", _CX_FLAT_SNIPPET, ROOT, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0]["loss"] == outs[1]["loss"]
+    a, b = outs[0]["dz"], outs[1]["dz"]
+    assert np.array_equal(a, b) and np.any(a != 0)
+
+
 def test_lpips_heads_in_one_launch_equal_the_five_launches(dev):
     """npp_lpips_layers (blockIdx.y = tap) against five npp_lpips_layer calls on VGG16-shaped taps: loss word (the fixed-point sums are
     order-independent), feature gradients and latent gradients bit for bit; adaptive and plain heads."""
