@@ -63,6 +63,7 @@ struct CxWs {           // workspace carve (floats unless noted)
   // sample groups (npp_cx_fwd_bwd_groups): group m = the nk samples from batch index iter[m].x0 on; iter == null: one group of N
   const StackIter* iter;
   int32_t M, mu_stride, N, dot_slots;
+  int32_t min_in_rows;  // the row pass (cx_rows_fwd32_kernel) takes the row minima of D itself: cx_sim_kernel issues no atomicMin
 };
 // group of sample n and the group's sample count
 __device__ __forceinline__ int cx_group(const CxWs& w, int n, int& ng) {
@@ -85,7 +86,7 @@ __host__ __device__ inline int64_t cx_ws_floats(int N, int C, int hw) {
 __host__ inline CxWs carve(float* base, int N, int C, int hw, const void* iter = nullptr, int M = 0) {
   CxWs w;
   float* p = base;
-  w.iter = (const StackIter*)iter; w.M = M; w.N = N; w.mu_stride = (C + 15) / 16 * 16; w.dot_slots = C / 32;
+  w.iter = (const StackIter*)iter; w.M = M; w.N = N; w.mu_stride = (C + 15) / 16 * 16; w.dot_slots = C / 32; w.min_in_rows = 0;
   w.mu = p; p += (int64_t)(M > 0 ? M : 1) * w.mu_stride;
   const int64_t nh = (int64_t)N * hw;
   w.ssx = p; p += nh;
@@ -171,6 +172,12 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   // (the features were just written by the trunk's last layer from other XCDs: ~1.5 us each, 8 chunks in a row) and nothing
   // overlapped.  Now the raw loads of chunk c + 2 are issued, chunk c is multiplied out of LDS, and only then chunk c + 1 (requested
   // a whole chunk earlier) is centred, squared and stored.  Same arithmetic in the same order: bit-identical.
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
+  auto body = [&](auto full_) {
+  constexpr bool FULL = decltype(full_)::value;
   struct Raw { float4 a[kCxNR], b[kCxNR]; float m[kCxNR]; };      // (the channel means travel with the chunk: a load of their own in front of the
                                                       //  centring would be waited for in every chunk)
   Raw R[2];
@@ -179,6 +186,12 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     for (int r = 0; r < kCxNR; ++r) {
       const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
       const int c = c0 + row;
+      if constexpr (FULL) {                              // whole tile inside the map, whole chunks: no predicate per element
+        q.m[r] = mu[c];
+        q.a[r] = *(const float4*)(xn + (int64_t)c * hw + i0 + col);
+        q.b[r] = *(const float4*)(yn + (int64_t)c * hw + j0 + col);
+        continue;
+      }
       float va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
       q.m[r] = 0.0f;
       if (c < C) {
@@ -193,13 +206,9 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
       q.b[r] = make_float4(vb[0], vb[1], vb[2], vb[3]);
     }
   };
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   // Round 4: the squared norms sum_c (x - mu)^2, (y - mu)^2 of the tile's 64 + 64 positions are summed HERE, from the centred
   // operands every thread stages anyway (2 rows x 4 columns per chunk), instead of in a launch of their own (cx_sumsq_kernel:
   // 7 us of launch ramp for 0.2 us of arithmetic).  Every tile sums in the same order, so the tiles of a row agree bit for bit.
-  float qa[4] = {0, 0, 0, 0}, qb[4] = {0, 0, 0, 0};
   // centre chunk c0 (in q), add its squares, store it as LDS buffer buf
   auto gfinish = [&](int c0, const Raw& q, int buf) {
 #pragma unroll
@@ -240,6 +249,9 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     chunk(c0, std::integral_constant<int, 0>{});
     if (c0 + kCxKc < C) chunk(c0 + kCxKc, std::integral_constant<int, 1>{});
   }
+  };
+  if (vec && i0 + 64 <= hw && j0 + 64 <= hw && C % kCxKc == 0) body(std::true_type{});      // (block-uniform)
+  else body(std::false_type{});
   // the 16 row classes' partials (thread tid holds rows tid >> 4 and 16 + (tid >> 4) of every chunk) meet in LDS, summed in class order
   float* ssl = &sA[0][0][0];                           // [2][16][64] floats: the operand buffers are idle now
   {
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
       w.D[((int64_t)n * hw + i) * hw + j] = d;
 #endif
     }
+    if (w.min_in_rows) continue;                       // (uniform) the block-parallel row pass reads the whole row anyway: 3 us of atomics saved
     float m = d;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
@@ -870,17 +883,41 @@ __global__ __launch_bounds__(64 * kCxRowWaves) void cx_rows_fwd32_kernel(int N, 
   for (int rr = 0; rr < kCxRowsPerWave; ++rr) {
     if (r0 + rr >= hw) break;
     const int64_t row = (int64_t)n * hw + r0 + rr;
-    const float dm = __uint_as_float(w.dmin[row]) + 1e-5f;
     const float* Dr = w.D + row * hw;
     float* cr = w.cx + row * hw;
     float wv[kCxMaxCols];
     float s = 0.0f;
+    float dm;
+    if (w.min_in_rows) {                                 // (uniform) the row is in this wave's registers: its minimum is 6 lane exchanges
+      float mn = 2.0f;                                   // (D <= 1)
 #pragma unroll
-    for (int q = 0; q < kCxMaxCols; ++q) {
-      if (q < ncol) {
-        const int j = lane + 64 * q;
-        wv[q] = j < hw ? __expf((1.0f - Dr[j] / dm) * inv_h) : 0.0f;
-        s += wv[q];
+      for (int q = 0; q < kCxMaxCols; ++q) {
+        if (q < ncol) {
+          const int j = lane + 64 * q;
+          wv[q] = j < hw ? Dr[j] : 2.0f;
+          mn = fminf(mn, wv[q]);
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
+      if (lane == 0) w.dmin[row] = __float_as_uint(mn);  // the backward row pass reads it
+      dm = mn + 1e-5f;
+#pragma unroll
+      for (int q = 0; q < kCxMaxCols; ++q) {
+        if (q < ncol) {
+          const int j = lane + 64 * q;
+          wv[q] = j < hw ? __expf((1.0f - wv[q] / dm) * inv_h) : 0.0f;
+          s += wv[q];
+        }
+      }
+    } else {
+      dm = __uint_as_float(w.dmin[row]) + 1e-5f;
+#pragma unroll
+      for (int q = 0; q < kCxMaxCols; ++q) {
+        if (q < ncol) {
+          const int j = lane + 64 * q;
+          wv[q] = j < hw ? __expf((1.0f - Dr[j] / dm) * inv_h) : 0.0f;
+          s += wv[q];
+        }
       }
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -976,14 +1013,15 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
   }
   if (workspace_bytes < 4 * cx_ws_floats(N, C, hw)) { set_error("%s: workspace too small", who); return NPP_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  const CxWs w = carve((float*)d_workspace, N, C, hw, d_iter, M);
+  CxWs w = carve((float*)d_workspace, N, C, hw, d_iter, M);
   const int groups = M > 0 ? M : 1;
   const int64_t nh = (int64_t)N * hw;
   const float inv_h = 1.0f / band_width;
-  hipLaunchKernelGGL(cx_mean_kernel, dim3(C, groups), dim3(256), 0, s, d_fy, N, C, hw, w);
-  const int tiles = (hw + 63) / 64;
   const bool big = hw > 64 * kCxMaxCols;     // whole-image crops: the generic kernels, column-chunked row pass
   const bool fast = !big && (hw % 32) == 0;  // LDS-free contractions + block-parallel row pass (all loop sizes: hw = (P/4)^2)
+  w.min_in_rows = fast ? 1 : 0;
+  hipLaunchKernelGGL(cx_mean_kernel, dim3(C, groups), dim3(256), 0, s, d_fy, N, C, hw, w);
+  const int tiles = (hw + 63) / 64;
   const bool loss_in_rows = fast && d_dfx && !d_weight;      // the loss terms ride in the row pass, their group sums in the backward row pass
   const int t32 = hw / 32;
   if (fast) {
