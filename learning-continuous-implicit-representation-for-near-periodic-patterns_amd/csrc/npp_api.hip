@@ -219,13 +219,32 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a_in, NetDe
     if (d.present[q] && i >= d.w_off[q]) l = q;
   int64_t r = i - d.w_off[l];
   int n = (int)__umulhi((uint32_t)r, magic[l]), k = (int)r - n * d.n_in[l];
+  // four consecutive columns of one weight row that start at a multiple of 4: in the forward pack they are elements j0 .. j0 + 3 of ONE
+  // 16-byte unit (npp_layout.h: a non-embedding column c sits at element 4 (c16 >> 3) + (c16 & 3) of lane half (c16 >> 2) & 1), so they
+  // leave as one 8-byte store instead of four 2-byte ones; the transposed pack keeps its 2-byte stores (its unit runs along n)
+  bool fwd4 = false;
+  if (cnt == 4 && n < d.n_out[l] && (k & 3) == 0 && k + 3 < d.n_in[l]) {
+    const int64_t p0 = fwd_pack_pos(d, l, n, k), p3 = fwd_pack_pos(d, l, n, k + 3);
+    if (p0 >= 0 && p3 == p0 + 3 && (p0 & 3) == 0) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t w4 = {(__bf16)pn[0], (__bf16)pn[1], (__bf16)pn[2], (__bf16)pn[3]};
+      *(bf16x4_t*)(a.wf + p0) = w4;
+      fwd4 = true;
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (e < cnt) {
+#ifdef NPP_DIAG_ADAM_NOSCATTER      // timing-only diagnostic (wrong results): no pack stores
+      if (false) {
+#else
       if (n < d.n_out[l]) {                               // a weight (rows beyond n_out = the layer's bias vector: not packed)
+#endif
         const __bf16 w = (__bf16)pn[e];
-        const int64_t pf = fwd_pack_pos(d, l, n, k);
-        if (pf >= 0) a.wf[pf] = w;
+        if (!fwd4) {
+          const int64_t pf = fwd_pack_pos(d, l, n, k);
+          if (pf >= 0) a.wf[pf] = w;
+        }
         const int64_t pb = bwd_pack_pos(b, l, n, k);
         if (pb >= 0) a.wb[pb] = w;
       }
