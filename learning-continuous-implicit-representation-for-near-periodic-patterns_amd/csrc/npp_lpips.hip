@@ -320,11 +320,13 @@ static int lp_fill(LpTap& T, const float* f0, const float* f1, int N, int C, int
   const int PLr = few ? 4 : 16;
   const int64_t groups = (nh + PLr - 1) / PLr;
   T.f0 = f0; T.f1 = f1; T.lin = lin; T.latents = latents; T.df0 = df0; T.dlatent = dlatent; T.fix = (unsigned long long*)ws;
-  // (blocks per tap, measured on the five VGG16 taps of two 96^2 patches in one launch: cap 128 / 256 / 384 / 512 / 1024 = 58 / 64 / 68 /
-  //  68 / 82 us inside 'same' iterations -- more blocks mean more same-address atomics in the tail; 256 kept: best alone, 50.7 -> 47.3 us
-  //  after the latent-gradient exchanges left the group loop.  Timing-only builds (tools/r4_lp_heads_probe.py): without the tail
-  //  (atomics + last arriver) 38.1 us, without the per-channel prologue 42.7, neither 33.1; a tap alone 15-20 us.)
-  T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)(groups < 256 ? groups : 256);
+  // Timing-only builds (tools/r4_lp_heads_probe.py, at one block per CU as the kernel then ran): without the tail (atomics + last arriver) 38.1 us of
+  // 47.3, without the per-channel prologue 42.7, neither 33.1; a tap alone 15-20 us.
+  // (at four blocks per CU: cap 128 / 160 / 192 / 224 / 256 = 30.6 / 29.7 / 30.2 / 30.0 / 32.1 us for the five taps alone; 384 .. 1152: 39.6 .. 56.5 -- every
+  //  block ends in 2 C + 1 same-address atomics per tap)
+  constexpr int nb_cap = 192;
+  const int64_t per = (groups + nb_cap - 1) / nb_cap;      // groups per block; then the fewest blocks that need no more than that
+  T.hw = hw; T.C = C; T.few = few ? 1 : 0; T.nb = (int)((groups + per - 1) / per);
   T.coef = scale / (float)nh;                             // spatial mean and batch mean folded with the caller's weight
   if (yact && !dflat) { set_error("%s: yact gates the flat gradient (dflat)", who); return NPP_ERR_ARG; }
   T.dflat = (__bf16*)dflat; T.yact = (const _Float16*)yact;
