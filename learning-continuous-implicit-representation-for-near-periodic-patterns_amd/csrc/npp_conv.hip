@@ -75,6 +75,11 @@ struct ConvArgs {
   // (lane b: row 2 rp + 1 + (b >> 4), column 16 cb + 1 + (b & 15)), so a pool window is lanes {b, b^1, b^16, b^17} of one tile;
   // pool_dz = the pooled fp16 tensor (geometry (H/2, W/2), pool_nposp units per chunk), pool_tiles = n_run * H/2 * pool_cbn.
   int32_t pool_tiles, pool_cbn;
+  // weight-stationary numbering (conv3x3_kernel, 1-D grid): block -> XCD is linear id % 8; with the natural (position, channel-group)
+  // grid every XCD runs every channel group and pulls the WHOLE weight pack into its L2 -- 8 x 4.7 MB from HBM for a 512 -> 512 layer
+  // on a handful of position tiles (VGG16 conv4_x / conv5_x on the LPIPS branch's four patches: the launch is that traffic).  Here
+  // channel group g lives on XCD g % 8: an XCD fetches one eighth of the pack and all (few) positions.
+  int32_t wstat, wstat_npos, wstat_ncg;
 };
 
 __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -103,9 +108,14 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = lane & 31, h = lane >> 5;
   // XCD-aware: consecutive position blocks (which share halo rows) go to the same XCD / L2
-  int bid = blockIdx.x;
+  int bid = blockIdx.x, cgrp = blockIdx.y;
   const int nb = gridDim.x;
-  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  if (a.wstat) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    cgrp = xcd + 8 * (slot / a.wstat_npos);
+    if (cgrp >= a.wstat_ncg) return;                      // (whole workgroup)
+    bid = slot % a.wstat_npos;
+  } else if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   // The next layer's weights were last read an iteration ago (1.1 GB of stash traffic since): its first workgroups would
   // take them from HBM.  Every XCD's workgroups of THIS launch together touch one dword per line of that pack; the value is
   // consumed at the very end (loads return in order, so it costs no extra wait).
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
     if (line + 4 <= a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
   }
   const int tile0 = bid * PT;
-  const int cot0 = blockIdx.y * CT;
+  const int cot0 = cgrp * CT;
   const int KS = a.CI * 9;
   const int ci_per = a.CI / S, ci_beg = wave * ci_per, ci_end = ci_beg + ci_per;
 
@@ -1270,7 +1280,15 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
 #undef NPP_WIN_GO
     return check_launch("npp_conv3x3");
   }
-  const dim3 grid((unsigned)(a.pos_tiles / pick.pt), (unsigned)(cot_n / pick.ct));
+  dim3 grid((unsigned)(a.pos_tiles / pick.pt), (unsigned)(cot_n / pick.ct));
+  // weight-stationary numbering where the pack outweighs the activations the launch reads and there are channel groups for all XCDs
+  static const int wstat_mode = getenv("NPP_CONV_WSTAT") ? atoi(getenv("NPP_CONV_WSTAT")) : 1;     // 0: never (A/B comparator)
+  const int64_t act_bytes = (int64_t)(Cin / 8) * range * 16;
+  if (wstat_mode && (int)grid.y >= 8 && (int64_t)a.pack_bytes > 2 * act_bytes) {
+    a.wstat = 1; a.wstat_npos = (int)grid.x; a.wstat_ncg = (int)grid.y;
+    a.pf = nullptr; a.pf_bytes = 0;                       // (the next pack is partitioned the same way: nothing to request into EVERY L2)
+    grid = dim3((unsigned)(8 * (((int)grid.y + 7) / 8) * (int)grid.x), 1);
+  }
   int lrc = NPP_OK;
 #define NPP_CONV_CASE(CT_, PT_, S_) if (pick.ct == CT_ && pick.pt == PT_ && pick.s == S_) lrc = conv_launch_mode<CT_, PT_, S_>(a, mode, grid, s)
   NPP_CONV_CASE(2, 2, 4); else NPP_CONV_CASE(2, 1, 4); else NPP_CONV_CASE(1, 1, 8); else NPP_CONV_CASE(1, 1, 4);
