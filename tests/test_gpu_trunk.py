@@ -499,3 +499,50 @@ def test_trunk_gradient_error_is_relu_gate_flips(dev, name, P, n, ntot):
     e_own, e_gated = rel_l2(dh, torch_grad(False)), rel_l2(dh, torch_grad(True))
     assert e_gated < 1.5e-2, (e_gated, e_own)
     assert e_gated < 0.5 * e_own, (e_gated, e_own)
+
+
+_WSTAT_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import oracle
+from npp_amd.losses import HipTrunk
+dev = torch.device('cuda:0')
+rng = np.random.RandomState(3)
+cfg, taps = oracle.VGG16_LPIPS_CFG, oracle.VGG16_LPIPS_TAPS
+sd, idx, cin = {}, 0, 3
+for v in cfg:
+    if v == 'M':
+        idx += 1
+        continue
+    sd[f'features.{idx}.weight'] = torch.from_numpy((rng.randn(v, cin, 3, 3) * np.sqrt(2.0 / (9 * cin))).astype(np.float32))
+    sd[f'features.{idx}.bias'] = torch.from_numpy((rng.randn(v) * 0.05).astype(np.float32))
+    idx += 2
+    cin = v
+hip = HipTrunk(cfg, taps, state_dict=sd, device=dev)
+x = torch.from_numpy(rng.rand(4, 3, 96, 96).astype(np.float32)).to(dev).requires_grad_(True)
+got = hip(x, 2, (4.3, 4.4, 4.5), (-2.1, -2.0, -1.8))
+gs = [torch.from_numpy(rng.randn(2, *g.shape[1:]).astype(np.float32)).to(dev) for g in got]
+sum((g[:2] * G).sum() for g, G in zip(got, gs)).backward()
+torch.cuda.synchronize()
+np.savez(sys.argv[2], dx=x.grad.cpu().numpy(), **{f'f{k}': g.detach().cpu().numpy() for k, g in enumerate(got)})
+"""
+
+
+def test_weight_stationary_block_numbering_changes_no_bit(dev, tmp_path):
+    """NPP_CONV_WSTAT=1 (the shipped numbering of conv3x3_kernel where the weight pack outweighs the activations: VGG16 conv4_x / conv5_x on
+    four 96^2 patches -- channel group g on XCD g % 8) against the natural (position, channel-group) grid: every tap and the image
+    gradient of the whole VGG16 stack bit for bit.  The switch is read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"ws{flag}.npz")
+        env = dict(os.environ, NPP_CONV_WSTAT=flag)
+        r = subprocess.run([sys.executable, "-c", _WSTAT_SNIPPET, root, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.any(outs[0]["dx"] != 0)
+    for k in outs[0].files:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
