@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+# the sampler's 50 / 30 / 20 source mix (sampler.py:297-354) as a period-10 pattern: any 10 consecutive pool entries hold 5 / 3 / 2
+POOL_PATTERN = ("val", "train", "val", "same", "val", "train", "val", "same", "train", "val")
 
 
 def parse():
@@ -50,6 +52,20 @@ def parse():
     ap.add_argument("--pool", type=int, default=40, help="pre-drawn sampler outputs the timed steps cycle through (a multiple of 10: the "
                     "sampler's 50 / 30 / 20 % source mix is then held exactly)")
     return ap.parse_args()
+
+
+def _dig(d, *keys):
+    """d[k0][k1]... or None when any level is missing (extras are optional)."""
+    for k_ in keys:
+        if not isinstance(d, dict) or k_ not in d:
+            return None
+        d = d[k_]
+    return d
+
+
+def _e2e_rate(e2e, key, n_rows):
+    ms = _dig(e2e, key, "ms_per_iter")
+    return (n_rows / (ms * 1e-3)) if ms else None
 
 
 def host_cores():
@@ -70,8 +86,8 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
     leg A -- the MLP half (embed + NPP_Net forward + robust pixel loss + backward + Adam) of WHOLE iterations
     (all n_pix + n_p * patch^2 rows at once) in PyTorch-CPU fp32 with autograd, torch.set_num_threads(all cores)
     (oracle/npp_torch_oracle.py, pinned to the NumPy oracle by tests/test_oracle_torch.py);
-    leg B -- the patch-loss half per iteration in the NumPy oracle (VGG19[0:18] trunk on the 2 * n_p * k patches as
-    im2col + SGEMM, contextual loss with its closed-form backward, trunk data-gradient; every 5th iteration also the
+    leg B -- the patch-loss half per iteration in PyTorch-CPU as well (VGG19[0:18] trunk on the 2 * n_p * k patches by
+    F.conv2d, the contextual loss as torch ops, autograd back to the prediction patches; every 5th iteration also the
     VGG16 trunk + LPIPS head on 2 * n_p patches, the 20 % 'same' iterations).
     value = rows of one iteration / (leg A time + leg B time per iteration)."""
     import oracle
@@ -101,33 +117,33 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
         n_a += 1
     t_a = (time.time() - t0) / n_a
 
-    # ---- leg B: patch-loss half, NumPy oracle
+    # ---- leg B: patch-loss half on PyTorch-CPU like the reference runs it (F.conv2d trunks on the host's oneDNN + autograd, torch
+    #      contextual core: oracle/npp_torch_oracle.py, pinned to the NumPy oracle by tests/test_oracle_torch.py); the LPIPS head's
+    #      per-channel robust NLL on the five taps stays in the NumPy oracle (elementwise work between two torch trunk passes)
     def weights(cfg):
         ws_, cin = [], 3
         for v in cfg:
             if v != "M":
                 ws_.append(((rng.randn(v, cin, 3, 3) * np.sqrt(2.0 / (9 * cin))).astype(np.float32), np.zeros(v, np.float32)))
                 cin = v
-        return ws_
+        return T.trunk_weights_t(ws_)
     w19, w16 = weights(oracle.VGG19_CX_CFG), weights(oracle.VGG16_LPIPS_CFG)
     chns = [64, 128, 256, 512, 512]
     lins = [np.abs(rng.randn(c_)).astype(np.float32) * 0.05 for c_ in chns]
     lat_a = [np.full((1, c_), 2.3841858e-07, np.float32) for c_ in chns]
     lat_s = [np.zeros((1, c_), np.float32) for c_ in chns]
+
+    def head(f0, f1):
+        loss_, dfs_, _, _ = oracle.lpips_head_grads(f0, f1, lins, lat_a, lat_s)
+        return loss_, dfs_
+    nk = n_p * k
+    xy = torch.from_numpy(rng.rand(2 * nk, 3, patch, patch).astype(np.float32))
+    T.contextual_step_t(xy, nk, oracle.VGG19_CX_CFG, w19, oracle.VGG19_CX_TAPS)                   # warm-up (oneDNN primitives)
     n_b, t1 = 0, time.time()
     while True:
-        nk = n_p * k
-        xy = rng.rand(2 * nk, 3, patch, patch).astype(np.float32)
-        f, cache = oracle.trunk_forward(xy, oracle.VGG19_CX_CFG, w19, oracle.VGG19_CX_TAPS, gemm=True)
-        _, dfx = oracle.cx_backward(f[0][:nk], f[0][nk:])
-        cache_x = [(c_[0], (nk,) + tuple(c_[1][1:]), c_[2][:nk]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:nk]) for c_ in cache]
-        oracle.trunk_backward(oracle.VGG19_CX_CFG, cache_x, oracle.VGG19_CX_TAPS, [dfx], gemm=True)
-        if n_b % 5 == 2:
-            xy2 = xy[:2 * n_p]
-            f, cache = oracle.trunk_forward(xy2, oracle.VGG16_LPIPS_CFG, w16, oracle.VGG16_LPIPS_TAPS, gemm=True)
-            _, dfs, _, _ = oracle.lpips_head_grads([t[:n_p] for t in f], [t[n_p:] for t in f], lins, lat_a, lat_s)
-            cache_x = [(c_[0], (n_p,) + tuple(c_[1][1:]), c_[2][:n_p]) if c_[0] == "pool" else (c_[0], c_[1], c_[2][:n_p]) for c_ in cache]
-            oracle.trunk_backward(oracle.VGG16_LPIPS_CFG, cache_x, oracle.VGG16_LPIPS_TAPS, dfs, gemm=True)
+        T.contextual_step_t(xy, nk, oracle.VGG19_CX_CFG, w19, oracle.VGG19_CX_TAPS)
+        if n_b % 5 == 2:                                                                              # the 20 % 'same' iterations
+            T.lpips_step_t(xy[:2 * n_p], n_p, oracle.VGG16_LPIPS_CFG, w16, oracle.VGG16_LPIPS_TAPS, head)
         n_b += 1
         if time.time() - t1 > seconds_target * 0.5 and n_b >= 5:
             break
@@ -137,7 +153,7 @@ def cpu_baseline(K, H, patch, n_pix, n_p, k, seconds_target=20.0):
     return {"value": total / (t_a + t_b), "unit": "rows/s", "cores": cores, "kind": "port",
             "mlp_half_rows_per_s": total / t_a, "mlp_half_s_per_iteration": t_a, "patch_half_s_per_iteration": t_b,
             "sample": f"{n_a} MLP-half steps of {total} rows (PyTorch-CPU fp32 autograd, {cores} threads = this process's CPU share of {os.cpu_count()} logical CPUs, whole batch) in {n_a * t_a:.1f}s + "
-                      f"{n_b} patch-loss halves (NumPy oracle: VGG19 trunk + contextual loss on {2 * n_p * k} {patch}x{patch} patches, "
+                      f"{n_b} patch-loss halves (PyTorch-CPU F.conv2d + autograd: VGG19 trunk + contextual loss on {2 * n_p * k} {patch}x{patch} patches, "
                       f"VGG16 + LPIPS head every 5th) in {n_b * t_b:.1f}s"}
 
 
@@ -236,18 +252,27 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before timing: the sampler's output for `pool` iterations
     #      (train.py:152-181: sample_patches -> pixel draw), in the reference's RNG order ----
-    # The pool holds the sampler's expected patch-source mix EXACTLY (50 / 30 / 20 % val / train / same, sampler.py:297-354):
-    # draws arrive in the reference's RNG order and fill per-source quotas ('same' iterations cost ~1.5x a 'val' one, so a
-    # short pool's random mix would move the headline by a few per cent either way).
+    # The pool holds the sampler's expected patch-source mix EXACTLY (50 / 30 / 20 % val / train / same, sampler.py:297-354) AND
+    # in an order in which EVERY window of 10 consecutive entries (cyclically) holds 5 val / 3 train / 2 same: draws arrive in the
+    # reference's RNG order, fill per-source quotas and are then dealt into the period-10 pattern below -- so any --steps that is a
+    # multiple of 10 (the driver's 20 included) times the sampler's own mix ('same' iterations cost ~1.2x a 'val' one).
     quota = {"val": args.pool // 2, "train": (args.pool * 3) // 10, "same": 0}
     quota["same"] = args.pool - quota["val"] - quota["train"]
-    pool = []
-    while len(pool) < args.pool:
+    by_src = {"val": [], "train": [], "same": []}
+    while sum(len(v_) for v_ in by_src.values()) < args.pool:
         b = fit.sample_batch()
-        if b is not None and quota[b["source"]] > 0:           # k == 0 -> the reference skips the iteration (train.py:160-161)
+        if b is not None and len(by_src[b["source"]]) < quota[b["source"]]:   # k == 0 -> the reference skips the iteration (train.py:160-161)
             assert b["n"] == n_rows and b["bp"] == bp
-            quota[b["source"]] -= 1
-            pool.append(b)
+            by_src[b["source"]].append(b)
+    pool = []
+    if args.pool % 10 == 0:
+        taken = {s_: 0 for s_ in by_src}
+        for i in range(args.pool):
+            s_ = POOL_PATTERN[i % 10]
+            pool.append(by_src[s_][taken[s_]])
+            taken[s_] += 1
+    else:
+        pool = by_src["val"] + by_src["train"] + by_src["same"]
     mix = {s_: sum(b["source"] == s_ for b in pool) for s_ in ("val", "train", "same")}
     ws = net.workspace(bp)
 
@@ -283,8 +308,10 @@ def main():
     # the timed steps walk the pool in order: a step count that is not a multiple of the pool weighs the sources by the pool's
     # ORDER instead of its 50 / 30 / 20 mix ('same' iterations cost 1.3x): say so in the line instead of hiding it
     mix_timed = {s_: sum(pool[i % len(pool)]["source"] == s_ for i in range(args.steps)) for s_ in ("val", "train", "same")}
-    if args.steps % len(pool) and rank == 0:
-        print(f"bench.py: --steps {args.steps} is not a multiple of --pool {len(pool)}: timed source mix {mix_timed}", file=sys.stderr)
+    mix_ok = (mix_timed["val"] * 10 == args.steps * 5 and mix_timed["train"] * 10 == args.steps * 3 and mix_timed["same"] * 10 == args.steps * 2)
+    if not mix_ok and rank == 0:
+        print(f"bench.py: --steps {args.steps} is not a multiple of 10 (or --pool is not): timed source mix {mix_timed} is not 50/30/20",
+              file=sys.stderr)
 
     # ---- host time to ENQUEUE one iteration (34 C-ABI calls through ctypes), measured on a drained queue over 8 iterations (well
     #      inside the HIP queue's depth, so no launch call blocks on the device): the loop is device-bound while this stays below
@@ -514,6 +541,14 @@ def main():
                                            "per job), NOT SURVEY 8(d)'s algorithmic bytes (32 B/row + weights)",
                                    "bytes_per_launch": hbm_bytes[dom], "GB_per_s": gbs[dom], "frac_of_8TBs": gbs[dom] / PEAK_HBM_GBS,
                                    "survey_8d_algorithmic_bytes_per_step": bp * 32 + 2.4e6 + 28 * n_par},
+                # the same launch under the HBM roof: measured bytes (PMC) against its duration, and where that traffic puts the ridge
+                "arithmetic_intensity_flop_per_byte": (flops[dom] / measured) if measured else None,
+                "ridge_flop_per_byte": PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9),
+                "hbm_roof_frac": (measured / kt_roof[dom] / 1e9 / PEAK_HBM_GBS) if measured else None,
+                "mfma_frac_ceiling_at_this_traffic": (flops[dom] / (measured / (PEAK_HBM_GBS * 1e9)) / 1e12 / PEAK_BF16_TFLOPS) if measured else None,
+                "fwd_mfma_frac": tf["mlp_fwd_train"] / PEAK_BF16_TFLOPS, "bwd_mfma_frac": tf["mlp_bwd_chain"] / PEAK_BF16_TFLOPS,
+                "wgrad_mfma_frac": tf["mlp_wgrad"] / PEAK_BF16_TFLOPS,
+                "fwd_us": kt_roof["mlp_fwd_train"] * 1e6, "bwd_us": kt_roof["mlp_bwd_chain"] * 1e6, "wgrad_us": kt_roof["mlp_wgrad"] * 1e6,
                 "mfma_pipe_busy_frac_pmc": mfma_pmc,
                 "all_kernels_us_in_iteration": {k: round(v * 1e6, 2) for k, v in kt_iter.items()},
                 "all_kernels_us_in_sequence": {k: round(v * 1e6, 2) for k, v in kt_seq.items()},
@@ -827,7 +862,20 @@ def main():
                                    f"VGG19 trunk + contextual loss + trunk dgrad (+ VGG16/LPIPS on 'same'), bwd chain, wgrad, Adam",
                        "rows_per_step": n_rows, "image": [H, H], "K": K, "width": 256, "ksplit": net.ksplit,
                        "images_per_gpu": 1, "patch_size": patch, "patch_source_mix_in_pool": mix,
-                       "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate"},
+                       "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate",
+                       # flat copies of the report's other headline numbers (the driver's parser keeps scalars of `config` only)
+                       "timed_source_mix": f"val {mix_timed['val']} / train {mix_timed['train']} / same {mix_timed['same']}",
+                       "timed_mix_is_50_30_20": bool(mix_ok),
+                       "rows_per_s_incl_sampling_reference_rng": _e2e_rate(e2e, "same_stream_native_rng_producer_thread", n_rows),
+                       "rows_per_s_incl_sampling_fast_rng": _e2e_rate(e2e, "fast_mode", n_rows),
+                       "render_pixels_per_s": render_px_s, "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters_dB": final_psnr,
+                       "stacked_M8_rows_per_s_per_gpu": _dig(stacked, "stacked_M8", "rows_per_s"),
+                       "stacked_M8_x_single": _dig(stacked, "stacked_M8", "x_single"),
+                       "stacked_M4_rows_per_s_per_gpu": _dig(stacked, "stacked_M4", "rows_per_s"),
+                       "c4_embedder_1024sq_fp32_frac_of_hbm_peak": _dig(c4, "fp32", "frac_of_hbm_peak"),
+                       "c4_render_1024sq_fp32_pixels_per_s": _dig(c4, "render_1024sq_fp32_fused", "pixels_per_s"),
+                       "ms_per_iter_val": _dig(per_source, "val"), "ms_per_iter_train": _dig(per_source, "train"),
+                       "ms_per_iter_same": _dig(per_source, "same"), "host_enqueue_ms_per_iter": host_enqueue_ms},
             "mlp_only_step": {"ms_per_step": mlp_ms, "rows_per_s": n_rows / (mlp_ms * 1e-3),
                               "mlp_mfma_frac": 2 * train_macs * n_rows / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                               },

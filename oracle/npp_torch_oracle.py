@@ -80,3 +80,75 @@ def train_step_t(P, opt, coords, gt, angles, periods, freqs, res, K, latent_alph
     pred.backward(torch.from_numpy(np.ascontiguousarray(dpred, dtype=np.float32)))
     opt.step()
     return float(loss)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Patch-loss half on PyTorch-CPU (the reference runs these as torch modules with autograd, F.conv2d on the host's MKL-DNN):
+# contextual_loss/modules/vgg.py:16-36 + lpips/pretrained_networks.py:96-134 (trunks), contextual_loss/functional.py:9-63,
+# 127-163 (core).  Pinned against the NumPy oracle (trunk_forward / trunk_backward / cx_backward) by tests/test_oracle_torch.py.
+# ----------------------------------------------------------------------------------------------------------------------
+def trunk_weights_t(weights):
+    """[(w (Co,Ci,3,3), b (Co,))] NumPy -> frozen torch tensors (vgg.py:26-28: requires_grad False)."""
+    return [(torch.from_numpy(np.ascontiguousarray(w, np.float32)), torch.from_numpy(np.ascontiguousarray(b, np.float32)))
+            for w, b in weights]
+
+
+def trunk_forward_t(x, cfg, weights_t, taps):
+    """x (N,3,H,W) torch, already normalised -> list of tap outputs (indices of torchvision's `features`, like the NumPy
+    oracle's trunk_forward); differentiable w.r.t. x."""
+    F = torch.nn.functional
+    outs, idx, wi = [], 0, 0
+    for v in cfg:
+        if v == "M":
+            x = F.max_pool2d(x, 2)
+            idx += 1
+        else:
+            w, b = weights_t[wi]
+            wi += 1
+            x = F.relu(F.conv2d(x, w, b, padding=1))
+            idx += 2
+            if idx - 1 in taps:
+                outs.append(x)
+    return outs
+
+
+def cx_loss_t(x, y, band_width=0.5, weight=None):
+    """functional.py:9-63 with loss_type 'cosine' (:139-163), relative distance (:133-136) and compute_cx (:127-130)."""
+    F = torch.nn.functional
+    N, C = x.shape[:2]
+    mu = y.mean(dim=(0, 2, 3), keepdim=True)
+    xn = F.normalize(x - mu, p=2, dim=1).reshape(N, C, -1)
+    yn = F.normalize(y - mu, p=2, dim=1).reshape(N, C, -1)
+    dist = 1 - torch.clamp(torch.bmm(xn.transpose(1, 2), yn), min=0, max=1)
+    dmin, _ = torch.min(dist, dim=2, keepdim=True)
+    w = torch.exp((1 - dist / (dmin + 1e-5)) / band_width)
+    cx = w / torch.sum(w, dim=2, keepdim=True)
+    cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)
+    if weight is not None:
+        return torch.sum(-torch.log(cx * weight + 1e-5))
+    return torch.mean(-torch.log(cx + 1e-5))
+
+
+def contextual_step_t(xy, nk, cfg, weights_t, taps, band_width=0.5):
+    """One contextual-loss evaluation with its gradient w.r.t. the prediction half (contextual.py:53-68 + backward): trunk on
+    all 2*nk patches ([x | y], the real half without a graph), core, autograd back to the first nk images."""
+    x = xy[:nk].clone().requires_grad_(True)
+    fx = trunk_forward_t(x, cfg, weights_t, taps)[0]
+    with torch.no_grad():
+        fy = trunk_forward_t(xy[nk:], cfg, weights_t, taps)[0]
+    loss = cx_loss_t(fx, fy, band_width)
+    loss.backward()
+    return loss.detach(), x.grad
+
+
+def lpips_step_t(xy, n, cfg, weights_t, taps, head_grads):
+    """The LPIPS branch of a 'same' iteration (lpips.py:92-133): VGG16 taps of both halves on torch, the per-layer adaptive head
+    and its tap gradients from `head_grads(feats0, feats1)` (the NumPy oracle's lpips_head_grads: elementwise work on the taps),
+    then autograd through the trunk back to the first n images."""
+    x = xy[:n].clone().requires_grad_(True)
+    f0 = trunk_forward_t(x, cfg, weights_t, taps)
+    with torch.no_grad():
+        f1 = trunk_forward_t(xy[n:], cfg, weights_t, taps)
+    loss, dfs = head_grads([t.detach().numpy() for t in f0], [t.numpy() for t in f1])
+    torch.autograd.backward(f0, [torch.from_numpy(np.ascontiguousarray(d, np.float32)) for d in dfs])
+    return loss, x.grad

@@ -32,3 +32,28 @@ def test_torch_restatement_matches_numpy_oracle(K):
     for k, g in G.items():
         rel = np.linalg.norm(Pt[k].grad.numpy() - g) / max(np.linalg.norm(g), 1e-20)
         assert rel < 2e-4, (k, rel)
+
+
+def test_torch_patch_half_matches_numpy_oracle():
+    """bench.py's cpu_baseline patch half (F.conv2d trunks + autograd, torch contextual core) against the NumPy oracle's trunk and
+    closed-form contextual backward: features, loss and dL/d(prediction patches)."""
+    rng = np.random.RandomState(5)
+    cfg, taps = oracle.VGG19_CX_CFG, oracle.VGG19_CX_TAPS
+    ws, cin = [], 3
+    for v in cfg:
+        if v != "M":
+            ws.append(((rng.randn(v, cin, 3, 3) * np.sqrt(2.0 / (9 * cin))).astype(np.float32), (rng.randn(v) * 0.05).astype(np.float32)))
+            cin = v
+    nk, P = 2, 16
+    xy = rng.rand(2 * nk, 3, P, P).astype(np.float32)
+    f, cache = oracle.trunk_forward(xy, cfg, ws, taps, gemm=True)
+    loss_np, dfx = oracle.cx_backward(f[0][:nk], f[0][nk:])
+    cache_x = [(c[0], (nk,) + tuple(c[1][1:]), c[2][:nk]) if c[0] == "pool" else (c[0], c[1], c[2][:nk]) for c in cache]
+    dx_np = oracle.trunk_backward(cfg, cache_x, taps, [dfx], gemm=True)
+    wt = T.trunk_weights_t(ws)
+    ft = T.trunk_forward_t(torch.from_numpy(xy), cfg, wt, taps)[0]
+    assert np.abs(ft.numpy() - f[0]).max() < 1e-4 * max(1.0, np.abs(f[0]).max())
+    loss_t, dx_t = T.contextual_step_t(torch.from_numpy(xy), nk, cfg, wt, taps)
+    assert abs(float(loss_t) - float(loss_np)) < 1e-4 * max(1.0, abs(float(loss_np)))
+    rel = np.linalg.norm(dx_t.numpy() - dx_np) / max(np.linalg.norm(dx_np), 1e-20)
+    assert rel < 5e-3, rel
