@@ -27,8 +27,11 @@ class CompletionFit:
                  vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
                  vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False, use_patch_weight=False,
-                 no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive", use_adaptive_perceptual_loss=True):
+                 no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive", use_adaptive_perceptual_loss=True, normalize_type=1):
         """img (H,W,3) float in [0,1]; mask (H,W,1) 1 = known (loaders.py:92-101).
+        normalize_type: --normalize_type (arg_config.py:31): 1 = sigmoid output, 2 = tanh output (helpers.py:55-58).  The reference
+        rescales ONLY its evaluation image to [-1, 1] under 2 (loaders.py:56,111); the loop still trains on masked_img in [0, 1]
+        (train.py:173) -- reproduced as it is: pass `img` already rescaled if the evaluation should see it that way.
         width: --netwidth, 256 (BASELINE configs) or 512 (the reference's default, arg_config.py:57); `params` must match.
         use_adaptive_perceptual_loss: False = LPIPS(use_robust=False) in the loop (arg_config.py:78, train.py:241-246).
         loss_type: --loss_type (arg_config.py:34; models/mse_calculator.py:19-23): 'robust_loss_adaptive' | 'l2' | 'robust_loss'.
@@ -96,7 +99,8 @@ class CompletionFit:
         self.masked_img = torch.from_numpy(np.ascontiguousarray(train_img, np.float32)).to(self.device).contiguous()
         self.pixel_mask = None if pixel_mask is None else torch.from_numpy(pixel_mask[..., 0].copy()).to(self.device)
         self.net = NPPNet(angles_deg, periods, freqs, (self.H, self.W), params=params, device=self.device,
-                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay, width=width, loss_type=loss_type)
+                          ksplit=ksplit, lrate=lrate, lrate_decay=lrate_decay, width=width, loss_type=loss_type,
+                          out_act=int(normalize_type))
         if task == "segmentation":
             self.net.lr_clock = False                              # NPP_segmentation/train.py:408 (see NPPNet.lr_clock)
         self.N_rand = int(min(N_rand, self.i_train.shape[0]))

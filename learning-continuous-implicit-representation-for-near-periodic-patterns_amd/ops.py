@@ -386,6 +386,16 @@ def batch_assemble(i_train, pix, cen, P, bp, img_hwc, pmask_hw=None, out=None):
 _cx_ws = {}
 
 
+def _cx_workspace(device, nbytes, st):
+    """The contextual core's scratch (D, cx, mu, row sums and the last-arriver tickets of its six launches): ONE PER STREAM -- two fits
+    of one shape on two streams (bench throughput mode, the LPIPS side stream) would otherwise race on the matrices and the tickets."""
+    key = (device, int(nbytes), st.value)
+    ws = _cx_ws.get(key)
+    if ws is None:
+        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return ws
+
+
 def cx_fwd_bwd(fx, fy, band_width=0.5, weight=None, scale=1.0, loss=None, want_grad=True):
     """contextual_loss(x, y, band_width, weight, 'cosine') on features (N,C,h,w) + dL/dx
     (externel_lib/contextual_loss/functional.py:9-63).  Returns (loss tensor[1], dfx or None)."""
@@ -395,15 +405,13 @@ def cx_fwd_bwd(fx, fy, band_width=0.5, weight=None, scale=1.0, loss=None, want_g
     hw = fx.shape[2] * fx.shape[3]
     nbytes = lib().npp_cx_workspace_bytes(N, C, hw)
     check(nbytes, "npp_cx_workspace_bytes")
-    key = (fx.device, int(nbytes))
-    ws = _cx_ws.get(key)
-    if ws is None:
-        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
+    st = _stream()
+    ws = _cx_workspace(fx.device, nbytes, st)
     if loss is None:
         loss = torch.zeros(1, dtype=torch.float32, device=fx.device)
     dfx = torch.empty_like(fx) if want_grad else None
     check(lib().npp_cx_fwd_bwd(_p(fx), _p(fy), N, C, hw, band_width, _p(weight), scale, _p(loss), _p(dfx), _p(ws),
-                               int(nbytes), _stream()), "npp_cx_fwd_bwd")
+                               int(nbytes), st), "npp_cx_fwd_bwd")
     return loss, dfx
 
 
@@ -946,13 +954,11 @@ def cx_fwd_bwd_groups(fx, fy, it, M, band_width, scale, loss, loss_stride=1):
     hw = fx.shape[2] * fx.shape[3]
     nbytes = lib().npp_cx_workspace_bytes(N, Cc, hw)
     check(nbytes, "npp_cx_workspace_bytes")
-    key = (fx.device, int(nbytes))
-    ws = _cx_ws.get(key)
-    if ws is None:
-        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
+    st = _stream()
+    ws = _cx_workspace(fx.device, nbytes, st)
     dfx = torch.empty_like(fx)
     check(lib().npp_cx_fwd_bwd_groups(_p(fx), _p(fy), N, Cc, hw, band_width, scale, _p(loss), loss_stride, _p(dfx), _p(it), M, _p(ws),
-                                      int(nbytes), _stream()), "npp_cx_fwd_bwd_groups")
+                                      int(nbytes), st), "npp_cx_fwd_bwd_groups")
     return dfx
 
 
@@ -965,16 +971,14 @@ def cx_fwd_bwd_flat(fx, fy, yact, dz, N_total, band_width, scale, loss, loss_str
     N, Cc, H, W = fx.shape
     nbytes = lib().npp_cx_workspace_bytes(N, Cc, H * W)
     check(nbytes, "npp_cx_workspace_bytes")
-    key = (fx.device, int(nbytes))
-    ws = _cx_ws.get(key)
-    if ws is None:
-        ws = _cx_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=fx.device)
-    key2 = (fx.device, "dxh", N * Cc * H * W)
+    st = _stream()
+    ws = _cx_workspace(fx.device, nbytes, st)
+    key2 = (fx.device, "dxh", N * Cc * H * W, st.value)
     dxh = _cx_ws.get(key2)
     if dxh is None:
         dxh = _cx_ws[key2] = torch.empty(N * Cc * H * W, dtype=torch.float32, device=fx.device)
     check(lib().npp_cx_fwd_bwd_flat(_p(fx), _p(fy), N, Cc, H, W, band_width, scale, _p(loss), loss_stride, _p(dxh), _p(yact), _p(dz),
-                                    N_total, _p(it), M, _p(ws), int(nbytes), _stream()), "npp_cx_fwd_bwd_flat")
+                                    N_total, _p(it), M, _p(ws), int(nbytes), st), "npp_cx_fwd_bwd_flat")
 
 
 def mlp_bwd_patch_stack(dpred, pred, M, K, wb, params, actF, dzF, dx_a, dx_b, cmasks, row0, n_p, P, it, width=NPP_WIDTH):

@@ -41,14 +41,25 @@ def parse(argv=None):
     ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth")
     ap.add_argument("--random-trunks", action="store_true", help="fixed-seed random VGG / AlexNet weights (synthetic runs only)")
     ap.add_argument("--rng_mode", default="reference", choices=["reference", "fast"])
-    ap.add_argument("--carry_adaptive_latents", action="store_true",
-                    help="fit the candidates one after the other through ONE set of adaptive pixel-loss latents, like the reference's module-level "
-                         "adaptive_pix (models/helpers.py:8); default: every candidate starts from the initial latents (independent, batched, shardable)")
+    ap.add_argument("--independent_candidates", "--fast", action="store_true",
+                    help="every candidate starts from the INITIAL adaptive pixel-loss latents: the candidates ride in one launch sequence "
+                         "(2-3x faster) and shard over ranks.  Default (one rank): the reference's behaviour -- ONE module-level adaptive_pix "
+                         "(models/helpers.py:8-9,144) trained through the candidates in order, each starting from the latents the previous "
+                         "one left.  Under torch.distributed with more than one rank the independent mode is always used")
+    ap.add_argument("--carry_adaptive_latents", action="store_true", help="(the default since round 5; accepted for compatibility)")
     ap.add_argument("--loss_type", default="robust_loss_adaptive", choices=["robust_loss_adaptive", "l2", "robust_loss"],
                     help="options/arg_config.py:34 (models/mse_calculator.py:19-23): the pixel loss of the candidate fits")
     ap.add_argument("--precision", default=None, choices=["fp32", "bf16"], help="arithmetic of the candidate fits (default: NPP_LIGHT_PRECISION, else fp32)")
     ap.add_argument("--device", default="cuda:0")
     return ap.parse_args(argv)
+
+
+def _carry(args):
+    """The reference's shared-latent chaining (models/helpers.py:8-9,144; NPP_proposal/search.py:85-205) unless the candidates are
+    asked to be independent or are sharded over ranks (a chain cannot be sharded)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return not (getattr(args, "independent_candidates", False) or multi)
 
 
 def find_mask_centroid(mask, topk=3, threshold_ratio=0.3):
@@ -99,10 +110,11 @@ def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
         raise RuntimeError("periodicity search: no displacement pair passed the angle test in any repeat-range group")
     _, i_train, i_val = pseudo_mask_split(m2, v2)
     t = trunks or {}
+    args.carry_effective = _carry(args)
     ranker = ProposalRanker(masked_img, i_train, i_val, device=args.device, N_iters=args.N_iters, N_rand=args.N_rand, W=args.netwidth,
                             D=args.netdepth, lrate=args.lrate, lrate_decay=args.lrate_decay, perceptual_weight=args.perceptual_weight,
                             contextual_weight=args.contextual_weight, vgg19_state_dict=t.get("vgg19"), vgg16_state_dict=t.get("vgg16"),
-                            lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode, carry_latents=args.carry_adaptive_latents,
+                            lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode, carry_latents=args.carry_effective,
                             loss_type=getattr(args, "loss_type", "robust_loss_adaptive"), precision=getattr(args, "precision", None))
     cands = list(zip(angles, periods, shifts))
     dist, order, details = ranker.rank(cands, topk=args.topk_detection)
@@ -142,8 +154,9 @@ def main(argv=None):
     odgt.update(search_range=list(args.search_range), epoch=args.N_iters)           # search.py:236-237
     # (not a reference field) how the candidates' adaptive-loss latents were handled: the reference trains ONE module-level
     # adaptive_pix through all candidates in order (models/helpers.py:8,144), so its distances depend on the candidate order; the
-    # default here starts every candidate from the initial latents.  Recorded so that rankings are compared like with like.
-    odgt.update(carry_adaptive_latents=bool(args.carry_adaptive_latents))
+    # single-rank default here does the same; --independent_candidates / more than one rank start every candidate from the initial
+    # latents.  Recorded so that rankings are compared like with like.
+    odgt.update(carry_adaptive_latents=bool(getattr(args, "carry_effective", _carry(args))))
     with open(os.path.join(out, "config.odgt"), "w") as f:
         json.dump(odgt, f)
         f.write("\n")

@@ -46,6 +46,15 @@ class StackedFit:
                 raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count, loss_type and the device")
             if f.use_patch_weight or not f.use_contextual_loss or f.pixel_mask is not None or f._prefetch:
                 raise ValueError("StackedFit: default loss switches, no producer thread (the stack draws for every image itself)")
+            if f.net.out_act != 1:
+                raise ValueError("StackedFit: sigmoid output (--normalize_type 1) only")
+            # every loss switch / weight the stacked launches take from fits[0] must hold for all images
+            same = ("pix_w", "use_comp", "cx_w", "lp_w", "lp_robust", "use_perceptual_loss")
+            for a_ in same:
+                if hasattr(f0, a_) and getattr(f, a_, None) != getattr(f0, a_):
+                    raise ValueError(f"StackedFit: the images of a stack share the loss switches and weights ({a_} differs)")
+            if (f.net.n_knots, f.net.x_scale) != (net0.n_knots, net0.x_scale) or not torch.equal(f.net.spline, net0.spline):
+                raise ValueError("StackedFit: the images of a stack share the robust loss's partition spline")
         M, dev = self.M, self.device
         self.n_p, self.P, self.kmax, self.n_pix = f0.patch_num, f0.patch_size, f0.topk, f0.N_rand
         self.n = self.n_pix + self.n_p * self.P * self.P
@@ -122,6 +131,15 @@ class StackedFit:
 
     # ---- host half: one draw per image (each fit's own sampler and random stream), device half into the stacked buffers ----
     def sample(self):
+        """-> the next list of M batches in the serial order of every image's random stream: the look-ahead draw step_full() left
+        pending if there is one (consumed), else a fresh draw.  At most TWO draws can be outstanding (two device buffer sets):
+        step_from() refuses a list whose set has been refilled since."""
+        if self._ahead is not None:
+            b, self._ahead = self._ahead, None
+            return b
+        return self._draw()
+
+    def _draw(self):
         """-> list of M batches (None for an image whose sampler found no valid real patch this iteration), materialised on the
         sampler stream into the buffer set that is not in use; the list carries that set (step_from waits for it)."""
         w = self._wset
@@ -146,15 +164,16 @@ class StackedFit:
             ev = torch.cuda.Event()
             ev.record(self._s_smp)
         st["filled"] = ev
+        st["gen"] = out.gen = st.get("gen", 0) + 1
         return out
 
     def step_full(self):
         """One iteration of the loop body for every image of the stack.  -> number of images that took a step.  The NEXT
         iteration's sampling (host draws + device half) is issued right behind this one's launches: it never reads network state, so
         the random streams and the results are those of the serial order; it runs on a side stream under this iteration's kernels."""
-        b = self._ahead if self._ahead is not None else self.sample()
+        b = self.sample()
         n = self.step_from(b)
-        self._ahead = self.sample()
+        self._ahead = self._draw()
         return n
 
     # ---- device half ---------------------------------------------------------------------------------------------------------
@@ -163,6 +182,14 @@ class StackedFit:
         M, fits = self.M, self.fits
         st = self._sets[getattr(batches, "set", 0)]
         coords, gt, crops, cmasks = st["coords"], st["gt"], st["crops"], st["cmasks"]
+        if getattr(batches, "gen", None) is not None and batches.gen != st.get("gen"):
+            raise RuntimeError("StackedFit.step_from: this draw's device buffers have been refilled by a later sample() (two draws can be "
+                               "outstanding at most)")
+        # the whole stack's shape is checked BEFORE any state moves (an image whose patch size decayed would otherwise leave the
+        # earlier images' step counters advanced)
+        for b in batches:
+            if b is not None and (b["P"], b["n_p"], b["n_pix"], b["bp"]) != (self.P, self.n_p, self.n_pix, self.Bp):
+                raise RuntimeError("StackedFit: an image's batch left the stack's shape (patch-size decay is not stacked: rebuild the stack)")
         if st["filled"] is not None:
             torch.cuda.current_stream(self.device).wait_event(st["filled"])
         it = (StackIter * M)()
@@ -172,8 +199,6 @@ class StackedFit:
             e = it[i]
             if b is None:
                 continue
-            if (b["P"], b["n_p"], b["n_pix"], b["bp"]) != (self.P, self.n_p, self.n_pix, self.Bp):
-                raise RuntimeError("StackedFit: an image's batch left the stack's shape (patch-size decay is not stacked: rebuild the stack)")
             net = f.net
             src, k = b["source"], b["k"]
             e.active, e.k, e.nk, e.x0 = 1, k, self.n_p * k, x0

@@ -107,10 +107,10 @@ def main(argv=None):
         raise SystemExit("the fused chain is built for --netwidth 256 (BASELINE.json) and 512 (the reference's default)")
     refused = [n for n, bad in (("--netdepth != 8", args.netdepth != 8), ("--activation != snake", args.activation != "snake"),
                                 ("--loss_type not in robust_loss_adaptive / l2 / robust_loss", args.loss_type not in ("robust_loss_adaptive", "l2", "robust_loss")),
-                                ("--normalize_type != 1", args.normalize_type != 1),
+                                ("--normalize_type not in 1 / 2", args.normalize_type not in (1, 2)),
                                 ) if bad]
     if refused:
-        raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (D = 8, snake, sigmoid output); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
+        raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (D = 8, snake, sigmoid / tanh output); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
     remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     from . import weights
@@ -129,7 +129,9 @@ def main(argv=None):
         d = nio.load_npp_segmentation(args.datadir, args.p_topk)
         d["mask"], d["masked_img"] = d["period_mask"], d["blur_img"]
     else:
-        d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown)
+        # --normalize_type 2: tanh output; the reference rescales only the evaluation image (loaders.py:111), training stays on
+        # masked_img in [0, 1] (train.py:173) -- reproduced, not fixed
+        d = nio.load_npp_completion(args.datadir, args.p_topk, args.invalid_as_unknown, normalize_type=args.normalize_type)
     name = os.path.basename(os.path.normpath(args.datadir))
     expname = args.expname if not ((remap or seg) and args.expname == "completion") else args.task
     outroot = os.path.join(args.basedir, f"{expname}_top{args.p_topk}", name)
@@ -167,7 +169,8 @@ def main(argv=None):
                         use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
                         use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
                         no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth,
-                        loss_type=args.loss_type, use_adaptive_perceptual_loss=args.use_adaptive_perceptual_loss)
+                        loss_type=args.loss_type, use_adaptive_perceptual_loss=args.use_adaptive_perceptual_loss,
+                        normalize_type=args.normalize_type)
     # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
     from concurrent.futures import ThreadPoolExecutor
     writer, pending = ThreadPoolExecutor(1), []

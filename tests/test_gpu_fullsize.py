@@ -291,7 +291,9 @@ def test_c4_remapping_loop_at_1024sq(dev):
     b.net.pixel_loss(bp, n_pix, batch["gt"], mask=batch.get("pmask"), weight=1.0)
     assert batch.get("pmask") is not None                         # remapping: gt_mask = clear_mask (train.py:203)
     da, db = a.net.workspace(bp)["dpred"][:n_pix], b.net.workspace(bp)["dpred"][:n_pix]
-    # (the gradient rows are written once each: bit-identical; the loss word is a float atomicAdd over 232 blocks: equal to round-off)
+    # (the gradient rows are written once each: bit-identical.  The loss word: fit `a` ran the iteration's form -- per-block partials
+    #  summed in block order by the Adam launch, no atomics --, `b` the STAND-ALONE npp_pixel_loss call, which adds its block sums
+    #  with atomicAdd and is not on the iteration's path: the two sums agree to round-off)
     assert torch.equal(da, db) and abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) <= 1e-6 * abs(float(b.net.loss_buf[0]))
 
 

@@ -1193,6 +1193,57 @@ def test_complete_iteration_is_bit_reproducible(dev):
         assert torch.equal(a, b), float((a - b).abs().max())
 
 
+def test_two_fits_on_two_streams_equal_their_serial_runs(dev):
+    """Two fits of the SAME shape interleaved on two streams (bench.py's throughput mode, config c3 with more images than GPUs): every
+    scratch buffer a launch sequence keeps across launches -- the contextual core's matrices and last-arriver tickets, the LPIPS
+    accumulators -- is per stream, so each fit ends at the bits of its own serial run."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 3
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def make(seed, stream=None):
+        img, mask = oracle.synthetic_image(H, seed=seed)               # (another noise draw: a second image of the same shape)
+        return CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=seed), device=dev, N_rand=4096,
+                             shifts=shifts, seed=4 + seed)
+
+    def state(f):
+        return [t.clone() for t in (f.net.params, f.net.m, f.net.v, f.net.latents, f.percepLoss._lat)]
+    serial = []
+    for seed in (0, 1):
+        f = make(seed)
+        pool = []
+        while len(pool) < 12:
+            b = f.sample_batch()
+            if b is not None:
+                pool.append(b)
+        for b in pool:
+            f.step_from(b)
+        torch.cuda.synchronize()
+        serial.append(state(f))
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    fits, pools = [], []
+    for seed in (0, 1):
+        with torch.cuda.stream(streams[seed]):
+            f = make(seed)
+            pool = []
+            while len(pool) < 12:
+                b = f.sample_batch()
+                if b is not None:
+                    pool.append(b)
+        fits.append(f)
+        pools.append(pool)
+    torch.cuda.synchronize()
+    assert {b["source"] for b in pools[0]} | {b["source"] for b in pools[1]} == {"val", "train", "same"}
+    for i in range(12):
+        for r in range(2):
+            with torch.cuda.stream(streams[r]):
+                fits[r].step_from(pools[r][i])
+    torch.cuda.synchronize()
+    for r in range(2):
+        for a, b in zip(serial[r], state(fits[r])):
+            assert torch.equal(a, b), (r, float((a - b).abs().max()))
+
+
 def test_minimal_and_ragged_batches(dev):
     """One 64-row tile (the smallest launch) and a batch that is not a multiple of the tile."""
     K, H = 3, 256
