@@ -108,9 +108,10 @@ def test_train_driver_ablation_switches(tmp_path):
 
 def test_train_driver_refuses_unbuilt_ablations(tmp_path):
     from npp_amd import train
-    for flags in (["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "2"], ["--loss_type", "mse"]):
+    for flags in (["--netdepth", "4"], ["--activation", "relu"], ["--normalize_type", "3"], ["--loss_type", "mse"]):
         with pytest.raises(SystemExit, match="ablation"):
             train.main(["--datadir", str(tmp_path), "--random-trunks"] + flags)
+    assert train.parse(["--datadir", "x", "--normalize_type", "2"]).normalize_type == 2                # accepted since round 5 (tanh output)
     a = train.parse(["--datadir", "x", "--loss_type", "l2", "--use_adaptive_perceptual_loss"])      # built in round 4
     assert a.loss_type == "l2" and a.use_adaptive_perceptual_loss is False
     a = train.parse(["--datadir", "x"])
