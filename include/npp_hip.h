@@ -66,6 +66,12 @@ typedef struct {
 int npp_version(void);
 const char* npp_last_error_string(void);
 int npp_device_count(void);
+/* Launch-time choice between kernel FORMS that compute the same result (the reference has no counterpart: torch / cuDNN pick
+ * their algorithms internally).  Keys: "conv_wink" (group-split window convolution: 0 never, 1 where measured best, 2 wherever
+ * feasible), "conv_win" (window-staged convolution, same values), "conv_wstat" (weight-stationary block numbering, 0 / 1),
+ * "conv_pair" (fused convolution pairs, 0 / 1).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
+ * key.  Initial values come from the environment (NPP_CONV_WINK=...), defaults are the measured-best forms. */
+int npp_tune(const char* key, int value);
 
 /* ---- parameters ---------------------------------------------------------- */
 /* Tensor table of the fp32 parameter blob for NPP_Net (K>1, models/networks.py:40-49)
@@ -427,6 +433,17 @@ int npp_conv3x3_poolin_ok(int N_total, int n_run, int H, int W, int Cin, int Cou
 int npp_conv3x3_poolin(const void* d_xpre, int N_total, int n_run, int H, int W, int Cin, int Cout,
                        const void* d_pack, const float* d_bias, void* d_y, float* d_tap, int Ctap,
                        const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
+/* TWO forward layers and the MaxPool2d(2,2) behind them in ONE launch (round 5): relu(conv a) -> relu(conv b) -> pool, the first
+ * blocks of VGG19 / VGG16 (contextual_loss/modules/vgg.py:16-21, lpips/pretrained_networks.py:106-115: features[0:5], [5:10]).  A
+ * workgroup owns a 16 x 16 tile of one image; the intermediate activation lives in LDS.  d_y_a / d_y_b (flat fp16, geometry
+ * (N_total, Cmid | Cout, H, W)) are written for the first n_keep images only -- what the data-gradient pass reads (ReLU gates, the
+ * pool's arg-max source); d_y_pool (geometry (N_total, Cout, H/2, W/2)) and the optional fp32 tap d_tap_b (n_run, Cout, H, W) for
+ * all n_run images.  Borders of the outputs are not touched (they are zero from npp_trunk_alloc-style zero initialisation).
+ * Bit-identical to npp_conv3x3 x 2 + npp_maxpool2_fwd.  npp_conv_pair_fwd_ok() != 0 says whether a shape is built. */
+int npp_conv_pair_fwd_ok(int H, int W, int Cin, int Cmid, int Cout);
+int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_keep, int H, int W, int Cin, int Cmid, int Cout,
+                      const void* d_pack_a, const float* d_bias_a, const void* d_pack_b, const float* d_bias_b,
+                      void* d_y_a, void* d_y_b, void* d_y_pool, float* d_tap_b, void* stream);
 int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
                            const void* d_pack, const void* d_xpre, const void* d_addend, void* d_dz,
                            const void* d_next_pack, int64_t next_pack_bytes, void* stream);

@@ -87,6 +87,7 @@ SYMBOLS = {
     "npp_version": (_i32, []),
     "npp_last_error_string": (C.c_char_p, []),
     "npp_device_count": (_i32, []),
+    "npp_tune": (_i32, [C.c_char_p, _i32]),
     "npp_param_layout": (_i32, [_i32, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(C.c_int32),
                                 C.POINTER(C.c_int32), C.POINTER(_i64)]),
     "npp_pack_bytes": (_i64, [_i32, _i32, _i32]),
@@ -197,6 +198,8 @@ SYMBOLS = {
                          _i64, _vp]),
     "npp_conv3x3_poolin_ok": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "npp_conv3x3_poolin": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, C.POINTER(C.c_float), _vp, _i64, _vp]),
+    "npp_conv_pair_fwd_ok": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "npp_conv_pair_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "npp_conv3x3_dgrad_pool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "npp_maxpool2_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "npp_maxpool2_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

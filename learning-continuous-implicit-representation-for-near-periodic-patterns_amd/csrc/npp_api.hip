@@ -324,6 +324,12 @@ __global__ void selftest_kernel(float* out) {
     }
 }
 
+static int tune_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 1)};
+
 }  // namespace npp
 
 using namespace npp;
@@ -331,6 +337,20 @@ using namespace npp;
 extern "C" {
 
 int npp_version(void) { return 100; }
+
+int npp_tune(const char* key, int value) {
+  struct { const char* k; int* v; } tab[] = {{"conv_wink", &g_tune.conv_wink}, {"conv_win", &g_tune.conv_win},
+                                             {"conv_wstat", &g_tune.conv_wstat}, {"conv_pair", &g_tune.conv_pair}};
+  if (key)
+    for (auto& t : tab)
+      if (!strcmp(key, t.k)) {
+        const int old = __atomic_load_n(t.v, __ATOMIC_RELAXED);
+        if (value >= 0) __atomic_store_n(t.v, value, __ATOMIC_RELAXED);
+        return old;
+      }
+  set_error("npp_tune: unknown key '%s'", key ? key : "(null)");
+  return NPP_ERR_ARG;
+}
 const char* npp_last_error_string(void) { return g_err; }
 
 int npp_device_count(void) {

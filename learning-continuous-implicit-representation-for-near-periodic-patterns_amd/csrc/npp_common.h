@@ -21,6 +21,17 @@ int check_launch(const char* what);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting of a kernel: each launch site remembers which devices
 // of this process already have it (bit d of the mask), so a second GPU driven from the same process is set up as well.
 struct SmemOnce { unsigned long long done = 0; };
+
+// Launch-time choices between kernel forms that compute the same result (npp_tune(); defaults = the measured-best forms).  Read
+// with relaxed loads by the launchers; an environment variable of the upper-cased name prefixed NPP_ (NPP_CONV_WINK=0) sets the
+// initial value, so that tools can A/B whole processes, and npp_tune() flips it inside one process (parity tests, probes).
+struct Tunables {
+  int conv_wink;      // 1: group-split window convolution on the channel-rich trunk layers; 0: never; 2: wherever feasible
+  int conv_win;       // 1: window-staged convolution on conv1_1 / conv1_2 / conv2_1 forward; 0: never; 2: wherever feasible
+  int conv_wstat;     // 1: weight-stationary block numbering where the pack outweighs the activations; 0: never
+  int conv_pair;      // 1: fused convolution pairs (conv a -> conv b [-> pool]) where the trunk asks for them; 0: never
+};
+extern Tunables g_tune;
 bool smem_attr(SmemOnce& once, const void* fn, int bytes);
 
 constexpr float kInv2Pi = 0.15915494309189535f;

@@ -33,6 +33,14 @@
 
 #include "npp_common.h"
 #include "npp_trunk_layout.h"
+#ifdef NPP_DIAG
+#include "npp_diag.h"          // tools/npp_diag.h: diagnostic builds only (in-kernel time stamps)
+#else
+#define NPP_DIAG_FIELD
+#define NPP_DIAG_FILL(a) do { } while (0)
+#define NPP_STAMP(a, k) do { } while (0)
+#define NPP_STAMP_DRAIN() do { } while (0)
+#endif
 
 namespace npp {
 
@@ -80,6 +88,7 @@ struct ConvArgs {
   // on a handful of position tiles (VGG16 conv4_x / conv5_x on the LPIPS branch's four patches: the launch is that traffic).  Here
   // channel group g lives on XCD g % 8: an XCD fetches one eighth of the pack and all (few) positions.
   int32_t wstat, wstat_npos, wstat_ncg;
+  NPP_DIAG_FIELD
 };
 
 __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -104,6 +113,8 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
   typedef typename OpT<FWD>::frag frag_t;                    // forward: fp16 operands; gradients: bf16
   typedef typename OpT<FWD>::elem elem_t;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [S][CT*PT][16 regs][64 lanes] when S > 1
+  NPP_STAMP(a, 0);
+  NPP_STAMP(a, 1);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = lane & 31, h = lane >> 5;
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 
 #pragma unroll
   for (int q = 0; q < kConvRing; ++q) load(q, ci_beg, q);
+  NPP_STAMP(a, 2);
   for (int ci = ci_beg; ci < ci_end; ++ci) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
     }
   }
 
+  NPP_STAMP(a, 3);
   // ---- epilogue of one 32 x 32 tile (ct, pt): bias / ReLU / gate, 16-bit store, optional fp32 tap -------
   auto finish = [&](const f32x16& v16, int ct, int pt, int q) {
     bool mine;
@@ -364,6 +377,9 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
       finish(v, t / PT, t % PT, q);
     }
   }
+  NPP_STAMP(a, 4);
+  NPP_STAMP_DRAIN();
+  NPP_STAMP(a, 5);
   asm volatile("" :: "v"(pf_val));
 }
 
@@ -399,6 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
   typedef typename OpT<MODE == kConvFwd>::elem elem_t;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char wlds[];
+  NPP_STAMP(a, 0);
+  NPP_STAMP(a, 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = lane & 31, h = lane >> 5;
@@ -527,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
   if (kWinDepth > 1 && a.CI > 1) gload(1, st[kWinDepth - 1]);
   sstore(0, st[0]);
   __syncthreads();
+  NPP_STAMP(a, 2);
   int buf = 0;
   const int posw = (kWinPos / 4) * wave + b;                        // this lane's first position inside the workgroup's 256
   // one step; PAR = ci % kWinDepth at compile time (the stage of an in-flight load must be a compile-time name)
@@ -537,18 +556,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
     else if (ci + 2 < a.CI) gload(ci + 2, st[PAR]);                 // stage PAR went to LDS before this step began
     const char* bA = wlds + buf * kBuf;
     const char* bW = bA + kA + h * kWinMaxUnits * 16;
+    // (round 5) tap + 1's fragments are requested before tap's MFMAs: see conv3x3_wink_kernel
+    frag_t A[2][CT], B[2][2];
+    auto lread = [&](int set, int tap) {
+      const int shift = (tap / 3) * a.Wp + (tap % 3);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) A[set][ct] = *(const frag_t*)(bA + ((ct * 9 + tap) * 64 + lane) * 16);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) B[set][pt] = *(const frag_t*)(bW + (posw + 32 * pt + shift) * 16);
+    };
+    lread(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int shift = (tap / 3) * a.Wp + (tap % 3);
-      frag_t A[CT], B[2];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) A[ct] = *(const frag_t*)(bA + ((ct * 9 + tap) * 64 + lane) * 16);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) B[pt] = *(const frag_t*)(bW + (posw + 32 * pt + shift) * 16);
+      if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = mfma16(A[ct], B[pt], acc[ct][pt]);
+        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = mfma16(A[tap & 1][ct], B[tap & 1][pt], acc[ct][pt]);
     }
     if (has_next) sstore(buf ^ 1, st[NXT]);
     __syncthreads();
@@ -558,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
     step(ci, std::integral_constant<int, 0>{});
     if (kWinDepth > 1 && ci + 1 < a.CI) step(ci + 1, std::integral_constant<int, kWinDepth - 1>{});
   }
+  NPP_STAMP(a, 3);
   // ---- epilogue: the same per-tile finish as conv3x3_kernel
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -590,6 +615,212 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
         if (a.y) ((frag_t*)a.y)[unit] = o;
       }
     }
+  NPP_STAMP(a, 4);
+  NPP_STAMP_DRAIN();
+  NPP_STAMP(a, 5);
+  asm volatile("" :: "v"(pf_val));
+}
+
+// ---- window-staged form with the contraction split over wave GROUPS (round 5) -------------------------------------
+// What bounds the channel-rich layers of the loop (relu3_x: 256 -> 256 on 8 k positions, conv2_2) in conv3x3_kernel is the operand
+// stream of a CU: a 2 x 2-tile workgroup pulls 64 couts x 2304 k x 2 B = 295 KB of weights AND 9 taps x 64 positions x 256 channels
+// x 2 B = 295 KB of activations through the vector memory pipe for 144 MFMAs per wave -- two such workgroups per CU are 1.18 MB at
+// the ~64 B/clk a CU draws = 9 us of a 17-us launch, against 4.6 us of matrix time.  The window form (one input window per
+// channel step in LDS, the nine taps as shifted LDS reads) cuts the activation half 6 x, and a workgroup that owns 128 / 256
+// positions instead of 64 halves / quarters the weight half per MFMA -- but with 4 waves per 256 positions the deep layers gave
+// only 128 workgroups of one wave per SIMD (round 4: slower).  Here a workgroup is KG groups of four waves: group g contracts the
+// channel steps ci = g (mod KG) from its OWN double-buffered LDS stage (weights of the step + the step's window, staged by the
+// group's 256 threads), all groups cover the same CT x 32 output channels x 128 NPT positions, and the partial tiles meet in LDS at
+// the end (fixed group order: deterministic).  relu3_x: 256 workgroups of 8 waves, one per CU, 388 KB of operands each.
+constexpr int kWinkMaxWp = 98;                      // widest padded row the staging registers are sized for (96-pixel maps)
+template <int CT, int NPT, int KG, int MODE>
+__global__ __launch_bounds__(256 * KG) void conv3x3_wink_kernel(ConvArgs a, int wu /* window units per chunk in LDS (>= WIN) */) {
+  constexpr bool FWD = MODE == kConvFwd;
+  typedef typename OpT<FWD>::frag frag_t;
+  typedef typename OpT<FWD>::elem elem_t;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char klds[];
+  NPP_STAMP(a, 0);
+  NPP_STAMP(a, 1);
+  constexpr int WP = 128 * NPT;                                      // positions of a workgroup
+  constexpr int NT = CT * NPT;                                       // output tiles of a wave
+  static_assert(NT % KG == 0, "tiles must split over the groups");
+  constexpr int NF = NT / KG;                                        // tiles a wave finishes
+  const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pw = wave & 3, kg = wave >> 2;
+  const int b = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);      // consecutive position blocks (shared halo rows) on one XCD
+  uint32_t pf_val = 0;
+  if (a.pf) {
+    const int64_t line = ((int64_t)((blockIdx.x >> 3) + blockIdx.y * ((gridDim.x + 7) >> 3)) * blockDim.x + threadIdx.x) * 128;
+    if (line + 4 <= a.pf_bytes) pf_val = *(const volatile uint32_t*)(a.pf + line);
+  }
+  const int tile0 = bid * (WP / 32);
+  const int cot0 = blockIdx.y * CT;
+  const int KS = a.CI * 9;
+  const int halo = a.Wp + 1, WIN = WP + 2 * halo;
+  constexpr int kA = CT * 9 * 1024;                                 // bytes of weight fragments per channel step
+  const int kBuf = kA + 2 * wu * 16;                                // one stage: weights + the two chunks' windows
+  constexpr int NA = (CT * 9 * 64 + 255) / 256;
+  constexpr int NW = (2 * (WP + 2 * (kWinkMaxWp + 1)) + 255) / 256;
+  const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack), 0, (int)a.pack_bytes, 0x00020000);
+  const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  int offA[NA], offW[NW], dstW[NW];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tg + 256 * i;                                     // unit (ct, tap, lane) of the step
+    const int ct = u / 576, r = u - ct * 576;
+    offA[i] = u < CT * 576 ? ((cot0 + ct) * KS) * 1024 + r * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int u = tg + 256 * i;
+    const int chunk = u >= WIN, pos = u - chunk * WIN;
+    offW[i] = u < 2 * WIN ? (int)((((int64_t)chunk * a.nposp) + kConvGuard + (int64_t)tile0 * 32 - halo + pos) * 16) : -1;
+    dstW[i] = kA + (chunk * wu + pos) * 16;
+  }
+  struct Stage { u32x4_t a[NA], w[NW]; };
+  Stage st;
+  auto gload = [&](int ci, Stage& r) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (offA[i] >= 0 || NA * 256 == CT * 576) r.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, offA[i] < 0 ? 0 : offA[i], ci * 9 * 1024, 0);
+    const uint32_t soff = (uint32_t)((int64_t)2 * ci * a.nposp * 16);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, offW[i] < 0 ? 0 : offW[i], (int)soff, 0);
+  };
+  char* const gbase = klds + kg * 2 * kBuf;                          // this group's two stages
+  auto sstore = [&](int buf, const Stage& r) {
+    char* base = gbase + buf * kBuf;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (offA[i] >= 0) *(u32x4_t*)(base + (tg + 256 * i) * 16) = r.a[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = r.w[i];
+  };
+  f32x16 acc[CT][NPT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.0f;
+  // epilogue operands of the tiles this wave finishes (tile t = ct * NPT + pt with t % KG == kg), requested before the contraction
+  f16x8 gate[MODE == kConvDgradMask ? NF : 1][2];
+  float bias_r[FWD ? NF : 1][16];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) {
+    const int t = kg + q * KG, ct = t / NPT, pt = t % NPT;
+    if (FWD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias_r[q][r] = a.bias[32 * (cot0 + ct) + acc_row(r, h)];
+    }
+    if (MODE == kConvDgradMask) {
+      const int64_t p = (int64_t)(tile0 + NPT * pw + pt) * 32 + b;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = 4 * (cot0 + ct) + 2 * s + h;
+        if (chunk < a.cout_chunks) gate[q][s] = ((const f16x8*)a.mask)[(int64_t)chunk * a.nposp + kConvGuard + p];
+      }
+    }
+  }
+  gload(kg, st);
+  sstore(0, st);
+  __syncthreads();
+  NPP_STAMP(a, 2);
+  int buf = 0;
+  const int posw = (WP / 4) * pw + b;                               // this lane's first position inside the workgroup's WP
+  for (int ci = kg; ci < a.CI; ci += KG) {
+    const bool has_next = ci + KG < a.CI;
+    if (has_next) gload(ci + KG, st);
+    const char* bA = gbase + buf * kBuf;
+    const char* bW = bA + kA + h * wu * 16;
+    // the fragments of tap + 1 are requested BEFORE the MFMAs of tap (two register sets): an LDS read takes ~130-200 cycles under
+    // load against 64 NPT cycles of matrix work per tap -- read-wait-multiply per tap left the pipe idle 55 % of the loop
+    frag_t A[2][CT], B[2][NPT];
+    auto lread = [&](int set, int tap) {
+      const int shift = (tap / 3) * a.Wp + (tap % 3);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) A[set][ct] = *(const frag_t*)(bA + ((ct * 9 + tap) * 64 + lane) * 16);
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) B[set][pt] = *(const frag_t*)(bW + (posw + 32 * pt + shift) * 16);
+    };
+    lread(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = mfma16(A[tap & 1][ct], B[tap & 1][pt], acc[ct][pt]);
+    }
+    if (has_next) sstore(buf ^ 1, st);
+    __syncthreads();
+    buf ^= 1;
+  }
+  NPP_STAMP(a, 3);
+  // ---- the groups' partial tiles meet in LDS (the stages are dead behind the last barrier): slot (pw, g, t) = 4 KiB ----
+  float* red = (float*)klds;
+  if (KG > 1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t % KG == kg) continue;                                   // (mine to finish: stays in registers)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((pw * KG + kg) * NT + t) * 16 + r) * 64 + lane] = acc[t / NPT][t % NPT][r];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {                                    // (t compile-time: a run-time tile index would put acc in scratch)
+    if (t % KG != kg) continue;
+    const int q = t / KG, ct = t / NPT, pt = t % NPT;
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.0f;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {                                  // fixed order: group 0 first
+      if (g == kg) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += acc[ct][pt][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += red[(((pw * KG + g) * NT + t) * 16 + r) * 64 + lane];
+      }
+    }
+    const int64_t p = (int64_t)(tile0 + NPT * pw + pt) * 32 + b;
+    const int n = (int)((uint32_t)p / (uint32_t)a.S);
+    const int r0 = (int)(p - (int64_t)n * a.S);
+    const int yy = r0 / a.Wp, xx = r0 - yy * a.Wp;
+    const bool interior = p < a.npos_valid && yy >= 1 && yy <= a.H && xx >= 1 && xx <= a.W;
+    const int64_t tap_base = (((int64_t)n * a.Ctap) * a.H + (yy - 1)) * a.W + (xx - 1);
+    const int cot = cot0 + ct;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = 4 * cot + 2 * s + h;
+      if (chunk >= a.cout_chunks) continue;
+      const int64_t unit = (int64_t)chunk * a.nposp + kConvGuard + p;
+      frag_t o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int co = 32 * cot + acc_row(8 * s + j, h);
+        float x = v[8 * s + j];
+        if (FWD) x = fminf(fmaxf(x + bias_r[q][8 * s + j], 0.0f), 65504.0f);
+        if (MODE == kConvDgradMask) x = (float)gate[q][s][j] > 0.0f ? x : 0.0f;
+        x = interior ? x : 0.0f;
+        o[j] = (elem_t)x;
+        if (a.tap && interior && co < a.Ctap)
+          a.tap[tap_base + (int64_t)co * a.H * a.W] = a.has_scale ? x * a.tap_scale[co & 3] : x;
+      }
+      if (a.y) ((frag_t*)a.y)[unit] = o;
+    }
+  }
+  NPP_STAMP(a, 4);
+  NPP_STAMP_DRAIN();
+  NPP_STAMP(a, 5);
   asm volatile("" :: "v"(pf_val));
 }
 
@@ -948,6 +1179,11 @@ __global__ void trunk_export_kernel(const void* __restrict__ act_, int N, int C,
 
 using namespace npp;
 
+#ifdef NPP_DIAG
+namespace npp { unsigned long long* g_diag_stamps = nullptr; long long g_diag_n = 0; }
+extern "C" void npp_diag_set_stamps(unsigned long long* buf, long long n_words) { npp::g_diag_stamps = buf; npp::g_diag_n = n_words; }
+#endif
+
 static int conv_geom_check(int N, int H, int W, const char* who) {
   if (N < 1 || H < 1 || W < 1 || W + 3 > kConvGuard) {
     set_error("%s: bad geometry N=%d H=%d W=%d (W <= %d)", who, N, H, W, kConvGuard - 3);
@@ -1209,6 +1445,7 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   a.pack_bytes = (uint32_t)((int64_t)cot_n * a.CI * 9 * 1024);
   a.pf = (const char*)d_next_pack;
   a.pf_bytes = d_next_pack ? next_pack_bytes : 0;
+  NPP_DIAG_FILL(a);
   if (fold && fold->ypool) {                       // forward + pool: two-row position tiles over the n_run images' interiors
     a.pool_dz = fold->ypool;
     a.pool_nposp = conv_nposp(N_total, H / 2, W / 2);
@@ -1261,8 +1498,35 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
     const int64_t need = mode == kConvFwdPool ? c.min_wgs * 9 / 10 : c.min_wgs;
     if (feasible(c) && wgs(c) >= need) { pick = c; found = true; }
   }
+  // window form with the contraction split over wave groups (conv3x3_wink_kernel): channel-rich layers (>= 8 channel steps) whose
+  // positions give about one 8-wave workgroup per CU; NPP_CONV_WINK=0: never (A/B comparator), 2: wherever feasible (probe)
+  const int wink_mode = __atomic_load_n(&g_tune.conv_wink, __ATOMIC_RELAXED);
+  if (wink_mode && !forced && !fold && cot_n % 2 == 0 && a.Wp <= kWinkMaxWp && a.CI % 2 == 0 && (a.CI >= 8 || wink_mode == 2) &&
+      (mode == kConvFwd || mode == kConvDgradMask || mode == kConvDgradLin)) {
+    const int64_t wgs2 = (int64_t)(a.pos_tiles / 8) * (cot_n / 2), wgs1 = (int64_t)(a.pos_tiles / 4) * (cot_n / 2);
+    const int npt = (a.pos_tiles % 8 == 0 && wgs2 >= 200) ? 2 : ((a.pos_tiles % 4 == 0 && (wgs1 >= 200 || wink_mode == 2)) ? 1 : 0);
+    if (npt) {
+      const int WPk = 128 * npt, wu = (WPk + 2 * (a.Wp + 1) + 7) / 8 * 8;
+      const int stage = 2 * 9 * 1024 + 2 * wu * 16;
+      const int red = 4 * 2 * (2 * npt) * 4096;
+      const int smem = 2 * 2 * stage > red ? 2 * 2 * stage : red;
+      const dim3 kgrid((unsigned)(a.pos_tiles / (4 * npt)), (unsigned)(cot_n / 2));
+#define NPP_WINK_GO(NPT_, M)                                                                                                    \
+      do {                                                                                                                        \
+        static SmemOnce once;                                                                                                     \
+        if (!smem_attr(once, (const void*)conv3x3_wink_kernel<2, NPT_, 2, M>, 160 * 1024)) { set_error("npp_conv3x3: smem attribute"); return NPP_ERR_LAUNCH; } \
+        hipLaunchKernelGGL((conv3x3_wink_kernel<2, NPT_, 2, M>), kgrid, dim3(512), smem, s, a, wu);                               \
+      } while (0)
+      if (smem <= 160 * 1024) {
+        if (npt == 2) { if (mode == kConvFwd) NPP_WINK_GO(2, kConvFwd); else if (mode == kConvDgradMask) NPP_WINK_GO(2, kConvDgradMask); else NPP_WINK_GO(2, kConvDgradLin); }
+        else { if (mode == kConvFwd) NPP_WINK_GO(1, kConvFwd); else if (mode == kConvDgradMask) NPP_WINK_GO(1, kConvDgradMask); else NPP_WINK_GO(1, kConvDgradLin); }
+        return check_launch("npp_conv3x3");
+      }
+#undef NPP_WINK_GO
+    }
+  }
   // window-staged form (conv3x3_win_kernel): few input-channel steps, many positions, 64-channel output blocks
-  static const int win_mode = getenv("NPP_CONV_WIN") ? atoi(getenv("NPP_CONV_WIN")) : 1;     // 0: never (A/B comparator)
+  const int win_mode = __atomic_load_n(&g_tune.conv_win, __ATOMIC_RELAXED);     // 0: never (A/B comparator)
   const int64_t win_wgs = (int64_t)(a.pos_tiles / 8) * (cot_n / 2);
   if (win_mode && !forced && !fold && a.CI <= 8 && cot_n % 2 == 0 && a.pos_tiles % 8 == 0 && 2 * (a.Wp + 1) + kWinPos <= kWinMaxUnits &&
       ((win_wgs >= 200 && mode == kConvFwd && a.CI <= 4) || win_mode == 2)) {       // measured: only these layers gain (conv1_1, conv1_2, conv2_1 forward)
@@ -1282,7 +1546,7 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
   }
   dim3 grid((unsigned)(a.pos_tiles / pick.pt), (unsigned)(cot_n / pick.ct));
   // weight-stationary numbering where the pack outweighs the activations the launch reads and there are channel groups for all XCDs
-  static const int wstat_mode = getenv("NPP_CONV_WSTAT") ? atoi(getenv("NPP_CONV_WSTAT")) : 1;     // 0: never (A/B comparator)
+  const int wstat_mode = __atomic_load_n(&g_tune.conv_wstat, __ATOMIC_RELAXED);     // 0: never (A/B comparator)
   const int64_t act_bytes = (int64_t)(Cin / 8) * range * 16;
   if (wstat_mode && (int)grid.y >= 8 && (int64_t)a.pack_bytes > 2 * act_bytes) {
     a.wstat = 1; a.wstat_npos = (int)grid.x; a.wstat_ncg = (int)grid.y;

@@ -99,7 +99,7 @@ class _Trunk(nn.Module):
 class _HipTrunkFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, trunk, n_grad, scale, shift):
-        taps = trunk._forward(x.contiguous(), scale, shift)
+        taps = trunk._forward(x.contiguous(), scale, shift, n_keep=n_grad)
         ctx.trunk, ctx.n_grad, ctx.scale, ctx.gen, ctx.shape = trunk, n_grad, scale, trunk._gen, tuple(x.shape)
         return tuple(taps)
 
@@ -147,6 +147,10 @@ class HipTrunk:
         # measured SLOWER in the c2 iteration -- trunk forward 130.5 -> 133.8 us, same box (four strided 16-byte loads per window unit
         # cost more than the 5.4-us pool launch they replace; profiles/r04_pool_fold_ab.txt 3.) -- hence opt-in
         self.fold_pool_in = os.environ.get("NPP_POOL_FOLD_IN", "0") != "0"
+        # conv a -> conv b -> pool of the first blocks as ONE launch (ops.conv_pair_fwd; round 5): the intermediate activation
+        # stays in LDS, the layer outputs are stored only for the images that carry a gradient
+        self.fuse_pairs = ops.tune("conv_pair") != 0
+        self._n_keep = None
 
     def twin(self):
         """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
@@ -156,6 +160,7 @@ class HipTrunk:
         t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
         t.fold_pool_bwd, t.fold_pool_fwd, t.fold_pool_fwd_min_cin = self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin
         t.fold_pool_in = self.fold_pool_in
+        t.fuse_pairs, t._n_keep = self.fuse_pairs, None
         return t
 
     def _pb_below(self, j):
@@ -179,18 +184,40 @@ class HipTrunk:
         """The flat C=16 input tensor of an (N,3,H,W) batch, for producers that write it directly (ops.trunk_patch_in)."""
         return self._flat("x0", N, 16, H, W)
 
-    def _forward(self, x, scale, shift, x0_ready=False, n_run=None):
+    def _forward(self, x, scale, shift, x0_ready=False, n_run=None, n_keep=None):
         """x: the (N,3,H,W) batch, or just its shape when the flat input was already written (x0_ready).  n_run: only the leading
-        n_run images are computed (N fixes the buffers' geometry; rows >= n_run of the returned taps are undefined)."""
+        n_run images are computed (N fixes the buffers' geometry; rows >= n_run of the returned taps are undefined).  n_keep: the
+        leading images a _backward() may follow for (None: all): a fused layer pair stores its layer outputs only for those."""
         N, _, H, W = x if x0_ready else x.shape
         nr = N if n_run is None else int(n_run)
+        self._n_keep = nr if n_keep is None else min(int(n_keep), nr)
         self._gen += 1
         self._geom = []
+        skip = 0
         cur = self._flat("x0", N, 16, H, W)
         if not x0_ready:
             ops.trunk_image_in(x, scale, shift, cur)
         c, outs, pooled, prepool = 16, [], None, None
         for j, L in enumerate(self.layers):
+            if skip:                                                  # layers j-1 .. of a fused pair: already run
+                skip -= 1
+                continue
+            Lb = self.layers[j + 1] if j + 2 < len(self.layers) else None
+            if (self.fuse_pairs and L["kind"] == "conv" and Lb is not None and Lb["kind"] == "conv" and self.layers[j + 2]["kind"] == "pool"
+                    and prepool is None and L["relu_idx"] not in self.taps and self.layers[j + 2]["idx"] not in self.taps
+                    and ops.conv_pair_fwd_ok(H, W, c, L["cout"], Lb["cout"])):
+                ya = self._flat(("a", j), N, L["cout"], H, W)
+                yb = self._flat(("a", j + 1), N, Lb["cout"], H, W)
+                yp = self._flat(("a", j + 2), N, Lb["cout"], H // 2, W // 2)
+                tap = None
+                if Lb["relu_idx"] in self.taps:
+                    tap = torch.empty((N, Lb["cout"], H, W), dtype=torch.float32, device=self.device)
+                    outs.append(tap)
+                ops.conv_pair_fwd(cur, N, nr, self._n_keep, H, W, c, L["cout"], Lb["cout"], L["pf"], L["b"], Lb["pf"], Lb["b"],
+                                  ya, yb, yp, tap)
+                self._geom += [(ya, L["cout"], H, W), (yb, Lb["cout"], H, W), (yp, Lb["cout"], H // 2, W // 2)]
+                c, H, W, cur, pooled, skip = Lb["cout"], H // 2, W // 2, yp, None, 2
+                continue
             if L["kind"] == "conv":
                 y = self._flat(("a", j), N, L["cout"], H, W)
                 tap = None
@@ -252,6 +279,8 @@ class HipTrunk:
         dimg = (torch.zeros if zero_rest else torch.empty)(xshape, dtype=torch.float32, device=self.device)
         if n == 0:
             return dimg
+        if self._n_keep is not None and n > self._n_keep:
+            raise RuntimeError(f"HipTrunk: backward for {n} images after a forward that kept the layer outputs of {self._n_keep}")
         tap_of = {}
         k = 0
         for j, L in enumerate(self.layers):
@@ -396,7 +425,7 @@ class ContextualLoss(nn.Module):
         SHAPE of the batch, whose normalised flat form was already written into hip_trunk.input_buffer()."""
         t = self.hip_trunk
         sc, sh = self.input_norm()
-        f = t._forward(xy, sc, sh, x0_ready)[0]
+        f = t._forward(xy, sc, sh, x0_ready, n_keep=n)[0]
         shape = tuple(xy) if x0_ready else tuple(xy.shape)
         if weight is None and _CX_FLAT:
             # the core's last launch writes the trunk's flat gradient tensor itself (no fp32 dL/dfeatures, no npp_trunk_grad_in)
@@ -538,7 +567,7 @@ class LPIPS(nn.Module):
             dfs[kk] = df0
         # (Measured and dropped, round 4: the five heads -- 15-25 us each, 100 us in a row behind the trunk -- on a helper stream beside
         # the deeper layers of the forward pass: the 'same' iteration went 0.791 -> 0.811 ms; the branch is not what the device waits for.)
-        feats = t._forward(xy, sc, sh)
+        feats = t._forward(xy, sc, sh, n_keep=n)
         if self.grouped_heads:                                  # the five heads in ONE launch (they are independent: 100 us in a row before)
             N = xy.shape[0]
             # the taps right before a pool hand their gradient over as the flat bf16 tensor the backward pass adds in (no fp32
@@ -626,7 +655,7 @@ class StyleLoss:
         """Explicit forward + backward of scale * style_loss(xy[:n], xy[n:], weight): returns dL/dxy ([:n] defined)."""
         ones, zeros = (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)
         t = self.hip_trunk
-        feats = t._forward(xy, ones, zeros)
+        feats = t._forward(xy, ones, zeros, n_keep=n)
         dfs = self.head(feats, n, scale, loss_buf, weight)
         return t._backward(dfs, n, ones, tuple(xy.shape), zero_rest=False)
 

@@ -11,6 +11,21 @@ from ._lib import lib, check, EmbedCfg, param_layout, NPP_ROW_TILE, NPP_E, NPP_W
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+def tune(key, value=-1):
+    """npp_tune: choose between kernel forms that compute the same result ("conv_wink", "conv_win", "conv_wstat", "conv_pair");
+    value < 0 only reads.  -> the previous value.  Both fused-width libraries are set (the trunk kernels live in the first)."""
+    from ._lib import FUSED_WIDTHS
+    old = None
+    for w in FUSED_WIDTHS:
+        try:
+            r = lib(w).npp_tune(key.encode(), int(value))
+        except OSError:
+            continue
+        check(r, "npp_tune", w)
+        old = r if old is None else old
+    return old
+
+
 def _stream():
     """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object per
     call (5-8 us, x ~45 kernel calls per iteration: it was most of the host enqueue time); the raw accessor is ~0.3 us."""
@@ -560,6 +575,17 @@ def conv3x3_pool(x, N_total, n_run, H, W, cin, cout, pack, bias, y, ypool, tap=N
     nb = 0 if next_pack is None else next_pack.numel() * next_pack.element_size()
     check(lib().npp_conv3x3_pool(_p(x), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), _p(y), _p(ypool), _p(tap), ctap, ts,
                                  _p(next_pack), nb, _stream()), "npp_conv3x3_pool")
+
+
+def conv_pair_fwd_ok(H, W, cin, cmid, cout):
+    """Whether the fused conv a -> conv b -> pool launch is built for this shape (and switched on: tune("conv_pair"))."""
+    return bool(lib().npp_conv_pair_fwd_ok(H, W, cin, cmid, cout))
+
+
+def conv_pair_fwd(x, N_total, n_run, n_keep, H, W, cin, cmid, cout, pack_a, bias_a, pack_b, bias_b, y_a, y_b, y_pool, tap_b=None):
+    """relu(conv a) -> relu(conv b) -> MaxPool2d(2,2) in one launch; y_a / y_b only for the first n_keep images."""
+    check(lib().npp_conv_pair_fwd(_p(x), N_total, n_run, n_keep, H, W, cin, cmid, cout, _p(pack_a), _p(bias_a), _p(pack_b), _p(bias_b),
+                                  _p(y_a), _p(y_b), _p(y_pool), _p(tap_b), _stream()), "npp_conv_pair_fwd")
 
 
 def conv3x3_poolin_ok(N_total, n_run, H, W, cin, cout):

@@ -258,7 +258,7 @@ class StackedFit:
                     dxb = f.lpips_branch(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1])     # (a captured graph from its third use on)
                     self.dxb[i, :nk].copy_(dxb[:nk])
         shape = (self.N_total, 3, self.P, self.P)
-        feats = t._forward(shape, sc, sh, True, n_run=2 * X)[0]
+        feats = t._forward(shape, sc, sh, True, n_run=2 * X, n_keep=X)[0]
 
         def top(y, N, nn, c, H, W, dz):                   # the core's last launch writes the trunk's flat gradient tensor itself
             ops.cx_fwd_bwd_flat(feats[:X], feats[X:2 * X], y, dz, N, cx.band_width, self.cx_w, self.patch_loss, 1, it_dev, M)
