@@ -550,6 +550,7 @@ def main():
                 "wgrad_mfma_frac": tf["mlp_wgrad"] / PEAK_BF16_TFLOPS,
                 "fwd_us": kt_roof["mlp_fwd_train"] * 1e6, "bwd_us": kt_roof["mlp_bwd_chain"] * 1e6, "wgrad_us": kt_roof["mlp_wgrad"] * 1e6,
                 "mfma_pipe_busy_frac_pmc": mfma_pmc,
+                "stacked_M8_fwd_mfma_frac": None, "stacked_M8_bwd_mfma_frac": None, "stacked_M8_wgrad_mfma_frac": None,
                 "all_kernels_us_in_iteration": {k: round(v * 1e6, 2) for k, v in kt_iter.items()},
                 "all_kernels_us_in_sequence": {k: round(v * 1e6, 2) for k, v in kt_seq.items()},
                 "all_kernels_mfma_frac_mlp_only_step": {k: round(v / PEAK_BF16_TFLOPS, 4) for k, v in tf_seq.items()},
@@ -830,6 +831,33 @@ def main():
                   bs_ = st.sample()
                   ts_.append(timed(lambda: st.step_from(bs_), reps=20))
               t_dev = float(np.mean(ts_))
+              # the three MLP launches of the stacked iteration between HIP events (same wrapping as in_iteration_times): rows of ALL
+              # M images per launch against the launch's duration
+              rec_ = {"mlp_fwd_stack": [], "mlp_bwd_patch_stack": [], "mlp_wgrad_stack": []}
+              saved_ = {}
+              for fn_ in rec_:
+                  saved_[fn_] = getattr(ops, fn_)
+
+                  def timed_call_(*a_, __o=saved_[fn_], __k=fn_, **k_):
+                      e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                      e0_.record()
+                      r_ = __o(*a_, **k_)
+                      e1_.record()
+                      rec_[__k].append((e0_, e1_))
+                      return r_
+                  setattr(ops, fn_, timed_call_)
+              try:
+                  for _ in range(20):
+                      st.step_from(bs_)
+                  torch.cuda.synchronize()
+              finally:
+                  for fn_, o_ in saved_.items():
+                      setattr(ops, fn_, o_)
+              kus_ = {k_: float(np.median([a_.elapsed_time(b_) for a_, b_ in v_])) * 1e3 for k_, v_ in rec_.items() if v_}
+              n_act_ = sum(1 for b_ in bs_ if b_ is not None)
+              kfl_ = {"mlp_fwd_stack": 2 * fwd_macs * n_rows * n_act_, "mlp_bwd_patch_stack": 2 * (train_macs - 2 * fwd_macs) * n_rows * n_act_,
+                      "mlp_wgrad_stack": 2 * fwd_macs * n_rows * n_act_}
+              kfr_ = {k_: kfl_[k_] / (v_ * 1e-6) / 1e12 / PEAK_BF16_TFLOPS for k_, v_ in kus_.items()}
               torch.cuda.synchronize()
               t6 = time.perf_counter()
               for _ in range(100):
@@ -839,13 +867,20 @@ def main():
               stacked[f"stacked_M{M_}"] = {"ms_per_stacked_iteration": t_dev * 1e3, "rows_per_s": M_ * n_rows / t_dev,
                                            "x_single": M_ * n_rows / t_dev / single_now, "x_headline_value": M_ * n_rows / t_dev / value, "wgrad_ksplit_per_image": st.ksplit,
                                            "e2e_ms_per_stacked_iteration": t_e2e * 1e3, "e2e_rows_per_s": M_ * n_rows / t_e2e,
-                                           "e2e_x_single": (M_ * e2e1 * 1e-3 / t_e2e) if e2e1 else None}
+                                           "e2e_x_single": (M_ * e2e1 * 1e-3 / t_e2e) if e2e1 else None,
+                                           "mlp_launch_us": {k_: round(v_, 1) for k_, v_ in kus_.items()},
+                                           "mlp_launch_mfma_frac": {k_: round(v_, 4) for k_, v_ in kfr_.items()}}
               st.close()
               del st, fs
               torch.cuda.empty_cache()
           except Exception as ex_:                        # (e.g. M = 8 at 1024^2: 96 patches of 160^2 exceed one trunk launch)
             stacked[f"stacked_M{M_}"] = {"error": str(ex_)[:200]}
 
+    if stacked and isinstance(stacked.get("stacked_M8"), dict) and "mlp_launch_mfma_frac" in stacked["stacked_M8"]:
+        fr8 = stacked["stacked_M8"]["mlp_launch_mfma_frac"]
+        roofline["stacked_M8_fwd_mfma_frac"] = fr8.get("mlp_fwd_stack")
+        roofline["stacked_M8_bwd_mfma_frac"] = fr8.get("mlp_bwd_patch_stack")
+        roofline["stacked_M8_wgrad_mfma_frac"] = fr8.get("mlp_wgrad_stack")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(K, H, patch, n_pix, fit.patch_num, fit.topk)

@@ -1,0 +1,38 @@
+"""Round 5: the stacked loop (npp_amd.stack.StackedFit, M images per launch sequence) as a profiling target: pre-drawn batch sets,
+device-only iterations -- run it under `rocprofv3 --kernel-trace --stats` (tools/r5_stack_prof.sh) for per-kernel durations, or
+with --pmc for FETCH_SIZE / WRITE_SIZE / SQ counters.  usage: r5_stack_prof.py [M] [iterations]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from npp_amd import synthetic as syn                 # noqa: E402
+from npp_amd.fit import CompletionFit                # noqa: E402
+from npp_amd.stack import StackedFit                 # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+H, K = 512, 3
+angles, periods, shifts = syn.synthetic_periodicity(H, K)
+fits = []
+for i in range(M):
+    img, mask = syn.synthetic_image(H, seed=i)
+    fits.append(CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=i), device=dev, N_rand=8192,
+                              shifts=shifts, seed=i, rng_mode="fast"))
+st = StackedFit(fits)
+for _ in range(10):
+    st.step_full()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(ITERS):
+    st.step_full()                                    # (the next draw rides on the sampler stream under the iteration)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / ITERS
+rows = fits[0].N_rand + fits[0].patch_num * fits[0].patch_size ** 2
+print(f"stacked M = {M}: {dt * 1e3:.4f} ms per stacked iteration (incl. sampling), {M * rows / dt / 1e6:.2f} M rows/s, ksplit {st.ksplit}")
+st.close()
