@@ -269,17 +269,27 @@ class CompletionFit:
         self.step_from(batch)
         return True
 
+    def decay_due(self):
+        """Whether the NEXT draw_batch() halves the patch size first (train.py:137-141: by iteration index, trange(start=1))."""
+        i = self._draw_iter + 1
+        return (self.patch_sampler is not None and i % self.patch_size_decay == 0 and i != 1 and self.patch_size > 31
+                and getattr(self, "_decayed_at", None) != i)
+
+    def apply_decay(self):
+        """The patch-size decay of the next iteration, now (a StackedFit re-forms around the new batch shape before it draws)."""
+        self._decayed_at = self._draw_iter + 1
+        self.patch_size //= 2
+        self.patch_num *= 2
+        self.patch_sampler.reset_patchsize(None, None, self.patch_size, self.patch_num)
+        self.patch_sampler.reset_pool(self.i_train, self.i_val)
+
     # ---- host half of one iteration's sampling (no device work: may run ahead on the producer thread) -------------
     def draw_batch(self):
         """train.py:137-141 (patch-size decay, by iteration index), :152-157 (sample_patches) and :172 (pixel draw), in the
         reference's RNG order.  One call per loop iteration, including the ones that end up skipped."""
+        if self.decay_due():
+            self.apply_decay()
         self._draw_iter += 1
-        i = self._draw_iter                                       # trange(start=1, N_iters)
-        if i % self.patch_size_decay == 0 and i != 1 and self.patch_size > 31:          # train.py:137-141
-            self.patch_size //= 2
-            self.patch_num *= 2
-            self.patch_sampler.reset_patchsize(None, None, self.patch_size, self.patch_num)
-            self.patch_sampler.reset_pool(self.i_train, self.i_val)
         d = self.patch_sampler.draw(topk=self.topk, invalid_ratio=self.invalid_ratio)
         d["n_p"] = self.patch_num
         if d["k"] > 0:

@@ -39,8 +39,10 @@ class StackedFit:
         net0 = f0.net
         self.K, self.width = net0.K, net0.width
         for f in fits:
-            if f.patch_sampler is None or f.task != "completion" or f.style is not None:
-                raise ValueError("StackedFit: completion fits with the patch losses (shifts=...) only")
+            # (segmentation is the completion loop with other inputs and weights -- NPP_segmentation/train.py:148-286; the remapping
+            #  task's style loss and pixel-weight mask are not stacked)
+            if f.patch_sampler is None or f.task not in ("completion", "segmentation") or f.style is not None or f.task != f0.task:
+                raise ValueError("StackedFit: completion / segmentation fits (one task per stack) with the patch losses (shifts=...) only")
             if (f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.device, f.net.quad) != (
                     self.K, self.width, f0.N_rand, f0.patch_size, f0.patch_num, f0.topk, f0.device, net0.quad):
                 raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count, loss_type and the device")
@@ -167,13 +169,30 @@ class StackedFit:
         st["gen"] = out.gen = st.get("gen", 0) + 1
         return out
 
+    def shape_change_due(self):
+        """Whether the next draw changes the batch shape (an image's patch-size decay, train.py:137-141): the stack must then be
+        re-formed (restacked()) before it draws."""
+        return self._ahead is None and any(f.decay_due() for f in self.fits)
+
+    def restacked(self):
+        """-> a new StackedFit over the same fits, after the patch-size decay that is due (the fits' tensors are views of this stack's
+        blobs; the new stack copies them into blobs of the new batch shape).  This object must not be stepped again."""
+        if self._ahead is not None:
+            raise RuntimeError("StackedFit.restacked: a look-ahead draw is pending")
+        torch.cuda.synchronize(self.device)
+        for f in self.fits:
+            if f.decay_due():
+                f.apply_decay()
+        return StackedFit(self.fits)
+
     def step_full(self):
         """One iteration of the loop body for every image of the stack.  -> number of images that took a step.  The NEXT
         iteration's sampling (host draws + device half) is issued right behind this one's launches: it never reads network state, so
         the random streams and the results are those of the serial order; it runs on a side stream under this iteration's kernels."""
         b = self.sample()
         n = self.step_from(b)
-        self._ahead = self._draw()
+        # (no look-ahead across a patch-size decay: the next draw belongs to another batch shape)
+        self._ahead = None if any(f.decay_due() for f in self.fits) else self._draw()
         return n
 
     # ---- device half ---------------------------------------------------------------------------------------------------------

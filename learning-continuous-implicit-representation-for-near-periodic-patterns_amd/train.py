@@ -97,7 +97,16 @@ def default_linear_init(layout, n_params, seed):
     return sd
 
 
-def main(argv=None):
+class _Job:
+    """One image's fit between _prepare() and _finish(): arguments, loaded data, the CompletionFit, its output directory and the
+    PNG writer thread."""
+    pass
+
+
+def _prepare(argv=None, stacked=False):
+    """Everything `main` does before the loop (NPP_completion/train.py:28-131): flags, data, output directory, network init, the
+    fit object.  -> _Job, or None when the result directory already exists (train.py:42-44).  stacked: the fit will ride in a
+    StackedFit (which draws for every image itself: no producer thread)."""
     args = parse(argv)
     if args.N_iters is None:
         args.N_iters = {"remapping": 2801, "segmentation": 601}.get(args.task, 2001)     # arg_config.py:96,202,289
@@ -111,7 +120,6 @@ def main(argv=None):
                                 ) if bad]
     if refused:
         raise SystemExit(f"{refused}: ablation switches of options/arg_config.py that the fused loop is not built for (D = 8, snake, sigmoid / tanh output); other widths / depths / activations run through reference_api.NPP_Net (dense.py)")
-    remap_task = args.task == "remapping"
     seg_task = args.task == "segmentation"
     from . import weights
     names = ["vgg19"] + ([] if seg_task else ["vgg16"]) + (["alexnet"] if seg_task else [])    # remapping: VGG16 is the style trunk
@@ -152,89 +160,178 @@ def main(argv=None):
     def load(path):
         return None if path is None else torch.load(path, map_location="cpu")
     lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
-    fit = CompletionFit(d["img"], d["mask"], d["angles"], d["periods"], freqs, params, device=args.device, N_rand=args.N_rand,
-                        seed=args.seed, lrate=args.lrate, lrate_decay=args.lrate_decay, valid_mask=d["valid_mask"],
-                        shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
-                        num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
-                        patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
-                        # --vgg16: the LPIPS trunk (completion) or the STYLE trunk of the remapping task (models/style_loss.py:11,
-                        # VGG16FeatureExtractor; LPIPS is off there, NPP_remapping/train.py:253-261)
-                        vgg16_state_dict=None if remap else load(args.vgg16),
-                        vgg16_style_state_dict=load(args.vgg16) if remap else None,
-                        lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=args.prefetch,
-                        task=args.task, clear_mask=d["clear_mask"] if remap else None,
-                        masked_img=None if remap else d.get("masked_img"),
-                        contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
-                        style_weight=args.style_weight if remap else None,
-                        use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
-                        use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
-                        no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth,
-                        loss_type=args.loss_type, use_adaptive_perceptual_loss=args.use_adaptive_perceptual_loss,
-                        normalize_type=args.normalize_type)
+    try:
+        fit = CompletionFit(d["img"], d["mask"], d["angles"], d["periods"], freqs, params, device=args.device, N_rand=args.N_rand,
+                            seed=args.seed, lrate=args.lrate, lrate_decay=args.lrate_decay, valid_mask=d["valid_mask"],
+                            shifts=d["shifts"], patch_size=d["patch_size"], patch_num=args.patch_num,
+                            num_real_patch_per_sample=args.num_real_patch_per_sample, invalid_ratio=args.invalid_ratio,
+                            patch_size_decay=args.patch_size_decay, vgg19_state_dict=load(args.vgg19),
+                            # --vgg16: the LPIPS trunk (completion) or the STYLE trunk of the remapping task (models/style_loss.py:11,
+                            # VGG16FeatureExtractor; LPIPS is off there, NPP_remapping/train.py:253-261)
+                            vgg16_state_dict=None if remap else load(args.vgg16),
+                            vgg16_style_state_dict=load(args.vgg16) if remap else None,
+                            lpips_lin_weights=lin, rng_mode=args.rng_mode, prefetch=0 if stacked else args.prefetch,
+                            task=args.task, clear_mask=d["clear_mask"] if remap else None,
+                            masked_img=None if remap else d.get("masked_img"),
+                            contextual_weight=args.contextual_weight if args.contextual_weight is not None else (0.01 if remap else (0.005 if seg else 1e-3)),
+                            style_weight=args.style_weight if remap else None,
+                            use_perceptual_loss=(not (remap or seg)) != args.use_perceptual_loss, perceptual_weight=args.perceptual_weight,
+                            use_comp=args.use_comp, no_reg_sampling=args.no_reg_sampling, use_patch_weight=args.use_patch_weight,
+                            no_pix_loss=args.no_pix_loss, use_contextual_loss=args.use_contextual_loss, width=args.netwidth,
+                            loss_type=args.loss_type, use_adaptive_perceptual_loss=args.use_adaptive_perceptual_loss,
+                            normalize_type=args.normalize_type)
+    except BaseException:
+        import shutil
+        shutil.rmtree(outroot, ignore_errors=True)          # (nothing was fitted: a re-run must not take the directory for a result)
+        raise
     # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
     from concurrent.futures import ThreadPoolExecutor
-    writer, pending = ThreadPoolExecutor(1), []
-    t0 = time.time()
-    failed, write_error = None, None
+    job = _Job()
+    job.args, job.fit, job.d, job.outroot, job.seg, job.load, job.weights, job.nio = args, fit, d, outroot, seg, load, weights, nio
+    job.writer, job.pending, job.t0, job.name = ThreadPoolExecutor(1), [], time.time(), name
+    return job
+
+
+def _finish(job, failed):
+    """The end of a fit, successful or not: producer thread stopped, queued PNG writers awaited; a fit that died mid-loop must not
+    leave an output directory behind that a re-run would take for a finished one (`file exists, exit!!`) -- but an interrupted one
+    (Ctrl-C) keeps the test sets it has already written.  Raises a writer's error when the loop itself succeeded."""
+    write_error = None
+    job.fit.close()                                         # the sampler's producer thread
+    # first the writers: a queued dump_testset re-creates its directory (os.makedirs(..., exist_ok=True)), so nothing is
+    # removed while one may still run
+    for p in job.pending:
+        if not p.cancel():
+            try:
+                p.result()
+            except Exception as e:
+                write_error = write_error or e
+                print(f"[WARN] writing a test set failed: {e}")
+    job.writer.shutdown(wait=True)
+    if (failed is not None and not isinstance(failed, KeyboardInterrupt)) or write_error is not None:
+        import shutil
+        shutil.rmtree(job.outroot, ignore_errors=True)
+    if write_error is not None and failed is None:          # the loop itself succeeded: a lost output is still a failed run
+        raise write_error
+
+
+def main(argv=None):
+    job = _prepare(argv)
+    if job is None:
+        return None
+    failed = None
     try:
-        _train_loop(args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0)
+        for i in range(1, job.args.N_iters):                                                # trange(start = 1, N_iters)
+            job.fit.step_full()
+            _after_iteration(job, i)
     except BaseException as e:
         failed = e
         raise
     finally:
-        fit.close()                                         # the sampler's producer thread
-        # first the writers: a queued dump_testset re-creates its directory (os.makedirs(..., exist_ok=True)), so nothing is
-        # removed while one may still run
-        for p in pending:
-            if not p.cancel():
-                try:
-                    p.result()
-                except Exception as e:
-                    write_error = write_error or e
-                    print(f"[WARN] writing a test set failed: {e}")
-        writer.shutdown(wait=True)
-        # a fit that dies mid-loop must not leave an output directory behind that a re-run would take for a finished one
-        # (`file exists, exit!!` above) -- but an interrupted one (Ctrl-C) keeps the test sets it has already written
-        if (failed is not None and not isinstance(failed, KeyboardInterrupt)) or write_error is not None:
-            import shutil
-            shutil.rmtree(outroot, ignore_errors=True)
-    if write_error is not None:                             # the loop itself succeeded: a lost output is still a failed run
-        raise write_error
-    return fit
+        _finish(job, failed)
+    return job.fit
 
 
-def _train_loop(args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0):
-    for i in range(1, args.N_iters):                                                        # trange(start = 1, N_iters)
-        fit.step_full()
-        if i % args.i_testset == 0:
-            pred = fit.render_image().cpu().numpy()
-            os.makedirs(os.path.join(outroot, f"testset_{i:06d}"), exist_ok=True)
-            pending.append(writer.submit(nio.dump_testset, os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"],
-                                         d["valid_mask"]))
-            print(f"[EVAL] iter {i}: PSNR known {fit.psnr('known'):.2f} dB, unknown {fit.psnr('unknown'):.2f} dB")
-            if seg:                                                                         # NPP_segmentation/train.py:337-406
-                from . import segment
-                alex = segment.AlexFeatures(load(args.alexnet), device=args.device)
-                lins = weights.lpips_lin("alex", args.lpips_alex_lin)
-                r = segment.segmentation_eval(pred * d["valid_mask"], d["blur_img"], d["valid_mask"], d["non_period_mask"], alex, lins,
-                                              args.l1_thresh, args.lpips_thresh, args.lpips_layers)
-                tdir = os.path.join(outroot, f"testset_{i:06d}")
-                import matplotlib
-                matplotlib.use("Agg")
-                import matplotlib.pyplot as plt                                             # single-channel plt.imsave: viridis, autoscaled (:356-389)
-                plt.imsave(os.path.join(tdir, "l1_diff_img.png"), r["l1_img"])
-                plt.imsave(os.path.join(tdir, "l1_img_mask.png"), ~r["l1_mask"])
-                for j, m in enumerate(r["lpips_maps"]):
-                    plt.imsave(os.path.join(tdir, f"lpips_diff_img_{j}.png"), m)
-                    plt.imsave(os.path.join(tdir, f"lpips_img_mask_{j}.png"), ~(m < args.lpips_thresh))
-                nio.imsave(os.path.join(tdir, "non_period_mask_final.png"), np.repeat(r["non_period_mask_final"].astype(np.float64), 3, 2))
-                m = r["non_period_mask_final"].astype(np.float64)
-                vis = d["img"] * 0.7 + 0.3 * (np.array([0.0, 1.0, 0.0]) * m + d["img"] * (1 - m))    # :396-404
-                nio.imsave(os.path.join(tdir, "segment.png"), vis * d["valid_mask"])
-                fit.segmentation = r
-        if i % args.i_print == 0:
-            print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
-                  f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
+def stack_key(job):
+    """Fits that can share one launch sequence (stack.StackedFit): same network shape, batch shape, loss switches and schedule."""
+    a, f = job.args, job.fit
+    if (f.patch_sampler is None or f.task == "remapping" or f.style is not None or f.pixel_mask is not None or f.use_patch_weight
+            or not f.use_contextual_loss or f.net.out_act != 1):
+        return None
+    return (a.task, f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.net.quad, f.pix_w, f.use_comp, f.cx_w, f.lp_w,
+            f.lp_robust, f.use_perceptual_loss, a.N_iters, a.i_testset, a.i_print, a.patch_size_decay, str(f.device))
+
+
+def main_stacked(argvs, max_stack=8):
+    """Several images' fits in ONE launch sequence per group (stack.StackedFit): what `python -m npp_amd.run` does when a rank has
+    more than one image (run_completion.sh:8-14 loops them serially; the fits are independent -- own weights, Adam state, random
+    stream -- so the image becomes a grid dimension: 1.4 x the rows per second of the serial loop at 8 images per GPU).  Images group by
+    stack_key() (detected periods give patch sizes 64 .. 160: loaders.py:133-134); a group of one, and the remapping task (style
+    loss + pixel mask: not stacked), run the plain loop.  -> list of fits (None for skipped / failed outputs), in the order of
+    argvs; main_stacked.last_error holds the first failure."""
+    from .stack import StackedFit
+    jobs = [_prepare(a, stacked=True) for a in argvs]
+    groups = {}
+    for idx, job in enumerate(jobs):
+        if job is not None:
+            key = stack_key(job)
+            groups.setdefault(key if key is not None else ("single", idx), []).append(job)
+    first_error = None
+    for key, group in groups.items():
+        for c0 in range(0, len(group), max_stack):
+            chunk = group[c0:c0 + max_stack]
+            failed = None
+            try:
+                if len(chunk) == 1 or key[0] == "single":
+                    for job in chunk:
+                        for i in range(1, job.args.N_iters):
+                            job.fit.step_full()
+                            _after_iteration(job, i)
+                else:
+                    st = StackedFit([j.fit for j in chunk])
+                    print(f"[stack] {len(chunk)} images per launch sequence: {[j.name for j in chunk]} (patch size {st.P}, wgrad split-K {st.ksplit})")
+                    for i in range(1, chunk[0].args.N_iters):
+                        if st.shape_change_due():                                           # patch-size decay (train.py:137-141): new batch shape
+                            st = st.restacked()
+                        st.step_full()
+                        for job in chunk:
+                            _after_iteration(job, i)
+            except BaseException as e:                                                      # noqa: B902
+                failed = e
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                import traceback
+                traceback.print_exc()
+                print(f"[stack] group {[j.name for j in chunk]} FAILED ({type(e).__name__}: {e})")
+                first_error = first_error or e
+            finally:
+                for job in chunk:
+                    try:
+                        _finish(job, failed)
+                    except Exception as e:                                                  # a lost output of one image
+                        first_error = first_error or e
+                        job.fit = None
+                if failed is not None:
+                    for job in chunk:
+                        job.fit = None
+    main_stacked.last_error = first_error
+    return [None if j is None else j.fit for j in jobs]
+
+
+def _after_iteration(job, i):
+    """What follows optimizer.step() in the reference's loop body at iteration i: the periodic evaluation dump (train.py:270-331;
+    segmentation: NPP_segmentation/train.py:337-406) and the progress line."""
+    args, fit, d, outroot, seg, load, weights, nio, writer, pending, t0 = (job.args, job.fit, job.d, job.outroot, job.seg, job.load,
+                                                                           job.weights, job.nio, job.writer, job.pending, job.t0)
+    if i % args.i_testset == 0:
+        pred = fit.render_image().cpu().numpy()
+        os.makedirs(os.path.join(outroot, f"testset_{i:06d}"), exist_ok=True)
+        pending.append(writer.submit(nio.dump_testset, os.path.join(outroot, f"testset_{i:06d}"), pred, d["img"], d["masked_img"], d["mask"],
+                                     d["valid_mask"]))
+        print(f"[EVAL] iter {i}: PSNR known {fit.psnr('known'):.2f} dB, unknown {fit.psnr('unknown'):.2f} dB")
+        if seg:                                                                         # NPP_segmentation/train.py:337-406
+            from . import segment
+            alex = segment.AlexFeatures(load(args.alexnet), device=args.device)
+            lins = weights.lpips_lin("alex", args.lpips_alex_lin)
+            r = segment.segmentation_eval(pred * d["valid_mask"], d["blur_img"], d["valid_mask"], d["non_period_mask"], alex, lins,
+                                          args.l1_thresh, args.lpips_thresh, args.lpips_layers)
+            tdir = os.path.join(outroot, f"testset_{i:06d}")
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt                                             # single-channel plt.imsave: viridis, autoscaled (:356-389)
+            plt.imsave(os.path.join(tdir, "l1_diff_img.png"), r["l1_img"])
+            plt.imsave(os.path.join(tdir, "l1_img_mask.png"), ~r["l1_mask"])
+            for j, m in enumerate(r["lpips_maps"]):
+                plt.imsave(os.path.join(tdir, f"lpips_diff_img_{j}.png"), m)
+                plt.imsave(os.path.join(tdir, f"lpips_img_mask_{j}.png"), ~(m < args.lpips_thresh))
+            nio.imsave(os.path.join(tdir, "non_period_mask_final.png"), np.repeat(r["non_period_mask_final"].astype(np.float64), 3, 2))
+            m = r["non_period_mask_final"].astype(np.float64)
+            vis = d["img"] * 0.7 + 0.3 * (np.array([0.0, 1.0, 0.0]) * m + d["img"] * (1 - m))    # :396-404
+            nio.imsave(os.path.join(tdir, "segment.png"), vis * d["valid_mask"])
+            fit.segmentation = r
+    if i % args.i_print == 0:
+        print(f"[TRAIN] Iter: {i} Loss: {float(fit.net.loss_buf[0]):.6f} Patch Loss: {float(fit.last_patch_loss[0]):.6f} "
+              f"({(time.time() - t0) / i * 1e3:.2f} ms/iter, skipped {fit.skipped})")
 
 
 if __name__ == "__main__":

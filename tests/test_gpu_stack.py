@@ -124,3 +124,82 @@ def test_stack_with_an_image_sitting_an_iteration_out(dev):
     assert torch.equal(st.fits[1].net.params, p1) and st.fits[1].net.opt_step == steps[1]
     assert st.fits[0].net.opt_step == steps[0] + 1
     assert st.step_full() == 2 and bool(torch.isfinite(st.params).all())
+
+
+def test_stack_re_forms_across_a_patch_size_decay(dev):
+    """train.py:137-141 halves the patch size (and doubles the patch count) every patch_size_decay iterations: another batch shape.
+    StackedFit.shape_change_due() / restacked() re-form the stack around it; every image still equals its stand-alone fit."""
+    from npp_amd.stack import StackedFit
+    H, K, M, iters = 256, 1, 2, 16
+    probe = StackedFit(_fits(dev, M, H, K, None, patch_size_decay=10))
+    ks = probe.ksplit
+    del probe
+    alone = _fits(dev, M, H, K, ks, patch_size_decay=10)
+    for f in alone:
+        for _ in range(iters):
+            f.step_full()
+    st = StackedFit(_fits(dev, M, H, K, ks, patch_size_decay=10), ksplit=ks)
+    P0, n_restack = st.P, 0
+    for _ in range(iters):
+        if st.shape_change_due():
+            st = st.restacked()
+            n_restack += 1
+        st.step_full()
+    torch.cuda.synchronize()
+    assert n_restack == 1 and st.P == P0 // 2 and st.n_p == 4
+    for i in range(M):
+        a, b = alone[i].net, st.fits[i].net
+        assert (a.opt_step, alone[i].patch_size, alone[i].patch_num) == (b.opt_step, st.fits[i].patch_size, st.fits[i].patch_num)
+        # (the re-formed stack picks the split-K of ITS batch shape: weight gradients sum in another order from there on)
+        assert rel_l2(b.params.cpu().numpy(), a.params.cpu().numpy()) < 2e-3
+        assert abs(alone[i].psnr("known") - st.fits[i].psnr("known")) < 0.1
+
+
+def test_segmentation_fits_stack_too(dev):
+    """The segmentation loop (NPP_segmentation/train.py:148-286) is the completion loop on other inputs: contextual weight 0.005, no
+    LPIPS, a learning rate that never decays -- two such fits in one launch sequence equal their stand-alone runs."""
+    from npp_amd.stack import StackedFit
+    H, K, M, iters = 256, 1, 2, 12
+    kw = dict(task="segmentation", contextual_weight=0.005, use_perceptual_loss=False)
+    probe = StackedFit(_fits(dev, M, H, K, None, **kw))
+    ks = probe.ksplit
+    del probe
+    alone = _fits(dev, M, H, K, ks, **kw)
+    for f in alone:
+        for _ in range(iters):
+            f.step_full()
+    st = StackedFit(_fits(dev, M, H, K, ks, **kw), ksplit=ks)
+    for _ in range(iters):
+        st.step_full()
+    torch.cuda.synchronize()
+    for i in range(M):
+        a, b = alone[i].net, st.fits[i].net
+        assert a.lr_clock is False and b.lr_clock is False and a.lr == b.lr and a.opt_step == b.opt_step
+        assert rel_l2(b.params.cpu().numpy(), a.params.cpu().numpy()) < 1e-3
+
+
+def test_directory_driver_fits_several_images_in_one_launch_sequence(dev, tmp_path):
+    """npp_amd.train.main_stacked (what `python -m npp_amd.run --stack M` calls): three detected/ directories -- two of one patch size,
+    one of another -- fitted as one stack of two and one plain loop, test sets written per image, and the stacked images end where
+    their own `train.main` runs end."""
+    from npp_amd import io as nio, train
+    H, K = 256, 3
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    dirs = []
+    for i, scale in enumerate((1.0, 1.0, 2.0)):                            # the third image: twice the period -> another patch size
+        img, mask = oracle.synthetic_image(H, seed=i)
+        pp = np.asarray(p, np.float64) * scale
+        dirs.append(nio.write_detected_dir(str(tmp_path / "detected" / f"img{i}"), img, mask, np.ones_like(mask), a, pp, s))
+    flags = ["--p_topk", "3", "--N_iters", "41", "--i_testset", "40", "--i_print", "40", "--rng_mode", "fast", "--random-trunks",
+             "--netwidth", "256", "--N_rand", "4096"]
+    fits = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "stacked")] + flags for d in dirs], max_stack=8)
+    assert train.main_stacked.last_error is None and all(f is not None for f in fits)
+    assert fits[0].patch_size == fits[1].patch_size != fits[2].patch_size
+    for i in range(3):
+        out = tmp_path / "stacked" / "completion_top3" / f"img{i}" / "testset_000040"
+        assert out.is_dir() and len(list(out.iterdir())) == 6
+    single = train.main(["--datadir", dirs[1], "--basedir", str(tmp_path / "single"), "--prefetch", "0"] + flags)
+    assert abs(single.psnr() - fits[1].psnr()) < 0.3 and fits[1].psnr() > 20.0
+    # a second call finds every output directory in place and fits nothing (train.py:42-44)
+    again = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "stacked")] + flags for d in dirs])
+    assert again == [None, None, None]
