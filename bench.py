@@ -327,7 +327,7 @@ def main():
     e2e_ranks = None
     if dist is not None and world > 1:
         fe = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=rank), device=dev, N_rand=8192,
-                           ksplit=args.ksplit, seed=rank, shifts=shifts, rng_mode="reference", prefetch=4)
+                           ksplit=args.ksplit, seed=rank, shifts=shifts, rng_mode="reference", prefetch=8)
         for _ in range(20):
             fe.step_full()
         barrier()
@@ -664,7 +664,7 @@ def main():
         # wall time per iteration of the complete loop INCLUDING the host-side sampler (not part of `value`, whose inputs
         # are resident before timing): with the reference's exact NumPy stream and with rng_mode='fast'
         e2e = {}
-        for mode, pf in ((("numpy", 0), ("reference", 4), ("fast", 0)) if world == 1 else ()):
+        for mode, pf in ((("numpy", 0), ("reference", 8), ("fast", 8)) if world == 1 else ()):
             f4 = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
                                N_rand=8192, ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode=mode, prefetch=pf)
             for _ in range(20):
@@ -778,7 +778,7 @@ def main():
         clear[Hr // 3:Hr // 2] = 0.0                              # a blurry band (the reference finds it with blur_detection.py)
         remap = {"workload": f"remapping task, {Hr}x{Hr}, K={K}: complete iterations incl. host sampling (contextual + style loss, "
                              f"whole image = {Hr * Hr} known pixels)"}
-        for mode, pf in (("reference", 4), ("fast", 0)):
+        for mode, pf in (("reference", 8), ("fast", 8)):
             fr = CompletionFit(im_r, np.ones((Hr, Hr, 1), np.float32), a_r, p_r, syn.SEED0_FREQS, syn.init_params(K, seed=0), device=dev,
                                N_rand=8192, seed=0, shifts=sh_r, task="remapping", clear_mask=clear, prefetch=pf, rng_mode=mode,
                                contextual_weight=0.01, style_weight=1.0, use_perceptual_loss=False)

@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--rng_mode", default="reference", choices=["reference", "numpy", "fast"],
                     help="reference: NumPy's stream from the native generator; numpy: NumPy itself; fast: O(size) draws, other stream")
-    ap.add_argument("--prefetch", type=int, default=4, help="iterations of sampler draws prepared ahead on a producer thread")
+    ap.add_argument("--prefetch", type=int, default=8, help="iterations of sampler draws prepared ahead on a producer thread")
     ap.add_argument("--vgg19", default=None, help="torchvision vgg19 state_dict (.pth) for the contextual loss trunk")
     ap.add_argument("--vgg16", default=None, help="torchvision vgg16 state_dict (.pth) for the LPIPS trunk")
     ap.add_argument("--lpips_lin", default=None, help="lpips weights/v0.1/vgg.pth (the five 1x1 lin layers)")
