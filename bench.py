@@ -277,9 +277,7 @@ def main():
     ws = net.workspace(bp)
 
     def step(i):
-        # (the next pool entry rides along for the real-half prefetch of CompletionFit.step_from, an option that is OFF by default
-        #  -- measured slower, profiles/r03_rejected_experiments.txt #5 -- so the timed step is the plain single-stream iteration)
-        fit.step_from(pool[i % len(pool)], pool[(i + 1) % len(pool)])
+        fit.step_from(pool[i % len(pool)])
 
     def barrier():
         torch.cuda.synchronize()
@@ -649,7 +647,7 @@ def main():
         for src in ("val", "train", "same"):
             bs = [b for b in pool if b["source"] == src]
             if bs:
-                per_source[src] = timed(lambda: [fit.step_from(b, bs[(j_ + 1) % len(bs)]) for j_, b in enumerate(bs)], reps=5) / len(bs) * 1e3
+                per_source[src] = timed(lambda: [fit.step_from(b) for b in bs], reps=5) / len(bs) * 1e3
 
     # ---- iterations to 28 dB on a fresh fit of the same image (not timed) -----------------
     iters_to_target, final_psnr, e2e = None, None, None

@@ -424,15 +424,6 @@ int npp_maxpool2_bwd(const void* d_dy, const void* d_x, const void* d_addend, in
 int npp_conv3x3_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
                      const void* d_pack, const float* d_bias, void* d_y, void* d_ypool, float* d_tap, int Ctap,
                      const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
-/* npp_maxpool2_fwd followed by npp_conv3x3 mode 0 as ONE launch, for the layers the window-staged kernel takes: d_xpre is the
- * PRE-pool tensor (geometry (N_total, Cin, 2H, 2W)); H, W are the pooled geometry = this convolution's.  The pool runs in the
- * operand staging (a window unit = the maximum of its four pre-pool units), the pooled tensor is never written.
- * npp_conv3x3_poolin_ok() != 0 says whether a shape is taken (16 <= Cin <= 64, Cout % 64 == 0, >= 200 workgroups, W <= 188);
- * otherwise NPP_ERR_ARG and the caller runs the two launches.  Bit-identical to them. */
-int npp_conv3x3_poolin_ok(int N_total, int n_run, int H, int W, int Cin, int Cout);
-int npp_conv3x3_poolin(const void* d_xpre, int N_total, int n_run, int H, int W, int Cin, int Cout,
-                       const void* d_pack, const float* d_bias, void* d_y, float* d_tap, int Ctap,
-                       const float* tap_scale, const void* d_next_pack, int64_t next_pack_bytes, void* stream);
 /* TWO forward layers and the MaxPool2d(2,2) behind them in ONE launch (round 5): relu(conv a) -> relu(conv b) -> pool, the first
  * blocks of VGG19 / VGG16 (contextual_loss/modules/vgg.py:16-21, lpips/pretrained_networks.py:106-115: features[0:5], [5:10]).  A
  * workgroup owns a 16 x 16 tile of one image; the intermediate activation lives in LDS.  d_y_a / d_y_b (flat fp16, geometry

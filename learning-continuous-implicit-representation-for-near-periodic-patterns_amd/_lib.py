@@ -196,8 +196,6 @@ SYMBOLS = {
                            C.POINTER(C.c_float), _vp, _i64, _vp]),
     "npp_conv3x3_pool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(C.c_float), _vp,
                          _i64, _vp]),
-    "npp_conv3x3_poolin_ok": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32]),
-    "npp_conv3x3_poolin": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, C.POINTER(C.c_float), _vp, _i64, _vp]),
     "npp_conv_pair_fwd_ok": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "npp_conv_pair_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "npp_conv3x3_dgrad_pool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

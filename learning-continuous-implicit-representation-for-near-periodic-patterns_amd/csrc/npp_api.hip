@@ -235,11 +235,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackArgs a_in, NetDe
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (e < cnt) {
-#ifdef NPP_DIAG_ADAM_NOSCATTER      // timing-only diagnostic (wrong results): no pack stores
-      if (false) {
-#else
       if (n < d.n_out[l]) {                               // a weight (rows beyond n_out = the layer's bias vector: not packed)
-#endif
         const __bf16 w = (__bf16)pn[e];
         if (!fwd4) {
           const int64_t pf = fwd_pack_pos(d, l, n, k);

@@ -136,18 +136,7 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& acc, int s) {
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-#ifdef NPP_DIAG_MFMA16     // timing-only diagnostic (wrong results): the same FLOPs as two v_mfma_f32_16x16x32_bf16 on quarter tiles
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x16 r = c;
-  f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[8], c[9], c[10], c[11]};
-  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
-  r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2]; r[3] = c0[3];
-  r[8] = c1[0]; r[9] = c1[1]; r[10] = c1[2]; r[11] = c1[3];
-  return r;
-#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-#endif
 }
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
@@ -158,10 +147,6 @@ __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
 #define NPP_STASH_NT 1
 #endif
 __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
-#ifdef NPP_DIAG_NOSTASH      // timing-only diagnostic: the value and its address stay live, the store is not issued
-  asm volatile("" :: "v"(v), "v"(p));
-  return;
-#endif
 #if NPP_STASH_NT
   __builtin_nontemporal_store(v, (bf16x8*)p);
 #else
@@ -173,10 +158,6 @@ __device__ __forceinline__ void stash_store(void* p, const bf16x8& v) {
 #define NPP_DZ_NT NPP_STASH_NT
 #endif
 __device__ __forceinline__ void dz_store(void* p, const bf16x8& v) {
-#ifdef NPP_DIAG_NOSTASH      // timing-only diagnostic, as in stash_store
-  asm volatile("" :: "v"(v), "v"(p));
-  return;
-#endif
 #if NPP_DZ_NT
   __builtin_nontemporal_store(v, (bf16x8*)p);
 #else
@@ -193,10 +174,6 @@ __device__ __forceinline__ f16x8 pack_acc_f16(const f32x16& acc, int s) {
   return r;
 }
 __device__ __forceinline__ void stash_store(void* p, const f16x8& v) {
-#ifdef NPP_DIAG_NOSTASH
-  asm volatile("" :: "v"(v), "v"(p));
-  return;
-#endif
 #if NPP_STASH_NT
   __builtin_nontemporal_store(v, (f16x8*)p);
 #else
@@ -376,16 +353,8 @@ struct WRing {
 template <int NTW, int NT>
 __device__ __forceinline__ void wslot_load(WRing<NTW>& r, int slot, wptr_t wp, int ks, int nt0, int lane) {
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-#if defined(NPP_DIAG_WNONE)     // ... or only the first kRD k-steps of a part are fetched at all
-  if (ks >= kRD) return;
-#endif
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-#if defined(NPP_DIAG_WSAME)     // timing-only diagnostics (wrong results): every wave streams wave 0's tiles (L1 hits) ...
-    nt0 = 0;
-#elif defined(NPP_DIAG_WONE)    // ... or every k-step re-reads k-step 0 (the stream stays, the footprint is one k-step)
-    ks = 0;
-#endif
     const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, lane * 16, (int)((wp + (uint32_t)((ks * NT + nt0 + nt) * 64)) * 16u), 0);
     r.w[slot][nt] = __builtin_bit_cast(bf16x8, raw);
   }

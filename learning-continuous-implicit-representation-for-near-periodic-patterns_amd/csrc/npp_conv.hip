@@ -165,21 +165,13 @@ __global__ __launch_bounds__(64 * S) void conv3x3_kernel(ConvArgs a) {
 
   frag_t A[kConvRing][CT], B[kConvRing][PT];
   auto load = [&](int slot, int ci, int tap) {
-#ifdef NPP_DIAG_CONV_ASAME      // timing-only diagnostic (wrong results): the weight stream collapsed onto k-step 0 of the tile
-    const int ks = 0;
-#else
     const int ks = ci * 9 + tap;
-#endif
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (int)((uint32_t)((cot0 + ct) * KS + ks) * 1024u), 0);
       A[slot][ct] = __builtin_bit_cast(frag_t, raw);
     }
-#ifdef NPP_DIAG_CONV_BSAME      // timing-only diagnostic (wrong results): every tap re-reads tap 0's operand (L1 hits): an upper
-    const int shift = 0;         // bound on what staging the activation window in LDS could save
-#else
     const int shift = (tap / 3) * a.Wp + (tap % 3);
-#endif
     const uint32_t soff = (uint32_t)(((int64_t)2 * ci * a.nposp + shift) * 16);
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -405,11 +397,9 @@ constexpr int kWinMaxUnits = 640;                  // window units per chunk the
 template <int CT>
 constexpr int win_lds_bytes() { return 2 * (CT * 9 * 1024 + 2 * kWinMaxUnits * 16); }
 
-// POOLIN (forward only; npp_conv3x3_poolin): the layer's input is the 2 x 2 max-pool of the tensor a.x points at (geometry
-// (2H, 2W), a.pool_nposp units per chunk) -- the pool runs in the window staging: a window unit is the maximum of the four units of
-// its pool window (4 global loads per unit instead of 1; the kernel is not bound by them), border / out-of-range units are zeros.
-// The pooled tensor is never materialised, the maxpool2_fwd launch is gone.
-template <int CT, int MODE, bool POOLIN = false>
+// (Round 4 also had a form that pooled its INPUT while staging the window -- pool1 inside conv2_1 --: bit-identical, trunk forward
+//  130.5 -> 133.8 us, removed in round 5; pool1 now rides in the fused pair of npp_conv_pair.hip.)
+template <int CT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
   typedef typename OpT<MODE == kConvFwd>::frag frag_t;
   typedef typename OpT<MODE == kConvFwd>::elem elem_t;
@@ -439,9 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
   const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack), 0, (int)a.pack_bytes, 0x00020000);
   const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   // per-thread source offsets (bytes) of its units inside a step; -1 = no unit
-  int offA[NA], offW[NW], dstW[NW];           // (POOLIN: offW = byte offset of the pool window's first unit, -2 = a zero unit)
-  constexpr int NWL = POOLIN ? 4 : 1;         // global loads per window unit
-  const int rowF = (2 * a.W + 2) * 16;        // POOLIN: bytes between the two rows of a pool window
+  int offA[NA], offW[NW], dstW[NW];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int u = tid + 256 * i;                                   // unit (ct, tap, lane) of the step
@@ -452,41 +440,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
   for (int i = 0; i < NW; ++i) {
     const int u = tid + 256 * i;
     const int chunk = u >= WIN, pos = u - chunk * WIN;
-    const bool ok = u < 2 * WIN;
-    if (!POOLIN) {
-      offW[i] = ok ? (int)((((int64_t)chunk * a.nposp) + kConvGuard + (int64_t)tile0 * 32 - halo + pos) * 16) : -1;
-    } else {
-      const int64_t q = (int64_t)tile0 * 32 - halo + pos;                 // flat position of the (virtual) pooled tensor
-      offW[i] = ok ? -2 : -1;
-      if (ok && q >= 0 && q < a.npos_valid) {
-        const int n = (int)(q / a.S), r = (int)(q - (int64_t)n * a.S), yo = r / a.Wp, xo = r - yo * a.Wp;
-        if (yo >= 1 && yo <= a.H && xo >= 1 && xo <= a.W)
-          offW[i] = (int)(((int64_t)chunk * a.pool_nposp + kConvGuard + (int64_t)n * (2 * a.H + 2) * (2 * a.W + 2) +
-                           (int64_t)(2 * yo - 1) * (2 * a.W + 2) + (2 * xo - 1)) * 16);
-      }
-    }
+    offW[i] = u < 2 * WIN ? (int)((((int64_t)chunk * a.nposp) + kConvGuard + (int64_t)tile0 * 32 - halo + pos) * 16) : -1;
     dstW[i] = kA + (chunk * kWinMaxUnits + pos) * 16;
   }
   // Register stages of the operand prefetch (NPP_CONV_WIN_DEPTH): with 2 the operands of step ci + 2 are requested while step ci is
   // multiplied.  Built on the hypothesis that a step lasts as long as its loads (the input was just written by the previous layer from
   // other XCDs); measured in the iteration, same box: trunk forward 132.1 us with one stage, 132.2 with two -- not the bound.
-  struct Stage { u32x4_t a[NA], w[NW][NWL]; };
+  struct Stage { u32x4_t a[NA], w[NW]; };
   Stage st[kWinDepth];
   auto gload = [&](int ci, Stage& r) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       if (offA[i] >= 0 || NA * 256 == CT * 576) r.a[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, offA[i] < 0 ? 0 : offA[i], ci * 9 * 1024, 0);
-    const uint32_t soff = (uint32_t)((int64_t)2 * ci * (POOLIN ? a.pool_nposp : a.nposp) * 16);
+    const uint32_t soff = (uint32_t)((int64_t)2 * ci * a.nposp * 16);
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int o = offW[i] < 0 ? 0 : offW[i];
-      r.w[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rB, o, (int)soff, 0);
-      if constexpr (POOLIN) {
-        r.w[i][NWL - 3] = __builtin_amdgcn_raw_buffer_load_b128(rB, o + 16, (int)soff, 0);
-        r.w[i][NWL - 2] = __builtin_amdgcn_raw_buffer_load_b128(rB, o + rowF, (int)soff, 0);
-        r.w[i][NWL - 1] = __builtin_amdgcn_raw_buffer_load_b128(rB, o + rowF + 16, (int)soff, 0);
-      }
-    }
+    for (int i = 0; i < NW; ++i) r.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, offW[i] < 0 ? 0 : offW[i], (int)soff, 0);
   };
   auto sstore = [&](int buf, const Stage& r) {
     char* base = wlds + buf * kBuf;
@@ -494,24 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(ConvArgs a) {
     for (int i = 0; i < NA; ++i)
       if (offA[i] >= 0) *(u32x4_t*)(base + (tid + 256 * i) * 16) = r.a[i];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      if constexpr (!POOLIN) {
-        if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = r.w[i][0];
-      } else if (offW[i] != -1) {
-        f16x8 m = __builtin_bit_cast(f16x8, r.w[i][0]);
-#pragma unroll
-        for (int k = 1; k < NWL; ++k) {
-          const f16x8 o = __builtin_bit_cast(f16x8, r.w[i][k]);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) m[j] = o[j] > m[j] ? o[j] : m[j];
-        }
-        if (offW[i] == -2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) m[j] = (_Float16)0.0f;
-        }
-        *(f16x8*)(base + dstW[i]) = m;
-      }
-    }
+    for (int i = 0; i < NW; ++i)
+      if (offW[i] >= 0) *(u32x4_t*)(base + dstW[i]) = r.w[i];
   };
   f32x16 acc[CT][2];
 #pragma unroll
@@ -1382,27 +1334,6 @@ extern "C" int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, i
   return conv3x3_impl(d_x, N_total, n_run, H, W, Cin, Cout, d_pack, nullptr, kConvDgradLin, nullptr, d_dz, nullptr, 0, nullptr,
                       d_next_pack, d_next_pack ? next_pack_bytes : 0, stream, &f);
 }
-// Forward layer whose INPUT is the 2 x 2 max-pool of d_xpre (geometry (N_total, Cin, 2H, 2W)): the pool runs inside the window
-// staging of conv3x3_win_kernel -- npp_maxpool2_fwd + npp_conv3x3 mode 0 in one launch, no pooled tensor, bit-identical.  Only for
-// the shapes the window-staged kernel takes (npp_conv3x3_poolin_ok: <= 64 input channels after the pool, Cout % 64 == 0, ...).
-static bool poolin_ok(int N_total, int n_run, int H, int W, int Cin, int Cout) {
-  if (N_total < 1 || n_run < 1 || n_run > N_total || H < 1 || W < 1 || Cin % 16 || Cout % 64 || Cin < 16 || Cin > 64 || Cout > 512) return false;
-  if (conv_geom_check(N_total, 2 * H, 2 * W, "npp_conv3x3_poolin_ok")) return false;
-  const int64_t range = n_run == N_total ? conv_npos_round(N_total, H, W)
-                                         : ((int64_t)n_run * (H + 2) * (W + 2) + kPosRound - 1) / kPosRound * kPosRound;
-  return (range / 32) % 8 == 0 && 2 * (W + 3) + kWinPos <= kWinMaxUnits && (range / 256) * (Cout / 64) >= 200;
-}
-extern "C" int npp_conv3x3_poolin_ok(int N_total, int n_run, int H, int W, int Cin, int Cout) {
-  return poolin_ok(N_total, n_run, H, W, Cin, Cout) ? 1 : 0;
-}
-extern "C" int npp_conv3x3_poolin(const void* d_xpre, int N_total, int n_run, int H, int W, int Cin, int Cout, const void* d_pack,
-                                  const float* d_bias, void* d_y, float* d_tap, int Ctap, const float* tap_scale,
-                                  const void* d_next_pack, int64_t next_pack_bytes, void* stream) {
-  if (!poolin_ok(N_total, n_run, H, W, Cin, Cout)) { set_error("npp_conv3x3_poolin: not a shape of the window-staged kernel (npp_conv3x3_poolin_ok)"); return NPP_ERR_ARG; }
-  const PoolFold f{d_xpre, nullptr, nullptr, nullptr};
-  return conv3x3_impl(d_xpre, N_total, n_run, H, W, Cin, Cout, d_pack, d_bias, kConvFwd, nullptr, d_y, d_tap, Ctap, tap_scale,
-                      d_next_pack, d_next_pack ? next_pack_bytes : 0, stream, &f);
-}
 // Forward layer with the nn.MaxPool2d(2,2) that follows it folded in: y = relu(conv(x) + bias) as npp_conv3x3 mode 0 (flat fp16
 // tensor + optional fp32 tap) AND d_ypool = maxpool(y) (geometry (N_total, Cout, H/2, W/2)) in one launch; H and W even.  Position
 // tiles are 16 columns x 2 rows, so a pool window sits in four lanes of one tile; bit-identical to the two launches.
@@ -1453,15 +1384,6 @@ static int conv3x3_impl(const void* d_x, int N_total, int n_run, int H, int W, i
     a.pool_tiles = n_run * (H / 2) * a.pool_cbn;
     a.pos_tiles = (a.pool_tiles + 1) / 2 * 2;
     mode = kConvFwdPool;
-  } else if (fold && mode == kConvFwd) {           // forward, pooling its input in the window staging (window kernel only)
-    a.pool_nposp = conv_nposp(N_total, 2 * H, 2 * W);
-    a.x_bytes = (uint32_t)((int64_t)(Cin / 8) * a.pool_nposp * 16);
-    const dim3 wgrid((unsigned)(a.pos_tiles / 8), (unsigned)(cot_n / 2));
-    constexpr int smem_in = win_lds_bytes<2>();
-    static SmemOnce once_in;
-    if (!smem_attr(once_in, (const void*)conv3x3_win_kernel<2, kConvFwd, true>, smem_in)) { set_error("npp_conv3x3_poolin: smem attribute"); return NPP_ERR_LAUNCH; }
-    hipLaunchKernelGGL((conv3x3_win_kernel<2, kConvFwd, true>), wgrid, dim3(256), smem_in, (hipStream_t)stream, a);
-    return check_launch("npp_conv3x3_poolin");
   } else if (fold) {
     a.pool_x = fold->x; a.pool_add = fold->add; a.pool_dz = fold->dz;
     a.pool_nposp = conv_nposp(N_total, 2 * H, 2 * W);

@@ -236,11 +236,7 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     for (int ks = 0; ks < kCxKc / 2; ++ks) {
       const float a = sA[PAR][2 * ks + kh][wi * 32 + l31];
       const float b = sB[PAR][2 * ks + kh][wj * 32 + l31];
-#ifdef NPP_DIAG_CXSIM_NOMFMA          // timing-only diagnostics (wrong results): tools/cx_probe.py under rocprofv3
-      asm volatile("" :: "v"(a), "v"(b));
-#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-#endif
     }
     if (has_next) gfinish(c0 + kCxKc, R[PAR ^ 1], PAR ^ 1);
     __syncthreads();
@@ -283,17 +279,13 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
     if (i < hw && j < hw) {
       const float raw = acc[r] * inv_norm(ssn[wi * 32 + acc_row(r, kh)]) * sj;
       d = 1.0f - fminf(fmaxf(raw, 0.0f), 1.0f);
-#ifndef NPP_DIAG_CXSIM_NOSTORE
       w.D[((int64_t)n * hw + i) * hw + j] = d;
-#endif
     }
     if (w.min_in_rows) continue;                       // (uniform) the block-parallel row pass reads the whole row anyway: 3 us of atomics saved
     float m = d;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-#ifndef NPP_DIAG_CXSIM_NOMIN
     if (l31 == 0 && i < hw) atomicMin(&w.dmin[(int64_t)n * hw + i], __float_as_uint(m));
-#endif
   }
 }
 
@@ -639,66 +631,6 @@ __global__ void cx_dx_finish_flat_kernel(const float* __restrict__ x, const floa
 //    prefetch depth), so that kernel stays LDS-tiled;
 //  * blocks are dealt round-robin to the 8 XCDs (4 MiB L2 each); with the natural order every XCD touches all samples.
 
-// dxh[c][i] = sum_j draw[i][j] yh[c][j]: both operands are contiguous along the contraction index j, so every lane
-// reads float4s of ITS row (A: channel c0 + lane, B: position i0 + lane) and the k order inside a block of 8 columns
-// is "lane-half kh owns columns 8t + 4kh + e" for both operands.
-__global__ __launch_bounds__(256) void cx_dx32_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C,
-                                                      int hw, CxWs w, float* __restrict__ dxh) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-  const int t32 = hw / 32, ct = C / 32, cg = ct / 4 + (ct % 4 ? 1 : 0);    // 4 waves: 4 channel tiles of one position tile
-  const int lb = xcd_block(N * t32 * cg);
-  if (lb < 0) return;
-  const int n = lb / (t32 * cg);
-  const int rem = lb - n * t32 * cg;
-  const int ti = rem / cg, tc = (rem - ti * cg) * 4 + wave;
-  if (tc >= ct) return;
-  const int i0 = ti * 32, c0 = tc * 32;
-  const float* mup = cx_mu(w, n);
-  const float mu = mup[c0 + l31];
-  const float4* yr = (const float4*)(y + ((int64_t)n * C + c0 + l31) * hw) + kh;       // float4 index 2t + kh
-  const float4* dr = (const float4*)(w.cx + ((int64_t)n * hw + i0 + l31) * hw) + kh;
-  const float4* sr = (const float4*)(w.iny + (int64_t)n * hw) + kh;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#ifndef NPP_CX_DX_PF
-#define NPP_CX_DX_PF 8
-#endif
-  constexpr int PF = NPP_CX_DX_PF;                      // blocks of 8 columns in flight (8: 32 MFMAs = 2048 cycles of cover)
-  float4 ya[PF], da[PF], sa[PF];
-  const int nt = hw / 8;
-#pragma unroll
-  for (int q = 0; q < PF; ++q)
-    if (q < nt) { ya[q] = yr[2 * q]; da[q] = dr[2 * q]; sa[q] = sr[2 * q]; }
-  for (int t0 = 0; t0 < nt; t0 += PF) {
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int t = t0 + q;
-      if (t < nt) {
-        const float4 yv = ya[q], dv = da[q], sv = sa[q];
-        if (t + PF < nt) { ya[q] = yr[2 * (t + PF)]; da[q] = dr[2 * (t + PF)]; sa[q] = sr[2 * (t + PF)]; }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.x - mu) * sv.x, dv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.y - mu) * sv.y, dv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.z - mu) * sv.z, dv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.w - mu) * sv.w, dv.w, acc, 0, 0, 0);
-      }
-    }
-  }
-  // accumulator: column = position (lane & 31), rows = channels
-  const int i = i0 + l31;
-  const float inx = w.inx[(int64_t)n * hw + i];
-  float part = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int c = c0 + acc_row(r, kh);
-    const int64_t o = ((int64_t)n * C + c) * hw + i;
-    dxh[o] = acc[r];
-    part = fmaf((x[o] - mup[c]) * inx, acc[r], part);
-  }
-  part += __shfl_xor(part, 32, 64);
-  if (kh == 0) w.dot[(int64_t)tc * N * hw + (int64_t)n * hw + i] = part;        // one partial per channel tile, summed by cx_dx_finish
-}
-
 // The same contraction with its operands staged through LDS (round 4, late).  In cx_dx32_kernel every lane streams ITS OWN row of both
 // operands: one load instruction touches 64 different 128-byte lines and uses 16 bytes of each, four waves per CU keep ~64 KiB of
 // half-used lines alive in a 32-KiB L1, lines are evicted before their fourth use, and the four waves of a workgroup fetch the same 32
@@ -788,81 +720,6 @@ __global__ __launch_bounds__(256) void cx_dx32s_kernel(const float* __restrict__
   }
   part += __shfl_xor(part, 32, 64);
   if (kh == 0) w.dot[(int64_t)tc * N * hw + (int64_t)n * hw + i] = part;        // one partial per channel tile, summed by cx_dx_finish
-}
-
-// cx_dx32_kernel + cx_dx_finish_flat_kernel in ONE launch for C = 256 (the loop's tap, relu3_4): a workgroup of EIGHT waves owns all
-// eight 32-channel tiles of one 32-position tile, so the per-position dot product xh . dxh is complete inside the workgroup (LDS,
-// summed in tile order like the finish kernel did) and every lane can finish its own two 16-byte units -- an accumulator tile converted
-// to bf16 IS two units of the trunk's flat layout (npp_trunk_layout.h conv_chan) -- gate them by the tapped layer's ReLU and store
-// them: no fp32 dxh tensor, no sixth launch.  Only interior positions are written: borders and tail positions of a flat gradient
-// tensor are zero from its allocation on and every producer keeps them so.
-__global__ __launch_bounds__(512) void cx_dx32_flat_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C,
-                                                           int H, int W, CxWs w, const f16x8* __restrict__ yact,
-                                                           bf16x8* __restrict__ dz, int64_t nposp) {
-  __shared__ float sdot[8][32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-  const int hw = H * W, t32 = hw / 32;
-  const int lb = xcd_block(N * t32);
-  if (lb < 0) return;                                   // (whole workgroup)
-  const int n = lb / t32, ti = lb - n * t32, tc = wave;
-  const int i0 = ti * 32, c0 = tc * 32;
-  const float* mup = cx_mu(w, n);
-  const float mu = mup[c0 + l31];
-  const float4* yr = (const float4*)(y + ((int64_t)n * C + c0 + l31) * hw) + kh;
-  const float4* dr = (const float4*)(w.cx + ((int64_t)n * hw + i0 + l31) * hw) + kh;
-  const float4* sr = (const float4*)(w.iny + (int64_t)n * hw) + kh;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  constexpr int PF = 8;
-  float4 ya[PF], da[PF], sa[PF];
-  const int nt = hw / 8;
-#pragma unroll
-  for (int q = 0; q < PF; ++q)
-    if (q < nt) { ya[q] = yr[2 * q]; da[q] = dr[2 * q]; sa[q] = sr[2 * q]; }
-  for (int t0 = 0; t0 < nt; t0 += PF) {
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int t = t0 + q;
-      if (t < nt) {
-        const float4 yv = ya[q], dv = da[q], sv = sa[q];
-        if (t + PF < nt) { ya[q] = yr[2 * (t + PF)]; da[q] = dr[2 * (t + PF)]; sa[q] = sr[2 * (t + PF)]; }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.x - mu) * sv.x, dv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.y - mu) * sv.y, dv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.z - mu) * sv.z, dv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((yv.w - mu) * sv.w, dv.w, acc, 0, 0, 0);
-      }
-    }
-  }
-  const int i = i0 + l31;
-  const float inx = w.inx[(int64_t)n * hw + i];
-  float xh[16], part = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int c = c0 + acc_row(r, kh);
-    xh[r] = (x[((int64_t)n * C + c) * hw + i] - mup[c]) * inx;
-    part = fmaf(xh[r], acc[r], part);
-  }
-  part += __shfl_xor(part, 32, 64);
-  if (kh == 0) sdot[wave][l31] = part;
-  __syncthreads();
-  float dot = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) dot += sdot[q][l31];        // channel tiles in order (what cx_dx_finish_flat_kernel summed from memory)
-  const int yy = i / W, xx = i - yy * W, Wp = W + 2;
-  const int64_t pflat = (int64_t)n * (H + 2) * Wp + (int64_t)(yy + 1) * Wp + (xx + 1);
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int64_t u = (int64_t)(4 * tc + 2 * s2 + kh) * nposp + kConvGuard + pflat;
-    const f16x8 m = yact[u];
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = (acc[8 * s2 + j] - xh[8 * s2 + j] * dot) * inx;
-      o[j] = (__bf16)((float)m[j] > 0.0f ? v : 0.0f);
-    }
-    dz[u] = o;
-  }
 }
 
 // Row pass, block-parallel: 16 waves x 1 row = 16 consecutive rows of one sample per block (all rows of the matrix are
@@ -1044,21 +901,11 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
     hipLaunchKernelGGL(cx_rows_bwd_kernel, dim3((unsigned)((nh + 3) / 4)), dim3(256), 0, s, N, hw, inv_h, w, loss_in_rows ? d_loss : nullptr,
                        loss_stride);
     const int ctiles = (C + 63) / 64;
-    // NPP_CX_DX_FUSED=1: five launches instead of six -- measured SLOWER inside the iteration (same box, x 3: contextual chain 314.3 ->
-    // 322.1 us, iteration 0.6759 -> 0.6821 ms): 108 workgroups of eight waves against 216 of four + a 6-us finish launch.  Off.
-    static const bool fuse_flat = [] { const char* e = getenv("NPP_CX_DX_FUSED"); return e && atoi(e) != 0; }();
-    if (fast && flat && C == 256 && fuse_flat) {
-      if (!flat->yact || !flat->dz || flat->H * flat->W != hw || N > flat->N_total) { set_error("%s: bad flat-output description", who); return NPP_ERR_ARG; }
-      const int64_t nb = (int64_t)N * t32;
-      hipLaunchKernelGGL(cx_dx32_flat_kernel, dim3((unsigned)((nb + 7) / 8 * 8)), dim3(512), 0, s, d_fx, d_fy, N, C, flat->H, flat->W, w,
-                         (const f16x8*)flat->yact, (bf16x8*)flat->dz, conv_nposp(flat->N_total, flat->H, flat->W));
-      return check_launch(who);
-    }
     if (fast) {
       const int64_t nb_dx = (int64_t)N * t32 * ((C / 32 + 3) / 4);
-      static const bool staged = !(getenv("NPP_CX_DX_LDS") && atoi(getenv("NPP_CX_DX_LDS")) == 0);      // 0: the row-streaming form (comparator)
-      if (staged) hipLaunchKernelGGL(cx_dx32s_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
-      else hipLaunchKernelGGL(cx_dx32_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
+      // (measured and removed, profiles/r04_cx_dx_staged_ab.txt: the row-streaming form of this contraction -- 30.9 us against 20.1 --
+      //  and a five-launch form with the finish fused behind eight-wave workgroups: +8 us on the chain)
+      hipLaunchKernelGGL(cx_dx32s_kernel, dim3((unsigned)((nb_dx + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, d_dfx);
     }
     else
       hipLaunchKernelGGL(cx_dx_kernel, dim3((unsigned)((int64_t)N * ctiles * tiles)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w,

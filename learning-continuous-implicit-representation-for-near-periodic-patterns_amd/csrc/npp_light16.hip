@@ -271,11 +271,7 @@ __device__ __forceinline__ void lmma(f32x16 (&acc)[NTW][kNB], const char* region
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int bt = 0; bt < kNB; ++bt) {
-#ifdef NPP_DIAG_L16_NOMFMA      // timing-only diagnostic (wrong results): operands stay live, the MFMA is not issued
-          asm volatile("" :: "v"(ring.w[slot][nt]), "v"(x[bt]));
-#else
           acc[nt][bt] = mfma_bf16(ring.w[slot][nt], x[bt], acc[nt][bt]);
-#endif
         }
     }
     if (ks + kLRD < KSREAL) lslot_load<NTW, NT>(ring, slot, wp, ks + kLRD, nt0, L.lane);

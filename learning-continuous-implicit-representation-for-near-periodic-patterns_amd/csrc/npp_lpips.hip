@@ -79,11 +79,7 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   for (int c = threadIdx.x; c < C; c += 256) {
     slin[c] = lin[c];
     if (plain) continue;
-#ifdef NPP_DIAG_LP_NOPROLOGUE        // timing-only diagnostic (wrong results): the per-channel parameters from constants
-    ChanParams P{}; P.alpha = 1.5f; P.c = 0.7f; P.beta = 0.5f; P.logc_plus_logz = 0.1f; P.dlogz = 0.1f; P.dalpha_dl = 0.2f; P.dc_dl = 0.3f;
-#else
     const ChanParams P = chan_params(latents[c], latents[C + c], spline, n_knots, x_scale);
-#endif
     LpChan L;
     L.e = 0.5f * P.alpha;
     L.inv_c = 1.0f / P.c;
@@ -217,9 +213,6 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
-#ifdef NPP_DIAG_LP_NOTAIL            // timing-only diagnostic (wrong results): no sums leave the block
-  return;
-#endif
   if (fix) {
     // Order-independent sums (round 4): every block adds its partials as 2^-40 fixed-point integers (integer addition is
     // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the

@@ -105,18 +105,6 @@ constexpr int kWgPerCuF = kSmemFwd <= 80 * 1024 ? 2 : 1;
 static_assert(kSmemFwd <= 160 * 1024, "LDS");
 constexpr int kWavesPerSimdF = kWgPerCuF * kWavesF / 4;          // 2 (256 VGPRs) except the 8-wave W = 256 form (4, 128 VGPRs)
 
-// Diagnostic build only (-DNPP_STAMPS): per-phase s_memtime stamps of wave 0 of two workgroups,
-// read back with npp_debug_read_stamps().  Never compiled into the shipped library.
-#ifdef NPP_STAMPS
-__device__ unsigned long long g_stamps[2][64];
-#define STAMP(i)                                                                                   \
-  do {                                                                                             \
-    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && threadIdx.x == 0)                      \
-      g_stamps[blockIdx.x == 0 ? 0 : 1][i] = __builtin_amdgcn_s_memtime();                         \
-  } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
 
 struct FwdArgs {
   const int32_t* coords;
@@ -303,12 +291,8 @@ __device__ __forceinline__ void gen_emb_quad(const float* v, int jb, int fr0, in
 #pragma unroll
   for (int bt = 0; bt < kNB; ++bt) {
     f32x2 x;
-#ifdef NPP_DIAG_NOGEN        // timing-only diagnostic (wrong results): no embedding arithmetic, no coordinate reads
-    x[0] = fa; x[1] = fb;
-#else
     x[0] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP) * kRowTile + bt * 32], fa, ph));
     x[1] = __builtin_amdgcn_sinf(fmaf(v[(2 * JP + 1) * kRowTile + bt * 32], fb, ph));
-#endif
     const bf16x2 pk = __builtin_convertvector(x, bf16x2);
     f[bt][2 * JP] = pk[0];
     f[bt][2 * JP + 1] = pk[1];
@@ -408,12 +392,8 @@ struct SlicedGen {
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
       f32x2 x;
-#ifdef NPP_DIAG_NOGEN
-      x[0] = fa; x[1] = fb;
-#else
       x[0] = __builtin_amdgcn_sinf(fmaf(val[0][bt], fa, ph));
       x[1] = __builtin_amdgcn_sinf(fmaf(val[1][bt], fb, ph));
-#endif
       const bf16x2 pk = __builtin_convertvector(x, bf16x2);
       f[bt][2 * JP] = pk[0];
       f[bt][2 * JP + 1] = pk[1];
@@ -465,14 +445,12 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
                                               wptr_t wp, wptr_t next_wp,
                                               int nt0, char* actF, int wg, const Lane& L, WRing<NTW>& ring,
                                               bool have_warp = false, bool have_chunk0 = false, int next_warp_p = -1) {
-  STAMP(50);
   if (!EMB_IN && !have_warp) {
     gen_warp(e.warp, p, sV, sY, sX, L);
     wg_barrier();
   } else if (EMB_IN) {
     wg_barrier();
   }
-  STAMP(51);
   // stash address = uniform (array, workgroup, k-step, batch tile) part + this lane's 32-bit offset (npp_layout.h wfmt_unit)
   char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
   const uint32_t lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
@@ -494,10 +472,8 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
   if (!have_chunk0) {
     gen_pair(0, 0);
     if (kPer == 2) gen_pair(0, 1);
-    STAMP(52);
     wg_barrier();
   }
-  STAMP(53);
   // chunk c is multiplied while chunk c+1 is generated: this wave's two k-steps of the next chunk
   // are produced at schedule positions 0 and 4 of the current one, so their LDS reads / v_sin /
   // stores issue between the MFMAs.
@@ -520,9 +496,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
     const auto g1 = sliced_for(1);
     g1.prologue();
     MMA_RING<0, 8, kKSEmb, 32, NTW, NT, decltype(g1), true>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, g1);
-    STAMP(55);
     wg_barrier();
-    STAMP(56);
     const auto g2 = sliced_for(2);
     g2.prologue();
     MMA_RING<8, 16, kKSEmb, 32, NTW, NT, decltype(g2), true>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, g2);
@@ -531,9 +505,7 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
 #endif
   {
     MMA_RING<0, 8, kKSEmb, 32, NTW, NT>(acc, lds_ring, 0, wp, next_wp, nt0, L, ring, hook_for(1));
-    STAMP(55);
     wg_barrier();
-    STAMP(56);
     MMA_RING<8, 16, kKSEmb, 32, NTW, NT>(acc, lds_ring + kChunkBytes, 0, wp, next_wp, nt0, L, ring, hook_for(2));
     wg_barrier();
   }
@@ -621,11 +593,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 z = {acc[nt][bt][r], acc[nt][bt][r + 1]};
-#ifdef NPP_DIAG_NOSNAKE      // timing-only diagnostic (wrong results): what the chain costs without the activation arithmetic
-        if (false) {
-#else
         if (SNAKE) {
-#endif
           const f32x2 rev = z * kInv2Pi;
           const f32x2 sn = {__builtin_amdgcn_sinf(rev[0]), __builtin_amdgcn_sinf(rev[1])};
           z = __builtin_elementwise_fma(sn, sn, z);
@@ -759,19 +727,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     for (int q = 0; q < NPP_FWD_PREFETCH_LINES; ++q, line += per_xcd_threads)
       pfv[q] = line < lines ? *(const volatile uint32_t*)((const char*)s_wf + line * 128) : 0u;
   }
-  STAMP(0);
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
   WRING_FILL(kNTW, kNT, ring, wl(L0), nt0, L);
   init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
   mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, s_actF, wg, L, ring);
-  STAMP(1);
   BiasPre<kNTW> bn;
   BiasPre<1> bnp;
   bias_fetch<kNTW>(bn, P + d.b_off[L1], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(0), wg, L);
-  STAMP(2);
   wg_barrier();
-  STAMP(3);
 
   // ---- L1..L4: 256 -> 256, snake, ping-pong R0 -> R1 -> R0 -> R1 -> R0
 #pragma unroll
@@ -780,12 +744,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     char* out = (l & 1) ? R1 : R0;
     bias_apply<kNTW>(acc, bn);
     MMA_RING<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), (l == L4 && !EMB_IN && kOverlapPro) ? wl(L5) + kKSEmb * U : wl(l + 1), nt0, L, ring);
-    STAMP(4 * l);
     bias_fetch<kNTW>(bn, P + d.b_off[l + 1], nt0, L);
     epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
-    STAMP(4 * l + 1);
     wg_barrier();
-    STAMP(4 * l + 2);
   }
 
   // ---- L5: [emb(p0) (LDS ring R1), h (R0)] -> 256, snake, out -> R1 (the LDS ring is idle
@@ -795,19 +756,15 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     // h part FIRST: sV still holds proposal 0's warped coordinates (written for L0, nothing else touches it), so chunk 0 of
     // the embedding part is generated in the gaps of these 16 k-steps instead of in an exposed prologue
     mma_plain_gen_chunk0<false, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, s_actF, wg, L, ring);
-    STAMP(20);
     wg_barrier();
     mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, s_actF, wg, L, ring, true, true);
   } else {
     mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, s_actF, wg, L, ring);
-    STAMP(20);
     MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   }
-  STAMP(21);
   bias_fetch<kNTW>(bn, P + d.b_off[L6], nt0, L);
   epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L);
   wg_barrier();
-  STAMP(22);
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
   bias_apply<kNTW>(acc, bn);
@@ -899,7 +856,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? s_actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
                              wg, L);
 
-  STAMP(40);
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,
   //      half-wave exchange by shuffle, 4-wave reduction through LDS.
   wg_barrier();       // every wave is done with R0 / R1: R0 now carries the rgb partial sums
@@ -953,7 +909,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       s_pred[(row0 + row) * 3 + c] = o;
     }
   }
-  STAMP(41);
 #pragma unroll
   for (int q = 0; q < NPP_FWD_PREFETCH_LINES; ++q) asm volatile("" :: "v"(pfv[q]));
 }
@@ -962,11 +917,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 
 using namespace npp;
 
-#ifdef NPP_STAMPS
-extern "C" int npp_debug_read_stamps(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
-}
-#endif
 
 #undef s_coords
 #undef s_wf

@@ -53,14 +53,10 @@ constexpr int kMaxJobs = 24;
 #ifndef NPP_WGRAD_XCD
 #define NPP_WGRAD_XCD 1
 #endif
-// Timing-only diagnostic builds (wrong results; never shipped): NPP_DIAG_WGRAD_SAMETILE (every load hits L2),
-// NPP_DIAG_WGRAD_NOLOOP=n (prologue + n tiles + epilogue), NPP_DIAG_WGRAD_NOEPI (no slab stores) -- DESIGN.md section 4.
+// (The timing-only diagnostic builds behind profiles/r04_wgrad_ablation.txt -- every load hitting L2, prologue + n tiles + epilogue,
+// no slab stores, phases switched off one at a time -- left the source in round 5; they are in the git history of round 4.)
 
-#ifdef NPP_DIAG_WGRAD_SAMETILE
-constexpr bool kSameTile = true;      // timing-only: every half re-reads the split's first tile (all L2 hits)
-#else
 constexpr bool kSameTile = false;
-#endif
 
 struct WJob {
   int32_t a_ks0, a_nks, m;     // dz array: k-step offset inside dzF, k-steps, valid outputs
@@ -290,11 +286,7 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
     char* base = smem + kBBase + (hidx & 1) * kHalfOp + wave * 2048 + lane * 16;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-#ifdef NPP_DIAG_WG_NOCONV
-      if (false) {
-#else
       if (ZB) {
-#endif
         const f16x8 z = __builtin_bit_cast(f16x8, r[q]);
         bf16x8 a;
 #pragma unroll
@@ -326,16 +318,6 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
     const char* sA = smem + a_off;
     const char* sB = smem + kBBase + (s & 1) * kHalfOp;
     bf16x8 a[2][2], b[2][4];
-#ifdef NPP_DIAG_WG_NOREAD
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("" : "=v"(a[q][i]));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(b[q][j]));
-    }
-    asm volatile("" :: "s"(sA), "s"(sB));
-#else
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -343,7 +325,6 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[q][j] = wfrag_read(sB, offB[0] + j * 2048 + q * 1024);
     }
-#endif
     store_b(s + 1, R[I1]);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -361,11 +342,7 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#ifdef NPP_DIAG_WG_NOMFMA
-          asm volatile("" :: "v"(a[q][i]), "v"(b[q][j]));
-#else
           acc[i][j] = mfma_bf16(a[q][i], b[q][j], acc[i][j]);
-#endif
         }
 #if NPP_WGRAD_LATE_ISSUE
       // the step's memory requests go out in the shadow of the first k-step's MFMAs instead of in front of the fragment reads:
@@ -501,11 +478,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
   for (int j = 0; j < 4; ++j) offB[j] = hfrag_offset(wn * 4 + j, lane);
 
   // four straight-line forms of the loop (input array holds z or ready operands; this wave sums db or not), selected once by uniform branches
-#ifdef NPP_DIAG_WGRAD_NOLOOP
-  const int g0 = (int)wg_begin, g1 = g0 + NPP_DIAG_WGRAD_NOLOOP;    // diagnostic: prologue + N tiles + epilogue only
-#else
   const int g0 = (int)wg_begin, g1 = (int)wg_end;
-#endif
 #if NPP_WGRAD_HYBRID
 #define wgrad_loop wgrad_loop_hybrid
 #endif
@@ -522,7 +495,6 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 
   // ---- epilogue: stores into this split's slab, reference layout
   float* slab = gslabs_ + (int64_t)split_id * A.slab_stride;
-#ifndef NPP_DIAG_WGRAD_NOEPI
   if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {        // (every layer of this network has an even input width)
     // Plain-column jobs (17 of 21 tiles at K = 3): the accumulator holds one column per lane, i.e. 4-byte stores, 128 per wave
     // -- the tail was bound by store INSTRUCTIONS, not bytes (cdna_hip_programming.md T21).  Each wave transposes its 32 x 128
@@ -567,7 +539,6 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next strip overwrites the staging area
     }
   } else
-#endif
   {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -587,11 +558,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int mrow = tm * kWT + wm * 64 + i * 32 + acc_row(r, h);
-#ifdef NPP_DIAG_WGRAD_NOEPI
-        if (col >= 0 && mrow < J.m && acc[i][j][r] == 123.456f) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
-#else
         if (col >= 0 && mrow < J.m) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
-#endif
       }
     }
   }

@@ -24,7 +24,7 @@ class CompletionFit:
                  ksplit=None, seed=0, lrate=5e-4, lrate_decay=500, valid_mask=None, shifts=None,
                  patch_size=None, patch_num=2, num_real_patch_per_sample=3, invalid_ratio=0.3,
                  contextual_weight=1e-3, perceptual_weight=1e-3, use_comp=True, patch_size_decay=2000,
-                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, trunk="hip", rng_mode="reference",
+                 vgg19_state_dict=None, vgg16_state_dict=None, lpips_lin_weights=None, rng_mode="reference",
                  prefetch=0, use_perceptual_loss=True, task="completion", clear_mask=None, style_weight=None,
                  vgg16_style_state_dict=None, masked_img=None, width=256, no_reg_sampling=False, use_patch_weight=False,
                  no_pix_loss=False, use_contextual_loss=True, loss_type="robust_loss_adaptive", use_adaptive_perceptual_loss=True, normalize_type=1):
@@ -52,16 +52,11 @@ class CompletionFit:
             raise ValueError("rng_mode must be 'reference', 'numpy' or 'fast'")
         if task not in ("completion", "remapping", "segmentation"):
             raise ValueError("task must be 'completion', 'remapping' or 'segmentation'")
-        self.fold_launches = os.environ.get("NPP_FIT_UNFUSED", "0") != "1"     # see step_from
-        # Row-group overlap (step_from): the pixel rows' forward / pixel loss / backward / weight gradient run on a side stream
-        # under the patch-loss chain of the patch rows ("a/b": split-K slabs of the pixel rows / of the patch rows).
-        ov = os.environ.get("NPP_FIT_OVERLAP", "0")      # measured NEGATIVE (profiles/r03_rejected_experiments.txt): default off
-        self.overlap = ov != "0"
-        # Real-half prefetch (step_from(b, next_b)): the trunk features of the NEXT iteration's real patches are computed on a
-        # side stream under this iteration's trunk / contextual chain; see ContextualLoss.prefetch_y.
-        self.prefetch_real = os.environ.get("NPP_FIT_PREFETCH_REAL", "0") != "0"      # measured NEGATIVE: default off
-        self._fy, self._lookahead = None, None
-        self.overlap_ks = tuple(int(v) for v in os.environ.get("NPP_FIT_OVERLAP_KS", "4/12").split("/"))
+        # False: the folded launches as separate ones (npp_pixel_loss, npp_patch_compose_bwd: the comparator of
+        # tests/test_gpu_parity.py::test_folded_launches_equal_the_separate_ones).  Measured and removed in round 5 (they are in the
+        # history of rounds 3-4, profiles/r03_rejected_experiments.txt #2 #5): the pixel rows as a row group of their own on a side
+        # stream (0.742 -> 0.762 ms) and the next iteration's real-patch trunk pass prefetched on a side stream (0.767 -> 0.776 ms).
+        self.fold_launches = True
         img = np.asarray(img, np.float32)
         mask = np.asarray(mask, np.float32).reshape(img.shape[0], img.shape[1], 1)
         self.H, self.W = img.shape[:2]
@@ -131,9 +126,9 @@ class CompletionFit:
                 img=self.masked_img[None], mask=self.mask[None], N_samples=self.patch_num, patch_size=self.patch_size,
                 height=self.H, width=self.W, pool_train=self.i_train, pool_val=self.i_val, selected_shifts=shifts,
                 no_reg_sampling=bool(no_reg_sampling), rng=self.rng, fast_rng=self.fast_rng)
-            self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, trunk=trunk, device=self.device).to(self.device)
+            self.contextualLoss = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device).to(self.device)
             self.percepLoss = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict,
-                                    device=self.device, trunk=trunk)
+                                    device=self.device)
             self.style, self.style_w = None, 0.0
             if style_weight is not None or task == "remapping":
                 from .losses import StyleLoss
@@ -141,11 +136,9 @@ class CompletionFit:
                 self.style_w = 1.0 if style_weight is None else float(style_weight)        # arg_config.py: style_weight 1
             self.last_source, self.skipped = None, 0
             self._xy, self._xy_key, self._xy_bufs = None, None, {}
-            # the LPIPS branch of a 'same' iteration as ONE captured HIP graph (lpips_branch): NPP_LP_GRAPH=0 keeps the 46 launches
-            self._lp_graphs, self.lp_graph = {}, os.environ.get("NPP_LP_GRAPH", "1") != "0"
+            # the LPIPS branch of a 'same' iteration as ONE captured HIP graph (lpips_branch); lp_graph = False keeps the launches
+            self._lp_graphs, self.lp_graph = {}, True
             self._s_lp = torch.cuda.Stream(self.device)
-            self._s_pix = torch.cuda.Stream(self.device)
-            self._s_y = torch.cuda.Stream(self.device)
             self.patch_loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def lpips_branch(self, xy, nk, scale, loss_buf):
@@ -164,7 +157,7 @@ class CompletionFit:
             lp.touched = lp.touched or self.lp_robust
             return ent[1]
         out = lp.fused(xy, nk, scale, loss_buf, normalize=True, use_robust=self.lp_robust)
-        if not self.lp_graph or lp.trunk_kind != "hip":
+        if not self.lp_graph:
             return out
         uses = 1 if ent is None else ent[2] + 1
         self._lp_graphs[key] = (None, None, uses)
@@ -239,28 +232,6 @@ class CompletionFit:
                 raise d
         else:
             d = self.draw_batch()
-        if self.prefetch_real and self.task == "completion" and self._prefetch > 0:     # (with the producer thread only: state_dict()
-            #                                                                           refuses there anyway, the stream being ahead)
-            # one batch of lookahead: the sampler never reads network state, so drawing and materialising iteration i + 1's
-            # batch before iteration i runs changes nothing -- and lets step_from start the next real half's trunk pass early
-            cur = self._lookahead if self._lookahead is not None else (d, self.materialise_batch(d))
-            if self._lookahead is not None:
-                nxt_d = d
-            elif self._prefetch > 0:
-                nxt_d = self._queue.get()
-                if isinstance(nxt_d, BaseException):
-                    raise nxt_d
-            else:
-                nxt_d = self.draw_batch()
-            self._lookahead = (nxt_d, self.materialise_batch(nxt_d))
-            d, batch = cur
-            self.last_draw = d
-            self.iteration += 1
-            if batch is None:
-                self.skipped += 1
-                return False
-            self.step_from(batch, self._lookahead[1])
-            return True
         if self._prefetch > 0 and self.side_sampler:
             # With the producer thread the draws run ahead anyway; the sampler's DEVICE half (one upload, the crop gather, the row
             # assembly: ~35 us of launches) then runs ahead too, on a side stream under the previous iteration's kernels instead of
@@ -406,14 +377,11 @@ class CompletionFit:
     def __del__(self):
         self._stop = True
 
-    def step_from(self, b, next_b=None):
+    def step_from(self, b):
         """Device side of one iteration (everything after sampling), train.py:183-264, as explicit kernel
         launches (no autograd): fused forward -> pixel loss -> patch plumbing (npp_patch_compose_fwd) -> VGG19 trunk
         -> contextual loss core -> trunk data-gradient (-> the same through VGG16 / LPIPS head on 'same' iterations)
-        -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam.
-        next_b: the batch of the NEXT iteration (when the caller has it): its real patches' trunk features are computed on a
-        side stream under this iteration's trunk / contextual chain, and that iteration then runs its trunk forward on the
-        prediction half only."""
+        -> npp_patch_compose_bwd -> backward chain + wgrad -> Adam."""
         ops.check_current(self.device)
         self.last_source = source = b["source"]
         net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
@@ -437,26 +405,8 @@ class CompletionFit:
         net.zero_grad()
         if self.percepLoss.touched:
             self.percepLoss.zero_latent_grads()
-        # Two row groups (NPPNet.workspace_split): A = the pixel rows, whose whole path (forward, pixel loss, backward chain,
-        # weight gradient) is independent of the patch losses and runs on the side stream _s_pix UNDER the trunk / contextual
-        # chain of B = the patch rows -- that chain is ~30 dependent small launches that leave most of the chip idle.  The two
-        # groups write disjoint stash arrays and disjoint split-K slabs; Adam (main stream, after the join) sums all slabs.
-        split = self.overlap and fold and n_pix % 64 == 0 and 0 < n_pix < bp
-        if split:
-            ws = net.workspace_split(bp, n_pix, *self.overlap_ks)
-            gA, gB = ws["A"], ws["B"]
-            coords = b["coords"]
-            self._s_pix.wait_stream(main)                        # inputs of this iteration + the previous Adam / re-pack
-            net.group_forward(gB, coords[n_pix:])
-            with torch.cuda.stream(self._s_pix):
-                net.group_forward(gA, coords[:n_pix])
-                ops.pixel_loss(gA["pred"], b["gt"], b.get("pmask"), net.latents, net.spline, net.n_knots, net.x_scale, self.pix_w,
-                               net.loss_buf, gA["dpred"], net.dlatent, quad=net.quad)
-                net.group_backward(gA)
-            pred = ws["pred"]
-        else:
-            ws = net.workspace(bp)
-            pred = net.forward_train(b["coords"])
+        ws = net.workspace(bp)
+        pred = net.forward_train(b["coords"])
         if ws.get("n_rows") != n:                                # rows >= n never receive a gradient
             ws["dpred"][n:].zero_()
             ws["n_rows"] = n
@@ -470,31 +420,9 @@ class CompletionFit:
         # the comparator of tests/test_gpu_parity.py and for A/B timing)
         if not fold:
             net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
-        # the real half's features may have been computed during the previous iteration (below): then only the prediction half
-        # goes through the trunk now.  Only on iterations whose other consumers do not need the fp32 [x | y] batch.
-        fy = None
-        if self._fy is not None and self._fy[0] is b and xy is None and self.use_contextual_loss:
-            fy, ev = self._fy[1], self._fy[2]
-            main.wait_event(ev)
-            fy.record_stream(main)
-        self._fy = None
         ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
-                           cx.hip_trunk.input_buffer((1 if fy is not None else 2) * nk, P, P), xy, self.patch_loss_buf,
-                           which=1 if fy is not None else 0,
-                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if (fold and not split) else None)
-        if (self.prefetch_real and fold and next_b is not None and next_b["source"] != "same" and self.style is None
-                and self.use_contextual_loss and cx.trunk_kind == "hip"):
-            # next iteration's real half: starts once this iteration's forward and plumbing are out of the way (event), runs
-            # beside the chain that follows
-            ev0 = torch.cuda.Event()
-            ev0.record(main)
-            self._s_y.wait_event(ev0)
-            with torch.cuda.stream(self._s_y):
-                nraw = next_b["raw"]
-                fy_next = cx.prefetch_y(nraw["real"], nraw["rmask"], next_b["n_p"], next_b["k"], next_b["P"])
-                ev1 = torch.cuda.Event()
-                ev1.record(self._s_y)
-            self._fy = (next_b, fy_next, ev1)
+                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf, which=0,
+                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if fold else None)
         dx_b = None
         # use_patch_weight (train.py:224-250): contextual term sum_i -log(cx_i w_i + 1e-5) (the core's weighted form), LPIPS term
         # sum_i d_i w_i -- on 'same' iterations the weights are all 1 (sampler.py:338), i.e. nk times the mean
@@ -504,9 +432,7 @@ class CompletionFit:
             with torch.cuda.stream(self._s_lp):
                 dx_b = self.lpips_branch(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
-        if fy is not None:
-            dx_a = cx.fused_x((nk, 3, P, P), fy, self.cx_w, self.patch_loss_buf, weight=weight)
-        elif self.use_contextual_loss:
+        if self.use_contextual_loss:
             dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, weight=weight, x0_ready=True)   # train.py:238-239
         else:                                                                                       # ablation: no contextual term
             dx_a = torch.zeros((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
@@ -519,11 +445,7 @@ class CompletionFit:
         self.last_patch_loss = self.patch_loss_buf
         lr_used = net.lr
         # npp_patch_compose_bwd folded into the backward launch: dL/dpred of the patch rows is formed (and written) there
-        if split:
-            net.group_backward(gB, patch=(dx_a, dx_b, raw["fmask"], raw["rmask"], 0, n_p, k, P, comp))
-            main.wait_stream(self._s_pix)
-            net.optimizer_step_split(ws)
-        elif fold:
+        if fold:
             net.backward(bp, patch=(dx_a, dx_b, raw["fmask"], raw["rmask"], n_pix, n_p, k, P, comp))
             net.optimizer_step(bp)
         else:

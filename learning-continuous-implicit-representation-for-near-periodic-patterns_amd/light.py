@@ -232,7 +232,7 @@ class NPPNetLightBatch:
         data-gradient chains as ONE launch each over all candidates (csrc/npp_light.hip) instead of one launch per layer.
         precision: "fp32" (exact fp32 MFMA everywhere) or "bf16" (csrc/npp_light16.hip: bf16 operands, fp32 accumulation, fp32 master
         weights and Adam -- the numeric contract of the main loop's MLP; fused topology, at most 16 candidates, batches of a multiple of
-        64 rows; anything else falls back to fp32).  Default: NPP_LIGHT_PRECISION, else "fp32"."""
+        64 rows; anything else falls back to fp32).  Default: "fp32"."""
         import os
         self.device = ops.select_device(device)
         self.quad = ops.quad_coef(loss_type)              # --loss_type: 0 = adaptive; > 0: 'l2' / 'robust_loss' (no latent gradient)
@@ -268,15 +268,16 @@ class NPPNetLightBatch:
         self._ws = {}
         can_fuse = self.W == 256 and self.D == 4 and in_pos == 42
         if fused is None:
-            fused = can_fuse and os.environ.get("NPP_LIGHT_FUSED", "1") != "0"
+            fused = can_fuse
         if fused and not can_fuse:
             raise ValueError("the fused NPP_Net_light chains are built for D = 4, W = 256, 42 positional and 20 periodic input columns")
         self.fused = bool(fused)
-        self.grouped_wgrad = os.environ.get("NPP_LIGHT_GROUPED_WGRAD", "1") != "0"
-        self.fused_adam = self.fused and os.environ.get("NPP_LIGHT_FUSED_ADAM", "1") != "0"
+        # comparator switches of tests/test_gpu_light.py: seven weight-gradient launches instead of the grouped one; pack + Adam + clear
+        # as separate launches
+        self.grouped_wgrad, self.fused_adam = True, self.fused
         self._pack_valid = self._pack16_valid = False
         if precision is None:
-            precision = os.environ.get("NPP_LIGHT_PRECISION", "fp32")
+            precision = "fp32"                # (the path pinned to the reference's trajectories g10 / g10c / g10d)
         if precision not in ("fp32", "bf16"):
             raise ValueError(f"precision {precision!r}: 'fp32' or 'bf16'")
         self.bf16 = precision == "bf16" and self.fused and self.fused_adam and self.C <= 16
@@ -309,8 +310,6 @@ class NPPNetLightBatch:
             # rows: ksplit 1 / 2 / 4 / 8 = 66 / 42 / 56 / 64 us (4 and 8 need a second / third round of workgroups)
             cost = lambda k: -(-9 * C * k // 256) * (2 * -(-n_wg // k) + 8)                      # noqa: E731
             ks = min(range(1, min(8, n_wg) + 1), key=cost)
-            if os.environ.get("NPP_LIGHT16_KSPLIT"):
-                ks = max(1, min(n_wg, int(os.environ["NPP_LIGHT16_KSPLIT"])))
             ws = dict(actF=u8(ab), dzF=u8(db), pred=torch.empty(C, B, 3, dtype=torch.float32, device=self.device),
                       gslabs=torch.zeros(C, ks, self.n_pad, dtype=torch.float32, device=self.device))
             if getattr(self, "_pack16", None) is None:
@@ -563,7 +562,7 @@ class ProposalRanker:
                  perceptual_weight=30.0, contextual_weight=1.0, freqs=None, vgg19_state_dict=None, vgg16_state_dict=None,
                  lpips_lin_weights=None, rng_mode="reference", carry_latents=False, record_losses=False, precision=None,
                  loss_type="robust_loss_adaptive"):
-        """precision: "fp32" | "bf16" | None (NPP_LIGHT_PRECISION, else fp32): the arithmetic of the candidate fits (NPPNetLightBatch).
+        """precision: "fp32" | "bf16" | None (fp32): the arithmetic of the candidate fits (NPPNetLightBatch).
         carry_latents: in the reference the adaptive pixel loss is ONE module-level object (models/helpers.py:8) that every
         candidate's optimiser trains on (helpers.py:144), so candidate k + 1 starts from the latents candidate k left (fresh Adam
         moments) and the ranking depends on the order of the candidates.  False (default; SURVEY 3.3 / 8 e: candidates are independent
@@ -681,16 +680,14 @@ class ProposalRanker:
         fused (default unless NPP_LIGHT_FUSED=0 / use_graph / a topology the chains are not built for): the fused forward and
         data-gradient chains with a candidate set of one (NPPNetLightBatch: 13 launches per iteration, 0.25 ms); else the
         layer-by-layer path below: ~40 small dependent launches on 2048 rows, 0.39 ms per iteration.
-        use_graph=True (or NPP_LIGHT_GRAPH=1): iterations 2 .. N replay ONE captured HIP graph (torch.cuda.CUDAGraph: the same
+        use_graph=True: iterations 2 .. N replay ONE captured HIP graph (torch.cuda.CUDAGraph: the same
         kernels in the same order; the iteration's inputs -- pixel-row indices, Adam's step-dependent scalars -- are read from
         fixed device buffers).  Built in round 3 on the hypothesis that the host's enqueue rate bounded the loop; MEASURED: it does
         not -- eager 0.400 ms per iteration, graph replay 0.417-0.44 (profiles/r03_rejected_experiments.txt): the device time of the
         twenty 2048 x 256 x 256 exact-fp32 GEMM launches (14-18 us each) is the bound.  Kept as an option (parity-tested), off."""
-        import os
-        if use_graph is None:
-            use_graph = os.environ.get("NPP_LIGHT_GRAPH", "0") != "0"
+        use_graph = bool(use_graph)
         if fused is None:
-            fused = (not use_graph and os.environ.get("NPP_LIGHT_FUSED", "1") != "0" and self.Wn == 256 and self.D == 4
+            fused = (not use_graph and self.Wn == 256 and self.D == 4
                      and len(self.freqs) == 10 and min(self.N_rand, self.i_train.shape[0]) % 32 == 0)
         if fused:
             return self._fit_candidates_batched([(angles_deg, periods)], init=params)[0]
@@ -750,13 +747,9 @@ class ProposalRanker:
         the host's enqueue rate: 9 x 40 launches per iteration).
         Same arithmetic per candidate as the serial form up to the summation order of the split weight-gradient contractions; the
         pixel rows and their colours (identical for every candidate, see _pixel_draws) are gathered once."""
-        import os
-        if os.environ.get("NPP_LIGHT_GRAPH", "0") != "0" and self.N_iters >= 3:
-            # graph replay makes one fit device-bound (fit_candidate): the candidates simply run one after the other
-            return [self.fit_candidate(a_, p_) for a_, p_ in cands]
         main = torch.cuda.current_stream(self.device)
         if batched is None:
-            batched = os.environ.get("NPP_LIGHT_BATCH", "1") != "0"
+            batched = True
         if self.carry_latents:                                       # the reference's shared adaptive_pix: strictly one after the other
             nets, lat = [], None
             for cand in cands:

@@ -139,29 +139,14 @@ class HipTrunk:
                 L["tap_ok"] = nxt in (None, "pool")
         self._buf, self._gen = {}, 0
         self.final_next_pack = None
-        self.prefetch_next = os.environ.get("NPP_CONV_PREFETCH", "1") != "0"      # next layer's weights requested into L2 (npp_conv3x3_pf)
-        self.fold_pool_bwd = os.environ.get("NPP_POOL_FOLD_BWD", "1") != "0"      # max-pool backward in the data-gradient launch above it
-        self.fold_pool_fwd = os.environ.get("NPP_POOL_FOLD_FWD", "1") != "0"      # max-pool forward in the launch of the layer below it
-        self.fold_pool_fwd_min_cin = int(os.environ.get("NPP_POOL_FOLD_FWD_MIN_CIN", "128"))
-        # max-pool forward in the operand staging of the layer above it (ops.conv3x3_poolin, the window-staged kernel): bit-identical, but
-        # measured SLOWER in the c2 iteration -- trunk forward 130.5 -> 133.8 us, same box (four strided 16-byte loads per window unit
-        # cost more than the 5.4-us pool launch they replace; profiles/r04_pool_fold_ab.txt 3.) -- hence opt-in
-        self.fold_pool_in = os.environ.get("NPP_POOL_FOLD_IN", "0") != "0"
+        self.prefetch_next = True      # next layer's weights requested into L2 (npp_conv3x3_pf)
+        # comparator switches of tests/test_gpu_trunk.py (bit-identical forms): the max-pool backward in the data-gradient launch above
+        # it, the max-pool forward in the epilogue of the layer below it (layers with >= fold_pool_fwd_min_cin input channels: measured)
+        self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin = True, True, 128
         # conv a -> conv b -> pool of the first blocks as ONE launch (ops.conv_pair_fwd; round 5): the intermediate activation
         # stays in LDS, the layer outputs are stored only for the images that carry a gradient
         self.fuse_pairs = ops.tune("conv_pair") != 0
         self._n_keep = None
-
-    def twin(self):
-        """A second executor over the SAME layers (weights, packs: shared device tensors) with activation buffers of its own:
-        two passes through the stack may then be in flight on different streams (ContextualLoss.prefetch_y)."""
-        t = HipTrunk.__new__(HipTrunk)
-        t.device, t.taps, t.layers = self.device, self.taps, self.layers
-        t._buf, t._gen, t.final_next_pack, t.prefetch_next = {}, 0, None, self.prefetch_next
-        t.fold_pool_bwd, t.fold_pool_fwd, t.fold_pool_fwd_min_cin = self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin
-        t.fold_pool_in = self.fold_pool_in
-        t.fuse_pairs, t._n_keep = self.fuse_pairs, None
-        return t
 
     def _pb_below(self, j):
         """The backward pack of the next convolution layer below layer j (what the data-gradient pass runs next)."""
@@ -197,14 +182,14 @@ class HipTrunk:
         cur = self._flat("x0", N, 16, H, W)
         if not x0_ready:
             ops.trunk_image_in(x, scale, shift, cur)
-        c, outs, pooled, prepool = 16, [], None, None
+        c, outs, pooled = 16, [], None
         for j, L in enumerate(self.layers):
             if skip:                                                  # layers j-1 .. of a fused pair: already run
                 skip -= 1
                 continue
             Lb = self.layers[j + 1] if j + 2 < len(self.layers) else None
             if (self.fuse_pairs and L["kind"] == "conv" and Lb is not None and Lb["kind"] == "conv" and self.layers[j + 2]["kind"] == "pool"
-                    and prepool is None and L["relu_idx"] not in self.taps and self.layers[j + 2]["idx"] not in self.taps
+                    and L["relu_idx"] not in self.taps and self.layers[j + 2]["idx"] not in self.taps
                     and ops.conv_pair_fwd_ok(H, W, c, L["cout"], Lb["cout"])):
                 ya = self._flat(("a", j), N, L["cout"], H, W)
                 yb = self._flat(("a", j + 1), N, Lb["cout"], H, W)
@@ -226,12 +211,7 @@ class HipTrunk:
                     outs.append(tap)
                 nxt = next((M["pf"] for M in self.layers[j + 1:] if M["kind"] == "conv"), None) if self.prefetch_next else None
                 pooled = None
-                if prepool is not None:
-                    # the pool below rides in THIS launch's operand staging (ops.conv3x3_poolin): cur is the pre-pool tensor
-                    ops.conv3x3_poolin(prepool, N, nr, H, W, c, L["cout"], L["pf"], L["b"], y, tap, L["cout"] if tap is not None else 0,
-                                       next_pack=nxt)
-                    prepool = None
-                elif (self.fold_pool_fwd and j + 1 < len(self.layers) and self.layers[j + 1]["kind"] == "pool" and H % 2 == 0
+                if (self.fold_pool_fwd and j + 1 < len(self.layers) and self.layers[j + 1]["kind"] == "pool" and H % 2 == 0
                         and W % 2 == 0 and c >= self.fold_pool_fwd_min_cin):
                     # the pool that follows rides in this launch's epilogue (ops.conv3x3_pool): no maxpool2_fwd launch.  Measured in
                     # the c2 iteration (profiles/r04_pool_fold_ab.txt): conv2_2 18.3 + pool 4.8 -> 20.8 us; conv1_2, whose plain
@@ -245,12 +225,8 @@ class HipTrunk:
                 c = L["cout"]
             else:
                 y = self._flat(("a", j), N, c, H // 2, W // 2)
-                nx = self.layers[j + 1] if j + 1 < len(self.layers) else None
                 if pooled is not None:
                     pass                                              # written by the launch of the layer below
-                elif (self.fold_pool_in and nx is not None and nx["kind"] == "conv" and L["idx"] not in self.taps and H % 2 == 0
-                        and W % 2 == 0 and ops.conv3x3_poolin_ok(N, nr, H // 2, W // 2, c, nx["cout"])):
-                    prepool = cur                                     # the layer above pools while it stages its operands; y stays unwritten
                 else:
                     ops.maxpool2_fwd(cur, N, H, W, c, y)
                 pooled = None
@@ -379,25 +355,19 @@ def contextual_loss(x, y, band_width=0.5, weight=None, loss_type="cosine"):
     return _CXFunction.apply(x, y, float(band_width), weight)
 
 
-_CX_FLAT = os.environ.get("NPP_CX_FLAT", "1") != "0"     # 0: the separate cx_dx_finish + npp_trunk_grad_in launches (comparator)
+_CX_FLAT = True     # False: the separate cx_dx_finish + npp_trunk_grad_in launches (comparator of tests/test_gpu_parity.py)
 
 
 class ContextualLoss(nn.Module):
     _MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)        # contextual.py:41-46
 
-    def __init__(self, band_width=0.5, loss_type="cosine", use_vgg=False, vgg_layer="relu3_4", vgg_state_dict=None,
-                 trunk="hip", device="cuda"):
+    def __init__(self, band_width=0.5, loss_type="cosine", use_vgg=False, vgg_layer="relu3_4", vgg_state_dict=None, device="cuda"):
         super().__init__()
         assert band_width > 0, "band_width parameter must be positive."
         assert loss_type == "cosine" and vgg_layer == "relu3_4"
         self.band_width = band_width
-        self.trunk_kind = trunk
-        if use_vgg and trunk == "hip":
+        if use_vgg:
             self.hip_trunk = HipTrunk(_VGG19, taps=(17,), state_dict=vgg_state_dict, device=device)
-        elif use_vgg:                  # comparator: the same stack through torch.nn / MIOpen (tests only)
-            self.vgg_model = _Trunk(_VGG19, taps=(17,), state_dict=vgg_state_dict)
-            self.register_buffer("vgg_mean", torch.tensor(self._MEAN).reshape(3, 1, 1))
-            self.register_buffer("vgg_std", torch.tensor(self._STD).reshape(3, 1, 1))
 
     def forward(self, x, y, weight=None):
         if hasattr(self, "hip_trunk"):
@@ -406,13 +376,6 @@ class ContextualLoss(nn.Module):
             f = self.hip_trunk(torch.cat([x, y.detach()], 0), n_grad=n, scale=[1.0 / s for s in self._STD],
                                shift=[-m / s for m, s in zip(self._MEAN, self._STD)])[0]
             x, y = f[:n], f[n:].detach()
-        elif hasattr(self, "vgg_model"):
-            assert x.shape[1] == 3 and y.shape[1] == 3, "VGG model takes 3 chennel images."
-            x = x.sub(self.vgg_mean).div(self.vgg_std)
-            y = y.sub(self.vgg_mean).div(self.vgg_std)
-            x = self.vgg_model(x)[0]
-            with torch.no_grad():
-                y = self.vgg_model(y)[0]
         return contextual_loss(x, y, self.band_width, weight)
 
     def input_norm(self):
@@ -434,33 +397,6 @@ class ContextualLoss(nn.Module):
             return t._backward([True], n, sc, shape, zero_rest=False, top_writer=top)
         _, dfx = ops.cx_fwd_bwd(f[:n], f[n:], self.band_width, weight, scale, loss_buf, True)
         return t._backward([dfx], n, sc, shape, zero_rest=False)
-
-
-    # ---- the two halves of the contextual batch as separate passes (round 3) -----------------------------------------------
-    # The REAL half of the batch (the y images: crops of the input image, train.py:206-208,235-236) does not depend on the
-    # network: its trunk features can be computed while something else runs.  CompletionFit.step_from(b, next_b) computes the
-    # features of the NEXT iteration's real patches on a side stream under the current iteration's trunk / contextual chain
-    # (both are chains of small dependent launches that leave most of the chip idle) and the next iteration then pushes only
-    # its prediction half through the trunk: the forward pass on the critical path handles n images instead of 2 n.
-    def prefetch_y(self, real, rmask, n_p, k, P):
-        """Trunk features of the real half, (n_p k, 256, P/4, P/4) fp32, on the current stream (a trunk executor of its own)."""
-        if not hasattr(self, "_trunk_y"):
-            self._trunk_y = self.hip_trunk.twin()
-        t = self._trunk_y
-        sc, sh = self.input_norm()
-        nk = n_p * k
-        ops.trunk_patch_in(None, None, None, real, rmask, n_p, k, P, False, sc, sh, t.input_buffer(nk, P, P), None, None, which=2)
-        return t._forward((nk, 3, P, P), sc, sh, True)[0]
-
-    def fused_x(self, shape_x, fy, scale, loss_buf, weight=None):
-        """fused() for a batch that holds ONLY the prediction half (its normalised flat form already written into
-        hip_trunk.input_buffer(), ops.trunk_patch_in(which=1)); fy: the real half's features from prefetch_y().
-        Returns dL/dx (n,3,P,P)."""
-        t = self.hip_trunk
-        sc, sh = self.input_norm()
-        fx = t._forward(tuple(shape_x), sc, sh, True)[0]
-        _, dfx = ops.cx_fwd_bwd(fx, fy, self.band_width, weight, scale, loss_buf, True)
-        return t._backward([dfx], shape_x[0], sc, tuple(shape_x), zero_rest=False)
 
 
 class _LPIPSLayerFunction(torch.autograd.Function):
@@ -504,15 +440,11 @@ class LPIPS(nn.Module):
 
     _SHIFT, _SCALE = (-.030, -.088, -.188), (.458, .448, .450)          # lpips.py:136-143 ScalingLayer
 
-    def __init__(self, net="vgg", lin_weights=None, vgg_state_dict=None, device="cuda", trunk="hip"):
+    def __init__(self, net="vgg", lin_weights=None, vgg_state_dict=None, device="cuda"):
         super().__init__()
         assert net in ("vgg", "vgg16")
         dev = torch.device(device)
-        self.trunk_kind = trunk
-        if trunk == "hip":
-            self.hip_trunk = HipTrunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321, device=dev)
-        else:                          # comparator: torch.nn / MIOpen (tests only)
-            self.net = _Trunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321)
+        self.hip_trunk = HipTrunk(_VGG16, taps=(3, 8, 15, 22, 29), state_dict=vgg_state_dict, seed=4321, device=dev)
         self.register_buffer("shift", torch.tensor(self._SHIFT)[None, :, None, None])
         self.register_buffer("scale", torch.tensor(self._SCALE)[None, :, None, None])
         if lin_weights is None:          # weights/v0.1/vgg.pth is not redistributed here: fixed-seed non-negative stand-ins
@@ -524,28 +456,21 @@ class LPIPS(nn.Module):
             [torch.cat([torch.full((c,), 2.3841858e-07), torch.zeros(c)]) for c in self.chns], dev)
         self.lat_step = 0
         self.touched = False
-        self.grouped_heads = os.environ.get("NPP_LP_GROUPED_HEADS", "1") != "0"
-        self.flat_tap_grads = os.environ.get("NPP_LP_FLAT_TAPS", "1") != "0"     # (needs grouped_heads) tap gradients written flat by the heads
-        self.flat_top_tap = os.environ.get("NPP_LP_FLAT_TOP", "1") != "0"
+        # comparator switches of tests/test_gpu_parity.py (all bit-identical; the defaults are the measured-best forms): one launch per
+        # head; tap gradients as fp32 tensors through npp_trunk_grad_in instead of written flat by the heads launch
+        self.grouped_heads, self.flat_tap_grads, self.flat_top_tap = True, True, True
         self.spline, self.n_knots, self.x_scale = ops.load_spline(dev)
         self.to(dev)
 
     def forward(self, in0, in1, use_robust=True, retPerLayer=False, normalize=False):
         """use_robust=False: the plain head (lpips.py:108-109) with its gradient -- the loop under --use_adaptive_perceptual_loss off."""
         assert not retPerLayer, "retPerLayer is not on the built path"
-        if self.trunk_kind == "hip":       # 2x-1 (lpips.py:96-98) and the scaling layer are folded into the image-in kernel
-            a = 2.0 if normalize else 1.0
-            n = in0.shape[0]
-            f = self.hip_trunk(torch.cat([in0, in1.detach()], 0), n_grad=n, scale=[a / s for s in self._SCALE],
-                               shift=[((-1.0 if normalize else 0.0) - sh) / s for sh, s in zip(self._SHIFT, self._SCALE)])
-            outs0, outs1 = [t[:n] for t in f], [t[n:].detach() for t in f]
-        else:
-            if normalize:
-                in0, in1 = 2 * in0 - 1, 2 * in1 - 1
-            in0, in1 = (in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale
-            outs0 = self.net(in0)
-            with torch.no_grad():
-                outs1 = self.net(in1)
+        # 2x-1 (lpips.py:96-98) and the scaling layer are folded into the image-in kernel
+        a = 2.0 if normalize else 1.0
+        n = in0.shape[0]
+        f = self.hip_trunk(torch.cat([in0, in1.detach()], 0), n_grad=n, scale=[a / s for s in self._SCALE],
+                           shift=[((-1.0 if normalize else 0.0) - sh) / s for sh, s in zip(self._SHIFT, self._SCALE)])
+        outs0, outs1 = [t[:n] for t in f], [t[n:].detach() for t in f]
         val = 0
         for kk in range(5):
             val = val + _LPIPSLayerFunction.apply(outs0[kk], outs1[kk], self, kk, bool(use_robust))

@@ -59,7 +59,7 @@ class NPPNet:
         self.wf = torch.zeros(ops.pack_bytes(self.K, 0, self.width), dtype=torch.uint8, device=self.device)
         self.wb = torch.zeros(ops.pack_bytes(self.K, 1, self.width), dtype=torch.uint8, device=self.device)
         self._ws = {}
-        self.fused_repack = os.environ.get("NPP_FUSED_REPACK", "1") != "0"
+        self.fused_repack = True    # False: Adam and the weight re-pack as two launches (comparator of the fused adam_pack launch)
         if params is not None:
             self.load_state_dict(params)
 
@@ -86,8 +86,7 @@ class NPPNet:
     def grads(self):
         """Sum of the split-K slabs, as a reference-named dict (for tests)."""
         ws = self._ws_last
-        n_slabs = sum(ws["ks"]) if "ks" in ws else self.ksplit                                       # (workspace_split: both row groups' slabs)
-        g = ws["gslabs"].view(n_slabs, -1)[:, :self.n_params].sum(0).cpu().numpy()     # slab stride = n_params rounded up to 4
+        g = ws["gslabs"].view(self.ksplit, -1)[:, :self.n_params].sum(0).cpu().numpy()     # slab stride = n_params rounded up to 4
         out = {}
         for name, off, rows, cols in self.layout:
             a = g[off:off + rows * cols]
@@ -113,52 +112,6 @@ class NPPNet:
             self._ws[Bp] = ws
         self._ws_last = ws
         return ws
-
-    def workspace_split(self, Bp, n_a, ks_a, ks_b):
-        """The batch as TWO row groups, A = rows [0, n_a) and B = rows [n_a, Bp), each with stash arrays of its own and its own
-        share of the split-K slabs (A: slabs [0, ks_a), B: slabs [ks_a, ks_a + ks_b)): the two groups' forward / backward /
-        weight-gradient launches are then independent of each other (no shared writes) and may run on different streams; the
-        Adam launch sums all ks_a + ks_b slabs.  pred / dpred stay ONE (Bp, 3) buffer each (row slices are contiguous)."""
-        key = ("split", Bp, n_a, ks_a, ks_b)
-        ws = self._ws.get(key)
-        if ws is None:
-            if n_a <= 0 or n_a >= Bp or n_a % 64 or Bp % 64:
-                raise ValueError(f"workspace_split: row groups must be non-empty multiples of 64 rows (Bp={Bp}, n_a={n_a})")
-            dev = self.device
-            sa = ops.train_workspace(self.K, n_a, ks_a, self.width)
-            sb = ops.train_workspace(self.K, Bp - n_a, ks_b, self.width)
-            stride = sa[3] // 4 // ks_a
-            gsl = torch.empty((ks_a + ks_b) * stride, dtype=torch.float32, device=dev)
-            pred = torch.empty((Bp, 3), dtype=torch.float32, device=dev)
-            dpred = torch.zeros((Bp, 3), dtype=torch.float32, device=dev)
-            ws = {"gslabs": gsl, "pred": pred, "dpred": dpred, "n_a": n_a, "ks": (ks_a, ks_b), "stride": stride,
-                  "A": {"actT": torch.empty(sa[1], dtype=torch.uint8, device=dev), "dzT": torch.empty(sa[2], dtype=torch.uint8, device=dev),
-                        "gslabs": gsl[:ks_a * stride], "pred": pred[:n_a], "dpred": dpred[:n_a], "rows": n_a, "ks": ks_a},
-                  "B": {"actT": torch.empty(sb[1], dtype=torch.uint8, device=dev), "dzT": torch.empty(sb[2], dtype=torch.uint8, device=dev),
-                        "gslabs": gsl[ks_a * stride:], "pred": pred[n_a:], "dpred": dpred[n_a:], "rows": Bp - n_a, "ks": ks_b}}
-            self._ws[key] = ws
-        self._ws_last = ws
-        return ws
-
-    def group_forward(self, g, coords_rows):
-        ops.mlp_fwd(coords_rows, self.cfg, self.wf, self.params, g["pred"], g["actT"], self.width, out_act=self.out_act)
-
-    def group_backward(self, g, patch=None, wgrad=True):
-        if patch is not None:
-            ops.mlp_bwd_patch(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], *patch, width=self.width, out_act=self.out_act)
-        else:
-            ops.mlp_bwd(g["dpred"], g["pred"], self.K, self.wb, self.params, g["actT"], g["dzT"], self.width, out_act=self.out_act)
-        if wgrad:
-            ops.mlp_wgrad(g["dzT"], g["actT"], g["rows"], self.K, g["ks"], g["gslabs"], self.width)
-
-    def optimizer_step_split(self, ws):
-        """optimizer_step() over the slabs of both row groups."""
-        self.opt_step += 1
-        idle = self._loss_bufs[1 - self._loss_idx:2 - self._loss_idx]
-        self._adam(ws["gslabs"], sum(ws["ks"]), ws["stride"], idle)
-        self.lr = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 100)))
-        if self.lr_clock:
-            self.global_step += 1
 
     # ---- the path ---------------------------------------------------------------------
     def render(self, coords):

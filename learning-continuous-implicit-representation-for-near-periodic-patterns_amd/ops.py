@@ -110,8 +110,8 @@ def h2d(a, device):
 
 
 PIXEL_LOSS_SCRATCH = 1024 * 8 + 8       # NPP_PIXEL_LOSS_SCRATCH_FLOATS (include/npp_hip.h)
-# 0: the float-atomic reductions of the pixel loss and the LPIPS head (arrival order; the A/B comparator of the fixed-order forms)
-DETERMINISTIC = __import__("os").environ.get("NPP_DETERMINISTIC", "1") != "0"
+# False: the float-atomic reductions of the pixel loss and the LPIPS head (arrival order; the A/B comparator of the fixed-order forms)
+DETERMINISTIC = True
 
 
 def pad_rows(n):
@@ -586,19 +586,6 @@ def conv_pair_fwd(x, N_total, n_run, n_keep, H, W, cin, cmid, cout, pack_a, bias
     """relu(conv a) -> relu(conv b) -> MaxPool2d(2,2) in one launch; y_a / y_b only for the first n_keep images."""
     check(lib().npp_conv_pair_fwd(_p(x), N_total, n_run, n_keep, H, W, cin, cmid, cout, _p(pack_a), _p(bias_a), _p(pack_b), _p(bias_b),
                                   _p(y_a), _p(y_b), _p(y_pool), _p(tap_b), _stream()), "npp_conv_pair_fwd")
-
-
-def conv3x3_poolin_ok(N_total, n_run, H, W, cin, cout):
-    """Whether conv3x3_poolin takes this shape (H, W: the pooled geometry)."""
-    return bool(lib().npp_conv3x3_poolin_ok(N_total, n_run, H, W, cin, cout))
-
-
-def conv3x3_poolin(xpre, N_total, n_run, H, W, cin, cout, pack, bias, y, tap=None, ctap=0, tap_scale=None, next_pack=None):
-    """2 x 2 max-pool of xpre (geometry (2H, 2W)) + the forward layer on it in one launch (the pooled tensor is never written)."""
-    ts = None if tap_scale is None else (C.c_float * len(tap_scale))(*[float(v) for v in tap_scale])
-    nb = 0 if next_pack is None else next_pack.numel() * next_pack.element_size()
-    check(lib().npp_conv3x3_poolin(_p(xpre), N_total, n_run, H, W, cin, cout, _p(pack), _p(bias), _p(y), _p(tap), ctap, ts,
-                                   _p(next_pack), nb, _stream()), "npp_conv3x3_poolin")
 
 
 def conv3x3_dgrad_pool(x, N_total, n_run, H, W, cin, cout, pack, xpre, addend, dz, next_pack=None):

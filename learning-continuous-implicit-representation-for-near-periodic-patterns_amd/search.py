@@ -49,7 +49,7 @@ def parse(argv=None):
     ap.add_argument("--carry_adaptive_latents", action="store_true", help="(the default since round 5; accepted for compatibility)")
     ap.add_argument("--loss_type", default="robust_loss_adaptive", choices=["robust_loss_adaptive", "l2", "robust_loss"],
                     help="options/arg_config.py:34 (models/mse_calculator.py:19-23): the pixel loss of the candidate fits")
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"], help="arithmetic of the candidate fits (default: NPP_LIGHT_PRECISION, else fp32)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"], help="arithmetic of the candidate fits (default fp32)")
     ap.add_argument("--device", default="cuda:0")
     return ap.parse_args(argv)
 

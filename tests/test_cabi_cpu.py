@@ -304,20 +304,21 @@ def test_pack_scatter_inverse_maps_reproduce_the_packers(K, width):
 
 
 def test_pool_fold_entry_points_validate_on_the_host():
-    """The pools folded into their neighbouring convolutions (csrc/npp_conv.hip): the shape query of the window-staged form and the
-    argument checks that come before any launch."""
+    """The pools folded into their neighbouring convolutions (csrc/npp_conv.hip) and the fused layer pair (csrc/npp_conv_pair.hip): the
+    shape query and the argument checks that come before any launch."""
     from npp_amd._lib import LpipsTap
     L = npp_amd.lib()
     fake = C.c_void_p(64)
-    # npp_conv3x3_poolin_ok: the loop's conv2_1 on twelve 96^2 patches is taken; four patches are too few workgroups, 128 input
-    # channels too many channel steps, an odd output-channel block count no 64-channel workgroup
-    assert L.npp_conv3x3_poolin_ok(12, 12, 48, 48, 64, 128) == 1
-    assert L.npp_conv3x3_poolin_ok(4, 4, 48, 48, 64, 128) == 0
-    assert L.npp_conv3x3_poolin_ok(12, 12, 24, 24, 128, 256) == 0
-    assert L.npp_conv3x3_poolin_ok(12, 12, 48, 48, 64, 96) == 0
-    assert L.npp_conv3x3_poolin_ok(12, 13, 48, 48, 64, 128) == 0
-    assert L.npp_conv3x3_poolin(fake, 4, 4, 48, 48, 64, 128, fake, fake, fake, None, 0, None, None, 0, None) < 0
-    assert b"npp_conv3x3_poolin_ok" in L.npp_last_error_string()
+    # the fused layer pair (csrc/npp_conv_pair.hip): the shape query, and the argument checks in front of the launch
+    assert L.npp_conv_pair_fwd_ok(96, 96, 16, 64, 64) == 1
+    assert L.npp_conv_pair_fwd_ok(95, 96, 16, 64, 64) == 0                  # the pool needs even sizes
+    assert L.npp_conv_pair_fwd_ok(48, 48, 64, 128, 128) == 0                # (the second block is not built as a pair)
+    assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 48, 48, 64, 128, 128, fake, fake, fake, fake, fake, fake, fake, None, None) < 0
+    assert b"npp_conv_pair_fwd_ok" in L.npp_last_error_string()
+    assert L.npp_conv_pair_fwd(fake, 4, 5, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, fake, fake, fake, None, None) < 0   # n_run > N_total
+    assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, None, fake, fake, None, None) < 0   # kept images need y_a
+    assert L.npp_tune(b"conv_pair", -1) in (0, 1) and L.npp_tune(b"no_such_key", 0) < 0
+    assert b"unknown key" in L.npp_last_error_string()
     assert L.npp_conv3x3_pool(fake, 2, 2, 47, 48, 64, 64, fake, fake, fake, fake, None, 0, None, None, 0, None) < 0            # odd H
     assert b"even" in L.npp_last_error_string()
     assert L.npp_conv3x3_pool(fake, 2, 2, 48, 48, 64, 64, fake, fake, fake, None, None, 0, None, None, 0, None) < 0            # no pooled output

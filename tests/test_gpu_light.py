@@ -359,9 +359,9 @@ def test_candidate_loop_vs_reference_trajectory_g10d(dev, golden):
     assert np.abs(loss_i[:, 1] - g["c1.loss"]).max() > 10 * np.abs(loss_c[:, 1] - g["c1.loss"]).max()
 
 
-def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
+def test_concurrent_candidate_fits_equal_the_serial_ones(dev):
     """ProposalRanker.fit_candidates -- all candidates in every launch (default: NPPNetLightBatch), advanced together on side
-    streams (batched=False), or iterations 2 .. N of each fit replayed as ONE captured HIP graph (NPP_LIGHT_GRAPH=1) -- against
+    streams (batched=False), or iterations 2 .. N of each fit replayed as ONE captured HIP graph (use_graph=True) -- against
     the eager fit_candidate loop: the same fitted
     parameters (split-K float atomics in the weight gradients give run-to-run noise of ~1e-6), step counts, LR clock and scores."""
     from npp_amd.light import ProposalRanker
@@ -374,9 +374,7 @@ def test_concurrent_candidate_fits_equal_the_serial_ones(dev, monkeypatch):
     ranker = ProposalRanker(img, i_train, i_val, device=dev, N_iters=40, N_rand=1024)
     cands = [(angles[0], periods[0]), (angles[0], periods[0] * 1.37), (angles[0] + 35.0, periods[0]), (angles[0] + 10.0, periods[0] * 0.8),
              (angles[0], periods[0] * 2.0)]
-    monkeypatch.setenv("NPP_LIGHT_GRAPH", "1")
-    graphed = ranker.fit_candidates(cands)
-    monkeypatch.setenv("NPP_LIGHT_GRAPH", "0")
+    graphed = [ranker.fit_candidate(a_, p_, use_graph=True) for a_, p_ in cands]
     together = ranker.fit_candidates(cands, n_streams=3, batched=False)
     stacked = ranker.fit_candidates(cands)                       # default: NPPNetLightBatch, the candidate is a grid dimension
     assert type(ranker._batch_keep).__name__ == "NPPNetLightBatch" and stacked[0].params.data_ptr() == ranker._batch_keep.params.data_ptr()

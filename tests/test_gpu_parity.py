@@ -212,63 +212,6 @@ def test_lpips_plain_head_with_gradient(dev, C, hw):
     assert fwd_only.item() == loss.item() or abs(fwd_only.item() - loss.item()) < 1e-6 * abs(loss.item())
 
 
-_CX_FLAT_SNIPPET = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from npp_amd import ops
-dev = torch.device('cuda:0')
-g = torch.Generator().manual_seed(21)
-N, C, H = 3, 256, 24
-fx = torch.rand(N, C, H, H, generator=g).to(dev)
-fy = torch.rand(N, C, H, H, generator=g).to(dev)
-yact = ops.trunk_alloc(2 * N, C, H, H, dev)
-yact.view(torch.int16)[:] = torch.randint(0, 2, (yact.numel() // 2,), generator=g, dtype=torch.int16).to(dev) * 0x3c00   # fp16 0 / 1: the ReLU gates
-dz = ops.trunk_alloc(2 * N, C, H, H, dev)
-loss = torch.zeros(1, device=dev)
-ops.cx_fwd_bwd_flat(fx, fy, yact, dz, 2 * N, 0.5, 1.0, loss)
-torch.cuda.synchronize()
-np.savez(sys.argv[2], dz=dz.cpu().numpy(), loss=loss.cpu().numpy())
-"""
-
-
-def test_cx_core_five_launch_form_equals_the_six_launch_form(dev, tmp_path):
-    """NPP_CX_DX_FUSED=1 (cx_dx32_flat_kernel: the backward contraction with the normalisation backward, ReLU gate and flat bf16 store in
-    its epilogue) against the shipped six-launch form: the flat gradient tensor bit for bit on its interior, zero elsewhere.  The
-    switch is read once per process, hence two child processes."""
-    import os
-    import subprocess
-    import sys
-    outs = []
-    for flag in ("0", "1"):
-        out = str(tmp_path / f"cx{flag}.npz")
-        env = dict(os.environ, NPP_CX_DX_FUSED=flag)
-        r = subprocess.run([sys.executable, "-c", _CX_FLAT_SNIPPET, ROOT, out], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(out))
-    assert outs[0]["loss"] == outs[1]["loss"]
-    a, b = outs[0]["dz"], outs[1]["dz"]
-    assert np.array_equal(a, b) and np.any(a != 0)
-
-
-def test_cx_backward_contraction_staged_through_lds_equals_the_row_streaming_form(dev, tmp_path):
-    """cx_dx32s_kernel (the backward contraction with both operands staged through LDS: the shipped form) against cx_dx32_kernel
-    (NPP_CX_DX_LDS=0: every lane streams its own rows): same column order per MFMA, so the flat gradient tensor and the loss are the
-    same bits.  The switch is read once per process, hence two child processes."""
-    import os
-    import subprocess
-    import sys
-    outs = []
-    for flag in ("0", "1"):
-        out = str(tmp_path / f"cxl{flag}.npz")
-        env = dict(os.environ, NPP_CX_DX_LDS=flag, NPP_CX_DX_FUSED="0")
-        r = subprocess.run([sys.executable, "-c", _CX_FLAT_SNIPPET, ROOT, out], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(out))
-    assert outs[0]["loss"] == outs[1]["loss"]
-    a, b = outs[0]["dz"], outs[1]["dz"]
-    assert np.array_equal(a, b) and np.any(a != 0)
-
-
 def test_lpips_heads_in_one_launch_equal_the_five_launches(dev):
     """npp_lpips_layers (blockIdx.y = tap) against five npp_lpips_layer calls on VGG16-shaped taps: loss word (the fixed-point sums are
     order-independent), feature gradients and latent gradients bit for bit; adaptive and plain heads."""
@@ -1413,39 +1356,6 @@ def test_fused_adam_repack_equals_adam_then_pack(dev, K, width):
     a, b = nets
     for name in ("params", "m", "v", "latents", "lat_m", "lat_v", "wf", "wb"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
-
-
-@pytest.mark.parametrize("source", ["val", "same"])
-def test_two_row_group_step_equals_the_single_stream_step(dev, source):
-    """CompletionFit.overlap (the pixel rows' forward / pixel loss / backward / wgrad as their own row group on a side stream,
-    NPPNet.workspace_split) against the plain step on the same batch: same loss, gradients and parameters up to the summation
-    order of the split-K slabs and the float atomics of the contextual-loss kernels."""
-    from npp_amd.fit import CompletionFit
-    H, K = 256, 3
-    img, mask = oracle.synthetic_image(H)
-    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
-
-    def make(ov):
-        f = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev, N_rand=2048,
-                          shifts=shifts, seed=3)
-        f.overlap, f.overlap_ks = ov, (2, 3)
-        return f
-    a, b = make(True), make(False)
-    batch = None
-    for _ in range(40):
-        d = a.draw_batch()
-        if d is not None and d["source"] == source:
-            batch = a.materialise_batch(d)
-            break
-    assert batch is not None
-    a.step_from(batch)
-    b.step_from(batch)
-    torch.cuda.synchronize()
-    ga, gb = a.net.grads(), b.net.grads()
-    for k_ in ga:
-        assert rel_l2(ga[k_], gb[k_]) < 6e-3, k_
-    assert abs(float(a.net.loss_buf[0]) - float(b.net.loss_buf[0])) < 1e-6 * abs(float(b.net.loss_buf[0])) + 1e-9
-    assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4
 
 
 def _run_task_golden(dev, g, fit, n_iters=100, loss_tol=0.03, n_loss=20, loss_tol_all=0.05):
