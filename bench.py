@@ -506,25 +506,26 @@ def main():
     # The kernels also stream this design's 16-bit activation / gradient stash through HBM (far more than 8(d)'s
     # algorithmic 32 B/row): that byte model and the rate it implies are reported beside it as `design_traffic`.
     measured, mfma_pmc, traffic_source = None, None, None
-    pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false, false>", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
-               "mlp_wgrad": "npp::wgrad_kernel"}
+    pmc_key = {"mlp_fwd_train": "npp::mlp_fwd_kernel<true, true, false, false", "mlp_bwd_chain": "npp::mlp_bwd_kernel<true>",
+               "mlp_wgrad": "npp::wgrad_kernel"}          # (prefixes of the profiler's kernel names)
     try:     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
              # doubled per the gfx950 note in MI355X_MICROARCH.md): the newest summary committed under profiles/
         import glob
-        pm_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_summary.json")))[-1]
+        pm_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_summary.json")))[-1]
         pm = json.load(open(pm_path))
-        measured = pm["kernels"][pmc_key[dom]]["hbm_bytes"]
+        measured = next(v_["hbm_bytes"] for k_, v_ in pm["kernels"].items() if k_.startswith(pmc_key[dom]))
         traffic_source = ("profiles/" + os.path.basename(pm_path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, committed; "
                           "NOT collected in this run)")
     except (OSError, IndexError, KeyError, ValueError):
         measured = None
     try:     # matrix-pipe busy fraction of the same kernel from SQ_VALU_MFMA_BUSY_CYCLES (tools/pmc_sq.sh), same source
         import glob
-        pq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))[-1]))
-        mfma_pmc = {k_: pq["kernels"][v_].get("mfma_pipe_busy_frac") for k_, v_ in pmc_key.items() if v_ in pq["kernels"]}
+        pq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sq_summary.json")))[-1]))
+        mfma_pmc = {k_: next((x_.get("mfma_pipe_busy_frac") for n_, x_ in pq["kernels"].items() if n_.startswith(v_)), None)
+                    for k_, v_ in pmc_key.items()}
         # the inference render (one 0.7-ms dispatch, long enough for GRBM_GUI_ACTIVE / 8 / wall to be the clock the chip held:
         # MI355X_MICROARCH.md 'DVFS give-back'): pipe-busy fraction AT that clock, next to the FLOP fraction of the 2.4-GHz peak
-        rk = pq["kernels"].get("npp::mlp_fwd_kernel<false, true, false, false>")
+        rk = next((x_ for n_, x_ in pq["kernels"].items() if n_.startswith("npp::mlp_fwd_kernel<false, true, false, false")), None)
         if rk:
             mfma_pmc["render_fwd_512sq"] = rk.get("mfma_pipe_busy_frac")
             mfma_pmc["render_effective_clock_GHz"] = rk.get("effective_clock_GHz")
