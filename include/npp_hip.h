@@ -69,7 +69,7 @@ int npp_device_count(void);
 /* Launch-time choice between kernel FORMS that compute the same result (the reference has no counterpart: torch / cuDNN pick
  * their algorithms internally).  Keys: "conv_wink" (group-split window convolution: 0 never, 1 where measured best, 2 wherever
  * feasible), "conv_win" (window-staged convolution, same values), "conv_wstat" (weight-stationary block numbering, 0 / 1),
- * "conv_pair" (fused convolution pairs, 0 / 1).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
+ * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second; 0 never, default 3).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
  * key.  Initial values come from the environment (NPP_CONV_WINK=...), defaults are the measured-best forms. */
 int npp_tune(const char* key, int value);
 

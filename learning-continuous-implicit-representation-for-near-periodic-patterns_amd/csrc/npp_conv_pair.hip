@@ -295,6 +295,221 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fwd_kernel(PairArgs a) {
   NPP_STAMP(a, 6);
 }
 
+// ---- the second block: 64 -> 128 -> 128 channels (+ pool2).  conv a's weights alone are 144 KB: BOTH layers' weights stream through
+// two 36-KB LDS stages, one per channel step, as ONE sequence of CAS + 8 stages (stage t in buffer t & 1; registers hold stage t + 1
+// while stage t is multiplied); the intermediate tile is 10 x 18 x 128 channels = 45 KB, the input window 12 x 20 x 64 = 30 KB: 147 KB,
+// one workgroup of EIGHT waves per CU (two per SIMD), an 8 x 16 output tile each: 216 workgroups at 12 x 48^2.
+// Wave roles: conv a -- output-channel tile w & 3, position tiles {g, g + 2, g + 4} (g = w >> 2) of the six 32-position tiles of the
+// halo-extended tile; conv b -- output-channel tile w & 3, position tiles {2 g, 2 g + 1} of the four (2 rows x 16 columns each).
+template <int CAS>
+__global__ __launch_bounds__(512) void conv_pair8_fwd_kernel(PairArgs a) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int CB = 128, CC = 128, TH = 8;
+  constexpr int MW = 18, MH = TH + 2, MN = MH * MW, IW = 20, IH = TH + 4, INN = IH * IW;
+  constexpr int CHA = 2 * CAS, CHB = CB / 8, CBS = CB / 16, NCB = CC / 32;
+  constexpr int kMid = CHB * MN * 16, kIn = CHA * INN * 16, kW = 4 * 9 * 1024;
+  static_assert(CB / 32 == 4 && NCB == 4 && (MN + 31) / 32 == 6 && TH / 2 == 4, "wave roles are written for this shape");
+  extern __shared__ __attribute__((aligned(16))) char plds[];
+  NPP_STAMP(a, 0);
+  NPP_STAMP(a, 1);
+  char* const lmid = plds;
+  char* const lin = plds + kMid;
+  char* const lw = plds + kMid + kIn;                                // two weight stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = lane & 31, h = lane >> 5;
+  const int ct = wave & 3, g = wave >> 2;
+  const int T = blockIdx.x;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int n = T / per_img, tr = T - n * per_img, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const bool keep = n < a.n_keep;
+  const wrsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack_a), 0, (int)a.pack_a_bytes, 0x00020000);
+  const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack_b), 0, (int)a.pack_b_bytes, 0x00020000);
+  // the weight stream: stage t < CAS = conv a's channel step t, else conv b's step t - CAS; unit u = (cot, tap, lane)
+  constexpr int NWU = (4 * 576 + 511) / 512;
+  u32x4_t rw[NWU];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+      const int u = tid + 512 * i, cot = u / 576, r = u - cot * 576;
+      const bool ok = u < 4 * 576;
+      if (t < CAS) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, ok ? ((cot * CAS + t) * 9) * 1024 + r * 16 : 0, 0, 0);
+      else rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, ok ? ((cot * CBS + (t - CAS)) * 9) * 1024 + r * 16 : 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NWU; ++i)
+      if (tid + 512 * i < 4 * 576) *(u32x4_t*)(lw + (t & 1) * kW + (tid + 512 * i) * 16) = rw[i];
+  };
+  // ---- phase 0: input window -> LDS, weight stage 0 -> LDS, stage 1 -> registers ----------------------------------------------
+  {
+    constexpr int NI = (CHA * INN + 511) / 512;
+    u32x4_t ri[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = tid + 512 * i;
+      const int chunk = u / INN, q = u - chunk * INN, r = q / IW, c = q - r * IW;
+      const int iy = y0 - 2 + r, ix = x0 - 2 + c;
+      const bool ok = u < CHA * INN && iy >= -1 && iy <= a.H && ix >= -1 && ix <= a.W;
+      const int64_t pos = (int64_t)n * a.S + (int64_t)(iy + 1) * a.Wp + (ix + 1);
+      const int off = ok ? (int)(((int64_t)chunk * a.nposp + kConvGuard + pos) * 16) : -1;
+      ri[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, off < 0 ? 0 : off, 0, 0);
+      if (off < 0) ri[i] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    gload(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (tid + 512 * i < CHA * INN) *(u32x4_t*)(lin + (tid + 512 * i) * 16) = ri[i];
+    sstore(0);
+    gload(1);
+  }
+  float bias_ar[16], bias_br[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    bias_ar[r] = a.bias_a[32 * ct + acc_row(r, h)];
+    bias_br[r] = a.bias_b[32 * ct + acc_row(r, h)];
+  }
+  __syncthreads();
+  NPP_STAMP(a, 2);
+
+  // ---- phase a: conv a on the 10 x 18 halo-extended tile -> LDS (fp16), -> y_a for the tile's own positions ----------------------
+  int mj[3], ibase[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    mj[j] = 32 * (g + 2 * j) + b;
+    const int mc_ = mj[j] < MN ? mj[j] : MN - 1;
+    ibase[j] = (mc_ / MW) * IW + (mc_ % MW);
+  }
+  {
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int ci = 0; ci < CAS; ++ci) {
+      const char* bA = lw + (ci & 1) * kW + ((ct * 9) * 64 + lane) * 16;
+      const char* bI = lin + ((2 * ci + h) * INN) * 16;
+      f16x8 A[2], B[2][3];
+      auto lread = [&](int set, int tap) {
+        A[set] = *(const f16x8*)(bA + tap * 1024);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B[set][j] = *(const f16x8*)(bI + (ibase[j] + (tap / 3) * IW + (tap % 3)) * 16);
+      };
+      lread(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = pmfma(A[tap & 1], B[tap & 1][j], acc[j]);
+      }
+      sstore(ci + 1);                                               // (registers hold stage ci + 1; its buffer was read in stage ci - 1)
+      gload(ci + 2);                                                // (CAS + 8 >= ci + 3 stages: always a valid stage)
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int m = mj[j], mc_ = m < MN ? m : MN - 1, mr = mc_ / MW, mc = mc_ - mr * MW;
+      const int iy = y0 - 1 + mr, ix = x0 - 1 + mc;
+      const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const bool own = keep && a.y_a && inside && mr >= 1 && mr <= TH && mc >= 1 && mc <= 16 && m < MN;
+      const int64_t pos = (int64_t)n * a.S + (int64_t)(iy + 1) * a.Wp + (ix + 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = 4 * ct + 2 * s + h;
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = fminf(fmaxf(acc[j][8 * s + k] + bias_ar[8 * s + k], 0.0f), 65504.0f);
+          o[k] = (_Float16)(inside ? v : 0.0f);
+        }
+        if (m < MN) *(f16x8*)(lmid + (chunk * MN + m) * 16) = o;
+        if (own) ((f16x8*)a.y_a)[(int64_t)chunk * a.nposp + kConvGuard + pos] = o;
+      }
+    }
+  }
+  __syncthreads();                                                   // the intermediate tile is complete (weight stage CAS is in LDS already)
+  NPP_STAMP(a, 3);
+
+  // ---- phase b: conv b, weight stages CAS .. CAS + 7 ----------------------------------------------------------------------------
+  int bbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bbase[j] = (2 * (2 * g + j) + (b >> 4)) * MW + (b & 15);
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  for (int ci = 0; ci < CBS; ++ci) {
+    const int t = CAS + ci;
+    const char* bA = lw + (t & 1) * kW + ((ct * 9) * 64 + lane) * 16;
+    const char* bM = lmid + ((2 * ci + h) * MN) * 16;
+    f16x8 A[2], B[2][2];
+    auto lread = [&](int set, int tap) {
+      A[set] = *(const f16x8*)(bA + tap * 1024);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) B[set][j] = *(const f16x8*)(bM + (bbase[j] + (tap / 3) * MW + (tap % 3)) * 16);
+    };
+    lread(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = pmfma(A[tap & 1], B[tap & 1][j], acc[j]);
+    }
+    if (ci + 1 < CBS) {
+      sstore(t + 1);
+      if (ci + 2 < CBS) gload(t + 2);
+    }
+    __syncthreads();
+  }
+  NPP_STAMP(a, 4);
+
+  // ---- epilogue: bias + ReLU, y_b / tap, 2 x 2 max-pool by lane exchanges (as conv_pair_fwd_kernel) -------------------------------
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 2 * (2 * g + j) + (b >> 4), col = b & 15;
+    const int iy = y0 + row, ix = x0 + col;
+    const bool inside = iy < a.H && ix < a.W;
+    const int64_t pos = (int64_t)n * a.S + (int64_t)(iy + 1) * a.Wp + (ix + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = 4 * ct + 2 * s + h;
+      f16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = fminf(fmaxf(acc[j][8 * s + k] + bias_br[8 * s + k], 0.0f), 65504.0f);
+        o[k] = (_Float16)(inside ? v : 0.0f);
+        if (a.tap_b && inside) {
+          const int co = 32 * ct + acc_row(8 * s + k, h);
+          a.tap_b[(((int64_t)n * CC + co) * a.H + iy) * a.W + ix] = v;
+        }
+      }
+      if (keep && a.y_b && inside) ((f16x8*)a.y_b)[(int64_t)chunk * a.nposp + kConvGuard + pos] = o;
+      typedef int i32x4_t __attribute__((ext_vector_type(4)));
+      i32x4_t w = __builtin_bit_cast(i32x4_t, o);
+#pragma unroll
+      for (int step = 0; step < 2; ++step) {
+        i32x4_t t2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t2[e] = __shfl_xor(w[e], step == 0 ? 1 : 16, 64);
+        w = __builtin_bit_cast(i32x4_t, __builtin_elementwise_max(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, t2)));
+      }
+      if (inside && (b & 17) == 0 && (iy >> 1) < Ho && (ix >> 1) < Wo) {
+        const int64_t up = (int64_t)chunk * a.pool_nposp + kConvGuard + (int64_t)n * (Ho + 2) * (Wo + 2) +
+                           (int64_t)((iy >> 1) + 1) * (Wo + 2) + ((ix >> 1) + 1);
+        ((f16x8*)a.y_pool)[up] = __builtin_bit_cast(f16x8, w);
+      }
+    }
+  }
+  NPP_STAMP(a, 5);
+  NPP_STAMP_DRAIN();
+  NPP_STAMP(a, 6);
+}
+
 }  // namespace npp
 
 using namespace npp;
@@ -315,10 +530,10 @@ static int pair_launch(PairArgs& a, hipStream_t s) {
   return check_launch("npp_conv_pair_fwd");
 }
 
-// Shapes the fused pair is built for: (Cin, Cmid, Cout).  H, W even (the pool), any size.
+// Shapes the fused pair is built for: (Cin, Cmid, Cout) = (16, 64, 64) and (64, 128, 128).  H, W even (the pool), any size.
 extern "C" int npp_conv_pair_fwd_ok(int H, int W, int Cin, int Cmid, int Cout) {
   if (H < 2 || W < 2 || (H & 1) || (W & 1)) return 0;
-  return (Cin == 16 && Cmid == 64 && Cout == 64) ? 1 : 0;
+  return ((Cin == 16 && Cmid == 64 && Cout == 64) || (Cin == 64 && Cmid == 128 && Cout == 128)) ? 1 : 0;
 }
 
 extern "C" int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_keep, int H, int W, int Cin, int Cmid, int Cout,
@@ -346,5 +561,13 @@ extern "C" int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_
 #ifdef NPP_DIAG
   a.stamps = npp::g_diag_stamps; a.stamps_n = npp::g_diag_n;
 #endif
-  return pair_launch<1, 64, 64, 16>(a, (hipStream_t)stream);
+  if (Cin == 16) return pair_launch<1, 64, 64, 16>(a, (hipStream_t)stream);
+  // the second block: 8 x 16 tiles, eight waves, both weight streams through LDS
+  constexpr int kLds8 = 16 * 180 * 16 + 8 * 240 * 16 + 2 * 4 * 9 * 1024;
+  a.tiles_x = (W + 15) / 16;
+  a.tiles_y = (H + 7) / 8;
+  static SmemOnce once8;
+  if (!smem_attr(once8, (const void*)conv_pair8_fwd_kernel<4>, kLds8)) { set_error("npp_conv_pair_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL((conv_pair8_fwd_kernel<4>), dim3((unsigned)(a.n_run * a.tiles_x * a.tiles_y)), dim3(512), kLds8, (hipStream_t)stream, a);
+  return check_launch("npp_conv_pair_fwd");
 }

@@ -145,7 +145,8 @@ class HipTrunk:
         self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin = True, True, 128
         # conv a -> conv b -> pool of the first blocks as ONE launch (ops.conv_pair_fwd; round 5): the intermediate activation
         # stays in LDS, the layer outputs are stored only for the images that carry a gradient
-        self.fuse_pairs = ops.tune("conv_pair") != 0
+        # (bit 0: the first block, 3 -> 64 -> 64; bit 1: the second, 64 -> 128 -> 128)
+        self.fuse_pairs = int(ops.tune("conv_pair"))
         self._n_keep = None
 
     def _pb_below(self, j):
@@ -188,7 +189,7 @@ class HipTrunk:
                 skip -= 1
                 continue
             Lb = self.layers[j + 1] if j + 2 < len(self.layers) else None
-            if (self.fuse_pairs and L["kind"] == "conv" and Lb is not None and Lb["kind"] == "conv" and self.layers[j + 2]["kind"] == "pool"
+            if ((int(self.fuse_pairs) & (1 if c == 16 else 2)) and L["kind"] == "conv" and Lb is not None and Lb["kind"] == "conv" and self.layers[j + 2]["kind"] == "pool"
                     and L["relu_idx"] not in self.taps and self.layers[j + 2]["idx"] not in self.taps
                     and ops.conv_pair_fwd_ok(H, W, c, L["cout"], Lb["cout"])):
                 ya = self._flat(("a", j), N, L["cout"], H, W)

@@ -312,12 +312,12 @@ def test_pool_fold_entry_points_validate_on_the_host():
     # the fused layer pair (csrc/npp_conv_pair.hip): the shape query, and the argument checks in front of the launch
     assert L.npp_conv_pair_fwd_ok(96, 96, 16, 64, 64) == 1
     assert L.npp_conv_pair_fwd_ok(95, 96, 16, 64, 64) == 0                  # the pool needs even sizes
-    assert L.npp_conv_pair_fwd_ok(48, 48, 64, 128, 128) == 0                # (the second block is not built as a pair)
-    assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 48, 48, 64, 128, 128, fake, fake, fake, fake, fake, fake, fake, None, None) < 0
+    assert L.npp_conv_pair_fwd_ok(48, 48, 64, 128, 128) == 1 and L.npp_conv_pair_fwd_ok(24, 24, 128, 256, 256) == 0
+    assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 24, 24, 128, 256, 256, fake, fake, fake, fake, fake, fake, fake, None, None) < 0
     assert b"npp_conv_pair_fwd_ok" in L.npp_last_error_string()
     assert L.npp_conv_pair_fwd(fake, 4, 5, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, fake, fake, fake, None, None) < 0   # n_run > N_total
     assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, None, fake, fake, None, None) < 0   # kept images need y_a
-    assert L.npp_tune(b"conv_pair", -1) in (0, 1) and L.npp_tune(b"no_such_key", 0) < 0
+    assert L.npp_tune(b"conv_pair", -1) in (0, 1, 2, 3) and L.npp_tune(b"no_such_key", 0) < 0
     assert b"unknown key" in L.npp_last_error_string()
     assert L.npp_conv3x3_pool(fake, 2, 2, 47, 48, 64, 64, fake, fake, fake, fake, None, 0, None, None, 0, None) < 0            # odd H
     assert b"even" in L.npp_last_error_string()
