@@ -69,7 +69,7 @@ int npp_device_count(void);
 /* Launch-time choice between kernel FORMS that compute the same result (the reference has no counterpart: torch / cuDNN pick
  * their algorithms internally).  Keys: "conv_wink" (group-split window convolution: 0 never, 1 where measured best, 2 wherever
  * feasible), "conv_win" (window-staged convolution, same values), "conv_wstat" (weight-stationary block numbering, 0 / 1),
- * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second; 0 never, default 3).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
+ * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second, bit 2 the first block's data gradient; 0 never, default 7).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
  * key.  Initial values come from the environment (NPP_CONV_WINK=...), defaults are the measured-best forms. */
 int npp_tune(const char* key, int value);
 
@@ -435,6 +435,14 @@ int npp_conv_pair_fwd_ok(int H, int W, int Cin, int Cmid, int Cout);
 int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_keep, int H, int W, int Cin, int Cmid, int Cout,
                       const void* d_pack_a, const float* d_bias_a, const void* d_pack_b, const float* d_bias_b,
                       void* d_y_a, void* d_y_b, void* d_y_pool, float* d_tap_b, void* stream);
+/* The data gradient of the first block in ONE launch: d_dz_b = dL/d(pre-activation of conv b) (flat bf16, Cmid channels) ->
+ * conv b's data gradient -> ReLU gate of conv a (d_y_a: flat fp16 relu(conv a)) -> conv a's data gradient -> d_dimg fp32
+ * (n_run, 3, H, W) times scale[c] -- npp_conv3x3 mode 1 (mask = d_y_a) + mode 2 with the fp32 tap, the gated intermediate gradient
+ * in LDS (contextual_loss/modules/vgg.py:16-21 / lpips/pretrained_networks.py:106 under autograd).  Packs: the data-gradient packs
+ * of npp_conv_pack.  Same arithmetic up to the fp32 summation order of the split-K forms it replaces. */
+int npp_conv_pair_dgrad_ok(int H, int W, int Cmid);
+int npp_conv_pair_dgrad(const void* d_dz_b, int N_total, int n_run, int H, int W, int Cmid, const void* d_pack_b_bwd,
+                        const void* d_y_a, const void* d_pack_a_bwd, float* d_dimg, const float scale[3], void* stream);
 int npp_conv3x3_dgrad_pool(const void* d_x, int N_total, int n_run, int H, int W, int Cin, int Cout,
                            const void* d_pack, const void* d_xpre, const void* d_addend, void* d_dz,
                            const void* d_next_pack, int64_t next_pack_bytes, void* stream);

@@ -510,6 +510,187 @@ __global__ __launch_bounds__(512) void conv_pair8_fwd_kernel(PairArgs a) {
   NPP_STAMP(a, 6);
 }
 
+// ---- the data gradient of the first block in one launch: dL/d(pre-activation of conv b) -> conv b's data gradient -> ReLU gate of
+// conv a -> conv a's data gradient -> dL/dimage (fp32, times the input scale): what HipTrunk._backward runs as npp_conv3x3 mode 1
+// (mask = relu(conv a)) followed by mode 2 with the fp32 tap.  bf16 operands like those launches, same (channel step, tap) order.
+// Eight waves own a 16 x 16 tile of one image: the 20 x 20 x 64-channel gradient window in LDS, both (flipped, transposed) weight
+// streams through two 18-KB LDS stages as ONE sequence of stages, the gated intermediate gradient (18 x 18 x 64) in LDS.
+// Wave roles: first contraction -- input-channel tile w & 1, position tiles {g, g + 4, g + 8} (g = w >> 1) of the eleven; second --
+// position tile w (2 rows x 16 columns), the one 32-row tile that holds the 3 image channels.
+struct PairDgradArgs {
+  const void* dz;           // flat bf16 dL/d(pre-activation of conv b), CM channels, geometry (N, H, W)
+  const void* pack_b;       // data-gradient pack of conv b  [cit (CM / 32)][co_step (CM / 16)][tap][64][8]
+  const void* gate;         // flat fp16 relu(conv a): the ReLU gate of the intermediate gradient
+  const void* pack_a;       // data-gradient pack of conv a  [1][co_step (CM / 16)][tap][64][8]
+  float* dimg;              // fp32 (N, 3, H, W)
+  float scale[4];
+  int32_t N, n_run, H, W, Wp, S, tiles_x, tiles_y;
+  int64_t nposp;
+  uint32_t dz_bytes, pack_a_bytes, pack_b_bytes;
+  NPP_DIAG_FIELD
+};
+
+__device__ __forceinline__ f32x16 pmfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void conv_pair_dgrad_kernel(PairDgradArgs a) {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int CM = 64, TH = 16;
+  constexpr int MW = 18, MH = TH + 2, MN = MH * MW, IW = 20, IH = TH + 4, INN = IH * IW;
+  constexpr int CH = CM / 8, KS = CM / 16, NPA = (MN + 31) / 32;      // 8 chunks, 4 channel steps per contraction, 11 position tiles
+  constexpr int kMid = CH * MN * 16, kIn = CH * INN * 16, kW = 2 * 9 * 1024;
+  extern __shared__ __attribute__((aligned(16))) char plds[];
+  NPP_STAMP(a, 0);
+  NPP_STAMP(a, 1);
+  char* const lmid = plds;
+  char* const lin = plds + kMid;
+  char* const lw = plds + kMid + kIn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = lane & 31, h = lane >> 5;
+  const int ct = wave & 1, g = wave >> 1;
+  const int T = blockIdx.x;
+  const int per_img = a.tiles_x * a.tiles_y;
+  const int n = T / per_img, tr = T - n * per_img, ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const wrsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dz), 0, (int)a.dz_bytes, 0x00020000);
+  const wrsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack_b), 0, (int)a.pack_b_bytes, 0x00020000);
+  const wrsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.pack_a), 0, (int)a.pack_a_bytes, 0x00020000);
+  // weight stream: stage t < KS = conv b's data-gradient step t (two 32-channel tiles), else conv a's step t - KS (one tile)
+  constexpr int NWU = (2 * 576 + 511) / 512;
+  u32x4_t rw[NWU];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+      const int u = tid + 512 * i, cot = u / 576, r = u - cot * 576;
+      if (t < KS) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, u < 2 * 576 ? ((cot * KS + t) * 9) * 1024 + r * 16 : 0, 0, 0);
+      else rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, u < 576 ? ((t - KS) * 9) * 1024 + r * 16 : 0, 0, 0);
+    }
+  };
+  auto sstore = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NWU; ++i)
+      if (tid + 512 * i < (t < KS ? 2 : 1) * 576) *(u32x4_t*)(lw + (t & 1) * kW + (tid + 512 * i) * 16) = rw[i];
+  };
+  {
+    constexpr int NI = (CH * INN + 511) / 512;
+    u32x4_t ri[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = tid + 512 * i;
+      const int chunk = u / INN, q = u - chunk * INN, r = q / IW, c = q - r * IW;
+      const int iy = y0 - 2 + r, ix = x0 - 2 + c;
+      const bool ok = u < CH * INN && iy >= -1 && iy <= a.H && ix >= -1 && ix <= a.W;
+      const int64_t pos = (int64_t)n * a.S + (int64_t)(iy + 1) * a.Wp + (ix + 1);
+      const int off = ok ? (int)(((int64_t)chunk * a.nposp + kConvGuard + pos) * 16) : -1;
+      ri[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, off < 0 ? 0 : off, 0, 0);
+      if (off < 0) ri[i] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    gload(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (tid + 512 * i < CH * INN) *(u32x4_t*)(lin + (tid + 512 * i) * 16) = ri[i];
+    sstore(0);
+    gload(1);
+  }
+  // first contraction: my position tiles, and the ReLU-gate units of their positions (requested now, used in the epilogue)
+  int mj[3], ibase[3];
+  bool insj[3];
+  f16x8 gate[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int p = g + 4 * j;
+    mj[j] = p < NPA ? 32 * p + b : MN;                                // (group 3 has two tiles)
+    const int mc_ = mj[j] < MN ? mj[j] : MN - 1, mr = mc_ / MW, mc = mc_ - mr * MW;
+    ibase[j] = mr * IW + mc;
+    const int iy = y0 - 1 + mr, ix = x0 - 1 + mc;
+    insj[j] = mj[j] < MN && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const int64_t pos = (int64_t)n * a.S + (int64_t)(iy + 1) * a.Wp + (ix + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (insj[j]) gate[j][s] = ((const f16x8*)a.gate)[(int64_t)(4 * ct + 2 * s + h) * a.nposp + kConvGuard + pos];
+  }
+  __syncthreads();
+  NPP_STAMP(a, 2);
+  {
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    for (int ci = 0; ci < KS; ++ci) {
+      const char* bA = lw + (ci & 1) * kW + ((ct * 9) * 64 + lane) * 16;
+      const char* bI = lin + ((2 * ci + h) * INN) * 16;
+      bf16x8 A[2], B[2][3];
+      auto lread = [&](int set, int tap) {
+        A[set] = *(const bf16x8*)(bA + tap * 1024);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B[set][j] = *(const bf16x8*)(bI + (ibase[j] + (tap / 3) * IW + (tap % 3)) * 16);
+      };
+      lread(0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = pmfma(A[tap & 1], B[tap & 1][j], acc[j]);
+      }
+      sstore(ci + 1);
+      gload(ci + 2);                                                // (2 KS >= ci + 3 stages)
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)((insj[j] && (float)gate[j][s][k] > 0.0f) ? acc[j][8 * s + k] : 0.0f);
+        if (mj[j] < MN) *(bf16x8*)(lmid + ((4 * ct + 2 * s + h) * MN + mj[j]) * 16) = o;
+      }
+  }
+  __syncthreads();
+  NPP_STAMP(a, 3);
+  // second contraction: position tile `wave`, the image-channel tile
+  const int bbase = (2 * wave + (b >> 4)) * MW + (b & 15);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int ci = 0; ci < KS; ++ci) {
+    const int t = KS + ci;
+    const char* bA = lw + (t & 1) * kW + lane * 16;
+    const char* bM = lmid + ((2 * ci + h) * MN) * 16;
+    bf16x8 A[2], B[2];
+    auto lread = [&](int set, int tap) {
+      A[set] = *(const bf16x8*)(bA + tap * 1024);
+      B[set] = *(const bf16x8*)(bM + (bbase + (tap / 3) * MW + (tap % 3)) * 16);
+    };
+    lread(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) lread((tap + 1) & 1, tap + 1);
+      acc = pmfma(A[tap & 1], B[tap & 1], acc);
+    }
+    if (ci + 1 < KS) {
+      sstore(t + 1);
+      if (ci + 2 < KS) gload(t + 2);
+    }
+    __syncthreads();
+  }
+  NPP_STAMP(a, 4);
+  {
+    const int row = 2 * wave + (b >> 4), col = b & 15;
+    const int iy = y0 + row, ix = x0 + col;
+    if (h == 0 && iy < a.H && ix < a.W) {                             // rows 0..2 of the accumulator tile = registers 0..2 of lane half 0
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.dimg[(((int64_t)n * 3 + c) * a.H + iy) * a.W + ix] = acc[c] * a.scale[c];
+    }
+  }
+  NPP_STAMP(a, 5);
+  NPP_STAMP_DRAIN();
+  NPP_STAMP(a, 6);
+}
+
 }  // namespace npp
 
 using namespace npp;
@@ -570,4 +751,35 @@ extern "C" int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_
   if (!smem_attr(once8, (const void*)conv_pair8_fwd_kernel<4>, kLds8)) { set_error("npp_conv_pair_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
   hipLaunchKernelGGL((conv_pair8_fwd_kernel<4>), dim3((unsigned)(a.n_run * a.tiles_x * a.tiles_y)), dim3(512), kLds8, (hipStream_t)stream, a);
   return check_launch("npp_conv_pair_fwd");
+}
+
+
+// Data gradient of the first block (H, W: any size; 3 -> Cmid -> Cmid forward channels with Cmid = 64).
+extern "C" int npp_conv_pair_dgrad_ok(int H, int W, int Cmid) { return (H >= 1 && W >= 1 && Cmid == 64) ? 1 : 0; }
+
+extern "C" int npp_conv_pair_dgrad(const void* d_dz_b, int N_total, int n_run, int H, int W, int Cmid, const void* d_pack_b_bwd,
+                                   const void* d_y_a, const void* d_pack_a_bwd, float* d_dimg, const float scale[3], void* stream) {
+  if (!npp_conv_pair_dgrad_ok(H, W, Cmid)) { set_error("npp_conv_pair_dgrad: not a shape of the fused pair (Cmid=%d)", Cmid); return NPP_ERR_ARG; }
+  if (N_total < 1 || n_run < 1 || n_run > N_total || W + 3 > kConvGuard || !d_dz_b || !d_pack_b_bwd || !d_y_a || !d_pack_a_bwd || !d_dimg || !scale) {
+    set_error("npp_conv_pair_dgrad: bad argument (N=%d n_run=%d)", N_total, n_run);
+    return NPP_ERR_ARG;
+  }
+  if (conv_nposp(N_total, H, W) * 16 * 64 > 0x7fffffffLL) { set_error("npp_conv_pair_dgrad: tensor too large for one launch"); return NPP_ERR_ARG; }
+  PairDgradArgs a{};
+  a.dz = d_dz_b; a.pack_b = d_pack_b_bwd; a.gate = d_y_a; a.pack_a = d_pack_a_bwd; a.dimg = d_dimg;
+  for (int i = 0; i < 3; ++i) a.scale[i] = scale[i];
+  a.N = N_total; a.n_run = n_run; a.H = H; a.W = W; a.Wp = W + 2; a.S = (H + 2) * (W + 2);
+  a.nposp = conv_nposp(N_total, H, W);
+  a.dz_bytes = (uint32_t)((int64_t)(Cmid / 8) * a.nposp * 16);
+  a.pack_b_bytes = (uint32_t)((int64_t)(Cmid / 32) * (Cmid / 16) * 9 * 1024);
+  a.pack_a_bytes = (uint32_t)((int64_t)1 * (Cmid / 16) * 9 * 1024);
+  a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+#ifdef NPP_DIAG
+  a.stamps = npp::g_diag_stamps; a.stamps_n = npp::g_diag_n;
+#endif
+  constexpr int kLds = 8 * 324 * 16 + 8 * 400 * 16 + 2 * 2 * 9 * 1024;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)conv_pair_dgrad_kernel, kLds)) { set_error("npp_conv_pair_dgrad: smem attribute"); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL(conv_pair_dgrad_kernel, dim3((unsigned)(n_run * a.tiles_x * a.tiles_y)), dim3(512), kLds, (hipStream_t)stream, a);
+  return check_launch("npp_conv_pair_dgrad");
 }

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import lib
 
 _VGG19 = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256]                       # features[0:18] -> relu3_4
 _VGG16 = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]
@@ -145,7 +146,7 @@ class HipTrunk:
         self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin = True, True, 128
         # conv a -> conv b -> pool of the first blocks as ONE launch (ops.conv_pair_fwd; round 5): the intermediate activation
         # stays in LDS, the layer outputs are stored only for the images that carry a gradient
-        # (bit 0: the first block, 3 -> 64 -> 64; bit 1: the second, 64 -> 128 -> 128)
+        # (bit 0: the first block, 3 -> 64 -> 64; bit 1: the second, 64 -> 128 -> 128; bit 2: the first block's data gradient)
         self.fuse_pairs = int(ops.tune("conv_pair"))
         self._n_keep = None
 
@@ -310,6 +311,11 @@ class HipTrunk:
                             next_pack=self.final_next_pack if self.prefetch_next else None)
                 return dimg
             prev = self.layers[j - 1]
+            if (j == 1 and prev["kind"] == "conv" and (int(self.fuse_pairs) & 4) and 0 not in tap_of and prev["cout"] == L["cout"]
+                    and lib().npp_conv_pair_dgrad_ok(H, W, L["cout"])):
+                # layers 1 and 0 in ONE launch: conv b's data gradient, conv a's ReLU gate, conv a's data gradient -> dL/dimage
+                ops.conv_pair_dgrad(cur, N, n, H, W, L["cout"], L["pb"], self._geom[0][0], prev["pb"], dimg, scale)
+                return dimg
             if prev["kind"] == "conv":
                 if (j - 1) in tap_of:
                     raise NotImplementedError("HipTrunk: gradient tap below a conv layer")

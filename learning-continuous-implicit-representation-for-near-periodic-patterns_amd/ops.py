@@ -588,6 +588,13 @@ def conv_pair_fwd(x, N_total, n_run, n_keep, H, W, cin, cmid, cout, pack_a, bias
                                   _p(y_a), _p(y_b), _p(y_pool), _p(tap_b), _stream()), "npp_conv_pair_fwd")
 
 
+def conv_pair_dgrad(dz_b, N_total, n_run, H, W, cmid, pack_b_bwd, y_a, pack_a_bwd, dimg, scale):
+    """dL/d(pre-activation of conv b) -> dL/dimage through the first block in one launch (conv b dgrad, conv a's ReLU gate, conv a dgrad)."""
+    ts = (C.c_float * 3)(*[float(v) for v in scale])
+    check(lib().npp_conv_pair_dgrad(_p(dz_b), N_total, n_run, H, W, cmid, _p(pack_b_bwd), _p(y_a), _p(pack_a_bwd), _p(dimg), ts, _stream()),
+          "npp_conv_pair_dgrad")
+
+
 def conv3x3_dgrad_pool(x, N_total, n_run, H, W, cin, cout, pack, xpre, addend, dz, next_pack=None):
     """Data gradient of a convolution that reads a pooled tensor + the pool's backward + the pre-pool ReLU gate (+ tap gradient)
     in one launch; H, W: the pooled geometry, xpre / addend / dz: the pre-pool layer's flat tensors."""

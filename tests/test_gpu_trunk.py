@@ -224,7 +224,8 @@ def test_pools_folded_into_their_neighbouring_convolutions_are_bit_identical(dev
 
 
 @pytest.mark.parametrize("name,P,n,ntot,fuse_mask", [("vgg19", 96, 6, 12, 1), ("vgg19", 96, 6, 12, 3), ("vgg16", 96, 2, 4, 3), ("vgg16", 48, 1, 3, 3),
-                                                     ("vgg19", 40, 3, 3, 3), ("vgg19", 24, 0, 2, 3), ("vgg19", 36, 2, 3, 2)])
+                                                     ("vgg19", 40, 3, 3, 3), ("vgg19", 24, 0, 2, 3), ("vgg19", 36, 2, 3, 2), ("vgg19", 96, 6, 12, 4),
+                                                     ("vgg16", 40, 2, 3, 7), ("vgg19", 36, 3, 3, 4)])
 def test_fused_layer_pairs_equal_their_launches(dev, name, P, n, ntot, fuse_mask):
     """npp_conv_pair_fwd (conv a -> ReLU -> conv b -> ReLU -> MaxPool2d(2,2) in one launch, the intermediate activation in LDS,
     layer outputs stored for the n gradient-carrying images only) against the separate launches: every feature tap and the image
