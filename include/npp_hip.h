@@ -69,7 +69,7 @@ int npp_device_count(void);
 /* Launch-time choice between kernel FORMS that compute the same result (the reference has no counterpart: torch / cuDNN pick
  * their algorithms internally).  Keys: "conv_wink" (group-split window convolution: 0 never, 1 where measured best, 2 wherever
  * feasible), "conv_win" (window-staged convolution, same values), "conv_wstat" (weight-stationary block numbering, 0 / 1),
- * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second, bit 2 the first block's data gradient; 0 never, default 7).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
+ * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second, bit 2 the first block's data gradient, bit 3 the loop's patch plumbing + pixel loss inside the first pair; 0 never, default 15).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
  * key.  Initial values come from the environment (NPP_CONV_WINK=...), defaults are the measured-best forms. */
 int npp_tune(const char* key, int value);
 
@@ -435,6 +435,16 @@ int npp_conv_pair_fwd_ok(int H, int W, int Cin, int Cmid, int Cout);
 int npp_conv_pair_fwd(const void* d_x, int N_total, int n_run, int n_keep, int H, int W, int Cin, int Cmid, int Cout,
                       const void* d_pack_a, const float* d_bias_a, const void* d_pack_b, const float* d_bias_b,
                       void* d_y_a, void* d_y_b, void* d_y_pool, float* d_tap_b, void* stream);
+/* npp_trunk_patch_in_loss + npp_conv_pair_fwd in ONE launch (first block; iterations that need no fp32 copy of the batch): the
+ * 2 n_p k patches are composed inside the pair's input staging from the prediction rows and the sampler's crops
+ * (NPP_completion/train.py:200-236; x * scale + shift), the flat trunk input is never written, and the launch's last blocks are the
+ * adaptive pixel loss (`loss` as in npp_trunk_patch_in_loss; NULL: none).  d_zero / n_zero: accumulators cleared on the way.
+ * Outputs as npp_conv_pair_fwd with N_total = n_run = 2 n_p k, H = W = P.  Bit-identical to the two launches. */
+int npp_conv_pair_fwd_patch(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                            const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3], const float shift[3],
+                            float* d_zero, int n_zero, const npp_pixel_loss_args* loss, int n_keep, int Cmid, int Cout,
+                            const void* d_pack_a, const float* d_bias_a, const void* d_pack_b, const float* d_bias_b,
+                            void* d_y_a, void* d_y_b, void* d_y_pool, float* d_tap_b, void* stream);
 /* The data gradient of the first block in ONE launch: d_dz_b = dL/d(pre-activation of conv b) (flat bf16, Cmid channels) ->
  * conv b's data gradient -> ReLU gate of conv a (d_y_a: flat fp16 relu(conv a)) -> conv a's data gradient -> d_dimg fp32
  * (n_run, 3, H, W) times scale[c] -- npp_conv3x3 mode 1 (mask = d_y_a) + mode 2 with the fp32 tap, the gated intermediate gradient

@@ -198,6 +198,8 @@ SYMBOLS = {
                          _i64, _vp]),
     "npp_conv_pair_fwd_ok": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "npp_conv_pair_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "npp_conv_pair_fwd_patch": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "npp_conv_pair_dgrad_ok": (_i32, [_i32, _i32, _i32]),
     "npp_conv_pair_dgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), _vp]),
     "npp_conv3x3_dgrad_pool": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -324,7 +324,7 @@ static int tune_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
 }
-Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 7)};
+Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 15)};
 
 }  // namespace npp
 

@@ -29,7 +29,7 @@ struct Tunables {
   int conv_wink;      // 1: group-split window convolution on the channel-rich trunk layers; 0: never; 2: wherever feasible
   int conv_win;       // 1: window-staged convolution on conv1_1 / conv1_2 / conv2_1 forward; 0: never; 2: wherever feasible
   int conv_wstat;     // 1: weight-stationary block numbering where the pack outweighs the activations; 0: never
-  int conv_pair;      // bit mask of the fused convolution pairs (conv a -> conv b -> pool) the trunks use: 1 = first block, 2 = second, 4 = the first block's data gradient; 0: never
+  int conv_pair;      // bit mask of the fused convolution pairs (conv a -> conv b -> pool) the trunks use: 1 = first block, 2 = second, 4 = the first block's data gradient, 8 = patch plumbing + pixel loss inside the first pair; 0: never
 };
 extern Tunables g_tune;
 bool smem_attr(SmemOnce& once, const void* fn, int bytes);

@@ -835,9 +835,9 @@ __global__ void trunk_image_in_kernel(const float* __restrict__ img, int N, int 
   if (n < N && y >= 1 && y <= H && x >= 1 && x <= W) {
     const int64_t base = ((int64_t)n * 3 * H + (y - 1)) * W + (x - 1);
     const int64_t cs = (int64_t)H * W;
-    o[0] = (_Float16)fmaf(img[base], s0, b0);
-    o[1] = (_Float16)fmaf(img[base + cs], s1, b1);
-    o[2] = (_Float16)fmaf(img[base + 2 * cs], s2, b2);
+    o[0] = trunk_in_f16(img[base], s0, b0);
+    o[1] = trunk_in_f16(img[base + cs], s1, b1);
+    o[2] = trunk_in_f16(img[base + 2 * cs], s2, b2);
   }
   out[kConvGuard + p] = o;
   out[nposp + kConvGuard + p] = z;
@@ -891,9 +891,9 @@ __global__ void trunk_patch_in_kernel(const float* __restrict__ pred, const floa
 #pragma unroll
       for (int c = 0; c < 3; ++c) xy[((int64_t)n * 3 + c) * pp + q] = v[c];
     }
-    o[0] = (_Float16)fmaf(v[0], s0, b0);
-    o[1] = (_Float16)fmaf(v[1], s1, b1);
-    o[2] = (_Float16)fmaf(v[2], s2, b2);
+    o[0] = trunk_in_f16(v[0], s0, b0);
+    o[1] = trunk_in_f16(v[1], s1, b1);
+    o[2] = trunk_in_f16(v[2], s2, b2);
   }
   out[kConvGuard + p] = o;
   out[nposp + kConvGuard + p] = z;
@@ -975,9 +975,9 @@ __global__ void trunk_patch_in_stack_kernel(PatchInStack a) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) xy[((int64_t)n * 3 + c) * pp + q] = v[c];
     }
-    o[0] = (_Float16)fmaf(v[0], a.s0, a.b0);
-    o[1] = (_Float16)fmaf(v[1], a.s1, a.b1);
-    o[2] = (_Float16)fmaf(v[2], a.s2, a.b2);
+    o[0] = trunk_in_f16(v[0], a.s0, a.b0);
+    o[1] = trunk_in_f16(v[1], a.s1, a.b1);
+    o[2] = trunk_in_f16(v[2], a.s2, a.b2);
   }
   a.out[kConvGuard + p] = o;
   a.out[a.nposp + kConvGuard + p] = z;

@@ -41,6 +41,13 @@ struct PairArgs {
   int32_t N, n_run, n_keep, H, W, Wp, S, tiles_x, tiles_y;
   int64_t nposp, pool_nposp;
   uint32_t x_bytes, pack_a_bytes, pack_b_bytes;
+  // SRC form (npp_conv_pair_fwd_patch): the input window is COMPOSED here -- npp_trunk_patch_in's arithmetic (train.py:200-236) on the
+  // prediction rows and the sampler's crops -- instead of read from x, and the launch's last nb_loss blocks are the adaptive pixel loss
+  const float* s_pred; const float* s_fake; const float* s_fmask; const float* s_real; const float* s_rmask;
+  float* s_zero;
+  float s_sc[3], s_sh[3];
+  int32_t s_n_p, s_k, s_comp, s_n_zero, nb_loss, n_tiles;
+  PixelLossArgs pl;
   NPP_DIAG_FIELD
 };
 
@@ -64,11 +71,15 @@ struct PairGeom {
   static_assert(NPB % WPG == 0 && NCB % WC == 0, "tile split");
 };
 
-template <int CAS, int CB, int CC, int TH>
+template <int CAS, int CB, int CC, int TH, bool SRC = false>
 __global__ __launch_bounds__(256, 2) void conv_pair_fwd_kernel(PairArgs a) {
   typedef PairGeom<CAS, CB, CC, TH> G;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char plds[];
+  if (SRC && (int)blockIdx.x >= a.n_tiles) {                          // the iteration's adaptive pixel loss rides in this launch
+    pixel_loss_body(a.pl, (int)blockIdx.x - a.n_tiles, a.nb_loss);
+    return;
+  }
   NPP_STAMP(a, 0);
   NPP_STAMP(a, 1);
   char* const lmid = plds;
@@ -93,6 +104,44 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fwd_kernel(PairArgs a) {
   f16x8 Areg[G::WA_REGS ? G::NCA * CAS * 9 : 1];
   {
     u32x4_t ri[NI], rw[G::WA_REGS ? 1 : NWA];
+    if constexpr (SRC) {
+      // unit u < INN: position q of the window, chunk 0 = [c0 c1 c2 0 ...] (chunk 1 is zeros); the value of trunk_patch_in_kernel
+      static_assert(!SRC || CAS == 1, "a composed input is a 3-channel image");
+      if (blockIdx.x == 0 && tid < a.s_n_zero) a.s_zero[tid] = 0.0f;
+      const int nk = a.s_n_p * a.s_k;
+      const int64_t pp = (int64_t)a.H * a.W;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int u = tid + 256 * i;
+        const int chunk = u / G::INN, q = u - chunk * G::INN, r = q / G::IW, c = q - r * G::IW;
+        const int iy = y0 - 2 + r, ix = x0 - 2 + c;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.0f;
+        if (chunk == 0 && u < G::INN && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          const int64_t qq = (int64_t)iy * a.W + ix;
+          const int pk = n < nk ? n : n - nk;
+          const float rm = a.s_rmask[(int64_t)pk * pp + qq];
+          float v[3];
+          if (n < nk) {                                                                 // prediction half
+            const int pi = pk / a.s_k;
+            const float fm = a.s_comp ? a.s_fmask[(int64_t)pi * pp + qq] : 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              const float pv = a.s_pred[((int64_t)pi * pp + qq) * 3 + cc];
+              const float w = a.s_comp ? a.s_fake[((int64_t)pi * 3 + cc) * pp + qq] * fm + pv * (1.0f - fm) : pv;   // train.py:230-231
+              v[cc] = w * rm;                                                                                       // :232-233
+            }
+          } else {                                                                      // real half, :235-236
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) v[cc] = a.s_real[((int64_t)pk * 3 + cc) * pp + qq] * rm;
+          }
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[cc] = trunk_in_f16(v[cc], a.s_sc[cc], a.s_sh[cc]);
+        }
+        ri[i] = __builtin_bit_cast(u32x4_t, o);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int u = tid + 256 * i;
@@ -103,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_fwd_kernel(PairArgs a) {
       const int off = ok ? (int)(((int64_t)chunk * a.nposp + kConvGuard + pos) * 16) : -1;
       ri[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, off < 0 ? 0 : off, 0, 0);
       if (off < 0) ri[i] = u32x4_t{0u, 0u, 0u, 0u};
+    }
     }
     if constexpr (G::WA_REGS) {
 #pragma unroll
@@ -782,4 +832,58 @@ extern "C" int npp_conv_pair_dgrad(const void* d_dz_b, int N_total, int n_run, i
   if (!smem_attr(once, (const void*)conv_pair_dgrad_kernel, kLds)) { set_error("npp_conv_pair_dgrad: smem attribute"); return NPP_ERR_LAUNCH; }
   hipLaunchKernelGGL(conv_pair_dgrad_kernel, dim3((unsigned)(n_run * a.tiles_x * a.tiles_y)), dim3(512), kLds, (hipStream_t)stream, a);
   return check_launch("npp_conv_pair_dgrad");
+}
+
+
+// npp_trunk_patch_in_loss + npp_conv_pair_fwd in ONE launch (first block only): the 2 n_p k patches of P x P are composed inside the
+// pair's input staging from the prediction rows and the sampler's crops (train.py:200-236, normalised with scale / shift) -- the
+// flat input tensor is never written -- and the launch's last blocks are the adaptive pixel loss.  For iterations that need no fp32
+// copy of the batch (no LPIPS / style branch).  Results: bit-identical to the two launches.
+extern "C" int npp_conv_pair_fwd_patch(const float* d_pred_rows, const float* d_fake, const float* d_fmask, const float* d_real,
+                                       const float* d_rmask, int n_p, int k, int P, int comp, const float scale[3], const float shift[3],
+                                       float* d_zero, int n_zero, const npp_pixel_loss_args* loss, int n_keep, int Cmid, int Cout,
+                                       const void* d_pack_a, const float* d_bias_a, const void* d_pack_b, const float* d_bias_b,
+                                       void* d_y_a, void* d_y_b, void* d_y_pool, float* d_tap_b, void* stream) {
+  const char* who = "npp_conv_pair_fwd_patch";
+  if (n_p < 1 || k < 1 || n_zero < 0 || n_zero > 256 || !(Cmid == 64 && Cout == 64) || P < 2 || (P & 1)) {
+    set_error("%s: bad n_p=%d k=%d n_zero=%d P=%d or not the first block (%d -> %d)", who, n_p, k, n_zero, P, Cmid, Cout);
+    return NPP_ERR_ARG;
+  }
+  const int N = 2 * n_p * k;
+  if (!d_pred_rows || !d_real || !d_rmask || !scale || !shift || (comp && (!d_fake || !d_fmask)) || (n_zero && !d_zero) || !d_pack_a ||
+      !d_bias_a || !d_pack_b || !d_bias_b || !d_y_pool || n_keep < 0 || (n_keep > 0 && (!d_y_a || !d_y_b)) || P + 3 > kConvGuard) {
+    set_error("%s: null pointer / bad size", who);
+    return NPP_ERR_ARG;
+  }
+  if (loss && (loss->N <= 0 || !loss->pred || !loss->gt || !loss->loss || !loss->dpred || loss->quad < 0.0f ||
+               (loss->quad == 0.0f && (!loss->latents || !loss->spline || !loss->dlatent || loss->n_knots < 2)))) {
+    set_error("%s: bad pixel-loss arguments (N=%lld)", who, (long long)loss->N);
+    return NPP_ERR_ARG;
+  }
+  if (conv_nposp(N, P, P) * 16 * 64 > 0x7fffffffLL) { set_error("%s: tensor too large for one launch", who); return NPP_ERR_ARG; }
+  PairArgs a{};
+  a.pack_a = d_pack_a; a.bias_a = d_bias_a; a.pack_b = d_pack_b; a.bias_b = d_bias_b;
+  a.y_a = d_y_a; a.y_b = d_y_b; a.y_pool = d_y_pool; a.tap_b = d_tap_b;
+  a.N = N; a.n_run = N; a.n_keep = n_keep > N ? N : n_keep; a.H = P; a.W = P; a.Wp = P + 2; a.S = (P + 2) * (P + 2);
+  a.nposp = conv_nposp(N, P, P);
+  a.pool_nposp = conv_nposp(N, P / 2, P / 2);
+  a.x = d_pack_a; a.x_bytes = 16;                                    // (unused in the SRC form: a valid descriptor)
+  a.pack_a_bytes = (uint32_t)(2 * 1 * 9 * 1024);
+  a.pack_b_bytes = (uint32_t)(2 * 4 * 9 * 1024);
+  a.s_pred = d_pred_rows; a.s_fake = d_fake; a.s_fmask = d_fmask; a.s_real = d_real; a.s_rmask = d_rmask; a.s_zero = d_zero;
+  for (int i = 0; i < 3; ++i) { a.s_sc[i] = scale[i]; a.s_sh[i] = shift[i]; }
+  a.s_n_p = n_p; a.s_k = k; a.s_comp = comp; a.s_n_zero = n_zero;
+  a.tiles_x = (P + 15) / 16; a.tiles_y = (P + 15) / 16;
+  a.n_tiles = N * a.tiles_x * a.tiles_y;
+  a.nb_loss = loss ? pixel_loss_blocks(loss->N) : 0;
+  if (loss) a.pl = PixelLossArgs{loss->pred, loss->gt, loss->mask, loss->N, loss->latents, loss->spline, loss->n_knots, loss->x_scale,
+                                 loss->weight, loss->loss, loss->dpred, loss->dlatent, loss->scratch, loss->quad};
+#ifdef NPP_DIAG
+  a.stamps = npp::g_diag_stamps; a.stamps_n = npp::g_diag_n;
+#endif
+  typedef PairGeom<1, 64, 64, 16> G;
+  static SmemOnce once;
+  if (!smem_attr(once, (const void*)conv_pair_fwd_kernel<1, 64, 64, 16, true>, G::kLds)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
+  hipLaunchKernelGGL((conv_pair_fwd_kernel<1, 64, 64, 16, true>), dim3((unsigned)(a.n_tiles + a.nb_loss)), dim3(256), G::kLds, (hipStream_t)stream, a);
+  return check_launch(who);
 }

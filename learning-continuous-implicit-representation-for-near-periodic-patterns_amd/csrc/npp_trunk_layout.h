@@ -15,6 +15,17 @@ NPP_HD int64_t conv_npos_round(int N, int H, int W) {
 }
 NPP_HD int64_t conv_nposp(int N, int H, int W) { return conv_npos_round(N, H, W) + 2 * kConvGuard; }
 
+// The trunk input x * scale + shift as fp16: the fma rounded to fp32 FIRST, then to fp16 (what `(x * scale + shift).half()` does).  The
+// register barrier keeps the compiler from fusing the two into v_fma_mixlo_f16 -- one rounding instead of two -- which it did for
+// SOME channels of SOME kernels: the same input then differed in the last fp16 bit between two launches that compose it (round 5).
+#if defined(__HIPCC__)
+__device__ __forceinline__ _Float16 trunk_in_f16(float x, float s, float b) {
+  float t = fmaf(x, s, b);
+  asm volatile("" : "+v"(t));
+  return (_Float16)t;
+}
+#endif
+
 // true channel of element j of chunk c8 in the stored (accumulator) order
 NPP_HD int conv_chan(int c8, int j) { return 32 * (c8 >> 2) + 16 * ((c8 >> 1) & 1) + perm16(c8 & 1, j); }
 

@@ -420,9 +420,16 @@ class CompletionFit:
         # the comparator of tests/test_gpu_parity.py and for A/B timing)
         if not fold:
             net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
-        ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
-                           cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf, which=0,
-                           loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if fold else None)
+        # Iterations whose other consumers need no fp32 copy of the batch ('val' / 'train' without a style term): the patch plumbing
+        # and the pixel loss ride inside the trunk's first launch (ops.conv_pair_fwd_patch) -- no npp_trunk_patch_in launch at all
+        x0_src = None
+        if fold and xy is None and self.use_contextual_loss and cx.hip_trunk.can_compose_input(P, P):
+            x0_src = dict(patch=(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp),
+                          zero=self.patch_loss_buf, loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w))
+        else:
+            ops.trunk_patch_in(pred[n_pix:n], raw["fake"], raw["fmask"], raw["real"], raw["rmask"], n_p, k, P, comp, sc, sh,
+                               cx.hip_trunk.input_buffer(2 * nk, P, P), xy, self.patch_loss_buf, which=0,
+                               loss=net.pixel_loss_args(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w) if fold else None)
         dx_b = None
         # use_patch_weight (train.py:224-250): contextual term sum_i -log(cx_i w_i + 1e-5) (the core's weighted form), LPIPS term
         # sum_i d_i w_i -- on 'same' iterations the weights are all 1 (sampler.py:338), i.e. nk times the mean
@@ -433,7 +440,7 @@ class CompletionFit:
                 dx_b = self.lpips_branch(xy, nk, self.lp_w * (nk if weight is not None else 1), self.patch_loss_buf)
         cx.hip_trunk.final_next_pack = net.wb        # the backward chain that follows streams this pack: requested into L2 early
         if self.use_contextual_loss:
-            dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, weight=weight, x0_ready=True)   # train.py:238-239
+            dx_a = cx.fused((2 * nk, 3, P, P), nk, self.cx_w, self.patch_loss_buf, weight=weight, x0_ready=True, x0_src=x0_src)   # train.py:238-239
         else:                                                                                       # ablation: no contextual term
             dx_a = torch.zeros((2 * nk, 3, P, P), dtype=torch.float32, device=self.device)
         if dx_b is not None:

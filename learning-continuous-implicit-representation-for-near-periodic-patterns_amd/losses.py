@@ -146,7 +146,8 @@ class HipTrunk:
         self.fold_pool_bwd, self.fold_pool_fwd, self.fold_pool_fwd_min_cin = True, True, 128
         # conv a -> conv b -> pool of the first blocks as ONE launch (ops.conv_pair_fwd; round 5): the intermediate activation
         # stays in LDS, the layer outputs are stored only for the images that carry a gradient
-        # (bit 0: the first block, 3 -> 64 -> 64; bit 1: the second, 64 -> 128 -> 128; bit 2: the first block's data gradient)
+        # (bit 0: the first block, 3 -> 64 -> 64; bit 1: the second, 64 -> 128 -> 128; bit 2: the first block's data gradient;
+        #  bit 3: the loop's patch plumbing + pixel loss composed inside the first block's launch)
         self.fuse_pairs = int(ops.tune("conv_pair"))
         self._n_keep = None
 
@@ -171,7 +172,14 @@ class HipTrunk:
         """The flat C=16 input tensor of an (N,3,H,W) batch, for producers that write it directly (ops.trunk_patch_in)."""
         return self._flat("x0", N, 16, H, W)
 
-    def _forward(self, x, scale, shift, x0_ready=False, n_run=None, n_keep=None):
+    def can_compose_input(self, H, W):
+        """Whether _forward(x0_src=...) can compose the patch batch inside the first block's fused launch (ops.conv_pair_fwd_patch)."""
+        Ls = self.layers
+        return bool((int(self.fuse_pairs) & 8) and (int(self.fuse_pairs) & 1) and len(Ls) >= 3 and Ls[0]["kind"] == "conv"
+                    and Ls[1]["kind"] == "conv" and Ls[2]["kind"] == "pool" and Ls[0]["relu_idx"] not in self.taps
+                    and Ls[2]["idx"] not in self.taps and H % 2 == 0 and W % 2 == 0 and (Ls[0]["cout"], Ls[1]["cout"]) == (64, 64))
+
+    def _forward(self, x, scale, shift, x0_ready=False, n_run=None, n_keep=None, x0_src=None):
         """x: the (N,3,H,W) batch, or just its shape when the flat input was already written (x0_ready).  n_run: only the leading
         n_run images are computed (N fixes the buffers' geometry; rows >= n_run of the returned taps are undefined).  n_keep: the
         leading images a _backward() may follow for (None: all): a fused layer pair stores its layer outputs only for those."""
@@ -181,6 +189,8 @@ class HipTrunk:
         self._gen += 1
         self._geom = []
         skip = 0
+        if x0_src is not None and not (x0_ready and nr == N and self.can_compose_input(H, W)):
+            raise ValueError("HipTrunk._forward(x0_src=...): the first block is not run as a fused pair here (can_compose_input)")
         cur = self._flat("x0", N, 16, H, W)
         if not x0_ready:
             ops.trunk_image_in(x, scale, shift, cur)
@@ -200,8 +210,13 @@ class HipTrunk:
                 if Lb["relu_idx"] in self.taps:
                     tap = torch.empty((N, Lb["cout"], H, W), dtype=torch.float32, device=self.device)
                     outs.append(tap)
-                ops.conv_pair_fwd(cur, N, nr, self._n_keep, H, W, c, L["cout"], Lb["cout"], L["pf"], L["b"], Lb["pf"], Lb["b"],
-                                  ya, yb, yp, tap)
+                if x0_src is not None and j == 0:
+                    # the flat input was NOT written: the pair composes the patches itself (and runs the pixel loss in its last blocks)
+                    ops.conv_pair_fwd_patch(*x0_src["patch"], scale, shift, x0_src.get("zero"), x0_src.get("loss"), self._n_keep,
+                                            L["cout"], Lb["cout"], L["pf"], L["b"], Lb["pf"], Lb["b"], ya, yb, yp, tap)
+                else:
+                    ops.conv_pair_fwd(cur, N, nr, self._n_keep, H, W, c, L["cout"], Lb["cout"], L["pf"], L["b"], Lb["pf"], Lb["b"],
+                                      ya, yb, yp, tap)
                 self._geom += [(ya, L["cout"], H, W), (yb, Lb["cout"], H, W), (yp, Lb["cout"], H // 2, W // 2)]
                 c, H, W, cur, pooled, skip = Lb["cout"], H // 2, W // 2, yp, None, 2
                 continue
@@ -389,13 +404,13 @@ class ContextualLoss(nn.Module):
         """(scale, shift) of the trunk's input normalisation (x - mean) / std, contextual.py:56-61."""
         return [1.0 / s for s in self._STD], [-m / s for m, s in zip(self._MEAN, self._STD)]
 
-    def fused(self, xy, n, scale, loss_buf, weight=None, x0_ready=False):
+    def fused(self, xy, n, scale, loss_buf, weight=None, x0_ready=False, x0_src=None):
         """Explicit forward + backward of `scale * self(xy[:n], xy[n:])` without autograd (the loop's path):
         accumulates the loss into loss_buf[0] and returns dL/dxy (only [:n] is defined).  x0_ready: xy is only the
         SHAPE of the batch, whose normalised flat form was already written into hip_trunk.input_buffer()."""
         t = self.hip_trunk
         sc, sh = self.input_norm()
-        f = t._forward(xy, sc, sh, x0_ready, n_keep=n)[0]
+        f = t._forward(xy, sc, sh, x0_ready, n_keep=n, x0_src=x0_src)[0]
         shape = tuple(xy) if x0_ready else tuple(xy.shape)
         if weight is None and _CX_FLAT:
             # the core's last launch writes the trunk's flat gradient tensor itself (no fp32 dL/dfeatures, no npp_trunk_grad_in)

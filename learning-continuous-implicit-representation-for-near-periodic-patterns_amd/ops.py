@@ -588,6 +588,37 @@ def conv_pair_fwd(x, N_total, n_run, n_keep, H, W, cin, cmid, cout, pack_a, bias
                                   _p(y_a), _p(y_b), _p(y_pool), _p(tap_b), _stream()), "npp_conv_pair_fwd")
 
 
+def _pixel_loss_args(loss):
+    """The argument tuple of pixel_loss() (NPPNet.pixel_loss_args) as the C struct npp_pixel_loss_args."""
+    from ._lib import PixelLossArgs
+    pred, gt, mask, latents, spline, n_knots, x_scale, weight, loss_buf, dpred, dlatent = loss[:11]
+    scratch = loss[11] if len(loss) > 11 else None
+    quad = float(loss[12]) if len(loss) > 12 else 0.0
+    _req(pred, torch.float32, "pred")
+    _req(gt, torch.float32, "gt", pred.shape)
+    return PixelLossArgs(pred.data_ptr(), gt.data_ptr(), None if mask is None else mask.data_ptr(), pred.shape[0], latents.data_ptr(),
+                         spline.data_ptr(), int(n_knots), float(x_scale), float(weight), loss_buf.data_ptr(), dpred.data_ptr(),
+                         dlatent.data_ptr(), None if scratch is None else scratch.data_ptr(), quad)
+
+
+def conv_pair_fwd_patch(pred_rows, fake, fmask, real, rmask, n_p, k, P, comp, scale, shift, zero, loss, n_keep, cmid, cout,
+                        pack_a, bias_a, pack_b, bias_b, y_a, y_b, y_pool, tap_b=None):
+    """trunk_patch_in(loss=...) + conv_pair_fwd of the first block in one launch (no flat input tensor, no fp32 batch copy)."""
+    _req(pred_rows, torch.float32, "pred_rows", (n_p * P * P, 3))
+    _req(real, torch.float32, "real", (n_p * k, 3, P, P))
+    _req(rmask, torch.float32, "rmask", (n_p * k, 1, P, P))
+    if comp:
+        _req(fake, torch.float32, "fake", (n_p, 3, P, P))
+        _req(fmask, torch.float32, "fmask", (n_p, 1, P, P))
+    s = (C.c_float * 3)(*[float(v) for v in scale])
+    b = (C.c_float * 3)(*[float(v) for v in shift])
+    la = None if loss is None else _pixel_loss_args(loss)
+    check(lib().npp_conv_pair_fwd_patch(_p(pred_rows), _p(fake), _p(fmask), _p(real), _p(rmask), n_p, k, P, int(bool(comp)), s, b, _p(zero),
+                                        0 if zero is None else zero.numel(), None if la is None else C.byref(la), n_keep, cmid, cout,
+                                        _p(pack_a), _p(bias_a), _p(pack_b), _p(bias_b), _p(y_a), _p(y_b), _p(y_pool), _p(tap_b), _stream()),
+          "npp_conv_pair_fwd_patch")
+
+
 def conv_pair_dgrad(dz_b, N_total, n_run, H, W, cmid, pack_b_bwd, y_a, pack_a_bwd, dimg, scale):
     """dL/d(pre-activation of conv b) -> dL/dimage through the first block in one launch (conv b dgrad, conv a's ReLU gate, conv a dgrad)."""
     ts = (C.c_float * 3)(*[float(v) for v in scale])

@@ -317,7 +317,7 @@ def test_pool_fold_entry_points_validate_on_the_host():
     assert b"npp_conv_pair_fwd_ok" in L.npp_last_error_string()
     assert L.npp_conv_pair_fwd(fake, 4, 5, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, fake, fake, fake, None, None) < 0   # n_run > N_total
     assert L.npp_conv_pair_fwd(fake, 4, 4, 2, 96, 96, 16, 64, 64, fake, fake, fake, fake, None, fake, fake, None, None) < 0   # kept images need y_a
-    assert 0 <= L.npp_tune(b"conv_pair", -1) <= 7 and L.npp_tune(b"no_such_key", 0) < 0
+    assert 0 <= L.npp_tune(b"conv_pair", -1) <= 15 and L.npp_tune(b"no_such_key", 0) < 0
     assert b"unknown key" in L.npp_last_error_string()
     assert L.npp_conv3x3_pool(fake, 2, 2, 47, 48, 64, 64, fake, fake, fake, fake, None, 0, None, None, 0, None) < 0            # odd H
     assert b"even" in L.npp_last_error_string()

@@ -1187,6 +1187,31 @@ def test_two_fits_on_two_streams_equal_their_serial_runs(dev):
             assert torch.equal(a, b), (r, float((a - b).abs().max()))
 
 
+def test_patch_plumbing_inside_the_first_trunk_launch_is_bit_identical(dev):
+    """npp_conv_pair_fwd_patch (the patch batch composed inside the first block's fused launch, the adaptive pixel loss in the launch's
+    last blocks: no npp_trunk_patch_in launch on 'val' / 'train' iterations) against the separate launches: identical parameters, Adam
+    moments and latents after iterations of every patch source."""
+    from npp_amd.fit import CompletionFit
+    H, K = 256, 3
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    outs = []
+    for mask_bits in (15, 7):
+        fit = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=0), device=dev, N_rand=4096,
+                            shifts=shifts, seed=4)
+        fit.contextualLoss.hip_trunk.fuse_pairs = mask_bits
+        assert fit.contextualLoss.hip_trunk.can_compose_input(fit.patch_size, fit.patch_size) == (mask_bits == 15)
+        seen = set()
+        for _ in range(16):
+            if fit.step_full():
+                seen.add(fit.last_source)
+        torch.cuda.synchronize()
+        assert {"val", "train"} <= seen
+        outs.append([t.clone() for t in (fit.net.params, fit.net.m, fit.net.v, fit.net.latents, fit.last_patch_loss)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 def test_minimal_and_ragged_batches(dev):
     """One 64-row tile (the smallest launch) and a batch that is not a multiple of the tile."""
     K, H = 3, 256
