@@ -214,17 +214,24 @@ __device__ __forceinline__ void lpips_layer_body(const LpTap& T, int N, const fl
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
   if (fix) {
-    // Order-independent sums (round 4): every block adds its partials as 2^-40 fixed-point integers (integer addition is
+    // Order-independent sums (round 4): every block adds its partials as fixed-point integers (integer addition is
     // associative, so the arrival order of the up to 256 blocks no longer shows in the result); the last arriver converts the
     // totals back, accumulates them into dlatent / loss and clears the accumulators for the next call.
-    auto tofix = [](float v) { return (unsigned long long)__double2ll_rn((double)v * 1099511627776.0); };
+    // Scales: the loss word keeps 2^-40 (|sum| < 2^23); the latent gradients -- coef x small lin weights: 1e-9 and below per
+    // channel -- are kept at 2^-52 (|sum| < 2^11: they are bounded by a few units), so that the up to 192 per-block roundings stay below
+    // 1e-5 of such a value.  Out-of-range values saturate instead of wrapping.
+    constexpr double kFixLoss = 1099511627776.0, kFixLat = 4503599627370496.0;          // 2^40, 2^52
+    auto tofix = [](float v, double scale) {
+      const double x = fmin(fmax((double)v * scale, -4.0e18), 4.0e18);
+      return (unsigned long long)__double2ll_rn(x);
+    };
     if (grad && !plain)
-      for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i]));
-    if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3])));
+      for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(fix + i, tofix(sdl[i], kFixLat));
+    if (threadIdx.x == 0) atomicAdd(fix + 2 * C, tofix(coef * (tot[0] + tot[1] + tot[2] + tot[3]), kFixLoss));
     if (!block_last_arriver((unsigned*)(fix + 2 * C + 1), nb)) return;
     for (int i = threadIdx.x; i <= 2 * C; i += 256) {
       const long long s = (long long)__hip_atomic_exchange(fix + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float v = (float)((double)s * (1.0 / 1099511627776.0));
+      const float v = (float)((double)s * (i == 2 * C ? 1.0 / kFixLoss : 1.0 / kFixLat));
       if (i == 2 * C) atomicAdd(loss, v);                    // (the contextual branch adds to the same word from its own stream)
       else if (grad && !plain) dlatent[i] += v;
     }

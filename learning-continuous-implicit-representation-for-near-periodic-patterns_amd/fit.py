@@ -149,8 +149,10 @@ class CompletionFit:
         and buffers are fixed -- xy / loss_buf / latents are persistent tensors, scale and n_p k part of the key)."""
         lp = self.percepLoss
         # (every address and scalar a captured launch holds is part of the key: re-homed latents or buffers get a capture of their own)
+        # -- incl. the stream (the heads' accumulators are per stream) and the trunk's choice of kernel forms
         key = (xy.data_ptr(), loss_buf.data_ptr(), int(nk), float(scale), self.lp_robust, lp._lat.data_ptr(), lp._dlat.data_ptr(),
-               lp.lins[0].data_ptr(), lp.grouped_heads)
+               lp.lins[0].data_ptr(), lp.grouped_heads, lp.flat_tap_grads, int(lp.hip_trunk.fuse_pairs), lp.hip_trunk.fold_pool_bwd,
+               lp.hip_trunk.fold_pool_fwd, ops._stream().value)
         ent = self._lp_graphs.get(key) if self.lp_graph else None
         if ent is not None and ent[0] is not None:
             ent[0].replay()
@@ -160,6 +162,8 @@ class CompletionFit:
         if not self.lp_graph:
             return out
         uses = 1 if ent is None else ent[2] + 1
+        if ent is None and len(self._lp_graphs) >= 8:          # each capture keeps a private pool (taps + gradients): bound their number
+            self._lp_graphs.pop(next(iter(self._lp_graphs)))
         self._lp_graphs[key] = (None, None, uses)
         if uses == 2:                                           # two eager passes have warmed every buffer / workspace: capture for the next use
             s = torch.cuda.current_stream(self.device)
