@@ -741,6 +741,11 @@ __global__ __launch_bounds__(512) void conv_pair_dgrad_kernel(PairDgradArgs a) {
   NPP_STAMP(a, 6);
 }
 
+// (Round 5 also built the SECOND block's data gradient + pool1's backward as one launch -- eight waves per 8 x 16 tile, ONE 36-KB weight
+// stage beside a 60-KB gradient window and a 45-KB intermediate tile, two barriers per stage: 108 workgroups at six 48 x 48 images =
+// 42 % of the CUs; measured SLOWER, data gradient 82.3 -> 85.2 us, and no gain at 4 / 8 stacked images: removed,
+// profiles/r05_conv_phase_stamps.txt.)
+
 }  // namespace npp
 
 using namespace npp;
