@@ -479,6 +479,8 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 
   // four straight-line forms of the loop (input array holds z or ready operands; this wave sums db or not), selected once by uniform branches
   const int g0 = (int)wg_begin, g1 = (int)wg_end;
+  // (round 5: a static s_setprio 1 for waves 4-7 here -- MI355X_MICROARCH.md 'Two waves per SIMD' item 4 -- changed nothing:
+  //  100.5-101.9 us without, 100.9-102.8 with, same box; profiles/r05_rejected.txt)
 #if NPP_WGRAD_HYBRID
 #define wgrad_loop wgrad_loop_hybrid
 #endif
