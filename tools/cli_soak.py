@@ -37,3 +37,15 @@ run("search", ["npp_amd.search", "--datadir", src, "--outdir", os.path.join(tmp,
                "--topk_detection", "3", "--random-trunks"])
 run("search alexnet", ["npp_amd.search", "--datadir", src, "--outdir", os.path.join(tmp, "det3"), "--N_iters", "60", "--search_range", "2", "9", "3",
                        "--topk_detection", "3", "--random-trunks", "--gray_only"])
+# the whole shell workflow, three images of one rank fitted together (round 5: python -m npp_amd.run --stack)
+inp = os.path.join(tmp, "data", "completion", "input")
+for i in range(3):
+    im_i, mk_i = syn.synthetic_image(S, seed=10 + i)
+    nio.write_detected_dir(os.path.join(inp, f"img{i}"), im_i[:H, :W], mk_i[:H, :W], np.ones_like(mk_i[:H, :W]), [[0, 0]], [[1, 1]], [[[1, 0], [0, 1]]])
+run("run --stack 8", ["npp_amd.run", "--task", "completion", "--input_path", inp, "--detected_path", os.path.join(tmp, "data", "completion", "detected"),
+                      "--basedir", os.path.join(tmp, "res_run"), "--random-trunks", "--stack", "8",
+                      "--search-args", "--N_iters 60 --search_range 2 9 3 --topk_detection 3",
+                      "--train-args", "--N_iters 121 --i_testset 120 --i_print 60 --netwidth 256"])
+out = [f for _, _, fs in os.walk(os.path.join(tmp, "res_run")) for f in fs]
+print(len(out), "files written by run --stack")
+assert len(out) == 18
