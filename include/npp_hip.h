@@ -510,7 +510,8 @@ int npp_mlp_fwd_stack(const int32_t* d_coords_yx, int64_t Bp, const void* d_embe
  * (>= 2 X: 2 M n_p kmax), so the trunk launches run with n_run = 2 X (forward) / X (data gradient).  d_xy (M, 2 n_p kmax,
  * 3, P, P), nullable: fp32 [x | y] of the images with with_lp set.  d_zero: M patch-loss accumulators, cleared.
  * loss: the pixel-loss arguments of image 0; image m at pred / dpred + m Bp 3, gt + m gt_stride, latents / dlatent +
- * m lat_stride, loss + m loss_stride, scratch + m scratch_stride. */
+ * m lat_stride, loss + m loss_stride, scratch + m scratch_stride; loss->mask (nullable: per-pixel loss weights of the remapping
+ * task, NPP_remapping/train.py:186-190) is (M, loss->N) contiguous. */
 int npp_trunk_patch_in_loss_stack(const float* d_pred, int64_t Bp, int64_t row0, const float* d_crops, int64_t crop_stride,
                                   const float* d_cmasks, int64_t cmask_stride, int M, int n_p, int P, int X, int N_total,
                                   const float scale[3], const float shift[3], void* d_x0, float* d_xy, int64_t xy_stride,

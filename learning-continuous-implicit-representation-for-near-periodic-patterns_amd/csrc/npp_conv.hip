@@ -926,6 +926,7 @@ __global__ void trunk_patch_in_stack_kernel(PatchInStack a) {
     if (!a.iter[m].active) return;
     PixelLossArgs pl = a.pl;
     pl.pred += (int64_t)m * a.Bp * 3; pl.dpred += (int64_t)m * a.Bp * 3; pl.gt += (int64_t)m * a.gt_stride;
+    if (pl.mask) pl.mask += (int64_t)m * pl.N;                       // per-pixel loss weights (remapping): (M, N) contiguous
     pl.latents += m * a.lat_stride; pl.dlatent += m * a.lat_stride; pl.loss_out += m * a.loss_stride;
     if (pl.scratch) pl.scratch += (int64_t)m * a.scratch_stride;
     pixel_loss_body(pl, b, a.nb_loss);

@@ -322,7 +322,7 @@ class CompletionFit:
 
     def materialise_batch(self, d, out=None):
         """Device half: crops, coordinates, ground-truth colours of a draw_batch().  None when no valid real patch exists.
-        out: dict(coords, gt, crops, cmasks) of preallocated buffers (this image's slices of a StackedFit's arrays)."""
+        out: dict(coords, gt, crops, cmasks[, pmask]) of preallocated buffers (this image's slices of a StackedFit's arrays)."""
         # (want_tuple=False: the loop reads the contiguous crops of last_raw; the reference-shaped views / tiled copies of the
         #  8-tuple would cost two more launches per iteration)
         if d["k"] == 0:
@@ -342,7 +342,8 @@ class CompletionFit:
         n = n_pix + n_p * P * P
         bp = ops.pad_rows(n)
         allc, gt, pm = ops.batch_assemble(self.i_train_dev, pix_dev, self.patch_sampler.last_cen_dev, P, bp,
-                                          self.masked_img, self.pixel_mask, out=None if out is None else (out["coords"], out["gt"]))
+                                          self.masked_img, self.pixel_mask,
+                                          out=None if out is None else (out["coords"], out["gt"], out.get("pmask")))
         w_dev = ops.h2d(np.ascontiguousarray(d["weights"], np.float32), self.device) if (self.use_patch_weight and d["weights"] is not None) else None
         return dict(coords=allc, n_pix=n_pix, n=n, bp=bp, gt=gt, source=source, k=k, P=P, n_p=d["n_p"],
                     raw=self.patch_sampler.last_raw, pmask=pm, weight=w_dev)

@@ -381,18 +381,25 @@ def patch_gather(img_hwc, mask_hw, centres_yx, P, want_mask=True, out=None):
 
 def batch_assemble(i_train, pix, cen, P, bp, img_hwc, pmask_hw=None, out=None):
     """-> (coords int32 (bp,2), gt (n_pix,3), pmask (n_pix,) | None): the input rows of one loop iteration, train.py:166-181.
-    out = (coords, gt): written in place (a stacked fit's slices)."""
+    out = (coords, gt[, pmask]): written in place (a stacked fit's slices)."""
     n_pix, n_p = pix.shape[0], 0 if cen is None else cen.shape[0]
     H, W = img_hwc.shape[:2]
     dev = img_hwc.device
+    pm = None
     if out is not None:
-        coords, gt = out
+        coords, gt = out[:2]
+        pm = out[2] if len(out) > 2 else None
         _req(coords, torch.int32, "out coords", (bp, 2))
         _req(gt, torch.float32, "out gt", (n_pix, 3))
+        if pm is not None:
+            _req(pm, torch.float32, "out pmask", (n_pix,))
     else:
         coords = torch.empty((bp, 2), dtype=torch.int32, device=dev)
         gt = torch.empty((n_pix, 3), dtype=torch.float32, device=dev)
-    pm = None if pmask_hw is None else torch.empty((n_pix,), dtype=torch.float32, device=dev)
+    if pmask_hw is None:
+        pm = None
+    elif pm is None:
+        pm = torch.empty((n_pix,), dtype=torch.float32, device=dev)
     check(lib().npp_batch_assemble(_p(i_train), i_train.shape[0], _p(pix), n_pix, _p(cen), n_p, P, bp, _p(img_hwc), _p(pmask_hw), H, W,
                                    _p(coords), _p(gt), _p(pm), _stream()), "npp_batch_assemble")
     return coords, gt, pm

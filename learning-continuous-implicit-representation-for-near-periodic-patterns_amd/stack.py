@@ -40,18 +40,20 @@ class StackedFit:
         self.K, self.width = net0.K, net0.width
         for f in fits:
             # (segmentation is the completion loop with other inputs and weights -- NPP_segmentation/train.py:148-286; the remapping
-            #  task's style loss and pixel-weight mask are not stacked)
-            if f.patch_sampler is None or f.task not in ("completion", "segmentation") or f.style is not None or f.task != f0.task:
-                raise ValueError("StackedFit: completion / segmentation fits (one task per stack) with the patch losses (shifts=...) only")
+            #  task -- NPP_remapping/train.py:158-300 -- adds per-pixel loss weights, which ride in the stacked pixel-loss launch, and a
+            #  style term per image with its own adaptive latents, which runs per image on the side stream like the LPIPS branch)
+            if f.patch_sampler is None or f.task != f0.task or (f.style is None) != (f0.style is None) or (
+                    (f.pixel_mask is None) != (f0.pixel_mask is None)):
+                raise ValueError("StackedFit: fits of ONE task with the patch losses (shifts=...) only")
             if (f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.device, f.net.quad) != (
                     self.K, self.width, f0.N_rand, f0.patch_size, f0.patch_num, f0.topk, f0.device, net0.quad):
                 raise ValueError("StackedFit: the images of a stack share K, width, N_rand, patch size / count, loss_type and the device")
-            if f.use_patch_weight or not f.use_contextual_loss or f.pixel_mask is not None or f._prefetch:
+            if f.use_patch_weight or not f.use_contextual_loss or f._prefetch:
                 raise ValueError("StackedFit: default loss switches, no producer thread (the stack draws for every image itself)")
             if f.net.out_act != 1:
                 raise ValueError("StackedFit: sigmoid output (--normalize_type 1) only")
             # every loss switch / weight the stacked launches take from fits[0] must hold for all images
-            same = ("pix_w", "use_comp", "cx_w", "lp_w", "lp_robust", "use_perceptual_loss")
+            same = ("pix_w", "use_comp", "cx_w", "lp_w", "lp_robust", "use_perceptual_loss", "style_w")
             for a_ in same:
                 if hasattr(f0, a_) and getattr(f, a_, None) != getattr(f0, a_):
                     raise ValueError(f"StackedFit: the images of a stack share the loss switches and weights ({a_} differs)")
@@ -90,6 +92,9 @@ class StackedFit:
                            crops=torch.zeros((M, nc, 3, self.P, self.P), dtype=f32, device=dev),
                            cmasks=torch.zeros((M, nc, 1, self.P, self.P), dtype=f32, device=dev),
                            filled=None, free=None) for _ in range(2)]
+        if f0.pixel_mask is not None:                     # remapping: per-pixel weights of the pixel rows (blurry pixels 0.3)
+            for st in self._sets:
+                st["pmask"] = torch.ones((M, self.n_pix), dtype=f32, device=dev)
         self._wset, self._ahead = 0, None
         self._s_smp = torch.cuda.Stream(dev)
         nxy = 2 * self.n_p * self.kmax
@@ -159,7 +164,10 @@ class StackedFit:
                 d = f.draw_batch()
                 f.last_draw = d
                 f.iteration += 1
-                b = f.materialise_batch(d, out=dict(coords=st["coords"][i], gt=st["gt"][i], crops=st["crops"][i], cmasks=st["cmasks"][i]))
+                o = dict(coords=st["coords"][i], gt=st["gt"][i], crops=st["crops"][i], cmasks=st["cmasks"][i])
+                if "pmask" in st:
+                    o["pmask"] = st["pmask"][i]
+                b = f.materialise_batch(d, out=o)
                 if b is None:
                     f.skipped += 1
                 out.append(b)
@@ -223,7 +231,9 @@ class StackedFit:
             e.active, e.k, e.nk, e.x0 = 1, k, self.n_p * k, x0
             e.comp = int(self.use_comp and src == "val")
             e.same = int(src == "same")
-            e.with_lp = int(src == "same" and f.use_perceptual_loss)
+            # with_lp: the image has a second patch-gradient term (LPIPS on 'same' iterations, the style term on every one) and
+            # its fp32 batch is written for that branch
+            e.with_lp = int((src == "same" and f.use_perceptual_loss) or f.style is not None)
             net.opt_step += 1
             step = net.opt_step
             # npp_adam_step_net_pack's host arithmetic: float arguments widened to double, pow / sqrt in double, result to float
@@ -260,7 +270,7 @@ class StackedFit:
         cx = self.cx
         sc, sh = cx.input_norm()
         net0 = fits[0].net
-        loss = (self.pred, gt, None, self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
+        loss = (self.pred, gt, st.get("pmask"), self.latents, net0.spline, net0.n_knots, net0.x_scale, fits[0].pix_w,
                 self.loss_bufs[:, self.loss_idx:], self.dpred, self.dlatent, self.n_pix, self.pl_scratch, net0.quad)
         t = cx.hip_trunk
         with_lp = [i for i, b in enumerate(batches) if b is not None and it[i].with_lp]
@@ -268,14 +278,20 @@ class StackedFit:
                                       t.input_buffer(self.N_total, self.P, self.P), self.xy if with_lp else None, self.patch_loss,
                                       it_dev, loss, gt.stride(0), self.latents.stride(0), self.loss_bufs.stride(0))
         main = torch.cuda.current_stream(self.device)
-        if with_lp:                                       # the LPIPS branch of the 'same' images beside the contextual chain
+        if with_lp:                                       # the LPIPS / style branches of the images beside the contextual chain
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
                 for i in with_lp:
                     nk = it[i].nk
                     f = fits[i]
-                    dxb = f.lpips_branch(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1])     # (a captured graph from its third use on)
-                    self.dxb[i, :nk].copy_(dxb[:nk])
+                    dxb = None
+                    if it[i].same and f.use_perceptual_loss:
+                        dxb = f.lpips_branch(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1])[:nk]   # (a captured graph from its third use on)
+                    if f.style is not None:               # NPP_remapping/train.py:253-261: own latents per image
+                        f.style.zero_latent_grads()
+                        dxs = f.style.fused(self.xy[i, :2 * nk], nk, f.style_w, self.patch_loss[i:i + 1])[:nk]
+                        dxb = dxs if dxb is None else dxb + dxs
+                    self.dxb[i, :nk].copy_(dxb)
         shape = (self.N_total, 3, self.P, self.P)
         feats = t._forward(shape, sc, sh, True, n_run=2 * X, n_keep=X)[0]
 
@@ -308,6 +324,8 @@ class StackedFit:
             f.last_patch_loss = self.patch_loss[i:i + 1]
             if f.percepLoss.touched:                      # only 'same' iterations give the LPIPS latents a gradient
                 f.percepLoss.adam_step(lr_used[i])
+            if f.style is not None:                       # the style latents are in the same optimiser (helpers.py:153-159)
+                f.style.adam_step(lr_used[i])
         self.iteration += 1
         return n_active
 

@@ -235,10 +235,9 @@ def main(argv=None):
 def stack_key(job):
     """Fits that can share one launch sequence (stack.StackedFit): same network shape, batch shape, loss switches and schedule."""
     a, f = job.args, job.fit
-    if (f.patch_sampler is None or f.task == "remapping" or f.style is not None or f.pixel_mask is not None or f.use_patch_weight
-            or not f.use_contextual_loss or f.net.out_act != 1):
+    if f.patch_sampler is None or f.use_patch_weight or not f.use_contextual_loss or f.net.out_act != 1:
         return None
-    return (a.task, f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.net.quad, f.pix_w, f.use_comp, f.cx_w, f.lp_w,
+    return (a.task, f.style is not None, f.style_w, f.pixel_mask is not None, f.net.K, f.net.width, f.N_rand, f.patch_size, f.patch_num, f.topk, f.net.quad, f.pix_w, f.use_comp, f.cx_w, f.lp_w,
             f.lp_robust, f.use_perceptual_loss, a.N_iters, a.i_testset, a.i_print, a.patch_size_decay, str(f.device))
 
 
@@ -246,8 +245,7 @@ def main_stacked(argvs, max_stack=8):
     """Several images' fits in ONE launch sequence per group (stack.StackedFit): what `python -m npp_amd.run` does when a rank has
     more than one image (run_completion.sh:8-14 loops them serially; the fits are independent -- own weights, Adam state, random
     stream -- so the image becomes a grid dimension: 1.4 x the rows per second of the serial loop at 8 images per GPU).  Images group by
-    stack_key() (detected periods give patch sizes 64 .. 160: loaders.py:133-134); a group of one, and the remapping task (style
-    loss + pixel mask: not stacked), run the plain loop.  -> list of fits (None for skipped / failed outputs), in the order of
+    stack_key() (detected periods give patch sizes 64 .. 160: loaders.py:133-134); a group of one runs the plain loop.  -> list of fits (None for skipped / failed outputs), in the order of
     argvs; main_stacked.last_error holds the first failure."""
     from .stack import StackedFit
     jobs = [_prepare(a, stacked=True) for a in argvs]

@@ -178,6 +178,63 @@ def test_segmentation_fits_stack_too(dev):
         assert rel_l2(b.params.cpu().numpy(), a.params.cpu().numpy()) < 1e-3
 
 
+def _remap_fits(dev, M, H, K, ksplit):
+    """M remapping fits (NPP_remapping/train.py:158-300): a box-blurred band per image (another band each), clear mask = the rest."""
+    from npp_amd.fit import CompletionFit
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    out = []
+    for i in range(M):
+        clean, _ = oracle.synthetic_image(H, noise=0.01, seed=i)
+        k = 9
+        pad = np.pad(clean, ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="edge")
+        box = sum(pad[dy:dy + H, dx:dx + H] for dy in range(k) for dx in range(k)) / (k * k)
+        band = slice(64 + 32 * i, 128 + 32 * i)
+        blurred = clean.copy()
+        blurred[band] = box[band]
+        clear = np.ones((H, H, 1), np.float32)
+        clear[band] = 0
+        out.append(CompletionFit(blurred, np.ones((H, H, 1), np.float32), angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=i),
+                                 device=dev, N_rand=4096, shifts=shifts, seed=20 + i, ksplit=ksplit, task="remapping", clear_mask=clear,
+                                 contextual_weight=0.01, use_perceptual_loss=False))
+    return out
+
+
+def test_remapping_fits_stack_too(dev):
+    """The remapping loop adds two things to the completion loop: per-pixel loss weights (blurry pixels 0.3: they ride in the stacked
+    pixel-loss launch, one mask row per image) and the Gram-matrix style term with ITS OWN adaptive latents per image (run per image
+    beside the contextual chain, its gradient joined in the stacked backward launch).  Two such fits in one launch sequence end where
+    their stand-alone runs end: network parameters, style latents, pixel-weight masks in use."""
+    from npp_amd.stack import StackedFit
+    # (8 iterations: Adam's first steps are sign-like, so the rounding differences of the larger trunk batch -- other tile shapes, other
+    #  summation order -- grow along the trajectory: 2e-4 after one step, 6e-4 .. 7e-4 after 8, 1e-3 after 12; a stack of ONE image starts
+    #  at 3e-7 and reaches 6e-4 after 8 just the same)
+    H, K, M, iters = 256, 1, 2, 8
+    probe = StackedFit(_remap_fits(dev, M, H, K, None))
+    ks = probe.ksplit
+    assert "pmask" in probe._sets[0] and all(f.style is not None for f in probe.fits)
+    del probe
+    alone = _remap_fits(dev, M, H, K, ks)
+    for f in alone:
+        for _ in range(iters):
+            f.step_full()
+    st = StackedFit(_remap_fits(dev, M, H, K, ks), ksplit=ks)
+    lat0 = [[l.clone() for l in f.style.latents] for f in st.fits]
+    for _ in range(iters):
+        assert st.step_full() == M
+    torch.cuda.synchronize()
+    for s_ in st._sets:                                                    # blurry pixel rows were drawn and weighted
+        pm = s_["pmask"].cpu().numpy()
+        assert ((pm == 0.0) | (pm == 1.0)).all() and (pm == 0.0).any() and (pm == 1.0).any()
+    for i in range(M):
+        a, b = alone[i], st.fits[i]
+        assert a.net.opt_step == b.net.opt_step == iters and a.style.lat_step == b.style.lat_step == iters
+        assert rel_l2(b.net.params.cpu().numpy(), a.net.params.cpu().numpy()) < 1e-3
+        for la, lb, l0 in zip(a.style.latents, b.style.latents, lat0[i]):
+            assert (lb - l0).abs().max() > 0                               # trained ...
+            assert rel_l2(lb.cpu().numpy(), la.cpu().numpy()) < 1e-3       # ... to the stand-alone fit's values
+        assert abs(float(a.last_patch_loss) - float(b.last_patch_loss)) <= 5e-3 * abs(float(a.last_patch_loss)) + 1e-6
+
+
 def test_directory_driver_fits_several_images_in_one_launch_sequence(dev, tmp_path):
     """npp_amd.train.main_stacked (what `python -m npp_amd.run --stack M` calls): three detected/ directories -- two of one patch size,
     one of another -- fitted as one stack of two and one plain loop, test sets written per image, and the stacked images end where

@@ -49,3 +49,14 @@ run("run --stack 8", ["npp_amd.run", "--task", "completion", "--input_path", inp
 out = [f for _, _, fs in os.walk(os.path.join(tmp, "res_run")) for f in fs]
 print(len(out), "files written by run --stack")
 assert len(out) == 18
+# the remapping task through the stacked driver (style term + per-pixel loss weights per image): two images of one patch size
+det = os.path.join(tmp, "data", "completion", "detected")
+dirs = sorted(os.path.join(det, n) for n in os.listdir(det))[:2]
+code = ("import sys; sys.path.insert(0, %r); from npp_amd import train; "
+        "fits = train.main_stacked([['--task', 'remapping', '--datadir', d, '--basedir', %r, '--p_topk', '3', '--N_iters', '81', '--i_testset', '80', "
+        "'--i_print', '40', '--random-trunks'] for d in %r]); "
+        "assert train.main_stacked.last_error is None and all(f is not None and f.style is not None for f in fits); print('stacked remapping ok')"
+        % (os.getcwd(), os.path.join(tmp, "res_remap"), dirs))
+r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+print("remapping, stacked", "rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-3:], r.stderr[-1500:] if r.returncode else "", flush=True)
+assert r.returncode == 0 and "[stack] 2 images per launch sequence" in r.stdout
