@@ -533,6 +533,33 @@ class LPIPS(nn.Module):
         self.touched = self.touched or bool(use_robust)        # (the plain head gives the latents no gradient: Adam skips them)
         return t._backward(dfs, n, sc, tuple(xy.shape), zero_rest=False)
 
+    def fused_groups(self, xy, XL, groups, scale, normalize=True, use_robust=True):
+        """fused() for several independent fits in ONE pass of the (frozen, shared) trunk -- the 'same' images of a stacked iteration
+        (stack.StackedFit): xy (N, 3, H, W) holds the prediction halves of all groups in [0, XL) and the real halves in [XL, 2 XL)
+        (N fixes the buffers' geometry); groups = [(o, n, lp, loss_buf)]: samples [o, o + n) of both halves belong to the LPIPS object
+        lp -- its latents, its latent gradients, its own batch mean (scale / n) accumulated into loss_buf[0].  The heads run one launch
+        per group, each writing its samples' rows of the shared flat tap-gradient tensors.  Returns dL/dxy ([:XL] defined)."""
+        if not (self.grouped_heads and self.flat_tap_grads and self.flat_top_tap):
+            raise RuntimeError("LPIPS.fused_groups: the grouped heads with flat tap gradients only")
+        a = 2.0 if normalize else 1.0
+        sc = [a / s for s in self._SCALE]
+        sh = [((-1.0 if normalize else 0.0) - b) / s for b, s in zip(self._SHIFT, self._SCALE)]
+        t = self.hip_trunk
+        N = xy.shape[0]
+        feats = t._forward(xy, sc, sh, n_run=2 * XL, n_keep=XL)
+        ytop = t._geom[-1][0]
+        flats = [t._flat("tapadd", N, f.shape[1], f.shape[2], f.shape[3]) for f in feats]
+
+        def from_image(buf, o, H, W):                           # the flat tensor as image o's launch sees it (csrc/npp_trunk_layout.h:
+            return buf[o * (H + 2) * (W + 2) * 16:]             # image n starts n (H + 2)(W + 2) 16-byte units into every channel row)
+        for o, n, lp, loss_buf in groups:
+            dfl = [(from_image(fl, o, f.shape[2], f.shape[3]), N,
+                    from_image(ytop, o, f.shape[2], f.shape[3]) if kk == len(feats) - 1 else None) for kk, (f, fl) in enumerate(zip(feats, flats))]
+            ops.lpips_layers([f[o:o + n] for f in feats], [f[XL + o:XL + o + n] for f in feats], lp.lins, lp.latents if use_robust else None,
+                             lp.spline, lp.n_knots, lp.x_scale, scale, loss_buf, [None] * len(feats), lp.dlatents, dflats=dfl)
+            lp.touched = lp.touched or bool(use_robust)
+        return t._backward(flats, XL, sc, tuple(xy.shape), zero_rest=False)
+
     @torch.no_grad()
     def plain(self, in0, in1, normalize=False):
         """LPIPS.forward(in0, in1, use_robust=False) (lpips.py:92-133), forward only: the candidate score of

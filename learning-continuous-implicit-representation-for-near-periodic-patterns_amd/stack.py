@@ -122,6 +122,7 @@ class StackedFit:
         self.cx = f0.contextualLoss
         self.cx_w, self.lp_w, self.use_comp = f0.cx_w, f0.lp_w, f0.use_comp
         self._s_lp = torch.cuda.Stream(dev)
+        self.batch_lpips, self._lp_in = True, None        # (False: every 'same' image's LPIPS branch on its own -- the tests' comparator)
         self.iteration = 0
         self.last_sources = None
         self._clean = False
@@ -281,7 +282,16 @@ class StackedFit:
         if with_lp:                                       # the LPIPS / style branches of the images beside the contextual chain
             self._s_lp.wait_stream(main)
             with torch.cuda.stream(self._s_lp):
+                # 'same' images without a style term: ONE pass of the (shared, frozen) VGG16 trunk for all of them when there are
+                # several (batch_lpips; the heads run per image on its own latents) -- a lone one replays its captured graph
+                together = [i for i in with_lp if it[i].same and fits[i].use_perceptual_loss and fits[i].style is None]
+                if self.batch_lpips and len(together) >= 2:
+                    self._lpips_together(together)
+                else:
+                    together = []
                 for i in with_lp:
+                    if i in together:
+                        continue
                     nk = it[i].nk
                     f = fits[i]
                     dxb = None
@@ -328,6 +338,24 @@ class StackedFit:
                 f.style.adam_step(lr_used[i])
         self.iteration += 1
         return n_active
+
+    def _lpips_together(self, idx):
+        """The LPIPS branch (train.py:241-250) of the 'same' images idx in one trunk pass: their fp32 batches [x | y] (n_p samples each
+        on 'same' draws: k = 1, sampler.py:338) are gathered into [x of all | y of all], LPIPS.fused_groups runs VGG16 forward, one
+        heads launch per image (its latents, its loss accumulator), one data-gradient pass; the gradients go back to the images' rows
+        of dxb.  Per image the arithmetic is lpips_branch()'s; the trunk launches see 2 n_p len(idx) patches instead of 2 n_p."""
+        n_p, M, P = self.n_p, self.M, self.P
+        nxy = self.xy.shape[1]
+        XL = n_p * len(idx)
+        rows = np.concatenate([np.concatenate([i * nxy + h * n_p + np.arange(n_p) for i in idx]) for h in (0, 1)]).astype(np.int64)
+        rows_dev = ops.h2d(rows, self.device)
+        if self._lp_in is None:                               # fixed geometry (every image a 'same' one): one set of trunk buffers
+            self._lp_in = torch.zeros((2 * M * n_p, 3, P, P), dtype=torch.float32, device=self.device)
+        torch.index_select(self.xy.view(M * nxy, 3, P, P), 0, rows_dev, out=self._lp_in[:2 * XL])
+        groups = [(j * n_p, n_p, self.fits[i].percepLoss, self.patch_loss[i:i + 1]) for j, i in enumerate(idx)]
+        f0 = self.fits[0]
+        dx = f0.percepLoss.fused_groups(self._lp_in, XL, groups, self.lp_w, normalize=True, use_robust=f0.lp_robust)
+        self.dxb.view(M * nxy, 3, P, P).index_copy_(0, rows_dev[:XL], dx[:XL])
 
     def close(self):
         for f in self.fits:

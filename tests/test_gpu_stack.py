@@ -79,6 +79,42 @@ def test_stacked_fit_equals_the_stand_alone_fits(dev, M, K):
         assert abs(alone[i].psnr("known") - st.fits[i].psnr("known")) < 0.05
 
 
+def test_lpips_branch_of_several_same_images_in_one_trunk_pass(dev):
+    """Iterations on which several images of a stack draw 'same' run ONE VGG16 pass for all of them (LPIPS.fused_groups: heads per
+    image on its own latents) instead of one branch per image: same parameters and LPIPS latents as the per-image branches
+    (batch_lpips = False) to the tolerance of another trunk batch size, and as the stand-alone fits."""
+    from npp_amd.stack import StackedFit
+    H, K, M, iters = 256, 1, 4, 24
+    probe = StackedFit(_fits(dev, M, H, K, None))
+    ks = probe.ksplit
+    del probe
+    runs = {}
+    for together in (True, False):
+        st = StackedFit(_fits(dev, M, H, K, ks), ksplit=ks)
+        st.batch_lpips = together
+        shared = 0
+        for _ in range(iters):
+            st.step_full()
+            shared += sum(1 for s_ in st.last_sources if s_ == "same") >= 2
+        torch.cuda.synchronize()
+        assert shared >= 2, "no iteration with two 'same' images: the shared pass was not exercised"
+        assert (st._lp_in is not None) == together
+        runs[together] = st
+    alone = _fits(dev, M, H, K, ks)
+    for f in alone:
+        for _ in range(iters):
+            f.step_full()
+    torch.cuda.synchronize()
+    for i in range(M):
+        a, b, c = runs[True].fits[i], runs[False].fits[i], alone[i]
+        assert a.percepLoss.lat_step == b.percepLoss.lat_step == c.percepLoss.lat_step > 0
+        for other in (b, c):
+            assert rel_l2(a.net.params.cpu().numpy(), other.net.params.cpu().numpy()) < 1e-3
+            for ta, tb in zip(a.percepLoss.latents, other.percepLoss.latents):
+                np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), atol=2e-4)
+            assert abs(float(a.last_patch_loss) - float(other.last_patch_loss)) <= 5e-3 * abs(float(other.last_patch_loss)) + 1e-6
+
+
 def test_stacked_mlp_half_is_bit_exact(dev):
     """With the patch-loss weights at zero the patch rows' gradient is an exact zero and what is left -- fused forward, adaptive
     pixel loss, backward chain, grouped weight gradient, Adam + re-pack -- is the same arithmetic in the same order: the stacked

@@ -1,6 +1,6 @@
 """Round 5: the stacked loop (npp_amd.stack.StackedFit, M images per launch sequence) as a profiling target: pre-drawn batch sets,
 device-only iterations -- run it under `rocprofv3 --kernel-trace --stats` (tools/r5_stack_prof.sh) for per-kernel durations, or
-with --pmc for FETCH_SIZE / WRITE_SIZE / SQ counters.  usage: r5_stack_prof.py [M] [iterations]"""
+with --pmc for FETCH_SIZE / WRITE_SIZE / SQ counters.  usage: r5_stack_prof.py [M] [iterations] [batch_lpips 0/1]"""
 import os
 import sys
 import time
@@ -23,8 +23,10 @@ fits = []
 for i in range(M):
     img, mask = syn.synthetic_image(H, seed=i)
     fits.append(CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=i), device=dev, N_rand=8192,
-                              shifts=shifts, seed=i, rng_mode="fast"))
+                              shifts=shifts, seed=i, rng_mode="fast", use_perceptual_loss=os.environ.get("R5_NO_LPIPS", "0") != "1"))   # R5_NO_LPIPS=1: the floor without the branch
 st = StackedFit(fits)
+if len(sys.argv) > 3:
+    st.batch_lpips = bool(int(sys.argv[3]))       # 0: one LPIPS branch per 'same' image (the comparator)
 for _ in range(10):
     st.step_full()
 torch.cuda.synchronize()
@@ -34,5 +36,5 @@ for _ in range(ITERS):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / ITERS
 rows = fits[0].N_rand + fits[0].patch_num * fits[0].patch_size ** 2
-print(f"stacked M = {M}: {dt * 1e3:.4f} ms per stacked iteration (incl. sampling), {M * rows / dt / 1e6:.2f} M rows/s, ksplit {st.ksplit}")
+print(f"stacked M = {M}: {dt * 1e3:.4f} ms per stacked iteration (incl. sampling), {M * rows / dt / 1e6:.2f} M rows/s, ksplit {st.ksplit}, LPIPS of several 'same' images in one pass: {st.batch_lpips}")
 st.close()
