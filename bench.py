@@ -872,6 +872,28 @@ def main():
               st.close()
               del st, fs
               torch.cuda.empty_cache()
+              if M_ == 8:
+                  # what `python -m npp_amd.run --stack 8` runs by default: every image on the reference's own random stream (host
+                  # draws of the 8 images in parallel threads, device half one iteration ahead on the sampler stream)
+                  fs = []
+                  for i_ in range(M_):
+                      im_, mk_ = syn.synthetic_image(H, seed=2000 + i_)
+                      fs.append(CompletionFit(im_, mk_, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=2000 + i_), device=dev,
+                                              N_rand=8192, seed=2000 + i_, shifts=shifts, rng_mode="reference"))
+                  st = StackedFit(fs)
+                  for _ in range(5):
+                      st.step_full()
+                  torch.cuda.synchronize()
+                  t6 = time.perf_counter()
+                  for _ in range(100):
+                      st.step_full()
+                  torch.cuda.synchronize()
+                  t_ref = (time.perf_counter() - t6) / 100
+                  stacked["stacked_M8"]["e2e_reference_rng_ms_per_stacked_iteration"] = t_ref * 1e3
+                  stacked["stacked_M8"]["e2e_reference_rng_rows_per_s"] = M_ * n_rows / t_ref
+                  st.close()
+                  del st, fs
+                  torch.cuda.empty_cache()
           except Exception as ex_:                        # (e.g. M = 8 at 1024^2: 96 patches of 160^2 exceed one trunk launch)
             stacked[f"stacked_M{M_}"] = {"error": str(ex_)[:200]}
 
@@ -905,6 +927,7 @@ def main():
                        "render_pixels_per_s": render_px_s, "iters_to_28dB": iters_to_target, "psnr_known_after_300_iters_dB": final_psnr,
                        "stacked_M8_rows_per_s_per_gpu": _dig(stacked, "stacked_M8", "rows_per_s"),
                        "stacked_M8_x_single": _dig(stacked, "stacked_M8", "x_single"),
+                       "stacked_M8_rows_per_s_incl_sampling_reference_rng": _dig(stacked, "stacked_M8", "e2e_reference_rng_rows_per_s"),
                        "stacked_M4_rows_per_s_per_gpu": _dig(stacked, "stacked_M4", "rows_per_s"),
                        "c4_embedder_1024sq_fp32_frac_of_hbm_peak": _dig(c4, "fp32", "frac_of_hbm_peak"),
                        "c4_render_1024sq_fp32_pixels_per_s": _dig(c4, "render_1024sq_fp32_fused", "pixels_per_s"),
