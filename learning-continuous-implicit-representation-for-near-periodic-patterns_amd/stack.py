@@ -153,9 +153,16 @@ class StackedFit:
             return b
         return self._draw()
 
-    def _draw(self):
+    def _host_draws(self):
+        """The M host draws of one iteration, started now: -> futures (thread pool) or the finished draws."""
+        if self._pool is not None:
+            return [self._pool.submit(f.draw_batch) for f in self.fits]
+        return [f.draw_batch() for f in self.fits]
+
+    def _draw(self, draws=None):
         """-> list of M batches (None for an image whose sampler found no valid real patch this iteration), materialised on the
-        sampler stream into the buffer set that is not in use; the list carries that set (step_from waits for it)."""
+        sampler stream into the buffer set that is not in use; the list carries that set (step_from waits for it).  draws: the
+        host halves if they were started earlier (_host_draws)."""
         w = self._wset
         self._wset ^= 1
         st = self._sets[w]
@@ -169,10 +176,9 @@ class StackedFit:
         # the host halves first, one thread per image: the images' random streams are independent and the native stream (the
         # reference's MT19937 sequence, csrc/npp_host_rng.hip) draws outside the GIL -- one after the other, 8 reference-stream draws
         # (0.4 ms each) took longer than the stacked iteration they feed (4.7 ms per iteration against 3.5 ms of device time)
-        if self._pool is not None:
-            draws = list(self._pool.map(lambda f_: f_.draw_batch(), self.fits))
-        else:
-            draws = [f.draw_batch() for f in self.fits]
+        if draws is None:
+            draws = self._host_draws()
+        draws = [d.result() if hasattr(d, "result") else d for d in draws]
         with torch.cuda.stream(self._s_smp):
             for i, (f, d) in enumerate(zip(self.fits, draws)):
                 f.last_draw = d
@@ -214,9 +220,16 @@ class StackedFit:
         iteration's sampling (host draws + device half) is issued right behind this one's launches: it never reads network state, so
         the random streams and the results are those of the serial order; it runs on a side stream under this iteration's kernels."""
         b = self.sample()
-        n = self.step_from(b)
-        # (no look-ahead across a patch-size decay: the next draw belongs to another batch shape)
-        self._ahead = None if any(f.decay_due() for f in self.fits) else self._draw()
+        # the NEXT iteration's host draws run on the pool's threads while this thread enqueues the launches below (no look-ahead
+        # across a patch-size decay: the next draw belongs to another batch shape)
+        nxt = None if any(f.decay_due() for f in self.fits) else self._host_draws()
+        try:
+            n = self.step_from(b)
+        except BaseException:
+            if nxt is not None:                           # the streams have advanced: keep the draws (the serial order holds)
+                self._ahead = self._draw(nxt)
+            raise
+        self._ahead = None if nxt is None else self._draw(nxt)
         return n
 
     # ---- device half ---------------------------------------------------------------------------------------------------------

@@ -258,7 +258,7 @@ def main_stacked(argvs, max_stack=8):
     for key, group in groups.items():
         for c0 in range(0, len(group), max_stack):
             chunk = group[c0:c0 + max_stack]
-            failed = None
+            failed, st = None, None
             try:
                 if len(chunk) == 1 or key[0] == "single":
                     for job in chunk:
@@ -283,6 +283,8 @@ def main_stacked(argvs, max_stack=8):
                 print(f"[stack] group {[j.name for j in chunk]} FAILED ({type(e).__name__}: {e})")
                 first_error = first_error or e
             finally:
+                if st is not None:
+                    st.close()                                                              # its draw threads; the fits' own close() follows
                 for job in chunk:
                     try:
                         _finish(job, failed)
