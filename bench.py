@@ -288,11 +288,17 @@ def main():
     for i in range(max(args.warmup, len(pool))):               # every pool entry at least once (allocations, first-call setup)
         step(i)
     barrier()
+    # (no cyclic garbage collection inside the timed steps: a generation-2 pass over a process that holds torch + the pool is a
+    #  multi-millisecond host stall, visible in a 20-step region of ~12 ms)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
