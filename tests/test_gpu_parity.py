@@ -317,23 +317,26 @@ def test_fit_with_the_plain_lpips_head(dev):
     assert bool(torch.isfinite(a.net.params).all())
 
 
-def test_lpips_branch_as_a_captured_graph_equals_its_launches(dev):
+@pytest.mark.parametrize("decay", [None, 20])
+def test_lpips_branch_as_a_captured_graph_equals_its_launches(dev, decay):
     """CompletionFit.lpips_branch: from its third use on a set of buffers the LPIPS branch of a 'same' iteration (46 launches) is replayed
     as one captured HIP graph -- the same launches with the same arguments: parameters, LPIPS latents and the patch loss must come out
-    bit for bit as from the launch-by-launch form."""
+    bit for bit as from the launch-by-launch form.  decay = 20: across two patch-size decays (train.py:137-141: 64 -> 32 -> 16 pixels,
+    2 -> 4 -> 8 patches): every batch shape gets buffers and a capture of its own."""
     from npp_amd.fit import CompletionFit
     H, K = 256, 1
     img, mask = oracle.synthetic_image(H, seed=4)
     angles, periods, shifts = oracle.synthetic_periodicity(H, K)
 
     def make(graph):
+        kw = {} if decay is None else {"patch_size_decay": decay}
         f = CompletionFit(img, mask, angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=3), device=dev, N_rand=2048, shifts=shifts,
-                          seed=9, perceptual_weight=1e-2)
+                          seed=9, perceptual_weight=1e-2, **kw)
         f.lp_graph = graph
         return f
     a, b = make(True), make(False)
     same, losses = 0, []
-    for it in range(60):
+    for it in range(60 if decay is None else 90):
         ba = None
         while ba is None:
             ba = a.sample_batch()
@@ -347,6 +350,8 @@ def test_lpips_branch_as_a_captured_graph_equals_its_launches(dev):
     replays = [e for e in a._lp_graphs.values() if e[0] is not None]
     print(f"{same} 'same' iterations, {len(replays)} captured graph(s)")
     assert same >= 5 and len(replays) >= 1 and not b._lp_graphs
+    if decay is not None:
+        assert a.patch_size == b.patch_size == 16 and a.patch_num == 8 and len(replays) >= 2
     # (the reported loss WORD is the sum of the two branches' terms in arrival order -- two streams add to it -- so it may differ in
     # its last bit between any two runs; what is trained on, the gradients, is order-independent)
     assert all(abs(x - y) <= 2e-7 * abs(y) for x, y in losses), losses
