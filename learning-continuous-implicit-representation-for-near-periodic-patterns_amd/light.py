@@ -529,27 +529,29 @@ def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
     """The reference's construction order and torch default nn.Linear init (models/networks.py:199-214) after
     torch.manual_seed(seed) -- search.py:92 reseeds with 0 before every candidate, so all candidates start from the same
     weights.  Draws the unused modules too, to keep the generator in step."""
-    g = torch.random.get_rng_state()
-    torch.manual_seed(seed)
-    # create_npp_net builds the position embedder FIRST (helpers.py:84): its Gaussian Fourier frequencies (embedder.py:26) come out of
-    # the same global generator, so the network's init starts n_freq normal draws into the stream (pinned by g10c_light_init.npz, the
-    # reference's own construction; until round 3 this function skipped them: a statistically equivalent but DIFFERENT start)
-    torch.normal(mean=0.0, std=1.0, size=((in_pos // 2 - 1) // 2, 1))
-    mods = {}
-    for i in range(D):
-        mods[f"periodic_linears.{i}"] = torch.nn.Linear(in_per if i == 0 else W, W)      # skips=[4] is never reached for D = 4
-    mods["scale_linears.0"] = torch.nn.Linear(0 + W, W)
-    mods["pos_linears.0"] = torch.nn.Linear(in_pos + W, W // 2)
-    mods["feature_linear1"] = torch.nn.Linear(W, W)
-    mods["feature_linear2"] = torch.nn.Linear(W, W)
-    mods["alpha_linear"] = torch.nn.Linear(W, 1)
-    mods["rgb_linear"] = torch.nn.Linear(W // 2, 3)
-    torch.random.set_rng_state(g)
+    with ops.RNG_LOCK:
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        # create_npp_net builds the position embedder FIRST (helpers.py:84): its Gaussian Fourier frequencies (embedder.py:26) come out of
+        # the same global generator, so the network's init starts n_freq normal draws into the stream (pinned by g10c_light_init.npz, the
+        # reference's own construction; until round 3 this function skipped them: a statistically equivalent but DIFFERENT start)
+        torch.normal(mean=0.0, std=1.0, size=((in_pos // 2 - 1) // 2, 1))
+        mods = {}
+        for i in range(D):
+            mods[f"periodic_linears.{i}"] = torch.nn.Linear(in_per if i == 0 else W, W)      # skips=[4] is never reached for D = 4
+        mods["scale_linears.0"] = torch.nn.Linear(0 + W, W)
+        mods["pos_linears.0"] = torch.nn.Linear(in_pos + W, W // 2)
+        mods["feature_linear1"] = torch.nn.Linear(W, W)
+        mods["feature_linear2"] = torch.nn.Linear(W, W)
+        mods["alpha_linear"] = torch.nn.Linear(W, 1)
+        mods["rgb_linear"] = torch.nn.Linear(W // 2, 3)
+        torch.random.set_rng_state(g)
     return {f"{k}.{p}": getattr(m, p).detach().numpy().copy() for k, m in mods.items() for p in ("weight", "bias")}
 
 
 _SCORE_TRUNKS = {}       # (device, id(weights...)) -> (LPIPS, ContextualLoss, weights): ProposalRanker's score trunks, shared between images
 _SCORE_LOCK = __import__("threading").Lock()      # the cache and the shared trunks' workspaces belong to one ranker at a time
+_SCORE_USE = __import__("threading").Lock()       # held while a ranker scores (score() ends in a host read-back: its launches are complete)
 
 
 class ProposalRanker:
@@ -586,10 +588,11 @@ class ProposalRanker:
         self.precision, self.loss_type = precision, loss_type
         ops.quad_coef(loss_type)
         if freqs is None:                                      # embedder.py:26 after torch.manual_seed(0) (search.py:92)
-            g = torch.random.get_rng_state()
-            torch.manual_seed(0)
-            freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()
-            torch.random.set_rng_state(g)
+            with ops.RNG_LOCK:
+                g = torch.random.get_rng_state()
+                torch.manual_seed(0)
+                freqs = (torch.normal(mean=0.0, std=1.0, size=(10, 1)) * 10).reshape(-1).numpy()
+                torch.random.set_rng_state(g)
         self.freqs = np.asarray(freqs, np.float32)
         self._draws, self._gt_all = None, None
         # the two score trunks are the same for every image of a run (same weights): built and packed once per (device, weights)
@@ -606,8 +609,9 @@ class ProposalRanker:
             else:
                 # every image scores a crop of its own size: the trunks' per-shape activation buffers of the previous image are
                 # dropped (they were never evicted: a directory run grew by a VGG16 + VGG19 activation set per image)
-                for t in (hit[0].hip_trunk, hit[1].hip_trunk):
-                    t._buf.clear()
+                with _SCORE_USE:
+                    for t in (hit[0].hip_trunk, hit[1].hip_trunk):
+                        t._buf.clear()
         self.percep, self.cx = hit[0], hit[1]
 
     def _pixel_draws(self):
@@ -843,7 +847,8 @@ class ProposalRanker:
             raise ValueError("carry_latents chains the candidates through one set of adaptive-loss latents: it cannot be sharded over ranks")
         mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
         nets = self.fit_candidates([(candidates[ci][0], candidates[ci][1]) for ci in mine])
-        details = [self.score(net) for net in nets]
+        with _SCORE_USE:                                       # the score trunks (and their activation buffers) are shared between rankers
+            details = [self.score(net) for net in nets]
         if multi:
             t = torch.tensor(details, dtype=torch.float32, device=self.device).reshape(-1, 3)
             details = [tuple(r) for r in gather_unit_scalars(t, len(candidates)).cpu().tolist()]

@@ -75,10 +75,11 @@ def _trunk_keys(state_dict, features):
 class _Trunk(nn.Module):
     def __init__(self, cfg, taps, state_dict=None, seed=1234):
         super().__init__()
-        g = torch.random.get_rng_state()
-        torch.manual_seed(seed)
-        self.features = _make_features(cfg)
-        torch.random.set_rng_state(g)
+        with ops.RNG_LOCK:
+            g = torch.random.get_rng_state()
+            torch.manual_seed(seed)
+            self.features = _make_features(cfg)
+            torch.random.set_rng_state(g)
         if state_dict is not None:
             self.features.load_state_dict(_trunk_keys(state_dict, self.features), strict=True)
         else:

@@ -77,12 +77,18 @@ class _PinnedRing:
     of pinned blocks allocated once, each guarded by the event recorded after its last copy."""
 
     def __init__(self, slots=8):
+        import threading
         self.slots, self.rings = slots, {}
+        self.lock = threading.Lock()          # (several host threads transfer: the images of a rank searched side by side, run.py)
 
     def __call__(self, a, device):
         a = np.ascontiguousarray(a)
         if device.type != "cuda":
             return torch.from_numpy(a).to(device)
+        with self.lock:
+            return self._copy(a, device)
+
+    def _copy(self, a, device):
         cap = 1 << max(12, int(a.nbytes - 1).bit_length())
         ring = self.rings.get((device, cap))
         if ring is None:
@@ -102,6 +108,10 @@ class _PinnedRing:
 
 
 _pinned_ring = _PinnedRing()
+# Sections that save / reseed / restore the PROCESS-WIDE torch generator (the reference's torch.manual_seed(0) before every candidate,
+# search.py:92; fixed-seed stand-in trunks) hold this lock: images searched on several host threads would otherwise read each other's
+# generator state.
+RNG_LOCK = __import__("threading").RLock()
 
 
 def h2d(a, device):

@@ -29,7 +29,10 @@ def parse(argv=None):
     ap.add_argument("--stack", type=int, default=8,
                     help="images of a rank fitted TOGETHER, one launch sequence for all of them (npp_amd.stack: the image is a grid "
                          "dimension; ~1.4 x the rows per second at 8).  1: one image after the other like the shell loop.  Images are "
-                         "searched first, then grouped by batch shape (patch size) and fitted; the remapping task is not stacked")
+                         "searched first, then grouped by batch shape (patch size) and fitted")
+    ap.add_argument("--search-threads", type=int, default=None,
+                    help="images of a rank SEARCHED side by side, each on its own host thread and stream (a candidate fit is a chain of "
+                         "small launches that leaves the chip idle; default: --stack, at most 8).  1: one after the other")
     return ap.parse_args(argv)
 
 
@@ -55,7 +58,7 @@ def main(argv=None, search_main=None, train_main=None):
         from .search import main as search_main
     common = ["--device", device] + (["--random-trunks"] if args.random_trunks else [])
     failed, t_all = [], time.time()
-    if args.stack > 1 and len(mine) > 1 and args.task != "remapping" and train_main is None:
+    if args.stack > 1 and len(mine) > 1 and train_main is None:
         return _main_stacked(args, mine, det, common, rank, world, search_main)
     if train_main is None:
         from .train import main as train_main
@@ -84,27 +87,64 @@ def main(argv=None, search_main=None, train_main=None):
     return 1 if failed else 0
 
 
+def search_all(srcs, det, flags, search_main=None, threads=8):
+    """The periodicity search of every directory in srcs (-> det/<name>), `threads` images side by side: each on its own host thread
+    and HIP stream.  The search of one image is nine candidate fits in a row (the reference chains them through one set of
+    adaptive-loss latents, models/helpers.py:8,144), each 300 iterations of four small launches -- a dependent chain that leaves the
+    chip idle; images are independent, so their chains interleave on the device.  Per image the results are those of the serial
+    loop (own random streams; the process-wide torch generator and the shared score trunks are taken under locks: ops.RNG_LOCK,
+    light._SCORE_USE).  -> list of None / the exception per directory ("file exists" is not an error: the directory is reused)."""
+    if search_main is None:
+        from .search import main as search_main
+
+    def one(src):
+        try:
+            try:
+                search_main(["--datadir", src, "--outdir", det] + list(flags))
+            except SystemExit as e:                                # "Searching: file exists, exit!!": the detected directory is reused
+                if "exists" not in str(e):
+                    raise
+                print(e)
+            return None
+        except (Exception, SystemExit) as e:                       # noqa: B014
+            traceback.print_exc()
+            return e
+    if threads <= 1 or len(srcs) <= 1:
+        return [one(s_) for s_ in srcs]
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    def on_stream(src):
+        if not torch.cuda.is_available():
+            return one(src)
+        dev = next((f for i, f in enumerate(flags) if i and flags[i - 1] == "--device"), None)
+        dev = torch.device(dev) if dev else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(dev)
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            r = one(src)
+        st.synchronize()
+        return r
+    with ThreadPoolExecutor(min(threads, len(srcs)), thread_name_prefix="npp-search") as pool:
+        return list(pool.map(on_stream, srcs))
+
+
 def _main_stacked(args, mine, det, common, rank, world, search_main):
     """Search every image of this rank, then fit them together (train.main_stacked: groups of up to --stack images of one batch
     shape per launch sequence)."""
     from .train import main_stacked
     failed, t_all, argvs, names = [], time.time(), [], []
-    for src in mine:
+    n_thr = args.search_threads if args.search_threads else min(8, max(1, args.stack))
+    errors = search_all(mine, det, common + shlex.split(args.search_args), search_main, threads=n_thr)
+    for src, err in zip(mine, errors):
         name = os.path.basename(os.path.normpath(src))
-        try:
-            try:
-                search_main(["--datadir", src, "--outdir", det] + common + shlex.split(args.search_args))
-            except SystemExit as e:                                # "Searching: file exists, exit!!": the detected directory is reused
-                if "exists" not in str(e):
-                    raise
-                print(e)
-            argvs.append(["--datadir", os.path.join(det, name), "--basedir", args.basedir, "--p_topk", str(args.p_topk)] + common
-                         + (["--task", args.task] if args.task != "completion" else []) + shlex.split(args.train_args))
-            names.append(name)
-        except (Exception, SystemExit) as e:                       # noqa: B014
-            traceback.print_exc()
-            print(f"[run rank {rank}/{world}] {args.task}/{name}: search FAILED ({type(e).__name__}: {e})", flush=True)
+        if err is not None:
+            print(f"[run rank {rank}/{world}] {args.task}/{name}: search FAILED ({type(err).__name__}: {err})", flush=True)
             failed.append(name)
+            continue
+        argvs.append(["--datadir", os.path.join(det, name), "--basedir", args.basedir, "--p_topk", str(args.p_topk)] + common
+                     + (["--task", args.task] if args.task != "completion" else []) + shlex.split(args.train_args))
+        names.append(name)
     t1 = time.time()
     existed = [os.path.exists(os.path.join(args.basedir, f"{args.task}_top{args.p_topk}", n)) for n in names]
     fits = main_stacked(argvs, max_stack=args.stack) if argvs else []

@@ -184,6 +184,39 @@ def test_search_driver_writes_a_loadable_detected_dir(tmp_path):
         search.main(["--datadir", str(src), "--outdir", str(out), "--random-trunks"])
 
 
+@pytest.mark.gpu
+def test_images_searched_side_by_side_rank_like_the_serial_loop(tmp_path):
+    """run.search_all: the images of a rank searched on several host threads, each on its own stream (what `python -m npp_amd.run
+    --stack M` does before it fits them together).  Per image the result is that of the serial loop: the same candidates in the
+    same order; the distances agree to the run-to-run spread of the candidate fits themselves (their weight gradients add split-K
+    partials atomically: two serial runs differ by ~3e-4)."""
+    import json
+    import warnings
+    from npp_amd import io as nio, run
+    H, M = 256, 4
+    srcs = []
+    for i in range(M):
+        img, mask = oracle.synthetic_image(H, noise=0.01, seed=i)
+        srcs.append(nio.write_detected_dir(str(tmp_path / "input" / f"img{i}"), img, mask, np.ones_like(mask), [[0, 0]], [[1, 1]], [[[1, 0], [0, 1]]]))
+    flags = ["--device", "cuda:0", "--N_iters", "40", "--N_rand", "1024", "--search_range", "2", "12", "5", "--topk_detection", "3", "--random-trunks"]
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for thr in (1, 4):
+            det = str(tmp_path / f"det{thr}")
+            assert run.search_all(srcs, det, flags, threads=thr) == [None] * M
+            out[thr] = [json.loads(open(os.path.join(det, f"img{i}", "config.odgt")).readline()) for i in range(M)]
+        # a second call finds the directories in place ("file exists"): not an error, nothing is searched again
+        assert run.search_all(srcs, str(tmp_path / "det4"), flags, threads=4) == [None] * M
+    for a, b in zip(out[1], out[4]):
+        assert a["selected_angles"] == b["selected_angles"] and a["selected_periods"] == b["selected_periods"]
+        assert a["carry_adaptive_latents"] is True and b["carry_adaptive_latents"] is True      # the reference's chained candidates, on every thread
+        np.testing.assert_allclose(b["distances"], a["distances"], rtol=5e-3)
+    # a failing image is reported in its slot, the others are searched
+    errs = run.search_all([srcs[0], str(tmp_path / "input" / "missing")], str(tmp_path / "det_err"), flags, threads=2)
+    assert errs[0] is None and errs[1] is not None
+
+
 def test_search_flags_keep_the_reference_store_false_semantics():
     """options/arg_config.py:122-126: --gray_only / --edge_searching are store_false switches, so the reference's default run is
     gray features + Canny edges and passing --gray_only turns the AlexNet features ON."""
