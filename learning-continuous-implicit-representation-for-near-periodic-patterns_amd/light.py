@@ -549,9 +549,6 @@ def default_light_init(W=256, D=4, in_pos=42, in_per=20, seed=0):
     return {f"{k}.{p}": getattr(m, p).detach().numpy().copy() for k, m in mods.items() for p in ("weight", "bias")}
 
 
-_SCORE_TRUNKS = {}       # (device, id(weights...)) -> (LPIPS, ContextualLoss, weights): ProposalRanker's score trunks, shared between images
-_SCORE_LOCK = __import__("threading").Lock()      # the cache and the shared trunks' workspaces belong to one ranker at a time
-_SCORE_USE = __import__("threading").Lock()       # held while a ranker scores (score() ends in a host read-back: its launches are complete)
 
 
 class ProposalRanker:
@@ -595,24 +592,11 @@ class ProposalRanker:
                 torch.random.set_rng_state(g)
         self.freqs = np.asarray(freqs, np.float32)
         self._draws, self._gt_all = None, None
-        # the two score trunks are the same for every image of a run (same weights): built and packed once per (device, weights)
-        key = (str(self.device), id(vgg16_state_dict), id(vgg19_state_dict), id(lpips_lin_weights))
-        with _SCORE_LOCK:
-            hit = _SCORE_TRUNKS.get(key)
-            if hit is None or any(a is not b for a, b in zip(hit[2], (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))):
-                hit = (LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device),
-                       ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device),
-                       (vgg16_state_dict, vgg19_state_dict, lpips_lin_weights))       # (keeps the keyed objects alive: ids stay unique)
-                if len(_SCORE_TRUNKS) >= 4:
-                    _SCORE_TRUNKS.clear()
-                _SCORE_TRUNKS[key] = hit
-            else:
-                # every image scores a crop of its own size: the trunks' per-shape activation buffers of the previous image are
-                # dropped (they were never evicted: a directory run grew by a VGG16 + VGG19 activation set per image)
-                with _SCORE_USE:
-                    for t in (hit[0].hip_trunk, hit[1].hip_trunk):
-                        t._buf.clear()
-        self.percep, self.cx = hit[0], hit[1]
+        # the two score trunks: objects of this ranker (their activation buffers go with it; images searched side by side on several
+        # host threads, run.search_all, score at the same time), device weights and MFMA packs shared by every trunk of the process
+        # (losses.HipTrunk._packs) -- until round 5 the rankers shared the objects, which only paid while packing was per object
+        self.percep = LPIPS(net="vgg", lin_weights=lpips_lin_weights, vgg_state_dict=vgg16_state_dict, device=self.device)
+        self.cx = ContextualLoss(use_vgg=True, vgg_state_dict=vgg19_state_dict, device=self.device)
 
     def _pixel_draws(self):
         """(N_iters, n_rand) int64 on the device: the pixel rows of every iteration.  search.py:92-93 reseeds NumPy with 0 before EVERY
@@ -847,8 +831,7 @@ class ProposalRanker:
             raise ValueError("carry_latents chains the candidates through one set of adaptive-loss latents: it cannot be sharded over ranks")
         mine = shard_units(len(candidates), dist.get_rank(), dist.get_world_size()) if multi else range(len(candidates))
         nets = self.fit_candidates([(candidates[ci][0], candidates[ci][1]) for ci in mine])
-        with _SCORE_USE:                                       # the score trunks (and their activation buffers) are shared between rankers
-            details = [self.score(net) for net in nets]
+        details = [self.score(net) for net in nets]
         if multi:
             t = torch.tensor(details, dtype=torch.float32, device=self.device).reshape(-1, 3)
             details = [tuple(r) for r in gather_unit_scalars(t, len(candidates)).cpu().tolist()]

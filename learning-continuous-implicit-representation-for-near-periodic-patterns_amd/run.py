@@ -92,8 +92,8 @@ def search_all(srcs, det, flags, search_main=None, threads=8):
     and HIP stream.  The search of one image is nine candidate fits in a row (the reference chains them through one set of
     adaptive-loss latents, models/helpers.py:8,144), each 300 iterations of four small launches -- a dependent chain that leaves the
     chip idle; images are independent, so their chains interleave on the device.  Per image the results are those of the serial
-    loop (own random streams; the process-wide torch generator and the shared score trunks are taken under locks: ops.RNG_LOCK,
-    light._SCORE_USE).  -> list of None / the exception per directory ("file exists" is not an error: the directory is reused)."""
+    loop (own random streams, own score trunks over the process's shared packed weights; the process-wide torch generator is borrowed
+    under ops.RNG_LOCK).  -> list of None / the exception per directory ("file exists" is not an error: the directory is reused)."""
     if search_main is None:
         from .search import main as search_main
 

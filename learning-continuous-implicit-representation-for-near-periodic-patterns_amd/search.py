@@ -138,8 +138,7 @@ def main(argv=None):
     rg = lambda f: nio._imread_gray(os.path.join(args.datadir, f))                  # noqa: E731
     masked_img, img, mask, valid = rd("masked_img.png"), rd("gt_img.png"), rg("unknown_mask.png"), rg("valid_mask.png")
 
-    def load(path):
-        return None if path is None else torch.load(path, map_location="cpu")
+    load = weights.load_state_dict                                                  # (one read per file and process)
     lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
     conv1 = None
     if not args.gray_only:

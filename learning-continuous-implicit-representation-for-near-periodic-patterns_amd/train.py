@@ -97,9 +97,6 @@ def default_linear_init(layout, n_params, seed):
     return sd
 
 
-_STATE_DICTS = {}      # (path, mtime) -> state dict
-
-
 class _Job:
     """One image's fit between _prepare() and _finish(): arguments, loaded data, the CompletionFit, its output directory and the
     PNG writer thread."""
@@ -160,15 +157,7 @@ def _prepare(argv=None, stacked=False):
     layout, n_params = param_layout(K, args.netwidth)
     params = default_linear_init(layout, n_params, args.seed)
 
-    def load(path):                                          # (one read per file and process: the images of a directory run share the dicts,
-        if path is None:                                     #  and with them the packed trunk weights -- losses.HipTrunk keys them by identity)
-            return None
-        key = (os.path.abspath(path), os.path.getmtime(path))
-        if key not in _STATE_DICTS:
-            if len(_STATE_DICTS) >= 8:
-                _STATE_DICTS.clear()
-            _STATE_DICTS[key] = torch.load(path, map_location="cpu")
-        return _STATE_DICTS[key]
+    load = weights.load_state_dict                           # (one read per file and process: shared dicts -> shared packed trunk weights)
     lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
     try:
         fit = CompletionFit(d["img"], d["mask"], d["angles"], d["periods"], freqs, params, device=args.device, N_rand=args.N_rand,

@@ -31,6 +31,23 @@ def find_checkpoint(name, explicit=None):
     return None
 
 
+_STATE_DICTS = {}      # (path, mtime) -> state dict
+
+
+def load_state_dict(path):
+    """torch.load(path) once per file and process: the images of a directory run share the dicts, and with them the packed trunk
+    weights (losses.HipTrunk keys its device weights / MFMA packs by the state dict's identity).  None -> None."""
+    if path is None:
+        return None
+    import torch
+    key = (os.path.abspath(path), os.path.getmtime(path))
+    if key not in _STATE_DICTS:
+        if len(_STATE_DICTS) >= 8:
+            _STATE_DICTS.clear()
+        _STATE_DICTS[key] = torch.load(path, map_location="cpu")
+    return _STATE_DICTS[key]
+
+
 def lpips_lin(net="vgg", path=None):
     """The five lin-layer weight vectors [(C,)] of LPIPS v0.1: from a user's lpips weights file (`lin{i}.model.1.weight`), else the
     packaged copy."""
