@@ -19,6 +19,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 H, K = 512, 3
 angles, periods, shifts = syn.synthetic_periodicity(H, K)
+if os.environ.get("R5_PERIOD_SCALE"):                 # e.g. 1.33: patch size 128 instead of 96 (loaders.py:133-134)
+    sc_ = float(os.environ["R5_PERIOD_SCALE"])
+    periods = [[float(v) * sc_ for v in p_] for p_ in periods]
+    shifts = [[[float(v) * sc_ for v in s_] for s_ in sh_] for sh_ in shifts]
 fits = []
 for i in range(M):
     img, mask = syn.synthetic_image(H, seed=i)
