@@ -214,7 +214,7 @@ def test_segmentation_fits_stack_too(dev):
         assert rel_l2(b.params.cpu().numpy(), a.params.cpu().numpy()) < 1e-3
 
 
-def _remap_fits(dev, M, H, K, ksplit):
+def _remap_fits(dev, M, H, K, ksplit, lpips=False):
     """M remapping fits (NPP_remapping/train.py:158-300): a box-blurred band per image (another band each), clear mask = the rest."""
     from npp_amd.fit import CompletionFit
     angles, periods, shifts = oracle.synthetic_periodicity(H, K)
@@ -231,29 +231,31 @@ def _remap_fits(dev, M, H, K, ksplit):
         clear[band] = 0
         out.append(CompletionFit(blurred, np.ones((H, H, 1), np.float32), angles, periods, oracle.SEED0_FREQS, oracle.init_params(K, seed=i),
                                  device=dev, N_rand=4096, shifts=shifts, seed=20 + i, ksplit=ksplit, task="remapping", clear_mask=clear,
-                                 contextual_weight=0.01, use_perceptual_loss=False))
+                                 contextual_weight=0.01, use_perceptual_loss=lpips))
     return out
 
 
-def test_remapping_fits_stack_too(dev):
+@pytest.mark.parametrize("lpips", [False, True])
+def test_remapping_fits_stack_too(dev, lpips):
     """The remapping loop adds two things to the completion loop: per-pixel loss weights (blurry pixels 0.3: they ride in the stacked
     pixel-loss launch, one mask row per image) and the Gram-matrix style term with ITS OWN adaptive latents per image (run per image
     beside the contextual chain, its gradient joined in the stacked backward launch).  Two such fits in one launch sequence end where
-    their stand-alone runs end: network parameters, style latents, pixel-weight masks in use."""
+    their stand-alone runs end: network parameters, style latents, pixel-weight masks in use.  lpips: with the LPIPS term switched on
+    as well (not the task's default): 'same' iterations then add BOTH gradients of an image in its side-stream branch."""
     from npp_amd.stack import StackedFit
     # (8 iterations: Adam's first steps are sign-like, so the rounding differences of the larger trunk batch -- other tile shapes, other
     #  summation order -- grow along the trajectory: 2e-4 after one step, 6e-4 .. 7e-4 after 8, 1e-3 after 12; a stack of ONE image starts
     #  at 3e-7 and reaches 6e-4 after 8 just the same)
     H, K, M, iters = 256, 1, 2, 8
-    probe = StackedFit(_remap_fits(dev, M, H, K, None))
+    probe = StackedFit(_remap_fits(dev, M, H, K, None, lpips))
     ks = probe.ksplit
     assert "pmask" in probe._sets[0] and all(f.style is not None for f in probe.fits)
     del probe
-    alone = _remap_fits(dev, M, H, K, ks)
+    alone = _remap_fits(dev, M, H, K, ks, lpips)
     for f in alone:
         for _ in range(iters):
             f.step_full()
-    st = StackedFit(_remap_fits(dev, M, H, K, ks), ksplit=ks)
+    st = StackedFit(_remap_fits(dev, M, H, K, ks, lpips), ksplit=ks)
     lat0 = [[l.clone() for l in f.style.latents] for f in st.fits]
     for _ in range(iters):
         assert st.step_full() == M
@@ -269,6 +271,10 @@ def test_remapping_fits_stack_too(dev):
             assert (lb - l0).abs().max() > 0                               # trained ...
             assert rel_l2(lb.cpu().numpy(), la.cpu().numpy()) < 1e-3       # ... to the stand-alone fit's values
         assert abs(float(a.last_patch_loss) - float(b.last_patch_loss)) <= 5e-3 * abs(float(a.last_patch_loss)) + 1e-6
+        if lpips:
+            assert a.percepLoss.lat_step == b.percepLoss.lat_step
+            for ta, tb in zip(a.percepLoss.latents, b.percepLoss.latents):
+                np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), atol=2e-4)
 
 
 def test_directory_driver_fits_several_images_in_one_launch_sequence(dev, tmp_path):

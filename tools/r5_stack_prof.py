@@ -28,7 +28,7 @@ for i in range(M):
     img, mask = syn.synthetic_image(H, seed=i)
     fits.append(CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=i), device=dev, N_rand=8192,
                               shifts=shifts, seed=i, rng_mode=os.environ.get("R5_RNG", "fast"), use_perceptual_loss=os.environ.get("R5_NO_LPIPS", "0") != "1"))   # R5_NO_LPIPS=1: the floor without the branch
-st = StackedFit(fits)
+st = StackedFit(fits, ksplit=int(os.environ["R5_KSPLIT"]) if os.environ.get("R5_KSPLIT") else None)
 if len(sys.argv) > 3:
     st.batch_lpips = bool(int(sys.argv[3]))       # 0: one LPIPS branch per 'same' image (the comparator)
 for _ in range(10):
