@@ -302,3 +302,24 @@ def test_directory_driver_fits_several_images_in_one_launch_sequence(dev, tmp_pa
     # a second call finds every output directory in place and fits nothing (train.py:42-44)
     again = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "stacked")] + flags for d in dirs])
     assert again == [None, None, None]
+
+
+def test_directory_driver_stacks_remapping_images(dev, tmp_path):
+    """train.main_stacked on two remapping runs (--task remapping: blur detection -> clear mask -> per-pixel loss weights, style term):
+    one stack of two, test sets written per image, style latents trained."""
+    from npp_amd import io as nio, train
+    H, K = 256, 3
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    dirs = []
+    for i in range(2):
+        img, mask = oracle.synthetic_image(H, seed=30 + i)
+        dirs.append(nio.write_detected_dir(str(tmp_path / "detected" / f"img{i}"), img, np.ones_like(mask), np.ones_like(mask), a, p, s))
+    flags = ["--task", "remapping", "--p_topk", "3", "--N_iters", "21", "--i_testset", "20", "--i_print", "20", "--rng_mode", "fast", "--random-trunks",
+             "--netwidth", "256", "--N_rand", "4096"]
+    fits = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "out")] + flags for d in dirs])
+    assert train.main_stacked.last_error is None and all(f is not None and f.style is not None and f.pixel_mask is not None for f in fits)
+    assert all(f.style.lat_step == 20 and f.net.opt_step == 20 for f in fits)
+    for i in range(2):
+        out = tmp_path / "out" / "remapping_top3" / f"img{i}" / "testset_000020"
+        assert out.is_dir() and len(list(out.iterdir())) >= 4
+
