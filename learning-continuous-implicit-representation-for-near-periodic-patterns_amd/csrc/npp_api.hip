@@ -324,7 +324,8 @@ static int tune_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
 }
-Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 15)};
+Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 15),
+                   tune_env("NPP_STASH8", 1)};
 
 }  // namespace npp
 
@@ -336,7 +337,8 @@ int npp_version(void) { return 100; }
 
 int npp_tune(const char* key, int value) {
   struct { const char* k; int* v; } tab[] = {{"conv_wink", &g_tune.conv_wink}, {"conv_win", &g_tune.conv_win},
-                                             {"conv_wstat", &g_tune.conv_wstat}, {"conv_pair", &g_tune.conv_pair}};
+                                             {"conv_wstat", &g_tune.conv_wstat}, {"conv_pair", &g_tune.conv_pair},
+                                             {"stash8", &g_tune.stash8}};
   if (key)
     for (auto& t : tab)
       if (!strcmp(key, t.k)) {
@@ -525,7 +527,9 @@ int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[
   if (rc) return rc;
   if (Bp <= 0 || Bp % kRowTile || ksplit < 1 || !sizes) { set_error("npp_train_workspace: bad Bp/ksplit"); return NPP_ERR_ARG; }
   sizes[0] = 0;   // (the separate snake-derivative stash is gone: npp_mlp_bwd reads z from actF)
-  sizes[1] = (int64_t)act_total_ks(K) * (Bp / kRowTile) * 2048;
+  // actF: the 16-bit W-format arrays, then (stash8 mode) the 8-bit W8 arrays of the same k-step table; dzF: sized for the 16-bit
+  // form, which also holds the 8-bit form + its per-tile scale words -- one allocation serves both settings of npp_tune("stash8")
+  sizes[1] = (int64_t)act_total_ks(K) * (Bp / kRowTile) * (2048 + 1024);
   sizes[2] = (int64_t)kDzTotalKs * (Bp / kRowTile) * 2048;
   sizes[3] = (int64_t)ksplit * slab_stride_of(make_desc(K).total_params) * 4;      // ksplit slabs, see slab_stride_of
   return NPP_OK;

@@ -30,6 +30,7 @@ struct Tunables {
   int conv_win;       // 1: window-staged convolution on conv1_1 / conv1_2 / conv2_1 forward; 0: never; 2: wherever feasible
   int conv_wstat;     // 1: weight-stationary block numbering where the pack outweighs the activations; 0: never
   int conv_pair;      // bit mask of the fused convolution pairs (conv a -> conv b -> pool) the trunks use: 1 = first block, 2 = second, 4 = the first block's data gradient, 8 = patch plumbing + pixel loss inside the first pair; 0: never
+  int stash8;         // 1 (default): the training stash that feeds the weight gradients is 8-bit (bf8 gradients with a per-tile power-of-two scale, fp8 layer inputs; npp_layout.h "W8-format") and npp_mlp_wgrad runs on v_mfma_scale_f32_32x32x64_f8f6f4; 0: the round-2..5 16-bit stash and bf16 weight-gradient launch.  Read by npp_mlp_fwd* / npp_mlp_bwd* / npp_mlp_wgrad* at launch: flip it only between complete iterations
 };
 extern Tunables g_tune;
 bool smem_attr(SmemOnce& once, const void* fn, int bytes);
@@ -162,6 +163,41 @@ __device__ __forceinline__ void dz_store(void* p, const bf16x8& v) {
   __builtin_nontemporal_store(v, (bf16x8*)p);
 #else
   *(bf16x8*)p = v;
+#endif
+}
+// ---- 8-bit stash helpers (npp_layout.h "W8-format") --------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+// v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 turn a finite value beyond the format's range into NaN / infinity unless MODE.FP16_OVFL is
+// set, in which case they saturate (0x7e = 448 / 0x7b = 57344; tools/micro/fp8_probe.hip, round 6).  Kernels that write the 8-bit
+// stash set the bit once at entry (it also makes the fp16 z stash saturate instead of overflowing to infinity).
+__device__ __forceinline__ void set_fp16_ovfl() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+// 8 consecutive accumulator registers (or any 8 floats) -> the 8 bytes of a W8 unit
+__device__ __forceinline__ u32x2 pack8_fp8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v4, v5, 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v6, v7, hi, true);
+  return u32x2{(uint32_t)lo, (uint32_t)hi};
+}
+__device__ __forceinline__ u32x2 pack8_bf8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  int lo = __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false);
+  lo = __builtin_amdgcn_cvt_pk_bf8_f32(v2, v3, lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_bf8_f32(v4, v5, 0, false);
+  hi = __builtin_amdgcn_cvt_pk_bf8_f32(v6, v7, hi, true);
+  return u32x2{(uint32_t)lo, (uint32_t)hi};
+}
+__device__ __forceinline__ u32x2 pack8_bf8_acc(const f32x16& a, int s) {
+  return pack8_bf8(a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]);
+}
+__device__ __forceinline__ u32x2 pack8_fp8_bf16(const bf16x8& f) {
+  return pack8_fp8((float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (float)f[5], (float)f[6], (float)f[7]);
+}
+__device__ __forceinline__ void stash8_store(void* p, const u32x2& v) {
+#if NPP_STASH_NT
+  __builtin_nontemporal_store(v, (u32x2*)p);
+#else
+  *(u32x2*)p = v;
 #endif
 }
 // Pre-activations of the snake layers are stashed as fp16 (|z| is O(10); 11 significand bits):

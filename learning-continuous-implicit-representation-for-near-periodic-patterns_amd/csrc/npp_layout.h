@@ -288,4 +288,30 @@ constexpr int kDzTotalKs = kDzKsRgb + 2;
 // of 4 so that every slab is 16-byte aligned (wgrad stores and Adam loads whole float4s; the parameter count itself is odd)
 NPP_HD int64_t slab_stride_of(int64_t total) { return (total + 3) / 4 * 4; }
 NPP_HD int64_t wfmt_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_off * n_wg * 2048; }
+
+// ---- 8-bit training stash (round 6, npp_tune "stash8"): "W8-format" --------------------------------------------------------
+// What npp_mlp_wgrad8 contracts: the pre-activation gradients as bf8 (e5m2) and the layer inputs (snake(z) of the snake layers, f1,
+// f2, the embedding slots) as fp8 (e4m3, OCP), both operands of v_mfma_scale_f32_32x32x64_f8f6f4 (K = the 64 rows of a workgroup
+// tile per instruction, twice the bf16 rate).  One unit = the same 8 features of one row as a W-format unit (features
+// 16 ks + perm16(hh, 0..7)), now 8 bytes.  An array with NKS k-steps occupies NKS * 1 KiB per 64-row workgroup tile:
+//   [wg][ks pair][row group of 8 rows (8)][line of 256 B], line = [ks & 1][hh][row & 7][8 B]
+// so that (a) the (ks pair) chunk of a workgroup tile -- 32 features x 64 rows -- is ONE contiguous 2-KiB run (two 1-KiB LDS-DMA
+// pieces), (b) a wave's 8-byte stores of one k-step fill 128 contiguous bytes of four lines, and (c) the transposing read
+// ds_read_b64_tr_b8 (lane 2q + p of a 16-lane group addresses row q, lane-half chunk p; lane i receives, for e = 0..7, row e of
+// byte i & 7 of chunk i >> 3: tools/micro/fp8_probe.hip) takes the 32 chunks of one line per 32-lane half: conflict-free.
+// After that read lane l & 31 of a wave holds feature w8_feat(l & 31) of the 32-feature pair (bits 2 and 3 swapped: perm16 order
+// inside the chunks), the same in both operands; the output maps of npp_mlp_wgrad8 undo it.
+NPP_HD int64_t wfmt8_unit(int nks, int64_t wg, int ks, int row64, int hh) {
+  return (((wg * (nks >> 1) + (ks >> 1)) * 8 + (row64 >> 3)) * 256) + (ks & 1) * 128 + hh * 64 + (row64 & 7) * 8;
+}
+NPP_HD int64_t wfmt8_array_base(int ks_off, int64_t n_wg) { return (int64_t)ks_off * n_wg * 1024; }
+NPP_HD int w8_feat(int lane32) { return (lane32 & 0x13) | ((lane32 & 4) << 1) | ((lane32 & 8) >> 1); }
+// actF in stash8 mode: the 16-bit W-format region keeps the fp16 pre-activations the backward chain reads (f1 / f2 / embedding
+// arrays of that region stay unwritten); the 8-bit arrays follow it with the SAME k-step offsets (kActF1 ..., kActKsEmb0 + 30 p)
+NPP_HD int64_t act8_region_base(int K, int64_t n_wg) { return wfmt_array_base(act_total_ks(K), n_wg); }
+// dzF in stash8 mode: the bf8 arrays with the k-step offsets of the 16-bit layout, then one int32 per workgroup tile: the E8M0
+// byte (127 + e) of the power of two 2^e that turns the stored values back into gradients (the backward chain runs on
+// dL/dpred * 2^-e, e chosen per 64-row tile from max |dL/draw|: npp_mlp_bwd.hip)
+NPP_HD int64_t dz8_scale_base(int64_t n_wg) { return wfmt8_array_base(kDzTotalKs, n_wg); }
+constexpr int kDz8Lift = 11;      // stored = dz * 2^(kDz8Lift - floor(log2 max |draw| of the tile))
 }  // namespace npp

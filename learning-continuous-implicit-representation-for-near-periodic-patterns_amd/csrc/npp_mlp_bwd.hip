@@ -69,7 +69,7 @@ __device__ __forceinline__ void z_prefetch(ZPre& zp, const char* z_array, int wg
 }
 
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
-template <bool HAS_S>
+template <bool HAS_S, bool S8>
 __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const ZPre* zp, char* dz_array,
                                              int wg, int kt0, const Lane& L) {
 #pragma unroll
@@ -91,15 +91,21 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
         if (out) lds_store_frag(out, 2 * ntg + s, bt, L.lane, f);
-        dz_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
+        if (S8) stash8_store(dz_array + wfmt8_unit(kKSAct, wg, 2 * ntg + s, 32 * bt + L.b, L.h), pack8_bf8_acc(g, s));
+        else dz_store(dz_array + wfmt_unit(kKSAct, wg, 2 * ntg + s, bt, L.b, L.h), f);
       }
     }
   }
 }
 
-template <bool MULTI>
+// S8 (npp_tune "stash8"): the gradients leave as bf8 in the W8-format (npp_layout.h).  The whole chain is linear in dL/draw, so the
+// workgroup runs it on dL/draw * 2^(kDz8Lift - e), e = floor(log2 max |dL/draw|) over its 64 rows: the stored bytes then sit in
+// bf8's range whatever the loss normalisation is, and the E8M0 byte of 2^(e - kDz8Lift) goes to the tile's scale word, which
+// npp_mlp_wgrad8 hands to the matrix instruction as the block scale of the tile's 64-row contraction step (no arithmetic anywhere).
+template <bool MULTI, bool S8>
 __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, NetDesc d, BwdDesc bd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (S8) set_fp16_ovfl();
   BwdArgs A = A_in;
   int img_, wg, xslot_, xcount_;
   if (!stack_decode(A.S, img_, wg, xslot_, xcount_)) return;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
   const float* P = A.params;
   const int kt0 = 2 * L.wave;
   auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, L.n_wg); };   // z of layer idx
-  auto dzr = [&](int idx) { return A.dzF + wfmt_array_base(idx * kKSAct, L.n_wg); };
+  auto dzr = [&](int idx) { return A.dzF + (S8 ? wfmt8_array_base(idx * kKSAct, L.n_wg) : wfmt_array_base(idx * kKSAct, L.n_wg)); };
 
   // Everything the prologue needs from memory is requested first (weight ring of the first dgrad, the rgb weights, the cold
   // z fragments of P), so that ONE latency is paid instead of one per dependent section.
@@ -201,18 +207,31 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
     sDraw[L.tid] = g;
   }
   wg_barrier();
+  float gs = 1.0f;                                       // 2^(kDz8Lift - e): what the chain is run on (S8)
+  if (S8) {
+    // every wave forms the tile's max |dL/draw| itself (192 values, three per lane): no second barrier
+    float m = fmaxf(fmaxf(fabsf(sDraw[L.lane]), fabsf(sDraw[64 + L.lane])), fabsf(sDraw[128 + L.lane]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;          // floor(log2 m) of a normal m; zero / subnormal: -127
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);                        // (NaN / infinity in dL/dpred: the run is lost anyway)
+    gs = __uint_as_float((uint32_t)(127 + kDz8Lift - e) << 23);
+    if (L.tid == 0) ((int32_t*)(A.dzF + dz8_scale_base(L.n_wg)))[wg] = 127 + e - kDz8Lift;
+  }
   // dz_rgb as a 2-k-step W-format array: features 0..2 real, the rest zero
   {
     const int q1 = L.tid >> 7, bt = (L.tid >> 6) & 1, row = bt * 32 + L.b;        // waves 0..3: (k-step q1, batch tile bt)
-    bf16x8 f;
+    const bool real = q1 == 0 && L.h == 0;
+    const float r0 = real ? sDraw[row * 3 + 0] * gs : 0.0f, r1 = real ? sDraw[row * 3 + 1] * gs : 0.0f, r2 = real ? sDraw[row * 3 + 2] * gs : 0.0f;
+    if (S8) {
+      if (q1 < 2) stash8_store(A.dzF + wfmt8_array_base(kDzKsRgb, L.n_wg) + wfmt8_unit(2, wg, q1, row, L.h), pack8_bf8(r0, r1, r2, 0.f, 0.f, 0.f, 0.f, 0.f));
+    } else {
+      bf16x8 f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
-    if (q1 == 0 && L.h == 0) {
-      f[0] = (__bf16)sDraw[row * 3 + 0];
-      f[1] = (__bf16)sDraw[row * 3 + 1];
-      f[2] = (__bf16)sDraw[row * 3 + 2];
+      for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.0f;
+      f[0] = (__bf16)r0; f[1] = (__bf16)r1; f[2] = (__bf16)r2;
+      if (q1 < 2) dz_store(A.dzF + wfmt_array_base(kDzKsRgb, L.n_wg) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
     }
-    if (q1 < 2) dz_store(A.dzF + wfmt_array_base(kDzKsRgb, L.n_wg) + wfmt_unit(2, wg, q1, bt, L.b, L.h), f);
   }
 
   // ---- rgb_linear dgrad (VALU, 3 outputs) fused with the snake derivative of P:
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
       const int row = bt * 32 + L.b;
-      const float g0 = sDraw[row * 3 + 0], g1 = sDraw[row * 3 + 1], g2 = sDraw[row * 3 + 2];
+      const float g0 = sDraw[row * 3 + 0] * gs, g1 = sDraw[row * 3 + 1] * gs, g2 = sDraw[row * 3 + 2] * gs;
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
@@ -235,7 +254,8 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
       for (int s = 0; s < 2; ++s) {
         const bf16x8 f = pack_acc(g, s);
         lds_store_frag(R0, 2 * L.wave + s, bt, L.lane, f);
-        dz_store(A.dzF + wfmt_array_base(kDzKsP, L.n_wg) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
+        if (S8) stash8_store(A.dzF + wfmt8_array_base(kDzKsP, L.n_wg) + wfmt8_unit(kKSAct / 2, wg, 2 * L.wave + s, 32 * bt + L.b, L.h), pack8_bf8_acc(g, s));
+        else dz_store(A.dzF + wfmt_array_base(kDzKsP, L.n_wg) + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h), f);
       }
     }
   }
@@ -250,19 +270,19 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
   if (MULTI) {
     zero_acc(acc);
     mma_ring<0, kKSP, kKSP, kKSP, 2, kNT>(acc, R0, 0, wbl(BP2), wbl(BF2), kt0, L, ring);   // df2 = dz_f2 (F2 is linear)
-    bwd_epilogue<false>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
+    bwd_epilogue<false, S8>(acc, R1, nullptr, dzr(kDzF2), wg, kt0, L);
     wg_barrier();
     // ---- F2 dgrad -> x snake'(z_S) -> dz_s -> R0
     zero_acc(acc);
     z_prefetch(zpre, zs(kActAS), wg, kt0, L);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, R1, 0, wbl(BF2), wbl(BS), kt0, L, ring);
-    bwd_epilogue<true>(acc, R0, &zpre, dzr(kDzS), wg, kt0, L);
+    bwd_epilogue<true, S8>(acc, R0, &zpre, dzr(kDzS), wg, kt0, L);
     wg_barrier();
     // ---- S dgrad (f1 columns only; aux columns are raw embedding, no gradient) added
     //      onto the P part: df1 complete = dz_f1 (F1 is linear) -> R1
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc1, R0, 0, wbl(BS), wbl(BF1), kt0, L, ring);
   }
-  bwd_epilogue<false>(acc1, R1, nullptr, dzr(kDzF1), wg, kt0, L);
+  bwd_epilogue<false, S8>(acc1, R1, nullptr, dzr(kDzF1), wg, kt0, L);
   wg_barrier();
 
   // ---- F1, L7 .. L1 dgrads, ping-pong R1 -> R0 -> R1 ...; each output is multiplied by
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
     zero_acc(acc);
     z_prefetch(zpre, zs(out_layer), wg, kt0, L);
     mma_ring<0, kKSAct, kKSAct, kKSAct, 2, kNT>(acc, in, 0, wbl(v), v == B1 ? kNoW : wbl(v + 1), kt0, L, ring);
-    bwd_epilogue<true>(acc, v == B1 ? nullptr : out, &zpre, dzr(out_layer), wg, kt0, L);
+    bwd_epilogue<true, S8>(acc, v == B1 ? nullptr : out, &zpre, dzr(out_layer), wg, kt0, L);
     if (v != B1) wg_barrier();
   }
   asm volatile("" :: "v"(pfv[0]), "v"(pfv[1]));
@@ -315,15 +335,17 @@ static int bwd_go(const BwdArgs& A, int K, void* stream) {
   const BwdDesc bd = make_bwd_desc(K);
   const dim3 grid(A.S.M ? stack_grid(A.S) : (unsigned)(A.Bp / kRowTile)), block(kThreadsB);
   hipStream_t s = (hipStream_t)stream;
-#define NPP_LAUNCH_B(M)                                                                            \
+#define NPP_LAUNCH_B(M, S8)                                                                        \
   do {                                                                                             \
     static SmemOnce once;                                                                          \
-    if (!smem_attr(once, (const void*)mlp_bwd_kernel<M>, kSmemBwd)) {                              \
+    if (!smem_attr(once, (const void*)mlp_bwd_kernel<M, S8>, kSmemBwd)) {                          \
       set_error("npp_mlp_bwd: smem attribute"); return NPP_ERR_LAUNCH;                             \
     }                                                                                              \
-    hipLaunchKernelGGL((mlp_bwd_kernel<M>), grid, block, kSmemBwd, s, A, d, bd);                   \
+    hipLaunchKernelGGL((mlp_bwd_kernel<M, S8>), grid, block, kSmemBwd, s, A, d, bd);               \
   } while (0)
-  if (K > 1) NPP_LAUNCH_B(true); else NPP_LAUNCH_B(false);
+  const bool s8 = __atomic_load_n(&g_tune.stash8, __ATOMIC_RELAXED) != 0;
+  if (K > 1) { if (s8) NPP_LAUNCH_B(true, true); else NPP_LAUNCH_B(true, false); }
+  else { if (s8) NPP_LAUNCH_B(false, true); else NPP_LAUNCH_B(false, false); }
 #undef NPP_LAUNCH_B
   return check_launch("npp_mlp_bwd");
 }

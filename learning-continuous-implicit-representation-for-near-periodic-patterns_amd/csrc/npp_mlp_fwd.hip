@@ -355,7 +355,8 @@ __device__ __forceinline__ void load_emb_pair(const float* __restrict__ emb, int
 // 4 fma, 4 v_sin, 2 packs) so that MMA_RING<..., SLICED> can thread it through the MFMAs of one schedule position.  The LDS
 // reads of a quad are issued one position before its arithmetic.  Only for chunks whose k-steps are all regular
 // (k-step < 28, hence < kKSEmb): no branch anywhere, so a position stays one scheduling region.
-template <bool STORE_EMB, int KPER>
+// STORE_EMB: 0 no stash, 1 bf16 W-format, 2 fp8 W8-format (emb_base / lane_off then address the 8-bit array)
+template <int STORE_EMB, int KPER>
 struct SlicedGen {
   const float* sFr;
   const float* vlane;      // sV + (lane & 31)
@@ -403,7 +404,8 @@ struct SlicedGen {
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
       lds_store_frag(dst, ksl0 + q2, bt, lane, f[bt]);
-      if (STORE_EMB) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks0 + q2, bt, 0, 0) + lane_off, f[bt]);
+      if (STORE_EMB == 1) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks0 + q2, bt, 0, 0) + lane_off, f[bt]);
+      if (STORE_EMB == 2) stash8_store(emb_base + (uint32_t)wfmt8_unit(kKSEmb, 0, ks0 + q2, 32 * bt, 0) + lane_off, pack8_fp8_bf16(f[bt]));
     }
   }
   template <int JP> __device__ __forceinline__ void quad(int q2) const {
@@ -439,7 +441,7 @@ struct SlicedGen {
 //  caller (sliced_chunk0 below, in the gaps of a preceding plain part) and a barrier has been passed since;
 //  next_warp_p >= 0: the warped coordinates of THAT proposal are computed in the gaps of the last chunk's MFMAs (sV is idle
 //  then), so the next pass starts with have_warp.  All three are workgroup-uniform.
-template <bool STORE_EMB, int NTW, int NT, bool EMB_IN = false>
+template <int STORE_EMB, int NTW, int NT, bool EMB_IN = false>
 __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const EmbTabs& e, int p, char* lds_ring,
                                               float* sV, const float* sY, const float* sX,
                                               wptr_t wp, wptr_t next_wp,
@@ -452,8 +454,10 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
     wg_barrier();
   }
   // stash address = uniform (array, workgroup, k-step, batch tile) part + this lane's 32-bit offset (npp_layout.h wfmt_unit)
-  char* emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
-  const uint32_t lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
+  // (STORE_EMB == 2: actF is the base of the 8-bit region, npp_layout.h act8_region_base)
+  char* emb_base = STORE_EMB == 2 ? actF + wfmt8_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt8_unit(kKSEmb, wg, 0, 0, 0)
+                   : STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  const uint32_t lane_off = STORE_EMB == 2 ? (uint32_t)wfmt8_unit(kKSEmb, 0, 0, L.b, L.h) : (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
   // this wave's k-step q (0, 1) of chunk c: generate, hand to the LDS ring, stash for wgrad
   constexpr int kPer = kChunkKS / kWavesF;                       // k-steps of a chunk generated by one wave (2 or 1)
   auto gen_pair = [&](int c, int q) {
@@ -465,7 +469,8 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
 #pragma unroll
       for (int bt = 0; bt < kNB; ++bt) {
         lds_store_frag(lds_ring + (c & 1) * kChunkBytes, ksl, bt, L.lane, f[bt]);
-        if (STORE_EMB) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks, bt, 0, 0) + lane_off, f[bt]);
+        if (STORE_EMB == 1) stash_store(emb_base + (uint32_t)wfmt_unit(kKSEmb, 0, ks, bt, 0, 0) + lane_off, f[bt]);
+        if (STORE_EMB == 2) stash8_store(emb_base + (uint32_t)wfmt8_unit(kKSEmb, 0, ks, 32 * bt, 0) + lane_off, pack8_fp8_bf16(f[bt]));
       }
     }
   };
@@ -523,15 +528,16 @@ __device__ __forceinline__ void mma_embedding(f32x16 (&acc)[NTW][kNB], const Emb
 // Chunk 0 of proposal p's embedding generated in the MFMA gaps of a PLAIN part (KS0..KS1 of the 16 k-steps of `region`) that
 // precedes the embedding part of the same layer: replaces the exposed prologue of mma_embedding.  sV must hold p's warped
 // coordinates.  The caller passes a barrier before the embedding part reads the chunk.
-template <bool STORE_EMB, int KS0, int KS1, int NTW, int NT>
+template <int STORE_EMB, int KS0, int KS1, int NTW, int NT>
 __device__ __forceinline__ void mma_plain_gen_chunk0(f32x16 (&acc)[NTW][kNB], const char* region, const EmbTabs& e, int p,
                                                      char* lds_ring, const float* sV, wptr_t wp, wptr_t next_wp, int nt0,
                                                      char* actF, int wg, const Lane& L, WRing<NTW>& ring) {
   constexpr int kPer = kChunkKS / kWavesF;
   SlicedGen<STORE_EMB, kPer> g;
   g.sFr = e.freq_rev; g.vlane = sV + L.b; g.dst = lds_ring;
-  g.emb_base = STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
-  g.lane_off = (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
+  g.emb_base = STORE_EMB == 2 ? actF + wfmt8_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt8_unit(kKSEmb, wg, 0, 0, 0)
+               : STORE_EMB ? actF + wfmt_array_base(kActKsEmb0 + p * kKSEmb, L.n_wg) + wfmt_unit(kKSEmb, wg, 0, 0, 0, 0) : nullptr;
+  g.lane_off = STORE_EMB == 2 ? (uint32_t)wfmt8_unit(kKSEmb, 0, 0, L.b, L.h) : (uint32_t)wfmt_unit(kKSEmb, 0, 0, 0, L.b, L.h);
   g.lane = L.lane; g.ksl0 = kPer * L.wave; g.ks0 = kPer * L.wave;
   g.ph = L.h ? 0.25f : 0.0f;
   g.prologue();
@@ -561,9 +567,16 @@ __device__ __forceinline__ void slot_from_halves(const float (&lo)[4], const flo
   slot[0] = pa[0]; slot[1] = pa[1]; slot[2] = pb[0]; slot[3] = pb[1];
 }
 
-template <bool SNAKE, bool TRAIN, int NTW>
+// TRAIN: 0 inference, 1 the 16-bit stash, 2 (npp_tune "stash8") the fp16 z as in 1 PLUS the layer's output (snake(z), or the
+// linear output INSTEAD of its bf16 copy) as fp8 units in the W8 array `stash8_array` -- what npp_mlp_wgrad8 contracts
+__device__ __forceinline__ uint32_t pack4_fp8(const float (&v)[4]) {
+  int x = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], x, true);
+}
+template <bool SNAKE, int TRAIN, int NTW>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int nt0, int ntl /*tiles in layer*/,
-                                         char* stash_array, int wg, const Lane& L, bf16x8 (*keep)[kNB][2] = nullptr) {
+                                         char* stash_array, int wg, const Lane& L, bf16x8 (*keep)[kNB][2] = nullptr,
+                                         char* stash8_array = nullptr) {
   typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
   const int g16 = L.lane >> 4;
@@ -619,7 +632,20 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
         }
         if (out) lds_store_frag(out, 2 * ntg + s, bt, sl_lane, f);
         if (keep) keep[nt][bt][s] = f;
-        if (TRAIN && !SNAKE) stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, sl_lane & 31, sl_lane >> 5), f);
+        if (TRAIN == 1 && !SNAKE) stash_store(stash_array + wfmt_unit(2 * ntl, wg, 2 * ntg + s, bt, sl_lane & 31, sl_lane >> 5), f);
+        if (TRAIN == 2) {
+          u32x2 u;
+          if (kM16) {
+            float lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lo[r] = a[8 * s + r]; hi[r] = a[8 * s + 4 + r]; }
+            const auto r2 = __builtin_amdgcn_permlane32_swap(pack4_fp8(lo), pack4_fp8(hi), false, false);
+            u = u32x2{r2[0], r2[1]};
+          } else {
+            u = pack8_fp8(a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]);
+          }
+          stash8_store(stash8_array + wfmt8_unit(2 * ntl, wg, 2 * ntg + s, 32 * bt + (sl_lane & 31), sl_lane >> 5), u);
+        }
       }
     }
   }
@@ -630,9 +656,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
 // pressure in a kernel that already spills 40 of them.
 // ACT: the output nonlinearity is read from A_.out_act (npp_mlp_fwd_act: tanh / raw); false = the sigmoid, compiled in -- a template
 // parameter for the same reason as STACK (the run-time test cost the default launch 0.9 us in a same-box A/B)
-template <bool TRAIN, bool MULTI, bool EMB_IN = false, bool STACK = false, bool ACT = false>
+template <int TRAIN, bool MULTI, bool EMB_IN = false, bool STACK = false, bool ACT = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdArgs A_, EmbedDev e_arg, NetDesc d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (TRAIN == 2) set_fp16_ovfl();
   int img_ = 0, wg = blockIdx.x, xslot_ = blockIdx.x >> 3, xcount_ = ((int)gridDim.x + 7) >> 3;
   if (STACK && !stack_decode(A_.S, img_, wg, xslot_, xcount_)) return;
   const int n_wg_ = STACK ? A_.S.n_items : (int)gridDim.x;
@@ -704,6 +731,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   wg_barrier();
 
   auto arow = [&](int idx) -> char* { return TRAIN ? s_actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr; };
+  // stash8: the 8-bit region behind the 16-bit one (same k-step table), and what the embedding passes stash into
+  auto arow8 = [&](int idx) -> char* { return TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) + wfmt8_array_base(idx * kKSAct, L.n_wg) : nullptr; };
+#define s_actE (TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) : s_actF)
 
   f32x16 acc[kNTW][kNB];
   WRing<kNTW> ring;                           // weight-stream register ring, live across layers
@@ -730,11 +760,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   // ---- L0: emb(p0) -> 256, snake.  LDS ring = R1, out -> R0
   WRING_FILL(kNTW, kNT, ring, wl(L0), nt0, L);
   init_bias<kNTW>(acc, P + d.b_off[L0], nt0, L);
-  mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, s_actF, wg, L, ring);
+  mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L0), wl(L1), nt0, s_actE, wg, L, ring);
   BiasPre<kNTW> bn;
   BiasPre<1> bnp;
   bias_fetch<kNTW>(bn, P + d.b_off[L1], nt0, L);
-  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(0), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(0), wg, L, nullptr, arow8(0));
   wg_barrier();
 
   // ---- L1..L4: 256 -> 256, snake, ping-pong R0 -> R1 -> R0 -> R1 -> R0
@@ -745,7 +775,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     bias_apply<kNTW>(acc, bn);
     MMA_RING<0, A, A, A, kNTW, kNT>(acc, in, 0, wl(l), (l == L4 && !EMB_IN && kOverlapPro) ? wl(L5) + kKSEmb * U : wl(l + 1), nt0, L, ring);
     bias_fetch<kNTW>(bn, P + d.b_off[l + 1], nt0, L);
-    epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L);
+    epilogue<true, TRAIN, kNTW>(acc, out, nt0, kNT, arow(l), wg, L, nullptr, arow8(l));
     wg_barrier();
   }
 
@@ -755,27 +785,27 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   if (!EMB_IN && kOverlapPro) {
     // h part FIRST: sV still holds proposal 0's warped coordinates (written for L0, nothing else touches it), so chunk 0 of
     // the embedding part is generated in the gaps of these 16 k-steps instead of in an exposed prologue
-    mma_plain_gen_chunk0<false, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, s_actF, wg, L, ring);
+    mma_plain_gen_chunk0<0, 0, A, kNTW, kNT>(acc, R0, e, 0, R1, sV, wl(L5) + kKSEmb * U, wl(L5), nt0, s_actF, wg, L, ring);
     wg_barrier();
-    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, s_actF, wg, L, ring, true, true);
+    mma_embedding<0, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L6), nt0, s_actF, wg, L, ring, true, true);
   } else {
-    mma_embedding<false, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, s_actF, wg, L, ring);
+    mma_embedding<0, kNTW, kNT, EMB_IN>(acc, e, 0, R1, sV, sY, sX, wl(L5), wl(L5) + kKSEmb * U, nt0, s_actF, wg, L, ring);
     MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L5) + kKSEmb * U, wl(L6), nt0, L, ring);
   }
   bias_fetch<kNTW>(bn, P + d.b_off[L6], nt0, L);
-  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(5), wg, L, nullptr, arow8(5));
   wg_barrier();
 
   // ---- L6: R1 -> R0, L7: R0 -> R1
   bias_apply<kNTW>(acc, bn);
   MMA_RING<0, A, A, A, kNTW, kNT>(acc, R1, 0, wl(L6), wl(L7), nt0, L, ring);
   bias_fetch<kNTW>(bn, P + d.b_off[L7], nt0, L);
-  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(6), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(6), wg, L, nullptr, arow8(6));
   wg_barrier();
   bias_apply<kNTW>(acc, bn);
   MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(L7), wl(LF1), nt0, L, ring);
   bias_fetch<kNTW>(bn, P + d.b_off[LF1], nt0, L);
-  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(7), wg, L);
+  epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(7), wg, L, nullptr, arow8(7));
   wg_barrier();
 
   // ---- F1 = feature_linear1 (linear): R1 -> R0; its fragments are also kept in
@@ -786,7 +816,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   if (!MULTI && p_wave) WRING_FILL(1, kNT / 2, ringp, wl(LP), L.wave, L);
   if (MULTI) bias_fetch<kNTW>(bn, P + d.b_off[LS], nt0, L);
   else if (p_wave) bias_fetch<1>(bnp, P + d.b_off[LP], L.wave, L);
-  epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L);
+  epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF1), wg, L, nullptr, arow8(kActF1));
   wg_barrier();
 
   f32x16 accp[1][kNB];
@@ -799,7 +829,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
       auto warp_hook = [&](int pos) { if (pos < kWarpPer) gen_warp(e.warp, 1, sV, sY, sX, L, pos); };
       MMA_RING<0, A / 2, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring, warp_hook);
       wg_barrier();
-      mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, s_actF, wg, L, ring);
+      mma_plain_gen_chunk0<TRAIN, A / 2, A, kNTW, kNT>(acc, R0, e, 1, R1, sV, wl(LS), wl(LS) + A * U, nt0, s_actE, wg, L, ring);
       wg_barrier();
     } else {
       MMA_RING<0, A, A, A, kNTW, kNT>(acc, R0, 0, wl(LS), wl(LS) + A * U, nt0, L, ring);
@@ -807,12 +837,12 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     for (int p = 1; p < d.K; ++p) {
       const wptr_t wpp = wl(LS) + (wptr_t)(A + (p - 1) * kKSEmb) * U;
       mma_embedding<TRAIN, kNTW, kNT, EMB_IN>(acc, e, p, R1, sV, sY, sX, wpp, (p + 1 < d.K) ? wpp + kKSEmb * U : kNoW, nt0,
-                                   s_actF, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
+                                   s_actE, wg, L, ring, /*have_warp=*/!EMB_IN && kOverlapPro, /*have_chunk0=*/!EMB_IN && kOverlapPro && p == 1,
                                    /*next_warp_p=*/(kOverlapPro && p + 1 < d.K) ? p + 1 : -1);
     }
     WRING_FILL(kNTW, kNT, ring, wl(LF2), nt0, L);        // flies under the epilogue
     bias_fetch<kNTW>(bn, P + d.b_off[LF2], nt0, L);
-    epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(kActAS), wg, L);
+    epilogue<true, TRAIN, kNTW>(acc, R1, nt0, kNT, arow(kActAS), wg, L, nullptr, arow8(kActAS));
     wg_barrier();
     // ---- F2 = feature_linear2 (linear): R1 -> R0
     bias_apply<kNTW>(acc, bn);
@@ -831,7 +861,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
 #pragma unroll
         for (int s = 0; s < 2; ++s) f1keep[nt][bt][s] = lds_frag(R0, 2 * (nt0 + nt) + s, bt, L.lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads have landed before the stores below are issued
-    epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF2), wg, L);
+    epilogue<false, TRAIN, kNTW>(acc, R0, nt0, kNT, arow(kActF2), wg, L, nullptr, arow8(kActF2));
     wg_barrier();
     // f1 back into LDS (R1 is idle: every wave passed the barrier after reading a_s)
 #pragma unroll
@@ -854,7 +884,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   }
   if (p_wave)
     epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? s_actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
-                             wg, L);
+                             wg, L, nullptr, TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) + wfmt8_array_base(kActKsAP, L.n_wg) : nullptr);
 
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,
   //      half-wave exchange by shuffle, 4-wave reduction through LDS.
@@ -923,10 +953,12 @@ using namespace npp;
 #undef s_params
 #undef s_pred
 #undef s_actF
+#undef s_actE
 
 static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, bool emb_in, void* stream, const char* who) {
   const dim3 grid(A.S.M ? stack_grid(A.S) : (unsigned)(A.Bp / kRowTile)), block(kThreads);
   const bool train = A.actF != nullptr, multi = d.K > 1;
+  const bool s8 = __atomic_load_n(&g_tune.stash8, __ATOMIC_RELAXED) != 0;     // npp_tune "stash8": the 8-bit training stash
   hipStream_t s = (hipStream_t)stream;
 #define NPP_LAUNCH(T, M, E)                                                                       \
   do {                                                                                            \
@@ -938,18 +970,22 @@ static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, boo
   } while (0)
 #define NPP_LAUNCH2(E)                                                                            \
   do {                                                                                            \
-    if (train) { if (multi) NPP_LAUNCH(true, true, E); else NPP_LAUNCH(true, false, E); }         \
-    else { if (multi) NPP_LAUNCH(false, true, E); else NPP_LAUNCH(false, false, E); }             \
+    if (train && s8) { if (multi) NPP_LAUNCH(2, true, E); else NPP_LAUNCH(2, false, E); }         \
+    else if (train) { if (multi) NPP_LAUNCH(1, true, E); else NPP_LAUNCH(1, false, E); }          \
+    else { if (multi) NPP_LAUNCH(0, true, E); else NPP_LAUNCH(0, false, E); }                     \
   } while (0)
   if (A.S.M) {                            // stacked launch: training form, coordinates in
-    static SmemOnce once_s[2];
-    if (multi) {
-      if (!smem_attr(once_s[0], (const void*)mlp_fwd_kernel<true, true, false, true>, kSmemFwd)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
-      hipLaunchKernelGGL((mlp_fwd_kernel<true, true, false, true>), grid, block, kSmemFwd, s, A, e, d);
-    } else {
-      if (!smem_attr(once_s[1], (const void*)mlp_fwd_kernel<true, false, false, true>, kSmemFwd)) { set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH; }
-      hipLaunchKernelGGL((mlp_fwd_kernel<true, false, false, true>), grid, block, kSmemFwd, s, A, e, d);
-    }
+#define NPP_LAUNCH_STACK(T, M)                                                                                 \
+    do {                                                                                                         \
+      static SmemOnce once;                                                                                      \
+      if (!smem_attr(once, (const void*)mlp_fwd_kernel<T, M, false, true>, kSmemFwd)) {                          \
+        set_error("%s: smem attribute", who); return NPP_ERR_LAUNCH;                                             \
+      }                                                                                                          \
+      hipLaunchKernelGGL((mlp_fwd_kernel<T, M, false, true>), grid, block, kSmemFwd, s, A, e, d);                \
+    } while (0)
+    if (s8) { if (multi) NPP_LAUNCH_STACK(2, true); else NPP_LAUNCH_STACK(2, false); }
+    else { if (multi) NPP_LAUNCH_STACK(1, true); else NPP_LAUNCH_STACK(1, false); }
+#undef NPP_LAUNCH_STACK
   } else if (emb_in) NPP_LAUNCH2(true);
   else if (A.out_act != 1) {               // npp_mlp_fwd_act: the instantiations that read the nonlinearity from the arguments
 #define NPP_LAUNCH_ACT(T, M)                                                                                   \
@@ -960,8 +996,9 @@ static int fwd_launch(const FwdArgs& A, const EmbedDev& e, const NetDesc& d, boo
       }                                                                                                          \
       hipLaunchKernelGGL((mlp_fwd_kernel<T, M, false, false, true>), grid, block, kSmemFwd, s, A, e, d);         \
     } while (0)
-    if (train) { if (multi) NPP_LAUNCH_ACT(true, true); else NPP_LAUNCH_ACT(true, false); }
-    else { if (multi) NPP_LAUNCH_ACT(false, true); else NPP_LAUNCH_ACT(false, false); }
+    if (train && s8) { if (multi) NPP_LAUNCH_ACT(2, true); else NPP_LAUNCH_ACT(2, false); }
+    else if (train) { if (multi) NPP_LAUNCH_ACT(1, true); else NPP_LAUNCH_ACT(1, false); }
+    else { if (multi) NPP_LAUNCH_ACT(0, true); else NPP_LAUNCH_ACT(0, false); }
 #undef NPP_LAUNCH_ACT
   } else NPP_LAUNCH2(false);
 #undef NPP_LAUNCH2

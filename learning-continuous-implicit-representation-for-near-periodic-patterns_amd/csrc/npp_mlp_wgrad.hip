@@ -400,22 +400,12 @@ __device__ __forceinline__ void wgrad_loop_hybrid(f32x16 (&acc)[2][4], float (&b
   wg_barrier();
 }
 
-__global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
-  const char* dzF_ = A.dzF;
-  const char* actF_ = A.actF;
-  float* gslabs_ = A.gslabs;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m_l = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows [64 wm, +64), cols [128 wn, +128)
-
-  // Work item (tile, split) of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (observed, speed only:
-  // MI355X_MICROARCH.md "Workgroup dispatch"), so linear id i runs on XCD group i % 8; the items are numbered so that
-  // every group owns a CONTIGUOUS range of them = all tiles of one batch split (+ part of the next): the tiles of a split
-  // that read the same dz / input array (3 tiles share dz_5, 5 share dz_S, emb_0 feeds L0 and L5, f1 feeds S and P) then
-  // stream it through ONE L2 at about the same time instead of each fetching it from HBM.
-  int item;
+// Work item (tile, split) of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (observed, speed only:
+// MI355X_MICROARCH.md "Workgroup dispatch"), so linear id i runs on XCD group i % 8; the items are numbered so that
+// every group owns a CONTIGUOUS range of them = all tiles of one batch split (+ part of the next): the tiles of a split
+// that read the same dz / input array (3 tiles share dz_5, 5 share dz_S, emb_0 feeds L0 and L5, f1 feeds S and P) then
+// stream it through ONE L2 at about the same time instead of each fetching it from HBM.  false: surplus workgroup / idle image.
+__device__ __forceinline__ bool wgrad_item(const WArgs& A, int& item, const char*& dzF_, const char*& actF_, float*& gslabs_) {
   if (A.S.M) {
     // stacked: image m owns S.g XCDs (npp_common.h); inside the image the same rule -- each of its XCDs a contiguous item range
     const int n_items = A.S.n_items, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -424,9 +414,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     else { img = (int)blockIdx.x / n_items; xl = 0; gx = 1; }
     const int q_ = n_items / gx, r_ = n_items % gx;
     const int lslot = A.S.g ? slot : (int)blockIdx.x - img * n_items;
-    if (lslot >= (xl < r_ ? q_ + 1 : q_)) return;
+    if (lslot >= (xl < r_ ? q_ + 1 : q_)) return false;
     item = (xl < r_ ? xl * (q_ + 1) : r_ * (q_ + 1) + (xl - r_) * q_) + lslot;
-    if (A.S.iter && !A.S.iter[img].active) return;
+    if (A.S.iter && !A.S.iter[img].active) return false;
     dzF_ += (int64_t)img * A.dz_img_stride;
     actF_ += (int64_t)img * A.act_img_stride;
     gslabs_ += (int64_t)img * A.slab_img_stride;
@@ -439,6 +429,112 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
     item = (int)blockIdx.x;
 #endif
   }
+  return true;
+}
+
+// ---- epilogue shared by the 16-bit and the 8-bit launch: stores into this split's slab, reference layout.  P8: the operands came
+// through ds_read_b64_tr_b8, so accumulator row / column index i of a 32-feature tile is feature w8_feat(i) (npp_layout.h); BI:
+// the accumulator row tile whose bias sum this wave carries in bsum[.] (16-bit launch: both, wave column 0; 8-bit: tile `wn`)
+template <bool P8>
+__device__ __forceinline__ void wgrad_epilogue(const WJob& J, f32x16 (&acc)[2][4], float (&bsum)[2], char* smem, float* gslabs_,
+                                               int64_t slab_stride, int split_id, int tm, int tn, int wm, int wn, int wave, int lane,
+                                               bool do_bias) {
+  const int m_l = lane & 31, h = lane >> 5;
+  const int m_f = P8 ? w8_feat(m_l) : m_l;                   // feature (within its 32-tile) of this lane's accumulator column
+  // ---- epilogue: stores into this split's slab, reference layout
+  float* slab = gslabs_ + (int64_t)split_id * slab_stride;
+  if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {        // (every layer of this network has an even input width)
+    // Plain-column jobs (17 of 21 tiles at K = 3): the accumulator holds one column per lane, i.e. 4-byte stores, 128 per wave
+    // -- the tail was bound by store INSTRUCTIONS, not bytes (cdna_hip_programming.md T21).  Each wave transposes its 32 x 128
+    // strips through its 16 KiB of the (now idle) operand buffers and stores float4s (two float2s where the reference rows
+    // are only 8-byte aligned: ld or col0 not a multiple of 4): 16-32 store instructions per strip instead of 64.
+    float* stg = (float*)(smem + wave * 16384);
+    const bool a16 = ((J.ld | J.col0) & 3) == 0;            // (w_off and the slab stride are multiples of 4 floats)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[(P8 ? w8_feat(acc_row(r, h)) : acc_row(r, h)) * 128 + 32 * j + m_f] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // same wave: the writes have landed before other lanes' elements are read
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int row = 2 * p + h, c4 = 4 * m_l;
+        const float4 v = *(const float4*)(stg + row * 128 + c4);
+        const int mrow = tm * kWT + wm * 64 + i * 32 + row;
+        const int n_idx = tn * kWT + wn * 128 + c4;
+        if (mrow < J.m && n_idx < J.n) {                    // J.n is a multiple of 4 for these jobs
+          float* dst = slab + J.w_off + (int64_t)mrow * J.ld + J.col0 + n_idx;
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          typedef float f2v __attribute__((ext_vector_type(2)));
+#if NPP_WGRAD_NT_SLABS
+          if (a16) {
+            __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, (f4v*)dst);
+          } else {
+            __builtin_nontemporal_store((f2v){v.x, v.y}, (f2v*)dst);
+            __builtin_nontemporal_store((f2v){v.z, v.w}, (f2v*)(dst + 2));
+          }
+#else
+          if (a16) {
+            *(f4v*)dst = (f4v){v.x, v.y, v.z, v.w};
+          } else {
+            *(f2v*)dst = (f2v){v.x, v.y};
+            *(f2v*)(dst + 2) = (f2v){v.z, v.w};
+          }
+#endif
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next strip overwrites the staging area
+    }
+  } else
+  {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n_idx = tn * kWT + wn * 128 + j * 32 + m_f;     // accumulator column = lane & 31 (P8: its feature)
+    int col = -1;
+    if (n_idx < J.n) {
+      if (J.colmode == 0) col = J.col0 + n_idx;
+      else {
+        // column c of k-step ks is element unperm_j(c) of lane-half unperm_hh(c) (perm16 order)
+        const int c16 = n_idx & 15;
+        const int c = emb_col(n_idx >> 4, unperm_hh(c16), unperm_j(c16));
+        col = c < 0 ? -1 : J.col0 + c;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mrow = tm * kWT + wm * 64 + i * 32 + (P8 ? w8_feat(acc_row(r, h)) : acc_row(r, h));
+        if (col >= 0 && mrow < J.m) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
+      }
+    }
+  }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (P8 && i != wn) continue;                           // 8-bit launch: wave column wn sums tile wn (in bsum[0])
+      const float b = P8 ? bsum[0] : bsum[i];
+      const float v = b + __shfl_xor(b, 32, 64);
+      const int mrow = tm * kWT + wm * 64 + i * 32 + m_f;
+      if (h == 0 && mrow < J.m) slab[J.b_off + mrow] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
+  const char* dzF_ = A.dzF;
+  const char* actF_ = A.actF;
+  float* gslabs_ = A.gslabs;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int m_l = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows [64 wm, +64), cols [128 wn, +128)
+
+  int item;
+  if (!wgrad_item(A, item, dzF_, actF_, gslabs_)) return;
   const int tile_id = item % A.ntiles, split_id = item / A.ntiles;
   // locate the job of this tile: compile-time indices into the kernel-argument table so
   // it is read with scalar loads (a run-time index would force a scratch copy of it)
@@ -495,84 +591,163 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_kernel(WArgs A) {
 #undef wgrad_loop
 #endif
 
-  // ---- epilogue: stores into this split's slab, reference layout
-  float* slab = gslabs_ + (int64_t)split_id * A.slab_stride;
-  if (J.colmode == 0 && ((J.ld | J.col0) & 1) == 0) {        // (every layer of this network has an even input width)
-    // Plain-column jobs (17 of 21 tiles at K = 3): the accumulator holds one column per lane, i.e. 4-byte stores, 128 per wave
-    // -- the tail was bound by store INSTRUCTIONS, not bytes (cdna_hip_programming.md T21).  Each wave transposes its 32 x 128
-    // strips through its 16 KiB of the (now idle) operand buffers and stores float4s (two float2s where the reference rows
-    // are only 8-byte aligned: ld or col0 not a multiple of 4): 16-32 store instructions per strip instead of 64.
-    float* stg = (float*)(smem + wave * 16384);
-    const bool a16 = ((J.ld | J.col0) & 3) == 0;            // (w_off and the slab stride are multiples of 4 floats)
+  wgrad_epilogue<false>(J, acc, bsum, smem, gslabs_, A.slab_stride, split_id, tm, tn, wm, wn, wave, lane, do_bias);
+}
+
+// ======== the 8-bit launch (round 6, npp_tune "stash8"): bf8 gradients x fp8 layer inputs on v_mfma_scale_f32_32x32x64_f8f6f4 ========
+// Both operands arrive in the W8-format (npp_layout.h): the (k-step pair, 64-row workgroup tile) chunk of an array is one contiguous
+// 2-KiB run, so a main-loop step = ONE workgroup tile (64 rows = the K of one matrix instruction): wave w copies pair w of the dz tile
+// and pair w of the input tile with two 1-KiB LDS-DMA pieces each, nothing passes through a register, nothing is converted (the forward
+// stashes snake(z) itself).  Per step and wave: 6 fragments x 4 ds_read_b64_tr_b8 + 8 MFMAs of 64 cycles -- half the LDS bytes, half
+// the DMA bytes and half the matrix-pipe time of the bf16 loop for the same rows.  The power-of-two scale of the tile's gradients
+// (npp_mlp_bwd: one int32 per workgroup tile behind the arrays) is the instruction's block scale for operand A.
+// LDS: a ring of four 32-KiB slots (A | B: three steps in flight behind the one being multiplied; the epilogue stages in it) + the
+// split's scale words.
+constexpr int kOp8 = 16 * 1024;                    // one operand's tile image: 8 pairs x 2 KiB
+constexpr int kSlot8 = 2 * kOp8;
+constexpr int kSlots8 = 4;
+constexpr int kScale8Max = 8192;                   // workgroup tiles per split whose scale words fit the 32 KiB behind the ring
+constexpr int kSmemW8 = kSlots8 * kSlot8 + kScale8Max * 4;
+static_assert(kSmemW8 <= 160 * 1024 && kSlots8 * kSlot8 >= 8 * 16384, "LDS (the epilogue stages 8 x 16 KiB)");
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2i_t lds_v2i_t;
+// this lane's offset of the first of the four ds_read_b64_tr_b8 that build the operand fragment "feature w8_feat(lane & 31) of
+// pair tt, rows 32 (lane >> 5) + 0..31" inside an operand's tile image; reads t = 1..3 are 256 B (one row group) further each
+__device__ __forceinline__ int frag8_offset(int tt, int lane) {
+  return tt * 2048 + (lane >> 5) * 1024 + ((lane >> 4) & 1) * 128 + (lane & 1) * 64 + ((lane & 15) >> 1) * 8;
+}
+__device__ __forceinline__ i32x8 frag8_read(const char* tile, int off) {
+  i32x8 r;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  for (int t = 0; t < 4; ++t) {
+    const v2i_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i_t*)(tile + off + t * 256));
+    r[2 * t] = v[0];
+    r[2 * t + 1] = v[1];
+  }
+  return r;
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void wgrad8_loop(f32x16 (&acc)[2][4], float& bsum, char* smem, const int* sScale, const rsrc_t ra, const rsrc_t rb,
+                                            const rsrc_t rzero, uint32_t a_stride, uint32_t b_stride, int g0, int g1, int wave, int lane,
+                                            const int (&offA)[2], const int (&offB)[4], int bias_i) {
+  const int ns = g1 - g0;
+  if (ns <= 0) return;
+  const int voff = wave * 2048 + lane * 16;          // pair `wave` of the tile, this lane's 16 bytes
+  // (LDS-DMA through inline asm and counted by hand, as in wgrad_loop above)
+  auto dma_step = [&](int sidx) {
+    const bool ok = sidx < ns;                       // wave-uniform
+    const rsrc_t xa = ok ? ra : rzero, xb = ok ? rb : rzero;
+    const int soa = ok ? (int)((uint32_t)(g0 + sidx) * a_stride) : 0;
+    const int sob = ok ? (int)((uint32_t)(g0 + sidx) * b_stride) : 0;
+    const uint32_t d0 = (uint32_t)(uintptr_t)(lds_void*)(smem + (sidx % kSlots8) * kSlot8 + wave * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[d0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa0] offen lds\n\t"
+        "s_mov_b32 m0, %[d1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xa], %[sa1] offen lds\n\t"
+        "s_mov_b32 m0, %[d2]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb0] offen lds\n\t"
+        "s_mov_b32 m0, %[d3]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[v], %[xb], %[sb1] offen lds\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [v] "v"(voff), [xa] "s"(xa), [xb] "s"(xb), [sa0] "s"(soa), [sa1] "s"(soa + 1024), [sb0] "s"(sob), [sb1] "s"(sob + 1024),
+          [d0] "s"(d0), [d1] "s"(d0 + 1024u), [d2] "s"(d0 + (uint32_t)kOp8), [d3] "s"(d0 + (uint32_t)kOp8 + 1024u)
+        : "memory");
+  };
+#pragma unroll
+  for (int i = 0; i < kSlots8 - 1; ++i) dma_step(i);
+  int slot_off = 0;
+  for (int s = 0; s < ns; ++s) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (kSlots8 - 2)) : "memory");    // this wave's pieces of step s have landed
+    wg_barrier();                                     // everybody's have; every read of step s - 1 is over
+    dma_step(s + kSlots8 - 1);                        // -> the slot step s - 1 occupied
+    const char* sA = smem + slot_off;
+    const char* sB = sA + kOp8;
+    const int sc = sScale[s];                         // E8M0 byte of the tile's gradient scale (uniform)
+    i32x8 a[2], b[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag8_read(sA, offA[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = frag8_read(sB, offB[j]);
+    if (BIAS) {
+      // db: this wave's share (tile bias_i of its two) -- the 32 rows this lane holds of its feature, decoded and summed
+      const i32x8 av = bias_i ? a[1] : a[0];
+      float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_bf8(av[q], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8(av[q], true);
+        t0 += lo[0] + hi[0];
+        t1 += lo[1] + hi[1];
+      }
+      bsum = fmaf(t0 + t1, __uint_as_float((uint32_t)sc << 23), bsum);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 1 /* A: bf8 */, 0 /* B: fp8 */, 0, sc, 0, 0x7f7f7f7f);
+    slot_off = slot_off + kSlot8 == kSlots8 * kSlot8 ? 0 : slot_off + kSlot8;
+  }
+  // the dummy / tail DMAs issued by the last steps must not land in LDS after the epilogue starts staging there
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wg_barrier();
+}
+
+__global__ __launch_bounds__(kWThreads, 2) void wgrad8_kernel(WArgs A) {
+  const char* dzF_ = A.dzF;
+  const char* actF_ = A.actF;
+  float* gslabs_ = A.gslabs;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows [64 wm, +64), cols [128 wn, +128)
+  int item;
+  if (!wgrad_item(A, item, dzF_, actF_, gslabs_)) return;
+  const int tile_id = item % A.ntiles, split_id = item / A.ntiles;
+  WJob J = A.jobs[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stg[acc_row(r, h) * 128 + 32 * j + m_l] = acc[i][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // same wave: the writes have landed before other lanes' elements are read
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int row = 2 * p + h, c4 = 4 * m_l;
-        const float4 v = *(const float4*)(stg + row * 128 + c4);
-        const int mrow = tm * kWT + wm * 64 + i * 32 + row;
-        const int n_idx = tn * kWT + wn * 128 + c4;
-        if (mrow < J.m && n_idx < J.n) {                    // J.n is a multiple of 4 for these jobs
-          float* dst = slab + J.w_off + (int64_t)mrow * J.ld + J.col0 + n_idx;
-          typedef float f4v __attribute__((ext_vector_type(4)));
-          typedef float f2v __attribute__((ext_vector_type(2)));
-#if NPP_WGRAD_NT_SLABS
-          if (a16) {
-            __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, (f4v*)dst);
-          } else {
-            __builtin_nontemporal_store((f2v){v.x, v.y}, (f2v*)dst);
-            __builtin_nontemporal_store((f2v){v.z, v.w}, (f2v*)(dst + 2));
-          }
-#else
-          if (a16) {
-            *(f4v*)dst = (f4v){v.x, v.y, v.z, v.w};
-          } else {
-            *(f2v*)dst = (f2v){v.x, v.y};
-            *(f2v*)(dst + 2) = (f2v){v.z, v.w};
-          }
-#endif
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the next strip overwrites the staging area
-    }
-  } else
+  for (int j = 1; j < kMaxJobs; ++j)
+    if (j < A.njobs && tile_id >= A.jobs[j].tile0) J = A.jobs[j];
+  const int t_local = tile_id - J.tile0;
+  const int tm = t_local / J.tiles_n, tn = t_local - tm * J.tiles_n;
+  const int64_t n_wg = A.n_wg;
+  const int64_t wg_begin = (int64_t)split_id * A.wg_chunk;
+  const int64_t wg_end = min(n_wg, wg_begin + (int64_t)A.wg_chunk);
+  const int g0 = (int)wg_begin, g1 = (int)wg_end;
+  // the split's scale words -> LDS behind the ring, before any LDS-DMA is in flight (plain loads, waited for here)
+  int* sScale = (int*)(smem + kSlots8 * kSlot8);
   {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n_idx = tn * kWT + wn * 128 + j * 32 + m_l;     // accumulator column = lane & 31
-    int col = -1;
-    if (n_idx < J.n) {
-      if (J.colmode == 0) col = J.col0 + n_idx;
-      else {
-        // column c of k-step ks is element unperm_j(c) of lane-half unperm_hh(c) (perm16 order)
-        const int c16 = n_idx & 15;
-        const int c = emb_col(n_idx >> 4, unperm_hh(c16), unperm_j(c16));
-        col = c < 0 ? -1 : J.col0 + c;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mrow = tm * kWT + wm * 64 + i * 32 + acc_row(r, h);
-        if (col >= 0 && mrow < J.m) slab[J.w_off + (int64_t)mrow * J.ld + col] = acc[i][j][r];
-      }
-    }
+    const int32_t* sc = (const int32_t*)(dzF_ + dz8_scale_base(n_wg));
+    for (int i = tid; i < g1 - g0; i += kWThreads) sScale[i] = sc[g0 + i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
   }
-  }
-  if (do_bias) {
+  // byte address of (workgroup tile g, pair p) inside an array: (g * nks/2 + p) * 2048; actF_ = the base of the 8-bit region
+  const int64_t a_col = wfmt8_array_base(J.a_ks0, n_wg) + (int64_t)tm * kWPairs * 2048;
+  const int64_t b_col = wfmt8_array_base(J.b_ks0, n_wg) + (int64_t)tn * kWPairs * 2048;
+  const int64_t a_left = A.dz_bytes - a_col, b_left = A.act_bytes - b_col;
+  const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_ + a_col), 0, (int)(a_left > 0x7fffffffLL ? 0x7fffffffLL : a_left), 0x00020000);
+  const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(actF_ + b_col), 0, (int)(b_left > 0x7fffffffLL ? 0x7fffffffLL : b_left), 0x00020000);
+  const rsrc_t rzero = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dzF_), 0, 0, 0x00020000);      // every access out of range
+  const uint32_t a_stride = (uint32_t)J.a_nks * 1024u, b_stride = (uint32_t)J.b_nks * 1024u;
+
+  f32x16 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int mrow = tm * kWT + wm * 64 + i * 32 + m_l;
-      if (h == 0 && mrow < J.m) slab[J.b_off + mrow] = v;
-    }
-  }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+  const bool do_bias = J.bias_on && tn == 0;                     // wave column wn sums accumulator row tile wn
+  int offA[2], offB[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA[i] = frag8_offset(wm * 2 + i, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = frag8_offset(wn * 4 + j, lane);
+  if (do_bias) wgrad8_loop<true>(acc, bsum[0], smem, sScale, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB, wn);
+  else wgrad8_loop<false>(acc, bsum[0], smem, sScale, ra, rb, rzero, a_stride, b_stride, g0, g1, wave, lane, offA, offB, wn);
+  wgrad_epilogue<true>(J, acc, bsum, smem, gslabs_, A.slab_stride, split_id, tm, tn, wm, wn, wave, lane, do_bias);
 }
 
 // Build the job table for NPP_Net (K>1) / NPP_Net_top1 (K==1).
@@ -661,26 +836,38 @@ static int wgrad_launch(const void* d_dzT, const void* d_actT, int64_t Bp, int K
   A.actF = (const char*)d_actT;
   A.n_wg = Bp / kRowTile;
   if (A.n_wg > 65536) { set_error("npp_mlp_wgrad: Bp=%lld too large (32-bit tile offsets: <= %d rows per call)", (long long)Bp, 65536 * kRowTile); return NPP_ERR_ARG; }
-  A.dz_bytes = wfmt_array_base(kDzTotalKs, A.n_wg);
+  const bool s8 = __atomic_load_n(&g_tune.stash8, __ATOMIC_RELAXED) != 0;     // npp_tune "stash8": both stashes are W8-format
+  A.dz_bytes = s8 ? dz8_scale_base(A.n_wg) + 4 * A.n_wg : wfmt_array_base(kDzTotalKs, A.n_wg);
   A.act_bytes = wfmt_array_base(act_total_ks(K), A.n_wg);
+  const int64_t act_need = A.act_bytes + (s8 ? wfmt8_array_base(act_total_ks(K), A.n_wg) : 0);
+  if (s8) {                                          // the 8-bit arrays follow the 16-bit region, same k-step table
+    A.actF += act8_region_base(K, A.n_wg);
+    A.act_bytes = wfmt8_array_base(act_total_ks(K), A.n_wg);
+  }
   A.gslabs = d_gslabs;
   A.slab_stride = slab_stride_of(make_desc(K).total_params);
   const int ntiles = build_jobs(K, A);
   A.wg_chunk = (int)((A.n_wg + ksplit - 1) / ksplit);
-  static SmemOnce once;
+  if (s8 && A.wg_chunk > kScale8Max) {
+    set_error("npp_mlp_wgrad: %d workgroup tiles per split exceed the %d whose scales fit in LDS: raise ksplit", A.wg_chunk, kScale8Max);
+    return NPP_ERR_ARG;
+  }
+  static SmemOnce once, once8;
   if (!smem_attr(once, (const void*)wgrad_kernel, kSmemW)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
+  if (!smem_attr(once8, (const void*)wgrad8_kernel, kSmemW8)) { set_error("npp_mlp_wgrad: smem attribute"); return NPP_ERR_LAUNCH; }
   A.ntiles = ntiles; A.ksplit = ksplit;
   unsigned grid = (unsigned)(ntiles * ksplit);
   if (M) {
     A.S = make_stack(M, ntiles * ksplit, d_iter);
     A.dz_img_stride = dz_stride; A.act_img_stride = act_stride; A.slab_img_stride = slab_stride;
-    if (dz_stride < A.dz_bytes || act_stride < A.act_bytes || slab_stride < (int64_t)ksplit * A.slab_stride) {
+    if (dz_stride < A.dz_bytes || act_stride < act_need || slab_stride < (int64_t)ksplit * A.slab_stride) {
       set_error("npp_mlp_wgrad_stack: image strides smaller than one image's arrays");
       return NPP_ERR_ARG;
     }
     grid = stack_grid(A.S);
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
+  if (s8) hipLaunchKernelGGL(wgrad8_kernel, dim3(grid), dim3(kWThreads), kSmemW8, (hipStream_t)stream, A);
+  else hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(kWThreads), kSmemW, (hipStream_t)stream, A);
   return check_launch("npp_mlp_wgrad");
 }
 

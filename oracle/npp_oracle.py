@@ -47,6 +47,45 @@ def bf16_round(x):
     return r.astype(np.uint32).view(F32).reshape(a.shape)
 
 
+def minifloat_round(x, mbits, emin, maxv):
+    """Round-to-nearest-even fp32 -> an OCP 8-bit float -> fp32, saturating, subnormals kept: what v_cvt_pk_fp8_f32 (e4m3:
+    mbits 3, emin -6, max 448) / v_cvt_pk_bf8_f32 (e5m2: mbits 2, emin -14, max 57344) do with MODE.FP16_OVFL set
+    (tools/micro/fp8_probe.hip).  Used only to EMULATE the build's 8-bit training stash (npp_tune "stash8"): the reference
+    has no such rounding."""
+    a = np.abs(np.asarray(x, dtype=np.float64))
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.maximum(e, emin)
+    q = np.exp2(e - mbits)
+    r = np.minimum(np.rint(a / q) * q, maxv)
+    return (np.sign(x) * r).astype(F32)
+
+
+def fp8_round(x):
+    return minifloat_round(x, 3, -6, 448.0)
+
+
+def bf8_round(x):
+    return minifloat_round(x, 2, -14, 57344.0)
+
+
+DZ8_LIFT = 11      # csrc/npp_layout.h kDz8Lift
+
+
+def dz8_quantise(dz, draw, tile=64):
+    """The build's bf8 gradient stash: per 64-row workgroup tile the chain runs on dL/draw * 2^(DZ8_LIFT - e), e =
+    floor(log2 max |dL/draw| of the tile) clipped to [-100, 100] (csrc/npp_mlp_bwd.hip); the scaled values are rounded to
+    e5m2 and the power of two is undone by the matrix instruction's block scale (exact)."""
+    out = np.empty_like(np.asarray(dz, dtype=F32))
+    for r0 in range(0, dz.shape[0], tile):
+        m = float(np.abs(draw[r0:r0 + tile]).max()) if draw[r0:r0 + tile].size else 0.0
+        e = int(np.floor(np.log2(m))) if m >= 2.0 ** -126 else -127
+        e = min(max(e, -100), 100)
+        sc = np.float64(2.0) ** (DZ8_LIFT - e)
+        out[r0:r0 + tile] = (bf8_round((dz[r0:r0 + tile].astype(np.float64) * sc).astype(F32)).astype(np.float64) / sc).astype(F32)
+    return out
+
+
 # --------------------------------------------------------------------------
 # a1: periodicity-aware warp  (models/embedder.py:102-148)
 # --------------------------------------------------------------------------
@@ -232,10 +271,14 @@ def render(P, emb, K, **kw):
     return sigmoid(raw), cache
 
 
-def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16=False):
+def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16=False, emulate_stash8=False):
     """Gradients of sum(raw * draw) w.r.t. every parameter (what autograd produces
-    for networks.py:56-95).  No gradient flows to the embedding inputs."""
+    for networks.py:56-95).  No gradient flows to the embedding inputs.
+    emulate_stash8 (with emulate_bf16): the operand roundings of the build's 8-bit stash in the WEIGHT-gradient products --
+    gradients bf8 with the per-tile scale (dz8_quantise), layer inputs fp8 (embedding columns via their bf16 fragments) -- the
+    data-gradient chain keeps its bf16 operands."""
     rb = emulate_bf16
+    s8 = emulate_stash8
     K = cache["K"]
     G = {}
     W = P["feature_linear1.weight"].shape[0]
@@ -243,7 +286,24 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
     def q(x):
         return bf16_round(x) if rb else x
 
+    def qin(name, inp):
+        if not s8:
+            return q(inp)
+        x = np.asarray(inp, dtype=F32).copy()
+        emb_cols = {"periodic_linears.0": slice(0, x.shape[1]), "periodic_linears.5": slice(0, E),
+                    "scale_linears.0": slice(W, x.shape[1])}.get(name)
+        if name == "periodic_linears.5" and 5 - 1 not in skips:
+            emb_cols = None
+        if emb_cols is not None:
+            x[:, emb_cols] = bf16_round(x[:, emb_cols])          # the embedding leaves the forward as bf16 fragments
+        return fp8_round(x)
+
     def wg(name, dz, inp):
+        if s8:
+            dq = dz8_quantise(dz, draw)
+            G[name + ".weight"] = (dq.astype(np.float64).T @ qin(name, inp).astype(np.float64)).astype(F32)
+            G[name + ".bias"] = dq.sum(axis=0).astype(F32)
+            return
         G[name + ".weight"] = (q(dz).T @ q(inp)).astype(F32)
         G[name + ".bias"] = dz.sum(axis=0).astype(F32)
 
@@ -254,8 +314,13 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
         return (q(dz) @ q(w)).astype(F32)
 
     draw = np.asarray(draw, dtype=F32)
-    G["rgb_linear.weight"] = (draw.T @ cache["in_rgb"]).astype(F32)
-    G["rgb_linear.bias"] = draw.sum(axis=0).astype(F32)
+    if s8:
+        dq = dz8_quantise(draw, draw)
+        G["rgb_linear.weight"] = (dq.astype(np.float64).T @ fp8_round(cache["in_rgb"]).astype(np.float64)).astype(F32)
+        G["rgb_linear.bias"] = dq.sum(axis=0).astype(F32)
+    else:
+        G["rgb_linear.weight"] = (draw.T @ cache["in_rgb"]).astype(F32)
+        G["rgb_linear.bias"] = draw.sum(axis=0).astype(F32)
     d_ap = (draw @ P["rgb_linear.weight"]).astype(F32)
     dzp = d_ap * snake_grad(cache["z_p"])
     wg("pos_linears.0", dzp, cache["in_p"])

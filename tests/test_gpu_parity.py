@@ -453,10 +453,23 @@ def test_fused_forward_matches_oracle(dev, K, n, width):
     assert rel_l2(pred, oracle.sigmoid(raw_f)) < 5e-3
 
 
+@pytest.fixture
+def stash_mode(request):
+    """npp_tune("stash8") for one test: 1 = the 8-bit training stash (bf8 gradients / fp8 layer inputs, the default), 0 = the
+    16-bit one; restored afterwards."""
+    from npp_amd import ops
+    old = ops.tune("stash8", request.param)
+    yield request.param
+    ops.tune("stash8", old)
+
+
+@pytest.mark.parametrize("stash_mode", [1, 0], indirect=True, ids=["stash8", "stash16"])
 @pytest.mark.parametrize("K,width", [(3, 256), (1, 256), (5, 256), (3, 512), (1, 512)])
-def test_fused_training_step_gradients(dev, K, width):
+def test_fused_training_step_gradients(dev, K, width, stash_mode):
     """forward(stash) -> pixel loss -> backward chain -> grouped wgrad, against the oracle's
-    hand-derived backward (itself pinned to the reference's autograd in test_oracle_golden)."""
+    hand-derived backward (itself pinned to the reference's autograd in test_oracle_golden).  stash8: the oracle emulates the
+    8-bit operand roundings of the weight-gradient products (oracle.mlp_backward emulate_stash8) at the same 3 %; the distance
+    to the PLAIN fp32 oracle is then the quantisation noise of bf8 x fp8 products on a 677-row batch of random-sign terms."""
     H, n = 256, 640 + 37       # ragged: 677 real rows padded to 704
     net, P, angles, periods = _net(dev, K, ksplit=3, width=width)
     c = _coords(n, H, H, seed=5)
@@ -483,7 +496,7 @@ def test_fused_training_step_gradients(dev, K, width):
     assert np.abs(pred_h - pr).max() < 4e-3
     assert abs(net.loss_buf.item() - loss) < 2e-3 * abs(loss) + 1e-4
     draw = dpred * pr * (1 - pr)
-    Gref = oracle.mlp_backward(P, cache, draw, emulate_bf16=True)
+    Gref = oracle.mlp_backward(P, cache, draw, emulate_bf16=True, emulate_stash8=bool(stash_mode))
     assert set(G) == set(Gref)
     for name in Gref:
         e = rel_l2(G[name], Gref[name])
@@ -498,7 +511,9 @@ def test_fused_training_step_gradients(dev, K, width):
     gap = {name: rel_l2(G[name], G32[name]) for name in G32}
     worst = max(gap, key=gap.get)
     print(f"gradient gap to the fp32 oracle: worst {worst} {gap[worst]:.3e}, median {float(np.median(list(gap.values()))):.3e}")
-    assert gap[worst] < 4e-2, (worst, gap[worst])
+    # stash8: per-product relative noise ~7 % (e5m2) and ~3.6 % (e4m3) rms; on this batch of random-sign terms the tensor-level
+    # gap is of that order (measured worst 5.7e-2), a fraction of a percent of the minibatch noise of the same sum
+    assert gap[worst] < (9e-2 if stash_mode else 4e-2), (worst, gap[worst])
     np.testing.assert_allclose(net.dlatent[:3].cpu().numpy(), dla.ravel(), rtol=5e-2, atol=1e-5)
     np.testing.assert_allclose(net.dlatent[3:].cpu().numpy(), dls.ravel(), rtol=5e-2, atol=1e-5)
     # padded rows contribute nothing: their dpred is zero
