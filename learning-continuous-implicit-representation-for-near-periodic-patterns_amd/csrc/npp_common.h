@@ -193,6 +193,19 @@ __device__ __forceinline__ u32x2 pack8_bf8_acc(const f32x16& a, int s) {
 __device__ __forceinline__ u32x2 pack8_fp8_bf16(const bf16x8& f) {
   return pack8_fp8((float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (float)f[5], (float)f[6], (float)f[7]);
 }
+// snake'(z) = 1 + sin 2z in [0, 2] as one unsigned byte: u = round(127.5 * snake'(z)) (error <= 1 / 255, the size of the bf16
+// rounding of the operand it multiplies); what the backward chain reads in stash8 mode instead of the fp16 pre-activation.
+// v_cvt_pk_u8_f32 rounds to nearest even and saturates to [0, 255] (NaN -> 0): measured on gfx950, round 6.
+constexpr float kSd8Scale = 127.5f, kSd8Inv = 1.0f / 127.5f;
+__device__ __forceinline__ uint32_t pack4_u8(float v0, float v1, float v2, float v3) {
+  uint32_t x = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0u, 0u);
+  x = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1u, x);
+  x = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, x);
+  return __builtin_amdgcn_cvt_pk_u8_f32(v3, 3u, x);
+}
+__device__ __forceinline__ float u8_byte_f32(uint32_t w, int j) {       // byte j of w as a float (v_cvt_f32_ubyteN)
+  return (float)((w >> (8 * j)) & 255u);
+}
 __device__ __forceinline__ void stash8_store(void* p, const u32x2& v) {
 #if NPP_STASH_NT
   __builtin_nontemporal_store(v, (u32x2*)p);

@@ -57,20 +57,26 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][kNB]) {
 
 // The z fragments a layer's epilogue needs (stash, cold in HBM), fetched BEFORE the layer's MFMA loop so that their
 // latency is covered by it instead of stalling every epilogue (32 VGPRs).
-struct ZPre { f16x8 z[2][kNB][2]; };
-__device__ __forceinline__ void z_prefetch(ZPre& zp, const char* z_array, int wg, int kt0, const Lane& L) {
+// S8 (stash8): the forward left snake'(z) itself, one unsigned byte per element in the W8-format (npp_common.h kSd8Scale): 8-byte
+// units, no sine here
+template <bool S8> struct ZPre { f16x8 z[2][kNB][2]; };
+template <> struct ZPre<true> { u32x2 z[2][kNB][2]; };
+template <bool S8>
+__device__ __forceinline__ void z_prefetch(ZPre<S8>& zp, const char* z_array, int wg, int kt0, const Lane& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        zp.z[t][bt][s] = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * (kt0 + t) + s, bt, L.b, L.h));
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (S8) zp.z[t][bt][s] = *(const u32x2*)(z_array + wfmt8_unit(kKSAct, wg, 2 * (kt0 + t) + s, 32 * bt + L.b, L.h));
+        else zp.z[t][bt][s] = *(const f16x8*)(z_array + wfmt_unit(kKSAct, wg, 2 * (kt0 + t) + s, bt, L.b, L.h));
+      }
 }
 
 // dz = acc (x stashed snake derivative); fragments -> LDS for the next dgrad, rows -> dzT.
 template <bool HAS_S, bool S8>
-__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const ZPre* zp, char* dz_array,
+__device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, const ZPre<S8>* zp, char* dz_array,
                                              int wg, int kt0, const Lane& L) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -81,10 +87,16 @@ __device__ __forceinline__ void bwd_epilogue(f32x16 (&acc)[2][kNB], char* out, c
       if (HAS_S) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const f16x8 zf = zp->z[t][bt][s];
+          if constexpr (S8) {
+            const u32x2 sd = zp->z[t][bt][s];
 #pragma unroll
-          for (int j = 0; j < 8; ++j)      // snake'(z) = 1 + sin 2z  (activations.py:29-35)
-            g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
+            for (int j = 0; j < 8; ++j) g[8 * s + j] *= u8_byte_f32(sd[j >> 2], j & 3) * kSd8Inv;
+          } else {
+            const f16x8 zf = zp->z[t][bt][s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)      // snake'(z) = 1 + sin 2z  (activations.py:29-35)
+              g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
+          }
         }
       }
 #pragma unroll
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
   const int64_t row0 = (int64_t)wg * kRowTile, Bp = A.Bp;
   const float* P = A.params;
   const int kt0 = 2 * L.wave;
-  auto zs = [&](int idx) { return A.actF + wfmt_array_base(idx * kKSAct, L.n_wg); };   // z of layer idx
+  auto zs = [&](int idx) { return A.actF + (S8 ? wfmt8_array_base(idx * kKSAct, L.n_wg) : wfmt_array_base(idx * kKSAct, L.n_wg)); };   // z (S8: snake' bytes) of layer idx
   auto dzr = [&](int idx) { return A.dzF + (S8 ? wfmt8_array_base(idx * kKSAct, L.n_wg) : wfmt_array_base(idx * kKSAct, L.n_wg)); };
 
   // Everything the prologue needs from memory is requested first (weight ring of the first dgrad, the rgb weights, the cold
@@ -163,12 +175,16 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
   auto wbl = [&](int v) -> wptr_t { return (wptr_t)bd.off16[v]; };
   wring_fill<2, kNT>(ring, wbl(BP1), kt0, L.lane);
   f16x8 zp_pre[kNB][2];
+  u32x2 sdp_pre[kNB][2];
   {
-    const char* zp = A.actF + wfmt_array_base(kActKsAP, L.n_wg);
+    const char* zp = A.actF + (S8 ? wfmt8_array_base(kActKsAP, L.n_wg) : wfmt_array_base(kActKsAP, L.n_wg));
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) zp_pre[bt][s] = *(const f16x8*)(zp + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h));
+      for (int s = 0; s < 2; ++s) {
+        if (S8) sdp_pre[bt][s] = *(const u32x2*)(zp + wfmt8_unit(kKSAct / 2, wg, 2 * L.wave + s, 32 * bt + L.b, L.h));
+        else zp_pre[bt][s] = *(const f16x8*)(zp + wfmt_unit(kKSAct / 2, wg, 2 * L.wave + s, bt, L.b, L.h));
+      }
   }
   float wr[3][16];
   {
@@ -246,9 +262,15 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
       for (int r = 0; r < 16; ++r) g[r] = wr[0][r] * g0 + wr[1][r] * g1 + wr[2][r] * g2;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const f16x8 zf = zp_pre[bt][s];
+        if (S8) {
+          const u32x2 sd = sdp_pre[bt][s];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
+          for (int j = 0; j < 8; ++j) g[8 * s + j] *= u8_byte_f32(sd[j >> 2], j & 3) * kSd8Inv;
+        } else {
+          const f16x8 zf = zp_pre[bt][s];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[8 * s + j] *= 1.0f + __builtin_amdgcn_sinf((float)zf[j] * (2.0f * kInv2Pi));
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(kThreadsB, 2) void mlp_bwd_kernel(BwdArgs A_in, Net
   wg_barrier();
 
   f32x16 acc[2][kNB], acc1[2][kNB];
-  ZPre zpre;
+  ZPre<S8> zpre;
 
   // ---- P dgrad: d[f1 ; f2] = W_P^T dz_p  (contraction over 128 neurons = 8 k-steps)
   zero_acc(acc1);

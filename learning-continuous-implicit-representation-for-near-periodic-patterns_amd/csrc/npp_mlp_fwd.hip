@@ -567,8 +567,10 @@ __device__ __forceinline__ void slot_from_halves(const float (&lo)[4], const flo
   slot[0] = pa[0]; slot[1] = pa[1]; slot[2] = pb[0]; slot[3] = pb[1];
 }
 
-// TRAIN: 0 inference, 1 the 16-bit stash, 2 (npp_tune "stash8") the fp16 z as in 1 PLUS the layer's output (snake(z), or the
-// linear output INSTEAD of its bf16 copy) as fp8 units in the W8 array `stash8_array` -- what npp_mlp_wgrad8 contracts
+// TRAIN: 0 inference, 1 the 16-bit stash, 2 (npp_tune "stash8") two W8 arrays per layer instead: the layer's output (snake(z) or
+// the linear output) as fp8 units in `stash8_array` -- what npp_mlp_wgrad8 contracts -- and, for a snake layer, snake'(z) = 1 +
+// sin 2z as unsigned bytes (npp_common.h kSd8Scale) in `stash_array` -- what npp_mlp_bwd multiplies by: 2 bytes per element
+// where the 16-bit stash writes the 2-byte fp16 z that both consumers re-derive from
 __device__ __forceinline__ uint32_t pack4_fp8(const float (&v)[4]) {
   int x = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
   return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], x, true);
@@ -586,7 +588,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
     const int ntg = nt0 + nt;
 #pragma unroll
     for (int bt = 0; bt < kNB; ++bt) {
-      if (TRAIN && SNAKE) {
+      if (TRAIN == 1 && SNAKE) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (kM16) {
@@ -602,13 +604,19 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
         }
       }
       // snake on aligned register pairs: v_pk_mul (z / 2pi), 2 x v_sin, v_pk_fma (s*s + z), v_cvt_pk
-      f32x16 a;
+      f32x16 a, sd;                 // sd (stash8, snake): 127.5 * snake'(z) = 127.5 + 255 sin z cos z
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 z = {acc[nt][bt][r], acc[nt][bt][r + 1]};
         if (SNAKE) {
           const f32x2 rev = z * kInv2Pi;
           const f32x2 sn = {__builtin_amdgcn_sinf(rev[0]), __builtin_amdgcn_sinf(rev[1])};
+          if (TRAIN == 2) {
+            const f32x2 cs = {__builtin_amdgcn_cosf(rev[0]), __builtin_amdgcn_cosf(rev[1])};
+            const f32x2 d = __builtin_elementwise_fma(sn * cs, (f32x2){2.0f * kSd8Scale, 2.0f * kSd8Scale}, (f32x2){kSd8Scale, kSd8Scale});
+            sd[r] = d[0];
+            sd[r + 1] = d[1];
+          }
           z = __builtin_elementwise_fma(sn, sn, z);
         }
         a[r] = z[0];
@@ -645,6 +653,17 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[NTW][kNB], char* out, int
             u = pack8_fp8(a[8 * s], a[8 * s + 1], a[8 * s + 2], a[8 * s + 3], a[8 * s + 4], a[8 * s + 5], a[8 * s + 6], a[8 * s + 7]);
           }
           stash8_store(stash8_array + wfmt8_unit(2 * ntl, wg, 2 * ntg + s, 32 * bt + (sl_lane & 31), sl_lane >> 5), u);
+          if (SNAKE) {
+            u32x2 d;
+            if (kM16) {
+              const auto r2 = __builtin_amdgcn_permlane32_swap(pack4_u8(sd[8 * s], sd[8 * s + 1], sd[8 * s + 2], sd[8 * s + 3]),
+                                                               pack4_u8(sd[8 * s + 4], sd[8 * s + 5], sd[8 * s + 6], sd[8 * s + 7]), false, false);
+              d = u32x2{r2[0], r2[1]};
+            } else {
+              d = u32x2{pack4_u8(sd[8 * s], sd[8 * s + 1], sd[8 * s + 2], sd[8 * s + 3]), pack4_u8(sd[8 * s + 4], sd[8 * s + 5], sd[8 * s + 6], sd[8 * s + 7])};
+            }
+            stash8_store(stash_array + wfmt8_unit(2 * ntl, wg, 2 * ntg + s, 32 * bt + (sl_lane & 31), sl_lane >> 5), d);
+          }
         }
       }
     }
@@ -730,7 +749,10 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
   }
   wg_barrier();
 
-  auto arow = [&](int idx) -> char* { return TRAIN ? s_actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr; };
+  // (stash8: the snake'(z) byte arrays live where the 16-bit layout has its fp16 z arrays, at W8 size)
+  auto arow = [&](int idx) -> char* {
+    return TRAIN == 2 ? s_actF + wfmt8_array_base(idx * kKSAct, L.n_wg) : TRAIN ? s_actF + wfmt_array_base(idx * kKSAct, L.n_wg) : nullptr;
+  };
   // stash8: the 8-bit region behind the 16-bit one (same k-step table), and what the embedding passes stash into
   auto arow8 = [&](int idx) -> char* { return TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) + wfmt8_array_base(idx * kKSAct, L.n_wg) : nullptr; };
 #define s_actE (TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) : s_actF)
@@ -883,7 +905,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimdF) void mlp_fwd_kernel(FwdAr
     MMA_RING<0, A, A, A, 1, kNT / 2>(accp, R0, 0, wl(LP), kNoW, L.wave, L, ringp);
   }
   if (p_wave)
-    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2, TRAIN ? s_actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
+    epilogue<true, TRAIN, 1>(accp, nullptr, L.wave, kNT / 2,
+                             TRAIN == 2 ? s_actF + wfmt8_array_base(kActKsAP, L.n_wg) : TRAIN ? s_actF + wfmt_array_base(kActKsAP, L.n_wg) : nullptr,
                              wg, L, nullptr, TRAIN == 2 ? s_actF + act8_region_base(d.K, L.n_wg) + wfmt8_array_base(kActKsAP, L.n_wg) : nullptr);
 
   // ---- rgb_linear 128 -> 3 + sigmoid: per-lane partial dot over its 16 features,

@@ -286,6 +286,11 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
     def q(x):
         return bf16_round(x) if rb else x
 
+    def sgrad(z):
+        """snake'(z); stash8: as the unsigned byte the forward leaves for the backward chain (round(127.5 s') / 127.5)"""
+        g = snake_grad(z)
+        return (np.clip(np.rint(g.astype(np.float64) * 127.5), 0, 255) / 127.5).astype(F32) if s8 else g
+
     def qin(name, inp):
         if not s8:
             return q(inp)
@@ -322,7 +327,7 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
         G["rgb_linear.weight"] = (draw.T @ cache["in_rgb"]).astype(F32)
         G["rgb_linear.bias"] = draw.sum(axis=0).astype(F32)
     d_ap = (draw @ P["rgb_linear.weight"]).astype(F32)
-    dzp = d_ap * snake_grad(cache["z_p"])
+    dzp = d_ap * sgrad(cache["z_p"])
     wg("pos_linears.0", dzp, cache["in_p"])
     d_pin = dg("pos_linears.0", dzp)
     if K > 1:
@@ -330,7 +335,7 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
         df2 = d_pin[:, W:]
         wg("feature_linear2", df2, cache["in_f2"])
         d_as = dg("feature_linear2", df2)
-        dzs = d_as * snake_grad(cache["z_s"])
+        dzs = d_as * sgrad(cache["z_s"])
         wg("scale_linears.0", dzs, cache["in_s"])
         df1 = df1 + dg("scale_linears.0", dzs, slice(0, W))
     else:
@@ -340,7 +345,7 @@ def mlp_backward(P, cache, draw, E=E_PER_PROPOSAL, D=8, skips=(4,), emulate_bf16
     for i in reversed(range(D)):
         if i in skips:
             dh = dh[:, E:]  # drop the part that would flow to the raw embedding
-        dz = dh * snake_grad(cache[f"z{i}"])
+        dz = dh * sgrad(cache[f"z{i}"])
         wg(f"periodic_linears.{i}", dz, cache[f"in{i}"])
         if i > 0:
             dh = dg(f"periodic_linears.{i}", dz)

@@ -441,9 +441,12 @@ def test_default_width_512_snake_is_the_fused_chain(dev):
     g = net.grads_by_name() if hasattr(net, "grads_by_name") else None
     ref = {k: p.grad for k, p in dn.named_parameters() if p.grad is not None}
     blob_g = net._blob.grad
+    from npp_amd import ops
+    # 16-bit stash: bf16 operands vs exact fp32; 8-bit stash (npp_tune "stash8", default): bf8 x fp8 products on 300 random rows
+    tol = 9e-2 if ops.tune("stash8") else 3e-2
     for name, off, r, c in net._layout:
         got = blob_g[off:off + r * c].cpu().numpy()
-        assert rel_l2(got, ref[name].reshape(-1).cpu().numpy()) < 3e-2, name      # bf16 operands vs exact fp32
+        assert rel_l2(got, ref[name].reshape(-1).cpu().numpy()) < tol, name
 
 
 def test_default_width_512_relu_trains(dev):

@@ -365,7 +365,10 @@ def test_explicit_loop_matches_autograd_loop(dev, switches):
         if switches.get("use_patch_weight") and source != "same":
             assert batch["weight"] is not None and abs(float(batch["weight"].sum()) - batch["n_p"]) < 1e-4     # 1/d weights, normalised per fake patch
         assert abs(float(a.last_patch_loss[0]) - float(b.last_patch_loss[0])) < 1e-5 * abs(float(b.last_patch_loss[0])) + 1e-9
-        assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < 2e-4   # Adam normalises: tiny-gradient entries move by +-lr
+        # Adam normalises: tiny-gradient entries move by +-lr.  With the 8-bit stash (npp_tune "stash8") the two forms' 6e-3 apart
+        # patch-row gradients also land on different bf8 values now and then: measured 3.3e-4 (16-bit stash: < 2e-4)
+        from npp_amd import ops
+        assert rel_l2(a.net.params.cpu().numpy(), b.net.params.cpu().numpy()) < (6e-4 if ops.tune("stash8") else 2e-4)
         if source == "same":
             for la, lb in zip(a.percepLoss.latents, b.percepLoss.latents):
                 assert rel_l2(la.cpu().numpy(), lb.cpu().numpy()) < 1e-3

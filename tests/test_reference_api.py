@@ -151,7 +151,9 @@ def test_module_forward_backward_against_oracle(dev, K):
     # backward through the module: .grad of the blob vs the oracle's hand-derived backward
     gout = torch.from_numpy(rng.randn(n, 3).astype(np.float32) * 0.1).to(dev)
     (raw * gout).sum().backward()
-    Gref = oracle.mlp_backward(P, cache, gout.cpu().numpy(), emulate_bf16=True)
+    from npp_amd import ops
+    # (the oracle emulates the operand roundings of whichever training stash the library runs: npp_tune "stash8")
+    Gref = oracle.mlp_backward(P, cache, gout.cpu().numpy(), emulate_bf16=True, emulate_stash8=bool(ops.tune("stash8")))
     gb = net._blob.grad.cpu().numpy()
     for name, off, r, c_ in net._layout:
         e = np.linalg.norm(gb[off:off + r * c_] - Gref[name].reshape(-1)) / (np.linalg.norm(Gref[name]) + 1e-12)
@@ -212,6 +214,9 @@ def test_reference_style_loop_matches_the_fused_path(dev):
         # early Adam steps move every weight by ~lr * sign(g): an element whose tiny gradient flips sign between the
         # two summation orders differs by up to 2 * lr per step; that must stay rare, everything else must agree
         assert d.max() < 3 * 2 * 5e-4 + 1e-6, (k, d.max())
-        assert (d > 1e-4).mean() < 5e-3, (k, (d > 1e-4).mean())
+        # (8-bit stash, npp_tune "stash8": the two paths' embedding values differ in their last bf16 bit -- table sin vs the
+        #  kernel's v_sin -- and a few of those cross an fp8 rounding boundary: more tiny gradients flip sign; measured 1.2e-2)
+        from npp_amd import ops
+        assert (d > 1e-4).mean() < (2.5e-2 if ops.tune("stash8") else 5e-3), (k, (d > 1e-4).mean())
     la = api.adaptive_pix().latent_alpha.detach().cpu().numpy().ravel()
     np.testing.assert_allclose(la, fused.latents[:3].cpu().numpy(), atol=2e-4)
