@@ -1090,6 +1090,65 @@ def test_complete_iteration_at_c2_size_vs_reference_g8c2(dev, golden):
         np.testing.assert_allclose(lat.cpu().numpy(), want, atol=2e-3)
 
 
+def test_full_length_c2_fit_vs_reference_output_g8c2_full(dev, golden):
+    """The OUTPUT, not a prefix (VERDICT r5 "Missing #2"): BASELINE config c2's complete fit for the reference's full iteration
+    count -- `for i in trange(1, 2001)`, NPP_completion/train.py:133, options/arg_config.py:96 -- including the patch-size decay
+    that fires at i = 2000 (train.py:137-141: patch 96 -> 48, patch_num 2 -> 4), against g8c2_full.npz (the reference's modules
+    driven for all 2000 iterations, tests/golden/make_golden_fit_full.py, tie order defined as in g8d).  Asserted: the (patch
+    source, k) of every iteration; the weighted patch loss of EVERY source to 3 % over the first 60 iterations (the bench's own
+    workload; 'val' / 'train' iterations could only be held to 35 % against the unstable-tie golden g8c2_loop); PSNR vs the ground
+    truth within 0.1 dB of the reference at iterations 100 / 250 / 500 / 1000 / 1500 / 2000; the decay; and the fitted IMAGE against the
+    reference's fitted image (uint8): PSNR(HIP, reference) above the floors below -- two fits whose every step differs at
+    rounding level (bf16 / 8-bit-stash operands here, fp32 there) agree with each other far better than either agrees with the
+    ground truth (31.3 / 29.4 dB)."""
+    from npp_amd.fit import CompletionFit
+    from refinit import reference_init
+    g = golden("g8c2_full.npz")
+    H, N_rand, K, n_it = int(g["H"]), int(g["N_rand"]), int(g["K"]), int(g["n_iters"])
+    assert (H, K, n_it) == (512, 3, 2000)
+    img, mask = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    fit = CompletionFit(img, mask, angles, periods, g["freqs"], reference_init(K), device=dev, N_rand=N_rand, seed=0, ksplit=4,
+                        shifts=shifts, rng_mode="reference", use_perceptual_loss=True, patch_size_decay=int(g["decay"]),
+                        lpips_lin_weights=[g[f"lin{k}"] for k in range(5)])
+    assert fit.patch_size == int(g["P"]) == 96
+    traj = {int(r[0]): r[1:] for r in g["traj"]}
+    ploss = {int(r[0]): r[1] for r in g["patch_loss"]}
+    code = {"val": 0, "train": 1, "same": 2}
+    n_same, worst = 0, {}
+    for i in range(1, n_it + 1):
+        ok = fit.step_full()
+        d = fit.last_draw
+        assert (code[d["source"]], d["k"]) == tuple(int(v) for v in g["seq"][i - 1]), i
+        assert (d["P"], d["n_p"]) == tuple(int(v) for v in g["sizes"][i - 1]), i        # (the draw's own sizes: the sampler runs one iteration ahead)
+        assert ok == (d["k"] > 0) == (i in ploss)
+        if ok:
+            n_same += d["source"] == "same"
+            if i <= 60:
+                rel = abs(float(fit.last_patch_loss[0]) - ploss[i]) / abs(ploss[i])
+                worst[d["source"]] = max(worst.get(d["source"], 0.0), rel)
+                assert rel < 3e-2, (i, d["source"], float(fit.last_patch_loss[0]), ploss[i])
+        if i in traj:
+            pk, pu = fit.psnr("known"), fit.psnr("unknown")
+            assert abs(pk - traj[i][0]) < 0.1 and abs(pu - traj[i][1]) < 0.1, (i, pk, pu, traj[i])
+    assert set(worst) == {"val", "train", "same"}
+    assert (fit.patch_size, fit.patch_num) == (48, 4)                        # the decay of iteration 2000 happened
+    assert n_same == len(g["lpips_values"]) and fit.net.global_step == int(g["global_step"])
+    # the output
+    out = fit.render_image().clamp(0, 1).cpu().numpy()
+    ref = g["final_image_u8"].astype(np.float32) / 255.0
+    m = mask.astype(np.float32)
+
+    def psnr_between(a, b, w):
+        return float(-10 * np.log10((((a - b) ** 2) * w).sum() / (w.sum() * 3)))
+    pk, pu = psnr_between(out, ref, m), psnr_between(out, ref, 1 - m)
+    print(f"fitted image vs the reference's fitted image: {pk:.2f} dB over known pixels, {pu:.2f} dB over unknown; "
+          f"worst early patch-loss deviation per source {worst}")
+    # measured: 55.1 / 53.9 dB with the 8-bit stash, 58.1 / 58.0 dB with the 16-bit one (the uint8 golden's own floor is 58.9 dB)
+    assert pk > 48.0 and pu > 46.0, (pk, pu)
+    fit.close()
+
+
 def test_native_stream_and_prefetch_reproduce_numpy_sequence(dev):
     """rng_mode='reference' (the library's MT19937) draws exactly what rng_mode='numpy' (np.random.RandomState) draws, with
     and without the producer thread: same patch sources, centres, pixel rows, skipped iterations -- the reference's stream
