@@ -242,15 +242,20 @@ class CompletionFit:
             # in front of this one's (round 5: end to end 0.683 -> 0.65 ms at c2).  It reads constants only (image, mask, pools).
             cur = self._ahead if self._ahead is not None else self._materialise_ahead(d)
             nxt_d = d if self._ahead is not None else self._next_draw()
+            self._ahead = None                                    # consumed: a step that raises must not be replayed by the next call
             d, batch, ev = cur
             self.last_draw = d
             self.iteration += 1
-            if batch is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                self.step_from(batch)
-            else:
-                self.skipped += 1
-            self._ahead = self._materialise_ahead(nxt_d)          # (behind this iteration's launches in the host's order)
+            try:
+                if batch is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    self.step_from(batch)
+                else:
+                    self.skipped += 1
+            finally:
+                # the draw already taken from the queue belongs to the NEXT iteration whatever happened to this one: a caller that
+                # catches the exception and goes on keeps the reference's random stream (as StackedFit.step_full does)
+                self._ahead = self._materialise_ahead(nxt_d)      # (behind this iteration's launches in the host's order)
             return batch is not None
         self.last_draw = d                                        # host-side record of this iteration's draws (tests, logging)
         batch = self.materialise_batch(d)
@@ -468,40 +473,6 @@ class CompletionFit:
             self.percepLoss.adam_step(lr_used)
         if self.style is not None:                                # the style latents are in the same optimiser (helpers.py:153-159)
             self.style.adam_step(lr_used)
-
-    def step_from_autograd(self, b):
-        """The same iteration written like the reference's loop body, through the torch.autograd wrappers of the loss
-        modules (train.py:200-251 line by line).  Kept as the comparator of step_from() in the tests."""
-        self.last_source = source = b["source"]
-        net, P, n_p, k, n_pix, n, bp = self.net, b["P"], b["n_p"], b["k"], b["n_pix"], b["n"], b["bp"]
-        ws = net.workspace(bp)
-        net.zero_grad()
-        self.percepLoss.zero_latent_grads()
-        pred = net.forward_train(b["coords"])
-        ws["dpred"][n:].zero_()
-        ws["n_rows"] = n
-        net.pixel_loss(bp, n_pix, b["gt"], mask=b.get("pmask"), weight=self.pix_w)
-        pp_leaf = pred[n_pix:n].detach().clone().requires_grad_(True)
-        pp = pp_leaf.reshape(n_p, 1, P, P, 3).permute(0, 1, 4, 2, 3).tile((1, k, 1, 1, 1)).reshape(-1, 3, P, P)
-        raw = b["raw"]                                    # contiguous crops: real (n_p k,3,P,P), rmask (n_p k,1,P,P), fake / fmask (n_p,..)
-        real_p, rm = raw["real"].reshape(-1, 3, P, P), raw["rmask"].reshape(-1, 1, P, P)
-        fk = raw["fake"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 3, P, P)             # train.py:219-226 tiling
-        fm = raw["fmask"][:, None].tile([1, k, 1, 1, 1]).reshape(-1, 1, P, P)
-        x_in = (fk * fm + pp * (1 - fm)) * rm if (self.use_comp and source == "val") else pp * rm
-        nk_ = n_p * k
-        weight = b.get("weight")
-        loss_patch = self.contextualLoss(x_in, real_p * rm, weight) * self.cx_w if self.use_contextual_loss else pp_leaf.sum() * 0.0
-        if source == "same" and self.use_perceptual_loss:
-            lp = self.percepLoss(pp * rm, fk * rm, use_robust=self.lp_robust, normalize=True)       # mean over the nk samples
-            loss_patch = loss_patch + lp * (nk_ if weight is not None else 1) * self.lp_w
-        loss_patch.backward()
-        ws["dpred"][n_pix:n].copy_(pp_leaf.grad)
-        self.last_patch_loss = loss_patch.detach().reshape(1)
-        lr_used = net.lr
-        net.backward(bp)
-        net.optimizer_step(bp)
-        if self.percepLoss.touched:
-            self.percepLoss.adam_step(lr_used)
 
     # ---- checkpoint / resume (the reference has none: start = 0, helpers.py:166; SURVEY.md section 5) ----------------
     def state_dict(self):

@@ -73,6 +73,10 @@ def _trunk_keys(state_dict, features):
 
 
 class _Trunk(nn.Module):
+    """The trunk's LAYERS and weights (torchvision `features` construction order, the user's state dict or the fixed-seed init):
+    what HipTrunk packs for the HIP kernels.  It has no forward of its own here -- the torch fp32 forward that the tests and the
+    golden generators compare against lives in tests/comparators.py (TorchTrunk)."""
+
     def __init__(self, cfg, taps, state_dict=None, seed=1234):
         super().__init__()
         with ops.RNG_LOCK:
@@ -87,15 +91,6 @@ class _Trunk(nn.Module):
         self.taps = taps
         for p in self.parameters():
             p.requires_grad = False     # vgg.py:26-28, pretrained_networks.py:116-118
-
-    def forward(self, x):
-        x = x.contiguous()          # strided views make MIOpen fall back to its naive "nonpacked" kernels
-        outs = []
-        for i, m in enumerate(self.features):
-            x = m(x)
-            if i in self.taps:
-                outs.append(x)
-        return outs
 
 
 class _HipTrunkFunction(torch.autograd.Function):
@@ -146,8 +141,12 @@ class HipTrunk:
                         layers.append(dict(kind="conv", relu_idx=i + 1, cin=w.shape[1], cout=w.shape[0], w=w, b=b, pf=pf, pb=pb))
                     elif isinstance(m, nn.MaxPool2d):
                         layers.append(dict(kind="pool", idx=i))
+                # The uploads and npp_conv_pack launches above ran on THIS thread's current stream; other threads (run.search_all:
+                # one stream per host thread) take the entry from the cache and launch on theirs with no event between the two.
+                # Publish only what has completed (once per weight set and process).
+                torch.cuda.current_stream(self.device).synchronize()
                 if len(HipTrunk._packs) >= 12:
-                    HipTrunk._packs.clear()
+                    HipTrunk._packs.pop(next(iter(HipTrunk._packs)))          # evict the oldest entry only (instances keep their own references)
                 hit = HipTrunk._packs[key] = (layers, state_dict)
         self.layers = [dict(L) for L in hit[0]]                    # (own dicts: the per-instance tap flags below; the tensors are shared)
         for j, L in enumerate(self.layers):                         # gradient taps are supported on the top layer and before pools

@@ -146,13 +146,16 @@ def _main_stacked(args, mine, det, common, rank, world, search_main):
                      + (["--task", args.task] if args.task != "completion" else []) + shlex.split(args.train_args))
         names.append(name)
     t1 = time.time()
-    existed = [os.path.exists(os.path.join(args.basedir, f"{args.task}_top{args.p_topk}", n)) for n in names]
+    def has_testset(n):
+        """A finished result: the directory holds at least one written test set (an empty directory is what an aborted earlier run
+        left behind -- train.py:42-44 would skip it forever: it counts as failed and is named, not as done)."""
+        root = os.path.join(args.basedir, f"{args.task}_top{args.p_topk}", n)
+        return os.path.isdir(root) and any(e.startswith("testset_") and os.listdir(os.path.join(root, e)) for e in os.listdir(root)
+                                           if os.path.isdir(os.path.join(root, e)))
     fits = main_stacked(argvs, max_stack=args.stack) if argvs else []
-    for n, f, ex in zip(names, fits, existed):
-        if f is None and not ex:
+    for n, f in zip(names, fits):
+        if not has_testset(n):                                   # whether fitted now (f) or found in place (f is None)
             failed.append(n)
-        elif f is not None and hasattr(f, "close"):
-            f.close()
     print(f"[run rank {rank}/{world}] {args.task}: {len(names)} images searched in {t1 - t_all:.1f} s, fitted {args.stack}-stacked in "
           f"{time.time() - t1:.1f} s; {len(mine) - len(failed)} of {len(mine)} done" + (f"; failed: {failed}" if failed else ""), flush=True)
     return 1 if failed else 0

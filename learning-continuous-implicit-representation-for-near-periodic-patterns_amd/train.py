@@ -107,6 +107,14 @@ def _prepare(argv=None, stacked=False):
     """Everything `main` does before the loop (NPP_completion/train.py:28-131): flags, data, output directory, network init, the
     fit object.  -> _Job, or None when the result directory already exists (train.py:42-44).  stacked: the fit will ride in a
     StackedFit (which draws for every image itself: no producer thread)."""
+    plan = _plan(argv)
+    return None if plan is None else _build(plan, stacked)
+
+
+def _plan(argv=None):
+    """The side-effect-free half of _prepare: flags, the loaded detection, the output directory's NAME.  Creates nothing and touches
+    no GPU memory, so a directory run can plan every image, group them by batch shape, and create an image's result directory only
+    when its group starts fitting.  -> _Job without a fit, or None when the result directory already exists (train.py:42-44)."""
     args = parse(argv)
     if args.N_iters is None:
         args.N_iters = {"remapping": 2801, "segmentation": 601}.get(args.task, 2001)     # arg_config.py:96,202,289
@@ -146,6 +154,18 @@ def _prepare(argv=None, stacked=False):
     if os.path.exists(outroot):                                                             # train.py:42-44: results are never overwritten
         print(f"{args.task.capitalize()}: file exists, exit!!")
         return None
+    plan = _Job()
+    plan.args, plan.d, plan.outroot, plan.name, plan.remap, plan.seg, plan.fit = args, d, outroot, name, remap, seg, None
+    return plan
+
+
+def _build(plan, stacked=False):
+    """The other half: the result directory (from here on a failure removes it again) and the CompletionFit."""
+    from . import weights
+    from . import io as nio
+    from ._lib import param_layout
+    from .fit import CompletionFit
+    args, d, outroot, name, remap, seg = plan.args, plan.d, plan.outroot, plan.name, plan.remap, plan.seg
     os.makedirs(outroot, exist_ok=True)
     print("Loaded NPP", d["img"].shape, args.datadir)
     print("selected_angles: " + str(np.asarray(d["angles"]).tolist()))
@@ -185,7 +205,7 @@ def _prepare(argv=None, stacked=False):
         raise
     # the six PNGs of a test set take ~150 ms to encode (zlib, GIL released): written behind the loop, joined before returning
     from concurrent.futures import ThreadPoolExecutor
-    job = _Job()
+    job = plan
     job.args, job.fit, job.d, job.outroot, job.seg, job.load, job.weights, job.nio = args, fit, d, outroot, seg, load, weights, nio
     job.writer, job.pending, job.t0, job.name = ThreadPoolExecutor(1), [], time.time(), name
     return job
@@ -240,26 +260,76 @@ def stack_key(job):
             f.lp_robust, f.use_perceptual_loss, a.N_iters, a.i_testset, a.i_print, a.patch_size_decay, str(f.device))
 
 
+def plan_key(plan):
+    """stack_key's refinement that needs no fit: every flag that shapes the loop + what the detection fixes (K, patch size).  Plans of
+    one key build fits of one stack_key (checked again on the built fits)."""
+    a, d = plan.args, plan.d
+    flags = tuple(sorted((k, str(v)) for k, v in vars(a).items() if k not in ("datadir", "expname", "seed")))
+    return (flags, len(d["angles"]), d["patch_size"], tuple(np.asarray(d["img"]).shape))
+
+
+class FitResult:
+    """What a directory run keeps of a finished fit.  The fit itself -- weights, stashes, the trunks' activation buffers, captured
+    LPIPS graphs -- is released with its group: device memory no longer grows with the number of images of a rank."""
+
+    def __init__(self, job):
+        f = job.fit
+        self.name, self.outroot = job.name, job.outroot
+        self.patch_size, self.patch_num, self.skipped = f.patch_size, f.patch_num, f.skipped
+        self.psnr_known, self.psnr_unknown = f.psnr("known"), f.psnr("unknown")
+        self.opt_step = f.net.opt_step
+        self.has_style, self.style_lat_step = f.style is not None, (f.style.lat_step if f.style is not None else None)
+        self.has_pixel_mask = f.pixel_mask is not None
+
+    def psnr(self, region="known"):
+        return self.psnr_known if region == "known" else self.psnr_unknown
+
+    def close(self):
+        pass
+
+
 def main_stacked(argvs, max_stack=8):
     """Several images' fits in ONE launch sequence per group (stack.StackedFit): what `python -m npp_amd.run` does when a rank has
     more than one image (run_completion.sh:8-14 loops them serially; the fits are independent -- own weights, Adam state, random
     stream -- so the image becomes a grid dimension: 1.4 x the rows per second of the serial loop at 8 images per GPU).  Images group by
-    stack_key() (detected periods give patch sizes 64 .. 160: loaders.py:133-134); a group of one runs the plain loop.  -> list of fits (None for skipped / failed outputs), in the order of
-    argvs; main_stacked.last_error holds the first failure."""
+    batch shape (plan_key / stack_key: detected periods give patch sizes 64 .. 160, loaders.py:133-134); a group of one runs the
+    plain loop.  Every image is PLANNED first (flags, detection: no directory, no device memory); an image's result directory is
+    created and its fit built when its group starts, a failure -- of the plan, of the build, of the loop -- is recorded for the
+    images it concerns only, and a group's fits are released before the next group is built.
+    -> list of FitResult (None for skipped / failed outputs), in the order of argvs; main_stacked.last_error holds the first failure,
+    main_stacked.errors the failure per argv (None where there was none)."""
     from .stack import StackedFit
-    jobs = [_prepare(a, stacked=True) for a in argvs]
+    n = len(argvs)
+    plans, errors, results = [None] * n, [None] * n, [None] * n
+    for idx, a in enumerate(argvs):
+        try:
+            plans[idx] = _plan(a)
+        except (Exception, SystemExit) as e:                                                # noqa: B014  (one image's bad flag / detection)
+            errors[idx] = e
+            print(f"[stack] {a}: not fitted ({type(e).__name__}: {e})")
     groups = {}
-    for idx, job in enumerate(jobs):
-        if job is not None:
-            key = stack_key(job)
-            groups.setdefault(key if key is not None else ("single", idx), []).append(job)
-    first_error = None
-    for key, group in groups.items():
-        for c0 in range(0, len(group), max_stack):
-            chunk = group[c0:c0 + max_stack]
+    for idx, plan in enumerate(plans):
+        if plan is not None:
+            groups.setdefault(plan_key(plan), []).append(idx)
+    for key, members in groups.items():
+        for c0 in range(0, len(members), max_stack):
+            chunk_idx = members[c0:c0 + max_stack]
+            jobs = []                                                                       # (idx, job) of the images whose fit was built
+            for idx in chunk_idx:
+                try:
+                    jobs.append((idx, _build(plans[idx], stacked=len(chunk_idx) > 1)))
+                except Exception as e:
+                    import shutil
+                    shutil.rmtree(plans[idx].outroot, ignore_errors=True)                   # (it did not exist when the image was planned)
+                    errors[idx] = e
+                    print(f"[stack] {plans[idx].name}: not fitted ({type(e).__name__}: {e})")
+            if not jobs:
+                continue
+            chunk = [j for _, j in jobs]
             failed, st = None, None
             try:
-                if len(chunk) == 1 or key[0] == "single":
+                keys = {stack_key(j) for j in chunk}
+                if len(chunk) == 1 or len(keys) != 1 or None in keys:
                     for job in chunk:
                         for i in range(1, job.args.N_iters):
                             job.fit.step_full()
@@ -275,26 +345,33 @@ def main_stacked(argvs, max_stack=8):
                             _after_iteration(job, i)
             except BaseException as e:                                                      # noqa: B902
                 failed = e
-                if isinstance(e, KeyboardInterrupt):
-                    raise
-                import traceback
-                traceback.print_exc()
-                print(f"[stack] group {[j.name for j in chunk]} FAILED ({type(e).__name__}: {e})")
-                first_error = first_error or e
+                if not isinstance(e, KeyboardInterrupt):
+                    import traceback
+                    traceback.print_exc()
+                    print(f"[stack] group {[j.name for j in chunk]} FAILED ({type(e).__name__}: {e})")
             finally:
                 if st is not None:
                     st.close()                                                              # its draw threads; the fits' own close() follows
-                for job in chunk:
+                for idx, job in jobs:
                     try:
+                        if failed is None:
+                            results[idx] = FitResult(job)
                         _finish(job, failed)
                     except Exception as e:                                                  # a lost output of one image
-                        first_error = first_error or e
-                        job.fit = None
-                if failed is not None:
-                    for job in chunk:
-                        job.fit = None
-    main_stacked.last_error = first_error
-    return [None if j is None else j.fit for j in jobs]
+                        errors[idx] = errors[idx] or e
+                        results[idx] = None
+                    if failed is not None:
+                        errors[idx] = errors[idx] or failed
+                        results[idx] = None
+                    job.fit = None                                                          # release the group's device memory ...
+                del st, chunk, jobs
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()                                                # ... before the next group allocates its own
+            if isinstance(failed, KeyboardInterrupt):
+                raise failed
+    main_stacked.errors = errors
+    main_stacked.last_error = next((e for e in errors if e is not None), None)
+    return results
 
 
 def _after_iteration(job, i):

@@ -32,6 +32,7 @@ def find_checkpoint(name, explicit=None):
 
 
 _STATE_DICTS = {}      # (path, mtime) -> state dict
+_STATE_DICTS_LOCK = __import__("threading").Lock()      # run.search_all loads from several host threads
 
 
 def load_state_dict(path):
@@ -41,11 +42,13 @@ def load_state_dict(path):
         return None
     import torch
     key = (os.path.abspath(path), os.path.getmtime(path))
-    if key not in _STATE_DICTS:
-        if len(_STATE_DICTS) >= 8:
-            _STATE_DICTS.clear()
-        _STATE_DICTS[key] = torch.load(path, map_location="cpu")
-    return _STATE_DICTS[key]
+    with _STATE_DICTS_LOCK:                                # one torch.load per file: two threads missing together must end up with ONE dict
+        sd = _STATE_DICTS.get(key)                         # (losses.HipTrunk keys its packs by the dict's identity)
+        if sd is None:
+            if len(_STATE_DICTS) >= 8:
+                _STATE_DICTS.pop(next(iter(_STATE_DICTS)))
+            sd = _STATE_DICTS[key] = torch.load(path, map_location="cpu")
+    return sd
 
 
 def lpips_lin(net="vgg", path=None):

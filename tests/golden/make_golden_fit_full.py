@@ -26,6 +26,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))                 # tests/: comparators.py
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_OFFSETS, _net  # noqa: E402
 from make_golden_fit_patch import reference_lpips  # noqa: E402
@@ -37,7 +38,8 @@ def main(n_last=2000, out_name="g8c2_full.npz", H=512, K=3, decay=2000, checkpoi
     R = import_reference()
     stable_topk()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
-    from npp_amd.losses import _Trunk, _VGG19
+    from npp_amd.losses import _VGG19
+    from comparators import TorchTrunk as _Trunk
     percep = reference_lpips(R)
     N_rand, topk = 8192, 3
     patch_num = 2                                                                # arg_config.py:63

@@ -16,6 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))                 # tests/: comparators.py
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_OFFSETS, _net  # noqa: E402
 import oracle  # noqa: E402
@@ -27,7 +28,8 @@ def reference_lpips(R):
     weights/v0.1/vgg.pth, the per-layer AdaptiveLossFunction objects are the reference's, and the trunk is the build's
     fixed-seed VGG16-shaped stack (losses._Trunk, seed 4321) behind the `net.forward(x) -> 5 taps` interface."""
     import lpips.lpips as LL
-    from npp_amd.losses import _Trunk, _VGG16
+    from npp_amd.losses import _VGG16
+    from comparators import TorchTrunk as _Trunk          # tests/comparators.py: losses._Trunk + the torch forward
     chns = [64, 128, 256, 512, 512]
     obj = LL.LPIPS.__new__(LL.LPIPS)
     torch.nn.Module.__init__(obj)
@@ -54,7 +56,8 @@ def main(with_lpips=False, n_iters=100, out_name="g8b_fit_patch.npz", checkpoint
     + 2 patches of 96^2 against 3 real patches each, contextual loss every iteration, LPIPS on 'same' ones (g8c2_loop.npz)."""
     R = import_reference()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
-    from npp_amd.losses import _Trunk, _VGG19                                   # the VGG19[0:18]-shaped stand-in, seed 1234
+    from npp_amd.losses import _VGG19
+    from comparators import TorchTrunk as _Trunk                                   # the VGG19[0:18]-shaped stand-in, seed 1234
     percep = reference_lpips(R) if with_lpips else None
     N_rand, n_p, topk = 8192, 2, 3
     img, mask = oracle.synthetic_image(H)

@@ -32,6 +32,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))                 # tests/: comparators.py
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from make_golden import import_reference, OUT, FREQ_SCALES, FREQ_OFFSETS, ANGLE_OFFSETS, _net  # noqa: E402
 from make_golden_fit_patch import reference_lpips  # noqa: E402
@@ -56,7 +57,8 @@ def reference_style(R):
     weights): enc_1..3 are slices [:5], [5:10], [10:17] of the build's fixed-seed VGG16[:17]-shaped stack; forward() and
     style_loss() are the reference's code, the adaptives its AdaptiveLossFunction(num_dims = chn ** 2)."""
     import models.style_loss as SL
-    from npp_amd.losses import _Trunk, _VGG16_STYLE
+    from npp_amd.losses import _VGG16_STYLE
+    from comparators import TorchTrunk as _Trunk
     trunk = _Trunk(_VGG16_STYLE, taps=(4, 9, 16), seed=777)
     obj = SL.VGG16FeatureExtractor.__new__(SL.VGG16FeatureExtractor)
     torch.nn.Module.__init__(obj)
@@ -90,7 +92,8 @@ def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 1
     R = import_reference()
     stable_topk()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
-    from npp_amd.losses import _Trunk, _VGG19
+    from npp_amd.losses import _VGG19
+    from comparators import TorchTrunk as _Trunk
     percep = reference_lpips(R) if with_lpips else None
     style = reference_style(R) if task == "remapping" else None
     cx_w = {"completion": 1e-3, "remapping": 0.01, "segmentation": 0.005}[task]     # arg_config.py:90,281,196

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
+from comparators import step_from_autograd  # noqa: E402  (tests/comparators.py)
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -190,7 +191,7 @@ def test_c5_full_size_iteration_set(dev):
         assert batch["n"] == 8192 + 2 * 96 * 96
         a, b = make(), make()
         a.step_from(batch)
-        b.step_from_autograd(batch)
+        step_from_autograd(b, batch)
         n_pix, n, bp = batch["n_pix"], batch["n"], batch["bp"]
         da, db = a.net.workspace(bp)["dpred"].cpu().numpy(), b.net.workspace(bp)["dpred"].cpu().numpy()
         assert np.isfinite(da).all() and np.abs(db[n_pix:n]).max() > 0

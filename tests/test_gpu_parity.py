@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
+from comparators import step_from_autograd  # noqa: E402  (tests/comparators.py)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -305,7 +306,7 @@ def test_fit_with_the_plain_lpips_head(dev):
             break
     assert batch is not None and batch["source"] == "same"
     a.step_from(batch)
-    b.step_from_autograd(batch)
+    step_from_autograd(b, batch)
     ga, gb = a.net.grads(), b.net.grads()
     for name in ga:
         assert rel_l2(ga[name], gb[name]) < 2e-3, name
@@ -732,7 +733,7 @@ def test_complete_loop_at_the_reference_default_width_512(dev):
     a, b = make(), make()
     batch = a.materialise_batch(a.draw_batch())
     a.step_from(batch)
-    b.step_from_autograd(batch)
+    step_from_autograd(b, batch)
     ga, gb = a.net.grads(), b.net.grads()
     for name in ga:
         assert rel_l2(ga[name], gb[name]) < 2e-3, name

@@ -304,6 +304,32 @@ def test_directory_driver_fits_several_images_in_one_launch_sequence(dev, tmp_pa
     assert again == [None, None, None]
 
 
+def test_directory_driver_isolates_a_failing_image_and_releases_finished_groups(dev, tmp_path):
+    """(high) one image with a missing detection fails alone -- the others are fitted, nothing is left behind under its
+    name, a re-run fits only what is missing; (medium) what main_stacked returns are FitResult summaries, the fits' device memory is
+    released group by group."""
+    import torch
+    from npp_amd import io as nio, train
+    H, K = 256, 3
+    a, p, s = oracle.synthetic_periodicity(H, K)
+    dirs = []
+    for i in range(2):
+        img, mask = oracle.synthetic_image(H, seed=40 + i)
+        dirs.append(nio.write_detected_dir(str(tmp_path / "detected" / f"img{i}"), img, mask, np.ones_like(mask), a, p, s))
+    dirs.insert(1, str(tmp_path / "detected" / "img_missing"))
+    flags = ["--p_topk", "3", "--N_iters", "21", "--i_testset", "20", "--i_print", "20", "--rng_mode", "fast", "--random-trunks",
+             "--netwidth", "256", "--N_rand", "4096"]
+    res = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "out")] + flags for d in dirs])
+    assert res[1] is None and train.main_stacked.errors[1] is not None and train.main_stacked.errors[0] is None
+    assert isinstance(res[0], train.FitResult) and isinstance(res[2], train.FitResult) and res[0].opt_step == 20
+    assert not (tmp_path / "out" / "completion_top3" / "img_missing").exists()
+    assert (tmp_path / "out" / "completion_top3" / "img0" / "testset_000020").is_dir()
+    free0 = torch.cuda.mem_get_info()[0]
+    again = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "out")] + flags for d in dirs])
+    assert again == [None, None, None] and train.main_stacked.errors[0] is None and train.main_stacked.errors[1] is not None
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)               # nothing of the finished groups is still allocated
+
+
 def test_directory_driver_stacks_remapping_images(dev, tmp_path):
     """train.main_stacked on two remapping runs (--task remapping: blur detection -> clear mask -> per-pixel loss weights, style term):
     one stack of two, test sets written per image, style latents trained."""
@@ -317,8 +343,8 @@ def test_directory_driver_stacks_remapping_images(dev, tmp_path):
     flags = ["--task", "remapping", "--p_topk", "3", "--N_iters", "21", "--i_testset", "20", "--i_print", "20", "--rng_mode", "fast", "--random-trunks",
              "--netwidth", "256", "--N_rand", "4096"]
     fits = train.main_stacked([["--datadir", d, "--basedir", str(tmp_path / "out")] + flags for d in dirs])
-    assert train.main_stacked.last_error is None and all(f is not None and f.style is not None and f.pixel_mask is not None for f in fits)
-    assert all(f.style.lat_step == 20 and f.net.opt_step == 20 for f in fits)
+    assert train.main_stacked.last_error is None and all(f is not None and f.has_style and f.has_pixel_mask for f in fits)
+    assert all(f.style_lat_step == 20 and f.opt_step == 20 for f in fits)
     for i in range(2):
         out = tmp_path / "out" / "remapping_top3" / f"img{i}" / "testset_000020"
         assert out.is_dir() and len(list(out.iterdir())) >= 4

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
+from comparators import step_from_autograd  # noqa: E402  (tests/comparators.py)
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -151,8 +152,8 @@ def test_maxpool_fwd_bwd_exact_with_ties(dev):
 
 
 def _torch_ref(cfg, taps, sd, dev):
-    from npp_amd.losses import _Trunk
-    return _Trunk(cfg, taps, state_dict=sd).to(dev)
+    from comparators import TorchTrunk
+    return TorchTrunk(cfg, taps, state_dict=sd).to(dev)
 
 
 @pytest.mark.parametrize("name,P,n,ntot", [("vgg19", 64, 6, 12), ("vgg19", 96, 2, 4), ("vgg16", 64, 2, 4), ("vgg16", 48, 1, 3)])
@@ -352,7 +353,7 @@ def test_explicit_loop_matches_autograd_loop(dev, switches):
     for source, batch in by_source.items():
         a, b = make(), make()              # identical fresh states: the saturated 'same' CX gradient is discontinuous in the
         a.step_from(batch)                 # prediction, so the comparison must not start from already-diverged parameters
-        b.step_from_autograd(batch)
+        step_from_autograd(b, batch)
         n_pix, n, bp = batch["n_pix"], batch["n"], batch["bp"]
         da, db = a.net.workspace(bp)["dpred"].cpu().numpy(), b.net.workspace(bp)["dpred"].cpu().numpy()
         if switches.get("use_contextual_loss", True) or source == "same":
@@ -404,11 +405,12 @@ def test_style_loss_trunk_with_pool_taps_vs_torch(dev):
     """StyleLoss end to end (VGG16 features[:17] with taps on the three POOLED tensors, Gram heads, gradient to the image)
     against the same computation in plain PyTorch fp32 with the oracle's robust NLL replaced by ... the HIP head on torch's
     features: isolates the trunk-with-pool-taps forward/backward (fp16 forward / bf16 gradient budget as in the other trunks)."""
-    from npp_amd.losses import StyleLoss, _Trunk, _VGG16_STYLE
+    from npp_amd.losses import StyleLoss, _VGG16_STYLE
+    from comparators import TorchTrunk
     rng = np.random.RandomState(8)
     sd = _state_dict(_VGG16_STYLE, rng)
     st = StyleLoss(vgg_state_dict=sd, device=dev)
-    ref = _Trunk(_VGG16_STYLE, taps=(4, 9, 16), state_dict=sd).to(dev)
+    ref = TorchTrunk(_VGG16_STYLE, taps=(4, 9, 16), state_dict=sd).to(dev)
     n, P = 2, 64
     xy = torch.from_numpy(rng.rand(2 * n, 3, P, P).astype(np.float32)).to(dev)
     feats = st.hip_trunk._forward(xy, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0))

@@ -83,3 +83,17 @@ def test_stacked_split_k_choice_fills_whole_rounds():
     assert [pick(M) for M in (1, 2, 4, 8)] == [12, 6, 3, 3]
     for M in (1, 2, 4):
         assert tiles * pick(M) * M <= cus                       # one round
+
+
+def test_main_stacked_records_a_failure_per_image_and_creates_nothing(tmp_path):
+    """an image whose preparation fails -- here: detection directories that do not exist -- is recorded for that
+    image only, aborts nothing, and leaves no result directory behind that a re-run would take for a finished fit
+    (NPP_completion/train.py:42-44 skips existing directories)."""
+    from npp_amd import train
+    base = tmp_path / "results"
+    argvs = [["--datadir", str(tmp_path / "detected" / f"missing{i}"), "--basedir", str(base), "--p_topk", "3", "--random-trunks",
+              "--netwidth", "256", "--device", "cpu"] for i in range(2)]
+    out = train.main_stacked(argvs)
+    assert out == [None, None]
+    assert all(e is not None for e in train.main_stacked.errors) and train.main_stacked.last_error is train.main_stacked.errors[0]
+    assert not base.exists()

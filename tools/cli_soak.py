@@ -55,7 +55,7 @@ dirs = sorted(os.path.join(det, n) for n in os.listdir(det))[:2]
 code = ("import sys; sys.path.insert(0, %r); from npp_amd import train; "
         "fits = train.main_stacked([['--task', 'remapping', '--datadir', d, '--basedir', %r, '--p_topk', '3', '--N_iters', '81', '--i_testset', '80', "
         "'--i_print', '40', '--random-trunks'] for d in %r]); "
-        "assert train.main_stacked.last_error is None and all(f is not None and f.style is not None for f in fits); print('stacked remapping ok')"
+        "assert train.main_stacked.last_error is None and all(f is not None and f.has_style for f in fits); print('stacked remapping ok')"
         % (os.getcwd(), os.path.join(tmp, "res_remap"), dirs))
 r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
 print("remapping, stacked", "rc", r.returncode, (r.stdout.strip().splitlines() or [""])[-3:], r.stderr[-1500:] if r.returncode else "", flush=True)
