@@ -16,7 +16,7 @@ import numpy as np
 
 from .npp_oracle import F32, adaptive_params, robust_nll, robust_nll_grads, load_partition_spline
 
-__all__ = ["extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
+__all__ = ["patch_compose", "patch_compose_bwd", "sampler_returns_to_crops", "extract_glimpse_int", "GridPatchSamplerOracle", "cx_forward", "cx_backward", "normalize_tensor",
            "lpips_head", "lpips_head_grads", "scaling_layer", "style_loss_grads", "VGG19_CX_CFG", "VGG16_LPIPS_CFG", "VGG19_CX_TAPS",
            "VGG16_LPIPS_TAPS", "conv3x3", "conv3x3_dgrad", "maxpool2", "maxpool2_bwd", "trunk_forward", "trunk_backward", "conv3x3_gemm", "conv3x3_dgrad_gemm"]
 
@@ -428,3 +428,54 @@ def trunk_backward(cfg, cache, taps, tap_grads, gemm=False):
         else:
             g = dgrad(np.where(c[2], g, 0).astype(F32), c[1])
     return g
+
+
+# --------------------------------------------------------------------------
+# a10: the patch plumbing between the prediction and the patch losses
+#   NPP_completion/train.py:200-236 (contextual inputs), :241-250 (LPIPS inputs); its backward is what autograd forms
+#   Pinned by tests/golden/g8p_patch_io.npz (the reference's own tensors for a 'val', a 'train' and a 'same' iteration).
+# --------------------------------------------------------------------------
+def patch_compose(pred_rows, real, rmask, fake, fmask, n_p, k, P, source, use_comp=True):
+    """Inputs as models/sampler.py GridPatchSampler.sample_patches returns them: real (n_p, k, P, P, 3), rmask (n_p, k, P, P, 1),
+    fake (n_p, k, 3, P, P) (the fake patch tiled k times, :219-226), fmask (n_p, k, 1, P, P); pred_rows (n_p P^2, 3) = the
+    network's prediction on the patch rows.  -> (x_in, y_in, lp0, lp1): the (n_p k, 3, P, P) tensors handed to the contextual
+    loss's trunk and, for source 'same', to percepLoss (else None)."""
+    pred_rows = np.asarray(pred_rows, F32)
+    pp = pred_rows.reshape(n_p, 1, P, P, 3).transpose(0, 1, 4, 2, 3)                                   # :201
+    pp = np.tile(pp, (1, k, 1, 1, 1)).reshape(-1, 3, P, P)                                             # :203
+    real_p = np.asarray(real, F32).reshape(-1, k, 3).reshape(n_p, k, P, P, 3).transpose(0, 1, 4, 2, 3).reshape(-1, 3, P, P)   # :206-208
+    rm = np.asarray(rmask, F32).transpose(0, 1, 4, 2, 3).reshape(-1, 1, P, P)                          # :213-214
+    fk, fm = np.asarray(fake, F32).reshape(-1, 3, P, P), np.asarray(fmask, F32).reshape(-1, 1, P, P)
+    if source == "val" and use_comp:                                                                   # :228-232: known pixels of the fake patch, prediction elsewhere
+        x_in = ((fk * fm + pp * (F32(1) - fm)) * rm).astype(F32)
+    else:
+        x_in = (pp * rm).astype(F32)                                                                   # :234-236
+    y_in = (real_p * rm).astype(F32)
+    lp0 = lp1 = None
+    if source == "same":                                                                               # :241-247
+        lp0, lp1 = (pp * rm).astype(F32), (fk * rm).astype(F32)
+    return x_in, y_in, lp0, lp1
+
+
+def patch_compose_bwd(dx_in, dlp0, rmask, fmask, n_p, k, P, source, use_comp=True):
+    """dL/dpred on the patch rows (n_p P^2, 3) from dL/dx_in (n_p k, 3, P, P) of the contextual branch and, for 'same', dL/dlp0 of
+    the LPIPS branch: the adjoint of patch_compose -- mask products back, then the k tiles of a patch summed (the `tile` of :203)."""
+    rm = np.asarray(rmask, F32).transpose(0, 1, 4, 2, 3).reshape(-1, 1, P, P)
+    fm = np.asarray(fmask, F32).reshape(-1, 1, P, P)
+    g = np.asarray(dx_in, np.float64) * rm
+    if source == "val" and use_comp:
+        g = g * (1.0 - fm)
+    if dlp0 is not None:
+        g = g + np.asarray(dlp0, np.float64) * rm
+    g = g.reshape(n_p, k, 3, P, P).sum(axis=1)                       # the k copies of a fake patch share one prediction
+    return g.transpose(0, 2, 3, 1).reshape(n_p * P * P, 3).astype(F32)
+
+
+def sampler_returns_to_crops(real, rmask, fake, fmask):
+    """The reference-shaped sampler returns -> the contiguous crops the C ABI takes (include/npp_hip.h npp_patch_compose_fwd): real
+    (n_p k, 3, P, P), rmask (n_p k, 1, P, P), fake (n_p, 3, P, P), fmask (n_p, 1, P, P) -- the fake patch once, not tiled."""
+    real, rmask, fake, fmask = (np.asarray(v, F32) for v in (real, rmask, fake, fmask))
+    n_p, k, P = real.shape[0], real.shape[1], real.shape[2]
+    return (np.ascontiguousarray(real.transpose(0, 1, 4, 2, 3).reshape(n_p * k, 3, P, P)),
+            np.ascontiguousarray(rmask.transpose(0, 1, 4, 2, 3).reshape(n_p * k, 1, P, P)),
+            np.ascontiguousarray(fake[:, 0]), np.ascontiguousarray(fmask[:, 0]))

@@ -99,7 +99,9 @@ def test_four_ranks_on_one_card_with_a_node_share_of_cpus_each():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 4 and j["collective"]["ranks"] == 4 and len(j["per_rank_rows_per_s"]) == 4
     e = j["all_ranks_incl_sampling"]
-    assert len(e["host_enqueue_ms_per_iter"]) == 4 and len(e["ms_per_iter_incl_sampling"]) == 4
+    # (round 6: the headline `value` IS the sampling-inclusive loop of every rank -- per_rank_rows_per_s; the pre-drawn-pool loop is
+    #  reported beside it)
+    assert len(e["host_enqueue_ms_per_iter"]) == 4 and len(j["device_only_per_rank_rows_per_s"]) == 4 and "samples" in j["config"]["value_is"]
     print("host enqueue ms per iteration, per rank:", [round(v, 3) for v in e["host_enqueue_ms_per_iter"]],
-          "| sampling-inclusive ms per iteration (card shared 4 ways):", [round(v, 3) for v in e["ms_per_iter_incl_sampling"]])
+          "| sampling-inclusive rows/s per rank (card shared 4 ways):", [round(v) for v in j["per_rank_rows_per_s"]])
     assert max(e["host_enqueue_ms_per_iter"]) < 0.6, e

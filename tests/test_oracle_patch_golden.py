@@ -114,3 +114,34 @@ def test_style_loss_oracle_vs_reference(golden):
             assert np.linalg.norm(dA[i] - g[f"{tag}_dA{i}"]) < 2e-4 * np.linalg.norm(g[f"{tag}_dA{i}"])
             assert np.linalg.norm(dla[i] - g[f"{tag}_dla{i}"]) < 2e-3 * np.linalg.norm(g[f"{tag}_dla{i}"]) + 1e-9
             assert np.linalg.norm(dls[i] - g[f"{tag}_dls{i}"]) < 2e-3 * np.linalg.norm(g[f"{tag}_dls{i}"]) + 1e-9
+
+
+@pytest.mark.parametrize("source", ["val", "train", "same"])
+def test_patch_plumbing_vs_reference_tensors_g8p(golden, source):
+    """SURVEY 8 row a10, directly: oracle.patch_compose / patch_compose_bwd against the tensors the reference's own loop produced
+    (NPP_completion/train.py:200-236, :241-250 and autograd through them; tests/golden/make_golden_patch_io.py) for the first
+    'val' (use_comp), 'train' and 'same' iteration: the inputs of both losses bit for bit, dL/dpred on the patch rows to fp32
+    summation order."""
+    g = golden("g8p_patch_io.npz")
+    P, n_p, k = int(g["P"]), int(g["n_p"]), int(g[f"{source}_k"])
+    x_in, y_in, lp0, lp1 = oracle.patch_compose(g[f"{source}_pred_rows"], g[f"{source}_real"], g[f"{source}_rmask"], g[f"{source}_fake"],
+                                                 g[f"{source}_fmask"], n_p, k, P, source)
+    np.testing.assert_array_equal(x_in, g[f"{source}_x_in"])
+    np.testing.assert_array_equal(y_in, g[f"{source}_y_in"])
+    dlp0 = None
+    if source == "same":
+        np.testing.assert_array_equal(lp0, g["same_lp0"])
+        np.testing.assert_array_equal(lp1, g["same_lp1"])
+        np.testing.assert_array_equal(lp0, x_in)                  # 'same': the two losses see the same tensors (what the
+        np.testing.assert_array_equal(lp1, y_in)                  # build exploits: one [x | y] batch feeds both trunks)
+        dlp0 = g["same_dlp0"]
+    else:
+        assert lp0 is None and lp1 is None
+    d = oracle.patch_compose_bwd(g[f"{source}_dx_in"], dlp0, g[f"{source}_rmask"], g[f"{source}_fmask"], n_p, k, P, source)
+    want = g[f"{source}_dpred_rows"]
+    assert np.abs(want).max() > 0
+    np.testing.assert_allclose(d, want, rtol=2e-6, atol=1e-12)
+    # 'val' with use_comp: the prediction only shows through where the fake patch is unknown
+    if source == "val":
+        fm = np.broadcast_to(g["val_fmask"][:, 0].transpose(0, 2, 3, 1).reshape(-1, 1), want.shape)
+        assert np.all(want[fm == 1] == 0)
