@@ -69,7 +69,16 @@ int npp_device_count(void);
 /* Launch-time choice between kernel FORMS that compute the same result (the reference has no counterpart: torch / cuDNN pick
  * their algorithms internally).  Keys: "conv_wink" (group-split window convolution: 0 never, 1 where measured best, 2 wherever
  * feasible), "conv_win" (window-staged convolution, same values), "conv_wstat" (weight-stationary block numbering, 0 / 1),
- * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second, bit 2 the first block's data gradient, bit 3 the loop's patch plumbing + pixel loss inside the first pair; 0 never, default 15).  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
+ * "conv_pair" (fused convolution pairs: bit 0 the first VGG block, bit 1 the second, bit 2 the first block's data gradient, bit 3 the loop's patch plumbing + pixel loss inside the first pair; 0 never, default 15),
+ * "light_det" (1 default / 0: the proposal-ranking fits' fp32 weight-gradient launch without / with split-K float atomics),
+ * "stash8" (round 6; 1 default / 0): the FORMAT of the training stash between npp_mlp_fwd*, npp_mlp_bwd* and npp_mlp_wgrad* -- 1: 8-bit
+ * (csrc/npp_layout.h "W8-format": per snake layer its output as fp8 e4m3 and snake'(z) as an unsigned byte, f1 / f2 / embedding slots
+ * as fp8, the pre-activation gradients as bf8 e5m2 scaled per 64-row tile by a power of two derived from max |dL/draw| of the tile;
+ * the weight gradients are contracted by v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate); 0: the 16-bit stash of rounds 2-5 (fp16
+ * z, bf16 gradients, bf16 MFMA).  Unlike the other keys this one changes operand ROUNDING (not the algorithm): forward values are
+ * identical, weight gradients differ by the quantisation noise of bf8 x fp8 products (tests/test_gpu_parity.py states both
+ * tolerances; every reference trajectory golden holds within 0.1 dB with either).  The three launches of an iteration must see the
+ * same value: flip it between complete iterations only.  value < 0 only reads.  Returns the previous value, NPP_ERR_ARG for an unknown
  * key.  Initial values come from the environment (NPP_CONV_WINK=...), defaults are the measured-best forms. */
 int npp_tune(const char* key, int value);
 
@@ -116,9 +125,12 @@ int npp_warp_fwd(const int32_t* d_coords_yx, int64_t N, const npp_embed_cfg* cfg
 /* ---- a5+a6+a7: fused coordinate MLP -------------------------------------- */
 /* Workspace sizes (bytes) for a padded batch of Bp rows (multiple of NPP_ROW_TILE):
  *  sizes[0] 0 (reserved)
- *  sizes[1] actF   forward stash, 16-byte fragments in W-format (csrc/npp_layout.h): fp16
- *                  pre-activations of the snake layers, bf16 f1 / f2, bf16 embedding slots
- *  sizes[2] dzF    pre-activation gradients, bf16 fragments in W-format
+ *  sizes[1] actF   forward stash: the 16-bit W-format region (csrc/npp_layout.h: fp16 pre-activations of the snake layers, bf16
+ *                  f1 / f2, bf16 embedding slots) followed by the 8-bit W8-format region of the same k-step table; with
+ *                  npp_tune("stash8") = 1 the first region holds the snake'(z) bytes (at W8 size) and the second the fp8 arrays,
+ *                  with 0 only the first is used -- one allocation serves both settings
+ *  sizes[2] dzF    pre-activation gradients: bf16 fragments in W-format, or (stash8) bf8 units in W8-format + one int32 scale
+ *                  word per 64-row tile behind them (fits the same allocation)
  *  sizes[3] grad slabs (ksplit * S * 4 bytes, S = the parameter count rounded up to a multiple of 4 floats: the slab stride) */
 int npp_train_workspace(int K, int width, int64_t Bp, int ksplit, int64_t sizes[4]);
 
@@ -628,6 +640,20 @@ int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params
                   const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
                   const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
                   float* d_draw, float* d_dstash, void* stream);
+/* Bit-reproducible forms (round 6; the reference's candidate fits are not -- cuBLAS / atomics -- but rankings with near-equal scores
+ * should not depend on arrival order): npp_light_bwd_det = npp_light_bwd with the pixel loss folded in (d_gt required) whose per-block
+ * loss / latent-gradient sums go to d_part (C, npp_light_part_blocks(C, B), 8) by plain stores; npp_light_adam_pack_det adds them in
+ * block order (latent gradients = d_dlat + the blocks' sums; d_loss_cur[c] += the blocks' loss terms, nullable).  With
+ * npp_tune("light_det") = 1 (default) npp_light_wgrad does not split its contraction (no float atomicAdd): the whole candidate fit
+ * has no order-dependent float sum left.  NPP_proposal/search.py:113-147. */
+int npp_light_part_blocks(int C, int64_t B);
+int npp_light_bwd_det(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                      const float* d_stash, const float* d_pred, const float* d_gt, const float* d_latents, const float* d_spline,
+                      int n_knots, float x_scale, float* d_part, int C, int64_t B, float* d_draw, float* d_dstash, void* stream);
+int npp_light_adam_pack_det(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n,
+                            int C, float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat,
+                            float* d_zero, float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part,
+                            float* d_loss_cur, void* stream);
 /* ---- f1 on the 16-bit matrix pipe (csrc/npp_light16.hip): the same chains with bf16 operands, fp32 accumulation and fp32 master
  * weights -- the numeric contract of the main loop's coordinate MLP (npp_mlp_fwd / npp_mlp_bwd / npp_mlp_wgrad), models/networks.py:176-263,
  * NPP_proposal/search.py:113-147.  B a multiple of 64.  Per candidate: a bf16 pack of npp_light16_pack_bytes() bytes (forward and
@@ -675,6 +701,12 @@ int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, void* stream);
  * candidate score of NPP_proposal/search.py:193): d_out[0] += scale * sum_n mean_pos sum_c lin_c (f0n - f1n)^2. */
 int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin,
                           float scale, float* d_out, void* stream);
+/* The same with the workgroups' partial sums added in block order instead of by float atomics (the candidate SCORES that rank the
+ * proposals, NPP_proposal/search.py:193, are then bit-reproducible): d_scratch = NPP_LPIPS_PLAIN_SCRATCH_FLOATS floats, zeroed once by
+ * the caller (each launch re-arms it); launches that may run concurrently need scratches of their own. */
+#define NPP_LPIPS_PLAIN_SCRATCH_FLOATS 264
+int npp_lpips_plain_layer_det(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale, float* d_out,
+                              float* d_scratch, void* stream);
 
 /* ---- remapping variant: Gram-matrix style loss (models/style_loss.py:37-74) ----------------- */
 /* G[n] = F[n] F[n]^T for (N, C, hw) features and its backward dF[n] = (dG[n] + dG[n]^T) F[n]; the per-element adaptive

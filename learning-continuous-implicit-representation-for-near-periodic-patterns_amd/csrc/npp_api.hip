@@ -325,7 +325,7 @@ static int tune_env(const char* name, int dflt) {
   return e && *e ? atoi(e) : dflt;
 }
 Tunables g_tune = {tune_env("NPP_CONV_WINK", 1), tune_env("NPP_CONV_WIN", 1), tune_env("NPP_CONV_WSTAT", 1), tune_env("NPP_CONV_PAIR", 15),
-                   tune_env("NPP_STASH8", 1)};
+                   tune_env("NPP_LIGHT_DET", 1), tune_env("NPP_STASH8", 1)};
 
 }  // namespace npp
 
@@ -338,7 +338,7 @@ int npp_version(void) { return 100; }
 int npp_tune(const char* key, int value) {
   struct { const char* k; int* v; } tab[] = {{"conv_wink", &g_tune.conv_wink}, {"conv_win", &g_tune.conv_win},
                                              {"conv_wstat", &g_tune.conv_wstat}, {"conv_pair", &g_tune.conv_pair},
-                                             {"stash8", &g_tune.stash8}};
+                                             {"stash8", &g_tune.stash8}, {"light_det", &g_tune.light_det}};
   if (key)
     for (auto& t : tab)
       if (!strcmp(key, t.k)) {

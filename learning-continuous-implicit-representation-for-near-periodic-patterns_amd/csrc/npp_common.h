@@ -30,6 +30,7 @@ struct Tunables {
   int conv_win;       // 1: window-staged convolution on conv1_1 / conv1_2 / conv2_1 forward; 0: never; 2: wherever feasible
   int conv_wstat;     // 1: weight-stationary block numbering where the pack outweighs the activations; 0: never
   int conv_pair;      // bit mask of the fused convolution pairs (conv a -> conv b -> pool) the trunks use: 1 = first block, 2 = second, 4 = the first block's data gradient, 8 = patch plumbing + pixel loss inside the first pair; 0: never
+  int light_det;      // 1 (default): the proposal-ranking fits' fp32 weight-gradient launch does not split its contraction (no float atomics on the gradient path: bit-reproducible fits); 0: split-K by atomicAdd
   int stash8;         // 1 (default): the training stash that feeds the weight gradients is 8-bit (bf8 gradients with a per-tile power-of-two scale, fp8 layer inputs; npp_layout.h "W8-format") and npp_mlp_wgrad runs on v_mfma_scale_f32_32x32x64_f8f6f4; 0: the round-2..5 16-bit stash and bf16 weight-gradient launch.  Read by npp_mlp_fwd* / npp_mlp_bwd* / npp_mlp_wgrad* at launch: flip it only between complete iterations
 };
 extern Tunables g_tune;

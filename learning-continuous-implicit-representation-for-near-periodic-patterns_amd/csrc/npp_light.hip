@@ -59,6 +59,7 @@ struct LightArgs {
   const float* gt;                              // backward with the pixel loss folded in: targets (B, 3) ... (null: d pred is an input)
   const float* latents; const float* spline; int n_knots; float x_scale;      // ... its adaptive-loss latents (C, 6) and spline table
   float* loss; float* dlatent;                  // ... and where the loss words (C) / latent gradients (C, 6) accumulate
+  float* part;                                  // npp_light_bwd_det: (C, blocks, 8) -- every block leaves its seven sums here instead (no atomics)
 };
 
 // ---- packs ----------------------------------------------------------------------------------------------------------------
@@ -104,6 +105,7 @@ struct LightAdamArgs {
   float* pack; int64_t pack_stride;
   float *lat, *lat_m, *lat_v, *dlat, *zero;               // (C, 6) x 4, (C)
   float step_size, b1, b2, inv_sqrt_bc2, eps;
+  const float* part; int32_t n_part; float* loss_cur;     // npp_light_adam_pack_det: the blocks' partial sums, added here in block order
 };
 __global__ __launch_bounds__(256) void light_adam_pack_kernel(LightAdamArgs a, LightPackDesc pd) {
   const int c = blockIdx.y;
@@ -111,10 +113,18 @@ __global__ __launch_bounds__(256) void light_adam_pack_kernel(LightAdamArgs a, L
     const int t = threadIdx.x;
     if (t < 6) {
       const int i = c * 6 + t;
+      float g = a.dlat[i];
+      if (a.part)                                             // fixed order: bit-reproducible latent gradients
+        for (int b = 0; b < a.n_part; ++b) g += a.part[((int64_t)c * a.n_part + b) * 8 + 1 + t];
       float m = a.lat_m[i], v = a.lat_v[i];
-      a.lat[i] = adam_update(a.lat[i], m, v, a.dlat[i], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+      a.lat[i] = adam_update(a.lat[i], m, v, g, a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
       a.lat_m[i] = m; a.lat_v[i] = v; a.dlat[i] = 0.0f;
     } else if (t == 6 && a.zero) a.zero[c] = 0.0f;
+    else if (t == 64 && a.part && a.loss_cur) {               // (another wave: the two sums run side by side)
+      float l = 0.0f;
+      for (int b = 0; b < a.n_part; ++b) l += a.part[((int64_t)c * a.n_part + b) * 8];
+      a.loss_cur[c] += l;
+    }
     return;
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -327,11 +337,13 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
   // (models/mse_calculator.py:13-27 without a mask: the arithmetic of pixel_loss_body, npp_common.h), loss / latent gradients by atomics
   __shared__ ChanParams cp[3];
   __shared__ float sred[7];
+  __shared__ float swv[kLThreads / 64][7];
   if (a.gt) {
     if (tid < 3) cp[tid] = chan_params(a.latents[c * 6 + tid], a.latents[c * 6 + 3 + tid], a.spline, a.n_knots, a.x_scale);
     if (tid < 7) sred[tid] = 0.0f;
     wg_barrier();
   }
+  float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;                 // this thread's loss term and latent-gradient terms (channel tid % 3)
   if (tid < RT * 3) {
     const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
     const float p = a.pred[g];
@@ -345,9 +357,14 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
       const float u = ssx / q.beta + 1.0f, e = 0.5f * q.alpha, lnu = logf(u);
       const float ue = expf(e * lnu), ue1 = ue / u;
       dp = inv * (x / (q.c * q.c)) * ue1;
-      atomicAdd(&sred[0], (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz);
-      atomicAdd(&sred[1 + ch], -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz);
-      atomicAdd(&sred[4 + ch], -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c);
+      t0 = (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz;
+      t1 = -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz;
+      t2 = -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c;
+      if (!a.part) {
+        atomicAdd(&sred[0], t0);
+        atomicAdd(&sred[1 + ch], t1);
+        atomicAdd(&sred[4 + ch], t2);
+      }
     } else {
       dp = a.dpred[g];
     }
@@ -356,12 +373,34 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
     sD[tid] = d;
     D[(int64_t)(LD_RAW + tid % 3) * B + row0 + tid / 3] = d;       // d raw^T for rgb_linear's weight gradient
   }
+  if (a.gt && a.part) {
+    // deterministic form (every wave, whole: threads past the 3 RT values carry zeros): the seven sums of a wave by shuffle
+    // butterflies -- a fixed tree, masked-out lanes add exact zeros -- then the waves' results in wave order
+    const int ch = tid % 3;
+    const float v7[7] = {t0, ch == 0 ? t1 : 0.0f, ch == 1 ? t1 : 0.0f, ch == 2 ? t1 : 0.0f, ch == 0 ? t2 : 0.0f, ch == 1 ? t2 : 0.0f, ch == 2 ? t2 : 0.0f};
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7) {
+      float v = v7[k7];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) swv[wave][k7] = v;
+    }
+  }
   wg_barrier();
   if (a.gt && tid < 7) {
-    const float inv = 1.0f / (3.0f * (float)B), v = sred[tid];
-    if (tid == 0) atomicAdd(a.loss + c, v * inv);
-    else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
-    else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+    const float inv = 1.0f / (3.0f * (float)B);
+    if (a.part) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w_ = 0; w_ < kLThreads / 64; ++w_) v += swv[w_][tid];                        // wave order
+      const float o = tid == 0 ? v * inv : (tid < 4 ? inv * v * cp[tid - 1].dalpha_dl : inv * v * cp[tid - 4].dc_dl);
+      a.part[((int64_t)c * gridDim.x + blockIdx.x) * 8 + tid] = o;                          // summed in block order by npp_light_adam_pack_det
+    } else {
+      const float v = sred[tid];
+      if (tid == 0) atomicAdd(a.loss + c, v * inv);
+      else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
+      else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+    }
   }
   // d a_p = d raw W_rgb; d z_p = d a_p * snake'(z_p) -> region rows 0..127 + stash
   {
@@ -489,10 +528,35 @@ extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int
   return check_launch("npp_light_fwd");
 }
 
+extern "C" int npp_light_part_blocks(int C, int64_t B) { return (C < 1 || B < 32 || B % 32) ? NPP_ERR_ARG : (int)(B / light_rows_per_wg(C, B, true)); }
+
+static int light_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                        const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
+                        const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
+                        float* d_draw, float* d_dstash, float* d_part, void* stream);
+
 extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                              const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
                              const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
                              float* d_draw, float* d_dstash, void* stream) {
+  return light_bwd_go(L, d_params, params_stride, d_pack, pack_stride, d_stash, d_pred, d_dpred, d_gt, d_latents, d_spline, n_knots, x_scale,
+                      d_loss, d_dlatent, C, B, d_draw, d_dstash, nullptr, stream);
+}
+
+// npp_light_bwd with the folded pixel loss's sums left per block in d_part (C, npp_light_part_blocks(C, B), 8) instead of added to
+// d_loss / d_dlatent by float atomics: npp_light_adam_pack_det adds them in block order -- candidate fits are bit-reproducible
+extern "C" int npp_light_bwd_det(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                                 const float* d_stash, const float* d_pred, const float* d_gt, const float* d_latents, const float* d_spline,
+                                 int n_knots, float x_scale, float* d_part, int C, int64_t B, float* d_draw, float* d_dstash, void* stream) {
+  if (!d_gt || !d_part) { set_error("npp_light_bwd_det: d_gt and d_part are required"); return NPP_ERR_ARG; }
+  return light_bwd_go(L, d_params, params_stride, d_pack, pack_stride, d_stash, d_pred, nullptr, d_gt, d_latents, d_spline, n_knots, x_scale,
+                      d_part, d_part, C, B, d_draw, d_dstash, d_part, stream);
+}
+
+static int light_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                        const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
+                        const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
+                        float* d_draw, float* d_dstash, float* d_part, void* stream) {
   int rc = light_check(L, d_params, d_pack, C, B, "npp_light_bwd");
   if (rc) return rc;
   if (!d_stash || !d_pred || !d_draw || !d_dstash || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || !d_loss || !d_dlatent) : !d_dpred)) {
@@ -503,6 +567,7 @@ extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
   a.stash = (float*)d_stash; a.pred = (float*)d_pred; a.dpred = d_dpred; a.draw = d_draw; a.dstash = d_dstash; a.B = B;
   a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
+  a.part = d_part;
   if (light_rows_per_wg(C, B, true) == 64) {
     static SmemOnce once;
     if (!smem_attr(once, (const void*)light_bwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
@@ -517,9 +582,28 @@ extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int
   return check_launch("npp_light_bwd");
 }
 
+static int light_adam_go(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n, int C,
+                         float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                         float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part, float* d_loss_cur, void* stream);
 extern "C" int npp_light_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n, int C,
                                    float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
                                    float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  return light_adam_go(L, d_params, d_m, d_v, d_grad, stride, n, C, d_pack, pack_stride, d_lat, d_lat_m, d_lat_v, d_dlat, d_zero, lr, beta1, beta2,
+                       eps, step, nullptr, 0, nullptr, stream);
+}
+// npp_light_adam_pack after npp_light_bwd_det: the latent gradients are d_dlat (+) the n_part per-block sums of d_part in block order,
+// and the iteration's loss word d_loss_cur[c] (nullable) receives the blocks' loss terms the same way
+extern "C" int npp_light_adam_pack_det(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n,
+                                       int C, float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat,
+                                       float* d_zero, float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part,
+                                       float* d_loss_cur, void* stream) {
+  if (!d_part || n_part < 1) { set_error("npp_light_adam_pack_det: d_part / n_part"); return NPP_ERR_ARG; }
+  return light_adam_go(L, d_params, d_m, d_v, d_grad, stride, n, C, d_pack, pack_stride, d_lat, d_lat_m, d_lat_v, d_dlat, d_zero, lr, beta1, beta2,
+                       eps, step, d_part, n_part, d_loss_cur, stream);
+}
+static int light_adam_go(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, float* d_grad, int64_t stride, int64_t n, int C,
+                         float* d_pack, int64_t pack_stride, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                         float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part, float* d_loss_cur, void* stream) {
   int rc = light_check(L, d_params, d_pack, C, 32, "npp_light_adam_pack");
   if (rc) return rc;
   const LightPackDesc pd = light_pack_desc();
@@ -534,6 +618,7 @@ extern "C" int npp_light_adam_pack(const npp_light_desc* L, float* d_params, flo
   a.pack = d_pack; a.pack_stride = pack_stride;
   a.lat = d_lat; a.lat_m = d_lat_m; a.lat_v = d_lat_v; a.dlat = d_dlat; a.zero = d_zero;
   a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+  a.part = d_part; a.n_part = n_part; a.loss_cur = d_loss_cur;
   hipLaunchKernelGGL(light_adam_pack_kernel, dim3((unsigned)((n + 255) / 256 + 1), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd);
   return check_launch("npp_light_adam_pack");
 }

@@ -222,8 +222,10 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, int64_t n, int act, 
 
 // LPIPS.forward(use_robust=False), one tap (lpips.py:99-101,110,117,130): sum over (n, pos) of
 // sum_c lin_c (f0_c / (|f0| + eps) - f1_c / (|f1| + eps))^2, scaled by coef.  16 positions x 16 channel lanes per block.
+// scratch (nullable): [gridDim.x partial sums | arrival counter], zero before the first launch that uses it -- the block that arrives
+// last adds the partials in block order (bit-reproducible score); null: one float atomicAdd per block
 __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restrict__ f0, const float* __restrict__ f1, int N, int C, int hw,
-                                                          const float* __restrict__ lin, float coef, float* __restrict__ out) {
+                                                          const float* __restrict__ lin, float coef, float* __restrict__ out, float* scratch) {
   __shared__ float red[2][16][17];
   __shared__ float tot[4];
   const int pl = threadIdx.x & 15, cl = threadIdx.x >> 4;
@@ -259,7 +261,16 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
+  if (!scratch) {
+    if (threadIdx.x == 0) atomicAdd(out, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
+    return;
+  }
+  if (threadIdx.x == 0) share_store(scratch + blockIdx.x, coef * (tot[0] + tot[1] + tot[2] + tot[3]));
+  if (block_last_arriver((unsigned*)(scratch + gridDim.x), (int)gridDim.x) && threadIdx.x == 0) {
+    float s = 0.0f;
+    for (unsigned b = 0; b < gridDim.x; ++b) s += share_load(scratch + b);
+    *out += s;                                   // (the taps of a score are consecutive launches on one stream: one writer at a time)
+  }
 }
 
 // Per-element adaptive robust NLL (robust_loss_pytorch/adaptive.py:183-204 with num_dims = D latents): one thread per
@@ -517,7 +528,13 @@ extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, co
     //  atomic adds were half of the launch: 215 -> 184 us per iteration)
     static const int gfill = [] { const char* e = getenv("NPP_LIGHT_WGRAD_FILL"); return e ? atoi(e) : 160; }();
     static const int gfill1 = [] { const char* e = getenv("NPP_LIGHT_WGRAD_FILL1"); return e ? atoi(e) : 128; }();
-    const dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : gfill1);
+    // npp_tune "light_det" (default 1): no split of the contraction -- every output element is the plain-store result of ONE
+    // workgroup's fixed-order sum (split partial sums meet by float atomicAdd in arrival order): bit-reproducible candidate fits
+    dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : gfill1);
+    if (g.splits > 1 && __atomic_load_n(&g_tune.light_det, __ATOMIC_RELAXED)) {
+      g.splits = 1; g.kchunk = (g.K + 31) / 32 * 32;
+      grid.z = (unsigned)(g.nbatch > 1 ? g.nbatch : 1);
+    }
     G.first_wg[i] = wg; G.gx[i] = (int)grid.x; G.gy[i] = (int)grid.y;
     wg += (int)(grid.x * grid.y * grid.z);
   }
@@ -544,15 +561,28 @@ extern "C" int npp_act_fwd(const float* d_x, int64_t n, int act, float* d_y, voi
   return check_launch("npp_act_fwd");
 }
 
+static int lpips_plain_go(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale, float* d_out,
+                          float* d_scratch, void* stream);
 extern "C" int npp_lpips_plain_layer(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale,
                                      float* d_out, void* stream) {
+  return lpips_plain_go(d_f0, d_f1, N, C, hw, d_lin, scale, d_out, nullptr, stream);
+}
+// the same with the blocks' partial sums added in block order (bit-reproducible): d_scratch = NPP_LPIPS_PLAIN_SCRATCH_FLOATS floats,
+// zeroed once by the caller (the launch re-arms it), not shared by launches that may run concurrently
+extern "C" int npp_lpips_plain_layer_det(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale,
+                                         float* d_out, float* d_scratch, void* stream) {
+  if (!d_scratch) { set_error("npp_lpips_plain_layer_det: null scratch"); return NPP_ERR_ARG; }
+  return lpips_plain_go(d_f0, d_f1, N, C, hw, d_lin, scale, d_out, d_scratch, stream);
+}
+static int lpips_plain_go(const float* d_f0, const float* d_f1, int N, int C, int hw, const float* d_lin, float scale, float* d_out,
+                          float* d_scratch, void* stream) {
   if (!d_f0 || !d_f1 || !d_lin || !d_out || N < 1 || C < 16 || (C % 16) || hw < 1) {
     set_error("npp_lpips_plain_layer: bad arguments (N=%d C=%d hw=%d)", N, C, hw);
     return NPP_ERR_ARG;
   }
   const int64_t groups = ((int64_t)N * hw + 15) / 16;
   hipLaunchKernelGGL(lpips_plain_kernel, dim3((unsigned)(groups < 256 ? groups : 256)), dim3(256), 0, (hipStream_t)stream, d_f0, d_f1, N, C,
-                     hw, d_lin, scale / (float)hw, d_out);
+                     hw, d_lin, scale / (float)hw, d_out, d_scratch);
   return check_launch("npp_lpips_plain_layer");
 }
 

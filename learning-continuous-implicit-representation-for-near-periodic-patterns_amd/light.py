@@ -424,6 +424,14 @@ class NPPNetLightBatch:
         if self.quad > 0:
             ops.pixel_loss_quad(ws["pred"], gt, None, self.quad, 1.0, loss, ws["dpred"])
             ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], ws["dpred"], ws["draw"], D_)
+        elif ops.DETERMINISTIC and self.fused_adam:
+            # bit-reproducible fit: the blocks' loss / latent-gradient sums by plain stores, added in block order by the Adam launch
+            part = ws.get("part")
+            if part is None:
+                part = ws["part"] = torch.zeros(self.C, ops.light_part_blocks(self.C, B), 8, dtype=torch.float32, device=self.device)
+            ops.light_bwd_det(self._desc, self.params, self._pack, S, ws["pred"], ws["draw"], D_, gt, self.latents, self.spline, self.n_knots,
+                              self.x_scale, part)
+            self._part = part
         else:
             ops.light_bwd(self._desc, self.params, self._pack, S, ws["pred"], None, ws["draw"], D_,
                           loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
@@ -512,8 +520,13 @@ class NPPNetLightBatch:
         self._li ^= 1
         if self.fused_adam:
             # optimizer.step() + zero_grad() + the packs of the next forward, one launch (csrc/npp_light.hip)
-            ops.light_adam_pack(self._desc, self.params, self.m, self.v, self.grad, self.n_params, self._pack, self.latents, self.lat_m, self.lat_v,
-                                self._dl_c, self._loss2[self._li], lr, step)
+            part, self._part = getattr(self, "_part", None), None
+            if part is not None:
+                ops.light_adam_pack_det(self._desc, self.params, self.m, self.v, self.grad, self.n_params, self._pack, self.latents, self.lat_m,
+                                        self.lat_v, self._dl_c, self._loss2[self._li], lr, step, part, loss)
+            else:
+                ops.light_adam_pack(self._desc, self.params, self.m, self.v, self.grad, self.n_params, self._pack, self.latents, self.lat_m, self.lat_v,
+                                    self._dl_c, self._loss2[self._li], lr, step)
             self._pack_valid, self._pack16_valid = True, False
         else:
             ops.adam_step_net(self.params.view(-1), self.m.view(-1), self.v.view(-1), self.grad.view(-1), 1, self.params.numel(),

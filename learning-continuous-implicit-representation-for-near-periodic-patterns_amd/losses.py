@@ -586,8 +586,16 @@ class LPIPS(nn.Module):
         n = in0.shape[0]
         feats = self.hip_trunk._forward(torch.cat([in0, in1], 0).contiguous(), sc, sh)
         out = torch.zeros(1, dtype=torch.float32, device=in0.device)
+        ws = None
+        if ops.DETERMINISTIC:                           # fixed-order sums: the score that ranks the proposals is bit-reproducible
+            key = torch.cuda.current_stream(in0.device).cuda_stream      # (one scratch per stream: search threads score side by side)
+            ws = self._plain_ws.get(key) if hasattr(self, "_plain_ws") else None
+            if ws is None:
+                if not hasattr(self, "_plain_ws"):
+                    self._plain_ws = {}
+                ws = self._plain_ws[key] = torch.zeros(len(feats), ops.LPIPS_PLAIN_SCRATCH, dtype=torch.float32, device=in0.device)
         for kk, f in enumerate(feats):
-            ops.lpips_plain_layer(f[:n], f[n:], self.lins[kk], 1.0, out)
+            ops.lpips_plain_layer(f[:n], f[n:], self.lins[kk], 1.0, out, None if ws is None else ws[kk])
         return out
 
     def zero_latent_grads(self):

@@ -12,7 +12,8 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def tune(key, value=-1):
-    """npp_tune: choose between kernel forms that compute the same result ("conv_wink", "conv_win", "conv_wstat", "conv_pair");
+    """npp_tune: choose between kernel forms that compute the same result ("conv_wink", "conv_win", "conv_wstat", "conv_pair", "light_det")
+    or the training stash's format ("stash8": 1 = 8-bit stash + fp8 weight-gradient MFMA (default), 0 = the 16-bit stash);
     value < 0 only reads.  -> the previous value.  Both fused-width libraries are set (the trunk kernels live in the first)."""
     from ._lib import FUSED_WIDTHS
     old = None
@@ -825,6 +826,29 @@ def light_adam_pack(desc, params, m, v, grad, n, pack, lat, lat_m, lat_v, dlat, 
                                     _p(lat_m), _p(lat_v), _p(dlat), _p(zero), lr, b1, b2, eps, step, _stream()), "npp_light_adam_pack")
 
 
+def light_part_blocks(C, B):
+    return int(check(lib().npp_light_part_blocks(C, B), "npp_light_part_blocks"))
+
+
+def light_bwd_det(desc, params, pack, stash, pred, draw, dstash, gt, lat, spline, n_knots, x_scale, part):
+    """light_bwd with the adaptive pixel loss folded in, its per-block sums to part (C, light_part_blocks(C, B), 8) by plain stores."""
+    import ctypes
+    C, B = pred.shape[:2]
+    assert all(t.is_contiguous() for t in (stash, pred, draw, dstash, part, gt, lat)) and part.shape == (C, light_part_blocks(C, B), 8)
+    check(lib().npp_light_bwd_det(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(gt), _p(lat),
+                                  _p(spline), n_knots, x_scale, _p(part), C, B, _p(draw), _p(dstash), _stream()), "npp_light_bwd_det")
+
+
+def light_adam_pack_det(desc, params, m, v, grad, n, pack, lat, lat_m, lat_v, dlat, zero, lr, step, part, loss_cur, b1=0.9, b2=0.999, eps=1e-8):
+    """light_adam_pack after light_bwd_det: the blocks' sums are added in block order (latent gradients, loss_cur (C))."""
+    import ctypes
+    C = params.shape[0]
+    assert part.is_contiguous() and part.shape[0] == C and part.shape[2] == 8
+    check(lib().npp_light_adam_pack_det(ctypes.byref(desc), _p(params), _p(m), _p(v), _p(grad), params.stride(0), n, C, _p(pack), pack.stride(0), _p(lat),
+                                        _p(lat_m), _p(lat_v), _p(dlat), _p(zero), lr, b1, b2, eps, step, _p(part), part.shape[1], _p(loss_cur), _stream()),
+          "npp_light_adam_pack_det")
+
+
 def light_wgrad(desc, stash, dstash, grad):
     """All seven weight / bias gradients of the C candidates in one launch: grad (C, n) += ... (clear first)."""
     import ctypes
@@ -939,10 +963,19 @@ def act_fwd(x, act, y):
     return y
 
 
-def lpips_plain_layer(f0, f1, lin, scale, out):
+LPIPS_PLAIN_SCRATCH = 264               # NPP_LPIPS_PLAIN_SCRATCH_FLOATS (include/npp_hip.h)
+
+
+def lpips_plain_layer(f0, f1, lin, scale, out, scratch=None):
+    """scratch (LPIPS_PLAIN_SCRATCH zeroed floats, one per tap launched back to back): the fixed-order, bit-reproducible form."""
     _req(f0, torch.float32, "f0")
     _req(f1, torch.float32, "f1", f0.shape)
     N, C = f0.shape[:2]
+    if scratch is not None:
+        assert scratch.dtype == torch.float32 and scratch.numel() >= LPIPS_PLAIN_SCRATCH and scratch.is_contiguous()
+        check(lib().npp_lpips_plain_layer_det(_p(f0), _p(f1), N, C, f0.shape[2] * f0.shape[3], _p(lin), scale, _p(out), _p(scratch), _stream()),
+              "npp_lpips_plain_layer_det")
+        return
     check(lib().npp_lpips_plain_layer(_p(f0), _p(f1), N, C, f0.shape[2] * f0.shape[3], _p(lin), scale, _p(out), _stream()),
           "npp_lpips_plain_layer")
 
