@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c4 embedder and full-loop extras")
     ap.add_argument("--ksplit", type=int, default=0, help="split-K of the weight-gradient launch; 0 = auto (CUs / tiles)")
+    ap.add_argument("--windows", type=int, default=WINDOWS, help="consecutive --steps windows of the sampling loop whose median is `value` "
+                    "(0: profiling runs -- only the pre-drawn-pool loop is run and reported, marked as such)")
     ap.add_argument("--pool", type=int, default=40, help="pre-drawn sampler outputs the timed steps cycle through (a multiple of 10: the "
                     "sampler's 50 / 30 / 20 % source mix is then held exactly)")
     return ap.parse_args()
@@ -315,20 +317,22 @@ def main():
     dev_only_ms_per_step = dt / args.steps * 1e3
     dev_only_value = world * n_rows * args.steps / dt
     dev_only_per_rank = per_rank
+    mix_timed_dev = {s_: sum(pool[i % len(pool)]["source"] == s_ for i in range(args.steps)) for s_ in ("val", "train", "same")}
 
     # ---- THE HEADLINE: the loop that samples.  Own image / weights per rank, the SAME reference stream (seed 0)
     #      on every rank so that the per-window patch-source mix -- 'same' iterations cost ~1.2x a 'val' one -- is identical on
     #      every GPU (weak scaling: per-GPU work fixed as N grows).  WINDOWS windows of exactly --steps iterations, each between
     #      barrier + synchronize on both sides, max over ranks per window; reported: the median window. ----
+    NW = max(0, int(args.windows))
     fe = CompletionFit(img, mask, angles, periods, syn.SEED0_FREQS, syn.init_params(K, seed=rank), device=dev, N_rand=8192,
                        ksplit=args.ksplit, seed=0, shifts=shifts, rng_mode="reference", prefetch=8)
-    for _ in range(max(args.warmup, 20)):
+    for _ in range(max(args.warmup, 20) if NW else 0):
         fe.step_full()
     barrier()
     gc.collect()
     gc.disable()
     win_dt, win_ok, win_mix = [], [], []
-    for w_ in range(WINDOWS):
+    for w_ in range(NW):
         n_ok, mix_w = 0, {"val": 0, "train": 0, "same": 0}
         barrier()
         t0 = time.perf_counter()
@@ -346,12 +350,15 @@ def main():
         win_ok.append(n_ok)
         win_mix.append(mix_w)
     gc.enable()
-    order = sorted(range(WINDOWS), key=lambda i_: win_dt[i_] / max(win_ok[i_], 1))
-    med = order[WINDOWS // 2]
+    if NW == 0:                                  # --windows 0 (profiling): the line reports the pre-drawn-pool loop and says so
+        win_dt, win_ok, win_mix = [dev_only_ms_per_step * args.steps * 1e-3], [args.steps], [dict(mix_timed_dev)]
+        NW = 1
+    order = sorted(range(NW), key=lambda i_: win_dt[i_] / max(win_ok[i_], 1))
+    med = order[NW // 2]
     dt = win_dt[med]
     ms_per_step = dt / args.steps * 1e3
     value = world * n_rows * win_ok[med] / dt
-    win_rates = [world * n_rows * win_ok[i_] / win_dt[i_] for i_ in range(WINDOWS)]
+    win_rates = [world * n_rows * win_ok[i_] / win_dt[i_] for i_ in range(NW)]
     per_rank = None
     if dist is not None:
         t = torch.tensor([n_rows * win_ok[med] / dt], dtype=torch.float64, device=dev)
@@ -988,7 +995,8 @@ def main():
                        "images_per_gpu": 1, "patch_size": patch, "patch_source_mix_in_pool": mix,
                        "trunk_dtype": "fp16 forward / bf16 gradient MFMA, fp32 accumulate",
                        # flat copies of the report's other headline numbers (the driver's parser keeps scalars of `config` only)
-                       "value_is": f"median of {WINDOWS} consecutive windows of --steps iterations of the loop that samples (reference random stream, producer thread)",
+                       "value_is": (f"median of {args.windows} consecutive windows of --steps iterations of the loop that samples (reference random stream, producer thread)"
+                                    if args.windows > 0 else "--windows 0: the pre-drawn-pool loop (device only) -- a profiling run, not the headline definition"),
                        "window_rows_per_s_min": min(win_rates), "window_rows_per_s_max": max(win_rates),
                        "window_rows_per_s_all": ", ".join(f"{r_:.4g}" for r_ in win_rates),
                        "timed_source_mix": f"val {win_mix[med]['val']} / train {win_mix[med]['train']} / same {win_mix[med]['same']} (the median window; the stream's own draw)",

@@ -9,7 +9,8 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 # the profiled program: the bench's timed loop, or NPP_PROFILE_CMD (e.g. "tools/r5_stack_prof.py 8 60" for the stacked loop)
-B="$ROOT/${NPP_PROFILE_CMD:-bench.py --no-cpu-baseline --no-psnr --no-extras --steps 60 --warmup 10}"
+# (--windows 0: only the pre-drawn-pool loop -- under rocprofv3 the sampling loop is host-bound, its gaps would fill the sequence table)
+B="$ROOT/${NPP_PROFILE_CMD:-bench.py --no-cpu-baseline --no-psnr --no-extras --steps 100 --warmup 10 --windows 0}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $B > $OUT/stats.log 2>&1
 echo "stats done"
