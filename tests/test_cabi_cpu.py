@@ -64,6 +64,25 @@ def test_bad_arguments_are_reported_not_crashed():
     assert sizes[3] == 4 * 1197316 * 4                       # 4 slabs of the parameter count rounded up to 4 floats (16-byte aligned slabs)
 
 
+def test_stash8_switch_and_its_host_side_checks():
+    """npp_tune("stash8") (round 6: the 8-bit training stash, default on) reads / writes / rejects like the other keys; the forward
+    stash of npp_train_workspace holds both formats; the 8-bit weight-gradient launch refuses a split whose per-tile scale words do
+    not fit its LDS -- on the host, before anything is launched -- and the deterministic f1 entry points check their scratch."""
+    L = npp_amd.lib()
+    assert L.npp_tune(b"stash8", -1) == 1 and L.npp_tune(b"light_det", -1) == 1
+    assert L.npp_tune(b"stash8", 0) == 1 and L.npp_tune(b"stash8", -1) == 0 and L.npp_tune(b"stash8", 1) == 0
+    assert L.npp_tune(b"no_such_key", 1) < 0
+    sizes = (C.c_int64 * 4)()
+    assert L.npp_train_workspace(3, 256, 64, 1, sizes) == 0
+    n_ks = 11 * 16 + 8 + 3 * 30                                        # k-steps of the forward arrays (csrc/npp_layout.h act_total_ks)
+    assert sizes[1] == n_ks * (2048 + 1024) and sizes[2] == (11 * 16 + 8 + 2) * 2048
+    fake = C.c_void_p(64)                                             # never dereferenced: validation comes first
+    assert L.npp_mlp_wgrad(fake, fake, 64 * 65536, 3, 256, 1, fake, None) < 0
+    assert b"raise ksplit" in L.npp_last_error_string()
+    assert L.npp_lpips_plain_layer_det(fake, fake, 1, 64, 100, fake, 1.0, fake, None, None) < 0
+    assert L.npp_light_part_blocks(9, 100) < 0 and L.npp_light_part_blocks(9, 2048) in (32, 64) and L.npp_light_part_blocks(64, 2048) == 32
+
+
 def test_light_chain_entry_points_validate_on_the_host():
     """The fused NPP_Net_light entry points refuse topologies / shapes they are not built for before anything is launched (no GPU
     needed to see it), and their layout queries are consistent."""
