@@ -647,6 +647,16 @@ int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params
  * npp_tune("light_det") = 1 (default) npp_light_wgrad does not split its contraction (no float atomicAdd): the whole candidate fit
  * has no order-dependent float sum left.  NPP_proposal/search.py:113-147. */
 int npp_light_part_blocks(int C, int64_t B);
+/* "multi" forms: candidate c = ONE IMAGE's fit (the searches of several images of a rank advanced in one launch sequence: candidate k of
+ * every image together, where run_completion.sh / search.py:85-215 walk images and candidates one after the other): per candidate its own
+ * positional table d_x_pos (C, n_src, 42), periodic table d_x_per (C, n_src, 20) as before, pixel rows d_idx (C, B) into its own tables
+ * (shorter tables padded to n_src rows) and targets d_gt (C, B, 3). */
+int npp_light_fwd_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                        const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
+                        float* d_pred, void* stream);
+int npp_light_bwd_det_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                            const float* d_stash, const float* d_pred, const float* d_gt, const float* d_latents, const float* d_spline,
+                            int n_knots, float x_scale, float* d_part, int C, int64_t B, float* d_draw, float* d_dstash, void* stream);
 int npp_light_bwd_det(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                       const float* d_stash, const float* d_pred, const float* d_gt, const float* d_latents, const float* d_spline,
                       int n_knots, float x_scale, float* d_part, int C, int64_t B, float* d_draw, float* d_dstash, void* stream);

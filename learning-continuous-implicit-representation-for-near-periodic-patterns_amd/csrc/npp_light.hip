@@ -60,6 +60,8 @@ struct LightArgs {
   const float* latents; const float* spline; int n_knots; float x_scale;      // ... its adaptive-loss latents (C, 6) and spline table
   float* loss; float* dlatent;                  // ... and where the loss words (C) / latent gradients (C, 6) accumulate
   float* part;                                  // npp_light_bwd_det: (C, blocks, 8) -- every block leaves its seven sums here instead (no atomics)
+  // "multi" forms (candidate = one IMAGE's fit: its own pixel rows, positional table and targets): elements per candidate, 0 = shared
+  int64_t x_pos_cs, idx_cs, gt_cs;
 };
 
 // ---- packs ----------------------------------------------------------------------------------------------------------------
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
     float* Rf = (float*)R;
     for (int i = tid; i < 32 * RT; i += kLThreads) {
       const int f = i / RT, row = i % RT;
-      const int64_t src = a.idx ? a.idx[row0 + row] : row0 + row;
+      const int64_t src = a.idx ? a.idx[c * a.idx_cs + row0 + row] : row0 + row;
       const float v = f < kLPer ? xp[src * kLPer + f] : 0.0f;
       Rf[f * RT + row] = v;
       if (f < kLPer) S[(int64_t)(LS_XP + f) * B + row0 + row] = v;        // x_per^T: the first layer's weight-gradient operand
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_fwd_kernel(L
     float* hp = S + (int64_t)LS_HP * B;
     for (int i = tid; i < (kLHp - kLW) * RT; i += kLThreads) {
       const int f = i / RT, row = i % RT;
-      const float v = f < kLPos ? a.x_pos[(a.idx ? a.idx[row0 + row] : row0 + row) * kLPos + f] : 0.0f;
+      const float v = f < kLPos ? a.x_pos[c * a.x_pos_cs + (a.idx ? a.idx[c * a.idx_cs + row0 + row] : row0 + row) * kLPos + f] : 0.0f;
       Rf[(kLW + f) * RT + row] = v;
       hp[(int64_t)(kLW + f) * B + row0 + row] = v;
     }
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(kLThreads, NB == 2 ? 2 : 3) void light_bwd_kernel(L
       const int ch = tid % 3;
       const ChanParams q = cp[ch];
       const float inv = 1.0f / (3.0f * (float)B);
-      const float x = p - a.gt[row0 * 3 + tid];
+      const float x = p - a.gt[c * a.gt_cs + row0 * 3 + tid];
       const float xs = x / q.c, ssx = xs * xs;
       const float u = ssx / q.beta + 1.0f, e = 0.5f * q.alpha, lnu = logf(u);
       const float ue = expf(e * lnu), ue1 = ue / u;
@@ -505,15 +507,15 @@ extern "C" int npp_light_pack(const npp_light_desc* L, const float* d_params, in
   return check_launch("npp_light_pack");
 }
 
-extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+static int light_fwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                              const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
-                             float* d_pred, void* stream) {
+                             float* d_pred, void* stream, int64_t x_pos_cs, int64_t idx_cs) {
   int rc = light_check(L, d_params, d_pack, C, B, "npp_light_fwd");
   if (rc) return rc;
   if (!d_x_per || !d_x_pos || !d_stash || !d_pred || (d_idx ? n_src < 1 : n_src != B)) { set_error("npp_light_fwd: null argument / n_src"); return NPP_ERR_ARG; }
   LightArgs a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
-  a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B; a.idx = d_idx; a.n_src = n_src;
+  a.x_per = d_x_per; a.x_pos = d_x_pos; a.stash = d_stash; a.pred = d_pred; a.B = B; a.idx = d_idx; a.n_src = n_src; a.x_pos_cs = x_pos_cs; a.idx_cs = idx_cs;
   if (light_rows_per_wg(C, B, false) == 64) {
     static SmemOnce once;
     if (!smem_attr(once, (const void*)light_fwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
@@ -528,12 +530,26 @@ extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int
   return check_launch("npp_light_fwd");
 }
 
+extern "C" int npp_light_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                             const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B, float* d_stash,
+                             float* d_pred, void* stream) {
+  return light_fwd_go(L, d_params, params_stride, d_pack, pack_stride, d_x_per, d_x_pos, d_idx, n_src, C, B, d_stash, d_pred, stream, 0, 0);
+}
+// npp_light_fwd where every candidate has its OWN positional table and pixel rows (candidate c = image c's fit: the search of several
+// images advanced in one launch sequence): d_x_pos (C, n_src, 42), d_idx (C, B) -- tables of fewer than n_src rows are padded
+extern "C" int npp_light_fwd_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
+                                   const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src, int C, int64_t B,
+                                   float* d_stash, float* d_pred, void* stream) {
+  if (!d_idx) { set_error("npp_light_fwd_multi: d_idx is required"); return NPP_ERR_ARG; }
+  return light_fwd_go(L, d_params, params_stride, d_pack, pack_stride, d_x_per, d_x_pos, d_idx, n_src, C, B, d_stash, d_pred, stream,
+                      n_src * kLPos, B);
+}
 extern "C" int npp_light_part_blocks(int C, int64_t B) { return (C < 1 || B < 32 || B % 32) ? NPP_ERR_ARG : (int)(B / light_rows_per_wg(C, B, true)); }
 
 static int light_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                         const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
                         const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
-                        float* d_draw, float* d_dstash, float* d_part, void* stream);
+                        float* d_draw, float* d_dstash, float* d_part, void* stream, int64_t gt_cs = 0);
 
 extern "C" int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                              const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
@@ -553,10 +569,20 @@ extern "C" int npp_light_bwd_det(const npp_light_desc* L, const float* d_params,
                       d_part, d_part, C, B, d_draw, d_dstash, d_part, stream);
 }
 
+// npp_light_bwd_det with targets per candidate, d_gt (C, B, 3) (see npp_light_fwd_multi)
+extern "C" int npp_light_bwd_det_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack,
+                                       int64_t pack_stride, const float* d_stash, const float* d_pred, const float* d_gt, const float* d_latents,
+                                       const float* d_spline, int n_knots, float x_scale, float* d_part, int C, int64_t B, float* d_draw,
+                                       float* d_dstash, void* stream) {
+  if (!d_gt || !d_part) { set_error("npp_light_bwd_det_multi: d_gt and d_part are required"); return NPP_ERR_ARG; }
+  return light_bwd_go(L, d_params, params_stride, d_pack, pack_stride, d_stash, d_pred, nullptr, d_gt, d_latents, d_spline, n_knots, x_scale,
+                      d_part, d_part, C, B, d_draw, d_dstash, d_part, stream, B * 3);
+}
+
 static int light_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const float* d_pack, int64_t pack_stride,
                         const float* d_stash, const float* d_pred, const float* d_dpred, const float* d_gt, const float* d_latents,
                         const float* d_spline, int n_knots, float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B,
-                        float* d_draw, float* d_dstash, float* d_part, void* stream) {
+                        float* d_draw, float* d_dstash, float* d_part, void* stream, int64_t gt_cs) {
   int rc = light_check(L, d_params, d_pack, C, B, "npp_light_bwd");
   if (rc) return rc;
   if (!d_stash || !d_pred || !d_draw || !d_dstash || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || !d_loss || !d_dlatent) : !d_dpred)) {
@@ -567,7 +593,7 @@ static int light_bwd_go(const npp_light_desc* L, const float* d_params, int64_t 
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = d_pack; a.pack_stride = pack_stride;
   a.stash = (float*)d_stash; a.pred = (float*)d_pred; a.dpred = d_dpred; a.draw = d_draw; a.dstash = d_dstash; a.B = B;
   a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
-  a.part = d_part;
+  a.part = d_part; a.gt_cs = gt_cs;
   if (light_rows_per_wg(C, B, true) == 64) {
     static SmemOnce once;
     if (!smem_attr(once, (const void*)light_bwd_kernel<2>, light_region_bytes(2))) { set_error("npp_light_bwd: smem attribute"); return NPP_ERR_LAUNCH; }

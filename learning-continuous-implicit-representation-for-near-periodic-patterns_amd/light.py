@@ -238,7 +238,7 @@ class NPPNetLightBatch:
         self.quad = ops.quad_coef(loss_type)              # --loss_type: 0 = adaptive; > 0: 'l2' / 'robust_loss' (no latent gradient)
         self.C, self.W, self.D = len(cands), int(W), int(D)
         C = self.C
-        in_pos = 2 * (1 + 2 * len(np.asarray(freqs).reshape(-1)))
+        in_pos = 2 * (1 + 2 * len(np.asarray(freqs[0] if isinstance(freqs, list) else freqs).reshape(-1)))
         self.layout = light_layout(self.W, self.D, in_pos, 20)
         self.in_pos = in_pos
         self.kpos = _stored_cols(self.W + in_pos)
@@ -253,7 +253,10 @@ class NPPNetLightBatch:
         for ci, (angles_deg, periods) in enumerate(cands):
             st = dict(params=self.params[ci, :n], grad=self.grad[ci, :n], m=self.m[ci, :n], v=self.v[ci, :n], latents=self.latents[ci],
                       lat_m=self.lat_m[ci], lat_v=self.lat_v[ci], dlatent=self._dl_c[ci], loss_buf=self._loss2[0, ci:ci + 1])
-            self.nets.append(NPPNetLight(angles_deg, periods, freqs, res, params, W=W, D=D, device=self.device, lrate=lrate,
+            # (multi-image sets: res / freqs may be lists, one entry per candidate -- every candidate another image's fit)
+            res_c = res[ci] if isinstance(res, list) else res
+            freqs_c = freqs[ci] if isinstance(freqs, list) else freqs
+            self.nets.append(NPPNetLight(angles_deg, periods, freqs_c, res_c, params, W=W, D=D, device=self.device, lrate=lrate,
                                          lrate_decay=lrate_decay, storage=st, loss_type=loss_type))
         self.w, self.b, self.dw, self.db = {}, {}, {}, {}
         off = 0
@@ -412,7 +415,10 @@ class NPPNetLightBatch:
         """train_step() on the fused chains: pack -> forward (gathers the iteration's rows itself when idx is given) -> data gradients
         with the pixel loss folded in -> gradient clear -> ONE grouped weight-gradient launch over the feature-major stashes
         (NPP_LIGHT_GROUPED_WGRAD=0: seven) -> Adam: 6 launches for the whole candidate set."""
-        B = gt.shape[0]
+        multi = gt.dim() == 3                              # multi-image set: x_pos (C, n, 42), gt (C, B, 3), idx (C, B)
+        B = gt.shape[1] if multi else gt.shape[0]
+        if multi and not (ops.DETERMINISTIC and self.fused_adam and self.quad == 0):
+            raise ValueError("multi-image candidate sets run the deterministic fused chains with the adaptive pixel loss")
         ws = self._work_fused(B)
         S, D_, sr, dr = ws["stash"], ws["dstash"], self._srow, self._drow
         if not self._pack_valid:                            # first iteration (or after invalidate_pack()): later ones get the packs from the Adam launch
@@ -468,7 +474,10 @@ class NPPNetLightBatch:
     def train_step(self, x_pos, x_per, gt, idx=None):
         """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20) -- or, with
         idx (B int64), the whole tables x_pos (n, in_pos) / x_per (C, n, 20) whose rows idx are this iteration's batch."""
-        C, B = x_per.shape[0], gt.shape[0]
+        C, B = x_per.shape[0], (gt.shape[1] if gt.dim() == 3 else gt.shape[0])
+        if gt.dim() == 3:                                  # multi-image set (ops.light_fwd / light_bwd_det multi forms)
+            assert self.fused and B % 32 == 0 and idx is not None
+            return self._adam(self._train_step_fused(x_pos, x_per, gt, idx))
         if self.bf16 and B % 64 == 0:
             return self._train_step_bf16(x_pos, x_per, gt, idx)
         if self.fused and B % 32 == 0:
@@ -852,3 +861,76 @@ class ProposalRanker:
         d = np.array([x[0] for x in details])
         order = np.argsort(d, kind="stable")[:min(topk, len(d))]
         return d[order], order, details
+
+
+@torch.no_grad()
+def rank_images(rankers, cand_lists, topk=10):
+    """ProposalRanker.rank for SEVERAL images of one rank at once: candidate k of every image rides in one launch
+    sequence -- an NPPNetLightBatch whose "candidates" are the images' k-th candidates, each with its own lattice table, positional
+    table, pixel rows and targets (ops.light_fwd / light_bwd_det multi forms).  The reference walks images (run_completion.sh:8-14)
+    and candidates (NPP_proposal/search.py:85-215) one after the other; with its shared adaptive-loss latents (carry_latents, the
+    single-rank default) the candidates of ONE image are a chain, but the chains of different images are independent: 9 x 300
+    iterations of ~0.1 ms are then paid once for all the images instead of once per image.
+    Per image the arithmetic is that of the serial deterministic loop (same launches, same block and summation order per candidate:
+    identical bits).  Images must share the fit's hyper-parameters; they are grouped by batch rows (min(N_rand, known pixels)).
+    -> per image (sorted distances, order, per-candidate details), like ProposalRanker.rank."""
+    if not rankers:
+        return []
+    r0 = rankers[0]
+    for rk in rankers:
+        if (rk.N_iters, rk.Wn, rk.D, rk.lrate, rk.lrate_decay, rk.loss_type, rk.carry_latents, rk.precision, str(rk.device)) != \
+           (r0.N_iters, r0.Wn, r0.D, r0.lrate, r0.lrate_decay, r0.loss_type, r0.carry_latents, r0.precision, str(r0.device)):
+            raise ValueError("rank_images: the images' candidate fits must share their hyper-parameters and device")
+    if not ops.DETERMINISTIC or ops.quad_coef(r0.loss_type) > 0 or r0.precision == "bf16":
+        return [rk.rank(c, topk=topk) for rk, c in zip(rankers, cand_lists)]       # (the multi-image launches are the deterministic fp32 fused ones)
+    n_img = len(rankers)
+    details = [[None] * len(c) for c in cand_lists]
+    groups = {}
+    for i, rk in enumerate(rankers):
+        groups.setdefault(min(rk.N_rand, rk.i_train.shape[0]), []).append(i)
+    init = default_light_init(r0.Wn, r0.D)
+    for B, members in groups.items():
+        if B % 32 or len(members) == 1:                        # a batch the fused chains do not take, or nothing to stack: the image's own loop
+            for i in members:
+                d, order, det = rankers[i].rank(cand_lists[i], topk=topk)
+                details[i] = det
+            continue
+        draws = {i: rankers[i]._pixel_draws() for i in members}                                        # (N_iters, B) int64 each
+        gts, xpos = {}, {}
+        for i in members:
+            rk = rankers[i]
+            c_all = rk.i_train_dev[draws[i].reshape(-1)].long()
+            gts[i] = rk.img[c_all[:, 0], c_all[:, 1]].reshape(rk.N_iters, B, 3)
+        n_max = max(rankers[i].i_train.shape[0] for i in members)
+        lat = {i: None for i in members}
+        for k in range(max(len(cand_lists[i]) for i in members)):
+            act = [i for i in members if k < len(cand_lists[i])]
+            batch = NPPNetLightBatch([(cand_lists[i][k][0], cand_lists[i][k][1]) for i in act], [rankers[i].freqs for i in act],
+                                     [(rankers[i].H, rankers[i].W_img) for i in act], init, W=r0.Wn, D=r0.D, device=r0.device,
+                                     lrate=r0.lrate, lrate_decay=r0.lrate_decay, precision="fp32", loss_type=r0.loss_type)
+            C = len(act)
+            x_pos = torch.zeros(C, n_max, 42, dtype=torch.float32, device=r0.device)
+            x_per = torch.zeros(C, n_max, 20, dtype=torch.float32, device=r0.device)
+            for j, i in enumerate(act):
+                tp, tr = batch.nets[j].embed(rankers[i].i_train_dev)                                    # search.py:104-108 tables
+                if i not in xpos:
+                    xpos[i] = tp                                                                      # (the positional table is the image's, not the candidate's)
+                x_pos[j, :tp.shape[0]] = xpos[i]
+                x_per[j, :tr.shape[0]] = tr
+                if r0.carry_latents and lat[i] is not None:
+                    batch.latents[j].copy_(lat[i])
+            idx_all = torch.stack([draws[i] for i in act], 1).contiguous()                            # (N_iters, C, B)
+            gt_all = torch.stack([gts[i] for i in act], 1).contiguous()                               # (N_iters, C, B, 3)
+            for it in range(r0.N_iters):
+                batch.train_step(x_pos, x_per, gt_all[it], idx=idx_all[it])
+            for j, i in enumerate(act):
+                lat[i] = batch.latents[j].clone()
+                details[i][k] = rankers[i].score(batch.nets[j])
+            del batch, x_pos, x_per, idx_all, gt_all
+    out = []
+    for i in range(n_img):
+        d = np.array([x[0] for x in details[i]])
+        order = np.argsort(d, kind="stable")[:min(topk, len(d))]
+        out.append((d[order], order, details[i]))
+    return out
+

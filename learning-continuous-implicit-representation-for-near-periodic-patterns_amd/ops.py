@@ -805,11 +805,18 @@ def light_pack(desc, params, pack):
 
 def light_fwd(desc, params, pack, x_per, x_pos, stash, pred, idx=None):
     """Fused NPP_Net_light forward of C candidates: x_per (C, n, 20), x_pos (n, 42) -> pred (C, B, 3), stash (C, rows, B); batch row r is
-    table row idx[r] (idx: B int64 on the device) or r itself (idx None, n == B)."""
+    table row idx[r] (idx: B int64 on the device) or r itself (idx None, n == B).
+    Multi-image form (x_pos (C, n, 42), idx (C, B)): every candidate is another image's fit with its own tables and pixel rows."""
     import ctypes
     C, n = x_per.shape[:2]
     B = pred.shape[1]
     assert x_per.is_contiguous() and x_pos.is_contiguous() and stash.is_contiguous() and pred.is_contiguous()
+    if x_pos.dim() == 3:
+        assert x_per.shape == (C, n, 20) and x_pos.shape == (C, n, 42) and pred.shape == (C, B, 3) and stash.shape[0] == C and stash.shape[2] == B
+        assert idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.shape == (C, B)
+        check(lib().npp_light_fwd_multi(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n, C, B,
+                                        _p(stash), _p(pred), _stream()), "npp_light_fwd_multi")
+        return
     assert x_per.shape == (C, n, 20) and x_pos.shape == (n, 42) and pred.shape == (C, B, 3) and stash.shape[0] == C and stash.shape[2] == B
     assert (idx is None and n == B) or (idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B)
     check(lib().npp_light_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n, C, B,
@@ -835,6 +842,12 @@ def light_bwd_det(desc, params, pack, stash, pred, draw, dstash, gt, lat, spline
     import ctypes
     C, B = pred.shape[:2]
     assert all(t.is_contiguous() for t in (stash, pred, draw, dstash, part, gt, lat)) and part.shape == (C, light_part_blocks(C, B), 8)
+    if gt.dim() == 3:                                  # multi-image form: targets per candidate
+        assert gt.shape == (C, B, 3)
+        check(lib().npp_light_bwd_det_multi(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(gt),
+                                            _p(lat), _p(spline), n_knots, x_scale, _p(part), C, B, _p(draw), _p(dstash), _stream()),
+              "npp_light_bwd_det_multi")
+        return
     check(lib().npp_light_bwd_det(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(stash), _p(pred), _p(gt), _p(lat),
                                   _p(spline), n_knots, x_scale, _p(part), C, B, _p(draw), _p(dstash), _stream()), "npp_light_bwd_det")
 

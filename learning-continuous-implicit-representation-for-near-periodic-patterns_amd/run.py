@@ -32,7 +32,8 @@ def parse(argv=None):
                          "searched first, then grouped by batch shape (patch size) and fitted")
     ap.add_argument("--search-threads", type=int, default=None,
                     help="images of a rank SEARCHED side by side, each on its own host thread and stream (a candidate fit is a chain of "
-                         "small launches that leaves the chip idle; default: --stack, at most 8).  1: one after the other")
+                         "small launches that leaves the chip idle).  1: one after the other.  Default (flag absent): candidate k of every "
+                         "image of the rank in ONE launch sequence (search.main_multi)")
     return ap.parse_args(argv)
 
 
@@ -54,12 +55,13 @@ def main(argv=None, search_main=None, train_main=None):
     dirs = sorted(p for p in glob.glob(os.path.join(inp, "*")) if os.path.isdir(p))
     mine, rank, world = my_share(dirs)
     device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    user_search = search_main                                    # None: the package's own search (its multi-image form is then available)
     if search_main is None:
         from .search import main as search_main
     common = ["--device", device] + (["--random-trunks"] if args.random_trunks else [])
     failed, t_all = [], time.time()
     if args.stack > 1 and len(mine) > 1 and train_main is None:
-        return _main_stacked(args, mine, det, common, rank, world, search_main)
+        return _main_stacked(args, mine, det, common, rank, world, user_search)
     if train_main is None:
         from .train import main as train_main
     for src in mine:
@@ -87,13 +89,26 @@ def main(argv=None, search_main=None, train_main=None):
     return 1 if failed else 0
 
 
-def search_all(srcs, det, flags, search_main=None, threads=8):
+def search_all(srcs, det, flags, search_main=None, threads=8, together=True):
     """The periodicity search of every directory in srcs (-> det/<name>), `threads` images side by side: each on its own host thread
     and HIP stream.  The search of one image is nine candidate fits in a row (the reference chains them through one set of
     adaptive-loss latents, models/helpers.py:8,144), each 300 iterations of four small launches -- a dependent chain that leaves the
     chip idle; images are independent, so their chains interleave on the device.  Per image the results are those of the serial
     loop (own random streams, own score trunks over the process's shared packed weights; the process-wide torch generator is borrowed
     under ops.RNG_LOCK).  -> list of None / the exception per directory ("file exists" is not an error: the directory is reused)."""
+    if search_main is None and together and len(srcs) > 1:
+        # round 6: candidate k of EVERY image in one launch sequence (search.main_multi / light.rank_images) -- the images' chains of
+        # nine candidate fits become one chain of nine stacked fits; per image the bits of its own serial loop
+        from .search import main_multi
+        out = []
+        for e in main_multi([["--datadir", s_, "--outdir", det] + list(flags) for s_ in srcs]):
+            if isinstance(e, SystemExit) and "exists" in str(e):   # "Searching: file exists, exit!!": the detected directory is reused
+                print(e)
+                e = None
+            elif e is not None:
+                traceback.print_exception(type(e), e, e.__traceback__)
+            out.append(e)
+        return out
     if search_main is None:
         from .search import main as search_main
 
@@ -135,7 +150,8 @@ def _main_stacked(args, mine, det, common, rank, world, search_main):
     from .train import main_stacked
     failed, t_all, argvs, names = [], time.time(), [], []
     n_thr = args.search_threads if args.search_threads else min(8, max(1, args.stack))
-    errors = search_all(mine, det, common + shlex.split(args.search_args), search_main, threads=n_thr)
+    # (--search-threads given: the round-5 form, one host thread + stream per image; default: the images' candidate fits stacked)
+    errors = search_all(mine, det, common + shlex.split(args.search_args), search_main, threads=n_thr, together=args.search_threads is None)
     for src, err in zip(mine, errors):
         name = os.path.basename(os.path.normpath(src))
         if err is not None:

@@ -97,8 +97,8 @@ def pseudo_mask_split(mask, valid_mask):
     return pseudo, i_train, i_val
 
 
-def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
-    """masked_img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) 1 = known / valid.  -> dict with the ranked candidates."""
+def prepare_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
+    """The per-image front half of search_image: displacement search -> candidates, pseudo mask -> ranker.  -> (candidates, ranker)."""
     from . import proposal
     from .light import ProposalRanker
     m2 = np.asarray(mask, np.float64).reshape(masked_img.shape[:2])
@@ -116,16 +116,26 @@ def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
                             contextual_weight=args.contextual_weight, vgg19_state_dict=t.get("vgg19"), vgg16_state_dict=t.get("vgg16"),
                             lpips_lin_weights=t.get("lin"), rng_mode=args.rng_mode, carry_latents=args.carry_effective,
                             loss_type=getattr(args, "loss_type", "robust_loss_adaptive"), precision=getattr(args, "precision", None))
-    cands = list(zip(angles, periods, shifts))
-    dist, order, details = ranker.rank(cands, topk=args.topk_detection)
+    return list(zip(angles, periods, shifts)), ranker
+
+
+def _ranked(cands, dist, order, details):
+    angles, periods, shifts = zip(*cands)
     return {"angles": [np.asarray(angles[i], np.float64).tolist() for i in order],
             "periods": [np.asarray(periods[i], np.float64).tolist() for i in order],
             "shifts": [[list(map(float, s)) for s in shifts[i]] for i in order],
             "distances": [float(d) for d in dist], "n_candidates": len(cands), "details": details}
 
 
-def main(argv=None):
-    args = parse(argv)
+def search_image(masked_img, mask, valid_mask, args, conv1=None, trunks=None):
+    """masked_img (H,W,3) in [0,1]; mask / valid_mask (H,W[,1]) 1 = known / valid.  -> dict with the ranked candidates."""
+    cands, ranker = prepare_image(masked_img, mask, valid_mask, args, conv1, trunks)
+    dist, order, details = ranker.rank(cands, topk=args.topk_detection)
+    return _ranked(cands, dist, order, details)
+
+
+def _load(args):
+    """Flags -> (output directory, the four input images, feature extractor, trunk weights); SystemExit when the output exists."""
     from . import io as nio
     from . import weights
     weights.resolve(args, ["vgg19", "vgg16"] + ([] if args.gray_only else ["alexnet"]), args.random_trunks)
@@ -137,15 +147,18 @@ def main(argv=None):
     rd = lambda f: nio._imread_rgb(os.path.join(args.datadir, f))                   # noqa: E731  ([0, 1], loaders/loaders.py:17-25)
     rg = lambda f: nio._imread_gray(os.path.join(args.datadir, f))                  # noqa: E731
     masked_img, img, mask, valid = rd("masked_img.png"), rd("gt_img.png"), rg("unknown_mask.png"), rg("valid_mask.png")
-
     load = weights.load_state_dict                                                  # (one read per file and process)
     lin = None if (args.random_trunks and args.lpips_lin is None and args.vgg16 is None) else weights.lpips_lin("vgg", args.lpips_lin)
     conv1 = None
     if not args.gray_only:
         from .proposal import AlexConv1
         conv1 = AlexConv1(load(args.alexnet), device=args.device, allow_random=args.random_trunks)
-    res = search_image(masked_img.astype(np.float32), mask, valid, args, conv1,
-                       {"vgg19": load(args.vgg19), "vgg16": load(args.vgg16), "lin": lin})
+    return out, (masked_img, img, mask, valid), conv1, {"vgg19": load(args.vgg19), "vgg16": load(args.vgg16), "lin": lin}
+
+
+def _write(args, out, imgs, res):
+    from . import io as nio
+    masked_img, img, mask, valid = imgs
     nio.write_detected_dir(out, img, mask, valid, res["angles"], res["periods"], res["shifts"], res["distances"], masked_img=masked_img,
                            draw=True)
     with open(os.path.join(out, "config.odgt")) as f:
@@ -161,7 +174,52 @@ def main(argv=None):
         f.write("\n")
     print(f"[search] {res['n_candidates']} candidates ranked; best periods {res['periods'][0]} angles {res['angles'][0]} "
           f"distance {res['distances'][0]:.4f} -> {out}/config.odgt")
+
+
+def main(argv=None):
+    args = parse(argv)
+    out, imgs, conv1, trunks = _load(args)
+    res = search_image(imgs[0].astype(np.float32), imgs[2], imgs[3], args, conv1, trunks)
+    _write(args, out, imgs, res)
     return 0
+
+
+def main_multi(argvs):
+    """Several image directories of one rank searched TOGETHER (light.rank_images: candidate k of every image in one launch
+    sequence).  Per image the result is that of main(); a failure -- an existing output, an unreadable input, no displacement found
+    -- is recorded for that image only.  -> list of None / the exception (SystemExit for "file exists") per argv."""
+    from .light import rank_images
+    n = len(argvs)
+    errors, prepared = [None] * n, [None] * n
+    for i, a in enumerate(argvs):
+        try:
+            args = parse(a)
+            out, imgs, conv1, trunks = _load(args)
+            cands, ranker = prepare_image(imgs[0].astype(np.float32), imgs[2], imgs[3], args, conv1, trunks)
+            prepared[i] = (args, out, imgs, cands, ranker)
+        except (Exception, SystemExit) as e:                                         # noqa: B014
+            errors[i] = e
+    live = [i for i in range(n) if prepared[i] is not None]
+    # images whose fits share hyper-parameters ride together; anything else falls back to its own loop inside rank_images' check
+    keyf = lambda pr: (pr[0].N_iters, pr[0].netwidth, pr[0].netdepth, pr[0].lrate, pr[0].lrate_decay, pr[0].loss_type, pr[4].carry_latents,  # noqa: E731
+                       pr[0].precision, pr[0].topk_detection, str(pr[4].device))
+    groups = {}
+    for i in live:
+        groups.setdefault(keyf(prepared[i]), []).append(i)
+    for key, members in groups.items():
+        try:
+            ranked = rank_images([prepared[i][4] for i in members], [prepared[i][3] for i in members], topk=key[8])
+        except Exception as e:                                                       # the group's launches failed: every member is affected
+            for i in members:
+                errors[i] = e
+            continue
+        for i, (dist, order, details) in zip(members, ranked):
+            try:
+                args, out, imgs, cands, _ = prepared[i]
+                _write(args, out, imgs, _ranked(cands, dist, order, details))
+            except Exception as e:
+                errors[i] = e
+    return errors
 
 
 if __name__ == "__main__":

@@ -393,6 +393,36 @@ def test_concurrent_candidate_fits_equal_the_serial_ones(dev):
             assert abs(ranker.score(other)[0] - sb[0]) <= 1e-3 * abs(sb[0])
 
 
+def test_candidates_of_several_images_in_one_launch_sequence(dev):
+    """light.rank_images (second half): candidate k of every image of a rank rides in one NPPNetLightBatch whose
+    members are IMAGES (own lattice / positional tables, pixel rows, targets: npp_light_fwd_multi / npp_light_bwd_det_multi), for the
+    reference's chained-latent candidate loop (NPP_proposal/search.py:85-215, models/helpers.py:8,144) and for independent candidates:
+    per image the SAME BITS as its own serial ProposalRanker.rank -- scores, order, fitted parameters -- and the same bits run to run;
+    images of different sizes (ragged tables) and different candidate counts included."""
+    from npp_amd.light import ProposalRanker, rank_images
+    rankers, cand_lists = [], []
+    for i, (H, Wd, ncand) in enumerate([(128, 128, 3), (96, 144, 2), (128, 128, 3)]):
+        img, mask = oracle.synthetic_image(max(H, Wd), noise=0.01, seed=i)
+        img = img[:H, :Wd]
+        angles, periods, shifts = oracle.synthetic_periodicity(128, 1)
+        pseudo = np.ones((H, Wd))
+        pseudo[30 + 5 * i:70, 40:80 + 4 * i] = 0
+        i_train, i_val = np.stack(np.nonzero(pseudo), 1), np.stack(np.nonzero(1 - pseudo), 1)
+        cands = [(angles[0] + 7.0 * j, periods[0] * (1.0 + 0.23 * j), shifts[0]) for j in range(ncand)]
+        cand_lists.append(cands)
+        rankers.append((img, i_train, i_val))
+    for carry in (True, False):
+        mk = lambda: [ProposalRanker(im, it, iv, device=dev, N_iters=40, N_rand=1024, carry_latents=carry) for im, it, iv in rankers]   # noqa: E731
+        serial = [rk.rank(c, topk=10) for rk, c in zip(mk(), cand_lists)]
+        together = rank_images(mk(), cand_lists, topk=10)
+        again = rank_images(mk(), cand_lists, topk=10)
+        for (d0, o0, det0), (d1, o1, det1), (d2, o2, det2) in zip(serial, together, again):
+            assert list(o0) == list(o1) == list(o2)
+            assert det1 == det2                                              # run to run: identical bits
+            assert det0 == det1, (carry, det0, det1)                         # and the image's own serial loop: identical bits
+            np.testing.assert_array_equal(d0, d1)
+
+
 def test_candidate_fits_are_bit_reproducible(dev):
     """VERDICT r5 "What's weak" #5: the candidate fits of the proposal search (NPP_proposal/search.py:113-147) had float atomics on
     their gradient path (split-K partial sums of the weight gradients, the folded pixel loss's sums): two runs differed by ~3e-4 and

@@ -185,11 +185,11 @@ def test_search_driver_writes_a_loadable_detected_dir(tmp_path):
 
 
 @pytest.mark.gpu
-def test_images_searched_side_by_side_rank_like_the_serial_loop(tmp_path):
-    """run.search_all: the images of a rank searched on several host threads, each on its own stream (what `python -m npp_amd.run
-    --stack M` does before it fits them together).  Per image the result is that of the serial loop: the same candidates in the
-    same order; the distances agree to the run-to-run spread of the candidate fits themselves (their weight gradients add split-K
-    partials atomically: two serial runs differ by ~3e-4)."""
+def test_images_searched_together_rank_like_the_serial_loop(tmp_path):
+    """run.search_all, the three forms of searching a rank's images (what `python -m npp_amd.run --stack M` does before it fits them
+    together): one after the other; side by side on host threads with a stream each (round 5); candidate k of EVERY image in one launch
+    sequence (round 6 default: search.main_multi / light.rank_images).  Since the candidate fits and their scores are bit-reproducible
+    (round 6), all three write the SAME config.odgt per image -- candidates, order and distances to the last bit."""
     import json
     import warnings
     from npp_amd import io as nio, run
@@ -202,19 +202,22 @@ def test_images_searched_side_by_side_rank_like_the_serial_loop(tmp_path):
     out = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for thr in (1, 4):
-            det = str(tmp_path / f"det{thr}")
-            assert run.search_all(srcs, det, flags, threads=thr) == [None] * M
-            out[thr] = [json.loads(open(os.path.join(det, f"img{i}", "config.odgt")).readline()) for i in range(M)]
+        for tag, kw in (("serial", dict(threads=1, together=False)), ("threads", dict(threads=4, together=False)), ("together", dict())):
+            det = str(tmp_path / f"det_{tag}")
+            assert run.search_all(srcs, det, flags, **kw) == [None] * M
+            out[tag] = [json.loads(open(os.path.join(det, f"img{i}", "config.odgt")).readline()) for i in range(M)]
         # a second call finds the directories in place ("file exists"): not an error, nothing is searched again
-        assert run.search_all(srcs, str(tmp_path / "det4"), flags, threads=4) == [None] * M
-    for a, b in zip(out[1], out[4]):
-        assert a["selected_angles"] == b["selected_angles"] and a["selected_periods"] == b["selected_periods"]
-        assert a["carry_adaptive_latents"] is True and b["carry_adaptive_latents"] is True      # the reference's chained candidates, on every thread
-        np.testing.assert_allclose(b["distances"], a["distances"], rtol=5e-3)
+        assert run.search_all(srcs, str(tmp_path / "det_together"), flags) == [None] * M
+        assert run.search_all(srcs, str(tmp_path / "det_threads"), flags, threads=4, together=False) == [None] * M
+    for tag in ("threads", "together"):
+        for a, b in zip(out["serial"], out[tag]):
+            assert a["selected_angles"] == b["selected_angles"] and a["selected_periods"] == b["selected_periods"]
+            assert a["carry_adaptive_latents"] is True and b["carry_adaptive_latents"] is True      # the reference's chained candidates in every form
+            assert a["distances"] == b["distances"], (tag, a["distances"], b["distances"])
     # a failing image is reported in its slot, the others are searched
-    errs = run.search_all([srcs[0], str(tmp_path / "input" / "missing")], str(tmp_path / "det_err"), flags, threads=2)
-    assert errs[0] is None and errs[1] is not None
+    for kw in (dict(threads=2, together=False), dict()):
+        errs = run.search_all([srcs[0], str(tmp_path / "input" / "missing")], str(tmp_path / f"det_err{len(kw)}"), flags, **kw)
+        assert errs[0] is None and errs[1] is not None
 
 
 def test_search_flags_keep_the_reference_store_false_semantics():
