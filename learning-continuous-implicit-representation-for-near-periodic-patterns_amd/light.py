@@ -895,7 +895,11 @@ def rank_images(rankers, cand_lists, topk=10):
                 d, order, det = rankers[i].rank(cand_lists[i], topk=topk)
                 details[i] = det
             continue
-        draws = {i: rankers[i]._pixel_draws() for i in members}                                        # (N_iters, B) int64 each
+        # (N_iters, B) int64 each: 300 shuffles of the image's known pixels from the reference's NumPy stream -- 60 ms of host time per
+        # image, GIL-free (host_rng.NativeRandomState), so the images' streams are drawn side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(8, len(members))) as pool:
+            draws = dict(zip(members, pool.map(lambda i: rankers[i]._pixel_draws(), members)))
         gts, xpos = {}, {}
         for i in members:
             rk = rankers[i]
@@ -903,6 +907,7 @@ def rank_images(rankers, cand_lists, topk=10):
             gts[i] = rk.img[c_all[:, 0], c_all[:, 1]].reshape(rk.N_iters, B, 3)
         n_max = max(rankers[i].i_train.shape[0] for i in members)
         lat = {i: None for i in members}
+        act_prev = idx_all = gt_all = None
         for k in range(max(len(cand_lists[i]) for i in members)):
             act = [i for i in members if k < len(cand_lists[i])]
             batch = NPPNetLightBatch([(cand_lists[i][k][0], cand_lists[i][k][1]) for i in act], [rankers[i].freqs for i in act],
@@ -919,14 +924,16 @@ def rank_images(rankers, cand_lists, topk=10):
                 x_per[j, :tr.shape[0]] = tr
                 if r0.carry_latents and lat[i] is not None:
                     batch.latents[j].copy_(lat[i])
-            idx_all = torch.stack([draws[i] for i in act], 1).contiguous()                            # (N_iters, C, B)
-            gt_all = torch.stack([gts[i] for i in act], 1).contiguous()                               # (N_iters, C, B, 3)
+            if act != act_prev:                                                                       # (the same images as long as all have a k-th candidate)
+                idx_all = torch.stack([draws[i] for i in act], 1).contiguous()                        # (N_iters, C, B)
+                gt_all = torch.stack([gts[i] for i in act], 1).contiguous()                           # (N_iters, C, B, 3)
+                act_prev = act
             for it in range(r0.N_iters):
                 batch.train_step(x_pos, x_per, gt_all[it], idx=idx_all[it])
             for j, i in enumerate(act):
                 lat[i] = batch.latents[j].clone()
                 details[i][k] = rankers[i].score(batch.nets[j])
-            del batch, x_pos, x_per, idx_all, gt_all
+            del batch, x_pos, x_per
     out = []
     for i in range(n_img):
         d = np.array([x[0] for x in details[i]])

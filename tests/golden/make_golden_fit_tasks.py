@@ -21,7 +21,7 @@ that the patch losses of 'val' / 'train' iterations are comparable value by valu
 Absent offline: pretrained VGG weights.  The trunks are the build's fixed-seed stand-ins of identical shape
 (losses._Trunk: VGG19[0:18] seed 1234, VGG16 seed 4321, VGG16[:17] seed 777) behind the reference's own forward code.
 
-    python tests/golden/make_golden_fit_tasks.py [--remap] [--seg] [--lpips]        (~3 min each)
+    python tests/golden/make_golden_fit_tasks.py [--remap] [--remap1024] [--seg] [--lpips]        (~3 min each)
 """
 import os
 import sys
@@ -88,7 +88,9 @@ def task_inputs(task, H):
     return img, img, period, None, np.stack(np.nonzero(period[..., 0]), 1), np.stack(np.nonzero(1 - period[..., 0]), 1)
 
 
-def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 100)):
+def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 100), H=256, P=64, K=1):
+    """H = 1024, P = 160, K = 3 (--remap1024, g8r1024): BASELINE config c4's grid -- the remapping loop at its real size (1 048 576
+    pixel rows in the 'train' pool, 2 patches of 160^2 against 3 real ones each, style Gram matrices of 6 x 160^2 patches)."""
     R = import_reference()
     stable_topk()
     emb, msec, cxf = R["emb"], R["msec"], R["cxf"]
@@ -97,17 +99,17 @@ def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 1
     percep = reference_lpips(R) if with_lpips else None
     style = reference_style(R) if task == "remapping" else None
     cx_w = {"completion": 1e-3, "remapping": 0.01, "segmentation": 0.005}[task]     # arg_config.py:90,281,196
-    H, N_rand, P, n_p, topk = 256, 8192, 64, 2, 3
+    N_rand, n_p, topk = 8192, 2, 3
     train_img, clean, mask, pix_mask, i_train, i_val = task_inputs(task, H)
-    angles, periods, shifts = oracle.synthetic_periodicity(H, 1)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
     i_all = np.stack(np.meshgrid(np.arange(H), np.arange(H), indexing="ij"), -1).reshape(-1, 2)
     torch.manual_seed(0)
     embedder, freq_nerf = emb.get_embedder(10, 0, (H, H))
     freqs = np.array([float(fn.__defaults__[1]) for fn in embedder.embed_fns[1::2]], np.float32)
-    ep, _ = emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[0]), selected_periods=torch.Tensor(periods[0]),
-                             freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)
+    eps = [emb.get_embedder(10, 0, (H, H), selected_angles=torch.Tensor(angles[k_]), selected_periods=torch.Tensor(periods[k_]),
+                            freq_scales=FREQ_SCALES, freq_offsets=FREQ_OFFSETS, angle_offsets=ANGLE_OFFSETS)[0] for k_ in range(K)]
     torch.manual_seed(0)
-    net = _net(R, 1, 256, int(freq_nerf))
+    net = _net(R, K, 256, int(freq_nerf))
     adaptive = R["adaptive"].AdaptiveLossFunction(3, np.float32, "cpu")
     grad_vars = list(net.parameters()) + list(adaptive.parameters())                  # helpers.py:144
     if percep is not None:                                                            # :147-151
@@ -121,8 +123,8 @@ def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 1
     mean = torch.tensor([0.485, 0.456, 0.406]).reshape(3, 1, 1)                      # contextual.py:41-46
     std = torch.tensor([0.229, 0.224, 0.225]).reshape(3, 1, 1)
     with torch.no_grad():
-        tab_train = embedder.embed(ep.embed(torch.Tensor(i_train)))
-        tab_all = embedder.embed(ep.embed(torch.Tensor(i_all))).reshape(H, H, -1)
+        tab_all = torch.cat([embedder.embed(ep.embed(torch.Tensor(i_all))) for ep in eps], 1).reshape(H, H, -1)
+        tab_train = tab_all[i_train[:, 0], i_train[:, 1], :]                         # (the same rows of the same table: train.py gathers them)
     train_t, clean_t, mask_t = torch.Tensor(train_img), torch.Tensor(clean), torch.Tensor(mask)
     pm_t = None if pix_mask is None else torch.Tensor(pix_mask)
     np.random.seed(0)
@@ -202,12 +204,14 @@ def main(task, with_lpips, out_name, n_iters=100, checkpoints=(10, 25, 50, 75, 1
             idx = np.arange(la.size) if la.size <= 4096 else np.sort(rs.choice(la.size, 4096, replace=False))
             extra[f"sidx{kk}"], extra[f"sla{kk}"], extra[f"sls{kk}"] = idx.astype(np.int64), la[idx], ls[idx]
     np.savez_compressed(os.path.join(OUT, out_name), traj=np.array(traj, np.float64), seq=np.array(seq, np.int64), freqs=freqs,
-                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step), **extra)
+                        H=np.int64(H), N_rand=np.int64(N_rand), global_step=np.int64(global_step), K=np.int64(K), P=np.int64(P), **extra)
 
 
 if __name__ == "__main__":
     if "--remap" in sys.argv:
         main("remapping", False, "g8r_fit_remap.npz")
+    if "--remap1024" in sys.argv:                        # g8r1024: config c4's grid, 16 iterations (~10 s each)
+        main("remapping", False, "g8r1024_fit_remap.npz", n_iters=16, checkpoints=(1, 4, 8, 12, 16), H=1024, P=160, K=3)
     if "--seg" in sys.argv:
         main("segmentation", False, "g8s_fit_segment.npz")
     if "--lpips" in sys.argv:

@@ -1533,6 +1533,37 @@ def test_remapping_loop_trajectory_vs_reference_g8r(dev, golden):
         np.testing.assert_allclose(lat[D:][idx], g[f"sls{k}"], atol=3e-3)
 
 
+def test_remapping_loop_at_1024sq_vs_reference_g8r1024(dev, golden):
+    """BASELINE config c4's grid: NPP_remapping/train.py:158-300 driven from the reference's modules at 1024^2,
+    K = 3, P = 160 (g8r1024_fit_remap.npz, make_golden_fit_tasks.py --remap1024: 1 048 576 'train' rows, 2 patches of 160^2 against
+    3 real ones, Gram style loss + 0.01 CX) for 16 iterations -- identical sampler decisions call by call, the weighted patch loss
+    (style + 0.01 CX) of EVERY iteration within 3 %, PSNR on the clear / blurry regions within 0.1 dB at iterations 1 / 4 / 8 / 12 /
+    16, the pixel-loss latents and a fixed sample of the style latents."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from refinit import reference_init
+    from npp_amd.fit import CompletionFit
+    g = golden("g8r1024_fit_remap.npz")
+    H, N_rand, K, P = int(g["H"]), int(g["N_rand"]), int(g["K"]), int(g["P"])
+    assert (H, K, P) == (1024, 3, 160)
+    img, _ = oracle.synthetic_image(H)
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+    clear = np.ones((H, H, 1), np.float32)
+    clear[H // 3:H // 2] = 0.0
+    fit = CompletionFit(img, np.ones((H, H, 1), np.float32), angles, periods, g["freqs"], reference_init(K), device=dev, N_rand=N_rand,
+                        seed=0, ksplit=4, shifts=shifts, rng_mode="reference", task="remapping", clear_mask=clear, patch_size=P,
+                        contextual_weight=0.01, style_weight=1.0, use_perceptual_loss=False)
+    assert fit.patch_size == P and fit.i_train.shape[0] == H * H
+    _run_task_golden(dev, g, fit, n_iters=len(g["seq"]), n_loss=len(g["seq"]))
+    for k in range(3):
+        lat = fit.style.latents[k].cpu().numpy()
+        D = lat.size // 2
+        idx = g[f"sidx{k}"]
+        np.testing.assert_allclose(lat[:D][idx], g[f"sla{k}"], atol=3e-3)
+        np.testing.assert_allclose(lat[D:][idx], g[f"sls{k}"], atol=3e-3)
+
+
 def test_segmentation_loop_trajectory_vs_reference_g8s(dev, golden):
     """NPP_segmentation/train.py:148-290 driven from the reference's modules (g8s_fit_segment.npz): the initial periodic region
     is the known mask and the 'train' pool, the input image is what is trained and sampled on, contextual weight 0.005, no
