@@ -647,6 +647,13 @@ int npp_light_bwd(const npp_light_desc* L, const float* d_params, int64_t params
  * npp_tune("light_det") = 1 (default) npp_light_wgrad does not split its contraction (no float atomicAdd): the whole candidate fit
  * has no order-dependent float sum left.  NPP_proposal/search.py:113-147. */
 int npp_light_part_blocks(int C, int64_t B);
+/* npp_light_wgrad with its contraction split over enough workgroups to fill the chip (a single candidate is 80 output tiles: 80
+ * workgroups walking 2048 rows each when unsplit) AND bit-reproducible: the row ranges of an output tile leave their partial tiles in
+ * d_scratch, the workgroup that arrives last adds them in range order and is the tile's only writer (no float atomicAdd).
+ * d_scratch: npp_light_wgrad_det_scratch_bytes(C, B) bytes, ZEROED once before the first use (the arrival tickets reset themselves). */
+int64_t npp_light_wgrad_det_scratch_bytes(int C, int64_t B);
+int npp_light_wgrad_det(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                        int64_t grad_stride, float* d_scratch, int64_t scratch_bytes, void* stream);
 /* "multi" forms: candidate c = ONE IMAGE's fit (the searches of several images of a rank advanced in one launch sequence: candidate k of
  * every image together, where run_completion.sh / search.py:85-215 walk images and candidates one after the other): per candidate its own
  * positional table d_x_pos (C, n_src, 42), periodic table d_x_per (C, n_src, 20) as before, pixel rows d_idx (C, B) into its own tables

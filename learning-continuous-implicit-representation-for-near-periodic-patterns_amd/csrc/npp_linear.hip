@@ -38,6 +38,10 @@ struct GemmArgs {
   const float* dact; int64_t lddact, sdactb; int dact_kind;   // optional: C = (A B) * act'(dact[m][n]) (kinds of act_bwd_kernel)
   int b_snake;                    // B operand is stored as pre-activations: snake() them on their way into LDS (fused-chain stashes)
   int vec_a, vec_b;               // set by the launcher: the operand's runs of 4 may be fetched as one 16-byte load
+  // deterministic split (npp_light_wgrad_det): the splits of an output tile leave their partial tiles in `slab`
+  // ([batch][tile][split][16][256] floats, then the bias partials [batch][tile row][split][64]); the workgroup that arrives LAST at the
+  // tile's ticket adds them in split order and is the only writer of C / rowsum -- no float atomics, the same bits every run
+  float* slab; float* rs_slab; unsigned* ticket;
 };
 
 // act'(.) : kind 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y)); 3 tanh from its
@@ -160,7 +164,32 @@ __device__ __forceinline__ void gemm32_body(GemmArgs g, const int bx, const int 
     for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks * kGemmLdp * 2], b[ks * kGemmLdp * 2], acc, 0, 0, 0);
     wg_barrier();
   }
-  if (do_rowsum && m0 + tid < g.M) atomicAdd(g.rowsum + m0 + tid, rs);
+  bool ordered = false;
+  if (g.slab && split) {                                // (uniform over the launch's problem)
+    const int gx = (g.N + 63) >> 6, gy = (g.M + 63) >> 6, tile = by * gx + bx;
+    float* sl = g.slab + (((int64_t)bz * gx * gy + tile) * g.splits + sp) * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) share_store(sl + r * 256 + tid, acc[r]);
+    float* rsl = g.rs_slab + ((int64_t)bz * gy + by) * g.splits * 64;
+    if (do_rowsum) share_store(rsl + sp * 64 + tid, rs);
+    if (!block_last_arriver(g.ticket + (int64_t)bz * gx * gy + tile, g.splits)) return;
+    sl -= (int64_t)sp * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = 0.0f;
+      for (int q = 0; q < g.splits; ++q) v += share_load(sl + (int64_t)q * 4096 + r * 256 + tid);
+      acc[r] = v;
+    }
+    if (do_rowsum) {
+      rs = 0.0f;
+      for (int q = 0; q < g.splits; ++q) rs += share_load(rsl + q * 64 + tid);
+    }
+    ordered = true;
+  }
+  if (do_rowsum && m0 + tid < g.M) {
+    if (ordered) g.rowsum[m0 + tid] += rs;              // one writer per element
+    else atomicAdd(g.rowsum + m0 + tid, rs);
+  }
   const int n = n0 + wn * 32 + l31;
   if (n >= g.N) return;
   const float bv = (g.bias && sp == 0) ? g.bias[n] : 0.0f;
@@ -169,7 +198,7 @@ __device__ __forceinline__ void gemm32_body(GemmArgs g, const int bx, const int 
     const int m = m0 + wm * 32 + acc_row(r, kh);
     if (m >= g.M) continue;
     float v = acc[r] + bv;
-    if (split) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
+    if (split && !ordered) { atomicAdd(g.C + (int64_t)m * g.ldc + n, v); continue; }      // linear outputs only (launcher guarantees)
     if (g.Z) g.Z[(int64_t)m * g.ldz + n] = v;
     if (g.dact) v *= act_deriv(g.dact[(int64_t)m * g.lddact + n], g.dact_kind);
     if (g.act == 1) { const float s = sinf(v); v = fmaf(s, s, v); }      // activations.py:29-35, a = 1
@@ -500,12 +529,35 @@ extern "C" int npp_linear_bwd_weight_strided(const float* d_dz, int64_t dz_sr, i
  * fused chains (npp_light_fwd / npp_light_bwd): dW_l += d z_l^T x_l with x_0 = x_per, x_l = snake(z_{l-1}), x_f1 = snake(z_3),
  * x_pos = [f1 | x_pos], x_rgb = snake(z_p); gradients go to d_grad + c * grad_stride at the offsets npp_light_desc gives the
  * parameters (accumulated: clear the blob first). */
-extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
-                               int64_t grad_stride, void* stream) {
+// the ordered-split form: ranges of 1024 rows whatever the number of candidates -- a candidate's gradient must not depend on how many
+// others ride in the launch (the images of a rank searched together give the bits of the serial loop).  Measured at 8 candidates x 2048
+// rows: 165 us unsplit (640 workgroups of 64 chunks, 2.5 per CU: every chunk waits for its own operand load) -> ~115 us with 2 ranges
+// (5 per CU); splitting by the candidate count instead (16 ranges for one candidate) left the serial search where it was -- that loop
+// is bound by the host's launches (tools/r6_search_together.py).  80 output tiles of 64 x 64 per candidate (4 + 3 x 16 + 16 + 10 + 2).
+static int light_det_splits(int C, int64_t B) {
+  (void)C;
+  static const int rows = [] { const char* e = getenv("NPP_LIGHT_DET_ROWS"); return e ? atoi(e) : 1024; }();
+  int64_t s = (B + rows - 1) / (rows > 32 ? rows : 32);
+  return (int)(s < 1 ? 1 : (s > 32 ? 32 : s));
+}
+constexpr int kLightTiles = 96, kLightTileRows = 24;    // upper bounds of the 80 tiles / 19 tile rows (layer widths are parameters)
+extern "C" int64_t npp_light_wgrad_det_scratch_bytes(int C, int64_t B) {
+  if (C < 1 || B < 32) return 0;
+  const int s = light_det_splits(C, B);
+  return 4 * ((int64_t)C * kLightTiles /* tickets */ + (int64_t)C * kLightTiles * s * 4096 + (int64_t)C * kLightTileRows * s * 64);
+}
+static int light_wgrad_go(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                          int64_t grad_stride, float* d_scratch, int64_t scratch_bytes, void* stream) {
   if (!L || !d_stash || !d_dstash || !d_grad || C < 1 || C > 4096 || B < 32 || B % 32 || B * 512 >= 0x7fffffffLL) {
     set_error("npp_light_wgrad: bad argument (C=%d B=%lld)", C, (long long)B);
     return NPP_ERR_ARG;
   }
+  const int det_s = d_scratch ? light_det_splits(C, B) : 0;
+  if (d_scratch && scratch_bytes < npp_light_wgrad_det_scratch_bytes(C, B)) { set_error("npp_light_wgrad_det: scratch too small"); return NPP_ERR_ARG; }
+  unsigned* tickets = (unsigned*)d_scratch;
+  float* slabs = d_scratch ? d_scratch + (int64_t)C * kLightTiles : nullptr;
+  float* rs_slabs = d_scratch ? slabs + (int64_t)C * kLightTiles * det_s * 4096 : nullptr;
+  int tiles_used = 0, rows_used = 0;
   // npp_light_desc index -> (d z rows, x rows, x stored as pre-activation)
   const int dz_row[7] = {LD_Z0, LD_Z1, LD_Z2, LD_Z3, LD_ZP, LD_F1, LD_RAW};
   const int x_row[7] = {LS_XP, LS_Z0, LS_Z1, LS_Z2, LS_HP, LS_Z3, LS_ZP};
@@ -531,7 +583,19 @@ extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, co
     // npp_tune "light_det" (default 1): no split of the contraction -- every output element is the plain-store result of ONE
     // workgroup's fixed-order sum (split partial sums meet by float atomicAdd in arrival order): bit-reproducible candidate fits
     dim3 grid = gemm_prepare(g, true, true, true, C > 1 ? gfill : gfill1);
-    if (g.splits > 1 && __atomic_load_n(&g_tune.light_det, __ATOMIC_RELAXED)) {
+    if (d_scratch) {
+      // npp_light_wgrad_det: the contraction IS split (det_s ranges of whole 32-row chunks), the ranges of a tile meet in the slab
+      g.kchunk = (((g.K + det_s - 1) / det_s) + 31) / 32 * 32;
+      g.splits = (g.K + g.kchunk - 1) / g.kchunk;
+      const int gx = (int)grid.x, gy = (int)grid.y;
+      if (tiles_used + gx * gy > kLightTiles || rows_used + gy > kLightTileRows) { set_error("npp_light_wgrad_det: layer %d too wide", i); return NPP_ERR_ARG; }
+      // (batch c of problem i: tile slabs [c][tile][split], one region per problem)
+      g.ticket = tickets + (int64_t)C * tiles_used;
+      g.slab = slabs + (int64_t)C * tiles_used * det_s * 4096;
+      g.rs_slab = rs_slabs + (int64_t)C * rows_used * det_s * 64;
+      tiles_used += gx * gy; rows_used += gy;
+      grid.z = (unsigned)(g.splits * (g.nbatch > 1 ? g.nbatch : 1));
+    } else if (g.splits > 1 && __atomic_load_n(&g_tune.light_det, __ATOMIC_RELAXED)) {
       g.splits = 1; g.kchunk = (g.K + 31) / 32 * 32;
       grid.z = (unsigned)(g.nbatch > 1 ? g.nbatch : 1);
     }
@@ -541,6 +605,18 @@ extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, co
   G.first_wg[7] = wg; G.n = 7;
   hipLaunchKernelGGL((gemm32_grouped_kernel<true, true>), dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, G);
   return check_launch("npp_light_wgrad");
+}
+extern "C" int npp_light_wgrad(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                               int64_t grad_stride, void* stream) {
+  return light_wgrad_go(L, d_stash, d_dstash, C, B, d_grad, grad_stride, nullptr, 0, stream);
+}
+/* npp_light_wgrad with the contraction split over enough workgroups to fill the chip AND bit-reproducible: the ranges of an output
+ * tile leave their partial tiles in d_scratch and the workgroup that arrives last adds them in range order (no float atomics).
+ * d_scratch: npp_light_wgrad_det_scratch_bytes(C, B) bytes, ZEROED once before its first use (the tickets reset themselves). */
+extern "C" int npp_light_wgrad_det(const npp_light_desc* L, const float* d_stash, const float* d_dstash, int C, int64_t B, float* d_grad,
+                                   int64_t grad_stride, float* d_scratch, int64_t scratch_bytes, void* stream) {
+  if (!d_scratch) { set_error("npp_light_wgrad_det: null scratch"); return NPP_ERR_ARG; }
+  return light_wgrad_go(L, d_stash, d_dstash, C, B, d_grad, grad_stride, d_scratch, scratch_bytes, stream);
 }
 
 extern "C" int npp_act_bwd(const float* d_dy, int64_t lddy, const float* d_zy, int64_t ldzy, int64_t B, int n, int act, float* d_dz,

@@ -444,7 +444,11 @@ class NPPNetLightBatch:
         if not self.fused_adam:
             self.grad.zero_()
         if self.grouped_wgrad:
-            ops.light_wgrad(self._desc, S, D_, self.grad)   # all seven layers, one launch
+            wsc = ws.get("wgrad_scratch", False)             # (False: not decided yet for this workspace)
+            if wsc is False:
+                wsc = ws["wgrad_scratch"] = (ops.light_wgrad_det_scratch(self.C, B, self.device)
+                                             if ops.DETERMINISTIC and ops.tune("light_det") else None)
+            ops.light_wgrad(self._desc, S, D_, self.grad, scratch=wsc)   # all seven layers, one launch
             return loss
         W = self.W
         for i in range(4):                                   # periodic_linears.i: x = x_per (row-major) or snake(z_{i-1}) (feature-major)

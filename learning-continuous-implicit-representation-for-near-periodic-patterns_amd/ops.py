@@ -862,12 +862,23 @@ def light_adam_pack_det(desc, params, m, v, grad, n, pack, lat, lat_m, lat_v, dl
           "npp_light_adam_pack_det")
 
 
-def light_wgrad(desc, stash, dstash, grad):
-    """All seven weight / bias gradients of the C candidates in one launch: grad (C, n) += ... (clear first)."""
+def light_wgrad(desc, stash, dstash, grad, scratch=None):
+    """All seven weight / bias gradients of the C candidates in one launch: grad (C, n) += ... (clear first).
+    scratch: light_wgrad_det_scratch(C, B, device) -- the ordered-split form (npp_light_wgrad_det: chip-filling AND bit-reproducible)."""
     import ctypes
     C, B = stash.shape[0], stash.shape[2]
     assert stash.is_contiguous() and dstash.is_contiguous() and grad.stride(1) == 1 and grad.shape[0] == C
+    if scratch is not None:
+        check(lib().npp_light_wgrad_det(ctypes.byref(desc), _p(stash), _p(dstash), C, B, _p(grad), grad.stride(0), _p(scratch),
+                                        scratch.numel() * 4, _stream()), "npp_light_wgrad_det")
+        return
     check(lib().npp_light_wgrad(ctypes.byref(desc), _p(stash), _p(dstash), C, B, _p(grad), grad.stride(0), _stream()), "npp_light_wgrad")
+
+
+def light_wgrad_det_scratch(C, B, device):
+    """Zeroed scratch of npp_light_wgrad_det for C candidates of B rows (tickets + partial tiles; the tickets reset themselves)."""
+    n = int(lib().npp_light_wgrad_det_scratch_bytes(int(C), int(B)))
+    return torch.zeros(n // 4, dtype=torch.float32, device=device)
 
 
 def light_bwd(desc, params, pack, stash, pred, dpred, draw, dstash, loss_args=None):
