@@ -388,6 +388,221 @@ __global__ __launch_bounds__(256) void cx_rows_fwd_big_kernel(int N, int hw, flo
   }
 }
 
+// ---- forward-only form for whole-image crops (hw > 64 * kCxMaxCols and no gradient wanted: the proposal ranking's score of a
+// candidate, NPP_proposal/search.py:180-197, on 128 x 128 feature positions: 137 GFLOP and a 1 GiB distance matrix per score) --------
+// cx_sim_kernel's 64 x 64 tiles ran that at 0.19 of the fp32 MFMA peak (4.5 ms: every 64 x 64 x 32 chunk is 16 KiB of operands for 16
+// MFMAs per wave and one accumulator chain) and the 8-rows-per-wave row pass at 1.4 TB/s (2.3 ms: it also writes the cx matrix only
+// the backward pass reads, and meets the column maxima with 33 M atomics).  Here: 128 x 128 tiles (four accumulator chains per wave,
+// half the operand bytes per FLOP), the row sums as one streaming read, the column maxima as a second one over 64-column strips with
+// the running maximum in a register -- the matrix is written once and read twice, nothing else is stored.
+// Operands first (cx_prep_big_kernel): x and y centred, NORMALISED and re-tiled as [sample][tile of 128 positions][channel][128] --
+// a tile's operand stream is then 128 KiB of consecutive bytes.  Read straight from the NCHW features every 16-channel chunk was 16
+// rows of 512 B, 64 KiB apart: the load skeleton alone (MFMAs compiled out) took 1.85 ms of the first form's 2.5.
+__global__ __launch_bounds__(256) void cx_prep_big_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int C, int hw,
+                                                          CxWs w, float* __restrict__ xt, float* __restrict__ yt) {
+  __shared__ float red[2][128];
+  const int tiles = (hw + 127) / 128;
+  int b = blockIdx.x;
+  const int tile = b % tiles; b /= tiles;
+  const int which = b & 1, n = b >> 1;
+  if (n >= N) return;
+  const float* src = (which ? y : x) + (int64_t)n * C * hw;
+  float* dst = (which ? yt : xt) + ((int64_t)n * tiles + tile) * C * 128;
+  const float* mu = cx_mu(w, n);
+  const int pl = threadIdx.x & 127, half = threadIdx.x >> 7, pos = tile * 128 + pl;
+  const bool live = pos < hw;
+  float ss = 0.0f;
+  for (int c = half; c < C; c += 2) {
+    const float v = live ? src[(int64_t)c * hw + pos] - mu[c] : 0.0f;
+    ss = fmaf(v, v, ss);
+  }
+  red[half][pl] = ss;
+  __syncthreads();
+  const float tot = red[0][pl] + red[1][pl];
+  if (half == 0 && live) (which ? w.ssy : w.ssx)[(int64_t)n * hw + pos] = tot;
+  const float inv = inv_norm(tot);
+  for (int c = half; c < C; c += 2) dst[c * 128 + pl] = live ? (src[(int64_t)c * hw + pos] - mu[c]) * inv : 0.0f;
+}
+
+#ifndef NPP_CXBIG_KC
+#define NPP_CXBIG_KC 16
+#endif
+constexpr int kBigKc = NPP_CXBIG_KC;
+__global__ __launch_bounds__(256) void cx_sim_big_kernel(const float* __restrict__ xt, const float* __restrict__ yt, int N, int C, int hw,
+                                                         CxWs w) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kBigKc][128];
+  __shared__ __attribute__((aligned(16))) float sB[2][kBigKc][128];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Tile order: an XCD's run of workgroups walks 8 x 8 SUPER-BLOCKS of tiles.  Row-major, the ~64 workgroups resident on an XCD held
+  // one x tile and 64 different y tiles (8.3 MB of operands against 4 MB of L2): every y tile missed, and the kernel ran at the
+  // L2-miss bandwidth (2.7 TB/s, 32 FLOP/B) whatever the MFMAs did.  A super-block needs 8 + 8 tiles = 2 MB.
+  const int tiles = (hw + 127) / 128, t8 = (tiles + 7) / 8;
+  const int lb = xcd_block(N * t8 * t8 * 64);
+  if (lb < 0) return;
+  const int n = lb / (t8 * t8 * 64);
+  const int rem = lb - n * t8 * t8 * 64, sb = rem >> 6, win = rem & 63;
+  const int ti = (sb / t8) * 8 + (win >> 3), tj = (sb % t8) * 8 + (win & 7), i0 = ti * 128, j0 = tj * 128;
+  if (ti >= tiles || tj >= tiles) return;               // (whole block)
+  const int wi = wave >> 1, wj = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const float4* xa = (const float4*)(xt + ((int64_t)n * tiles + ti) * C * 128);
+  const float4* yb = (const float4*)(yt + ((int64_t)n * tiles + tj) * C * 128);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  // chunk c0 = channels [c0, c0 + 16): 512 consecutive float4 per operand, two per thread.  Two chunks in flight in NAMED registers
+  // (an array of structs handed to the staging lambdas by reference went to scratch memory, and every load was waited for where it
+  // was issued: 2.1 ms with or without the MFMAs)
+  static_assert(kBigKc == 16, "two float4 per thread and operand");
+  float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;       // set P: even chunks, set Q: odd chunks
+#define CXBIG_ISSUE(c0, A0, A1, B0, B1) { A0 = xa[(c0) * 32 + tid]; A1 = xa[(c0) * 32 + tid + 256]; B0 = yb[(c0) * 32 + tid]; B1 = yb[(c0) * 32 + tid + 256]; }
+#define CXBIG_FINISH(buf, A0, A1, B0, B1) { float4* da = (float4*)&sA[buf][0][0]; float4* db = (float4*)&sB[buf][0][0]; \
+    da[tid] = A0; da[tid + 256] = A1; db[tid] = B0; db[tid + 256] = B1; }
+#ifdef NPP_CXBIG_NOMFMA          // (timing-only build)
+#define CXBIG_MMA(PAR) _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) { \
+      const float a0 = sA[PAR][2 * ks + kh][wi * 64 + l31], a1 = sA[PAR][2 * ks + kh][wi * 64 + 32 + l31]; \
+      const float b0 = sB[PAR][2 * ks + kh][wj * 64 + l31], b1 = sB[PAR][2 * ks + kh][wj * 64 + 32 + l31]; \
+      acc[0][0][ks] += a0 * b0; acc[0][1][ks] += a0 * b1; acc[1][0][ks] += a1 * b0; acc[1][1][ks] += a1 * b1; }
+#else
+#define CXBIG_MMA(PAR) _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) { \
+      const float a0 = sA[PAR][2 * ks + kh][wi * 64 + l31], a1 = sA[PAR][2 * ks + kh][wi * 64 + 32 + l31]; \
+      const float b0 = sB[PAR][2 * ks + kh][wj * 64 + l31], b1 = sB[PAR][2 * ks + kh][wj * 64 + 32 + l31]; \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0); \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0); \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0); \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0); }
+#endif
+  CXBIG_ISSUE(0, pa0, pa1, pb0, pb1);
+  CXBIG_ISSUE(16, qa0, qa1, qb0, qb1);                  // (C >= 32)
+  CXBIG_FINISH(0, pa0, pa1, pb0, pb1);
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 32) {                  // (C % 32 == 0: chunk pairs)
+    // even chunk c0 in LDS buffer 0, chunk c0 + 16 in flight in Q
+    if (c0 + 32 < C) CXBIG_ISSUE(c0 + 32, pa0, pa1, pb0, pb1);
+    CXBIG_MMA(0);
+    CXBIG_FINISH(1, qa0, qa1, qb0, qb1);
+    __syncthreads();
+    if (c0 + 48 < C) CXBIG_ISSUE(c0 + 48, qa0, qa1, qb0, qb1);
+    CXBIG_MMA(1);
+    if (c0 + 32 < C) CXBIG_FINISH(0, pa0, pa1, pb0, pb1);
+    __syncthreads();
+  }
+#undef CXBIG_ISSUE
+#undef CXBIG_FINISH
+#undef CXBIG_MMA
+  // the distance matrix is stored TILED ([sample][ti][tj][128][128]: this tile is 64 KiB of consecutive bytes; in row-major form
+  // every store instruction was two 128-byte pieces 64 KiB apart and the launch ran at the scattered-line write rate, 0.7 TB/s)
+  float* Dt = w.D + (((int64_t)n * tiles + ti) * tiles + tj) * 16384;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wi * 64 + bi * 32 + acc_row(r, kh);
+      float m = 2.0f;
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const int j = j0 + wj * 64 + bj * 32 + l31;
+        if (i < hw && j < hw) {
+          const float d = 1.0f - fminf(fmaxf(acc[bi][bj][r], 0.0f), 1.0f);
+#ifdef NPP_CXBIG_NOSTORE         // (timing-only build)
+          if (d == 12345.0f)
+#endif
+          Dt[(i - i0) * 128 + (j - j0)] = d;
+          m = fminf(m, d);
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+#ifdef NPP_CXBIG_NOATOMIC        // (timing-only build)
+      if (m == 12345.0f)
+#endif
+      if (l31 == 0 && i < hw) atomicMin(&w.dmin[(int64_t)n * hw + i], __float_as_uint(m));
+    }
+}
+
+// s_i = sum_j exp((1 - D_ij / (dmin_i + 1e-5)) / h) over the tiled matrix: one workgroup per (sample, tile row, quarter of the tile
+// columns); wave w owns rows w, w + 4, .. of the 128 (32 partial sums per lane), lane l the column pair 2 l: every load instruction is one
+// 512-byte row of a tile.  The quarters' sums meet in the order of arrival-independent slots (s4), added by the column pass.
+constexpr int kBigQ = 4;                    // column-tile ranges per tile row
+__global__ __launch_bounds__(256) void cx_rowsum_big_kernel(int N, int hw, float inv_h, CxWs w, float* __restrict__ s4) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles = (hw + 127) / 128;
+  int b = blockIdx.x;
+  const int q = b % kBigQ; b /= kBigQ;
+  const int ti = b % tiles, n = b / tiles;
+  if (n >= N) return;
+  float rdm[32], acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int i = ti * 128 + wave + 4 * k;
+    rdm[k] = i < hw ? 1.0f / (__uint_as_float(w.dmin[(int64_t)n * hw + i]) + 1e-5f) : 0.0f;
+    acc[k] = 0.0f;
+  }
+  const int tq = (tiles + kBigQ - 1) / kBigQ;
+  for (int tj = q * tq; tj < min(tiles, (q + 1) * tq); ++tj) {
+    const float* Dt = w.D + (((int64_t)n * tiles + ti) * tiles + tj) * 16384 + wave * 128 + 2 * lane;
+    const int j = tj * 128 + 2 * lane;
+    const float m0 = j < hw ? 1.0f : 0.0f, m1 = j + 1 < hw ? 1.0f : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float2 d = *(const float2*)(Dt + k * 512);
+      acc[k] += m0 * __expf((1.0f - d.x * rdm[k]) * inv_h) + m1 * __expf((1.0f - d.y * rdm[k]) * inv_h);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    float v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int i = ti * 128 + wave + 4 * k;
+    if (lane == 0 && i < hw) s4[((int64_t)n * hw + i) * kBigQ + q] = v;
+  }
+}
+
+// cmax_j = max_i exp(.) / s_i: one workgroup per (sample, tile column, range of tile rows); lane = column pair, the running maxima in
+// registers; one atomicMax per column and range (cmax cleared by cx_mean_kernel).  s_i = the quarters' sums in quarter order.
+constexpr int kBigR = 8;                    // tile-row ranges per tile column
+__global__ __launch_bounds__(256) void cx_colmax_big_kernel(int N, int hw, float inv_h, CxWs w, const float* __restrict__ s4) {
+  __shared__ float red[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles = (hw + 127) / 128;
+  int b = blockIdx.x;
+  const int rg = b % kBigR; b /= kBigR;
+  const int tj = b % tiles, n = b / tiles;
+  if (n >= N) return;
+  const int tr = (tiles + kBigR - 1) / kBigR;
+  float best0 = 0.0f, best1 = 0.0f;
+  for (int ti = rg * tr; ti < min(tiles, (rg + 1) * tr); ++ti) {
+    const float* Dt = w.D + (((int64_t)n * tiles + ti) * tiles + tj) * 16384 + wave * 128 + 2 * lane;
+    // this wave's 32 rows: lane k < 32 fetches row k's scalars, handed round by shuffles
+    const int irow = ti * 128 + wave + 4 * (lane & 31);
+    float my_rdm = 0.0f, my_rs = 0.0f;
+    if (irow < hw) {
+      const int64_t row = (int64_t)n * hw + irow;
+      my_rdm = 1.0f / (__uint_as_float(w.dmin[row]) + 1e-5f);
+      const float* sq = s4 + row * kBigQ;
+      my_rs = 1.0f / (((sq[0] + sq[1]) + sq[2]) + sq[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float2 d = *(const float2*)(Dt + k * 512);
+      const float rdm = __shfl(my_rdm, k, 64), rs = __shfl(my_rs, k, 64);        // (rows beyond the map: rs = 0 -> contributes 0)
+      best0 = fmaxf(best0, __expf((1.0f - d.x * rdm) * inv_h) * rs);
+      best1 = fmaxf(best1, __expf((1.0f - d.y * rdm) * inv_h) * rs);
+    }
+  }
+  red[wave][2 * lane] = best0;
+  red[wave][2 * lane + 1] = best1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int j = tj * 128 + threadIdx.x;
+    const float v = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    if (j < hw) atomicMax(&w.cmax[(int64_t)n * hw + j], __float_as_uint(v));
+  }
+}
+
 // per sample (one block each): cxn = mean_j cmax, l_n = -log(cxn [* weight] + 1e-5) [/ N_group], g = dL/dcxn / J, and the inverse
 // norms of the sample's positions (once instead of once per use).  The block that arrives last adds each group's l_n in sample
 // order to loss[group * loss_stride] (round 4: one float atomic per sample in arrival order before).
@@ -860,6 +1075,11 @@ struct CxFlatOut {        // optional: dL/dx * [y > 0] into the trunk's flat bf1
   void* dz;               // flat bf16 gradient tensor, same geometry
   int N_total, H, W;
 };
+// the value-only big form's arrays (tiled matrix, re-tiled operands, row-sum quarters) inside the 2 N hw^2 floats of D + cx
+static bool big_fwd_fits(int N, int C, int hw) {
+  const int64_t t = (hw + 127) / 128;
+  return (int64_t)N * (t * t * 16384 + 2 * t * C * 128 + (int64_t)hw * kBigQ) <= 2LL * N * hw * hw;
+}
 static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw, float band_width, const float* d_weight,
                      float scale, float* d_loss, int loss_stride, float* d_dfx, void* d_workspace, int64_t workspace_bytes,
                      const void* d_iter, int M, void* stream, const char* who, const CxFlatOut* flat = nullptr) {
@@ -890,6 +1110,19 @@ static int cx_launch(const float* d_fx, const float* d_fy, int N, int C, int hw,
     }
     hipLaunchKernelGGL(cx_rows_fwd32_kernel, dim3((unsigned)((int64_t)N * ((hw + kCxRowWaves - 1) / kCxRowWaves))), dim3(64 * kCxRowWaves), smem, s, N,
                        hw, inv_h, w, scale, (int)loss_in_rows);
+  } else if (big && !d_dfx && big_fwd_fits(N, C, hw)) {
+    // whole-image crop, value only (the ranking's score): re-tiled normalised operands, 128 x 128 tiles in super-block order, the
+    // matrix stored tiled, written once and read twice.  Everything lives in the D + cx regions (2 N hw^2 floats).
+    const int t128 = (hw + 127) / 128;
+    const int64_t t8 = (t128 + 7) / 8;
+    if ((int64_t)N * t8 * t8 * 64 > 0x7fffffffLL) { set_error("%s: grid too large", who); return NPP_ERR_ARG; }
+    float* xt = w.D + (int64_t)N * t128 * t128 * 16384;
+    float* yt = xt + (int64_t)N * t128 * C * 128;
+    float* s4 = yt + (int64_t)N * t128 * C * 128;
+    hipLaunchKernelGGL(cx_prep_big_kernel, dim3((unsigned)(2 * N * t128)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w, xt, yt);
+    hipLaunchKernelGGL(cx_sim_big_kernel, dim3((unsigned)((int64_t)N * t8 * t8 * 64)), dim3(256), 0, s, xt, yt, N, C, hw, w);
+    hipLaunchKernelGGL(cx_rowsum_big_kernel, dim3((unsigned)(N * t128 * kBigQ)), dim3(256), 0, s, N, hw, inv_h, w, s4);
+    hipLaunchKernelGGL(cx_colmax_big_kernel, dim3((unsigned)(N * t128 * kBigR)), dim3(256), 0, s, N, hw, inv_h, w, s4);
   } else {
     hipLaunchKernelGGL(cx_sim_kernel, dim3((unsigned)(((int64_t)N * tiles * tiles + 7) / 8 * 8)), dim3(256), 0, s, d_fx, d_fy, N, C, hw, w);
     const int64_t row_groups = (int64_t)N * ((hw + kCxRows - 1) / kCxRows);
