@@ -210,7 +210,14 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   // operands every thread stages anyway (2 rows x 4 columns per chunk), instead of in a launch of their own (cx_sumsq_kernel:
   // 7 us of launch ramp for 0.2 us of arithmetic).  Every tile sums in the same order, so the tiles of a row agree bit for bit.
   // centre chunk c0 (in q), add its squares, store it as LDS buffer buf
-  auto gfinish = [&](int c0, const Raw& q, int buf) {
+  auto gfinish = [&](int c0, Raw& q, int buf) {
+    // (the loaded values become visible HERE: without the empty asm the centring arithmetic -- pure VALU work, not ordered against a
+    //  sched_barrier -- is hoisted above the MFMA loop together with the wait for its loads)
+#pragma unroll
+    for (int r = 0; r < kCxNR; ++r) {
+      asm volatile("" : "+v"(q.a[r].x), "+v"(q.a[r].y), "+v"(q.a[r].z), "+v"(q.a[r].w));
+      asm volatile("" : "+v"(q.b[r].x), "+v"(q.b[r].y), "+v"(q.b[r].z), "+v"(q.b[r].w), "+v"(q.m[r]));
+    }
 #pragma unroll
     for (int r = 0; r < kCxNR; ++r) {
       const int idx = tid + 256 * r, row = idx >> 4, col = (idx & 15) * 4;
@@ -228,23 +235,31 @@ __global__ __launch_bounds__(256) void cx_sim_kernel(const float* __restrict__ x
   gfinish(0, R[0], 0);
   __syncthreads();
   // one chunk; PAR = (c0 / kCxKc) % 2 at compile time: chunk c0 sits in LDS buffer PAR, chunk c0 + 1 in register set PAR ^ 1, set PAR is free
-  auto chunk = [&](int c0, auto par_) {
+  // one chunk; NEXT (compile time): another chunk follows.  Then BOTH the request for chunk c0 + 2 kc and the finish of chunk c0 + kc
+  // are unconditional (the request is clamped: the chunk before the last asks for the last one again).  Found in the ISA, round 6:
+  // with `if (c0 + 2 kc < C)` around the request, the wait in front of the LDS stores had to hold for the path WITHOUT new loads as
+  // well -- the compiler emitted vmcnt(2..0), so every chunk also waited for the six loads it had just issued and "two chunks in
+  // flight" was one; and loads whose only use sits under a condition are sunk into it.  Same arithmetic, same order.
+  auto chunk = [&](int c0, auto par_, auto next_) {
     constexpr int PAR = decltype(par_)::value;
-    const bool has_next = c0 + kCxKc < C;
-    if (c0 + 2 * kCxKc < C) gissue(c0 + 2 * kCxKc, R[PAR]);
-#pragma unroll
+    constexpr bool NEXT = decltype(next_)::value;
+    if constexpr (NEXT) gissue(max(0, min(c0 + 2 * kCxKc, (C - 1) / kCxKc * kCxKc)), R[PAR]);
+    __builtin_amdgcn_sched_barrier(0);      // (requests first, the finish last: left alone the scheduler moves the centring of the next
+#pragma unroll                              //  chunk -- and the wait for its loads -- up among the first MFMAs and the requests down)
     for (int ks = 0; ks < kCxKc / 2; ++ks) {
       const float a = sA[PAR][2 * ks + kh][wi * 32 + l31];
       const float b = sB[PAR][2 * ks + kh][wj * 32 + l31];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (has_next) gfinish(c0 + kCxKc, R[PAR ^ 1], PAR ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NEXT) gfinish(c0 + kCxKc, R[PAR ^ 1], PAR ^ 1);
     __syncthreads();
   };
-  for (int c0 = 0; c0 < C; c0 += 2 * kCxKc) {
-    chunk(c0, std::integral_constant<int, 0>{});
-    if (c0 + kCxKc < C) chunk(c0 + kCxKc, std::integral_constant<int, 1>{});
-  }
+  using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+  int c0 = 0;
+  for (; c0 + 2 * kCxKc < C; c0 += 2 * kCxKc) { chunk(c0, P0{}, std::true_type{}); chunk(c0 + kCxKc, P1{}, std::true_type{}); }
+  if (c0 + kCxKc < C) { chunk(c0, P0{}, std::true_type{}); chunk(c0 + kCxKc, P1{}, std::false_type{}); }
+  else chunk(c0, P0{}, std::false_type{});
   };
   if (vec && i0 + 64 <= hw && j0 + 64 <= hw && C % kCxKc == 0) body(std::true_type{});      // (block-uniform)
   else body(std::false_type{});
@@ -481,13 +496,19 @@ __global__ __launch_bounds__(256) void cx_sim_big_kernel(const float* __restrict
   __syncthreads();
   for (int c0 = 0; c0 < C; c0 += 32) {                  // (C % 32 == 0: chunk pairs)
     // even chunk c0 in LDS buffer 0, chunk c0 + 16 in flight in Q
-    if (c0 + 32 < C) CXBIG_ISSUE(c0 + 32, pa0, pa1, pb0, pb1);
+    // (the requests are unconditional -- the last pair asks for the last chunks again: a conditional request makes the compiler wait
+    //  for ALL outstanding loads in front of the LDS stores, see cx_sim_kernel)
+    CXBIG_ISSUE(min(c0 + 32, C - 32), pa0, pa1, pb0, pb1);
+    __builtin_amdgcn_sched_barrier(0);                  // (the scheduler sank the requests below the MFMAs, next to their use)
     CXBIG_MMA(0);
+    __builtin_amdgcn_sched_barrier(0);
     CXBIG_FINISH(1, qa0, qa1, qb0, qb1);
     __syncthreads();
-    if (c0 + 48 < C) CXBIG_ISSUE(c0 + 48, qa0, qa1, qb0, qb1);
+    CXBIG_ISSUE(min(c0 + 48, C - 16), qa0, qa1, qb0, qb1);
+    __builtin_amdgcn_sched_barrier(0);
     CXBIG_MMA(1);
-    if (c0 + 32 < C) CXBIG_FINISH(0, pa0, pa1, pb0, pb1);
+    __builtin_amdgcn_sched_barrier(0);
+    CXBIG_FINISH(0, pa0, pa1, pb0, pb1);                // (unconditional too: loads used only under a condition get SUNK into it)
     __syncthreads();
   }
 #undef CXBIG_ISSUE
