@@ -566,11 +566,13 @@ __global__ __launch_bounds__(256) void cx_rowsum_big_kernel(int N, int hw, float
   for (int tj = q * tq; tj < min(tiles, (q + 1) * tq); ++tj) {
     const float* Dt = w.D + (((int64_t)n * tiles + ti) * tiles + tj) * 16384 + wave * 128 + 2 * lane;
     const int j = tj * 128 + 2 * lane;
-    const float m0 = j < hw ? 1.0f : 0.0f, m1 = j + 1 < hw ? 1.0f : 0.0f;
+    const bool v0 = j < hw, v1 = j + 1 < hw;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
+      // (entries beyond the map were never written: SELECTED out, not multiplied by 0 -- stale workspace bytes there can be anything,
+      //  and 0 * exp(garbage) = NaN made the row's sum NaN, which the column pass's fmaxf then silently dropped)
       const float2 d = *(const float2*)(Dt + k * 512);
-      acc[k] += m0 * __expf((1.0f - d.x * rdm[k]) * inv_h) + m1 * __expf((1.0f - d.y * rdm[k]) * inv_h);
+      acc[k] += (v0 ? __expf((1.0f - d.x * rdm[k]) * inv_h) : 0.0f) + (v1 ? __expf((1.0f - d.y * rdm[k]) * inv_h) : 0.0f);
     }
   }
 #pragma unroll
@@ -609,9 +611,10 @@ __global__ __launch_bounds__(256) void cx_colmax_big_kernel(int N, int hw, float
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
       const float2 d = *(const float2*)(Dt + k * 512);
-      const float rdm = __shfl(my_rdm, k, 64), rs = __shfl(my_rs, k, 64);        // (rows beyond the map: rs = 0 -> contributes 0)
-      best0 = fmaxf(best0, __expf((1.0f - d.x * rdm) * inv_h) * rs);
-      best1 = fmaxf(best1, __expf((1.0f - d.y * rdm) * inv_h) * rs);
+      const float rdm = __shfl(my_rdm, k, 64), rs = __shfl(my_rs, k, 64);        // (rows beyond the map: rs = 0, selected out)
+      const float c0 = __expf((1.0f - d.x * rdm) * inv_h) * rs, c1 = __expf((1.0f - d.y * rdm) * inv_h) * rs;
+      best0 = fmaxf(best0, rs > 0.0f ? c0 : 0.0f);
+      best1 = fmaxf(best1, rs > 0.0f ? c1 : 0.0f);
     }
   }
   red[wave][2 * lane] = best0;
