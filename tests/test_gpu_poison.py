@@ -132,3 +132,33 @@ def test_candidate_ranking_does_not_read_unwritten_memory(dev):
     with poisoned_empty():
         d1, o1, det1 = run()
     assert np.all(np.isfinite(d0)) and o0 == o1 and d0.tolist() == d1.tolist() and det0 == det1
+
+
+def test_stacked_images_do_not_read_unwritten_memory(dev):
+    """Three images in one launch sequence (stack.StackedFit: job tables, per-image slabs, grouped contextual core, batched LPIPS
+    branch), 20 stacked iterations: the same parameter bits under poisoned allocations."""
+    from npp_amd.fit import CompletionFit
+    from npp_amd.stack import StackedFit
+    H, K, M = 256, 3, 3
+    angles, periods, shifts = oracle.synthetic_periodicity(H, K)
+
+    def run():
+        fits = []
+        for i in range(M):
+            img, mask = oracle.synthetic_image(H, seed=i)
+            fits.append(CompletionFit(img, mask, np.asarray(angles, np.float64) + 0.3 * i, periods, oracle.SEED0_FREQS,
+                                      oracle.init_params(K, seed=i), device=dev, N_rand=4096, shifts=shifts, seed=10 + i))
+        st = StackedFit(fits)
+        seen = set()
+        for _ in range(20):
+            st.step_full()
+            seen |= {s for s in st.last_sources if s}
+        torch.cuda.synchronize()
+        return seen, [f.net.params.clone() for f in st.fits] + [f.net.latents.clone() for f in st.fits] + [f.percepLoss._lat.clone() for f in st.fits]
+    seen, clean = run()
+    assert "same" in seen
+    with poisoned_empty():
+        seen_p, dirty = run()
+    assert seen_p == seen
+    for a, b in zip(clean, dirty):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b), float((a - b).abs().max())
