@@ -731,6 +731,11 @@ int npp_lpips_plain_layer_det(const float* d_f0, const float* d_f1, int N, int C
  * d_loss[0] += sum_n coef_n[n] sum_j nll(a - b)[n][j]; d_diff (N, D) scratch; d_ddiff / d_dlatent (nullable together):
  * coef_n dnll/dx and the accumulated latent gradients.  coef_n is a HOST array of N <= 64 factors. */
 int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, void* stream);
+/* (round 6) the same with the split contraction's partial sums added in range order: bit-reproducible where npp_gram_fwd adds them with
+ * float atomics in arrival order.  d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes, ZEROED once before its first use, not
+ * shared by launches that may run concurrently. */
+int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw);
+int npp_gram_fwd_det(const float* d_f, int N, int C, int hw, float* d_g, float* d_scratch, int64_t scratch_bytes, void* stream);
 int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream);
 int64_t npp_robust_elem_workspace_bytes(int D);
 int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const float* d_latents,

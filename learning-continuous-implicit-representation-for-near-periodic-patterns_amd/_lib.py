@@ -217,6 +217,8 @@ SYMBOLS = {
     "npp_trunk_grad_in": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "npp_trunk_grad_in_pf": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i64, _vp]),
     "npp_gram_fwd": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "npp_gram_fwd_det_scratch_bytes": (_i64, [_i32, _i32, _i32]),
+    "npp_gram_fwd_det": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "npp_gram_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "npp_robust_elem_workspace_bytes": (_i64, [_i32]),
     "npp_robust_elem": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f32, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
 // matrices.  loss += sum_n coef_n sum_j nll(d[n][j]); dd[n][j] = coef_n dnll/dx; dlatent[j] / [D + j] += the latent gradients.
 __global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restrict__ d, int N, int D, const ChanParams* __restrict__ cp,
                                                           const float* __restrict__ coef_n, float* __restrict__ loss,
-                                                          float* __restrict__ dd, float* __restrict__ dlatent) {
+                                                          float* __restrict__ dd, float* __restrict__ dlatent, float* __restrict__ part,
+                                                          unsigned* __restrict__ ticket) {
   __shared__ float tot[4];
   const int j = blockIdx.x * 256 + threadIdx.x;
   float val = 0.0f;
@@ -334,12 +335,21 @@ __global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restric
   for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
   if ((threadIdx.x & 63) == 0) tot[threadIdx.x >> 6] = val;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, tot[0] + tot[1] + tot[2] + tot[3]);
+  // (round 6: the blocks' sums meet in block order -- one float atomicAdd per block in arrival order before; the style term was the
+  //  last order-dependent float sum on a task's iteration path)
+  if (threadIdx.x == 0) share_store(part + blockIdx.x, tot[0] + tot[1] + tot[2] + tot[3]);
+  if (!block_last_arriver(ticket, gridDim.x)) return;
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (unsigned b = 0; b < gridDim.x; ++b) t += share_load(part + b);
+    atomicAdd(loss, t);                           // ONE add per launch (the word is shared with launches on other streams: the
+  }                                               //  contextual core's term of the same iteration)
 }
 
 __global__ void elem_chan_kernel(const float* __restrict__ latents, int D, const float* __restrict__ spline, int n_knots, float x_scale,
-                                 ChanParams* __restrict__ cp) {
+                                 ChanParams* __restrict__ cp, unsigned* __restrict__ ticket) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *ticket = 0u;                       // (the workspace is not required to be zeroed: the arrival ticket of the launch that follows)
   if (c < D) cp[c] = chan_params(latents[c], latents[D + c], spline, n_knots, x_scale);
 }
 
@@ -378,9 +388,25 @@ static dim3 gemm_prepare(GemmArgs& g, bool a_kc, bool b_kc, bool batch_split, in
   return dim3((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)(splits * nb));
 }
 
-static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false) {
+// scratch of the ordered split of one (batched) problem: tickets, partial tiles, bias partials
+static int64_t gemm_det_floats(const GemmArgs& g, const dim3& grid) {
+  const int64_t nb = g.nbatch > 1 ? g.nbatch : 1, tiles = (int64_t)grid.x * grid.y;
+  return nb * tiles + nb * tiles * g.splits * 4096 + nb * grid.y * g.splits * 64;
+}
+static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false, float* det_scratch = nullptr,
+                       int64_t det_bytes = 0) {
   const dim3 grid = gemm_prepare(g, a_kc, b_kc, batch_split);
   const int nb = g.nbatch > 1 ? g.nbatch : 1;
+  if (det_scratch && g.splits > 1) {
+    // the ranges of a tile meet in range order (gemm32_body): no float atomics, no clear of C; tickets zeroed once by the caller
+    if (det_bytes < 4 * gemm_det_floats(g, grid)) { set_error("ordered-split scratch too small"); return NPP_ERR_ARG; }
+    const int64_t tiles = (int64_t)grid.x * grid.y;
+    g.ticket = (unsigned*)det_scratch;
+    g.slab = det_scratch + nb * tiles;
+    g.rs_slab = g.slab + nb * tiles * g.splits * 4096;
+    if (g.rowsum && !g.accumulate)                       // (the last arriver ADDS the bias sums)
+      for (int b = 0; b < nb; ++b) (void)hipMemsetAsync(g.rowsum + b * g.srsb, 0, (size_t)g.M * sizeof(float), s);
+  } else
   if (nb == 1) {
     if (g.splits > 1 && !g.accumulate) (void)hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * sizeof(float), s);
     if (g.rowsum && !g.accumulate) (void)hipMemsetAsync(g.rowsum, 0, (size_t)g.M * sizeof(float), s);
@@ -676,6 +702,27 @@ extern "C" int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, 
   gemm_launch(g, true, true, (hipStream_t)stream, true);
   return check_launch("npp_gram_fwd");
 }
+static GemmArgs gram_args(const float* d_f, int N, int C, int hw, float* d_g) {
+  GemmArgs g{};
+  g.A = d_f; g.sam = hw; g.sak = 1;
+  g.B = d_f; g.sbk = 1; g.sbn = hw;
+  g.C = d_g; g.ldc = C;
+  g.M = C; g.N = C; g.K = hw; g.nbatch = N; g.sab = g.sbb = (int64_t)C * hw; g.scb = (int64_t)C * C;
+  return g;
+}
+/* npp_gram_fwd with the split contraction's partial sums added in range order (bit-reproducible; npp_gram_fwd adds them with float
+ * atomics in arrival order).  d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes, ZEROED once before its first use. */
+extern "C" int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw) {
+  if (N < 1 || C < 1 || hw < 1) return NPP_ERR_ARG;
+  GemmArgs g = gram_args(nullptr, N, C, hw, nullptr);
+  const dim3 grid = gemm_prepare(g, true, true, true);
+  return 4 * gemm_det_floats(g, grid) + 64;
+}
+extern "C" int npp_gram_fwd_det(const float* d_f, int N, int C, int hw, float* d_g, float* d_scratch, int64_t scratch_bytes, void* stream) {
+  if (!d_f || !d_g || !d_scratch || N < 1 || C < 1 || hw < 1) { set_error("npp_gram_fwd_det: bad argument"); return NPP_ERR_ARG; }
+  const int rc = gemm_launch(gram_args(d_f, N, C, hw, d_g), true, true, (hipStream_t)stream, true, d_scratch, scratch_bytes);
+  return rc != NPP_OK ? rc : check_launch("npp_gram_fwd_det");
+}
 
 extern "C" int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream) {
   if (!d_dg || !d_f || !d_df || N < 1 || C < 1 || hw < 1) { set_error("npp_gram_bwd: bad argument"); return NPP_ERR_ARG; }
@@ -705,12 +752,17 @@ extern "C" int npp_robust_elem(const float* d_a, const float* d_b, int N, int D,
   hipStream_t s = (hipStream_t)stream;
   ChanParams* cp = (ChanParams*)d_workspace;
   float* d_coef = (float*)((char*)d_workspace + (size_t)D * sizeof(ChanParams));
+  float* d_part = d_coef + 64;                       // [blocks] partial sums, then the arrival ticket
+  const unsigned blocks = (unsigned)((D + 255) / 256);
+  unsigned* d_ticket = (unsigned*)(d_part + blocks);
   (void)hipMemcpyAsync(d_coef, coef_n, sizeof(float) * N, hipMemcpyHostToDevice, s);
   const int64_t n = (int64_t)N * D;
   hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_a, d_b, n, d_diff);
-  hipLaunchKernelGGL(elem_chan_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, d_latents, D, d_spline, n_knots, x_scale, cp);
-  hipLaunchKernelGGL(robust_elem_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, s, d_diff, N, D, cp, d_coef, d_loss, d_ddiff, d_dlatent);
+  hipLaunchKernelGGL(elem_chan_kernel, dim3(blocks), dim3(256), 0, s, d_latents, D, d_spline, n_knots, x_scale, cp, d_ticket);
+  hipLaunchKernelGGL(robust_elem_kernel, dim3(blocks), dim3(256), 0, s, d_diff, N, D, cp, d_coef, d_loss, d_ddiff, d_dlatent, d_part, d_ticket);
   return check_launch("npp_robust_elem");
 }
 
-extern "C" int64_t npp_robust_elem_workspace_bytes(int D) { return D < 1 ? NPP_ERR_ARG : (int64_t)D * sizeof(ChanParams) + 64 * sizeof(float); }
+extern "C" int64_t npp_robust_elem_workspace_bytes(int D) {
+  return D < 1 ? NPP_ERR_ARG : (int64_t)D * sizeof(ChanParams) + (64 + (D + 255) / 256 + 16) * sizeof(float);
+}

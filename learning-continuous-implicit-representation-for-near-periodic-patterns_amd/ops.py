@@ -1005,11 +1005,24 @@ def lpips_plain_layer(f0, f1, lin, scale, out, scratch=None):
 
 
 # ---- remapping variant: Gram-matrix style loss pieces (models/style_loss.py:37-74) ----------------------------
+_gram_ws = {}
+
+
 def gram_fwd(f):
+    """Gram matrices (N, C, C) of features (N, C, h, w) (models/style_loss.py:55-58).  ops.DETERMINISTIC: the ordered-split form
+    (npp_gram_fwd_det) over a zeroed per-stream scratch."""
     _req(f, torch.float32, "f")
     N, Cc = f.shape[:2]
+    hw = f.shape[2] * f.shape[3]
     g = torch.empty((N, Cc, Cc), dtype=torch.float32, device=f.device)
-    check(lib().npp_gram_fwd(_p(f), N, Cc, f.shape[2] * f.shape[3], _p(g), _stream()), "npp_gram_fwd")
+    if DETERMINISTIC:
+        key = (f.device, N, Cc, hw, _stream().value)
+        ws = _gram_ws.get(key)
+        if ws is None:
+            ws = _gram_ws[key] = torch.zeros(int(lib().npp_gram_fwd_det_scratch_bytes(N, Cc, hw)) // 4, dtype=torch.float32, device=f.device)
+        check(lib().npp_gram_fwd_det(_p(f), N, Cc, hw, _p(g), _p(ws), ws.numel() * 4, _stream()), "npp_gram_fwd_det")
+        return g
+    check(lib().npp_gram_fwd(_p(f), N, Cc, hw, _p(g), _stream()), "npp_gram_fwd")
     return g
 
 
@@ -1026,7 +1039,7 @@ _re_ws = {}
 def robust_elem(a, b, latents, spline, n_knots, x_scale, coef_n, loss, want_grad=True, dlatent=None):
     """per-element adaptive robust NLL of (a - b) over (N, D); returns d(loss)/d(a) (N, D) or None."""
     N, D = a.shape
-    key = (a.device, D)
+    key = (a.device, D, _stream().value)                 # (it holds the launch's partial sums and arrival ticket: one per stream)
     ws = _re_ws.get(key)
     if ws is None:
         ws = _re_ws[key] = torch.empty(int(lib().npp_robust_elem_workspace_bytes(D)), dtype=torch.uint8, device=a.device)

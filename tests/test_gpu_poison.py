@@ -98,18 +98,17 @@ def test_complete_iterations_do_not_read_unwritten_memory(dev, task):
     with poisoned_empty():
         seen_p, dirty = _fit_state(dev, task)
     assert seen_p == seen
-    for a, b in zip(clean, dirty):
+    for k, (a, b) in enumerate(zip(clean, dirty)):
         assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
-        if task == "completion":
-            assert torch.equal(a, b), float((a - b).abs().max())
-    if task == "remapping":
-        # (the Gram-matrix style term adds with float atomics: two CLEAN runs differ in the 8th digit of the second iteration's loss and
-        #  drift apart from there -- so this leg asserts finiteness everywhere, the first iteration to the bit and the rest to the
-        #  spread two clean runs show)
-        assert torch.equal(clean[5][0], dirty[5][0])
-        torch.testing.assert_close(dirty[5][:8], clean[5][:8], rtol=2e-3, atol=1e-7)
-        torch.testing.assert_close(dirty[5], clean[5], rtol=1e-1, atol=1e-6)
-        torch.testing.assert_close(dirty[4], clean[4], rtol=0, atol=3e-2)
+        if k == 5:
+            # the REPORTED patch loss of an iteration is one word that the contextual core (main stream) and the LPIPS / style branch
+            # (side stream) each add their term to, in arrival order: a + b against b + a onto the word's previous content can differ in
+            # the last bit (seen once in ~12 runs, 7e-9 on 7e-2).  No gradient is computed from it.
+            torch.testing.assert_close(b, a, rtol=1e-6, atol=0)
+            continue
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
+    # (the remapping leg is exact since the Gram matrices' split contraction and the style term's loss word are summed in a fixed order,
+    #  npp_gram_fwd_det / npp_robust_elem: before, two CLEAN runs differed in the 8th digit of the second iteration's loss)
 
 
 def test_candidate_ranking_does_not_read_unwritten_memory(dev):
