@@ -14,7 +14,8 @@ from npp_amd.model import NPPNet          # noqa: E402
 dev = torch.device("cuda", 0)
 H, K, n = 512, 3, 26624
 angles, periods, _ = syn.synthetic_periodicity(H, K)
-net = NPPNet(angles, periods, syn.SEED0_FREQS, (H, H), params=syn.init_params(K, seed=0), device=dev)
+net = NPPNet(angles, periods, syn.SEED0_FREQS, (H, H), params=syn.init_params(K, seed=0), device=dev,
+             ksplit=int(os.environ['R6_KSPLIT']) if os.environ.get('R6_KSPLIT') else None)
 bp = ops.pad_rows(n)
 rng = np.random.RandomState(0)
 c = torch.from_numpy(np.stack([rng.randint(0, H, bp), rng.randint(0, H, bp)], 1).astype(np.int32)).to(dev)
@@ -39,4 +40,4 @@ for r in range(R + 5):
     if e: e[5].record()
 torch.cuda.synchronize()
 t = np.median(np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(5)] for e in evs]), 0)
-print(f"{os.environ.get('NPP_LIB_PATH', 'default'):32s} stash8={ops.tune('stash8')}  fwd {t[0]:6.1f}  loss {t[1]:5.1f}  bwd {t[2]:6.1f}  wgrad {t[3]:6.1f}  adam {t[4]:5.1f} us")
+print(f"{os.environ.get('NPP_LIB_PATH', 'default'):32s} stash8={ops.tune('stash8')} ksplit={net.ksplit}  fwd {t[0]:6.1f}  loss {t[1]:5.1f}  bwd {t[2]:6.1f}  wgrad {t[3]:6.1f}  adam {t[4]:5.1f} us")
