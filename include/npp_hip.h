@@ -732,8 +732,9 @@ int npp_lpips_plain_layer_det(const float* d_f0, const float* d_f1, int N, int C
  * coef_n dnll/dx and the accumulated latent gradients.  coef_n is a HOST array of N <= 64 factors. */
 int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, void* stream);
 /* (round 6) the same with the split contraction's partial sums added in range order: bit-reproducible where npp_gram_fwd adds them with
- * float atomics in arrival order.  d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes, ZEROED once before its first use, not
- * shared by launches that may run concurrently. */
+ * float atomics in arrival order.  Two launches: the ranges leave their partial tiles in d_scratch, a small second launch adds them.
+ * d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes, no initial content required, not shared by launches that may run
+ * concurrently. */
 int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw);
 int npp_gram_fwd_det(const float* d_f, int N, int C, int hw, float* d_g, float* d_scratch, int64_t scratch_bytes, void* stream);
 int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream);

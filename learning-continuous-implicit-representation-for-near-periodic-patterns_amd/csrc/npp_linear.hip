@@ -172,6 +172,7 @@ __device__ __forceinline__ void gemm32_body(GemmArgs g, const int bx, const int 
     for (int r = 0; r < 16; ++r) share_store(sl + r * 256 + tid, acc[r]);
     float* rsl = g.rs_slab + ((int64_t)bz * gy + by) * g.splits * 64;
     if (do_rowsum) share_store(rsl + sp * 64 + tid, rs);
+    if (!g.ticket) return;                                // two-pass form: gemm_slab_reduce_kernel adds the ranges in a launch of its own
     if (!block_last_arriver(g.ticket + (int64_t)bz * gx * gy + tile, g.splits)) return;
     sl -= (int64_t)sp * 4096;
 #pragma unroll
@@ -228,6 +229,29 @@ __global__ __launch_bounds__(256, NPP_GEMM_WAVES) void gemm32_grouped_kernel(Gem
   const int local = (int)blockIdx.x - G.first_wg[p];
   const int bx = local % G.gx[p], rest = local / G.gx[p];
   gemm32_body<A_KC, B_KC>(G.g[p], bx, rest % G.gy[p], rest / G.gy[p]);
+}
+
+// Second pass of the two-pass ordered split (npp_gram_fwd_det): one block per (batch, output tile) adds the ranges' partial tiles in range
+// order and writes C (no bias sums, no activation: plain linear outputs).  The ranges were written by the PREVIOUS launch: what makes
+// them visible is the launch boundary, not an in-launch handshake -- the one-launch form (last arriver reads the others' tiles) gave
+// results that moved in the last bits when the style branch of stacked images ran beside the contextual chain on a second stream.
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(GemmArgs g, int gx, int gy) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x % (gx * gy), bz = blockIdx.x / (gx * gy);
+  const int by = tile / gx, bx = tile - by * gx;
+  const float* sl = g.slab + ((int64_t)bz * gx * gy + tile) * g.splits * 4096;
+  float* C = g.C + (g.nbatch > 1 ? bz * g.scb : 0);
+  const int n = bx * 64 + wn * 32 + l31;
+  if (n >= g.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = by * 64 + wm * 32 + acc_row(r, kh);
+    if (m >= g.M) continue;
+    float v = 0.0f;
+    for (int q = 0; q < g.splits; ++q) v += sl[(int64_t)q * 4096 + r * 256 + tid];
+    float* c = C + (int64_t)m * g.ldc + n;
+    *c = g.accumulate ? *c + v : v;
+  }
 }
 
 // dz = dy * act'(.) : act 1 snake from the stashed pre-activation z (1 + sin 2z); 2 sigmoid from its output y (y (1 - y));
@@ -305,11 +329,15 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
 // Per-element adaptive robust NLL (robust_loss_pytorch/adaptive.py:183-204 with num_dims = D latents): one thread per
 // element index j walks the N samples -- models/style_loss.py:60-69 applies it to the N x C^2 differences of two Gram
 // matrices.  loss += sum_n coef_n sum_j nll(d[n][j]); dd[n][j] = coef_n dnll/dx; dlatent[j] / [D + j] += the latent gradients.
+struct ElemCoef { float v[64]; };            // the N <= 64 per-sample factors, by value (kernel argument)
 __global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restrict__ d, int N, int D, const ChanParams* __restrict__ cp,
-                                                          const float* __restrict__ coef_n, float* __restrict__ loss,
+                                                          const ElemCoef coef_arg, float* __restrict__ loss,
                                                           float* __restrict__ dd, float* __restrict__ dlatent, float* __restrict__ part,
                                                           unsigned* __restrict__ ticket) {
   __shared__ float tot[4];
+  __shared__ float coef_n[64];
+  if (threadIdx.x < 64) coef_n[threadIdx.x] = coef_arg.v[threadIdx.x];     // (read from the kernel-argument segment)
+  __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
   float val = 0.0f;
   if (j < D) {
@@ -394,14 +422,14 @@ static int64_t gemm_det_floats(const GemmArgs& g, const dim3& grid) {
   return nb * tiles + nb * tiles * g.splits * 4096 + nb * grid.y * g.splits * 64;
 }
 static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool batch_split = false, float* det_scratch = nullptr,
-                       int64_t det_bytes = 0) {
+                       int64_t det_bytes = 0, bool two_pass = false) {
   const dim3 grid = gemm_prepare(g, a_kc, b_kc, batch_split);
   const int nb = g.nbatch > 1 ? g.nbatch : 1;
   if (det_scratch && g.splits > 1) {
     // the ranges of a tile meet in range order (gemm32_body): no float atomics, no clear of C; tickets zeroed once by the caller
     if (det_bytes < 4 * gemm_det_floats(g, grid)) { set_error("ordered-split scratch too small"); return NPP_ERR_ARG; }
     const int64_t tiles = (int64_t)grid.x * grid.y;
-    g.ticket = (unsigned*)det_scratch;
+    g.ticket = two_pass ? nullptr : (unsigned*)det_scratch;
     g.slab = det_scratch + nb * tiles;
     g.rs_slab = g.slab + nb * tiles * g.splits * 4096;
     if (g.rowsum && !g.accumulate)                       // (the last arriver ADDS the bias sums)
@@ -419,6 +447,8 @@ static int gemm_launch(GemmArgs g, bool a_kc, bool b_kc, hipStream_t s, bool bat
   else if (a_kc) hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (b_kc) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, dim3(256), 0, s, g);
+  if (two_pass && g.slab && g.splits > 1 && !g.ticket)
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)(nb * grid.x * grid.y)), dim3(256), 0, s, g, (int)grid.x, (int)grid.y);
   return NPP_OK;
 }
 
@@ -711,7 +741,8 @@ static GemmArgs gram_args(const float* d_f, int N, int C, int hw, float* d_g) {
   return g;
 }
 /* npp_gram_fwd with the split contraction's partial sums added in range order (bit-reproducible; npp_gram_fwd adds them with float
- * atomics in arrival order).  d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes, ZEROED once before its first use. */
+ * atomics in arrival order): the ranges leave their partial tiles in d_scratch, a second small launch adds them.
+ * d_scratch: npp_gram_fwd_det_scratch_bytes(N, C, hw) bytes (no initial content required). */
 extern "C" int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw) {
   if (N < 1 || C < 1 || hw < 1) return NPP_ERR_ARG;
   GemmArgs g = gram_args(nullptr, N, C, hw, nullptr);
@@ -720,7 +751,7 @@ extern "C" int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw) {
 }
 extern "C" int npp_gram_fwd_det(const float* d_f, int N, int C, int hw, float* d_g, float* d_scratch, int64_t scratch_bytes, void* stream) {
   if (!d_f || !d_g || !d_scratch || N < 1 || C < 1 || hw < 1) { set_error("npp_gram_fwd_det: bad argument"); return NPP_ERR_ARG; }
-  const int rc = gemm_launch(gram_args(d_f, N, C, hw, d_g), true, true, (hipStream_t)stream, true, d_scratch, scratch_bytes);
+  const int rc = gemm_launch(gram_args(d_f, N, C, hw, d_g), true, true, (hipStream_t)stream, true, d_scratch, scratch_bytes, true);
   return rc != NPP_OK ? rc : check_launch("npp_gram_fwd_det");
 }
 
@@ -751,15 +782,17 @@ extern "C" int npp_robust_elem(const float* d_a, const float* d_b, int N, int D,
   }
   hipStream_t s = (hipStream_t)stream;
   ChanParams* cp = (ChanParams*)d_workspace;
-  float* d_coef = (float*)((char*)d_workspace + (size_t)D * sizeof(ChanParams));
-  float* d_part = d_coef + 64;                       // [blocks] partial sums, then the arrival ticket
+  float* d_part = (float*)((char*)d_workspace + (size_t)D * sizeof(ChanParams)) + 64;     // [blocks] partial sums, then the arrival ticket
   const unsigned blocks = (unsigned)((D + 255) / 256);
   unsigned* d_ticket = (unsigned*)(d_part + blocks);
-  (void)hipMemcpyAsync(d_coef, coef_n, sizeof(float) * N, hipMemcpyHostToDevice, s);
+  // (round 6) the per-sample factors travel as a kernel argument: they were an asynchronous copy from the caller's pageable array into
+  // the shared workspace -- one API call more per launch, and two launches of one size on one stream shared the landing area
+  ElemCoef coef{};
+  for (int q = 0; q < N; ++q) coef.v[q] = coef_n[q];
   const int64_t n = (int64_t)N * D;
   hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_a, d_b, n, d_diff);
   hipLaunchKernelGGL(elem_chan_kernel, dim3(blocks), dim3(256), 0, s, d_latents, D, d_spline, n_knots, x_scale, cp, d_ticket);
-  hipLaunchKernelGGL(robust_elem_kernel, dim3(blocks), dim3(256), 0, s, d_diff, N, D, cp, d_coef, d_loss, d_ddiff, d_dlatent, d_part, d_ticket);
+  hipLaunchKernelGGL(robust_elem_kernel, dim3(blocks), dim3(256), 0, s, d_diff, N, D, cp, coef, d_loss, d_ddiff, d_dlatent, d_part, d_ticket);
   return check_launch("npp_robust_elem");
 }
 

@@ -124,6 +124,7 @@ class StackedFit:
         self.cx = f0.contextualLoss
         self.cx_w, self.lp_w, self.use_comp = f0.cx_w, f0.lp_w, f0.use_comp
         self._s_lp = torch.cuda.Stream(dev)
+        self.style_side_stream = False    # the remapping task's style terms beside the contextual chain (see step_full)
         import os
         from concurrent.futures import ThreadPoolExecutor
         workers = min(M, max(1, (os.cpu_count() or 2) - 1))
@@ -325,11 +326,25 @@ class StackedFit:
                     dxb = None
                     if it[i].same and f.use_perceptual_loss:
                         dxb = f.lpips_branch(self.xy[i, :2 * nk], nk, self.lp_w, self.patch_loss[i:i + 1])[:nk]   # (a captured graph from its third use on)
-                    if f.style is not None:               # NPP_remapping/train.py:253-261: own latents per image
+                    if f.style is not None and self.style_side_stream:   # NPP_remapping/train.py:253-261: own latents per image
                         f.style.zero_latent_grads()
                         dxs = f.style.fused(self.xy[i, :2 * nk], nk, f.style_w, self.patch_loss[i:i + 1])[:nk]
                         dxb = dxs if dxb is None else dxb + dxs
-                    self.dxb[i, :nk].copy_(dxb)
+                    if dxb is not None:
+                        self.dxb[i, :nk].copy_(dxb)
+        style_main = []
+        if with_lp and not self.style_side_stream:
+            # the style terms on the MAIN stream (default): on the side stream, beside the contextual chain, the style latents' gradients of
+            # the image served last moved in their last bits from run to run (a few near-zero Gram entries; every Gram matrix checked
+            # against float64 to 6e-7 of its largest entry, the chain's other results bit-stable) -- the cause was not found, the
+            # main-stream order removes it (tests/test_gpu_poison.py); style_side_stream = True restores the overlap
+            for i in with_lp:
+                f = fits[i]
+                if f.style is not None:
+                    nk = it[i].nk
+                    f.style.zero_latent_grads()
+                    style_main.append((i, nk, f.style.fused(self.xy[i, :2 * nk], nk, f.style_w, self.patch_loss[i:i + 1])[:nk],
+                                       bool(it[i].same and f.use_perceptual_loss)))
         shape = (self.N_total, 3, self.P, self.P)
         feats = t._forward(shape, sc, sh, True, n_run=2 * X, n_keep=X)[0]
 
@@ -338,6 +353,11 @@ class StackedFit:
         dx_a = t._backward([True], X, sc, shape, zero_rest=False, top_writer=top)
         if with_lp:
             main.wait_stream(self._s_lp)
+            for i, nk, dxs, has_lp in style_main:           # (joined: the LPIPS branch of a 'same' image wrote its share already)
+                if has_lp:
+                    self.dxb[i, :nk].add_(dxs)
+                else:
+                    self.dxb[i, :nk].copy_(dxs)
         ops.mlp_bwd_patch_stack(self.dpred, self.pred, M, K, self.wb, self.params, self.actF, self.dzF, dx_a,
                                 self.dxb if with_lp else None, cmasks, self.n_pix, self.n_p, self.P, it_dev, W)
         ops.mlp_wgrad_stack(self.dzF, self.actF, self.Bp, M, K, self.ksplit, self.gslabs, it_dev, W)

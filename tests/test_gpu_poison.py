@@ -161,3 +161,38 @@ def test_stacked_images_do_not_read_unwritten_memory(dev):
     assert seen_p == seen
     for a, b in zip(clean, dirty):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("stacked", [False, True])
+def test_remapping_with_lpips_does_not_read_unwritten_memory(dev, stacked):
+    """The remapping loop with the LPIPS term switched on as well (style term + LPIPS branch + contextual chain in one iteration), alone
+    and as a stack of two.  Found by running the suite's files in another order: the stacked / stand-alone comparison of
+    tests/test_gpu_stack.py moved from 7e-4 to 2.5e-3 -- not unwritten memory but a run-to-run drift of the LAST stacked image's style
+    latent gradients while its style term ran on the side stream beside the contextual chain; StackedFit now runs the style terms on
+    the main stream (style_side_stream = False) and two clean runs, and the poisoned one, agree to the bit."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_stack import _remap_fits
+    from npp_amd.stack import StackedFit
+
+    def run():
+        fits = _remap_fits(dev, 2, 256, 1, 4, True)
+        if stacked:
+            st = StackedFit(fits, ksplit=4)
+            for _ in range(8):
+                st.step_full()
+            fits = st.fits
+        else:
+            for f in fits:
+                for _ in range(8):
+                    f.step_full()
+        torch.cuda.synchronize()
+        out = []
+        for f in fits:
+            out += [f.net.params.clone(), f.net.latents.clone(), f.percepLoss._lat.clone()] + [l.clone() for l in f.style.latents]
+        return out
+    clean = run()
+    with poisoned_empty():
+        dirty = run()
+    for k, (a, b) in enumerate(zip(clean, dirty)):
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all()), k
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
