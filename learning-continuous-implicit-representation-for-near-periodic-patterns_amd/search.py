@@ -191,14 +191,27 @@ def main_multi(argvs):
     from .light import rank_images
     n = len(argvs)
     errors, prepared = [None] * n, [None] * n
-    for i, a in enumerate(argvs):
+    def prep(i):
+        # the images' front halves side by side: PNG decoding, the displacement search (host NumPy + a few small launches) and the
+        # ranker's tables are 30 ms per image of mostly host time -- each on its own thread and stream, like run.search_all's thread form
         try:
-            args = parse(a)
-            out, imgs, conv1, trunks = _load(args)
-            cands, ranker = prepare_image(imgs[0].astype(np.float32), imgs[2], imgs[3], args, conv1, trunks)
+            args = parse(argvs[i])
+            st = torch.cuda.Stream(torch.device(args.device)) if torch.cuda.is_available() else None
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                out, imgs, conv1, trunks = _load(args)
+                cands, ranker = prepare_image(imgs[0].astype(np.float32), imgs[2], imgs[3], args, conv1, trunks)
+            if st is not None:
+                st.synchronize()
             prepared[i] = (args, out, imgs, cands, ranker)
         except (Exception, SystemExit) as e:                                         # noqa: B014
             errors[i] = e
+    import contextlib
+    from concurrent.futures import ThreadPoolExecutor
+    if n > 1:
+        with ThreadPoolExecutor(min(8, n), thread_name_prefix="npp-prep") as pool:
+            list(pool.map(prep, range(n)))
+    else:
+        prep(0)
     live = [i for i in range(n) if prepared[i] is not None]
     # images whose fits share hyper-parameters ride together; anything else falls back to its own loop inside rank_images' check
     keyf = lambda pr: (pr[0].N_iters, pr[0].netwidth, pr[0].netdepth, pr[0].lrate, pr[0].lrate_decay, pr[0].loss_type, pr[4].carry_latents,  # noqa: E731
