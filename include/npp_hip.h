@@ -701,6 +701,24 @@ int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, 
                           const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
                           int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero, float lr,
                           float beta1, float beta2, float eps, int step, void* stream);
+/* (round 6) the 16-bit candidate fits, bit-reproducible and across images -- what npp_light_bwd_det / npp_light_adam_pack_det /
+ * npp_light_fwd_multi are to the fp32 chains.  npp_light16_bwd_det: the pixel loss folded in (d_gt required), every block's seven loss /
+ * latent-gradient sums to d_part (C, B / 64, 8) by plain stores; gt_cs = elements per candidate of d_gt (0: one (B, 3) target shared;
+ * 3 B: candidate c = one image's fit with its own targets).  npp_light16_adam_pack_det adds them in block order (latent gradients =
+ * d_dlat + the sums; d_loss_cur[c] += the loss terms, nullable).  npp_light16_fwd_multi: per candidate its own positional table
+ * d_x_pos (C, n_src, 42) and pixel rows d_idx (C, B).  NPP_proposal/search.py:85-215. */
+int npp_light16_fwd_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                          int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
+                          int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, void* stream);
+int npp_light16_bwd_det(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                        int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
+                        const float* d_gt, int64_t gt_cs, const float* d_latents, const float* d_spline, int n_knots, float x_scale,
+                        float* d_part, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes, void* stream);
+int npp_light16_adam_pack_det(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                              const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                              int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                              float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part,
+                              float* d_loss_cur, void* stream);
 /* img2mse with --loss_type l2 (coef = 1) or robust_loss (coef = 50: lossfun(diff, alpha = 2, scale = 0.1) = 0.5 (diff / 0.1)^2),
  * models/mse_calculator.py:13-27, for nbatch problems: d_loss[b] += weight * coef * mean(x^2), d_dpred = its gradient; the (N) mask
  * (nullable) is shared, the targets too when gt_stride == 0. */

@@ -174,6 +174,9 @@ SYMBOLS = {
     "npp_light16_bwd": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _i32, _i64, _vp, _i64, _vp]),
     "npp_light16_wgrad": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _i32, _i64, _i32, _vp, _i64, _i64, _vp]),
     "npp_light16_adam_pack": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "npp_light16_fwd_multi": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _vp]),
+    "npp_light16_bwd_det": (_i32, [C.POINTER(LightDesc), _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i32, _i64, _vp, _i64, _vp]),
+    "npp_light16_adam_pack_det": (_i32, [C.POINTER(LightDesc), _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i32, _vp, _i32, _vp, _vp]),
     "npp_light_part_blocks": (_i32, [_i32, _i64]),
     "npp_light_wgrad_det_scratch_bytes": (_i64, [_i32, _i64]),
     "npp_light_wgrad_det": (_i32, [C.POINTER(LightDesc), _vp, _vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -66,6 +66,11 @@ struct L16Args {
   int64_t B;
   const float* gt; const float* latents; const float* spline; int n_knots; float x_scale;
   float* loss; float* dlatent;
+  // (round 6) bit-reproducible form: every block leaves its seven loss / latent-gradient sums in part[(c n_wg + wg) * 8 + k] (no atomics;
+  // npp_light16_adam_pack_det adds them in block order).  "multi" forms (candidate = one IMAGE's fit): elements per candidate of the
+  // positional table, the row indices and the targets; 0 = shared
+  float* part;
+  int64_t x_pos_cs, idx_cs, gt_cs;
 };
 
 // ---- packs ----------------------------------------------------------------------------------------------------------------
@@ -110,6 +115,7 @@ struct L16AdamArgs {
   __bf16* pack; int64_t pack_stride16;
   float *lat, *lat_m, *lat_v, *dlat, *zero;
   float step_size, b1, b2, inv_sqrt_bc2, eps;
+  const float* part; int32_t n_part; float* loss_cur;   // npp_light16_adam_pack_det: the blocks' sums of npp_light16_bwd_det, added in block order
 };
 __global__ __launch_bounds__(256) void light16_adam_pack_kernel(L16AdamArgs a, L16Pack pd) {
   const int c = blockIdx.y;
@@ -117,10 +123,18 @@ __global__ __launch_bounds__(256) void light16_adam_pack_kernel(L16AdamArgs a, L
     const int t = threadIdx.x;
     if (t < 6) {
       const int i = c * 6 + t;
+      float g = a.dlat[i];
+      if (a.part)
+        for (int b = 0; b < a.n_part; ++b) g += a.part[((int64_t)c * a.n_part + b) * 8 + 1 + t];
       float m = a.lat_m[i], v = a.lat_v[i];
-      a.lat[i] = adam_update(a.lat[i], m, v, a.dlat[i], a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
+      a.lat[i] = adam_update(a.lat[i], m, v, g, a.step_size, a.b1, a.b2, a.inv_sqrt_bc2, a.eps);
       a.lat_m[i] = m; a.lat_v[i] = v; a.dlat[i] = 0.0f;
     } else if (t == 6 && a.zero) a.zero[c] = 0.0f;
+    else if (t == 64 && a.part && a.loss_cur) {
+      float l = 0.0f;
+      for (int b = 0; b < a.n_part; ++b) l += a.part[((int64_t)c * a.n_part + b) * 8];
+      a.loss_cur[c] += l;
+    }
     return;
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -328,14 +342,14 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_fwd_kernel(L16Args a, 
   // inputs -> fragments: x_per (2 k-steps, region R1) and x_pos (4 k-steps, region RX), both also into their stash arrays
   {
     const int ks = L.tid >> 7, bt = (L.tid >> 6) & 1;
-    const int64_t r = row0 + bt * 32 + L.b, src = a.idx ? a.idx[r] : r;
+    const int64_t r = row0 + bt * 32 + L.b, src = a.idx ? a.idx[(int64_t)c * a.idx_cs + r] : r;
     const bf16x8 f = l16_in_frag(a.x_per + ((int64_t)c * a.n_src + src) * kLPer, ks, L.h, kLPer);
     lds_store_frag(R1, ks, bt, L.lane, f);
     stash_store(arr(L16A_XP) + wfmt_unit(2, wg, ks, bt, L.b, L.h), f);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int ksl = 2 * q + ks;
-      const bf16x8 g = l16_in_frag(a.x_pos + src * kLPos, ksl, L.h, kLPos);
+      const bf16x8 g = l16_in_frag(a.x_pos + (int64_t)c * a.x_pos_cs + src * kLPos, ksl, L.h, kLPos);
       lds_store_frag(RX, ksl, bt, L.lane, g);
       stash_store(arr(L16A_HP) + wfmt_unit(kL16KsHp, wg, kKSAct + ksl, bt, L.b, L.h), g);
     }
@@ -508,11 +522,13 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
   // (models/mse_calculator.py:13-27 without a mask: the arithmetic of pixel_loss_body, npp_common.h), loss / latent gradients by atomics
   __shared__ ChanParams cp[3];
   __shared__ float sred[7];
+  __shared__ float swv[kL16Threads / 64][7];
   if (a.gt) {
     if (tid < 3) cp[tid] = chan_params(a.latents[c * 6 + tid], a.latents[c * 6 + 3 + tid], a.spline, a.n_knots, a.x_scale);
     if (tid < 7) sred[tid] = 0.0f;
     wg_barrier();
   }
+  float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;                 // this thread's loss term and latent-gradient terms (channel tid % 3)
   if (tid < kRowTile * 3) {
     const int64_t g = ((int64_t)c * B + row0) * 3 + tid;
     const float p = a.pred[g];
@@ -521,25 +537,51 @@ __global__ __launch_bounds__(kL16Threads, 2) void light16_bwd_kernel(L16Args a, 
       const int ch = tid % 3;
       const ChanParams q = cp[ch];
       const float inv = 1.0f / (3.0f * (float)B);
-      const float x = p - a.gt[row0 * 3 + tid];
+      const float x = p - a.gt[(int64_t)c * a.gt_cs + row0 * 3 + tid];
       const float xs = x / q.c, ssx = xs * xs;
       const float u = ssx / q.beta + 1.0f, e = 0.5f * q.alpha, lnu = logf(u);
       const float ue = expf(e * lnu), ue1 = ue / u;
       dp = inv * (x / (q.c * q.c)) * ue1;
-      atomicAdd(&sred[0], (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz);
-      atomicAdd(&sred[1 + ch], -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz);
-      atomicAdd(&sred[4 + ch], -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c);
+      t0 = (q.beta / q.alpha) * (ue - 1.0f) + q.logc_plus_logz;
+      t1 = -(2.0f / (q.alpha * q.alpha)) * (ue - 1.0f) + (q.beta / q.alpha) * ue * (0.5f * lnu + e * ssx / (q.beta * q.beta * u)) + q.dlogz;
+      t2 = -(x * x) / (q.c * q.c * q.c) * ue1 + 1.0f / q.c;
+      if (!a.part) {
+        atomicAdd(&sred[0], t0);
+        atomicAdd(&sred[1 + ch], t1);
+        atomicAdd(&sred[4 + ch], t2);
+      }
     } else {
       dp = a.dpred[g];
     }
     sD[tid] = dp * p * (1.0f - p);
   }
+  if (a.gt && a.part) {
+    // deterministic form (every wave, whole: threads past the 3 x 64 values carry zeros): the seven sums of a wave by shuffle butterflies
+    // -- a fixed tree -- then the waves' results in wave order (csrc/npp_light.hip light_bwd_kernel does the same)
+    const int ch = tid % 3, lane_ = tid & 63, wave_ = tid >> 6;
+    const float v7[7] = {t0, ch == 0 ? t1 : 0.0f, ch == 1 ? t1 : 0.0f, ch == 2 ? t1 : 0.0f, ch == 0 ? t2 : 0.0f, ch == 1 ? t2 : 0.0f, ch == 2 ? t2 : 0.0f};
+#pragma unroll
+    for (int k7 = 0; k7 < 7; ++k7) {
+      float v = v7[k7];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane_ == 0) swv[wave_][k7] = v;
+    }
+  }
   wg_barrier();
   if (a.gt && tid < 7) {
-    const float inv = 1.0f / (3.0f * (float)B), v = sred[tid];
-    if (tid == 0) atomicAdd(a.loss + c, v * inv);
-    else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
-    else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+    const float inv = 1.0f / (3.0f * (float)B);
+    if (a.part) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w_ = 0; w_ < kL16Threads / 64; ++w_) v += swv[w_][tid];
+      a.part[((int64_t)c * n_wg + wg) * 8 + tid] = tid == 0 ? v * inv : (tid < 4 ? inv * v * cp[tid - 1].dalpha_dl : inv * v * cp[tid - 4].dc_dl);
+    } else {
+      const float v = sred[tid];
+      if (tid == 0) atomicAdd(a.loss + c, v * inv);
+      else if (tid < 4) atomicAdd(a.dlatent + c * 6 + (tid - 1), inv * v * cp[tid - 1].dalpha_dl);
+      else atomicAdd(a.dlatent + c * 6 + 3 + (tid - 4), inv * v * cp[tid - 4].dc_dl);
+    }
   }
   // d raw as a 2-k-step W-format array (rgb_linear's weight gradient): features 0..2 real, the rest zero
   {
@@ -637,9 +679,26 @@ extern "C" int npp_light16_pack(const npp_light_desc* L, const float* d_params, 
   return check_launch("npp_light16_pack");
 }
 
+static int l16_fwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                      int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
+                      int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, int64_t x_pos_cs, int64_t idx_cs, void* stream);
 extern "C" int npp_light16_fwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
                                int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
                                int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, void* stream) {
+  return l16_fwd_go(L, d_params, params_stride, d_pack, pack_stride_bytes, d_x_per, d_x_pos, d_idx, n_src, C, B, d_actF, act_stride_bytes, d_pred, 0, 0,
+                    stream);
+}
+// "multi" form (round 6): candidate c = one IMAGE's fit -- its own positional table d_x_pos (C, n_src, 42) and pixel rows d_idx (C, B)
+extern "C" int npp_light16_fwd_multi(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                                     int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
+                                     int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, void* stream) {
+  if (!d_idx) { set_error("npp_light16_fwd_multi: null row indices"); return NPP_ERR_ARG; }
+  return l16_fwd_go(L, d_params, params_stride, d_pack, pack_stride_bytes, d_x_per, d_x_pos, d_idx, n_src, C, B, d_actF, act_stride_bytes, d_pred,
+                    n_src * kLPos, B, stream);
+}
+static int l16_fwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                      int64_t pack_stride_bytes, const float* d_x_per, const float* d_x_pos, const int64_t* d_idx, int64_t n_src,
+                      int C, int64_t B, void* d_actF, int64_t act_stride_bytes, float* d_pred, int64_t x_pos_cs, int64_t idx_cs, void* stream) {
   int rc = l16_check(L, d_params, d_pack, C, B, "npp_light16_fwd");
   if (rc) return rc;
   if (!d_x_per || !d_x_pos || !d_actF || !d_pred || (d_idx ? n_src < 1 : n_src != B) || pack_stride_bytes % 16 || act_stride_bytes % 16 ||
@@ -650,7 +709,7 @@ extern "C" int npp_light16_fwd(const npp_light_desc* L, const float* d_params, i
   L16Args a{};
   a.L = *L; a.params = d_params; a.params_stride = params_stride; a.pack = (const bf16x8*)d_pack; a.pack_stride16 = pack_stride_bytes / 16;
   a.x_per = d_x_per; a.x_pos = d_x_pos; a.idx = d_idx; a.n_src = n_src; a.actF = (char*)d_actF; a.act_stride = act_stride_bytes;
-  a.pred = d_pred; a.B = B;
+  a.pred = d_pred; a.B = B; a.x_pos_cs = x_pos_cs; a.idx_cs = idx_cs;
   static SmemOnce once;
   if (!smem_attr(once, (const void*)light16_fwd_kernel, kL16SmemF)) { set_error("npp_light16_fwd: smem attribute"); return NPP_ERR_LAUNCH; }
   const int n_wg = (int)(B / kRowTile);
@@ -659,14 +718,38 @@ extern "C" int npp_light16_fwd(const npp_light_desc* L, const float* d_params, i
   return check_launch("npp_light16_fwd");
 }
 
+static int l16_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                      int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
+                      const float* d_dpred, const float* d_gt, const float* d_latents, const float* d_spline, int n_knots,
+                      float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes,
+                      float* d_part, int64_t gt_cs, void* stream);
 extern "C" int npp_light16_bwd(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
                                int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
                                const float* d_dpred, const float* d_gt, const float* d_latents, const float* d_spline, int n_knots,
                                float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes,
                                void* stream) {
+  return l16_bwd_go(L, d_params, params_stride, d_pack, pack_stride_bytes, d_actF, act_stride_bytes, d_pred, d_dpred, d_gt, d_latents, d_spline,
+                    n_knots, x_scale, d_loss, d_dlatent, C, B, d_dzF, dz_stride_bytes, nullptr, 0, stream);
+}
+// Bit-reproducible form (round 6): the pixel loss folded in (d_gt required), every block's seven loss / latent-gradient sums go to
+// d_part (C, B / 64, 8) by plain stores; npp_light16_adam_pack_det adds them in block order.  gt_cs: elements per candidate of d_gt
+// (0: one (B, 3) target shared by the candidates; 3 B: the "multi" form, candidate = one image's fit with its own targets (C, B, 3)).
+extern "C" int npp_light16_bwd_det(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                                   int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
+                                   const float* d_gt, int64_t gt_cs, const float* d_latents, const float* d_spline, int n_knots, float x_scale,
+                                   float* d_part, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes, void* stream) {
+  if (!d_gt || !d_part || (gt_cs != 0 && gt_cs != 3 * B)) { set_error("npp_light16_bwd_det: targets / partial-sum buffer / gt_cs"); return NPP_ERR_ARG; }
+  return l16_bwd_go(L, d_params, params_stride, d_pack, pack_stride_bytes, d_actF, act_stride_bytes, d_pred, nullptr, d_gt, d_latents, d_spline,
+                    n_knots, x_scale, nullptr, nullptr, C, B, d_dzF, dz_stride_bytes, d_part, gt_cs, stream);
+}
+static int l16_bwd_go(const npp_light_desc* L, const float* d_params, int64_t params_stride, const void* d_pack,
+                      int64_t pack_stride_bytes, const void* d_actF, int64_t act_stride_bytes, const float* d_pred,
+                      const float* d_dpred, const float* d_gt, const float* d_latents, const float* d_spline, int n_knots,
+                      float x_scale, float* d_loss, float* d_dlatent, int C, int64_t B, void* d_dzF, int64_t dz_stride_bytes,
+                      float* d_part, int64_t gt_cs, void* stream) {
   int rc = l16_check(L, d_params, d_pack, C, B, "npp_light16_bwd");
   if (rc) return rc;
-  if (!d_actF || !d_pred || !d_dzF || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || !d_loss || !d_dlatent) : !d_dpred) ||
+  if (!d_actF || !d_pred || !d_dzF || (d_gt ? (!d_latents || !d_spline || n_knots < 2 || (!d_part && (!d_loss || !d_dlatent))) : !d_dpred) ||
       pack_stride_bytes % 16 || act_stride_bytes % 16 || dz_stride_bytes % 16 || act_stride_bytes < wfmt_array_base(L16A_TOTAL, B / kRowTile) ||
       dz_stride_bytes < wfmt_array_base(L16D_TOTAL, B / kRowTile)) {
     set_error("npp_light16_bwd: null argument (d_dpred, or d_gt with latents / spline / loss / dlatent) / strides");
@@ -677,6 +760,7 @@ extern "C" int npp_light16_bwd(const npp_light_desc* L, const float* d_params, i
   a.actF = (char*)d_actF; a.act_stride = act_stride_bytes; a.dzF = (char*)d_dzF; a.dz_stride = dz_stride_bytes;
   a.pred = (float*)d_pred; a.dpred = d_dpred; a.B = B;
   a.gt = d_gt; a.latents = d_latents; a.spline = d_spline; a.n_knots = n_knots; a.x_scale = x_scale; a.loss = d_loss; a.dlatent = d_dlatent;
+  a.part = d_part; a.gt_cs = gt_cs;
   static SmemOnce once;
   if (!smem_attr(once, (const void*)light16_bwd_kernel, kL16SmemB)) { set_error("npp_light16_bwd: smem attribute"); return NPP_ERR_LAUNCH; }
   const int n_wg = (int)(B / kRowTile);
@@ -685,10 +769,32 @@ extern "C" int npp_light16_bwd(const npp_light_desc* L, const float* d_params, i
   return check_launch("npp_light16_bwd");
 }
 
+static int l16_adam_go(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                       const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                       int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                       float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part, float* d_loss_cur, void* stream);
 extern "C" int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
                                      const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
                                      int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
                                      float lr, float beta1, float beta2, float eps, int step, void* stream) {
+  return l16_adam_go(L, d_params, d_m, d_v, stride, n, C, d_gslabs, n_slabs, slab_stride, slab_cand_stride, d_pack, pack_stride_bytes, d_lat, d_lat_m,
+                     d_lat_v, d_dlat, d_zero, lr, beta1, beta2, eps, step, nullptr, 0, nullptr, stream);
+}
+// npp_light16_adam_pack after npp_light16_bwd_det: latent gradients = d_dlat + the blocks' sums of d_part (C, n_part, 8) in block order;
+// d_loss_cur[c] += the blocks' loss terms (nullable)
+extern "C" int npp_light16_adam_pack_det(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                                         const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                                         int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                                         float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part,
+                                         float* d_loss_cur, void* stream) {
+  if (!d_part || n_part < 1) { set_error("npp_light16_adam_pack_det: partial sums"); return NPP_ERR_ARG; }
+  return l16_adam_go(L, d_params, d_m, d_v, stride, n, C, d_gslabs, n_slabs, slab_stride, slab_cand_stride, d_pack, pack_stride_bytes, d_lat, d_lat_m,
+                     d_lat_v, d_dlat, d_zero, lr, beta1, beta2, eps, step, d_part, n_part, d_loss_cur, stream);
+}
+static int l16_adam_go(const npp_light_desc* L, float* d_params, float* d_m, float* d_v, int64_t stride, int64_t n, int C,
+                       const float* d_gslabs, int n_slabs, int64_t slab_stride, int64_t slab_cand_stride, void* d_pack,
+                       int64_t pack_stride_bytes, float* d_lat, float* d_lat_m, float* d_lat_v, float* d_dlat, float* d_zero,
+                       float lr, float beta1, float beta2, float eps, int step, const float* d_part, int n_part, float* d_loss_cur, void* stream) {
   int rc = l16_check(L, d_params, d_pack, C, kRowTile, "npp_light16_adam_pack");
   if (rc) return rc;
   const L16Pack pd = l16_pack_desc();
@@ -705,6 +811,7 @@ extern "C" int npp_light16_adam_pack(const npp_light_desc* L, float* d_params, f
   a.pack = (__bf16*)d_pack; a.pack_stride16 = pack_stride_bytes / 16;
   a.lat = d_lat; a.lat_m = d_lat_m; a.lat_v = d_lat_v; a.dlat = d_dlat; a.zero = d_zero;
   a.step_size = (float)((double)lr / bc1); a.b1 = beta1; a.b2 = beta2; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2)); a.eps = eps;
+  a.part = d_part; a.n_part = n_part; a.loss_cur = d_loss_cur;
   hipLaunchKernelGGL(light16_adam_pack_kernel, dim3((unsigned)((n + 255) / 256 + 1), (unsigned)C), dim3(256), 0, (hipStream_t)stream, a, pd);
   return check_launch("npp_light16_adam_pack");
 }

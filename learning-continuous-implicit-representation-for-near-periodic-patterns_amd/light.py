@@ -313,6 +313,11 @@ class NPPNetLightBatch:
             # rows: ksplit 1 / 2 / 4 / 8 = 66 / 42 / 56 / 64 us (4 and 8 need a second / third round of workgroups)
             cost = lambda k: -(-9 * C * k // 256) * (2 * -(-n_wg // k) + 8)                      # noqa: E731
             ks = min(range(1, min(8, n_wg) + 1), key=cost)
+            if ops.DETERMINISTIC:
+                # (round 6) the slab split fixes the summation order of the weight gradients: it must not depend on how many candidates
+                # ride in the launch, or a candidate fitted alone and the same candidate in a stacked set differ in their last bits
+                # (light.rank_images: the images of a rank searched together give the bits of the serial loop).  1024 rows per slab.
+                ks = max(1, min(8, n_wg // 16))
             ws = dict(actF=u8(ab), dzF=u8(db), pred=torch.empty(C, B, 3, dtype=torch.float32, device=self.device),
                       gslabs=torch.zeros(C, ks, self.n_pad, dtype=torch.float32, device=self.device))
             if getattr(self, "_pack16", None) is None:
@@ -323,25 +328,40 @@ class NPPNetLightBatch:
     def _train_step_bf16(self, x_pos, x_per, gt, idx=None):
         """train_step() on the 16-bit chains: forward -> data gradients with the pixel loss folded in -> ONE grouped split-K
         weight-gradient launch (partial sums by plain stores) -> Adam + bf16 re-pack: 4 launches for the whole candidate set."""
-        B = gt.shape[0]
+        multi = gt.dim() == 3                               # multi-image set: x_pos (C, n, 42), gt (C, B, 3), idx (C, B)
+        B = gt.shape[1] if multi else gt.shape[0]
         ws = self._work16(B)
         if not self._pack16_valid:
             ops.light16_pack(self._desc, self.params, self._pack16)
         ops.light16_fwd(self._desc, self.params, self._pack16, x_per.contiguous(), x_pos.contiguous(), ws["actF"], ws["pred"], idx=idx)
         loss = self._loss2[self._li]
+        part = None
         if self.quad > 0:                                   # non-adaptive pixel loss: its own launch, d pred handed to the chain
+            assert not multi
             dp = ws.setdefault("dpred", torch.empty_like(ws["pred"]))
             ops.pixel_loss_quad(ws["pred"], gt, None, self.quad, 1.0, loss, dp)
             ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], dp, ws["dzF"])
+        elif ops.DETERMINISTIC:
+            # bit-reproducible fit: the blocks' loss / latent-gradient sums by plain stores, added in block order by the Adam launch
+            part = ws.get("part")
+            if part is None:
+                part = ws["part"] = torch.zeros(self.C, B // 64, 8, dtype=torch.float32, device=self.device)
+            ops.light16_bwd_det(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], ws["dzF"], gt, self.latents, self.spline,
+                                self.n_knots, self.x_scale, part)
         else:
+            assert not multi
             ops.light16_bwd(self._desc, self.params, self._pack16, ws["actF"], ws["pred"], None, ws["dzF"],
                             loss_args=(gt, self.latents, self.spline, self.n_knots, self.x_scale, loss, self._dl_c))
         ops.light16_wgrad(self._desc, ws["actF"], ws["dzF"], B, ws["gslabs"])
         n0 = self.nets[0]
         step, lr = n0.opt_step + 1, n0.lr
         self._li ^= 1
-        ops.light16_adam_pack(self._desc, self.params, self.m, self.v, self.n_params, ws["gslabs"], self._pack16, self.latents, self.lat_m,
-                              self.lat_v, self._dl_c, self._loss2[self._li], lr, step)
+        if part is not None:
+            ops.light16_adam_pack_det(self._desc, self.params, self.m, self.v, self.n_params, ws["gslabs"], self._pack16, self.latents,
+                                      self.lat_m, self.lat_v, self._dl_c, self._loss2[self._li], lr, step, part, loss)
+        else:
+            ops.light16_adam_pack(self._desc, self.params, self.m, self.v, self.n_params, ws["gslabs"], self._pack16, self.latents, self.lat_m,
+                                  self.lat_v, self._dl_c, self._loss2[self._li], lr, step)
         self._pack16_valid, self._pack_valid = True, False
         for net in self.nets:
             net.opt_step = step
@@ -380,12 +400,26 @@ class NPPNetLightBatch:
         step, lr, gstp, li = n0.opt_step, n0.lr, n0.global_step, self._li
         fwd, bwd, wg, adam = Lb.npp_light16_fwd, Lb.npp_light16_bwd, Lb.npp_light16_wgrad, Lb.npp_light16_adam_pack
         nk, xs, npar = self.n_knots, self.x_scale, self.n_params
+        det = ops.DETERMINISTIC                              # (round 6) the bit-reproducible launches: npp_light16_bwd_det / _adam_pack_det
+        if det:
+            part_t = ws.get("part")
+            if part_t is None:
+                part_t = ws["part"] = torch.zeros(Cn, B // 64, 8, dtype=torch.float32, device=self.device)
+            part, n_part = vp(part_t), B // 64
+            bwd_d, adam_d = Lb.npp_light16_bwd_det, Lb.npp_light16_adam_pack_det
         for j in range(n_it):
             rc = fwd(desc, par, pst, pk, pks, xper, xpos, C_.c_void_p(d0 + j * dstep), n_src, Cn, B, act, acs, pred, st)
-            rc = rc or bwd(desc, par, pst, pk, pks, act, acs, pred, None, C_.c_void_p(g0 + j * gstep), lat, spl, nk, xs, loss_p[li], dl, Cn, B, dz, dzs, st)
+            if det:
+                rc = rc or bwd_d(desc, par, pst, pk, pks, act, acs, pred, C_.c_void_p(g0 + j * gstep), 0, lat, spl, nk, xs, part, Cn, B, dz, dzs, st)
+            else:
+                rc = rc or bwd(desc, par, pst, pk, pks, act, acs, pred, None, C_.c_void_p(g0 + j * gstep), lat, spl, nk, xs, loss_p[li], dl, Cn, B, dz, dzs, st)
             rc = rc or wg(desc, act, acs, dz, dzs, Cn, B, ks, gsl, ns, ks * ns, st)
             step += 1
-            rc = rc or adam(desc, par, m_, v_, pst, npar, Cn, gsl, ks, ns, ks * ns, pk, pks, lat, latm, latv, dl, loss_p[li ^ 1], lr, 0.9, 0.999, 1e-8, step, st)
+            if det:
+                rc = rc or adam_d(desc, par, m_, v_, pst, npar, Cn, gsl, ks, ns, ks * ns, pk, pks, lat, latm, latv, dl, loss_p[li ^ 1], lr, 0.9, 0.999,
+                                  1e-8, step, part, n_part, loss_p[li], st)
+            else:
+                rc = rc or adam(desc, par, m_, v_, pst, npar, Cn, gsl, ks, ns, ks * ns, pk, pks, lat, latm, latv, dl, loss_p[li ^ 1], lr, 0.9, 0.999, 1e-8, step, st)
             if rc:
                 ops.check(rc, "npp_light16_* (fit_loop_bf16)")
             if log is not None:
@@ -479,8 +513,10 @@ class NPPNetLightBatch:
         """One iteration of search.py:113-147 for every candidate: x_pos (B, in_pos) and gt (B, 3) shared, x_per (C, B, 20) -- or, with
         idx (B int64), the whole tables x_pos (n, in_pos) / x_per (C, n, 20) whose rows idx are this iteration's batch."""
         C, B = x_per.shape[0], (gt.shape[1] if gt.dim() == 3 else gt.shape[0])
-        if gt.dim() == 3:                                  # multi-image set (ops.light_fwd / light_bwd_det multi forms)
+        if gt.dim() == 3:                                  # multi-image set (ops.light_fwd / light_bwd_det multi forms; bf16: light16_*)
             assert self.fused and B % 32 == 0 and idx is not None
+            if self.bf16 and B % 64 == 0:
+                return self._train_step_bf16(x_pos, x_per, gt, idx)
             return self._adam(self._train_step_fused(x_pos, x_per, gt, idx))
         if self.bf16 and B % 64 == 0:
             return self._train_step_bf16(x_pos, x_per, gt, idx)
@@ -885,8 +921,9 @@ def rank_images(rankers, cand_lists, topk=10):
         if (rk.N_iters, rk.Wn, rk.D, rk.lrate, rk.lrate_decay, rk.loss_type, rk.carry_latents, rk.precision, str(rk.device)) != \
            (r0.N_iters, r0.Wn, r0.D, r0.lrate, r0.lrate_decay, r0.loss_type, r0.carry_latents, r0.precision, str(r0.device)):
             raise ValueError("rank_images: the images' candidate fits must share their hyper-parameters and device")
-    if not ops.DETERMINISTIC or ops.quad_coef(r0.loss_type) > 0 or r0.precision == "bf16":
-        return [rk.rank(c, topk=topk) for rk, c in zip(rankers, cand_lists)]       # (the multi-image launches are the deterministic fp32 fused ones)
+    if not ops.DETERMINISTIC or ops.quad_coef(r0.loss_type) > 0:
+        return [rk.rank(c, topk=topk) for rk, c in zip(rankers, cand_lists)]       # (the multi-image launches are the deterministic fused ones)
+    bf16 = r0.precision == "bf16"
     n_img = len(rankers)
     details = [[None] * len(c) for c in cand_lists]
     groups = {}
@@ -894,7 +931,7 @@ def rank_images(rankers, cand_lists, topk=10):
         groups.setdefault(min(rk.N_rand, rk.i_train.shape[0]), []).append(i)
     init = default_light_init(r0.Wn, r0.D)
     for B, members in groups.items():
-        if B % 32 or len(members) == 1:                        # a batch the fused chains do not take, or nothing to stack: the image's own loop
+        if B % (64 if bf16 else 32) or len(members) == 1 or (bf16 and len(members) > 16):   # a batch the fused chains do not take, or nothing to stack: the image's own loop
             for i in members:
                 d, order, det = rankers[i].rank(cand_lists[i], topk=topk)
                 details[i] = det
@@ -916,7 +953,7 @@ def rank_images(rankers, cand_lists, topk=10):
             act = [i for i in members if k < len(cand_lists[i])]
             batch = NPPNetLightBatch([(cand_lists[i][k][0], cand_lists[i][k][1]) for i in act], [rankers[i].freqs for i in act],
                                      [(rankers[i].H, rankers[i].W_img) for i in act], init, W=r0.Wn, D=r0.D, device=r0.device,
-                                     lrate=r0.lrate, lrate_decay=r0.lrate_decay, precision="fp32", loss_type=r0.loss_type)
+                                     lrate=r0.lrate, lrate_decay=r0.lrate_decay, precision="bf16" if bf16 else "fp32", loss_type=r0.loss_type)
             C = len(act)
             x_pos = torch.zeros(C, n_max, 42, dtype=torch.float32, device=r0.device)
             x_per = torch.zeros(C, n_max, 20, dtype=torch.float32, device=r0.device)

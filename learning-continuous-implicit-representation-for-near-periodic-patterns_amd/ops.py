@@ -927,6 +927,12 @@ def light16_fwd(desc, params, pack, x_per, x_pos, actF, pred, idx=None):
     _bytes2d(pack, "pack")
     _bytes2d(actF, "actF")
     assert x_per.is_contiguous() and x_pos.is_contiguous() and pred.is_contiguous()
+    if x_pos.dim() == 3:                                   # multi-image set: per candidate its own positional table and pixel rows
+        assert x_per.shape == (C, n, 20) and x_pos.shape == (C, n, 42) and pred.shape == (C, B, 3) and actF.shape[0] == C
+        assert idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.shape == (C, B)
+        check(lib().npp_light16_fwd_multi(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n,
+                                          C, B, _p(actF), actF.stride(0), _p(pred), _stream()), "npp_light16_fwd_multi")
+        return
     assert x_per.shape == (C, n, 20) and x_pos.shape == (n, 42) and pred.shape == (C, B, 3) and actF.shape[0] == C
     assert (idx is None and n == B) or (idx is not None and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == B)
     check(lib().npp_light16_fwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(x_per), _p(x_pos), _p(idx), n, C, B,
@@ -952,6 +958,33 @@ def light16_bwd(desc, params, pack, actF, pred, dpred, dzF, loss_args=None):
     check(lib().npp_light16_bwd(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(actF), actF.stride(0), _p(pred),
                                 _p(dpred), _p(gt), _p(lat), _p(spl), nk, xs, _p(loss), _p(dlat), C, B, _p(dzF), dzF.stride(0), _stream()),
           "npp_light16_bwd")
+
+
+def light16_bwd_det(desc, params, pack, actF, pred, dzF, gt, lat, spline, n_knots, x_scale, part):
+    """light16_bwd with the pixel loss folded in and the blocks' loss / latent-gradient sums left in part (C, B / 64, 8) by plain stores
+    (added in block order by light16_adam_pack_det): bit-reproducible.  gt (B, 3) shared, or (C, B, 3) per candidate (multi-image set)."""
+    import ctypes
+    C, B = pred.shape[:2]
+    _bytes2d(pack, "pack")
+    _bytes2d(actF, "actF")
+    _bytes2d(dzF, "dzF")
+    multi = gt.dim() == 3
+    assert pred.is_contiguous() and dzF.shape[0] == C and gt.is_contiguous() and gt.shape == ((C, B, 3) if multi else (B, 3))
+    assert lat.shape == (C, 6) and lat.is_contiguous() and part.is_contiguous() and part.shape == (C, B // 64, 8) and part.dtype == torch.float32
+    check(lib().npp_light16_bwd_det(ctypes.byref(desc), _p(params), params.stride(0), _p(pack), pack.stride(0), _p(actF), actF.stride(0), _p(pred),
+                                    _p(gt), 3 * B if multi else 0, _p(lat), _p(spline), n_knots, x_scale, _p(part), C, B, _p(dzF), dzF.stride(0),
+                                    _stream()), "npp_light16_bwd_det")
+
+
+def light16_adam_pack_det(desc, params, m, v, n, gslabs, pack, lat, lat_m, lat_v, dlat, zero, lr, step, part, loss_cur, b1=0.9, b2=0.999, eps=1e-8):
+    """light16_adam_pack after light16_bwd_det: the blocks' sums of `part` added in block order (latent gradients; loss_cur[c] += loss terms)."""
+    import ctypes
+    C, ks, ns = gslabs.shape
+    _bytes2d(pack, "pack")
+    assert params.stride(1) == 1 and params.shape[0] == C and part.is_contiguous() and part.shape[0] == C and part.shape[2] == 8
+    check(lib().npp_light16_adam_pack_det(ctypes.byref(desc), _p(params), _p(m), _p(v), params.stride(0), n, C, _p(gslabs), ks, ns, ks * ns, _p(pack),
+                                          pack.stride(0), _p(lat), _p(lat_m), _p(lat_v), _p(dlat), _p(zero), lr, b1, b2, eps, step, _p(part),
+                                          part.shape[1], _p(loss_cur), _stream()), "npp_light16_adam_pack_det")
 
 
 def light16_wgrad(desc, actF, dzF, B, gslabs):

@@ -181,3 +181,36 @@ def test_candidate_fits_with_a_quadratic_pixel_loss(dev, lt):
     assert rel_l2(nets[0].params.cpu().numpy(), nets[1].params.cpu().numpy()) < 2e-5
     for n_ in nets:
         assert torch.equal(n_.latents, lat0)
+
+
+def test_bf16_candidate_fits_reproducible_and_across_images(dev):
+    """Round 6: the 16-bit candidate fits without order-dependent float sums (npp_light16_bwd_det: the blocks' loss / latent-gradient
+    sums by plain stores, added in block order by npp_light16_adam_pack_det; the weight gradients were slab sums already) and with
+    candidate k of every image of a rank in one launch sequence (npp_light16_fwd_multi, per-candidate targets): per image the bits of
+    its own serial bf16 ranking -- scores, order -- run to run and against light.rank_images; chained and independent candidates;
+    images of different sizes and candidate counts."""
+    from npp_amd import ops
+    from npp_amd.light import ProposalRanker, rank_images
+    assert ops.DETERMINISTIC
+    rankers, cand_lists = [], []
+    for i, (H, Wd, ncand) in enumerate([(128, 128, 3), (96, 144, 2), (128, 128, 3)]):
+        img, mask = oracle.synthetic_image(max(H, Wd), noise=0.01, seed=i)
+        img = img[:H, :Wd]
+        angles, periods, shifts = oracle.synthetic_periodicity(128, 1)
+        pseudo = np.ones((H, Wd))
+        pseudo[30 + 5 * i:70, 40:80 + 4 * i] = 0
+        i_train, i_val = np.stack(np.nonzero(pseudo), 1), np.stack(np.nonzero(1 - pseudo), 1)
+        cand_lists.append([(angles[0] + 7.0 * j, periods[0] * (1.0 + 0.23 * j), shifts[0]) for j in range(ncand)])
+        rankers.append((img, i_train, i_val))
+    for carry in (True, False):
+        mk = lambda: [ProposalRanker(im, it, iv, device=dev, N_iters=40, N_rand=1024, carry_latents=carry, precision="bf16")   # noqa: E731
+                      for im, it, iv in rankers]
+        serial = [rk.rank(c, topk=10) for rk, c in zip(mk(), cand_lists)]
+        serial2 = [rk.rank(c, topk=10) for rk, c in zip(mk(), cand_lists)]
+        together = rank_images(mk(), cand_lists, topk=10)
+        again = rank_images(mk(), cand_lists, topk=10)
+        for (d0, o0, det0), (d3, o3, det3), (d1, o1, det1), (d2, o2, det2) in zip(serial, serial2, together, again):
+            assert det0 == det3                                              # the serial bf16 loop, run to run
+            assert list(o0) == list(o1) == list(o2) and det1 == det2
+            assert det0 == det1, (carry, det0, det1)                         # stacked across images = the image's own loop, to the bit
+            np.testing.assert_array_equal(d0, d1)

@@ -19,7 +19,7 @@ srcs = []
 for i in range(M):
     im, mk = syn.synthetic_image(S, seed=10 + i)
     srcs.append(nio.write_detected_dir(os.path.join(tmp, "input", f"img{i}"), im, mk, np.ones_like(mk), [[0, 0]], [[1, 1]], [[[1, 0], [0, 1]]]))
-flags = ["--device", "cuda:0", "--random-trunks"]
+flags = ["--device", "cuda:0", "--random-trunks"] + sys.argv[1:]          # e.g. --precision bf16
 res = {}
 for tag, kw in (("together", {}), ("serial", dict(threads=1, together=False)), ("threads8", dict(threads=8, together=False)), ("together", {}), ("threads8", dict(threads=8, together=False))):
     det = os.path.join(tmp, f"det_{tag}_{len(res)}")
