@@ -111,7 +111,8 @@ def test_complete_iterations_do_not_read_unwritten_memory(dev, task):
     #  npp_gram_fwd_det / npp_robust_elem: before, two CLEAN runs differed in the 8th digit of the second iteration's loss)
 
 
-def test_candidate_ranking_does_not_read_unwritten_memory(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_candidate_ranking_does_not_read_unwritten_memory(dev, precision):
     """The proposal ranking (fused fp32 candidate fits, ordered-split weight gradients, whole-crop score: plain LPIPS + the value-only
     contextual core) under poisoned allocations: the same distances to the last bit."""
     from npp_amd.light import ProposalRanker
@@ -124,7 +125,7 @@ def test_candidate_ranking_does_not_read_unwritten_memory(dev):
     cands = [(angles[i], periods[i], shifts[i]) for i in range(3)]
 
     def run():
-        rk = ProposalRanker(img, i_train, i_val, device=dev, N_iters=40, N_rand=2048, carry_latents=True)
+        rk = ProposalRanker(img, i_train, i_val, device=dev, N_iters=40, N_rand=2048, carry_latents=True, precision=precision)
         d, order, details = rk.rank(cands, topk=3)
         return np.asarray(d), list(order), details
     d0, o0, det0 = run()
