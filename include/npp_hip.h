@@ -756,6 +756,9 @@ int npp_gram_fwd(const float* d_f, int N, int C, int hw, float* d_g, void* strea
 int64_t npp_gram_fwd_det_scratch_bytes(int N, int C, int hw);
 int npp_gram_fwd_det(const float* d_f, int N, int C, int hw, float* d_g, float* d_scratch, int64_t scratch_bytes, void* stream);
 int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, int hw, float* d_df, void* stream);
+/* (round 6) ONE launch: the per-channel constants, the difference a - b (written to d_diff) and the loss are all formed inside it
+ * -- nothing is handed from one launch to the next through the workspace, which now holds only the blocks' loss partials and their
+ * arrival ticket (the launcher clears the ticket itself; no initial content required; not shared by concurrent launches). */
 int64_t npp_robust_elem_workspace_bytes(int D);
 int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const float* d_latents,
                     const float* d_spline, int n_knots, float x_scale, const float* coef_n, float* d_loss,

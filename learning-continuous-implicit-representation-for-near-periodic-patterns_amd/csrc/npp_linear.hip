@@ -330,8 +330,13 @@ __global__ __launch_bounds__(256) void lpips_plain_kernel(const float* __restric
 // element index j walks the N samples -- models/style_loss.py:60-69 applies it to the N x C^2 differences of two Gram
 // matrices.  loss += sum_n coef_n sum_j nll(d[n][j]); dd[n][j] = coef_n dnll/dx; dlatent[j] / [D + j] += the latent gradients.
 struct ElemCoef { float v[64]; };            // the N <= 64 per-sample factors, by value (kernel argument)
-__global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restrict__ d, int N, int D, const ChanParams* __restrict__ cp,
-                                                          const ElemCoef coef_arg, float* __restrict__ loss,
+// (round 6) ONE launch: the difference a - b and the element's ChanParams are formed by the thread that uses them.  They were two
+// launches of their own in front of this one (sub_kernel, elem_chan_kernel -> a ChanParams table in the workspace): three launches
+// and two round trips through memory per Gram level for 2 N D subtractions and D table rows.  (It does NOT settle the run-to-run
+// drift of the style latents' gradients on a side stream, which is what prompted it: DESIGN section 4.)
+__global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restrict__ a_in, const float* __restrict__ b_in, float* __restrict__ d_out,
+                                                          int N, int D, const float* __restrict__ latents, const float* __restrict__ spline,
+                                                          int n_knots, float x_scale, const ElemCoef coef_arg, float* __restrict__ loss,
                                                           float* __restrict__ dd, float* __restrict__ dlatent, float* __restrict__ part,
                                                           unsigned* __restrict__ ticket) {
   __shared__ float tot[4];
@@ -341,10 +346,11 @@ __global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restric
   const int j = blockIdx.x * 256 + threadIdx.x;
   float val = 0.0f;
   if (j < D) {
-    const ChanParams P = cp[j];
+    const ChanParams P = chan_params(latents[j], latents[D + j], spline, n_knots, x_scale);
     float ga = 0.0f, gc = 0.0f;
     for (int n = 0; n < N; ++n) {
-      const float x = d[(int64_t)n * D + j], cf = coef_n[n];
+      const float x = a_in[(int64_t)n * D + j] - b_in[(int64_t)n * D + j], cf = coef_n[n];
+      d_out[(int64_t)n * D + j] = x;
       const float xs = x / P.c, ssx = xs * xs;
       const float uu = ssx / P.beta + 1.0f, e = 0.5f * P.alpha, lnu = logf(uu);
       const float ue = expf(e * lnu), ue1 = ue / uu;
@@ -372,19 +378,6 @@ __global__ __launch_bounds__(256) void robust_elem_kernel(const float* __restric
     for (unsigned b = 0; b < gridDim.x; ++b) t += share_load(part + b);
     atomicAdd(loss, t);                           // ONE add per launch (the word is shared with launches on other streams: the
   }                                               //  contextual core's term of the same iteration)
-}
-
-__global__ void elem_chan_kernel(const float* __restrict__ latents, int D, const float* __restrict__ spline, int n_knots, float x_scale,
-                                 ChanParams* __restrict__ cp, unsigned* __restrict__ ticket) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0) *ticket = 0u;                       // (the workspace is not required to be zeroed: the arrival ticket of the launch that follows)
-  if (c < D) cp[c] = chan_params(latents[c], latents[D + c], spline, n_knots, x_scale);
-}
-
-// c = a - b elementwise
-__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ c) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) c[t] = a[t] - b[t];
 }
 
 // Split the contraction when the output is small and K long (weight gradients: 256 x 256 outputs over 2048 rows would
@@ -771,7 +764,7 @@ extern "C" int npp_gram_bwd(const float* d_dg, const float* d_f, int N, int C, i
 
 /* diff = a - b, then the per-element adaptive robust NLL over (N, D) with D latent pairs [alpha(D) | scale(D)]:
  * d_loss[0] += sum_n coef_n sum_j nll ; d_ddiff (N, D) = coef_n dnll/dx ; d_dlatent [2 D] += latent gradients (both nullable
- * together).  d_coef_n: N per-sample factors (host array).  d_workspace: npp_lpips_workspace_bytes(D) bytes + N floats. */
+ * together).  coef_n: N per-sample factors (host array).  d_workspace: npp_robust_elem_workspace_bytes(D) bytes. */
 extern "C" int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const float* d_latents, const float* d_spline,
                                int n_knots, float x_scale, const float* coef_n, float* d_loss, float* d_diff, float* d_ddiff,
                                float* d_dlatent, void* d_workspace, void* stream) {
@@ -781,21 +774,18 @@ extern "C" int npp_robust_elem(const float* d_a, const float* d_b, int N, int D,
     return NPP_ERR_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
-  ChanParams* cp = (ChanParams*)d_workspace;
-  float* d_part = (float*)((char*)d_workspace + (size_t)D * sizeof(ChanParams)) + 64;     // [blocks] partial sums, then the arrival ticket
+  // workspace: [blocks] partial loss sums, then the arrival ticket (cleared here: the workspace needs no initial content)
   const unsigned blocks = (unsigned)((D + 255) / 256);
+  float* d_part = (float*)d_workspace;
   unsigned* d_ticket = (unsigned*)(d_part + blocks);
-  // (round 6) the per-sample factors travel as a kernel argument: they were an asynchronous copy from the caller's pageable array into
-  // the shared workspace -- one API call more per launch, and two launches of one size on one stream shared the landing area
+  (void)hipMemsetAsync(d_ticket, 0, sizeof(unsigned), s);
   ElemCoef coef{};
   for (int q = 0; q < N; ++q) coef.v[q] = coef_n[q];
-  const int64_t n = (int64_t)N * D;
-  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_a, d_b, n, d_diff);
-  hipLaunchKernelGGL(elem_chan_kernel, dim3(blocks), dim3(256), 0, s, d_latents, D, d_spline, n_knots, x_scale, cp, d_ticket);
-  hipLaunchKernelGGL(robust_elem_kernel, dim3(blocks), dim3(256), 0, s, d_diff, N, D, cp, coef, d_loss, d_ddiff, d_dlatent, d_part, d_ticket);
+  hipLaunchKernelGGL(robust_elem_kernel, dim3(blocks), dim3(256), 0, s, d_a, d_b, d_diff, N, D, d_latents, d_spline, n_knots, x_scale, coef, d_loss, d_ddiff,
+                     d_dlatent, d_part, d_ticket);
   return check_launch("npp_robust_elem");
 }
 
 extern "C" int64_t npp_robust_elem_workspace_bytes(int D) {
-  return D < 1 ? NPP_ERR_ARG : (int64_t)D * sizeof(ChanParams) + (64 + (D + 255) / 256 + 16) * sizeof(float);
+  return D < 1 ? NPP_ERR_ARG : (int64_t)((D + 255) / 256 + 16) * sizeof(float);
 }

@@ -334,10 +334,10 @@ class StackedFit:
                         self.dxb[i, :nk].copy_(dxb)
         style_main = []
         if with_lp and not self.style_side_stream:
-            # the style terms on the MAIN stream (default): on the side stream, beside the contextual chain, the style latents' gradients of
-            # the image served last moved in their last bits from run to run (a few near-zero Gram entries; every Gram matrix checked
-            # against float64 to 6e-7 of its largest entry, the chain's other results bit-stable) -- the cause was not found, the
-            # main-stream order removes it (tests/test_gpu_poison.py); style_side_stream = True restores the overlap
+            # the style terms on the MAIN stream (default): on the side stream, beside the contextual chain, the style latents' gradients
+            # moved in their last bits from run to run (16-entry groups of the alpha half; needs the side stream's temporaries to be freed
+            # and re-used each iteration -- kept alive, every run agrees).  Not resolved (tools/r6_side_stream_repro.py);
+            # the main-stream order removes it (tests/test_gpu_poison.py); style_side_stream = True restores the overlap
             for i in with_lp:
                 f = fits[i]
                 if f.style is not None:
