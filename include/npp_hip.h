@@ -764,6 +764,23 @@ int npp_robust_elem(const float* d_a, const float* d_b, int N, int D, const floa
                     const float* d_spline, int n_knots, float x_scale, const float* coef_n, float* d_loss,
                     float* d_diff, float* d_ddiff, float* d_dlatent, void* d_workspace, void* stream);
 
+/* ---- SURVEY.md 8 f3 / f4 front ends: around the AlexNet convolutions ------------------------ */
+/* (round 6) The segmentation task's LPIPS(alex, spatial = True) criterion (NPP_segmentation/train.py:361-372; externel_lib/lpips/
+ * lpips.py:92-133, pretrained_networks.py alexnet slices) and the proposal search's conv1 features (NPP_proposal/feature_searching.py:
+ * 20-24) run their convolutions as im2col rows x npp_linear_fwd; these are the pieces around the products (torch calls before).
+ * Activations between the layers are POSITION-MAJOR (n, y, x, c) -- what npp_linear_fwd writes for rows (n, y, x).
+ * npp_im2col: rows (n, oy, ox), columns (c, ky, kx) (torch.nn.functional.unfold's order = the (Cout, Cin k k) weight matrix's), zeros
+ *   outside the image; nhwc != 0: d_x is position-major, else (N, C, H, W).  d_cols: N ho wo x C k k floats, ho = (H + 2 pad - k) / stride + 1.
+ * npp_maxpool_nhwc: nn.MaxPool2d(k, stride) (no padding, floor size) on a position-major tensor; NaN propagates.
+ * npp_lpips_spatial_layer: one tap of LPIPS.forward(spatial = True, use_robust = False) before the upsampling: d_map[p] = sum_c lin_c
+ *   (a_c / (|a| + 1e-10) - b_c / (|b| + 1e-10))^2 for P positions of C channels (lpips.py:99-110, lpips/__init__.py:42-44).
+ * npp_resize_bilinear: F.interpolate(size = (H, W), mode = 'bilinear', align_corners = False) of N maps (h, w) (lpips.py:20-22);
+ *   accumulate != 0 adds into d_y (lpips.py:125-127 sums the taps). */
+int npp_im2col(const float* d_x, int N, int C, int H, int W, int k, int stride, int pad, int nhwc, float* d_cols, void* stream);
+int npp_maxpool_nhwc(const float* d_x, int N, int H, int W, int C, int k, int stride, float* d_y, void* stream);
+int npp_lpips_spatial_layer(const float* d_f0, const float* d_f1, int64_t P, int C, const float* d_lin, float* d_map, void* stream);
+int npp_resize_bilinear(const float* d_x, int N, int h, int w, int H, int W, int accumulate, float* d_y, void* stream);
+
 /* ---- brute-force displacement search ------------------------------------- */
 /* compute_loss of NPP_proposal/feature_searching.py:208-264: act (C, h, w) fp32 feature map whose LAST channel is excluded
  * from the sum (:247,250), mask (h, w) 1 = known, shifts (n, 2) int32 (dx, dy).  losses[s] = sum over positions of

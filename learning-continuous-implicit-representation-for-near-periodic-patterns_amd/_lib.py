@@ -226,6 +226,10 @@ SYMBOLS = {
     "npp_robust_elem_workspace_bytes": (_i64, [_i32]),
     "npp_robust_elem": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i32, _f32, C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp, _vp]),
     "npp_trunk_export": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "npp_im2col": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "npp_maxpool_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "npp_lpips_spatial_layer": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "npp_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _LIBS = {}

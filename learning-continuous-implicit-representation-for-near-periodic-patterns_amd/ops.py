@@ -1037,6 +1037,51 @@ def lpips_plain_layer(f0, f1, lin, scale, out, scratch=None):
           "npp_lpips_plain_layer")
 
 
+# ---- around the AlexNet convolutions (segmentation criterion, proposal conv1 features): include/npp_hip.h "f3 / f4 front ends" ----
+def im2col(x, k, stride, pad, nhwc=False):
+    """Rows (n, oy, ox) x columns (c, ky, kx) of a k x k / stride / zero-pad convolution over x: (N,C,H,W), or (N,H,W,C) with nhwc."""
+    _req(x, torch.float32, "x")
+    if nhwc:
+        N, H, W, Cc = x.shape
+    else:
+        N, Cc, H, W = x.shape
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    cols = torch.empty((N * ho * wo, Cc * k * k), dtype=torch.float32, device=x.device)
+    check(lib().npp_im2col(_p(x), N, Cc, H, W, k, stride, pad, 1 if nhwc else 0, _p(cols), _stream()), "npp_im2col")
+    return cols, ho, wo
+
+
+def maxpool_nhwc(x, k, stride):
+    _req(x, torch.float32, "x")
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, (H - k) // stride + 1, (W - k) // stride + 1, Cc), dtype=torch.float32, device=x.device)
+    check(lib().npp_maxpool_nhwc(_p(x), N, H, W, Cc, k, stride, _p(y), _stream()), "npp_maxpool_nhwc")
+    return y
+
+
+def lpips_spatial_layer(f0, f1, lin):
+    """(N,h,w,C) position-major features of the two images -> the tap's distance map (N,h,w) (lpips.py:99-110, spatial, plain head)."""
+    _req(f0, torch.float32, "f0")
+    _req(f1, torch.float32, "f1", f0.shape)
+    _req(lin, torch.float32, "lin", (f0.shape[-1],))
+    d = torch.empty(f0.shape[:-1], dtype=torch.float32, device=f0.device)
+    check(lib().npp_lpips_spatial_layer(_p(f0), _p(f1), d.numel(), f0.shape[-1], _p(lin), _p(d), _stream()), "npp_lpips_spatial_layer")
+    return d
+
+
+def resize_bilinear(x, H, W, out=None, accumulate=False):
+    """F.interpolate(x[:, None], size=(H, W), mode='bilinear', align_corners=False)[:, 0] of maps (N,h,w); accumulate: out += it."""
+    _req(x, torch.float32, "x")
+    N, h, w = x.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, torch.float32, "out", (N, H, W))
+    check(lib().npp_resize_bilinear(_p(x), N, h, w, H, W, 1 if accumulate else 0, _p(out), _stream()), "npp_resize_bilinear")
+    return out
+
+
 # ---- remapping variant: Gram-matrix style loss pieces (models/style_loss.py:37-74) ----------------------------
 _gram_ws = {}
 

@@ -13,7 +13,6 @@ import warnings
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops, cvlite
 from ._lib import lib, check
@@ -118,8 +117,7 @@ class AlexConv1:
         mean = torch.tensor(_IMAGENET_MEAN, device=self.device).view(3, 1, 1)
         std = torch.tensor(_IMAGENET_STD, device=self.device).view(3, 1, 1)
         x = ((x - mean) / std)[None]
-        ho, wo = (Hp + 10 - 11) // 4 + 1, (Wp + 10 - 11) // 4 + 1
-        cols = F.unfold(x, 11, padding=5, stride=4).transpose(1, 2).reshape(ho * wo, -1).contiguous()
+        cols, ho, wo = ops.im2col(x.contiguous(), 11, 4, 5)
         y = torch.empty((ho * wo, 64), dtype=torch.float32, device=self.device)
         ops.linear_fwd(cols, self.w, self.b, 0, y)
         return y.reshape(ho, wo, 64).permute(2, 0, 1).contiguous()

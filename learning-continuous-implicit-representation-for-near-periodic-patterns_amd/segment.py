@@ -17,7 +17,6 @@ vectors are lpips' weights/v0.1/alex.pth.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -57,36 +56,43 @@ class AlexFeatures:
                 b = torch.zeros(co)
             self.layers.append((idx, k, st, pd, w.reshape(co, -1).contiguous().to(self.device), b.contiguous().to(self.device)))
 
-    def __call__(self, x):
-        outs = []
+    def features_nhwc(self, x):
+        """The five ReLU taps POSITION-MAJOR, (N, h, w, C) each: im2col rows (npp_im2col) x the filter matrix (npp_linear_fwd, bias + ReLU
+        in its epilogue), nn.MaxPool2d(3, 2) in front of conv2 / conv3 (npp_maxpool_nhwc); no transposition between the layers."""
+        outs, nhwc = [], False
         for idx, k, st, pd, w, b in self.layers:
             if idx in _ALEX_POOL_BEFORE:
-                x = F.max_pool2d(x, 3, 2)
-            N, _, H, W = x.shape
-            ho, wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
-            cols = F.unfold(x, k, padding=pd, stride=st).transpose(1, 2).reshape(N * ho * wo, -1).contiguous()
+                x = ops.maxpool_nhwc(x, 3, 2)
+            N = x.shape[0]
+            cols, ho, wo = ops.im2col(x, k, st, pd, nhwc=nhwc)
             y = torch.empty((cols.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
             ops.linear_fwd(cols, w, b, _RELU, y)
-            x = y.reshape(N, ho, wo, -1).permute(0, 3, 1, 2).contiguous()
+            x, nhwc = y.view(N, ho, wo, -1), True
             outs.append(x)
         return outs
+
+    def __call__(self, x):
+        """The taps as (N, C, h, w) views (the layout of the reference's alexnet slices, pretrained_networks.py:60-96)."""
+        return [f.permute(0, 3, 1, 2) for f in self.features_nhwc(x)]
 
 
 def lpips_alex_spatial(in0, in1, alex, lins, normalize=True):
     """LPIPS(net='alex', spatial=True).forward(in0, in1, use_robust=False, retPerLayer=True, normalize) -> (val, [per-layer
     maps]) each (N,1,H,W).  in0 / in1: (N,1,H,W) or (N,3,H,W) (the reference feeds GRAYSCALE images: the scaling layer's
-    (1,3,1,1) constants broadcast them to three channels, lpips.py:141-143)."""
+    (1,3,1,1) constants broadcast them to three channels, lpips.py:141-143).  Per tap: npp_lpips_spatial_layer on the position-major
+    features, npp_resize_bilinear to the input size; the sum over the taps is accumulated by the same launches."""
     dev = in0.device
     sh, sc = torch.tensor(_SHIFT, device=dev).view(1, 3, 1, 1), torch.tensor(_SCALE, device=dev).view(1, 3, 1, 1)
     if normalize:
         in0, in1 = 2 * in0 - 1, 2 * in1 - 1
-    f0, f1 = alex(((in0 - sh) / sc).contiguous()), alex(((in1 - sh) / sc).contiguous())
+    N, _, H, W = in0.shape
+    f0, f1 = alex.features_nhwc(((in0 - sh) / sc).contiguous()), alex.features_nhwc(((in1 - sh) / sc).contiguous())
     res = []
     for a, b, lin in zip(f0, f1, lins):
-        na = a / (torch.sqrt(torch.sum(a ** 2, dim=1, keepdim=True)) + 1e-10)          # lpips/__init__.py:42-44
-        nb = b / (torch.sqrt(torch.sum(b ** 2, dim=1, keepdim=True)) + 1e-10)
-        d = ((na - nb) ** 2 * torch.as_tensor(lin, device=dev, dtype=torch.float32).view(1, -1, 1, 1)).sum(1, keepdim=True)
-        res.append(F.interpolate(d, size=in0.shape[2:], mode="bilinear", align_corners=False))
+        lin_t = lin.to(device=dev, dtype=torch.float32).reshape(-1).contiguous() if isinstance(lin, torch.Tensor) else \
+            torch.as_tensor(lin, dtype=torch.float32).reshape(-1).contiguous().to(dev)
+        d = ops.lpips_spatial_layer(a.contiguous(), b.contiguous(), lin_t)
+        res.append(ops.resize_bilinear(d, H, W)[:, None])
     # lpips.py:125-127: `val = res[0]; for l in 1..L-1: val += res[l]` accumulates IN PLACE, so the list entry 0 the caller
     # receives (retPerLayer=True) IS the sum over all layers, not layer 0's own map -- and with the default lpips_layers = 1
     # that sum is what NPP_segmentation/train.py:366-372 thresholds.  Reproduced.

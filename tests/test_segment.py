@@ -80,6 +80,57 @@ def test_lpips_alex_spatial_vs_reference(dev):
 
 
 @pytest.mark.gpu
+def test_alexnet_front_end_pieces_vs_torch(dev):
+    """The four launches around the AlexNet products against the torch calls they replace (the reference's own modules are
+    nn.Conv2d / nn.MaxPool2d of torchvision's alexnet, pretrained_networks.py:60-96, and F.interpolate / normalize_tensor of
+    lpips.py:20-22, lpips/__init__.py:42-44): the rows of every convolution geometry in the net from both source layouts and the
+    pooling BIT-EXACT (they move values), the per-pixel head and the upsampling to float rounding -- incl. ragged sizes,
+    a non-integer upsampling ratio, a zero feature vector (the 1e-10 in the norm) and the bad-argument paths."""
+    import torch
+    import torch.nn.functional as F
+    from npp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (N, C, H, W, k, st, pd) in [(2, 3, 67, 45, 11, 4, 2), (1, 3, 64, 96, 11, 4, 5), (2, 64, 15, 10, 5, 1, 2), (1, 192, 7, 4, 3, 1, 1),
+                                    (1, 5, 3, 3, 3, 1, 0)]:
+        x = torch.randn(N, C, H, W, generator=g).to(dev)
+        want = F.unfold(x, k, padding=pd, stride=st).transpose(1, 2).reshape(-1, C * k * k)
+        ho, wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+        for nhwc in (False, True):
+            cols, h_, w_ = ops.im2col(x.permute(0, 2, 3, 1).contiguous() if nhwc else x, k, st, pd, nhwc=nhwc)
+            assert (h_, w_) == (ho, wo) and torch.equal(cols, want), (N, C, H, W, k, st, pd, nhwc)
+    for (N, C, H, W) in [(2, 64, 15, 10), (1, 192, 7, 7), (1, 3, 3, 3), (1, 7, 4, 9)]:
+        x = torch.randn(N, C, H, W, generator=g).to(dev)
+        y = ops.maxpool_nhwc(x.permute(0, 2, 3, 1).contiguous(), 3, 2)
+        assert torch.equal(y.permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2))
+    x = torch.full((1, 3, 3, 1), 1.0, device=dev)
+    x[0, 1, 1, 0] = float("nan")
+    assert bool(torch.isnan(ops.maxpool_nhwc(x, 3, 2)).all())
+    for (N, h, w, H, W) in [(2, 15, 15, 64, 64), (1, 3, 7, 50, 33), (1, 1, 1, 5, 4), (1, 8, 8, 8, 8), (1, 9, 5, 4, 3)]:
+        x = torch.randn(N, h, w, generator=g).to(dev)
+        want = F.interpolate(x[:, None], size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+        got = ops.resize_bilinear(x, H, W)
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()), (N, h, w, H, W)
+        twice = ops.resize_bilinear(x, H, W, out=got.clone(), accumulate=True)
+        assert float((twice - 2 * want).abs().max()) <= 4e-6 * float(want.abs().max())
+    for (N, h, w, C) in [(2, 15, 15, 64), (1, 3, 3, 384), (1, 1, 5, 100)]:
+        a, b = torch.randn(N, h, w, C, generator=g).to(dev), torch.randn(N, h, w, C, generator=g).to(dev)
+        a[0, 0, 0] = 0.0                                                    # |a| = 0: a / (0 + 1e-10) = 0
+        lin = torch.rand(C, generator=g).to(dev)
+        na = a / (torch.sqrt(torch.sum(a ** 2, dim=-1, keepdim=True)) + 1e-10)
+        nb = b / (torch.sqrt(torch.sum(b ** 2, dim=-1, keepdim=True)) + 1e-10)
+        want = ((na - nb) ** 2 * lin).sum(-1)
+        got = ops.lpips_spatial_layer(a, b, lin)
+        assert bool(torch.isfinite(got).all()) and float((got - want).abs().max()) <= 5e-6 * float(want.abs().max())
+    x = torch.zeros(1, 3, 4, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.im2col(x, 11, 4, 0)                                              # window larger than the padded image
+    with pytest.raises(RuntimeError):
+        ops.maxpool_nhwc(torch.zeros(1, 2, 2, 3, device=dev), 3, 2)
+    with pytest.raises(ValueError):
+        ops.im2col(x.permute(0, 2, 3, 1), 3, 1, 1, nhwc=True)               # not contiguous
+
+
+@pytest.mark.gpu
 def test_segmentation_task_end_to_end(dev):
     """CompletionFit(task='segmentation') + segment.segmentation_eval on a lattice image with a planted non-periodic blob:
     the fit (on the blurred image, periodic region = everything outside a candidate rectangle, constant LR) explains the
